@@ -1,0 +1,70 @@
+"""ctypes loader for libcl3d.so -- the only way the Python layer reaches the HIP kernels.
+
+There is no CPU fallback: if the shared object is missing or does not load, importing any op
+raises.  (`closerlook3d_amd.build.build()` compiles it; `__graft_entry__.build()` calls that.)
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  -- imported first so libcl3d binds to the HIP runtime torch already loaded
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "libcl3d.so")
+_lib = None
+
+_P = ctypes.c_void_p  # device pointers travel as void*
+_I = ctypes.c_int
+_F = ctypes.c_float
+_Z = ctypes.c_size_t
+
+# name -> argtypes; restype is int for every op.  Mirrors include/cl3d.h (tests/test_abi.py checks
+# that every symbol declared in the header is exported by the library and listed here).
+SIGNATURES = {
+    "cl3d_masked_ordered_ball_query": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _Z, _P],
+    "cl3d_group_points": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "cl3d_group_points_grad": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
+    "cl3d_masked_grid_subsampling": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P],
+    "cl3d_masked_nearest_query": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "cl3d_group_xyz_features": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P],
+}
+
+
+class Cl3dError(RuntimeError):
+    pass
+
+
+def _declare(handle):
+    handle.cl3d_abi_version.restype = _I
+    handle.cl3d_abi_version.argtypes = []
+    handle.cl3d_last_error_string.restype = ctypes.c_char_p
+    handle.cl3d_last_error_string.argtypes = []
+    handle.cl3d_workspace_bytes.restype = _Z
+    handle.cl3d_workspace_bytes.argtypes = [_I] * 6
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(handle, name)
+        fn.argtypes = argtypes
+        fn.restype = _I
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            raise ImportError(
+                f"{_PATH} not found: the HIP engine is not built. Run `python -m closerlook3d_amd.build` "
+                "(there is no CPU or PyTorch fallback for these ops).")
+        handle = ctypes.CDLL(_PATH)
+        _declare(handle)
+        if handle.cl3d_abi_version() != 1:
+            raise ImportError("libcl3d.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise Cl3dError(f"cl3d error {rc}: {lib().cl3d_last_error_string().decode()}")
+
+
+def stream_ptr(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

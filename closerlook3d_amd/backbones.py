@@ -1,0 +1,118 @@
+"""Residual backbone and segmentation decode that call the hot path.
+
+`ResNet` / `Bottleneck` follow `pytorch/models/backbones/resnet.py:22-188` and `SceneSegHeadResNet`
+follows `pytorch/models/heads/segmentation_head.py:15-77`: same constructor arguments, same
+sub-module names (so reference checkpoints load), same `end_points` dictionary.  They exist here so
+the integration tests and the backbone benchmark can run on the GPU box, where the reference tree is
+absent; the reference's own files run unchanged on this engine through `drop_in/`.
+"""
+import torch
+import torch.nn as nn
+
+from .local_aggregation_operators import LocalAggregation
+from .pt_utils import MaskedMaxPool, MaskedUpsample
+
+
+def _conv_bn(cin, cout, momentum, relu):
+    layers = [nn.Conv1d(cin, cout, kernel_size=1, bias=False), nn.BatchNorm1d(cout, momentum=momentum)]
+    if relu:
+        layers.append(nn.ReLU(inplace=True))
+    return nn.Sequential(*layers)
+
+
+class MultiInputSequential(nn.Sequential):
+    def forward(self, *inputs):
+        for module in self._modules.values():
+            inputs = module(*inputs)
+        return inputs
+
+
+class Bottleneck(nn.Module):
+    def __init__(self, in_channels, out_channels, bottleneck_ratio, radius, nsample, config,
+                 downsample=False, sampleDl=None, npoint=None):
+        super().__init__()
+        self.in_channels, self.out_channels, self.downsample = in_channels, out_channels, downsample
+        mid = out_channels // bottleneck_ratio
+        if downsample:
+            self.maxpool = MaskedMaxPool(npoint, radius, nsample, sampleDl)
+        self.conv1 = _conv_bn(in_channels, mid, config.bn_momentum, relu=True)
+        self.local_aggregation = LocalAggregation(mid, mid, radius, nsample, config)
+        self.conv2 = _conv_bn(mid, out_channels, config.bn_momentum, relu=False)
+        self.relu = nn.ReLU(inplace=True)
+        if in_channels != out_channels:
+            self.shortcut = _conv_bn(in_channels, out_channels, config.bn_momentum, relu=False)
+
+    def forward(self, xyz, mask, features):
+        if self.downsample:
+            query_xyz, query_mask, identity = self.maxpool(xyz, mask, features)
+        else:
+            query_xyz, query_mask, identity = xyz, mask, features
+        out = self.conv1(features)
+        out = self.local_aggregation(query_xyz, xyz, query_mask, mask, out)
+        out = self.conv2(out)
+        if self.in_channels != self.out_channels:
+            identity = self.shortcut(identity)
+        return query_xyz, query_mask, self.relu(out + identity)
+
+
+class ResNet(nn.Module):
+    def __init__(self, config, input_features_dim, radius, sampleDl, nsamples, npoints,
+                 width=144, depth=2, bottleneck_ratio=2):
+        super().__init__()
+        self.input_features_dim = input_features_dim
+        self.conv1 = _conv_bn(input_features_dim, width // 2, config.bn_momentum, relu=True)
+        self.la1 = LocalAggregation(width // 2, width // 2, radius, nsamples[0], config)
+        self.btnk1 = Bottleneck(width // 2, width, bottleneck_ratio, radius, nsamples[0], config)
+        # four strided stages: grid size, radius and width double at each one
+        for stage in range(4):
+            layer = MultiInputSequential()
+            sampleDl *= 2
+            layer.add_module("strided_bottleneck",
+                             Bottleneck(width, 2 * width, bottleneck_ratio, radius, nsamples[stage], config,
+                                        downsample=True, sampleDl=sampleDl, npoint=npoints[stage]))
+            radius *= 2
+            width *= 2
+            for i in range(depth - 1):
+                layer.add_module(f"bottlneck{i}",  # (sic) the reference's spelling, kept for checkpoints
+                                 Bottleneck(width, width, bottleneck_ratio, radius, nsamples[stage + 1], config))
+            setattr(self, f"layer{stage + 1}", layer)
+
+    def forward(self, xyz, mask, features, end_points=None):
+        if not end_points:
+            end_points = {}
+        features = self.conv1(features)
+        features = self.la1(xyz, xyz, mask, mask, features)
+        xyz, mask, features = self.btnk1(xyz, mask, features)
+        end_points['res1_xyz'], end_points['res1_mask'], end_points['res1_features'] = xyz, mask, features
+        for stage in range(4):
+            xyz, mask, features = getattr(self, f"layer{stage + 1}")(xyz, mask, features)
+            end_points[f'res{stage + 2}_xyz'] = xyz
+            end_points[f'res{stage + 2}_mask'] = mask
+            end_points[f'res{stage + 2}_features'] = features
+        return end_points
+
+
+class SceneSegHeadResNet(nn.Module):
+    def __init__(self, num_classes, width, base_radius, nsamples):
+        super().__init__()
+        self.num_classes, self.base_radius, self.nsamples = num_classes, base_radius, nsamples
+        for lvl in range(4):
+            setattr(self, f"up{lvl}", MaskedUpsample(radius=(8 >> lvl) * base_radius, nsample=nsamples[3 - lvl],
+                                                     mode='nearest'))
+        bn = 0.1  # the reference's heads use BatchNorm1d's default momentum
+        self.up_conv0 = _conv_bn(24 * width, 4 * width, bn, relu=True)
+        self.up_conv1 = _conv_bn(8 * width, 2 * width, bn, relu=True)
+        self.up_conv2 = _conv_bn(4 * width, width, bn, relu=True)
+        self.up_conv3 = _conv_bn(2 * width, width // 2, bn, relu=True)
+        self.head = nn.Sequential(nn.Conv1d(width // 2, width // 2, kernel_size=1, bias=False),
+                                  nn.BatchNorm1d(width // 2), nn.ReLU(inplace=True),
+                                  nn.Conv1d(width // 2, num_classes, kernel_size=1, bias=True))
+
+    def forward(self, end_points):
+        feats = end_points['res5_features']
+        for lvl, (fine, coarse) in enumerate(((4, 5), (3, 4), (2, 3), (1, 2))):
+            feats = getattr(self, f"up{lvl}")(end_points[f'res{fine}_xyz'], end_points[f'res{coarse}_xyz'],
+                                              end_points[f'res{fine}_mask'], end_points[f'res{coarse}_mask'], feats)
+            feats = torch.cat([feats, end_points[f'res{fine}_features']], 1)
+            feats = getattr(self, f"up_conv{lvl}")(feats)
+        return self.head(feats)

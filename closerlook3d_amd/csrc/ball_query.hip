@@ -1,0 +1,266 @@
+// ball_query.hip -- masked ordered ball query and masked nearest query for gfx950.
+//
+// Replaces masked_ordered_ball_query_gpu.cu:11-96 and masked_nearest_query_gpu.cu:8-62 of the
+// reference (one thread per query, one block per cloud, serial scan, scratch in global memory,
+// in-thread sort).  Design here, MI355X-first:
+//
+//   * one wavefront owns QW queries; the 64 lanes hold 64 consecutive support points in
+//     registers and the QW query positions are wave-uniform (SGPR) operands, so every support
+//     load is amortised over QW distance evaluations and no per-lane candidate list exists;
+//   * "first 3*nsample in-radius points in support-index order" (the reference's candidate
+//     rule) falls out of the lane order: a ballot of the in-radius predicate plus mbcnt gives
+//     every hit its position in index order, and the candidates go to a per-query LDS list;
+//   * the running strict minimum (needed for the reference's "patch the last slot" step) is
+//     tracked per lane and reduced once per query as a 64-bit (d2 bits, index) key;
+//   * the reference's stable sort by distance is a wave-parallel rank sort on
+//     (d2, candidate position) out of LDS -- same permutation as any stable sort;
+//   * grid = (ceil(M / (4*QW)), B) blocks of 4 waves: thousands of blocks instead of B.
+//
+// Results are bit-identical to the reference semantics (tests/test_native_gpu.py); the
+// distance uses cl3d::dist2's canonical operation order.
+#include "cl3d_common.h"
+
+namespace cl3d {
+
+constexpr int kWavesPerBlock = 4;
+
+template <int QW>
+__global__ __launch_bounds__(256) void ball_query_kernel(
+    const float *__restrict__ query_xyz, const float *__restrict__ support_xyz,
+    const int *__restrict__ query_mask, const int *__restrict__ support_mask, int M, int N,
+    float radius2, int K, int *__restrict__ idx, int *__restrict__ idx_mask) {
+  extern __shared__ int smem[];
+  __shared__ int s_nv;
+  const int cap = 3 * K;
+  const int b = blockIdx.y;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int nq_block = kWavesPerBlock * QW;
+
+  // LDS carve: candidate distances, candidate indices, sorted indices
+  float *cand_d = reinterpret_cast<float *>(smem) + (size_t)wave * QW * cap;
+  int *cand_i = smem + (size_t)nq_block * cap + (size_t)wave * QW * cap;
+  int *sorted_i = smem + (size_t)2 * nq_block * cap + (size_t)wave * QW * K;
+
+  const float *q = query_xyz + (size_t)b * M * 3;
+  const float *s = support_xyz + (size_t)b * N * 3;
+  const int nv = block_first_zero(support_mask + (size_t)b * N, N, &s_nv);
+
+  const int j0 = blockIdx.x * nq_block + wave * QW;  // first query of this wave (uniform)
+
+  float qx[QW], qy[QW], qz[QW];
+  float lmin[QW];
+  int lidx[QW];
+  int cnt[QW];
+#pragma unroll
+  for (int t = 0; t < QW; ++t) {
+    int j = j0 + t;
+    j = j < M ? j : M - 1;
+    qx[t] = q[j * 3 + 0];
+    qy[t] = q[j * 3 + 1];
+    qz[t] = q[j * 3 + 2];
+    lmin[t] = radius2;
+    lidx[t] = 0;
+    cnt[t] = 0;
+  }
+
+  for (int base = 0; base < nv; base += CL3D_WAVE) {
+    const int k = base + lane;
+    const bool valid = k < nv;
+    const int kk = valid ? k : nv - 1;
+    const float sx = s[kk * 3 + 0];
+    const float sy = s[kk * 3 + 1];
+    const float sz = s[kk * 3 + 2];
+#pragma unroll
+    for (int t = 0; t < QW; ++t) {
+      const float d2 = dist2(qx[t], qy[t], qz[t], sx, sy, sz);
+      const bool hit = valid && (d2 < radius2);
+      const unsigned long long m = __ballot(hit);
+      if (m != 0ull) {
+        if (hit && d2 < lmin[t]) {
+          lmin[t] = d2;
+          lidx[t] = k;
+        }
+        const int c = cnt[t];
+        if (c < cap) {
+          const int pos = c + prefix_popc(m);
+          if (hit && pos < cap) {
+            cand_d[t * cap + pos] = d2;
+            cand_i[t * cap + pos] = k;
+          }
+          const int nc = c + (int)__popcll(m);
+          cnt[t] = nc < cap ? nc : cap;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // patch-up: if the candidate list was cut at 3K and the global strict minimum lies beyond
+  // its last entry, the last entry is replaced by the minimum (reference :72-75).
+#pragma unroll
+  for (int t = 0; t < QW; ++t) {
+    unsigned long long key = ((unsigned long long)__float_as_uint(lmin[t]) << 32) | (unsigned)lidx[t];
+    key = wave_min_u64(key);
+    const int c = __builtin_amdgcn_readfirstlane(cnt[t]);
+    cnt[t] = c;
+    if (cap > 0 && c >= cap) {
+      const int gidx = (int)(unsigned)(key & 0xffffffffull);
+      const int last = cand_i[t * cap + cap - 1];
+      if (gidx > last && lane == 0) {
+        cand_i[t * cap + cap - 1] = gidx;
+        cand_d[t * cap + cap - 1] = __uint_as_float((unsigned)(key >> 32));
+      }
+    }
+  }
+  __syncthreads();
+
+  // stable sort by distance == rank by (d2, list position)
+#pragma unroll
+  for (int t = 0; t < QW; ++t) {
+    const int c = cnt[t];
+    const float *cd = cand_d + t * cap;
+    for (int e = lane; e < c; e += CL3D_WAVE) {
+      const float de = cd[e];
+      int rank = 0;
+      for (int f = 0; f < c; ++f) {
+        const float df = cd[f];
+        rank += (df < de || (df == de && f < e)) ? 1 : 0;
+      }
+      if (rank < K) sorted_i[t * K + rank] = cand_i[t * cap + e];
+    }
+  }
+  __syncthreads();
+
+  const int *qm = query_mask + (size_t)b * M;
+#pragma unroll
+  for (int t = 0; t < QW; ++t) {
+    const int j = j0 + t;
+    if (j >= M) break;
+    const int c = cnt[t];
+    const int qmk = qm[j];
+    int *oi = idx + ((size_t)b * M + j) * K;
+    int *om = idx_mask + ((size_t)b * M + j) * K;
+    for (int i = lane; i < K; i += CL3D_WAVE) {
+      int v = 0, mk = 0;
+      if (c > 0) {
+        v = sorted_i[t * K + (i < c ? i : i % c)];
+        mk = (i < c && qmk != 0) ? 1 : 0;
+      }
+      oi[i] = v;
+      om[i] = mk;
+    }
+  }
+}
+
+template <int QW>
+__global__ __launch_bounds__(256) void nearest_query_kernel(
+    const float *__restrict__ query_xyz, const float *__restrict__ support_xyz,
+    const int *__restrict__ query_mask, const int *__restrict__ support_mask, int M, int N,
+    int *__restrict__ idx, int *__restrict__ idx_mask) {
+  __shared__ int s_nv;
+  const int b = blockIdx.y;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const float *q = query_xyz + (size_t)b * M * 3;
+  const float *s = support_xyz + (size_t)b * N * 3;
+  const int nv = block_first_zero(support_mask + (size_t)b * N, N, &s_nv);
+  const int j0 = (blockIdx.x * kWavesPerBlock + wave) * QW;
+
+  float qx[QW], qy[QW], qz[QW], lmin[QW];
+  int lidx[QW];
+#pragma unroll
+  for (int t = 0; t < QW; ++t) {
+    int j = j0 + t;
+    j = j < M ? j : M - 1;
+    qx[t] = q[j * 3 + 0];
+    qy[t] = q[j * 3 + 1];
+    qz[t] = q[j * 3 + 2];
+    lmin[t] = 100.0f;  // reference: min_dist = 100, min_idx = -1 (masked_nearest_query_gpu.cu:37-38)
+    lidx[t] = -1;
+  }
+  for (int base = 0; base < nv; base += CL3D_WAVE) {
+    const int k = base + lane;
+    const bool valid = k < nv;
+    const int kk = valid ? k : nv - 1;
+    const float sx = s[kk * 3 + 0];
+    const float sy = s[kk * 3 + 1];
+    const float sz = s[kk * 3 + 2];
+#pragma unroll
+    for (int t = 0; t < QW; ++t) {
+      const float d2 = dist2(qx[t], qy[t], qz[t], sx, sy, sz);
+      if (valid && d2 < lmin[t]) {
+        lmin[t] = d2;
+        lidx[t] = k;
+      }
+    }
+  }
+  const int *qm = query_mask + (size_t)b * M;
+#pragma unroll
+  for (int t = 0; t < QW; ++t) {
+    // lanes that never saw d2 < 100 keep (100.0f, 0xffffffff): larger than every real key
+    unsigned long long key = ((unsigned long long)__float_as_uint(lmin[t]) << 32) | (unsigned)lidx[t];
+    key = wave_min_u64(key);
+    const int j = j0 + t;
+    if (j < M && lane == 0) {
+      idx[(size_t)b * M + j] = (int)(unsigned)(key & 0xffffffffull);
+      idx_mask[(size_t)b * M + j] = qm[j] == 0 ? 0 : 1;
+    }
+  }
+}
+
+template <int QW>
+static int launch_ball_query(const float *q, const float *s, const int *qm, const int *sm, int B,
+                             int M, int N, float radius, int K, int *idx, int *idx_mask,
+                             hipStream_t st) {
+  const int nq_block = kWavesPerBlock * QW;
+  const size_t lds = (size_t)nq_block * (2 * 3 * K + K) * sizeof(int);
+  dim3 grid(ceil_div(M, nq_block), B);
+  hipLaunchKernelGGL(ball_query_kernel<QW>, grid, dim3(256), lds, st, q, s, qm, sm, M, N,
+                     radius * radius, K, idx, idx_mask);
+  return check_launch("cl3d_masked_ordered_ball_query");
+}
+
+}  // namespace cl3d
+
+extern "C" int cl3d_masked_ordered_ball_query(const float *query_xyz, const float *support_xyz,
+                                              const int32_t *query_mask,
+                                              const int32_t *support_mask, int B, int M, int N,
+                                              float radius, int nsample, int32_t *idx,
+                                              int32_t *idx_mask, void *ws, size_t ws_bytes,
+                                              cl3d_stream_t stream) {
+  (void)ws;
+  (void)ws_bytes;
+  CL3D_REQUIRE(B >= 0 && M >= 0 && N >= 1 && nsample >= 1, "ball_query: bad sizes B=%d M=%d N=%d K=%d", B, M, N, nsample);
+  if (B == 0 || M == 0) return CL3D_OK;
+  CL3D_REQUIRE(query_xyz && support_xyz && query_mask && support_mask && idx && idx_mask, "ball_query: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  // LDS per block = 4*QW*7K ints; stay within the 64 KiB a kernel gets without opting in.
+  const size_t per_q = (size_t)7 * nsample * sizeof(int);
+  const size_t budget = 64 * 1024;
+  if (4 * 8 * per_q <= budget && M >= 64)
+    return cl3d::launch_ball_query<8>(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx, idx_mask, st);
+  if (4 * 4 * per_q <= budget && M >= 16)
+    return cl3d::launch_ball_query<4>(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx, idx_mask, st);
+  if (4 * 1 * per_q <= budget)
+    return cl3d::launch_ball_query<1>(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx, idx_mask, st);
+  return cl3d::fail(CL3D_E_UNSUPPORTED, "ball_query: nsample=%d needs more than 64 KiB of LDS", nsample);
+}
+
+extern "C" int cl3d_masked_nearest_query(const float *query_xyz, const float *support_xyz,
+                                         const int32_t *query_mask, const int32_t *support_mask,
+                                         int B, int M, int N, int32_t *idx, int32_t *idx_mask,
+                                         cl3d_stream_t stream) {
+  CL3D_REQUIRE(B >= 0 && M >= 0 && N >= 1, "nearest_query: bad sizes B=%d M=%d N=%d", B, M, N);
+  if (B == 0 || M == 0) return CL3D_OK;
+  CL3D_REQUIRE(query_xyz && support_xyz && query_mask && support_mask && idx && idx_mask, "nearest_query: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (M >= 64) {
+    dim3 grid(cl3d::ceil_div(M, cl3d::kWavesPerBlock * 8), B);
+    hipLaunchKernelGGL(cl3d::nearest_query_kernel<8>, grid, dim3(256), 0, st, query_xyz, support_xyz, query_mask, support_mask, M, N, idx, idx_mask);
+  } else {
+    dim3 grid(cl3d::ceil_div(M, cl3d::kWavesPerBlock * 1), B);
+    hipLaunchKernelGGL(cl3d::nearest_query_kernel<1>, grid, dim3(256), 0, st, query_xyz, support_xyz, query_mask, support_mask, M, N, idx, idx_mask);
+  }
+  return cl3d::check_launch("cl3d_masked_nearest_query");
+}

@@ -1,0 +1,81 @@
+// cl3d_common.h -- shared device/host helpers of libcl3d (gfx950 only; no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/cl3d.h"
+
+#define CL3D_WAVE 64
+
+namespace cl3d {
+
+// ---- per-thread error text ------------------------------------------------------------
+inline char *err_buf() {
+  static thread_local char buf[512] = "";
+  return buf;
+}
+inline int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(CL3D_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return CL3D_OK;
+}
+#define CL3D_REQUIRE(cond, ...) \
+  do {                          \
+    if (!(cond)) return cl3d::fail(CL3D_E_INVALID, __VA_ARGS__); \
+  } while (0)
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// ---- device helpers -------------------------------------------------------------------
+// Squared distance in the canonical operation order (see DESIGN.md "floating-point canon"):
+// what hipcc -O2 makes of the reference expression on gfx950,
+//   d2 = fadd(fma(dy,dy, fmul(dx,dx)), fmul(dz,dz)).
+// The library is compiled with -ffp-contract=off, so nothing here is re-fused.
+__device__ __forceinline__ float dist2(float qx, float qy, float qz, float x, float y, float z) {
+  const float dx = qx - x, dy = qy - y, dz = qz - z;
+  const float xx = dx * dx;
+  const float zz = dz * dz;
+  return __builtin_fmaf(dy, dy, xx) + zz;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// number of set bits of m strictly below this lane
+__device__ __forceinline__ int prefix_popc(unsigned long long m) {
+  return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    unsigned long long o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+// first index i in [0,n) with mask[i]==0, else n.  All threads of the block call it;
+// result is block-uniform.  `s_tmp` is one int of LDS.
+__device__ __forceinline__ int block_first_zero(const int *__restrict__ mask, int n, int *s_tmp) {
+  if (threadIdx.x == 0) *s_tmp = n;
+  __syncthreads();
+  int best = n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x)
+    if (mask[i] == 0) { best = i; break; }
+  if (best < n) atomicMin(s_tmp, best);
+  __syncthreads();
+  int r = *s_tmp;
+  __syncthreads();
+  return r;
+}
+
+}  // namespace cl3d

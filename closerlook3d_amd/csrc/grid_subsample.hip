@@ -1,0 +1,280 @@
+// grid_subsample.hip -- masked grid subsampling for gfx950.
+//
+// Replaces masked_grid_subsampling_gpu.cu:11-153 of the reference, which runs ONE thread per
+// cloud (<<<b,1>>>): three linear passes and two in-thread sorts of N keys, serial.
+// Same results, bit for bit, from one 1024-thread workgroup per cloud:
+//
+//   1. bounding box over all N points (reference :31-46 does not look at the mask here) and the
+//      number of leading valid points -- block reductions;
+//   2. one 64-bit key per valid point, (cell id biased to unsigned) << 32 | original index, sorted
+//      by a bitonic network in LDS.  Keys are unique, so the result equals the reference's stable
+//      sort by cell id;
+//   3. every thread walks a contiguous run of the sorted array; cell heads are counted, an
+//      exclusive block scan gives each head its rank (= the reference's `top`), and the thread
+//      that owns a head folds that cell's points in ascending original index with plain float
+//      adds -- the same summation order as the reference's sequential loop (:84-122);
+//   4. the reference's LCG shuffle (keys k0 = cell0 % 256, k_i = (17 k_{i-1} + 139) % 256, stable
+//      sort, :125-135) has period 256 after a transient of < 256 steps, so the position of
+//      barycentre i in the shuffled order is computed in closed form from a 512-entry table
+//      instead of sorting; each barycentre is written straight to its final slot;
+//   5. wrap-around padding with mask 0 (:146-151).
+#include "cl3d_common.h"
+
+namespace cl3d {
+
+constexpr int kSubThreads = 1024;
+constexpr int kSubMaxN = 16384;  // 128 KiB of sort keys; the CU has 160 KiB of LDS
+
+__device__ __forceinline__ int key_cell(unsigned long long k) {
+  return (int)(((unsigned)(k >> 32)) ^ 0x80000000u);
+}
+__device__ __forceinline__ int key_orig(unsigned long long k) { return (int)(unsigned)(k & 0xffffffffull); }
+
+__global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
+    const float *__restrict__ xyz, const int *__restrict__ mask, int N, int m, float dl, int P,
+    float *__restrict__ sub_xyz, int *__restrict__ sub_mask) {
+  extern __shared__ unsigned long long keys[];  // [P]
+  __shared__ float s_red[6][kSubThreads / 64];
+  __shared__ int s_scan[kSubThreads / 64];
+  __shared__ int s_tmp;
+  __shared__ int s_T[512];
+  __shared__ int s_E[256];
+  __shared__ int s_invB[256];
+  __shared__ int s_cntA[511];
+  __shared__ int s_base[512];
+
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const float *p = xyz + (size_t)b * N * 3;
+  const int *mk = mask + (size_t)b * N;
+  float *o = sub_xyz + (size_t)b * m * 3;
+  int *om = sub_mask + (size_t)b * m;
+
+  const int nv = block_first_zero(mk, N, &s_tmp);
+
+  // ---- 1. bounding box over all N points
+  float mn[3], mx[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = p[a];
+    mx[a] = p[a];
+  }
+  for (int i = tid; i < N; i += kSubThreads) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = p[i * 3 + a];
+      if (v > mx[a]) mx[a] = v;
+      if (v < mn[a]) mn[a] = v;
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float omx = __shfl_xor(mx[a], off, 64);
+      const float omn = __shfl_xor(mn[a], off, 64);
+      if (omx > mx[a]) mx[a] = omx;
+      if (omn < mn[a]) mn[a] = omn;
+    }
+    if (lane == 0) {
+      s_red[a][wave] = mn[a];
+      s_red[3 + a][wave] = mx[a];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = s_red[a][0];
+    mx[a] = s_red[3 + a][0];
+    for (int w = 1; w < kSubThreads / 64; ++w) {
+      const float vmn = s_red[a][w], vmx = s_red[3 + a][w];
+      if (vmn < mn[a]) mn[a] = vmn;
+      if (vmx > mx[a]) mx[a] = vmx;
+    }
+  }
+  const float inv = 1.0f / dl;
+  const float ox = floorf(mn[0] * inv) * dl;
+  const float oy = floorf(mn[1] * inv) * dl;
+  const float oz = floorf(mn[2] * inv) * dl;
+  const int NX = (int)floorf((mx[0] - ox) / dl) + 1;
+  const int NY = (int)floorf((mx[1] - oy) / dl) + 1;
+
+  // ---- 2. keys + bitonic sort
+  for (int i = tid; i < P; i += kSubThreads) {
+    unsigned long long key = ~0ull;
+    if (i < nv) {
+      const int iX = (int)floorf((p[i * 3 + 0] - ox) / dl);
+      const int iY = (int)floorf((p[i * 3 + 1] - oy) / dl);
+      const int iZ = (int)floorf((p[i * 3 + 2] - oz) / dl);
+      const int cell = iX + NX * iY + NX * NY * iZ;
+      key = ((unsigned long long)(((unsigned)cell) ^ 0x80000000u) << 32) | (unsigned)i;
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (P >> 1); t += kSubThreads) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int l = i | j;
+        const unsigned long long a = keys[i], c = keys[l];
+        const bool up = (i & k) == 0;
+        if ((a > c) == up) {
+          keys[i] = c;
+          keys[l] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- 3. heads: contiguous run per thread, block scan of head counts
+  const int run = (P + kSubThreads - 1) / kSubThreads;
+  const int r0 = tid * run;
+  int r1 = r0 + run;
+  r1 = r1 < nv ? r1 : nv;
+  int heads = 0;
+  for (int pos = r0; pos < r1; ++pos)
+    heads += (pos == 0 || key_cell(keys[pos]) != key_cell(keys[pos - 1])) ? 1 : 0;
+  // exclusive scan over threads
+  int incl = heads;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) s_scan[wave] = incl;
+  __syncthreads();
+  int wave_off = 0, total = 0;
+  for (int w = 0; w < kSubThreads / 64; ++w) {
+    const int v = s_scan[w];
+    if (w < wave) wave_off += v;
+    total += v;
+  }
+  int top = wave_off + incl - heads;
+  // nv == 0: the reference reads its zero-filled scratch and ends up with one cell {point 0}
+  const int end = nv > 0 ? total : 1;
+
+  // ---- 4. shuffle position tables
+  if (tid == 0) {
+    int k0 = nv > 0 ? key_cell(keys[0]) % 256 : 0;
+    s_T[0] = k0;
+    for (int i = 1; i < 512; ++i) {
+      k0 = (17 * k0 + 139) % 256;
+      s_T[i] = k0;
+    }
+  }
+  __syncthreads();
+  const int nA = end < 256 ? end : 256;
+  if (tid < 256) {
+    int e = 0;
+    const int v = s_T[tid];
+    for (int i = 0; i < tid; ++i) e += (s_T[i] == v) ? 1 : 0;
+    s_E[tid] = e;
+    s_invB[s_T[256 + tid]] = tid;  // T[256..511] is a permutation of 0..255
+  }
+  if (tid < 511) {
+    const int v = tid - 255;
+    int c = 0;
+    for (int i = 0; i < nA; ++i) c += (s_T[i] == v) ? 1 : 0;
+    s_cntA[tid] = c;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    const int nB = end - 256;  // number of cells with i >= 256 (may be <= 0)
+    for (int vi = 0; vi < 511; ++vi) {
+      s_base[vi] = acc;
+      const int v = vi - 255;
+      int cB = 0;
+      if (v >= 0 && nB > 0) {
+        const int r = s_invB[v];
+        if (nB > r) cB = ((nB - 1 - r) >> 8) + 1;
+      }
+      acc += s_cntA[vi] + cB;
+    }
+  }
+  __syncthreads();
+
+  auto position = [&](int i) -> int {
+    if (i < 256) return s_base[s_T[i] + 255] + s_E[i];
+    const int r = (i - 256) & 255;
+    const int v = s_T[256 + r];
+    return s_base[v + 255] + s_cntA[v + 255] + ((i - 256) >> 8);
+  };
+
+  // ---- barycentres, written straight to their shuffled slot
+  if (nv == 0) {
+    if (tid == 0 && m > 0) {
+      o[0] = p[0] / 1.0f;
+      o[1] = p[1] / 1.0f;
+      o[2] = p[2] / 1.0f;
+      om[0] = 1;
+    }
+  } else {
+    for (int pos = r0; pos < r1; ++pos) {
+      const int cell = key_cell(keys[pos]);
+      if (!(pos == 0 || cell != key_cell(keys[pos - 1]))) continue;
+      int j = key_orig(keys[pos]);
+      float xs = p[j * 3 + 0], ys = p[j * 3 + 1], zs = p[j * 3 + 2];
+      float pnum = 1.0f;
+      for (int pp = pos + 1; pp < nv; ++pp) {
+        const unsigned long long kk = keys[pp];
+        if (key_cell(kk) != cell) break;
+        j = key_orig(kk);
+        xs += p[j * 3 + 0];
+        ys += p[j * 3 + 1];
+        zs += p[j * 3 + 2];
+        pnum += 1.0f;
+      }
+      const int dst = position(top);
+      if (dst < m) {
+        o[dst * 3 + 0] = xs / pnum;
+        o[dst * 3 + 1] = ys / pnum;
+        o[dst * 3 + 2] = zs / pnum;
+        om[dst] = 1;
+      }
+      ++top;
+    }
+  }
+  __syncthreads();
+
+  // ---- 5. wrap-around padding
+  for (int i = end + tid; i < m; i += kSubThreads) {
+    const int src = i % end;
+    o[i * 3 + 0] = o[src * 3 + 0];
+    o[i * 3 + 1] = o[src * 3 + 1];
+    o[i * 3 + 2] = o[src * 3 + 2];
+    om[i] = 0;
+  }
+}
+
+}  // namespace cl3d
+
+extern "C" int cl3d_masked_grid_subsampling(const float *xyz, const int32_t *mask, int B, int N,
+                                            int m, float sampleDl, float *sub_xyz,
+                                            int32_t *sub_mask, void *ws, size_t ws_bytes,
+                                            cl3d_stream_t stream) {
+  (void)ws;
+  (void)ws_bytes;
+  CL3D_REQUIRE(B >= 0 && N >= 1 && m >= 0, "grid_subsampling: bad sizes B=%d N=%d m=%d", B, N, m);
+  if (B == 0 || m == 0) return CL3D_OK;
+  CL3D_REQUIRE(xyz && mask && sub_xyz && sub_mask, "grid_subsampling: null pointer");
+  if (N > cl3d::kSubMaxN)
+    return cl3d::fail(CL3D_E_UNSUPPORTED, "grid_subsampling: N=%d > %d (multi-workgroup sort path not built yet)", N, cl3d::kSubMaxN);
+  int P = 2;
+  while (P < N) P <<= 1;
+  const size_t lds = (size_t)P * sizeof(unsigned long long);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cl3d::grid_subsample_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) return cl3d::fail(CL3D_E_LAUNCH, "grid_subsampling: LDS opt-in: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(cl3d::grid_subsample_kernel, dim3(B), dim3(cl3d::kSubThreads), lds, (hipStream_t)stream,
+                     xyz, mask, N, m, sampleDl, P, sub_xyz, sub_mask);
+  return cl3d::check_launch("cl3d_masked_grid_subsampling");
+}

@@ -1,0 +1,277 @@
+"""The reference's operator API (`pytorch/models/local_aggregation_operators.py`) on the HIP engine.
+
+`LocalAggregation(in_channels, out_channels, radius, nsample, config)` with
+`forward(query_xyz, support_xyz, query_mask, support_mask, support_features) -> [B, C_out, M]`
+(reference :429-464), dispatching on `config.local_aggregation_type` to PosPool (:16-112),
+AdaptiveWeight (:115-224), PointWiseMLP (:227-316) and PseudoGrid (:319-426).
+
+Sub-module / parameter / buffer names equal the reference's, so its checkpoints load with
+`load_state_dict` unchanged (`local_aggregation_operator.out_conv.0.weight`, `mlps.conv0.weight`,
+`mlps.conv0.0.weight`, `K_points`, `kernel_weights`, ...).
+
+Two execution paths per operator, same numbers (tests/test_operators_gpu.py):
+  * `impl='fused'`   hand-written HIP kernels that never materialise the [B,C,M,K] neighbourhood
+                     tensor (closerlook3d_amd/fused.py);
+  * `impl='grouped'` the reference's own dataflow -- MaskedQueryAndGroup followed by element-wise
+                     PyTorch ops over the materialised tensor -- kept as the in-framework
+                     cross-check and for configurations the fused kernels do not cover.
+`config.cl3d_impl` (optional) selects it; default 'auto' = fused where available.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .pt_utils import MaskedQueryAndGroup
+
+
+def _cfg(config, name, default=None):
+    return getattr(config, name, default) if not isinstance(config, dict) else config.get(name, default)
+
+
+def _masked_reduce(agg, reduction, neighborhood_mask, query_mask, nsample, who):
+    """max / avg / sum over the K axis with the reference's padding rule (:87-103): padded queries
+    get an all-ones mask (`idx_mask + (1 - query_mask)`) so they average over their K copies."""
+    if reduction == 'max':
+        return F.max_pool2d(agg, kernel_size=[1, nsample]).squeeze(-1)
+    if reduction in ('avg', 'mean', 'sum'):
+        feature_mask = (neighborhood_mask + (1 - query_mask[:, :, None]))[:, None, :, :]
+        agg = agg * feature_mask
+        out = agg.sum(-1)
+        if reduction != 'sum':
+            out = out / feature_mask.sum(-1)
+        return out
+    raise NotImplementedError(f'Reduction {reduction} not implemented in {who}')
+
+
+class _OutputTransform(nn.Module):
+    """`out_conv` (Conv1d+BN+ReLU) or `out_transform` (BN+ReLU) with the reference's attribute names."""
+
+    def _make_output(self, in_channels, out_channels, output_conv, bn_momentum):
+        self.output_conv = output_conv or (in_channels != out_channels)
+        if self.output_conv:
+            self.out_conv = nn.Sequential(
+                nn.Conv1d(in_channels, out_channels, kernel_size=1, bias=False),
+                nn.BatchNorm1d(out_channels, momentum=bn_momentum),
+                nn.ReLU(inplace=True))
+        else:
+            self.out_transform = nn.Sequential(
+                nn.BatchNorm1d(out_channels, momentum=bn_momentum),
+                nn.ReLU(inplace=True))
+
+    def _output(self, x):
+        return self.out_conv(x) if self.output_conv else self.out_transform(x)
+
+
+class PosPool(_OutputTransform):
+    def __init__(self, in_channels, out_channels, radius, nsample, config):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.radius, self.nsample = radius, nsample
+        self.position_embedding = config.pospool.position_embedding
+        self.reduction = config.pospool.reduction
+        self.impl = _cfg(config, 'cl3d_impl', 'auto')
+        self.grouper = MaskedQueryAndGroup(radius, nsample, use_xyz=False, ret_grouped_xyz=True, normalize_xyz=True)
+        self._make_output(in_channels, out_channels, config.pospool.output_conv, config.bn_momentum)
+
+    def _embedding(self, rel, C):
+        B, _, M, K = rel.shape
+        if self.position_embedding == 'xyz':
+            if C % 3:
+                raise RuntimeError(f"PosPool xyz needs C % 3 == 0, got {C}")
+            return rel.unsqueeze(1).expand(B, C // 3, 3, M, K).reshape(B, C, M, K)
+        if self.position_embedding == 'sin_cos':
+            if C % 6:
+                raise RuntimeError(f"PosPool sin_cos needs C % 6 == 0, got {C}")
+            fd = C // 6
+            feat_range = torch.arange(fd, dtype=torch.float32, device=rel.device)
+            dim_mat = torch.pow(1.0 * 1000, (1.0 / fd) * feat_range)
+            div = torch.div((100 * rel).unsqueeze(-1), dim_mat)  # B,3,M,K,fd
+            emb = torch.cat([torch.sin(div), torch.cos(div)], -1)  # B,3,M,K,2fd
+            return emb.permute(0, 1, 4, 2, 3).reshape(B, C, M, K)
+        raise NotImplementedError(f'Position Embedding {self.position_embedding} not implemented in PosPool')
+
+    def forward(self, query_xyz, support_xyz, query_mask, support_mask, support_features):
+        from . import fused
+        if fused.use_fused(self.impl, 'pospool', self):
+            out = fused.pospool(query_xyz, support_xyz, query_mask, support_mask, support_features,
+                                self.radius, self.nsample, self.position_embedding, self.reduction)
+            return self._output(out)
+        feats, rel, nmask = self.grouper(query_xyz, support_xyz, query_mask, support_mask, support_features)
+        agg = feats * self._embedding(rel, support_features.shape[1])
+        return self._output(_masked_reduce(agg, self.reduction, nmask, query_mask, self.nsample, 'PosPool'))
+
+
+class AdaptiveWeight(_OutputTransform):
+    def __init__(self, in_channels, out_channels, radius, nsample, config):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.radius, self.nsample = radius, nsample
+        aw = config.adaptive_weight
+        self.weight_type = aw.weight_type
+        self.weight_to_channels = {'dp': 3, 'df': in_channels, 'fj': in_channels, 'dp_df': 3 + in_channels,
+                                   'dp_fj': 3 + in_channels, 'fi_df': 2 * in_channels,
+                                   'dp_fi_df': 3 + 2 * in_channels, 'rscnn': 10}
+        self.weight_input_channels = self.weight_to_channels[self.weight_type]
+        self.num_mlps = aw.num_mlps
+        self.shared_channels = aw.shared_channels
+        self.weight_softmax = aw.weight_softmax  # stored and unused, as in the reference (:142)
+        self.reduction = aw.reduction
+        self.impl = _cfg(config, 'cl3d_impl', 'auto')
+        self.grouper = MaskedQueryAndGroup(radius, nsample, use_xyz=False, ret_grouped_xyz=True, normalize_xyz=True)
+        hidden = in_channels // self.shared_channels
+        self.mlps = nn.Sequential()
+        self.mlps.add_module('conv0', nn.Conv2d(self.weight_input_channels, hidden, kernel_size=1))
+        for i in range(self.num_mlps - 1):
+            self.mlps.add_module(f'relu{i}', nn.ReLU(inplace=True))
+            self.mlps.add_module(f'conv{i + 1}', nn.Conv2d(hidden, hidden, kernel_size=1))
+        self._make_output(in_channels, out_channels, aw.output_conv, config.bn_momentum)
+
+    def forward(self, query_xyz, support_xyz, query_mask, support_mask, support_features):
+        if self.weight_type != 'dp':
+            raise NotImplementedError(f'Weight Type {self.weight_type} not implemented in AdaptiveWeight')
+        from . import fused
+        if fused.use_fused(self.impl, 'adaptive_weight', self):
+            out = fused.adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, support_features,
+                                        self.radius, self.nsample, self.mlps, self.shared_channels,
+                                        self.reduction)
+            return self._output(out)
+        B, C, M = support_features.shape[0], support_features.shape[1], query_xyz.shape[1]
+        feats, rel, nmask = self.grouper(query_xyz, support_xyz, query_mask, support_mask, support_features)
+        w = self.mlps(rel).unsqueeze(2)  # B, C/S, 1, M, K
+        S = self.shared_channels
+        agg = (feats.view(B, C // S, S, M, self.nsample) * w).view(B, C, M, self.nsample)
+        return self._output(_masked_reduce(agg, self.reduction, nmask, query_mask, self.nsample, 'AdaptiveWeight'))
+
+
+class PointWiseMLP(nn.Module):
+    def __init__(self, in_channels, out_channels, radius, nsample, config):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.radius, self.nsample = radius, nsample
+        pw = config.pointwisemlp
+        self.feature_type = pw.feature_type
+        self.feature_input_channels = {'dp_fj': 3 + in_channels, 'fi_df': 2 * in_channels,
+                                       'dp_fi_df': 3 + 2 * in_channels}[self.feature_type]
+        self.num_mlps = pw.num_mlps
+        self.reduction = pw.reduction
+        self.impl = _cfg(config, 'cl3d_impl', 'auto')
+        self.grouper = MaskedQueryAndGroup(radius, nsample, use_xyz=False, ret_grouped_xyz=True, normalize_xyz=True)
+
+        def block(cin, cout):
+            return nn.Sequential(nn.Conv2d(cin, cout, kernel_size=1, bias=False),
+                                 nn.BatchNorm2d(cout, momentum=config.bn_momentum),
+                                 nn.ReLU(inplace=True))
+
+        self.mlps = nn.Sequential()
+        if self.num_mlps == 1:
+            self.mlps.add_module('conv0', block(self.feature_input_channels, out_channels))
+        else:
+            mfdim = max(in_channels // 2, 9)
+            self.mlps.add_module('conv0', block(self.feature_input_channels, mfdim))
+            for i in range(self.num_mlps - 2):
+                self.mlps.add_module(f'conv{i + 1}', block(mfdim, mfdim))
+            self.mlps.add_module(f'conv{self.num_mlps - 1}', block(mfdim, out_channels))
+
+    def forward(self, query_xyz, support_xyz, query_mask, support_mask, support_features):
+        if self.feature_type != 'dp_fi_df':
+            raise NotImplementedError(f'Feature Type {self.feature_type} not implemented in PointWiseMLP')
+        from . import fused
+        if fused.use_fused(self.impl, 'pointwisemlp', self):
+            return fused.pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, support_features,
+                                       self.radius, self.nsample, self.mlps, self.reduction, self.training)
+        feats, rel, nmask = self.grouper(query_xyz, support_xyz, query_mask, support_mask, support_features)
+        center = feats[..., :1].expand(-1, -1, -1, self.nsample)
+        agg = self.mlps(torch.cat([rel, center, feats - center], 1))
+        return _masked_reduce(agg, self.reduction, nmask, query_mask, self.nsample, 'PointWiseMLP')
+
+
+def make_kernel_points(radius, num_points, seed=0, iters=400):
+    """Deterministic kernel-point disposition for PseudoGrid: one point at the centre, the others
+    spread in the ball by repulsion, rescaled so the outermost sits at `radius`.
+
+    The reference (`models/utlis.py:153-284`) optimises random initial points, so its result differs
+    from run to run and from this one; trained models carry their `K_points` in the state dict (it
+    is a registered buffer, reference :353), which overrides whatever is generated here.
+    """
+    rng = np.random.default_rng(seed)
+    pts = rng.normal(size=(num_points, 3))
+    pts /= np.linalg.norm(pts, axis=1, keepdims=True) + 1e-9
+    pts *= rng.random((num_points, 1)) ** (1 / 3)
+    pts[0] = 0
+    for it in range(iters):
+        diff = pts[:, None, :] - pts[None, :, :]
+        d2 = (diff ** 2).sum(-1) + 1e-6
+        rep = (diff / (d2[..., None] ** 1.5)).sum(1)
+        att = -2.0 * pts  # keeps the cloud bounded
+        step = 0.02 * (rep * 0.01 + att * 0.1)
+        step[0] = 0
+        pts = pts + step
+    scale = np.linalg.norm(pts, axis=1).max()
+    return (pts * (radius / scale)).astype(np.float32)
+
+
+class PseudoGrid(_OutputTransform):
+    def __init__(self, in_channels, out_channels, radius, nsample, config):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.radius, self.nsample = radius, nsample
+        pg = config.pseudo_grid
+        self.KP_influence = pg.KP_influence
+        self.num_kernel_points = pg.num_kernel_points
+        self.convolution_mode = pg.convolution_mode
+        self.impl = _cfg(config, 'cl3d_impl', 'auto')
+        self.extent = 2 * pg.KP_extent * radius / config.density_parameter
+        k_points = make_kernel_points(1.5 * self.extent, self.num_kernel_points)
+        self.register_buffer('K_points', torch.from_numpy(k_points).type(torch.float32))
+        self.grouper = MaskedQueryAndGroup(radius, nsample, use_xyz=False, ret_grouped_xyz=True, normalize_xyz=False)
+        # truncated-normal init, std sqrt(2/C), values beyond 2 std zeroed (reference utlis.py:297-303)
+        std = math.sqrt(2.0 / in_channels)
+        w = torch.randn(self.num_kernel_points, in_channels) * std
+        w[w.abs() > 2 * std] = 0
+        self.kernel_weights = nn.Parameter(w)
+        self._make_output(in_channels, out_channels, pg.output_conv, config.bn_momentum)
+
+    def forward(self, query_xyz, support_xyz, query_mask, support_mask, support_features):
+        if self.KP_influence not in ('constant', 'linear'):
+            # 'gaussian' raises TypeError in the reference as well (utlis.py:294 calls torch.pow(float, int))
+            raise ValueError('Unknown influence function type (config.KP_influence)')
+        if self.convolution_mode != 'sum':
+            raise NotImplementedError(f"convolution_mode:{self.convolution_mode} not support in PseudoGrid")
+        from . import fused
+        if fused.use_fused(self.impl, 'pseudo_grid', self):
+            out = fused.pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, support_features,
+                                    self.radius, self.nsample, self.K_points, self.kernel_weights,
+                                    self.extent, self.KP_influence)
+            return self._output(out)
+        B, C, M = support_features.shape[0], support_features.shape[1], query_xyz.shape[1]
+        feats, rel, nmask = self.grouper(query_xyz, support_xyz, query_mask, support_mask, support_features)
+        rel = rel.permute(0, 2, 3, 1).unsqueeze(3)  # B,M,K,1,3
+        sq = ((rel - self.K_points) ** 2).sum(-1)  # B,M,K,P
+        if self.KP_influence == 'constant':
+            w = torch.ones_like(sq)
+        else:
+            w = torch.clamp(1 - torch.sqrt(sq) / self.extent, min=0.0)
+        w = w.permute(0, 1, 3, 2)  # B,M,P,K
+        feature_mask = nmask + (1 - query_mask[:, :, None])
+        w = w * feature_mask[:, :, None, :]
+        w = w.reshape(-1, self.num_kernel_points, self.nsample)
+        nf = feats.permute(0, 2, 3, 1).reshape(-1, self.nsample, C)
+        out = (torch.bmm(w, nf) * self.kernel_weights).sum(1).view(B, M, C).transpose(1, 2)
+        return self._output(out)
+
+
+class LocalAggregation(nn.Module):
+    def __init__(self, in_channels, out_channels, radius, nsample, config):
+        super().__init__()
+        kinds = {'pospool': PosPool, 'adaptive_weight': AdaptiveWeight, 'pointwisemlp': PointWiseMLP,
+                 'pseudo_grid': PseudoGrid}
+        kind = config.local_aggregation_type
+        if kind not in kinds:
+            raise NotImplementedError(f'LocalAggregation {kind} not implemented')
+        self.local_aggregation_operator = kinds[kind](in_channels, out_channels, radius, nsample, config)
+
+    def forward(self, query_xyz, support_xyz, query_mask, support_mask, support_features):
+        return self.local_aggregation_operator(query_xyz, support_xyz, query_mask, support_mask, support_features)

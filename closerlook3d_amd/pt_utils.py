@@ -1,0 +1,242 @@
+"""Grouping API of the reference (`pytorch/ops/pt_custom_ops/pt_utils.py`) on the HIP engine.
+
+Same public names, constructor arguments, forward signatures and return tuples as the reference
+module, so `models/local_aggregation_operators.py`, `models/backbones/resnet.py` and
+`models/heads/segmentation_head.py` of the reference run unchanged when this file is what
+`from pt_utils import ...` resolves to (see INTEGRATION.md and `drop_in/`).
+
+Differences that are implementation, not behaviour:
+  * `MaskedQueryAndGroup` issues one fused C-ABI call (`cl3d_group_xyz_features`) for what the
+    reference does with a transpose, two generic gathers and two in-place element-wise passes
+    (pt_utils.py:124-132);
+  * an optional per-forward ball-query memo (`ball_query_cache`) removes the identical searches the
+    reference repeats inside every strided bottleneck.
+"""
+import contextlib
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.autograd import Function
+
+from . import _ext
+
+
+# --------------------------------------------------------------------------- autograd wrappers
+class GroupingOperation(Function):
+    """features (B,C,N), idx (B,M,K) int32 -> (B,C,M,K).  Reference: pt_utils.py:16-61."""
+
+    @staticmethod
+    def forward(ctx, features, idx):
+        ctx.save_for_backward(idx)
+        ctx.n_support = features.size(2)
+        return _ext.group_points(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return _ext.group_points_grad(grad_out.contiguous(), idx, ctx.n_support), None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class MaskedOrderedBallQuery(Function):
+    """Reference: pt_utils.py:67-77.  Outputs are index tensors, non-differentiable."""
+
+    @staticmethod
+    def forward(ctx, radius, nsample, query_xyz, support_xyz, query_mask, support_mask):
+        inds, inds_mask = _ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+        ctx.mark_non_differentiable(inds, inds_mask)
+        return inds, inds_mask
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None, None, None
+
+
+masked_ordered_ball_query = MaskedOrderedBallQuery.apply
+
+
+class MaskedNearestQuery(Function):
+    """Reference: pt_utils.py:83-92."""
+
+    @staticmethod
+    def forward(ctx, query_xyz, support_xyz, query_mask, support_mask):
+        inds, inds_mask = _ext.masked_nearest_query(query_xyz, support_xyz, query_mask, support_mask)
+        ctx.mark_non_differentiable(inds, inds_mask)
+        return inds, inds_mask
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None
+
+
+masked_nearest_query = MaskedNearestQuery.apply
+
+
+class MaskedGridSubsampling(Function):
+    """Reference: pt_utils.py:98-108."""
+
+    @staticmethod
+    def forward(ctx, xyz, mask, npoint, sampleDl):
+        sub_xyz, sub_mask = _ext.masked_grid_subsampling(xyz, mask, npoint, sampleDl)
+        ctx.mark_non_differentiable(sub_xyz, sub_mask)
+        return sub_xyz, sub_mask
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None, None, None
+
+
+masked_grid_subsampling = MaskedGridSubsampling.apply
+
+
+# ----------------------------------------------------------------- per-forward ball-query memo
+_BQ_CACHE = None
+
+
+@contextlib.contextmanager
+def ball_query_cache():
+    """Within the context, ball queries with identical (tensors, radius, nsample) are computed once.
+
+    Keys hold the tensors' storage pointers *and versions*, and the cache keeps the key tensors
+    alive, so a recycled allocation can never alias a stale entry.  Meant to wrap one model forward.
+    """
+    global _BQ_CACHE
+    prev, _BQ_CACHE = _BQ_CACHE, {}
+    try:
+        yield
+    finally:
+        _BQ_CACHE = prev
+
+
+def _ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample):
+    if _BQ_CACHE is None:
+        return _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+    tensors = (query_xyz, support_xyz, query_mask, support_mask)
+    key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors) + (float(radius), int(nsample))
+    hit = _BQ_CACHE.get(key)
+    if hit is None:
+        out = _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+        hit = (out, tensors)
+        _BQ_CACHE[key] = hit
+    return hit[0]
+
+
+class _GroupXyzFeatures(Function):
+    """(rel, grouped) of MaskedQueryAndGroup in one engine call; gradient flows to `features` only
+    (coordinates are data in every caller of the reference; they never require grad there)."""
+
+    @staticmethod
+    def forward(ctx, query_xyz, support_xyz, features, idx, radius, normalize_xyz):
+        rel, grouped = _ext.group_xyz_features(query_xyz, support_xyz, features, idx, radius, normalize_xyz)
+        ctx.save_for_backward(idx)
+        ctx.n_support = support_xyz.size(1)
+        ctx.mark_non_differentiable(rel)
+        return rel, grouped
+
+    @staticmethod
+    def backward(ctx, grad_rel, grad_grouped):
+        (idx,) = ctx.saved_tensors
+        g = _ext.group_points_grad(grad_grouped.contiguous(), idx, ctx.n_support)
+        return None, None, g, None, None, None
+
+
+def _group(query_xyz, support_xyz, features, idx, radius, normalize_xyz):
+    if features is None:
+        rel, _ = _ext.group_xyz_features(query_xyz, support_xyz, None, idx, radius, normalize_xyz)
+        return rel, None
+    return _GroupXyzFeatures.apply(query_xyz, support_xyz, features.contiguous(), idx, radius, normalize_xyz)
+
+
+def _assemble(rel, grouped, use_xyz, ret_grouped_xyz, idx_mask):
+    if grouped is None:
+        assert use_xyz, "Cannot have not features and not use xyz as a feature!"
+        new_features = rel
+    elif use_xyz:
+        new_features = torch.cat([rel, grouped], dim=1)
+    else:
+        new_features = grouped
+    if ret_grouped_xyz:
+        return new_features, rel, idx_mask
+    return new_features, idx_mask
+
+
+# ------------------------------------------------------------------------------------- modules
+class MaskedQueryAndGroup(nn.Module):
+    """Ball query + grouping.  Reference: pt_utils.py:114-144."""
+
+    def __init__(self, radius, nsample, use_xyz=True, ret_grouped_xyz=False, normalize_xyz=False):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+        self.ret_grouped_xyz = ret_grouped_xyz
+        self.normalize_xyz = normalize_xyz
+
+    def forward(self, query_xyz, support_xyz, query_mask, support_mask, features=None):
+        idx, idx_mask = masked_ordered_ball_query(self.radius, self.nsample, query_xyz, support_xyz,
+                                                  query_mask, support_mask)
+        rel, grouped = _group(query_xyz, support_xyz, features, idx, self.radius, self.normalize_xyz)
+        return _assemble(rel, grouped, self.use_xyz, self.ret_grouped_xyz, idx_mask)
+
+
+class MaskedNearestQueryAndGroup(nn.Module):
+    """1-NN query + grouping.  Reference: pt_utils.py:147-176 (its normalize_xyz=True branch reads an
+    attribute that does not exist there and is never enabled; rejected here at construction)."""
+
+    def __init__(self, use_xyz=True, ret_grouped_xyz=False, normalize_xyz=False):
+        super().__init__()
+        if normalize_xyz:
+            raise AttributeError("'MaskedNearestQueryAndGroup' object has no attribute 'radius'")
+        self.use_xyz = use_xyz
+        self.ret_grouped_xyz = ret_grouped_xyz
+        self.normalize_xyz = normalize_xyz
+
+    def forward(self, query_xyz, support_xyz, query_mask, support_mask, features=None):
+        idx, idx_mask = masked_nearest_query(query_xyz, support_xyz, query_mask, support_mask)
+        rel, grouped = _group(query_xyz, support_xyz, features, idx, 1.0, False)
+        return _assemble(rel, grouped, self.use_xyz, self.ret_grouped_xyz, idx_mask)
+
+
+class MaskedMaxPool(nn.Module):
+    """Grid subsample, then max over each sub-point's ball.  Reference: pt_utils.py:179-202."""
+
+    def __init__(self, npoint, radius, nsample, sampleDl):
+        super().__init__()
+        self.npoint = npoint
+        self.radius = radius
+        self.nsample = nsample
+        self.sampleDl = sampleDl
+        self.grouper = MaskedQueryAndGroup(radius, nsample, use_xyz=False, ret_grouped_xyz=True)
+
+    def forward(self, xyz, mask, features):
+        sub_xyz, sub_mask = masked_grid_subsampling(xyz, mask, self.npoint, self.sampleDl)
+        sub_xyz = sub_xyz.contiguous()
+        sub_mask = sub_mask.contiguous()
+        neighborhood_features, _, _ = self.grouper(sub_xyz, xyz, sub_mask, mask, features)
+        # max_pool2d, not amax: on ties its backward routes the gradient to the first maximum, as the
+        # reference does; amax would split it evenly (ties are common: ReLU zeros, wrap-around padding)
+        sub_features = F.max_pool2d(neighborhood_features, kernel_size=[1, neighborhood_features.shape[3]]).squeeze(-1)
+        return sub_xyz, sub_mask, sub_features
+
+
+class MaskedUpsample(nn.Module):
+    """Feature up-sampling to a denser level.  Reference: pt_utils.py:205-227."""
+
+    def __init__(self, radius, nsample, mode='nearest'):
+        super().__init__()
+        self.radius = radius
+        self.nsample = nsample
+        self.mode = mode
+        if mode == 'nearest':
+            self.grouper = MaskedNearestQueryAndGroup(use_xyz=False, ret_grouped_xyz=True)
+        else:
+            self.grouper = MaskedQueryAndGroup(radius, nsample, use_xyz=False, ret_grouped_xyz=True)
+
+    def forward(self, up_xyz, xyz, up_mask, mask, features):
+        neighborhood_features, _, _ = self.grouper(up_xyz, xyz, up_mask, mask, features)
+        if self.mode == 'nearest':
+            return neighborhood_features[..., 0].contiguous()
+        if self.mode == 'max':
+            return F.max_pool2d(neighborhood_features, kernel_size=[1, neighborhood_features.shape[3]]).squeeze(-1)
+        raise NotImplementedError(f"mode:{self.mode} not supported in MaskedUpsample")

@@ -1,0 +1,307 @@
+/*
+ * cl3d_oracle.c -- TEST INFRASTRUCTURE ONLY (never imported by the product path).
+ *
+ * Plain-C, single-threaded-per-cloud CPU restatement of the five native ops of
+ * zeliu98/CloserLook3D's `pt_custom_ops._ext`.  Every function follows the
+ * reference kernel it names, statement for statement in *meaning* (same scan
+ * order, same candidate cap, same stable sorts, same float operations in the
+ * same order) but is written from scratch as ordinary host C.
+ *
+ * Pinning: the reference has no tests and no CPU path.  This
+ * restatement is pinned against the reference's *own* kernels compiled for
+ * gfx950 (oracle/build_ref.py -> oracle/_ref/ref_ext.so) on the MI355X box:
+ * tests/test_ref_pin_gpu.py compares them bit for bit, and
+ * tests/golden/native_*.npz holds vectors produced by that reference build
+ * (tests/golden/make_native_golden.py).
+ *
+ * Floating-point canon.  The reference writes
+ *     d2 = (qx-x)*(qx-x) + (qy-y)*(qy-y) + (qz-z)*(qz-z)
+ * and lets the device compiler contract it.  hipcc 7.2 -O2 for gfx950 emits
+ *     d2 = fadd( fma(dy,dy, fmul(dx,dx)), fmul(dz,dz) )
+ * for both kernels that contain it (checked in the ISA of the reference build).
+ * That form is the canon here and in the HIP engine; CL3D_D2_FORM selects the
+ * two other plausible contractions for maintainers on a different compiler.
+ * Everything else in the path (floor, divide, sequential sums) has no
+ * contraction freedom; plain IEEE float operations are used as written.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef CL3D_D2_FORM
+#define CL3D_D2_FORM 0
+#endif
+
+static inline float oracle_d2(float qx, float qy, float qz, float x, float y, float z) {
+  volatile float dx = qx - x, dy = qy - y, dz = qz - z;
+#if CL3D_D2_FORM == 0 /* hipcc/gfx950 build of the reference */
+  volatile float xx = dx * dx;
+  volatile float zz = dz * dz;
+  volatile float t = fmaf(dy, dy, xx);
+  volatile float r = t + zz;
+  return r;
+#elif CL3D_D2_FORM == 1 /* no contraction at all */
+  volatile float xx = dx * dx;
+  volatile float yy = dy * dy;
+  volatile float zz = dz * dz;
+  volatile float t = xx + yy;
+  volatile float r = t + zz;
+  return r;
+#else /* full left-to-right fma chain */
+  volatile float xx = dx * dx;
+  volatile float t = fmaf(dy, dy, xx);
+  volatile float r = fmaf(dz, dz, t);
+  return r;
+#endif
+}
+
+/* stable insertion sort of (key,val) pairs by key: the reference calls
+ * thrust::sort_by_key from inside a device thread, which is Thrust's
+ * sequential *stable* sort (masked_ordered_ball_query_gpu.cu:77,
+ * masked_grid_subsampling_gpu.cu:77,135). */
+static void stable_sort_f32_i32(float *key, int *val, int n) {
+  for (int i = 1; i < n; ++i) {
+    float k = key[i];
+    int v = val[i];
+    int j = i - 1;
+    while (j >= 0 && key[j] > k) {
+      key[j + 1] = key[j];
+      val[j + 1] = val[j];
+      --j;
+    }
+    key[j + 1] = k;
+    val[j + 1] = v;
+  }
+}
+
+typedef struct { int key; int val; } kv_i32;
+
+static void merge_sort_kv(kv_i32 *a, kv_i32 *tmp, int n) {
+  /* bottom-up stable merge sort on int keys */
+  for (int w = 1; w < n; w <<= 1) {
+    for (int lo = 0; lo < n; lo += 2 * w) {
+      int mid = lo + w < n ? lo + w : n;
+      int hi = lo + 2 * w < n ? lo + 2 * w : n;
+      int i = lo, j = mid, o = lo;
+      while (i < mid && j < hi) tmp[o++] = (a[j].key < a[i].key) ? a[j++] : a[i++];
+      while (i < mid) tmp[o++] = a[i++];
+      while (j < hi) tmp[o++] = a[j++];
+    }
+    memcpy(a, tmp, (size_t)n * sizeof(kv_i32));
+  }
+}
+
+/* -------------------------------------------------------------------------
+ * masked_ordered_ball_query  (reference: masked_ordered_ball_query_gpu.cu:11-96,
+ * host wrapper masked_ordered_ball_query.cpp:13-59 zero-fills idx/idx_mask and
+ * the two [.,.,3*nsample] scratch arrays).
+ * cnt == 0 is undefined in the reference (i % 0); this restatement leaves
+ * idx = 0, idx_mask = 0 for such a query, which is what the zero-filled scratch
+ * yields for any finite remainder.
+ * ------------------------------------------------------------------------- */
+int oracle_masked_ordered_ball_query(const float *query_xyz, const float *support_xyz,
+                                     const int *query_mask, const int *support_mask,
+                                     int B, int M, int N, float radius, int nsample,
+                                     int *idx, int *idx_mask) {
+  const int cap = 3 * nsample;
+  float *dists = (float *)malloc(sizeof(float) * (size_t)(cap > 0 ? cap : 1));
+  int *cand = (int *)malloc(sizeof(int) * (size_t)(cap > 0 ? cap : 1));
+  if (!dists || !cand) return -1;
+  volatile float r2v = radius * radius;
+  const float radius2 = r2v;
+  for (int b = 0; b < B; ++b) {
+    const float *q = query_xyz + (size_t)b * M * 3;
+    const float *s = support_xyz + (size_t)b * N * 3;
+    const int *qm = query_mask + (size_t)b * M;
+    const int *sm = support_mask + (size_t)b * N;
+    int *oi = idx + (size_t)b * M * nsample;
+    int *om = idx_mask + (size_t)b * M * nsample;
+    for (int j = 0; j < M; ++j) {
+      const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
+      int cnt = 0;
+      float min_dist = radius2;
+      int min_idx = 0;
+      memset(dists, 0, sizeof(float) * (size_t)cap);
+      memset(cand, 0, sizeof(int) * (size_t)cap);
+      for (int k = 0; k < N; ++k) {
+        if (sm[k] == 0) break;
+        float d2 = oracle_d2(qx, qy, qz, s[k * 3 + 0], s[k * 3 + 1], s[k * 3 + 2]);
+        if (d2 < radius2) {
+          if (d2 < min_dist) { min_dist = d2; min_idx = k; }
+          if (cnt >= cap) continue;
+          dists[cnt] = d2;
+          cand[cnt] = k;
+          cnt++;
+        }
+      }
+      if (cnt >= cap && cap > 0 && min_idx > cand[cnt - 1]) {
+        cand[cnt - 1] = min_idx;
+        dists[cnt - 1] = min_dist;
+      }
+      stable_sort_f32_i32(dists, cand, cnt);
+      for (int i = 0; i < cnt && i < nsample; ++i) {
+        oi[j * nsample + i] = cand[i];
+        om[j * nsample + i] = 1;
+      }
+      for (int i = cnt; i < nsample; ++i) {
+        oi[j * nsample + i] = cnt > 0 ? cand[i % cnt] : 0;
+        om[j * nsample + i] = 0;
+      }
+      if (qm[j] == 0)
+        for (int l = 0; l < nsample; ++l) om[j * nsample + l] = 0;
+    }
+  }
+  free(dists);
+  free(cand);
+  return 0;
+}
+
+/* group_points (reference: group_points_gpu.cu:13-33) */
+int oracle_group_points(const float *points, const int *idx, int B, int C, int N, int M, int K,
+                        float *out) {
+  for (int b = 0; b < B; ++b)
+    for (int l = 0; l < C; ++l)
+      for (int j = 0; j < M; ++j)
+        for (int k = 0; k < K; ++k) {
+          int ii = idx[((size_t)b * M + j) * K + k];
+          out[(((size_t)b * C + l) * M + j) * K + k] = points[((size_t)b * C + l) * N + ii];
+        }
+  return 0;
+}
+
+/* group_points_grad (reference: group_points_gpu.cu:48-69; float atomicAdd there, so the
+ * summation order is undefined -- this restatement accumulates in double and rounds once,
+ * which is the tightest statement of "the sum"; parity tolerance 1e-5). */
+int oracle_group_points_grad(const float *grad_out, const int *idx, int B, int C, int N, int M,
+                             int K, float *grad_points) {
+  double *acc = (double *)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1));
+  if (!acc) return -1;
+  for (int b = 0; b < B; ++b)
+    for (int l = 0; l < C; ++l) {
+      memset(acc, 0, sizeof(double) * (size_t)N);
+      for (int j = 0; j < M; ++j)
+        for (int k = 0; k < K; ++k) {
+          int ii = idx[((size_t)b * M + j) * K + k];
+          acc[ii] += (double)grad_out[(((size_t)b * C + l) * M + j) * K + k];
+        }
+      for (int i = 0; i < N; ++i) grad_points[((size_t)b * C + l) * N + i] = (float)acc[i];
+    }
+  free(acc);
+  return 0;
+}
+
+/* -------------------------------------------------------------------------
+ * masked_grid_subsampling (reference: masked_grid_subsampling_gpu.cu:11-153).
+ * All float arithmetic is single precision (the device overload of floor is
+ * floorf).  nsub == 0 valid points: the reference then reads its zero-filled
+ * scratch, i.e. behaves as one cell {point 0}; restated the same way.
+ * ------------------------------------------------------------------------- */
+int oracle_masked_grid_subsampling(const float *xyz, const int *mask, int B, int N, int m,
+                                   float sampleDl, float *sub_xyz, int *sub_mask) {
+  kv_i32 *kv = (kv_i32 *)malloc(sizeof(kv_i32) * (size_t)(N > 0 ? N : 1));
+  kv_i32 *tmp = (kv_i32 *)malloc(sizeof(kv_i32) * (size_t)(N > 0 ? N : 1));
+  float *cell_xyz = (float *)malloc(sizeof(float) * 3 * (size_t)(N > 0 ? N : 1));
+  if (!kv || !tmp || !cell_xyz) return -1;
+  for (int b = 0; b < B; ++b) {
+    const float *p = xyz + (size_t)b * N * 3;
+    const int *mk = mask + (size_t)b * N;
+    float *o = sub_xyz + (size_t)b * m * 3;
+    int *om = sub_mask + (size_t)b * m;
+    float minx = p[0], miny = p[1], minz = p[2], maxx = p[0], maxy = p[1], maxz = p[2];
+    for (int i = 1; i < N; ++i) { /* bbox over ALL n points, padded ones included (:31-46) */
+      float x = p[i * 3], y = p[i * 3 + 1], z = p[i * 3 + 2];
+      if (x > maxx) maxx = x;
+      if (y > maxy) maxy = y;
+      if (z > maxz) maxz = z;
+      if (x < minx) minx = x;
+      if (y < miny) miny = y;
+      if (z < minz) minz = z;
+    }
+    volatile float inv = 1.0f / sampleDl;
+    volatile float tx = minx * inv, ty = miny * inv, tz = minz * inv;
+    volatile float ox = floorf(tx) * sampleDl, oy = floorf(ty) * sampleDl, oz = floorf(tz) * sampleDl;
+    volatile float ex = (maxx - ox) / sampleDl, ey = (maxy - oy) / sampleDl;
+    int NX = (int)floorf(ex) + 1;
+    int NY = (int)floorf(ey) + 1;
+    int nv = 0;
+    for (int i = 0; i < N; ++i) {
+      if (mk[i] == 0) break;
+      volatile float fx = (p[i * 3] - ox) / sampleDl;
+      volatile float fy = (p[i * 3 + 1] - oy) / sampleDl;
+      volatile float fz = (p[i * 3 + 2] - oz) / sampleDl;
+      int iX = (int)floorf(fx), iY = (int)floorf(fy), iZ = (int)floorf(fz);
+      kv[i].key = iX + NX * iY + NX * NY * iZ;
+      kv[i].val = i;
+      nv++;
+    }
+    if (nv == 0) { kv[0].key = 0; kv[0].val = 0; }
+    merge_sort_kv(kv, tmp, nv);
+    /* sequential barycentres in (cell, original index) order (:84-122) */
+    int top = 0;
+    {
+      int cur = kv[0].key;
+      int j = kv[0].val;
+      volatile float xs = p[j * 3], ys = p[j * 3 + 1], zs = p[j * 3 + 2];
+      float pnum = 1;
+      for (int i = 1; i < nv; ++i) {
+        j = kv[i].val;
+        if (kv[i].key == cur) {
+          xs += p[j * 3]; ys += p[j * 3 + 1]; zs += p[j * 3 + 2];
+          pnum += 1;
+        } else {
+          cell_xyz[top * 3] = xs / pnum; cell_xyz[top * 3 + 1] = ys / pnum; cell_xyz[top * 3 + 2] = zs / pnum;
+          top++;
+          xs = p[j * 3]; ys = p[j * 3 + 1]; zs = p[j * 3 + 2];
+          pnum = 1;
+          cur = kv[i].key;
+        }
+      }
+      cell_xyz[top * 3] = xs / pnum; cell_xyz[top * 3 + 1] = ys / pnum; cell_xyz[top * 3 + 2] = zs / pnum;
+      top++;
+    }
+    const int end = top;
+    /* LCG shuffle keys + stable sort (:125-135) */
+    kv[0].key = kv[0].key % 256;
+    kv[0].val = 0;
+    for (int i = 1; i < end; ++i) {
+      kv[i].key = (17 * kv[i - 1].key + 139) % 256;
+      kv[i].val = i;
+    }
+    merge_sort_kv(kv, tmp, end);
+    for (int i = 0; i < end && i < m; ++i) {
+      int j = kv[i].val;
+      o[i * 3] = cell_xyz[j * 3]; o[i * 3 + 1] = cell_xyz[j * 3 + 1]; o[i * 3 + 2] = cell_xyz[j * 3 + 2];
+      om[i] = 1;
+    }
+    for (int i = end; i < m; ++i) {
+      o[i * 3] = o[(i % end) * 3]; o[i * 3 + 1] = o[(i % end) * 3 + 1]; o[i * 3 + 2] = o[(i % end) * 3 + 2];
+      om[i] = 0;
+    }
+  }
+  free(kv); free(tmp); free(cell_xyz);
+  return 0;
+}
+
+/* masked_nearest_query (reference: masked_nearest_query_gpu.cu:8-62) */
+int oracle_masked_nearest_query(const float *query_xyz, const float *support_xyz,
+                                const int *query_mask, const int *support_mask, int B, int M, int N,
+                                int *idx, int *idx_mask) {
+  for (int b = 0; b < B; ++b) {
+    const float *q = query_xyz + (size_t)b * M * 3;
+    const float *s = support_xyz + (size_t)b * N * 3;
+    const int *sm = support_mask + (size_t)b * N;
+    for (int j = 0; j < M; ++j) {
+      float min_dist = 100;
+      int min_idx = -1;
+      for (int k = 0; k < N; ++k) {
+        if (sm[k] == 0) break;
+        float d2 = oracle_d2(q[j * 3], q[j * 3 + 1], q[j * 3 + 2], s[k * 3], s[k * 3 + 1], s[k * 3 + 2]);
+        if (d2 < min_dist) { min_dist = d2; min_idx = k; }
+      }
+      idx[(size_t)b * M + j] = min_idx;
+      idx_mask[(size_t)b * M + j] = query_mask[(size_t)b * M + j] == 0 ? 0 : 1;
+    }
+  }
+  return 0;
+}
