@@ -1,0 +1,99 @@
+"""CPU: the C-ABI library builds, loads, and exports every symbol include/cl3d.h declares; the Python
+binding table covers the header; the product never imports the oracle; missing library fails loudly."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "cl3d.h")
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cl3d_[a-z0-9_]+)\s*\(", src)) - {"cl3d_stream_t"})
+
+
+@pytest.fixture(scope="module")
+def libpath():
+    from closerlook3d_amd import build
+    return build.build()
+
+
+def test_header_symbols_exported(libpath):
+    names = _declared()
+    assert "cl3d_masked_ordered_ball_query" in names and len(names) >= 9
+    out = subprocess.check_output(["nm", "-D", "--defined-only", libpath]).decode()
+    exported = set(re.findall(r" T (cl3d_[a-z0-9_]+)", out))
+    missing = [n for n in names if n not in exported]
+    assert not missing, f"declared in cl3d.h but not exported: {missing}"
+    undeclared = sorted(exported - set(names))
+    assert not undeclared, f"exported but not declared in cl3d.h: {undeclared}"
+
+
+def test_library_loads_and_reports_version(libpath):
+    import torch  # noqa: F401  (binds the HIP runtime first, as the product does)
+    h = ctypes.CDLL(libpath)
+    assert h.cl3d_abi_version() == 1
+    h.cl3d_last_error_string.restype = ctypes.c_char_p
+    assert isinstance(h.cl3d_last_error_string(), bytes)
+    h.cl3d_workspace_bytes.restype = ctypes.c_size_t
+    assert h.cl3d_workspace_bytes(1, 16, 4096, 4096, 32, 64) >= 0
+
+
+def test_invalid_arguments_return_codes_not_exit(libpath):
+    """Bad sizes / null pointers come back as negative codes with a message (the reference exit(-1)s)."""
+    import torch  # noqa: F401
+    from closerlook3d_amd import _lib
+    h = _lib.lib()
+    rc = h.cl3d_group_points(None, None, 1, 4, 16, 8, 2, None, None)
+    assert rc == -1 and b"null" in h.cl3d_last_error_string()
+    rc = h.cl3d_masked_ordered_ball_query(None, None, None, None, 1, 8, 0, 0.1, 4, None, None, None, 0, None)
+    assert rc == -1 and b"bad sizes" in h.cl3d_last_error_string()
+    # empty problems are fine and touch nothing
+    assert h.cl3d_group_points(None, None, 0, 4, 16, 8, 2, None, None) == 0
+
+
+def test_python_binding_table_covers_header():
+    from closerlook3d_amd import _lib
+    names = set(_declared()) - {"cl3d_abi_version", "cl3d_last_error_string", "cl3d_workspace_bytes"}
+    assert names == set(_lib.SIGNATURES), (names ^ set(_lib.SIGNATURES))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "closerlook3d_amd")
+    bad = []
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "libcl3d_oracle" in text:
+                    bad.append(os.path.join(dirpath, f))
+    for f in ("drop_in/pt_utils.py", "drop_in/pt_custom_ops/_ext.py"):
+        text = open(os.path.join(ROOT, f)).read()
+        if re.search(r"\boracle\b", text):
+            bad.append(f)
+    assert not bad, f"product files reference the oracle: {bad}"
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    from closerlook3d_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_PATH", str(tmp_path / "libcl3d.so"))
+    with pytest.raises(ImportError, match="not built"):
+        _lib.lib()
+
+
+def test_cpu_tensors_rejected_like_the_reference():
+    import torch
+    from closerlook3d_amd import _ext
+    x = torch.rand(1, 8, 3)
+    m = torch.ones(1, 8, dtype=torch.int32)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        _ext.masked_ordered_ball_query(x, x, m, m, 0.1, 4)
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        _ext.group_points(torch.rand(1, 2, 8), torch.zeros(1, 2, 2, dtype=torch.int32))

@@ -1,0 +1,77 @@
+"""CPU, world_size 2 over gloo: the data-parallel harness (closerlook3d_amd/dp.py) -- shard ranges and
+gradient averaging (bucketed/overlapped and one-shot) equal the single-process mean of per-shard
+gradients.  The model is a small stand-in: dp.py is independent of what produces the gradients."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from closerlook3d_amd.dp import GradientSynchronizer, allreduce_gradients, shard_range
+
+
+def test_shard_range_partitions():
+    for n in (0, 1, 7, 16, 33):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Conv1d(6, 16, 1, bias=False), torch.nn.BatchNorm1d(16), torch.nn.ReLU(),
+                               torch.nn.Conv1d(16, 4, 1))
+
+
+def _batch():
+    g = torch.Generator().manual_seed(1)
+    return torch.randn(8, 6, 32, generator=g)
+
+
+def _worker(rank, world, port, mode, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _model()
+        lo, hi = shard_range(8, rank, world)
+        x = _batch()[lo:hi]
+        params = list(model.parameters())
+        if mode == "bucketed":
+            sync = GradientSynchronizer(params, world, bucket_bytes=256)  # several tiny buckets
+            model(x).square().sum().backward()
+            sync.finish()
+            model.zero_grad()
+            model(x).square().sum().backward()  # second step reuses the buckets
+            sync.finish()
+        else:
+            model(x).square().sum().backward()
+            allreduce_gradients(params, world)
+        if rank == 0:
+            torch.save([p.grad.clone() for p in params], out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["bucketed", "oneshot"])
+def test_gradient_mean_world2(tmp_path, mode):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "grads.pt")
+    mp.spawn(_worker, args=(2, port, mode, out), nprocs=2, join=True)
+    got = torch.load(out)
+    want = None
+    for r in range(2):
+        model = _model()
+        lo, hi = shard_range(8, r, 2)
+        model(_batch()[lo:hi]).square().sum().backward()
+        g = [p.grad for p in model.parameters()]
+        want = g if want is None else [a + b for a, b in zip(want, g)]
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b / 2, atol=1e-6, rtol=1e-5)

@@ -1,0 +1,196 @@
+"""GPU parity of the five native ops: HIP engine (through the C ABI) vs the CPU oracle, bit for bit
+for indices / masks / subsampled coordinates / gathered values, 1e-5 for the scatter-add."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import native as on
+from oracle import operators as oo
+from tests.helpers import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(*arrs):
+    return [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in arrs]
+
+
+def _radius(N, K, mult):
+    return float((mult * K * 3 / (4 * np.pi * N)) ** (1 / 3))
+
+
+BQ_CASES = [
+    # B, N, M(None=N), K, mult (mean in-radius count / K), cloud kind, pad fraction
+    (2, 256, None, 16, 1.5, "uniform", 0.0),
+    (2, 1024, None, 16, 1.5, "uniform", 0.1),
+    (3, 1000, None, 20, 4.0, "uniform", 0.1),       # dense: cnt >= 3K, patch-up branch
+    (2, 2048, None, 32, 4.0, "planes", 0.1),
+    (2, 4096, None, 32, 1.5, "uniform", 0.0),       # the metric shape (per cloud)
+    (1, 4096, None, 32, 6.0, "planes", 0.25),
+    (2, 777, 130, 7, 2.0, "uniform", 0.3),          # ragged sizes, M != N
+    (1, 64, 5, 3, 8.0, "uniform", 0.0),             # tiny M -> small-QW kernel
+    (2, 512, None, 42, 1.0, "uniform", 0.0),        # largest nsample in the reference cfgs
+    (1, 300, None, 100, 0.5, "uniform", 0.0),       # K large -> QW=1 kernel, heavy wrap padding
+]
+
+
+@pytest.mark.parametrize("B,N,M,K,mult,kind,pad", BQ_CASES)
+def test_ball_query_bit_exact(B, N, M, K, mult, kind, pad):
+    from closerlook3d_amd import _ext
+    rng = np.random.default_rng(hash((B, N, K)) % 2**32)
+    s, sm = oo.make_cloud(rng, B, N, kind=kind, pad_frac=pad)
+    if M is None:
+        q, qm = s, sm
+    else:
+        sel = rng.integers(0, N, (B, M))
+        q = np.take_along_axis(s, sel[..., None], 1) + 0.003 * rng.standard_normal((B, M, 3)).astype(np.float32)
+        q = q.astype(np.float32)
+        qm = np.ones((B, M), np.int32)
+        qm[:, M - M // 4:] = 0
+    r = _radius(N, K, mult)
+    want_idx, want_msk = on.masked_ordered_ball_query(q, s, qm, sm, r, K)
+    got_idx, got_msk = _ext.masked_ordered_ball_query(*_dev(q, s, qm, sm), r, K)
+    assert np.array_equal(got_idx.cpu().numpy(), want_idx)
+    assert np.array_equal(got_msk.cpu().numpy(), want_msk)
+
+
+def test_ball_query_ties_and_duplicates():
+    """Exact distance ties (lattice), duplicated points and an all-duplicates cloud: stable order."""
+    from closerlook3d_amd import _ext
+    g = np.stack(np.meshgrid(*[np.arange(8)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * 0.125
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(g))
+    s = np.stack([g[perm], np.concatenate([g[:256], g[:256]])], 0)  # cloud 1: every point twice
+    sm = np.ones(s.shape[:2], np.int32)
+    for r, K in ((0.13, 8), (0.26, 16), (0.5, 10)):
+        want = on.masked_ordered_ball_query(s, s, sm, sm, r, K)
+        got = _ext.masked_ordered_ball_query(*_dev(s, s, sm, sm), r, K)
+        assert np.array_equal(got[0].cpu().numpy(), want[0])
+        assert np.array_equal(got[1].cpu().numpy(), want[1])
+
+
+def test_ball_query_empty_neighbourhoods_and_masks():
+    """cnt == 0 (undefined in the reference) -> idx 0 / mask 0 here and in the oracle; first-zero rule."""
+    from closerlook3d_amd import _ext
+    rng = np.random.default_rng(9)
+    s = rng.random((2, 200, 3), dtype=np.float32)
+    q = s[:, :50] + 5.0  # far away: nothing in radius
+    sm = np.ones((2, 200), np.int32)
+    sm[0, 120] = 0  # first zero cuts the scan even though later entries are 1
+    sm[1, :] = 0    # no valid support at all
+    qm = np.ones((2, 50), np.int32)
+    for qq in (q, s[:, :50].copy()):
+        want = on.masked_ordered_ball_query(qq, s, qm, sm, 0.2, 8)
+        got = _ext.masked_ordered_ball_query(*_dev(qq, s, qm, sm), 0.2, 8)
+        assert np.array_equal(got[0].cpu().numpy(), want[0])
+        assert np.array_equal(got[1].cpu().numpy(), want[1])
+
+
+@pytest.mark.parametrize("B,N,M", [(2, 256, 100), (2, 4096, 1024), (1, 777, 3), (3, 64, 640)])
+def test_nearest_query_bit_exact(B, N, M):
+    from closerlook3d_amd import _ext
+    rng = np.random.default_rng(N + M)
+    s, sm = oo.make_cloud(rng, B, N, pad_frac=0.2)
+    q = rng.random((B, M, 3), dtype=np.float32)
+    qm = (rng.random((B, M)) > 0.2).astype(np.int32)
+    if B > 1:
+        sm[-1, :] = 0  # no valid support: idx must be -1
+    q[0, 0] = 50.0     # farther than sqrt(100) from everything: idx -1
+    want = on.masked_nearest_query(q, s, qm, sm)
+    got = _ext.masked_nearest_query(*_dev(q, s, qm, sm))
+    assert np.array_equal(got[0].cpu().numpy(), want[0])
+    assert np.array_equal(got[1].cpu().numpy(), want[1])
+
+
+SUB_CASES = [
+    # B, N, m, dl, kind, pad
+    (2, 256, 64, 0.12, "uniform", 0.25),     # end > m: truncation
+    (2, 1024, 1024, 0.2, "uniform", 0.1),    # end < m: wrap padding
+    (3, 4096, 1024, 0.04, "uniform", 0.0),   # ModelNet stage 1 shape
+    (2, 4096, 1024, 0.08, "planes", 0.1),
+    (1, 1000, 300, 0.03, "uniform", 0.0),    # nearly one point per cell, > 256 cells (LCG period)
+    (1, 5000, 700, 0.05, "planes", 0.3),     # N not a power of two, > 4096 (LDS opt-in path)
+    (1, 15000, 4000, 0.04, "uniform", 0.05), # S3DIS crop size
+    (2, 17, 5, 0.5, "uniform", 0.0),
+]
+
+
+@pytest.mark.parametrize("B,N,m,dl,kind,pad", SUB_CASES)
+def test_grid_subsampling_bit_exact(B, N, m, dl, kind, pad):
+    from closerlook3d_amd import _ext
+    rng = np.random.default_rng(N * 7 + m)
+    xyz, mask = oo.make_cloud(rng, B, N, kind=kind, pad_frac=pad)
+    xyz = (xyz * 1.7 - 0.6).astype(np.float32)  # negative coordinates too
+    want = on.masked_grid_subsampling(xyz, mask, m, dl)
+    got = _ext.masked_grid_subsampling(*_dev(xyz, mask), m, dl)
+    assert np.array_equal(got[1].cpu().numpy(), want[1])
+    assert np.array_equal(got[0].cpu().numpy().view(np.uint32), want[0].view(np.uint32))
+
+
+def test_grid_subsampling_degenerate():
+    from closerlook3d_amd import _ext
+    rng = np.random.default_rng(3)
+    xyz = rng.random((3, 128, 3), dtype=np.float32)
+    mask = np.ones((3, 128), np.int32)
+    mask[0, :] = 0          # no valid point: the reference yields one cell {point 0}
+    xyz[1, :] = xyz[1, 0]   # all points identical: one cell
+    mask[2, 1:] = 0         # a single valid point
+    want = on.masked_grid_subsampling(xyz, mask, 16, 0.1)
+    got = _ext.masked_grid_subsampling(*_dev(xyz, mask), 16, 0.1)
+    assert np.array_equal(got[1].cpu().numpy(), want[1])
+    assert np.array_equal(got[0].cpu().numpy().view(np.uint32), want[0].view(np.uint32))
+
+
+GROUP_CASES = [(2, 3, 256, 256, 16), (2, 64, 4096, 4096, 32), (1, 72, 1024, 256, 16), (2, 5, 300, 77, 7),
+               (1, 8, 20000, 512, 9), (3, 1, 64, 64, 1)]
+
+
+@pytest.mark.parametrize("B,C,N,M,K", GROUP_CASES)
+def test_group_points_fwd_bwd(B, C, N, M, K):
+    from closerlook3d_amd import _ext
+    rng = np.random.default_rng(B * 1000 + C)
+    f = rng.standard_normal((B, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, (B, M, K)).astype(np.int32)
+    idx[:, :, K // 2:] = idx[:, :, :1]  # heavy collisions, like wrap-around padding
+    want = on.group_points(f, idx)
+    got = _ext.group_points(*_dev(f, idx))
+    assert np.array_equal(got.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    g = rng.standard_normal((B, C, M, K)).astype(np.float32)
+    want_g = on.group_points_grad(g, idx, N)
+    d = _dev(g, idx)
+    got_g = _ext.group_points_grad(d[0], d[1], N)
+    assert_close(got_g.cpu().numpy(), want_g, 1e-5, "group_points_grad")
+    again = _ext.group_points_grad(d[0], d[1], N)
+    assert torch.equal(got_g, again), "scatter-add must be repeatable run to run"
+
+
+def test_group_xyz_features_matches_reference_dataflow():
+    from closerlook3d_amd import _ext
+    rng = np.random.default_rng(11)
+    B, N, M, K, C = 2, 512, 200, 16, 12
+    s, sm = oo.make_cloud(rng, B, N, pad_frac=0.1)
+    q = s[:, :M].copy()
+    qm = np.ones((B, M), np.int32)
+    f = rng.standard_normal((B, C, N)).astype(np.float32)
+    r = 0.2
+    for normalize in (True, False):
+        g, rel, m, idx = oo.query_and_group(*[torch.from_numpy(a) for a in (q, s, qm, sm, f)], r, K, normalize)
+        dq, ds, df, di = _dev(q, s, f, idx.numpy())
+        rel_g, grp_g = _ext.group_xyz_features(dq, ds, df, di, r, normalize)
+        assert np.array_equal(grp_g.cpu().numpy().view(np.uint32), g.numpy().view(np.uint32))
+        assert_close(rel_g.cpu().numpy(), rel.numpy(), 1e-6, "relative position")
+
+
+def test_error_behaviour_matches_reference():
+    """dtype / contiguity / device errors are RuntimeError as in the reference's CHECK_* macros."""
+    from closerlook3d_amd import _ext
+    x = torch.rand(1, 8, 3, device="cuda")
+    m = torch.ones(1, 8, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="must be a contiguous tensor"):
+        _ext.masked_ordered_ball_query(x.transpose(1, 2).transpose(1, 2)[:, ::2], x, m[:, ::2], m, 0.1, 4)
+    with pytest.raises(RuntimeError, match="must be an int tensor"):
+        _ext.masked_ordered_ball_query(x, x, m.float(), m, 0.1, 4)
+    with pytest.raises(RuntimeError, match="must be a float tensor"):
+        _ext.group_points(x.double(), torch.zeros(1, 2, 2, dtype=torch.int32, device="cuda"))
+    with pytest.raises(RuntimeError, match="CPU not supported"):
+        _ext.masked_nearest_query(x.cpu(), x.cpu(), m.cpu(), m.cpu())
