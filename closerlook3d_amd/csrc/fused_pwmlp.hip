@@ -1,0 +1,473 @@
+// fused_pwmlp.hip -- PointWiseMLP ('dp_fi_df', one conv+BN+ReLU layer, max reduction) for gfx950.
+//
+// Reference (models/local_aggregation_operators.py:288-301): gather [B,C,M,K], build
+// x = cat[rel(3), f_centre(C), f_nbr - f_centre(C)] (68.7 MB per cloud at the metric shape), 1x1
+// Conv2d (131 -> C_out) over all B*M*K positions (2.2 GFLOP per cloud), BatchNorm2d, ReLU, max over K.
+//
+// The contraction is linear, so it factors through the points instead of the (point, neighbour) pairs:
+//     W x = W_r rel + (W_c - W_d) f_centre + W_d f_nbr
+// With G = W_d F and H = (W_c - W_d) F computed ONCE PER POINT (a plain [B*N, C] x [C, 2*C_out] GEMM,
+// K times fewer flops than the reference's contraction; done by the caller with a library GEMM so
+// autograd also provides dF and dW from dG, dH), every pre-activation is
+//     y[b,o,j,k] = W_r[o,:] . rel[b,j,k] + H[b, idx[b,j,0], o] + G[b, idx[b,j,k], o]
+// i.e. one point-major row gather + 3 FMAs.  `ght` is [B, N, 2*C_out]: row i = [G_i | H_i].
+//
+// Passes (all recompute y from rows; nothing of size B*C*M*K is ever stored):
+//   STATS      sum y, sum y^2 per channel (double partials)          -> batch mean / variance
+//   FWD        z = y*scale + shift, ReLU, max over k with first arg-max -> out_t [B,M,Co], kstar_t (uint8)
+//   BWD_SPARSE dz at the arg-max only (ReLU + max route the gradient to one slot per (b,o,j));
+//              d beta = sum dz, d gamma = sum dz * xhat (double partials); dzs_t [B,M,Co]
+//   BWD_QUERY  dense: dy = A dz + Bc + D y (the BatchNorm backward, affine in y);  per-query
+//              sum_k dy (-> dH through the centre index) and dW_r partials
+//   BWD_SUPPORT dense, support-major through the CSR inverse of idx: dG_i = sum over slots -> i of dy,
+//              dH_i = sum over queries centred on i of the per-query sums.  Ordered gathers, no atomics.
+#include "fused_common.h"
+
+namespace cl3d {
+
+enum { PW_STATS = 0, PW_FWD = 1, PW_BWD_SPARSE = 2, PW_BWD_QUERY = 3 };
+
+struct PwArgs {
+  const float *query_xyz, *support_xyz;
+  const int *idx;
+  const float *ght;  // [B,N,2Co]
+  const float *wr;   // [Co,3]
+  const float *v0, *v1, *v2, *v3;  // per-channel vectors: FWD scale,shift | SPARSE scale,shift,mean,invstd | QUERY/SUPPORT A,Bc,D
+  const float *gout_t;             // [B,M,Co]
+  const float *dzs_in;             // [B,M,Co]
+  const unsigned char *kstar_in;   // [B,M,Co]
+  float *out_t;                    // FWD
+  unsigned char *kstar_out;        // FWD
+  float4 *slotrec;                 // FWD writes {rel, 0} (may be null); SUPPORT reads
+  float *dzs_out;                  // SPARSE
+  float *sq_t;                     // QUERY writes, SUPPORT reads
+  double *partial;                 // [gridDim.x, Co, 4]
+  const int *inv_off, *inv_slots, *cen_off, *cen_slots;
+  float *dght;                     // SUPPORT: [B,N,2Co]
+  int B, N, M, K, Co;
+  int L, QW, chunks;
+  float inv_radius;
+};
+
+__device__ __forceinline__ float pw_preact(const float w[3], float rx, float ry, float rz, float hc, float g) {
+  float t = w[0] * rx;
+  t = __builtin_fmaf(w[1], ry, t);
+  t = __builtin_fmaf(w[2], rz, t);
+  return (t + hc) + g;
+}
+
+template <int V>
+__device__ __forceinline__ Vec<V> load_row_tail(const float *p, int c0, int C) {
+  if (c0 + V <= C) return load_row<V>(p);
+  Vec<V> r;
+#pragma unroll
+  for (int v = 0; v < V; ++v) r.v[v] = c0 + v < C ? p[v] : 0.f;
+  return r;
+}
+
+// query-major passes.  Persistent blocks: tile = 4*QW queries of one cloud.
+template <int MODE, int V>
+__global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
+  extern __shared__ float4 lds4[];
+  const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
+  const int TQ = 4 * QW;
+  const int row = 2 * Co;
+  float4 *slot4 = lds4;  // [TQ*K] {idx, rx, ry, rz}
+  double *red = reinterpret_cast<double *>(slot4 + TQ * K);  // partial-sum slices
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / L, cl = lane - g * L;
+  const bool lane_on = g < QW;
+  const int tiles_per_cloud = (M + TQ - 1) / TQ;
+  const int ntiles = a.B * tiles_per_cloud;
+  constexpr int NACC = MODE == PW_STATS ? 2 : (MODE == PW_BWD_SPARSE ? 2 : (MODE == PW_BWD_QUERY ? 3 : 0));
+
+  for (int ch = 0; ch < a.chunks; ++ch) {
+    const int c0 = (ch * L + cl) * V;
+    const bool chan_on = lane_on && c0 < Co;
+    double dacc[NACC > 0 ? NACC : 1][V];
+#pragma unroll
+    for (int p = 0; p < (NACC > 0 ? NACC : 1); ++p)
+#pragma unroll
+      for (int v = 0; v < V; ++v) dacc[p][v] = 0.0;
+    float w[V][3], c_v0[V], c_v1[V], c_v2[V], c_v3[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c = (chan_on && c0 + v < Co) ? c0 + v : 0;
+      w[v][0] = a.wr[c * 3 + 0];
+      w[v][1] = a.wr[c * 3 + 1];
+      w[v][2] = a.wr[c * 3 + 2];
+      c_v0[v] = a.v0 ? a.v0[c] : 0.f;
+      c_v1[v] = a.v1 ? a.v1[c] : 0.f;
+      c_v2[v] = a.v2 ? a.v2[c] : 0.f;
+      c_v3[v] = a.v3 ? a.v3[c] : 0.f;
+    }
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int b = tile / tiles_per_cloud;
+      const int j0 = (tile - b * tiles_per_cloud) * TQ;
+      const float *q = a.query_xyz + (size_t)b * M * 3;
+      const float *s = a.support_xyz + (size_t)b * N * 3;
+      __syncthreads();  // previous tile's readers are done with slot4
+      for (int t = threadIdx.x; t < TQ * K; t += 256) {
+        const int jq = t / K;
+        const int j = j0 + jq;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < M) {
+          const size_t e = ((size_t)b * M + j) * K + (t - jq * K);
+          const int i = a.idx[e];
+          r = make_float4(__int_as_float(i), (s[i * 3 + 0] - q[j * 3 + 0]) * a.inv_radius,
+                          (s[i * 3 + 1] - q[j * 3 + 1]) * a.inv_radius, (s[i * 3 + 2] - q[j * 3 + 2]) * a.inv_radius);
+          if (MODE == PW_FWD && ch == 0 && a.slotrec != nullptr) a.slotrec[e] = make_float4(r.y, r.z, r.w, 0.f);
+        }
+        slot4[t] = r;
+      }
+      __syncthreads();
+      const int jq = wave * QW + g;
+      const int j = j0 + jq;
+      if (!chan_on || j >= M) continue;
+      const float4 *myslots = slot4 + jq * K;
+      const float *rows = a.ght + (size_t)b * N * row;
+      const int ic = __float_as_int(myslots[0].x);  // centre = nearest neighbour (reference :290)
+      const Vec<V> hc = load_row_tail<V>(rows + (size_t)ic * row + Co + c0, c0, Co);
+      const size_t orow = ((size_t)b * M + j) * Co + c0;
+
+      if constexpr (MODE == PW_STATS) {
+        float s1[V], s2[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) s1[v] = s2[v] = 0.f;
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+          const float4 sr = myslots[k];
+          const Vec<V> gr = load_row_tail<V>(rows + (size_t)__float_as_int(sr.x) * row + c0, c0, Co);
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gr.v[v]);
+            s1[v] += y;
+            s2[v] = __builtin_fmaf(y, y, s2[v]);
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          dacc[0][v] += (double)s1[v];
+          dacc[1][v] += (double)s2[v];
+        }
+      } else if constexpr (MODE == PW_FWD) {
+        float best[V];
+        int kb[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          best[v] = 0.f;
+          kb[v] = 0;
+        }
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+          const float4 sr = myslots[k];
+          const Vec<V> gr = load_row_tail<V>(rows + (size_t)__float_as_int(sr.x) * row + c0, c0, Co);
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gr.v[v]);
+            float z = __builtin_fmaf(y, c_v0[v], c_v1[v]);
+            z = z > 0.f ? z : 0.f;
+            if (k == 0 || z > best[v]) {
+              best[v] = z;
+              kb[v] = k;
+            }
+          }
+        }
+        _Pragma("unroll") for (int v = 0; v < V; ++v) if (c0 + v < Co) {
+          a.out_t[orow + v] = best[v];
+          if (a.kstar_out) a.kstar_out[orow + v] = (unsigned char)kb[v];
+        }
+      } else if constexpr (MODE == PW_BWD_SPARSE) {
+        _Pragma("unroll") for (int v = 0; v < V; ++v) if (c0 + v < Co) {
+          const int ks = a.kstar_in[orow + v];
+          const float4 sr = myslots[ks];
+          const float gi = rows[(size_t)__float_as_int(sr.x) * row + c0 + v];
+          const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gi);
+          const float z = __builtin_fmaf(y, c_v0[v], c_v1[v]);
+          const float dz = z > 0.f ? a.gout_t[orow + v] : 0.f;
+          a.dzs_out[orow + v] = dz;
+          dacc[0][v] += (double)dz;
+          dacc[1][v] += (double)(dz * ((y - c_v2[v]) * c_v3[v]));
+        }
+      } else {  // PW_BWD_QUERY
+        float dzA[V], sdy[V], dw0[V], dw1[V], dw2[V];
+        int ks[V];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const bool on = c0 + v < Co;
+          dzA[v] = on ? a.dzs_in[orow + v] * c_v0[v] : 0.f;
+          ks[v] = on ? (int)a.kstar_in[orow + v] : -1;
+          sdy[v] = dw0[v] = dw1[v] = dw2[v] = 0.f;
+        }
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+          const float4 sr = myslots[k];
+          const Vec<V> gr = load_row_tail<V>(rows + (size_t)__float_as_int(sr.x) * row + c0, c0, Co);
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gr.v[v]);
+            float dy = __builtin_fmaf(c_v2[v], y, c_v1[v]);
+            dy += (k == ks[v]) ? dzA[v] : 0.f;
+            sdy[v] += dy;
+            dw0[v] = __builtin_fmaf(dy, sr.y, dw0[v]);
+            dw1[v] = __builtin_fmaf(dy, sr.z, dw1[v]);
+            dw2[v] = __builtin_fmaf(dy, sr.w, dw2[v]);
+          }
+        }
+        _Pragma("unroll") for (int v = 0; v < V; ++v) if (c0 + v < Co) a.sq_t[orow + v] = sdy[v];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          dacc[0][v] += (double)dw0[v];
+          dacc[1][v] += (double)dw1[v];
+          dacc[2][v] += (double)dw2[v];
+        }
+      }
+    }
+
+    if constexpr (NACC > 0) {  // fixed-order block reduction of the double partials of this chunk
+      const int LV = L * V;
+      const int slice = LV * NACC;
+      __syncthreads();
+      if (lane_on) {
+        double *mine = red + (size_t)(wave * QW + g) * slice + cl * V * NACC;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+          for (int p = 0; p < NACC; ++p) mine[v * NACC + p] = chan_on ? dacc[p][v] : 0.0;
+      }
+      __syncthreads();
+      for (int t = threadIdx.x; t < slice; t += 256) {
+        double sum = 0.0;
+        for (int sl = 0; sl < 4 * QW; ++sl) sum += red[(size_t)sl * slice + t];
+        const int c = ch * LV + t / NACC;
+        if (c < Co) a.partial[((size_t)blockIdx.x * Co + c) * 4 + (t - (t / NACC) * NACC)] = sum;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// support-major dense backward pass through the CSR inverse
+template <int V>
+__global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
+  const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
+  const int row = 2 * Co;
+  const int MK = M * K;
+  const int TR = 4 * QW;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / L, cl = lane - g * L;
+  if (g >= QW) return;
+  const int tiles_per_cloud = (N + TR - 1) / TR;
+  const int ntiles = a.B * tiles_per_cloud;
+  for (int ch = 0; ch < a.chunks; ++ch) {
+    const int c0 = (ch * L + cl) * V;
+    if (c0 >= Co) continue;
+    float w[V][3], cA[V], cB[V], cD[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c = c0 + v < Co ? c0 + v : 0;
+      w[v][0] = a.wr[c * 3 + 0];
+      w[v][1] = a.wr[c * 3 + 1];
+      w[v][2] = a.wr[c * 3 + 2];
+      cA[v] = a.v0[c];
+      cB[v] = a.v1[c];
+      cD[v] = a.v2[c];
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int b = tile / tiles_per_cloud;
+      const int i = (tile - b * tiles_per_cloud) * TR + wave * QW + g;
+      if (i >= N) continue;
+      const float *rows = a.ght + (size_t)b * N * row;
+      const int *ib = a.idx + (size_t)b * MK;
+      const int *off = a.inv_off + (size_t)b * (N + 1);
+      const int *slots = a.inv_slots + (size_t)b * MK;
+      const float4 *rec = a.slotrec + (size_t)b * MK;
+      const Vec<V> gi = load_row_tail<V>(rows + (size_t)i * row + c0, c0, Co);
+      float acc[V], acch[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = acch[v] = 0.f;
+      const int s0 = off[i], s1 = off[i + 1];
+      for (int e = s0; e < s1; ++e) {
+        const int slot = slots[e];
+        const int j = slot / K;
+        const int k = slot - j * K;
+        const float4 r = rec[slot];
+        const int ic = ib[(size_t)j * K];
+        const Vec<V> hc = load_row_tail<V>(rows + (size_t)ic * row + Co + c0, c0, Co);
+        const size_t orow = ((size_t)b * M + j) * Co + c0;
+        const Vec<V> dz = load_row_tail<V>(a.dzs_in + orow, c0, Co);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const int ks = c0 + v < Co ? (int)a.kstar_in[orow + v] : -1;
+          const float y = pw_preact(w[v], r.x, r.y, r.z, hc.v[v], gi.v[v]);
+          float dy = __builtin_fmaf(cD[v], y, cB[v]);
+          dy += (k == ks) ? dz.v[v] * cA[v] : 0.f;
+          acc[v] += dy;
+        }
+      }
+      const int *coff = a.cen_off + (size_t)b * (N + 1);
+      const int *cslots = a.cen_slots + (size_t)b * M;
+      const int t0 = coff[i], t1 = coff[i + 1];
+      for (int e = t0; e < t1; ++e) {
+        const int j = cslots[e];
+        const Vec<V> sq = load_row_tail<V>(a.sq_t + ((size_t)b * M + j) * Co + c0, c0, Co);
+#pragma unroll
+        for (int v = 0; v < V; ++v) acch[v] += sq.v[v];
+      }
+      float *dst = a.dght + ((size_t)b * N + i) * row + c0;
+      _Pragma("unroll") for (int v = 0; v < V; ++v) if (c0 + v < Co) {
+        dst[v] = acc[v];
+        dst[Co + v] = acch[v];
+      }
+    }
+  }
+}
+
+static int pw_check(const PwArgs &a, const char *who) {
+  if (a.B < 0 || a.N < 1 || a.M < 1 || a.K < 1 || a.Co < 1) return fail(CL3D_E_INVALID, "%s: bad sizes", who);
+  if (a.K > 255) return fail(CL3D_E_UNSUPPORTED, "%s: nsample=%d > 255 (arg-max is stored in a byte)", who, a.K);
+  if ((long long)a.M * a.K > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "%s: M*K too large", who);
+  return CL3D_OK;
+}
+
+static LaneMap pw_lane_map(int Co, int K, int V, int nacc, size_t *lds_out) {
+  LaneMap m = pick_lane_map(Co, V);
+  if (m.QW > 16) {
+    m.QW = 16;
+    m.L = 4;
+    m.chunks = ((Co + V - 1) / V + m.L - 1) / m.L;
+  }
+  for (;;) {
+    const size_t tq = 4 * (size_t)m.QW;
+    const size_t lds = tq * K * sizeof(float4) + tq * m.L * V * nacc * sizeof(double);
+    if (lds <= 60 * 1024 || m.QW == 1) {
+      *lds_out = lds;
+      return m;
+    }
+    m.QW -= 1;
+  }
+}
+
+template <int MODE>
+static int launch_query(PwArgs &a, int nacc, int n_partials, hipStream_t st, const char *who) {
+  const int V = (a.Co % 4 == 0) ? 4 : 1;
+  size_t lds = 0;
+  const LaneMap m = pw_lane_map(a.Co, a.K, V, nacc, &lds);
+  if (lds > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "%s: nsample=%d needs %zu B of LDS", who, a.K, lds);
+  a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
+  const long long tiles = (long long)a.B * ceil_div(a.M, 4 * m.QW);
+  int gx = nacc > 0 ? n_partials : (int)(tiles < 8192 ? tiles : 8192);
+  if (gx < 1) gx = 1;
+  if (V == 4) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4>), dim3(gx), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1>), dim3(gx), dim3(256), lds, st, a);
+  return check_launch(who);
+}
+
+}  // namespace cl3d
+
+extern "C" int cl3d_pwmlp_partials(int B, int M, int Co) {
+  (void)Co;
+  long long tiles = ((long long)B * M + 15) / 16;
+  return (int)(tiles < 1 ? 1 : (tiles > 2048 ? 2048 : tiles));
+}
+
+extern "C" int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
+                                const float *ght, const float *wr, int B, int N, int M, int K, int Co,
+                                float radius, double *partial, int n_partials, cl3d_stream_t stream) {
+  using namespace cl3d;
+  PwArgs a{};
+  a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr; a.partial = partial;
+  a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
+  int rc = pw_check(a, "pwmlp_stats");
+  if (rc != CL3D_OK) return rc;
+  CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && partial, "pwmlp_stats: null pointer");
+  CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_stats: partial buffer must have cl3d_pwmlp_partials() blocks");
+  if (B == 0) return CL3D_OK;
+  return launch_query<PW_STATS>(a, 2, n_partials, (hipStream_t)stream, "cl3d_pwmlp_stats");
+}
+
+extern "C" int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, const int32_t *idx,
+                              const float *ght, const float *wr, const float *scale, const float *shift,
+                              int B, int N, int M, int K, int Co, float radius, float *out_t,
+                              unsigned char *kstar_t, float *slotrec, cl3d_stream_t stream) {
+  using namespace cl3d;
+  PwArgs a{};
+  a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr;
+  a.v0 = scale; a.v1 = shift; a.out_t = out_t; a.kstar_out = kstar_t; a.slotrec = reinterpret_cast<float4 *>(slotrec);
+  a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
+  int rc = pw_check(a, "pwmlp_fwd");
+  if (rc != CL3D_OK) return rc;
+  CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && scale && shift && out_t, "pwmlp_fwd: null pointer");
+  if (B == 0) return CL3D_OK;
+  return launch_query<PW_FWD>(a, 0, 0, (hipStream_t)stream, "cl3d_pwmlp_fwd");
+}
+
+extern "C" int cl3d_pwmlp_bwd_sparse(const float *query_xyz, const float *support_xyz, const int32_t *idx,
+                                     const float *ght, const float *wr, const float *scale,
+                                     const float *shift, const float *mean, const float *invstd,
+                                     const float *gout_t, const unsigned char *kstar_t, int B, int N, int M,
+                                     int K, int Co, float radius, float *dzs_t, double *partial,
+                                     int n_partials, cl3d_stream_t stream) {
+  using namespace cl3d;
+  PwArgs a{};
+  a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr;
+  a.v0 = scale; a.v1 = shift; a.v2 = mean; a.v3 = invstd; a.gout_t = gout_t; a.kstar_in = kstar_t;
+  a.dzs_out = dzs_t; a.partial = partial;
+  a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
+  int rc = pw_check(a, "pwmlp_bwd_sparse");
+  if (rc != CL3D_OK) return rc;
+  CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && scale && shift && mean && invstd && gout_t && kstar_t && dzs_t && partial,
+               "pwmlp_bwd_sparse: null pointer");
+  CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_bwd_sparse: wrong partial block count");
+  if (B == 0) return CL3D_OK;
+  return launch_query<PW_BWD_SPARSE>(a, 2, n_partials, (hipStream_t)stream, "cl3d_pwmlp_bwd_sparse");
+}
+
+extern "C" int cl3d_pwmlp_bwd_query(const float *query_xyz, const float *support_xyz, const int32_t *idx,
+                                    const float *ght, const float *wr, const float *cA, const float *cB,
+                                    const float *cD, const float *dzs_t, const unsigned char *kstar_t, int B,
+                                    int N, int M, int K, int Co, float radius, float *sq_t, double *partial,
+                                    int n_partials, cl3d_stream_t stream) {
+  using namespace cl3d;
+  PwArgs a{};
+  a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr;
+  a.v0 = cA; a.v1 = cB; a.v2 = cD; a.dzs_in = dzs_t; a.kstar_in = kstar_t; a.sq_t = sq_t; a.partial = partial;
+  a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
+  int rc = pw_check(a, "pwmlp_bwd_query");
+  if (rc != CL3D_OK) return rc;
+  CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && cA && cB && cD && dzs_t && kstar_t && sq_t && partial,
+               "pwmlp_bwd_query: null pointer");
+  CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_bwd_query: wrong partial block count");
+  if (B == 0) return CL3D_OK;
+  return launch_query<PW_BWD_QUERY>(a, 3, n_partials, (hipStream_t)stream, "cl3d_pwmlp_bwd_query");
+}
+
+extern "C" int cl3d_pwmlp_bwd_support(const int32_t *idx, const float *ght, const float *wr, const float *cA,
+                                      const float *cB, const float *cD, const float *dzs_t,
+                                      const unsigned char *kstar_t, const float *slotrec, const float *sq_t,
+                                      const int32_t *inv_off, const int32_t *inv_slots, const int32_t *cen_off,
+                                      const int32_t *cen_slots, int B, int N, int M, int K, int Co, float *dght,
+                                      cl3d_stream_t stream) {
+  using namespace cl3d;
+  PwArgs a{};
+  a.idx = idx; a.ght = ght; a.wr = wr; a.v0 = cA; a.v1 = cB; a.v2 = cD; a.dzs_in = dzs_t; a.kstar_in = kstar_t;
+  a.slotrec = reinterpret_cast<float4 *>(const_cast<float *>(slotrec)); a.sq_t = const_cast<float *>(sq_t);
+  a.inv_off = inv_off; a.inv_slots = inv_slots; a.cen_off = cen_off; a.cen_slots = cen_slots; a.dght = dght;
+  a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co;
+  int rc = pw_check(a, "pwmlp_bwd_support");
+  if (rc != CL3D_OK) return rc;
+  CL3D_REQUIRE(idx && ght && wr && cA && cB && cD && dzs_t && kstar_t && slotrec && sq_t && inv_off && inv_slots && cen_off && cen_slots && dght,
+               "pwmlp_bwd_support: null pointer");
+  if (B == 0) return CL3D_OK;
+  const int V = (Co % 4 == 0) ? 4 : 1;
+  const LaneMap m = pick_lane_map(Co, V);
+  a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
+  const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
+  const int gx = (int)(tiles < 8192 ? (tiles < 1 ? 1 : tiles) : 8192);
+  if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((pwmlp_support_kernel<1>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("cl3d_pwmlp_bwd_support");
+}

@@ -1,0 +1,519 @@
+// fused_reduce.hip -- PosPool / AdaptiveWeight / PseudoGrid without the [B,C,M,K] tensor (gfx950).
+//
+// All three operators of the reference have the shape
+//     out[b,c,j] = reduce_k  w_c(rel[b,j,k]) * mask[b,j,k] * f[b,c,idx[b,j,k]]
+// (models/local_aggregation_operators.py: PosPool :65-103, AdaptiveWeight :188-214, PseudoGrid
+// :383-419) and differ only in the positional weight w_c.  The reference materialises the grouped
+// features (33.5 MB per cloud at the metric shape) and runs 6-10 element-wise passes over them; here
+// one kernel reads each neighbour row once (point-major rows, see fused_common.h) and keeps the
+// K-reduction in registers.  The backward kernel is a gather as well, through the CSR inverse of idx
+// (csr.hip): d f[b,i,:] = sum over the slots referencing i, in ascending slot order -- no atomics.
+//
+//   OP_POSPOOL_XYZ     w_c = rel[c % 3]
+//   OP_POSPOOL_SINCOS  c = a*2fd + s*fd + f:  w_c = s ? cos : sin ((100*rel_a) / dim[f])
+//   OP_ADAPTIVE        w_c = bias[c/S] + W[c/S,:] . rel          (weight_type 'dp', one conv layer)
+//   OP_PSEUDOGRID      out_c = sum_p kw[p,c] * sum_k h_p(rel_k) mask_k f_c,k,  h_p = max(1 - |rel-KP_p| / extent, 0)
+#include "fused_common.h"
+
+namespace cl3d {
+
+enum { OP_POSPOOL_XYZ = 0, OP_POSPOOL_SINCOS = 1, OP_ADAPTIVE = 2, OP_PSEUDOGRID = 3 };
+enum { RED_SUM = 0, RED_AVG = 1 };
+constexpr int kMaxKP = 16;  // kernel points per PseudoGrid operator (reference default 15)
+
+struct ReduceArgs {
+  const float *query_xyz, *support_xyz;
+  const int *query_mask, *idx, *idx_mask;
+  const float *ft;       // [B,N,C]
+  const float *gout_t;   // bwd: [B,M,C]
+  const float *p0, *p1;  // operator parameters (see table above)
+  float *out_t;          // fwd: [B,M,C]
+  float4 *slotrec;       // [B,M,K]  {rel.x, rel.y, rel.z, coef}; fwd writes (may be null), bwd reads
+  const int *inv_off, *inv_slots;
+  float *dft;            // bwd: [B,N,C]
+  float *dparam;         // bwd: [gridDim.x, C, NP] partial parameter gradients (may be null)
+  int B, N, M, K, C;
+  int L, QW, chunks;
+  int reduction, normalize, pint;  // pint: S (adaptive) / P (pseudo grid)
+  int constant_influence;
+  float inv_radius, pfloat;        // pfloat: 1/extent (pseudo grid)
+};
+
+__device__ __forceinline__ float kp_influence(float rx, float ry, float rz, const float *kp, float inv_extent,
+                                              int constant) {
+  if (constant) return 1.0f;
+  const float dx = rx - kp[0], dy = ry - kp[1], dz = rz - kp[2];
+  const float sq = dx * dx + dy * dy + dz * dz;
+  const float h = 1.0f - sqrtf(sq) * inv_extent;
+  return h > 0.0f ? h : 0.0f;
+}
+
+// per-lane description of how its V channels turn a relative position into a weight
+template <int OP, int V>
+struct ChannelWeights {
+  int axis[V];     // xyz / sincos: which coordinate
+  int is_cos[V];   // sincos
+  float dim[V];    // sincos divisor
+  float w[V][3];   // adaptive: conv weight row
+  float bias[V];   // adaptive
+  __device__ __forceinline__ void init(const ReduceArgs &a, int c0) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c = c0 + v < a.C ? c0 + v : a.C - 1;
+      if constexpr (OP == OP_POSPOOL_XYZ) {
+        axis[v] = c % 3;
+      } else if constexpr (OP == OP_POSPOOL_SINCOS) {
+        const int fd = a.C / 6;
+        axis[v] = c / (2 * fd);
+        const int rem = c - axis[v] * 2 * fd;
+        is_cos[v] = rem / fd;
+        dim[v] = a.p0[rem - is_cos[v] * fd];
+      } else if constexpr (OP == OP_ADAPTIVE) {
+        const int cw = c / a.pint;
+        w[v][0] = a.p0[cw * 3 + 0];
+        w[v][1] = a.p0[cw * 3 + 1];
+        w[v][2] = a.p0[cw * 3 + 2];
+        bias[v] = a.p1[cw];
+      }
+    }
+  }
+  __device__ __forceinline__ float weight(int v, float rx, float ry, float rz) const {
+    if constexpr (OP == OP_POSPOOL_XYZ) {
+      return axis[v] == 0 ? rx : (axis[v] == 1 ? ry : rz);
+    } else if constexpr (OP == OP_POSPOOL_SINCOS) {
+      const float r = axis[v] == 0 ? rx : (axis[v] == 1 ? ry : rz);
+      const float arg = (100.0f * r) / dim[v];
+      return is_cos[v] ? cosf(arg) : sinf(arg);
+    } else if constexpr (OP == OP_ADAPTIVE) {
+      return bias[v] + w[v][0] * rx + w[v][1] * ry + w[v][2] * rz;
+    } else {
+      return 0.0f;
+    }
+  }
+};
+
+// -------------------------------------------------------------------------------- forward
+template <int OP, int V>
+__global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
+  extern __shared__ float4 lds4[];
+  const int K = a.K, C = a.C, M = a.M, N = a.N, L = a.L, QW = a.QW;
+  const int TQ = 4 * QW;
+  float4 *slot4 = lds4;                                   // [TQ*K] {idx, rx, ry, rz}
+  float *coef = reinterpret_cast<float *>(slot4 + TQ * K);  // [TQ*K] mask weight
+  float *cntq = coef + TQ * K;                            // [TQ]
+  float *hbuf = cntq + TQ;                                // PseudoGrid: [TQ*K][kMaxKP]
+  const int b = blockIdx.y;
+  const int j0 = blockIdx.x * TQ;
+  const float *q = a.query_xyz + (size_t)b * M * 3;
+  const float *s = a.support_xyz + (size_t)b * N * 3;
+
+  // ---- phase A: per-slot scalars, once per block
+  for (int t = threadIdx.x; t < TQ * K; t += 256) {
+    const int jq = t / K;
+    const int j = j0 + jq;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    float m = 0.f;
+    if (j < M) {
+      const size_t e = ((size_t)b * M + j) * K + (t - jq * K);
+      const int i = a.idx[e];
+      m = (float)(a.idx_mask[e] + (1 - a.query_mask[(size_t)b * M + j]));
+      float dx = s[i * 3 + 0] - q[j * 3 + 0];
+      float dy = s[i * 3 + 1] - q[j * 3 + 1];
+      float dz = s[i * 3 + 2] - q[j * 3 + 2];
+      if (a.normalize) {
+        dx *= a.inv_radius;
+        dy *= a.inv_radius;
+        dz *= a.inv_radius;
+      }
+      r = make_float4(__int_as_float(i), dx, dy, dz);
+      if constexpr (OP == OP_PSEUDOGRID) {
+        for (int p = 0; p < kMaxKP; ++p)
+          hbuf[(size_t)t * kMaxKP + p] =
+              p < a.pint ? kp_influence(dx, dy, dz, a.p0 + p * 3, a.pfloat, a.constant_influence) * m : 0.f;
+      }
+    } else if constexpr (OP == OP_PSEUDOGRID) {
+      for (int p = 0; p < kMaxKP; ++p) hbuf[(size_t)t * kMaxKP + p] = 0.f;
+    }
+    slot4[t] = r;
+    coef[t] = m;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < TQ) {
+    float n = 0.f;
+    for (int k = 0; k < K; ++k) n += coef[threadIdx.x * K + k];
+    cntq[threadIdx.x] = n;
+  }
+  __syncthreads();
+  if (a.slotrec != nullptr) {
+    for (int t = threadIdx.x; t < TQ * K; t += 256) {
+      const int jq = t / K;
+      const int j = j0 + jq;
+      if (j < M) {
+        const float4 r = slot4[t];
+        const float cf = a.reduction == RED_AVG ? coef[t] / cntq[jq] : coef[t];
+        a.slotrec[((size_t)b * M + j) * K + (t - jq * K)] = make_float4(r.y, r.z, r.w, cf);
+      }
+    }
+  }
+
+  // ---- phase B: one lane group per query, K-reduction in registers
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / L, cl = lane - g * L;
+  if (g >= QW) return;
+  const int jq = wave * QW + g;
+  const int j = j0 + jq;
+  if (j >= M) return;
+  const float n = cntq[jq];
+  const float4 *myslots = slot4 + jq * K;
+  const float *mycoef = coef + jq * K;
+  const float *frow = a.ft + (size_t)b * N * C;
+  for (int ch = 0; ch < a.chunks; ++ch) {
+    const int c0 = (ch * L + cl) * V;
+    if (c0 >= C) continue;
+    Vec<V> out;
+    if constexpr (OP == OP_PSEUDOGRID) {
+      float wf[kMaxKP][V];
+#pragma unroll
+      for (int p = 0; p < kMaxKP; ++p)
+#pragma unroll
+        for (int v = 0; v < V; ++v) wf[p][v] = 0.f;
+#pragma unroll 2
+      for (int k = 0; k < K; ++k) {
+        const int i = __float_as_int(myslots[k].x);
+        const Vec<V> f = load_row<V>(frow + (size_t)i * C + c0);
+        const float4 *h4 = reinterpret_cast<const float4 *>(hbuf + (size_t)(jq * K + k) * kMaxKP);
+#pragma unroll
+        for (int p4 = 0; p4 < kMaxKP / 4; ++p4) {
+          const float4 h = h4[p4];
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            wf[p4 * 4 + 0][v] = __builtin_fmaf(h.x, f.v[v], wf[p4 * 4 + 0][v]);
+            wf[p4 * 4 + 1][v] = __builtin_fmaf(h.y, f.v[v], wf[p4 * 4 + 1][v]);
+            wf[p4 * 4 + 2][v] = __builtin_fmaf(h.z, f.v[v], wf[p4 * 4 + 2][v]);
+            wf[p4 * 4 + 3][v] = __builtin_fmaf(h.w, f.v[v], wf[p4 * 4 + 3][v]);
+          }
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float o = 0.f;
+        const int c = c0 + v < C ? c0 + v : C - 1;
+#pragma unroll
+        for (int p = 0; p < kMaxKP; ++p)
+          if (p < a.pint) o += wf[p][v] * a.p1[(size_t)p * C + c];
+        out.v[v] = o;
+      }
+    } else {
+      ChannelWeights<OP, V> cw;
+      cw.init(a, c0);
+      float acc[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = 0.f;
+#pragma unroll 4
+      for (int k = 0; k < K; ++k) {
+        const float4 sr = myslots[k];
+        const int i = __float_as_int(sr.x);
+        const Vec<V> f = load_row<V>(frow + (size_t)i * C + c0);
+        const float m = mycoef[k];
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const float t = cw.weight(v, sr.y, sr.z, sr.w) * f.v[v];  // (embedding * feature) ...
+          acc[v] += t * m;                                           // ... * mask, as the reference orders it
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < V; ++v) out.v[v] = a.reduction == RED_AVG ? acc[v] / n : acc[v];
+    }
+    float *dst = a.out_t + ((size_t)b * M + j) * C + c0;
+    if (c0 + V <= C) {
+      store_row<V>(dst, out);
+    } else {
+      _Pragma("unroll") for (int v = 0; v < V; ++v) if (c0 + v < C) dst[v] = out.v[v];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- backward
+// NP parameter-gradient accumulators per channel: adaptive 4 (3 weights + bias), pseudo grid kMaxKP.
+template <int OP>
+struct ParamCount {
+  static constexpr int value = OP == OP_ADAPTIVE ? 4 : (OP == OP_PSEUDOGRID ? kMaxKP : 0);
+};
+
+template <int OP, int V>
+__global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
+  extern __shared__ float lds[];
+  constexpr int NP = ParamCount<OP>::value;
+  const int K = a.K, C = a.C, M = a.M, N = a.N, L = a.L, QW = a.QW;
+  const int waves = blockDim.x >> 6;
+  const int TR = waves * QW;  // support rows per tile
+  const int MK = M * K;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / L, cl = lane - g * L;
+  const bool lane_on = g < QW;
+  const int tiles_per_cloud = (N + TR - 1) / TR;
+  const int ntiles = a.B * tiles_per_cloud;
+
+  for (int ch = 0; ch < a.chunks; ++ch) {
+    const int c0 = (ch * L + cl) * V;
+    const bool chan_on = lane_on && c0 < C;
+    float pacc[NP > 0 ? NP : 1][V];
+#pragma unroll
+    for (int p = 0; p < (NP > 0 ? NP : 1); ++p)
+#pragma unroll
+      for (int v = 0; v < V; ++v) pacc[p][v] = 0.f;
+    ChannelWeights<OP, V> cw;
+    float kw[OP == OP_PSEUDOGRID ? kMaxKP : 1][V];
+    if (chan_on) {
+      cw.init(a, c0);
+      if constexpr (OP == OP_PSEUDOGRID) {
+#pragma unroll
+        for (int p = 0; p < kMaxKP; ++p)
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+            kw[p][v] = (p < a.pint && c0 + v < C) ? a.p1[(size_t)p * C + c0 + v] : 0.f;
+      }
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      const int b = tile / tiles_per_cloud;
+      const int i = (tile - b * tiles_per_cloud) * TR + wave * QW + g;
+      if (!chan_on || i >= N) continue;
+      const int *off = a.inv_off + (size_t)b * (N + 1);
+      const int *slots = a.inv_slots + (size_t)b * MK;
+      const float4 *rec = a.slotrec + (size_t)b * MK;
+      const float *grow = a.gout_t + (size_t)b * M * C + c0;
+      const int s0 = off[i], s1 = off[i + 1];
+      Vec<V> fown;
+      if constexpr (NP > 0) {
+        if (c0 + V <= C) {
+          fown = load_row<V>(a.ft + ((size_t)b * N + i) * C + c0);
+        } else {
+#pragma unroll
+          for (int v = 0; v < V; ++v) fown.v[v] = c0 + v < C ? a.ft[((size_t)b * N + i) * C + c0 + v] : 0.f;
+        }
+      }
+      float acc[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = 0.f;
+      for (int e = s0; e < s1; ++e) {
+        const int slot = slots[e];
+        const int j = slot / K;
+        const float4 r = rec[slot];
+        Vec<V> go;
+        if (c0 + V <= C) {
+          go = load_row<V>(grow + (size_t)j * C);
+        } else {
+#pragma unroll
+          for (int v = 0; v < V; ++v) go.v[v] = c0 + v < C ? grow[(size_t)j * C + v] : 0.f;
+        }
+        if constexpr (OP == OP_PSEUDOGRID) {
+          float h[kMaxKP];
+#pragma unroll
+          for (int p = 0; p < kMaxKP; ++p)
+            h[p] = p < a.pint ? kp_influence(r.x, r.y, r.z, a.p0 + p * 3, a.pfloat, a.constant_influence) * r.w : 0.f;
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            float w = 0.f;
+#pragma unroll
+            for (int p = 0; p < kMaxKP; ++p) {
+              w = __builtin_fmaf(kw[p][v], h[p], w);
+              pacc[p][v] = __builtin_fmaf(h[p] * fown.v[v], go.v[v], pacc[p][v]);
+            }
+            acc[v] = __builtin_fmaf(w, go.v[v], acc[v]);
+          }
+        } else {
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const float gm = go.v[v] * r.w;  // d out * (mask / count)
+            acc[v] = __builtin_fmaf(cw.weight(v, r.x, r.y, r.z), gm, acc[v]);
+            if constexpr (OP == OP_ADAPTIVE) {
+              const float gf = gm * fown.v[v];
+              pacc[0][v] = __builtin_fmaf(gf, r.x, pacc[0][v]);
+              pacc[1][v] = __builtin_fmaf(gf, r.y, pacc[1][v]);
+              pacc[2][v] = __builtin_fmaf(gf, r.z, pacc[2][v]);
+              pacc[3][v] += gf;
+            }
+          }
+        }
+      }
+      float *dst = a.dft + ((size_t)b * N + i) * C + c0;
+      if (c0 + V <= C) {
+        Vec<V> o;
+#pragma unroll
+        for (int v = 0; v < V; ++v) o.v[v] = acc[v];
+        store_row<V>(dst, o);
+      } else {
+        _Pragma("unroll") for (int v = 0; v < V; ++v) if (c0 + v < C) dst[v] = acc[v];
+      }
+    }
+    // ---- fixed-order block reduction of the parameter partials for this channel chunk
+    if constexpr (NP > 0) {
+      if (a.dparam != nullptr) {
+        const int LV = L * V;
+        const int slice = LV * NP;
+        __syncthreads();
+        if (lane_on) {
+          float *mine = lds + (size_t)(wave * QW + g) * slice + cl * V * NP;
+#pragma unroll
+          for (int v = 0; v < V; ++v)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) mine[v * NP + p] = chan_on ? pacc[p][v] : 0.f;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < slice; t += blockDim.x) {
+          float sum = 0.f;
+          for (int sl = 0; sl < waves * QW; ++sl) sum += lds[(size_t)sl * slice + t];
+          const int c = ch * LV + t / NP;
+          if (c < C) a.dparam[((size_t)blockIdx.x * C + c) * NP + (t - (t / NP) * NP)] = sum;
+        }
+        __syncthreads();
+      }
+    }
+  }
+}
+
+static int check_common(const ReduceArgs &a, const char *who) {
+  if (a.B < 0 || a.N < 1 || a.M < 0 || a.K < 1 || a.C < 1) return fail(CL3D_E_INVALID, "%s: bad sizes", who);
+  if (a.B > 65535) return fail(CL3D_E_UNSUPPORTED, "%s: B exceeds grid.y limit", who);
+  if ((long long)a.M * a.K > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "%s: M*K too large", who);
+  return CL3D_OK;
+}
+
+static int validate_op(int op, int C, int pint, const char *who) {
+  switch (op) {
+    case OP_POSPOOL_XYZ:
+      if (C % 3) return fail(CL3D_E_INVALID, "%s: PosPool xyz needs C %% 3 == 0 (C=%d)", who, C);
+      return CL3D_OK;
+    case OP_POSPOOL_SINCOS:
+      if (C % 6) return fail(CL3D_E_INVALID, "%s: PosPool sin_cos needs C %% 6 == 0 (C=%d)", who, C);
+      return CL3D_OK;
+    case OP_ADAPTIVE:
+      if (pint < 1 || C % pint) return fail(CL3D_E_INVALID, "%s: shared_channels=%d does not divide C=%d", who, pint, C);
+      return CL3D_OK;
+    case OP_PSEUDOGRID:
+      if (pint < 1 || pint > kMaxKP) return fail(CL3D_E_UNSUPPORTED, "%s: %d kernel points (max %d)", who, pint, kMaxKP);
+      return CL3D_OK;
+    default:
+      return fail(CL3D_E_INVALID, "%s: unknown operator %d", who, op);
+  }
+}
+
+template <int V>
+static void launch_fwd(int op, const ReduceArgs &a, dim3 grid, size_t lds, hipStream_t st) {
+  switch (op) {
+    case OP_POSPOOL_XYZ: hipLaunchKernelGGL((fused_reduce_fwd_kernel<OP_POSPOOL_XYZ, V>), grid, dim3(256), lds, st, a); break;
+    case OP_POSPOOL_SINCOS: hipLaunchKernelGGL((fused_reduce_fwd_kernel<OP_POSPOOL_SINCOS, V>), grid, dim3(256), lds, st, a); break;
+    case OP_ADAPTIVE: hipLaunchKernelGGL((fused_reduce_fwd_kernel<OP_ADAPTIVE, V>), grid, dim3(256), lds, st, a); break;
+    default: hipLaunchKernelGGL((fused_reduce_fwd_kernel<OP_PSEUDOGRID, V>), grid, dim3(256), lds, st, a); break;
+  }
+}
+
+template <int V>
+static void launch_bwd(int op, const ReduceArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
+  switch (op) {
+    case OP_POSPOOL_XYZ: hipLaunchKernelGGL((fused_reduce_bwd_kernel<OP_POSPOOL_XYZ, V>), grid, block, lds, st, a); break;
+    case OP_POSPOOL_SINCOS: hipLaunchKernelGGL((fused_reduce_bwd_kernel<OP_POSPOOL_SINCOS, V>), grid, block, lds, st, a); break;
+    case OP_ADAPTIVE: hipLaunchKernelGGL((fused_reduce_bwd_kernel<OP_ADAPTIVE, V>), grid, block, lds, st, a); break;
+    default: hipLaunchKernelGGL((fused_reduce_bwd_kernel<OP_PSEUDOGRID, V>), grid, block, lds, st, a); break;
+  }
+}
+
+static LaneMap fwd_lane_map(int op, int C, int K, int V, size_t *lds_out) {
+  LaneMap m = pick_lane_map(C, V);
+  if (m.QW > 16) {  // keep the per-block slot tile modest
+    m.QW = 16;
+    m.L = 4;
+    m.chunks = ((C + V - 1) / V + m.L - 1) / m.L;
+  }
+  for (;;) {
+    const size_t tq = 4 * (size_t)m.QW;
+    size_t lds = tq * K * (sizeof(float4) + sizeof(float)) + tq * sizeof(float);
+    if (op == OP_PSEUDOGRID) lds += tq * K * kMaxKP * sizeof(float);
+    if (lds <= 60 * 1024 || m.QW == 1) {
+      *lds_out = lds;
+      return m;
+    }
+    m.QW -= 1;  // fewer queries per wave (some lanes idle) until the tile fits
+  }
+}
+
+}  // namespace cl3d
+
+extern "C" int cl3d_fused_param_partials(int op, int B, int N, int C) {
+  (void)C;
+  if (op != cl3d::OP_ADAPTIVE && op != cl3d::OP_PSEUDOGRID) return 0;
+  long long rows = (long long)B * N;
+  long long tiles = (rows + 3) / 4;
+  return (int)(tiles < 1024 ? (tiles < 1 ? 1 : tiles) : 1024);
+}
+
+extern "C" int cl3d_fused_reduce_fwd(int op, const float *query_xyz, const float *support_xyz,
+                                     const int32_t *query_mask, const int32_t *idx,
+                                     const int32_t *idx_mask, const float *ft, int B, int N, int M,
+                                     int K, int C, float radius, int normalize_xyz, int reduction,
+                                     const float *p0, const float *p1, int pint, float pfloat,
+                                     int constant_influence, float *out_t, float *slotrec,
+                                     cl3d_stream_t stream) {
+  using namespace cl3d;
+  ReduceArgs a{};
+  a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.query_mask = query_mask; a.idx = idx; a.idx_mask = idx_mask;
+  a.ft = ft; a.p0 = p0; a.p1 = p1; a.out_t = out_t; a.slotrec = reinterpret_cast<float4 *>(slotrec);
+  a.B = B; a.N = N; a.M = M; a.K = K; a.C = C;
+  a.reduction = reduction; a.normalize = normalize_xyz; a.pint = pint; a.constant_influence = constant_influence;
+  a.inv_radius = 1.0f / radius; a.pfloat = pfloat;
+  int rc = check_common(a, "fused_reduce_fwd");
+  if (rc != CL3D_OK) return rc;
+  rc = validate_op(op, C, pint, "fused_reduce_fwd");
+  if (rc != CL3D_OK) return rc;
+  CL3D_REQUIRE(reduction == RED_SUM || reduction == RED_AVG, "fused_reduce_fwd: reduction must be sum or avg");
+  if (B == 0 || M == 0) return CL3D_OK;
+  CL3D_REQUIRE(query_xyz && support_xyz && query_mask && idx && idx_mask && ft && out_t, "fused_reduce_fwd: null pointer");
+  CL3D_REQUIRE(op == OP_POSPOOL_XYZ || p0, "fused_reduce_fwd: missing operator parameters");
+  const int V = (C % 4 == 0) ? 4 : 1;
+  size_t lds = 0;
+  const LaneMap m = fwd_lane_map(op, C, K, V, &lds);
+  if (lds > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "fused_reduce_fwd: nsample=%d needs %zu B of LDS per block", K, lds);
+  a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
+  dim3 grid(ceil_div(M, 4 * m.QW), B);
+  if (V == 4) launch_fwd<4>(op, a, grid, lds, (hipStream_t)stream);
+  else launch_fwd<1>(op, a, grid, lds, (hipStream_t)stream);
+  return check_launch("cl3d_fused_reduce_fwd");
+}
+
+extern "C" int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *ft,
+                                     const float *slotrec, const int32_t *inv_off,
+                                     const int32_t *inv_slots, int B, int N, int M, int K, int C,
+                                     const float *p0, const float *p1, int pint, float pfloat,
+                                     int constant_influence, float *dft, float *dparam,
+                                     int n_partials, cl3d_stream_t stream) {
+  using namespace cl3d;
+  ReduceArgs a{};
+  a.gout_t = gout_t; a.ft = ft; a.slotrec = reinterpret_cast<float4 *>(const_cast<float *>(slotrec));
+  a.inv_off = inv_off; a.inv_slots = inv_slots; a.p0 = p0; a.p1 = p1; a.dft = dft; a.dparam = dparam;
+  a.B = B; a.N = N; a.M = M; a.K = K; a.C = C; a.pint = pint; a.pfloat = pfloat; a.constant_influence = constant_influence;
+  int rc = check_common(a, "fused_reduce_bwd");
+  if (rc != CL3D_OK) return rc;
+  rc = validate_op(op, C, pint, "fused_reduce_bwd");
+  if (rc != CL3D_OK) return rc;
+  if (B == 0) return CL3D_OK;
+  CL3D_REQUIRE(gout_t && slotrec && inv_off && inv_slots && dft, "fused_reduce_bwd: null pointer");
+  CL3D_REQUIRE(op == OP_POSPOOL_XYZ || p0, "fused_reduce_bwd: missing operator parameters");
+  const bool has_params = op == OP_ADAPTIVE || op == OP_PSEUDOGRID;
+  CL3D_REQUIRE(!has_params || (ft && dparam && n_partials == cl3d_fused_param_partials(op, B, N, C)),
+               "fused_reduce_bwd: parameter-gradient buffer must have cl3d_fused_param_partials() blocks");
+  const int V = (C % 4 == 0) ? 4 : 1;
+  LaneMap m = pick_lane_map(C, V);
+  // PseudoGrid carries 2*kMaxKP*V accumulators per lane: two waves per block keep the LDS slice at 32 KiB
+  const int waves = op == OP_PSEUDOGRID ? 2 : 4;
+  const int NP = op == OP_ADAPTIVE ? 4 : (op == OP_PSEUDOGRID ? kMaxKP : 0);
+  const size_t lds = (size_t)waves * m.QW * m.L * V * NP * sizeof(float);
+  a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
+  const long long tiles = (long long)B * ceil_div(N, waves * m.QW);
+  int gx = has_params ? n_partials : (int)(tiles < 4096 ? tiles : 4096);
+  if (gx < 1) gx = 1;
+  if (V == 4) launch_bwd<4>(op, a, dim3(gx), dim3(64 * waves), lds, (hipStream_t)stream);
+  else launch_bwd<1>(op, a, dim3(gx), dim3(64 * waves), lds, (hipStream_t)stream);
+  return check_launch("cl3d_fused_reduce_bwd");
+}

@@ -14,13 +14,14 @@
 //     W waves streams a fixed slice of grad_out (float4, coalesced) and accumulates into its own
 //     private LDS row with ds_add_f32; the W rows are combined in a fixed order.  No global
 //     atomics, and the summation order does not depend on scheduling.
-//   * rows that do not fit LDS (N > kMaxLdsRow) take the direct global-memory kernels below
-//     (correct for any N; the large-scene fast path is a cell-ordered gather).
+//   * rows that do not fit LDS (N > kMaxLdsRow = 16384): the forward takes the direct
+//     global-memory gather below; the backward tiles the support range, one LDS tile per block.
 #include "cl3d_common.h"
 
 namespace cl3d {
 
 constexpr int kMaxLdsRow = 16384;  // floats: 64 KiB, the no-opt-in dynamic LDS limit
+constexpr int kUnroll = 4;
 
 // ------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void group_fwd_lds_kernel(const float *__restrict__ points,
@@ -42,7 +43,25 @@ __global__ __launch_bounds__(256) void group_fwd_lds_kernel(const float *__restr
   if (((MK | chunk) & 3) == 0) {
     const int4 *i4 = reinterpret_cast<const int4 *>(ib);
     float4 *o4 = reinterpret_cast<float4 *>(ob);
-    for (int g = (e0 >> 2) + threadIdx.x; g < (e1 >> 2); g += 256) {
+    const int g1 = e1 >> 2;
+    int g = (e0 >> 2) + threadIdx.x;
+    // kUnroll index loads in flight per thread before the first LDS read: the loop is otherwise
+    // bound by the latency of one idx load per iteration
+    for (; g + (kUnroll - 1) * 256 < g1; g += kUnroll * 256) {
+      int4 ii[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) ii[u] = i4[g + u * 256];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        float4 v;
+        v.x = row[ii[u].x];
+        v.y = row[ii[u].y];
+        v.z = row[ii[u].z];
+        v.w = row[ii[u].w];
+        o4[g + u * 256] = v;
+      }
+    }
+    for (; g < g1; g += 256) {
       const int4 ii = i4[g];
       float4 v;
       v.x = row[ii.x];
@@ -72,17 +91,19 @@ __global__ __launch_bounds__(256) void group_fwd_direct_kernel(const float *__re
 template <int W>
 __global__ __launch_bounds__(64 * W) void group_bwd_lds_kernel(const float *__restrict__ grad_out,
                                                               const int *__restrict__ idx, int C,
-                                                              int N, int MK,
+                                                              int N, int MK, int T,
                                                               float *__restrict__ grad_points) {
-  extern __shared__ float acc[];  // [W][N]
+  extern __shared__ float acc[];  // [W][T]: this block owns support indices [n0, n0+T)
   const int bc = blockIdx.x;
   const int b = bc / C;
   const int wave = threadIdx.x >> 6;
   const int lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < W * N; i += 64 * W) acc[i] = 0.0f;
+  const int n0 = blockIdx.y * T;
+  const unsigned span = (unsigned)(N - n0 < T ? N - n0 : T);
+  for (int i = threadIdx.x; i < W * T; i += 64 * W) acc[i] = 0.0f;
   __syncthreads();
 
-  float *mine = acc + (size_t)wave * N;
+  float *mine = acc + (size_t)wave * T;
   const float *g = grad_out + (size_t)bc * MK;
   const int *ib = idx + (size_t)b * MK;
   // fixed slice per wave, multiple of 4 elements
@@ -93,38 +114,47 @@ __global__ __launch_bounds__(64 * W) void group_bwd_lds_kernel(const float *__re
   if ((MK & 3) == 0) {
     const int4 *i4 = reinterpret_cast<const int4 *>(ib);
     const float4 *g4 = reinterpret_cast<const float4 *>(g);
-    for (int q = (e0 >> 2) + lane; q < (e1 >> 2); q += 64) {
+    const int q1 = e1 >> 2;
+    int q = (e0 >> 2) + lane;
+    // 2*kUnroll independent 16-byte loads in flight per lane (the stream comes from HBM)
+    for (; q + (kUnroll - 1) * 64 < q1; q += kUnroll * 64) {
+      int4 ii[kUnroll];
+      float4 vv[kUnroll];
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        ii[u] = i4[q + u * 64];
+        vv[u] = g4[q + u * 64];
+      }
+#pragma unroll
+      for (int u = 0; u < kUnroll; ++u) {
+        if ((unsigned)(ii[u].x - n0) < span) atomicAdd(&mine[ii[u].x - n0], vv[u].x);
+        if ((unsigned)(ii[u].y - n0) < span) atomicAdd(&mine[ii[u].y - n0], vv[u].y);
+        if ((unsigned)(ii[u].z - n0) < span) atomicAdd(&mine[ii[u].z - n0], vv[u].z);
+        if ((unsigned)(ii[u].w - n0) < span) atomicAdd(&mine[ii[u].w - n0], vv[u].w);
+      }
+    }
+    for (; q < q1; q += 64) {
       const int4 ii = i4[q];
       const float4 v = g4[q];
-      atomicAdd(&mine[ii.x], v.x);
-      atomicAdd(&mine[ii.y], v.y);
-      atomicAdd(&mine[ii.z], v.z);
-      atomicAdd(&mine[ii.w], v.w);
+      if ((unsigned)(ii.x - n0) < span) atomicAdd(&mine[ii.x - n0], v.x);
+      if ((unsigned)(ii.y - n0) < span) atomicAdd(&mine[ii.y - n0], v.y);
+      if ((unsigned)(ii.z - n0) < span) atomicAdd(&mine[ii.z - n0], v.z);
+      if ((unsigned)(ii.w - n0) < span) atomicAdd(&mine[ii.w - n0], v.w);
     }
   } else {
-    for (int e = e0 + lane; e < e1; e += 64) atomicAdd(&mine[ib[e]], g[e]);
+    for (int e = e0 + lane; e < e1; e += 64) {
+      const int i = ib[e];
+      if ((unsigned)(i - n0) < span) atomicAdd(&mine[i - n0], g[e]);
+    }
   }
   __syncthreads();
-  float *dst = grad_points + (size_t)bc * N;
-  for (int i = threadIdx.x; i < N; i += 64 * W) {
+  float *dst = grad_points + (size_t)bc * N + n0;
+  for (int i = threadIdx.x; i < (int)span; i += 64 * W) {
     float s = acc[i];
 #pragma unroll
-    for (int w = 1; w < W; ++w) s += acc[(size_t)w * N + i];
+    for (int w = 1; w < W; ++w) s += acc[(size_t)w * T + i];
     dst[i] = s;
   }
-}
-
-__global__ __launch_bounds__(256) void group_bwd_direct_kernel(const float *__restrict__ grad_out,
-                                                               const int *__restrict__ idx, int C,
-                                                               int N, int MK,
-                                                               float *__restrict__ grad_points) {
-  const int bc = blockIdx.y;
-  const int b = bc / C;
-  const float *g = grad_out + (size_t)bc * MK;
-  const int *ib = idx + (size_t)b * MK;
-  float *dst = grad_points + (size_t)bc * N;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < MK; e += gridDim.x * 256)
-    atomicAdd(&dst[ib[e]], g[e]);
 }
 
 // -------------------------------------------------- fused relative-position + feature gather
@@ -216,23 +246,22 @@ extern "C" int cl3d_group_points_grad(const float *grad_out, const int32_t *idx,
     return CL3D_OK;
   }
   CL3D_REQUIRE(grad_out && idx, "group_points_grad: null pointer");
-  if (N <= cl3d::kMaxLdsRow) {
-    // W private rows; keep a block at <= 32 KiB of LDS when possible so >= 5 blocks share a CU
-    const size_t row = (size_t)N * sizeof(float);
-    if (row * 4 <= 32 * 1024 && MK >= 4096)
-      hipLaunchKernelGGL(cl3d::group_bwd_lds_kernel<4>, dim3(B * C), dim3(256), row * 4, st, grad_out, idx, C, N, MK, grad_points);
-    else if (row * 2 <= 32 * 1024 && MK >= 2048)
-      hipLaunchKernelGGL(cl3d::group_bwd_lds_kernel<2>, dim3(B * C), dim3(128), row * 2, st, grad_out, idx, C, N, MK, grad_points);
-    else
-      hipLaunchKernelGGL(cl3d::group_bwd_lds_kernel<1>, dim3(B * C), dim3(64), row, st, grad_out, idx, C, N, MK, grad_points);
-  } else {
-    CL3D_REQUIRE((long long)B * C <= 65535, "group_points_grad: B*C exceeds grid.y limit");
-    hipError_t e = hipMemsetAsync(grad_points, 0, (size_t)B * C * N * sizeof(float), st);
-    if (e != hipSuccess) return cl3d::fail(CL3D_E_LAUNCH, "group_points_grad: memset: %s", hipGetErrorString(e));
-    int gx = cl3d::ceil_div(MK, 256 * 8);
-    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
-    hipLaunchKernelGGL(cl3d::group_bwd_direct_kernel, dim3(gx, B * C), dim3(256), 0, st, grad_out, idx, C, N, MK, grad_points);
-  }
+  // Each block owns one (cloud, channel) row and one tile of T support indices, accumulated in W
+  // private LDS rows (one per wave, combined in a fixed order).  N <= 16384: a single tile; larger
+  // clouds sweep the grad_out row once per tile (still no global atomics, still order-fixed).
+  CL3D_REQUIRE((long long)B * C <= 0x7fffffffLL, "group_points_grad: B*C too large");
+  const int T = N <= cl3d::kMaxLdsRow ? N : cl3d::kMaxLdsRow;
+  const int ntiles = cl3d::ceil_div(N, T);
+  CL3D_REQUIRE(ntiles <= 65535, "group_points_grad: N too large");
+  const size_t row = (size_t)T * sizeof(float);
+  const dim3 grid(B * C, ntiles);
+  // keep a block at <= 32 KiB of LDS when possible so >= 5 blocks share a CU
+  if (row * 4 <= 32 * 1024 && MK >= 4096)
+    hipLaunchKernelGGL(cl3d::group_bwd_lds_kernel<4>, grid, dim3(256), row * 4, st, grad_out, idx, C, N, MK, T, grad_points);
+  else if (row * 2 <= 32 * 1024 && MK >= 2048)
+    hipLaunchKernelGGL(cl3d::group_bwd_lds_kernel<2>, grid, dim3(128), row * 2, st, grad_out, idx, C, N, MK, T, grad_points);
+  else
+    hipLaunchKernelGGL(cl3d::group_bwd_lds_kernel<1>, grid, dim3(64), row, st, grad_out, idx, C, N, MK, T, grad_points);
   return cl3d::check_launch("cl3d_group_points_grad");
 }
 

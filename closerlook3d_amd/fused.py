@@ -1,16 +1,263 @@
-"""Fused local-aggregation kernels (no [B,C,M,K] materialisation) -- Python side.
+"""Fused local-aggregation operators: Python side of csrc/fused_reduce.hip, fused_pwmlp.hip, csr.hip.
 
-`use_fused(impl, kind, module)` decides whether an operator instance takes the fused HIP path.
-Until a kind is listed in `_AVAILABLE` the operators run their 'grouped' dataflow (still on the HIP
-engine's native ops); `impl='fused'` on an unavailable kind raises instead of silently degrading.
+The reference's operators materialise the grouped neighbourhood tensor [B,C,M,K] and run element-wise
+PyTorch ops over it (models/local_aggregation_operators.py).  These entry points compute the same
+`[B, C_out, M]` result (up to the output transform, which stays ordinary PyTorch) from point-major
+feature rows with hand-written HIP kernels, forward and backward, without that tensor.
+
+`use_fused(impl, kind, module)` decides per operator instance; configurations the fused kernels do not
+cover (non-shipped variants such as PosPool with max reduction or a two-layer AdaptiveWeight MLP) run the
+'grouped' dataflow instead -- still on the engine's native ops -- and `impl='fused'` raises for them.
 """
-_AVAILABLE = set()
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from .pt_utils import _ball_query
+
+OP_POSPOOL_XYZ, OP_POSPOOL_SINCOS, OP_ADAPTIVE, OP_PSEUDOGRID = 0, 1, 2, 3
+_RED = {'sum': 0, 'avg': 1, 'mean': 1}
+
+
+def _supported(kind, m):
+    if kind == 'pospool':
+        return m.position_embedding in ('xyz', 'sin_cos') and m.reduction in _RED
+    if kind == 'adaptive_weight':
+        return m.weight_type == 'dp' and m.num_mlps == 1 and m.reduction in _RED
+    if kind == 'pointwisemlp':
+        return m.feature_type == 'dp_fi_df' and m.num_mlps == 1 and m.reduction == 'max' and m.nsample <= 255
+    if kind == 'pseudo_grid':
+        return m.KP_influence in ('linear', 'constant') and m.num_kernel_points <= 16 and m.convolution_mode == 'sum'
+    return False
 
 
 def use_fused(impl, kind, module):
     if impl == 'grouped':
         return False
-    ok = kind in _AVAILABLE
+    ok = _supported(kind, module)
+    if kind == 'pointwisemlp' and ok and not module.training and torch.is_grad_enabled():
+        ok = False  # backward through frozen BatchNorm statistics: only the grouped path implements it
     if impl == 'fused' and not ok:
-        raise NotImplementedError(f"fused path for '{kind}' is not built in this version")
+        raise NotImplementedError(f"fused path does not cover this '{kind}' configuration")
     return ok
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _stream(t):
+    return _lib.stream_ptr(t.device)
+
+
+def inverse_index(idx, n_support):
+    """CSR inverse of idx [B,M,K] (or [B,M]) -> (off [B,N+1], slots [B,MK]); memoised on the tensor."""
+    cached = getattr(idx, '_cl3d_inverse', None)
+    if cached is not None and cached[0] == n_support:
+        return cached[1], cached[2]
+    B = idx.shape[0]
+    MK = idx[0].numel()
+    off = torch.empty((B, n_support + 1), dtype=torch.int32, device=idx.device)
+    slots = torch.empty((B, MK), dtype=torch.int32, device=idx.device)
+    ws = torch.empty((B * n_support + B * MK,), dtype=torch.int32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _lib.check(_lib.lib().cl3d_build_inverse_index(_p(idx), B, n_support, MK, _p(off), _p(slots), _p(ws),
+                                                       ws.numel() * 4, _stream(idx)))
+    idx._cl3d_inverse = (n_support, off, slots)
+    return off, slots
+
+
+class _FusedReduce(Function):
+    """out[b,c,j] = reduce_k w_c(rel) * mask * f[b,c,idx]  (PosPool / AdaptiveWeight / PseudoGrid)."""
+
+    @staticmethod
+    def forward(ctx, features, p0, p1, op, query_xyz, support_xyz, query_mask, idx, idx_mask, radius,
+                normalize, reduction, pint, pfloat, constant):
+        B, C, N = features.shape
+        _, M, K = idx.shape
+        ft = features.transpose(1, 2).contiguous()
+        out_t = torch.empty((B, M, C), dtype=torch.float32, device=features.device)
+        need_grad = any(ctx.needs_input_grad[:3])
+        slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=features.device) if need_grad else None
+        with torch.cuda.device(features.device):
+            _lib.check(_lib.lib().cl3d_fused_reduce_fwd(
+                op, _p(query_xyz), _p(support_xyz), _p(query_mask), _p(idx), _p(idx_mask), _p(ft), B, N, M, K, C,
+                float(radius), int(normalize), reduction, _p(p0), _p(p1), pint, float(pfloat), int(constant),
+                _p(out_t), _p(slotrec), _stream(features)))
+        ctx.save_for_backward(ft, slotrec, p0, p1)
+        ctx.idx = idx
+        ctx.meta = (op, B, N, M, K, C, pint, pfloat, constant)
+        return out_t.transpose(1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, gout):
+        ft, slotrec, p0, p1 = ctx.saved_tensors
+        op, B, N, M, K, C, pint, pfloat, constant = ctx.meta
+        gout_t = gout.transpose(1, 2).contiguous()
+        off, slots = inverse_index(ctx.idx, N)
+        dft = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
+        lib = _lib.lib()
+        nparts = lib.cl3d_fused_param_partials(op, B, N, C)
+        npar = {OP_ADAPTIVE: 4, OP_PSEUDOGRID: 16}.get(op, 0)
+        dparam = torch.empty((nparts, C, npar), dtype=torch.float32, device=gout.device) if nparts else None
+        with torch.cuda.device(gout.device):
+            _lib.check(lib.cl3d_fused_reduce_bwd(op, _p(gout_t), _p(ft), _p(slotrec), _p(off), _p(slots), B, N, M, K,
+                                                 C, _p(p0), _p(p1), pint, float(pfloat), int(constant), _p(dft),
+                                                 _p(dparam), nparts, _stream(gout)))
+        g0 = g1 = None
+        if op == OP_ADAPTIVE:
+            d = dparam.sum(0).view(C // pint, pint, 4).sum(1)  # fixed-order reductions
+            g0, g1 = d[:, :3].contiguous(), d[:, 3].contiguous()
+        elif op == OP_PSEUDOGRID:
+            g1 = dparam.sum(0)[:, :pint].t().contiguous()
+        return (dft.transpose(1, 2), g0, g1) + (None,) * 12
+
+
+def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample):
+    return _ball_query(query_xyz.contiguous(), support_xyz.contiguous(), query_mask.contiguous(),
+                       support_mask.contiguous(), radius, nsample)
+
+
+def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, embedding, reduction):
+    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+    C = features.shape[1]
+    if embedding == 'xyz':
+        if C % 3:
+            raise RuntimeError(f"PosPool xyz needs C % 3 == 0, got {C}")
+        op, p0 = OP_POSPOOL_XYZ, None
+    else:
+        if C % 6:
+            raise RuntimeError(f"PosPool sin_cos needs C % 6 == 0, got {C}")
+        fd = C // 6
+        op = OP_POSPOOL_SINCOS
+        p0 = torch.pow(1.0 * 1000, (1.0 / fd) * torch.arange(fd, dtype=torch.float32, device=features.device))
+    return _FusedReduce.apply(features, p0, None, op, query_xyz, support_xyz, query_mask, idx, idx_mask, radius,
+                              True, _RED[reduction], 0, 0.0, False)
+
+
+def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps,
+                    shared_channels, reduction):
+    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+    conv = mlps.conv0
+    w = conv.weight.view(conv.weight.shape[0], 3)
+    return _FusedReduce.apply(features, w, conv.bias, OP_ADAPTIVE, query_xyz, support_xyz, query_mask, idx,
+                              idx_mask, radius, True, _RED[reduction], int(shared_channels), 0.0, False)
+
+
+def pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, k_points,
+                kernel_weights, extent, influence):
+    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+    return _FusedReduce.apply(features, k_points.contiguous(), kernel_weights, OP_PSEUDOGRID, query_xyz,
+                              support_xyz, query_mask, idx, idx_mask, radius, False, _RED['sum'],
+                              int(k_points.shape[0]), 1.0 / float(extent), influence == 'constant')
+
+
+class _PointwiseMLP(Function):
+    """max_k ReLU(BN(W_r rel + H[centre] + G[nbr])) on point-major rows; see csrc/fused_pwmlp.hip."""
+
+    @staticmethod
+    def forward(ctx, ght, wr, gamma, beta, running_mean, running_var, query_xyz, support_xyz, idx, radius,
+                training, momentum, eps):
+        B, N, two_co = ght.shape
+        Co = two_co // 2
+        _, M, K = idx.shape
+        dev = ght.device
+        lib = _lib.lib()
+        n = B * M * K
+        nparts = lib.cl3d_pwmlp_partials(B, M, Co)
+        with torch.cuda.device(dev):
+            if training:
+                partial = torch.empty((nparts, Co, 4), dtype=torch.float64, device=dev)
+                _lib.check(lib.cl3d_pwmlp_stats(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), B, N, M, K,
+                                                Co, float(radius), _p(partial), nparts, _stream(ght)))
+                sums = partial[:, :, :2].sum(0)
+                mean64 = sums[:, 0] / n
+                var64 = (sums[:, 1] / n - mean64 * mean64).clamp_min(0.0)
+                invstd64 = torch.rsqrt(var64 + eps)
+                if running_mean is not None:
+                    with torch.no_grad():
+                        running_mean.mul_(1 - momentum).add_(mean64.float(), alpha=momentum)
+                        running_var.mul_(1 - momentum).add_((var64 * (n / max(n - 1, 1))).float(), alpha=momentum)
+            else:
+                mean64 = running_mean.double()
+                invstd64 = torch.rsqrt(running_var.double() + eps)
+            scale64 = gamma.double() * invstd64
+            scale = scale64.float()
+            shift = (beta.double() - mean64 * scale64).float()
+            out_t = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
+            need_grad = any(ctx.needs_input_grad[:4])
+            kstar = torch.empty((B, M, Co), dtype=torch.uint8, device=dev) if need_grad else None
+            slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev) if need_grad else None
+            _lib.check(lib.cl3d_pwmlp_fwd(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(scale),
+                                          _p(shift), B, N, M, K, Co, float(radius), _p(out_t), _p(kstar), _p(slotrec),
+                                          _stream(ght)))
+        if need_grad:
+            if not training:
+                raise NotImplementedError("fused PointWiseMLP backward needs training-mode BatchNorm")
+            ctx.save_for_backward(ght, wr, gamma, scale, shift, mean64.float(), invstd64.float(), kstar, slotrec,
+                                  query_xyz, support_xyz)
+            ctx.idx = idx
+            ctx.meta = (B, N, M, K, Co, float(radius), nparts)
+        return out_t.transpose(1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, gout):
+        ght, wr, gamma, scale, shift, mean, invstd, kstar, slotrec, query_xyz, support_xyz = ctx.saved_tensors
+        B, N, M, K, Co, radius, nparts = ctx.meta
+        idx = ctx.idx
+        dev = gout.device
+        lib = _lib.lib()
+        n = B * M * K
+        gout_t = gout.transpose(1, 2).contiguous()
+        with torch.cuda.device(dev):
+            st = _stream(gout)
+            dzs = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
+            partial = torch.empty((nparts, Co, 4), dtype=torch.float64, device=dev)
+            _lib.check(lib.cl3d_pwmlp_bwd_sparse(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(scale),
+                                                 _p(shift), _p(mean), _p(invstd), _p(gout_t), _p(kstar), B, N, M, K,
+                                                 Co, radius, _p(dzs), _p(partial), nparts, st))
+            sums = partial[:, :, :2].sum(0)
+            dbeta64, dgamma64 = sums[:, 0], sums[:, 1]
+            # BatchNorm backward is affine in y:  dy = A dz + Bc + D y
+            A64 = gamma.double() * invstd.double()
+            D64 = -A64 * invstd.double() * dgamma64 / n
+            Bc64 = -A64 * dbeta64 / n - D64 * mean.double()
+            cA, cB, cD = A64.float(), Bc64.float(), D64.float()
+            sq = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
+            partial2 = torch.empty((nparts, Co, 4), dtype=torch.float64, device=dev)
+            _lib.check(lib.cl3d_pwmlp_bwd_query(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(cA),
+                                                _p(cB), _p(cD), _p(dzs), _p(kstar), B, N, M, K, Co, radius, _p(sq),
+                                                _p(partial2), nparts, st))
+            dwr = partial2[:, :, :3].sum(0).float()
+            off, slots = inverse_index(idx, N)
+            centre = getattr(idx, '_cl3d_centre', None)
+            if centre is None:
+                centre = idx[:, :, 0].contiguous()
+                idx._cl3d_centre = centre
+            coff, cslots = inverse_index(centre, N)
+            dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
+            _lib.check(lib.cl3d_pwmlp_bwd_support(_p(idx), _p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(dzs), _p(kstar),
+                                                  _p(slotrec), _p(sq), _p(off), _p(slots), _p(coff), _p(cslots), B, N,
+                                                  M, K, Co, _p(dght), st))
+        return (dght, dwr, dgamma64.float(), dbeta64.float()) + (None,) * 9
+
+
+def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps, reduction,
+                  training):
+    assert reduction == 'max'
+    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+    conv, bn = mlps.conv0[0], mlps.conv0[1]
+    C = features.shape[1]
+    Co = conv.weight.shape[0]
+    W = conv.weight.view(Co, 3 + 2 * C)
+    wr = W[:, :3].contiguous()
+    wc, wd = W[:, 3:3 + C], W[:, 3 + C:]
+    # once per point instead of once per (point, neighbour): rows [W_d f_i | (W_c - W_d) f_i]
+    ght = torch.matmul(features.transpose(1, 2), torch.cat([wd, wc - wd], 0).t())
+    use_batch_stats = training or bn.running_mean is None
+    if use_batch_stats and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    momentum = bn.momentum if bn.momentum is not None else 0.1
+    return _PointwiseMLP.apply(ght.contiguous(), wr, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                               query_xyz.contiguous(), support_xyz.contiguous(), idx, radius, use_batch_stats,
+                               momentum, bn.eps)

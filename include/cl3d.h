@@ -104,6 +104,66 @@ int cl3d_group_xyz_features(const float *query_xyz, const float *support_xyz,
                             int K, float radius, int normalize_xyz, float *rel, float *grouped,
                             cl3d_stream_t stream);
 
+/* ---- fused local-aggregation operators (no [B,C,M,K] tensor) -----------------------------------
+ * These replace, each in one or a few launches, what the reference's Python does after the grouper
+ * in models/local_aggregation_operators.py.  Features and outputs are POINT-MAJOR here:
+ * ft [B,N,C], out_t [B,M,C] (the Python layer transposes at the operator boundary). */
+
+/* CSR inverse of a neighbour-index tensor: inv_off [B,N+1], inv_slots [B,MK] (ascending slot ids per
+ * support point).  ws: (B*N + B*MK) * 4 bytes.  Used by every fused backward pass (ordered gather
+ * instead of the reference's atomicAdd scatter, group_points_gpu.cu:65). */
+int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK, int32_t *inv_off,
+                             int32_t *inv_slots, void *ws, size_t ws_bytes, cl3d_stream_t stream);
+
+/* op: 0 PosPool xyz, 1 PosPool sin_cos (p0 = dim table [C/6]), 2 AdaptiveWeight 'dp' with one conv
+ * (p0 = W [C/S,3], p1 = bias [C/S], pint = S), 3 PseudoGrid (p0 = K_points [P,3], p1 = kernel_weights
+ * [P,C], pint = P, pfloat = 1/extent).  reduction: 0 sum, 1 avg (masked as the reference does,
+ * local_aggregation_operators.py:92-103).  Replaces PosPool.forward :65-103, AdaptiveWeight.forward
+ * :188-214, PseudoGrid.forward :383-419 up to the output transform.
+ * slotrec [B,M,K,4] (nullable) receives what the backward pass needs per slot. */
+int cl3d_fused_reduce_fwd(int op, const float *query_xyz, const float *support_xyz,
+                          const int32_t *query_mask, const int32_t *idx, const int32_t *idx_mask,
+                          const float *ft, int B, int N, int M, int K, int C, float radius,
+                          int normalize_xyz, int reduction, const float *p0, const float *p1, int pint,
+                          float pfloat, int constant_influence, float *out_t, float *slotrec,
+                          cl3d_stream_t stream);
+/* number of partial blocks of the parameter-gradient buffer dparam [n, C, NP] (NP = 4 adaptive:
+ * dW[:,0..2], dbias; 16 pseudo grid: d kernel_weights[p]); 0 for operators without parameters. */
+int cl3d_fused_param_partials(int op, int B, int N, int C);
+int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *ft, const float *slotrec,
+                          const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K,
+                          int C, const float *p0, const float *p1, int pint, float pfloat,
+                          int constant_influence, float *dft, float *dparam, int n_partials,
+                          cl3d_stream_t stream);
+
+/* PointWiseMLP 'dp_fi_df', one Conv2d+BatchNorm2d+ReLU layer, max reduction
+ * (local_aggregation_operators.py:288-301).  ght [B,N,2*Co]: row i = [W_d f_i | (W_c - W_d) f_i];
+ * wr [Co,3] = the conv weight's columns for the relative position.  See csrc/fused_pwmlp.hip. */
+int cl3d_pwmlp_partials(int B, int M, int Co);
+int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
+                     const float *ght, const float *wr, int B, int N, int M, int K, int Co, float radius,
+                     double *partial, int n_partials, cl3d_stream_t stream);
+int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, const int32_t *idx,
+                   const float *ght, const float *wr, const float *scale, const float *shift, int B,
+                   int N, int M, int K, int Co, float radius, float *out_t, unsigned char *kstar_t,
+                   float *slotrec, cl3d_stream_t stream);
+int cl3d_pwmlp_bwd_sparse(const float *query_xyz, const float *support_xyz, const int32_t *idx,
+                          const float *ght, const float *wr, const float *scale, const float *shift,
+                          const float *mean, const float *invstd, const float *gout_t,
+                          const unsigned char *kstar_t, int B, int N, int M, int K, int Co, float radius,
+                          float *dzs_t, double *partial, int n_partials, cl3d_stream_t stream);
+int cl3d_pwmlp_bwd_query(const float *query_xyz, const float *support_xyz, const int32_t *idx,
+                         const float *ght, const float *wr, const float *cA, const float *cB,
+                         const float *cD, const float *dzs_t, const unsigned char *kstar_t, int B, int N,
+                         int M, int K, int Co, float radius, float *sq_t, double *partial, int n_partials,
+                         cl3d_stream_t stream);
+int cl3d_pwmlp_bwd_support(const int32_t *idx, const float *ght, const float *wr, const float *cA,
+                           const float *cB, const float *cD, const float *dzs_t,
+                           const unsigned char *kstar_t, const float *slotrec, const float *sq_t,
+                           const int32_t *inv_off, const int32_t *inv_slots, const int32_t *cen_off,
+                           const int32_t *cen_slots, int B, int N, int M, int K, int Co, float *dght,
+                           cl3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,8 +19,8 @@ echo "== bench" | tee -a $OUT/summary.txt
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
 cat $OUT/bench.json | tee -a $OUT/summary.txt
 echo "== rocprofv3 kernel trace of the same bench command" | tee -a $OUT/summary.txt
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
 find $OUT/prof -name '*stats*' | head -5 | tee -a $OUT/summary.txt
 # keep the merged output small: drop raw traces, keep stats
-find $OUT/prof -type f ! -name '*stats*' -size +2M -delete 2>/dev/null
+find $OUT/prof -type f ! -name "*stats*" -size +1M -delete 2>/dev/null
 echo "== done" | tee -a $OUT/summary.txt

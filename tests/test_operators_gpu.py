@@ -82,4 +82,106 @@ def test_resnet_and_seg_head_match_reference(kind):
     assert_close(ep["res5_features"].detach().cpu().numpy(), fx["out2"], 2e-4, "res5_features")
     assert_close(logits.detach().cpu().numpy(), fx["out"], 2e-4, "logits")
     (logits * torch.from_numpy(fx["probe"]).cuda()).sum().backward()
-    assert_close(feats.grad.cpu().numpy(), fx["grad_features"], 1e-3, "d logits / d input features")
+    got, want = feats.grad.cpu().numpy().astype(np.float64), fx["grad_features"].astype(np.float64)
+    # arg-max routing makes the input gradient discontinuous: near-ties can pick another neighbour, so
+    # the deep-network gradient is compared in norm, not element by element
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert rel < 2e-2, f"relative L2 error of d logits / d input features: {rel:.3e}"
+
+
+# ---------------------------------------------------------------- fused kernels at realistic widths
+FUSED_CASES = [
+    # kind, overrides, C, K, N, in-radius multiple
+    ("pospool", {"pospool__position_embedding": "xyz", "pospool__reduction": "avg"}, 72, 32, 1024, 1.5),
+    ("pospool", {"pospool__position_embedding": "sin_cos", "pospool__reduction": "avg"}, 72, 16, 512, 4.0),
+    ("pospool", {"pospool__position_embedding": "xyz", "pospool__reduction": "sum"}, 9, 20, 300, 1.5),   # V=1 path
+    ("adaptive_weight", {"adaptive_weight__num_mlps": 1, "adaptive_weight__reduction": "avg"}, 64, 32, 1024, 1.5),
+    ("adaptive_weight", {"adaptive_weight__num_mlps": 1, "adaptive_weight__shared_channels": 4,
+                         "adaptive_weight__reduction": "sum"}, 144, 23, 512, 4.0),
+    ("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df", "pointwisemlp__num_mlps": 1,
+                      "pointwisemlp__reduction": "max"}, 64, 32, 1024, 1.5),
+    ("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df", "pointwisemlp__num_mlps": 1,
+                      "pointwisemlp__reduction": "max"}, 18, 9, 300, 4.0),                              # V=1 path
+    ("pseudo_grid", {"pseudo_grid__KP_influence": "linear"}, 64, 26, 1024, 1.5),
+    ("pseudo_grid", {"pseudo_grid__KP_influence": "constant"}, 36, 16, 400, 4.0),
+]
+
+
+@pytest.mark.parametrize("kind,over,C,K,N,mult", FUSED_CASES)
+def test_fused_operator_matches_oracle(kind, over, C, K, N, mult):
+    """impl='fused' (must not fall back) against the CPU oracle, forward and all gradients."""
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    from oracle import operators as oo
+    from tests.helpers import oracle_operator
+    B = 2
+    rng = np.random.default_rng(C * 1000 + K)
+    xyz, mask = oo.make_cloud(rng, B, N, kind="uniform", pad_frac=0.0)
+    x1, m1 = oo.make_cloud(rng, 1, N, kind="planes", pad_frac=0.2)
+    xyz[-1], mask[-1] = x1[0], m1[0]
+    feats = rng.standard_normal((B, C, N)).astype(np.float32)
+    radius = float((mult * K * 3 / (4 * np.pi * N)) ** (1 / 3))
+    torch.manual_seed(C + K)
+    mod = LocalAggregation(C, C, radius, K, default_config(kind, over, cl3d_impl="fused"))
+    with torch.no_grad():
+        for m in mod.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    state = {"state__" + k: v.detach().clone().numpy() for k, v in mod.state_dict().items()}
+    probe = rng.standard_normal((B, C, N)).astype(np.float32)
+    fx = dict(state, xyz=xyz, mask=mask, features=feats, radius=np.float32(radius), nsample=np.int32(K),
+              training=np.int32(1), kind=kind, over=over, probe=probe)
+    want, want_gf, want_grads = oracle_operator(fx)
+
+    mod = mod.cuda().train(True)
+    t_xyz, t_mask = torch.from_numpy(xyz).cuda(), torch.from_numpy(mask).cuda()
+    f = torch.from_numpy(feats).cuda().requires_grad_(True)
+    out = mod(t_xyz, t_xyz, t_mask, t_mask, f)
+    (out * torch.from_numpy(probe).cuda()).sum().backward()
+    assert_close(out.detach().cpu().numpy(), want.numpy(), 1e-5, f"{kind} fused out")
+    assert_close(f.grad.cpu().numpy(), want_gf.numpy(), 5e-5, f"{kind} fused grad_features")
+    for k, p in mod.named_parameters():
+        if k in want_grads:
+            scale = float(want_grads[k].abs().max()) + 1e-12
+            assert_close(p.grad.cpu().numpy() / scale, want_grads[k].numpy() / scale, 2e-5, f"{kind} fused grad {k}")
+    # run-to-run repeatability of the fused backward (ordered gathers, no float atomics)
+    f2 = torch.from_numpy(feats).cuda().requires_grad_(True)
+    mod.zero_grad()
+    out2 = mod(t_xyz, t_xyz, t_mask, t_mask, f2)
+    (out2 * torch.from_numpy(probe).cuda()).sum().backward()
+    assert torch.equal(out, out2) and torch.equal(f.grad, f2.grad)
+
+
+def test_inverse_index_matches_numpy():
+    from closerlook3d_amd.fused import inverse_index
+    rng = np.random.default_rng(4)
+    B, N, M, K = 3, 500, 321, 17
+    idx = rng.integers(0, N, (B, M, K)).astype(np.int32)
+    idx[0, :, :] = 7  # one support point referenced by every slot of cloud 0 (segment of 5457 entries)
+    off, slots = inverse_index(torch.from_numpy(idx).cuda(), N)
+    off, slots = off.cpu().numpy(), slots.cpu().numpy()
+    for b in range(B):
+        flat = idx[b].reshape(-1)
+        order = np.argsort(flat, kind="stable")
+        assert np.array_equal(slots[b], order.astype(np.int32))
+        counts = np.bincount(flat, minlength=N)
+        assert np.array_equal(off[b], np.concatenate([[0], np.cumsum(counts)]).astype(np.int32))
+
+
+def test_eval_mode_inference_paths_agree():
+    """eval-mode (running statistics) forward: fused == grouped for every operator kind."""
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    from oracle import operators as oo
+    rng = np.random.default_rng(8)
+    B, N, K, C = 2, 512, 16, 24
+    xyz, mask = oo.make_cloud(rng, B, N, pad_frac=0.1)
+    feats = rng.standard_normal((B, C, N)).astype(np.float32)
+    t = [torch.from_numpy(a).cuda() for a in (xyz, xyz, mask, mask, feats)]
+    for kind, over in (("pospool", {"pospool__reduction": "avg"}), ("adaptive_weight", {}),
+                       ("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df"}), ("pseudo_grid", {})):
+        torch.manual_seed(1)
+        a = LocalAggregation(C, C, 0.2, K, default_config(kind, over, cl3d_impl="fused")).cuda().eval()
+        b = LocalAggregation(C, C, 0.2, K, default_config(kind, over, cl3d_impl="grouped")).cuda().eval()
+        b.load_state_dict(a.state_dict())
+        with torch.no_grad():
+            assert_close(a(*t).cpu().numpy(), b(*t).cpu().numpy(), 1e-5, f"{kind} eval fused vs grouped")
