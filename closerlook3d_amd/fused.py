@@ -72,12 +72,11 @@ class _FusedReduce(Function):
 
     @staticmethod
     def forward(ctx, features, p0, p1, op, query_xyz, support_xyz, query_mask, idx, idx_mask, radius,
-                normalize, reduction, pint, pfloat, constant):
+                normalize, reduction, pint, pfloat, constant, need_grad):
         B, C, N = features.shape
         _, M, K = idx.shape
         ft = features.transpose(1, 2).contiguous()
         out_t = torch.empty((B, M, C), dtype=torch.float32, device=features.device)
-        need_grad = any(ctx.needs_input_grad[:3])
         slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=features.device) if need_grad else None
         with torch.cuda.device(features.device):
             _lib.check(_lib.lib().cl3d_fused_reduce_fwd(
@@ -110,7 +109,11 @@ class _FusedReduce(Function):
             g0, g1 = d[:, :3].contiguous(), d[:, 3].contiguous()
         elif op == OP_PSEUDOGRID:
             g1 = dparam.sum(0)[:, :pint].t().contiguous()
-        return (dft.transpose(1, 2), g0, g1) + (None,) * 12
+        return (dft.transpose(1, 2), g0, g1) + (None,) * 13
+
+
+def _wants_grad(*tensors):
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample):
@@ -132,7 +135,7 @@ def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, 
         op = OP_POSPOOL_SINCOS
         p0 = torch.pow(1.0 * 1000, (1.0 / fd) * torch.arange(fd, dtype=torch.float32, device=features.device))
     return _FusedReduce.apply(features, p0, None, op, query_xyz, support_xyz, query_mask, idx, idx_mask, radius,
-                              True, _RED[reduction], 0, 0.0, False)
+                              True, _RED[reduction], 0, 0.0, False, _wants_grad(features))
 
 
 def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps,
@@ -141,7 +144,8 @@ def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, 
     conv = mlps.conv0
     w = conv.weight.view(conv.weight.shape[0], 3)
     return _FusedReduce.apply(features, w, conv.bias, OP_ADAPTIVE, query_xyz, support_xyz, query_mask, idx,
-                              idx_mask, radius, True, _RED[reduction], int(shared_channels), 0.0, False)
+                              idx_mask, radius, True, _RED[reduction], int(shared_channels), 0.0, False,
+                              _wants_grad(features, w, conv.bias))
 
 
 def pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, k_points,
@@ -149,7 +153,8 @@ def pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, features, radi
     idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
     return _FusedReduce.apply(features, k_points.contiguous(), kernel_weights, OP_PSEUDOGRID, query_xyz,
                               support_xyz, query_mask, idx, idx_mask, radius, False, _RED['sum'],
-                              int(k_points.shape[0]), 1.0 / float(extent), influence == 'constant')
+                              int(k_points.shape[0]), 1.0 / float(extent), influence == 'constant',
+                              _wants_grad(features, kernel_weights))
 
 
 class _PointwiseMLP(Function):
@@ -157,7 +162,7 @@ class _PointwiseMLP(Function):
 
     @staticmethod
     def forward(ctx, ght, wr, gamma, beta, running_mean, running_var, query_xyz, support_xyz, idx, radius,
-                training, momentum, eps):
+                training, momentum, eps, need_grad):
         B, N, two_co = ght.shape
         Co = two_co // 2
         _, M, K = idx.shape
@@ -185,7 +190,6 @@ class _PointwiseMLP(Function):
             scale = scale64.float()
             shift = (beta.double() - mean64 * scale64).float()
             out_t = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
-            need_grad = any(ctx.needs_input_grad[:4])
             kstar = torch.empty((B, M, Co), dtype=torch.uint8, device=dev) if need_grad else None
             slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev) if need_grad else None
             _lib.check(lib.cl3d_pwmlp_fwd(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(scale),
@@ -239,7 +243,7 @@ class _PointwiseMLP(Function):
             _lib.check(lib.cl3d_pwmlp_bwd_support(_p(idx), _p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(dzs), _p(kstar),
                                                   _p(slotrec), _p(sq), _p(off), _p(slots), _p(coff), _p(cslots), B, N,
                                                   M, K, Co, _p(dght), st))
-        return (dght, dwr, dgamma64.float(), dbeta64.float()) + (None,) * 9
+        return (dght, dwr, dgamma64.float(), dbeta64.float()) + (None,) * 10
 
 
 def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps, reduction,
@@ -260,4 +264,4 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
     momentum = bn.momentum if bn.momentum is not None else 0.1
     return _PointwiseMLP.apply(ght.contiguous(), wr, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                query_xyz.contiguous(), support_xyz.contiguous(), idx, radius, use_batch_stats,
-                               momentum, bn.eps)
+                               momentum, bn.eps, _wants_grad(features, conv.weight, bn.weight, bn.bias))
