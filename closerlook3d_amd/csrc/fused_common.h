@@ -40,6 +40,32 @@ inline LaneMap pick_lane_map(int C, int V) {
   return m;
 }
 
+// ---- XCD-aware tile order.  The fused kernels gather point-major rows of one cloud over and over
+// (C*4 bytes per neighbour); a cloud's rows (1-2 MB) fit the 4 MiB L2 of one XCD, all clouds together
+// do not.  The dispatcher is observed to place workgroup b on XCD b % 8 (MI355X_MICROARCH.md), so the
+// virtual tile id v = x + 8*s is decoded as "XCD x works through clouds x, x+8, ... one after the
+// other".  This is a speed hint only: any placement computes the same result.  Used when B is a
+// multiple of 8; otherwise tiles are simply cloud-major.
+// grid sizes of grid-stride kernels are kept multiples of 8 so a block stays on its XCD across iterations
+inline int round_grid(long long want, int cap) {
+  long long g = want < cap ? want : cap;
+  if (g >= 8) g &= ~7LL;
+  return (int)(g < 1 ? 1 : g);
+}
+inline int virtual_tiles(int B, int tiles_per_cloud) {
+  return B * tiles_per_cloud;
+}
+__device__ __forceinline__ void decode_tile(int v, int B, int tiles_per_cloud, int &b, int &tile) {
+  if ((B & 7) == 0) {
+    const int x = v & 7, s = v >> 3;
+    b = x + 8 * (s / tiles_per_cloud);
+    tile = s - (s / tiles_per_cloud) * tiles_per_cloud;
+  } else {
+    b = v / tiles_per_cloud;
+    tile = v - b * tiles_per_cloud;
+  }
+}
+
 template <int V>
 struct Vec {
   float v[V];

@@ -104,8 +104,9 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
     }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      const int b = tile / tiles_per_cloud;
-      const int j0 = (tile - b * tiles_per_cloud) * TQ;
+      int b, tq;
+      decode_tile(tile, a.B, tiles_per_cloud, b, tq);
+      const int j0 = tq * TQ;
       const float *q = a.query_xyz + (size_t)b * M * 3;
       const float *s = a.support_xyz + (size_t)b * N * 3;
       __syncthreads();  // previous tile's readers are done with slot4
@@ -277,8 +278,9 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
       cD[v] = a.v2[c];
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      const int b = tile / tiles_per_cloud;
-      const int i = (tile - b * tiles_per_cloud) * TR + wave * QW + g;
+      int b, tr;
+      decode_tile(tile, a.B, tiles_per_cloud, b, tr);
+      const int i = tr * TR + wave * QW + g;
       if (i >= N) continue;
       const float *rows = a.ght + (size_t)b * N * row;
       const int *ib = a.idx + (size_t)b * MK;
@@ -359,8 +361,7 @@ static int launch_query(PwArgs &a, int nacc, int n_partials, hipStream_t st, con
   if (lds > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "%s: nsample=%d needs %zu B of LDS", who, a.K, lds);
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)a.B * ceil_div(a.M, 4 * m.QW);
-  int gx = nacc > 0 ? n_partials : (int)(tiles < 8192 ? tiles : 8192);
-  if (gx < 1) gx = 1;
+  const int gx = nacc > 0 ? n_partials : round_grid(tiles, 8192);
   if (V == 4) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4>), dim3(gx), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1>), dim3(gx), dim3(256), lds, st, a);
   return check_launch(who);
@@ -370,8 +371,7 @@ static int launch_query(PwArgs &a, int nacc, int n_partials, hipStream_t st, con
 
 extern "C" int cl3d_pwmlp_partials(int B, int M, int Co) {
   (void)Co;
-  long long tiles = ((long long)B * M + 15) / 16;
-  return (int)(tiles < 1 ? 1 : (tiles > 2048 ? 2048 : tiles));
+  return cl3d::round_grid(((long long)B * M + 15) / 16, 2048);
 }
 
 extern "C" int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
@@ -466,7 +466,7 @@ extern "C" int cl3d_pwmlp_bwd_support(const int32_t *idx, const float *ght, cons
   const LaneMap m = pick_lane_map(Co, V);
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
-  const int gx = (int)(tiles < 8192 ? (tiles < 1 ? 1 : tiles) : 8192);
+  const int gx = round_grid(tiles, 8192);
   if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((pwmlp_support_kernel<1>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_bwd_support");

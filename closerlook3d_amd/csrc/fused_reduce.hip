@@ -102,8 +102,9 @@ __global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
   float *coef = reinterpret_cast<float *>(slot4 + TQ * K);  // [TQ*K] mask weight
   float *cntq = coef + TQ * K;                            // [TQ]
   float *hbuf = cntq + TQ;                                // PseudoGrid: [TQ*K][kMaxKP]
-  const int b = blockIdx.y;
-  const int j0 = blockIdx.x * TQ;
+  int b, tq;
+  decode_tile(blockIdx.x, a.B, (M + TQ - 1) / TQ, b, tq);
+  const int j0 = tq * TQ;
   const float *q = a.query_xyz + (size_t)b * M * 3;
   const float *s = a.support_xyz + (size_t)b * N * 3;
 
@@ -277,8 +278,9 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
       }
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      const int b = tile / tiles_per_cloud;
-      const int i = (tile - b * tiles_per_cloud) * TR + wave * QW + g;
+      int b, tr;
+      decode_tile(tile, a.B, tiles_per_cloud, b, tr);
+      const int i = tr * TR + wave * QW + g;
       if (!chan_on || i >= N) continue;
       const int *off = a.inv_off + (size_t)b * (N + 1);
       const int *slots = a.inv_slots + (size_t)b * MK;
@@ -376,7 +378,6 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
 
 static int check_common(const ReduceArgs &a, const char *who) {
   if (a.B < 0 || a.N < 1 || a.M < 0 || a.K < 1 || a.C < 1) return fail(CL3D_E_INVALID, "%s: bad sizes", who);
-  if (a.B > 65535) return fail(CL3D_E_UNSUPPORTED, "%s: B exceeds grid.y limit", who);
   if ((long long)a.M * a.K > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "%s: M*K too large", who);
   return CL3D_OK;
 }
@@ -444,9 +445,7 @@ static LaneMap fwd_lane_map(int op, int C, int K, int V, size_t *lds_out) {
 extern "C" int cl3d_fused_param_partials(int op, int B, int N, int C) {
   (void)C;
   if (op != cl3d::OP_ADAPTIVE && op != cl3d::OP_PSEUDOGRID) return 0;
-  long long rows = (long long)B * N;
-  long long tiles = (rows + 3) / 4;
-  return (int)(tiles < 1024 ? (tiles < 1 ? 1 : tiles) : 1024);
+  return cl3d::round_grid(((long long)B * N + 3) / 4, 1024);
 }
 
 extern "C" int cl3d_fused_reduce_fwd(int op, const float *query_xyz, const float *support_xyz,
@@ -476,7 +475,7 @@ extern "C" int cl3d_fused_reduce_fwd(int op, const float *query_xyz, const float
   const LaneMap m = fwd_lane_map(op, C, K, V, &lds);
   if (lds > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "fused_reduce_fwd: nsample=%d needs %zu B of LDS per block", K, lds);
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
-  dim3 grid(ceil_div(M, 4 * m.QW), B);
+  dim3 grid(virtual_tiles(B, ceil_div(M, 4 * m.QW)));
   if (V == 4) launch_fwd<4>(op, a, grid, lds, (hipStream_t)stream);
   else launch_fwd<1>(op, a, grid, lds, (hipStream_t)stream);
   return check_launch("cl3d_fused_reduce_fwd");
@@ -511,8 +510,7 @@ extern "C" int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *f
   const size_t lds = (size_t)waves * m.QW * m.L * V * NP * sizeof(float);
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)B * ceil_div(N, waves * m.QW);
-  int gx = has_params ? n_partials : (int)(tiles < 4096 ? tiles : 4096);
-  if (gx < 1) gx = 1;
+  const int gx = has_params ? n_partials : round_grid(tiles, 4096);
   if (V == 4) launch_bwd<4>(op, a, dim3(gx), dim3(64 * waves), lds, (hipStream_t)stream);
   else launch_bwd<1>(op, a, dim3(gx), dim3(64 * waves), lds, (hipStream_t)stream);
   return check_launch("cl3d_fused_reduce_bwd");

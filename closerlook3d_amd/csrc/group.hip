@@ -10,10 +10,9 @@
 //     (1 lane/clk/CU for divergent addresses); the index stream is read as int4 and the output
 //     is written as float4 -- both fully coalesced, 1 KiB per wave instruction.  HBM traffic is
 //     the algorithmic minimum: 4*C*M*K bytes out, 4*C*N in (+ the index stream from L2).
-//   * backward: the mirror image.  One block owns one (cloud, channel) gradient row; each of its
-//     W waves streams a fixed slice of grad_out (float4, coalesced) and accumulates into its own
-//     private LDS row (tag-resolved read-add-write, see below); the W rows are combined in a fixed
-//     order.  No atomics anywhere, and the summation order does not depend on scheduling.
+//   * backward: the mirror image.  One block owns one (cloud, channel) gradient row; its waves stream
+//     grad_out (float4, coalesced, prefetched) and accumulate into one LDS row of doubles
+//     (ds_add_f64), rounded to float once at the end.  No global atomics.
 //   * rows that do not fit LDS (N > kMaxLdsRow = 16384): the forward takes the direct
 //     global-memory gather below; the backward tiles the support range, one LDS tile per block.
 #include "cl3d_common.h"
@@ -88,111 +87,82 @@ __global__ __launch_bounds__(256) void group_fwd_direct_kernel(const float *__re
 }
 
 // ----------------------------------------------------------------------------- backward
-// LDS float atomics are not an option on gfx950: ds_add_f32 sustains 0.33 op/clk/CU under random
-// addresses (measured, scripts/microbench_lds.hip; ds_add_u32: 8.1, plain read-add-write: 4.3).  So the
-// scatter is a plain read-add-write into a row PRIVATE to the wave, with same-instruction address
-// collisions resolved by a tag word per accumulator: every lane writes a unique tag, reads it back, and
-// only the lane whose tag survived performs its add; the others go round again (2.8 op/clk/CU
-// measured, and the order in which colliding lanes add is the hardware's fixed lane order).
-struct AccSlot {
-  float sum;
-  unsigned tag;
-};
-// LDS-address-space volatile views: `volatile` because the tag must really be re-read from LDS after
-// all lanes have written theirs (the compiler would otherwise forward a lane's own store to its load)
-// and the accesses must stay in program order; the explicit address space keeps them ds_* instructions
-// (a plain volatile pointer degrades to flat_load/flat_store).
-typedef __attribute__((address_space(3))) volatile float lds_vf32;
-typedef __attribute__((address_space(3))) volatile unsigned lds_vu32;
+// One block owns one (cloud, channel) gradient row and a tile of T support indices; its four waves
+// stream disjoint slices of grad_out (float4 + int4, software-prefetched one stage ahead) and
+// accumulate into ONE shared LDS row of doubles with ds_add_f64.
+// Why f64: measured on gfx950 (scripts/microbench_lds.hip, random addresses, op/clk/CU):
+//   ds_add_f32 0.33 | ds_add_f64 2.5 | ds_add_u32 8.1 | plain read-add-write 4.3 | tag-resolved RMW 2.8.
+// The f32 LDS atomic is 8x slower than the f64 one.  A double accumulator also makes the result
+// independent of the order the waves arrive in, up to the final rounding to float: it equals
+// round_f32(exact sum) except when the exact sum lies within ~1e-15 relative of a rounding boundary.
+// A wave-private tag-resolved float row is strictly order-fixed, but at 8 B per accumulator it allows
+// only one wave per 32 KiB of LDS and was measured latency-bound (0.60 ms vs 0.67 ms for ds_add_f32).
+constexpr int kBwdStage = 2;  // float4 groups per lane per pipeline stage
 
-__device__ __forceinline__ void scatter_add4(AccSlot *mine, int n0, unsigned span, const int4 &ii,
-                                             const float4 &v, unsigned tag) {
-  const int id[4] = {ii.x - n0, ii.y - n0, ii.z - n0, ii.w - n0};
-  const float val[4] = {v.x, v.y, v.z, v.w};
-  bool todo[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) todo[c] = (unsigned)id[c] < span;
-  while (__ballot(todo[0] | todo[1] | todo[2] | todo[3])) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-      if (todo[c]) *(lds_vu32 *)(&mine[id[c]].tag) = tag + c;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (todo[c] && *(lds_vu32 *)(&mine[id[c]].tag) == tag + c) {
-        lds_vf32 *ps = (lds_vf32 *)(&mine[id[c]].sum);
-        *ps = *ps + val[c];
-        todo[c] = false;
-      }
-    }
-  }
+__device__ __forceinline__ void add4(double *acc, int n0, unsigned span, const int4 &ii, const float4 &v) {
+  if ((unsigned)(ii.x - n0) < span) atomicAdd(&acc[ii.x - n0], (double)v.x);
+  if ((unsigned)(ii.y - n0) < span) atomicAdd(&acc[ii.y - n0], (double)v.y);
+  if ((unsigned)(ii.z - n0) < span) atomicAdd(&acc[ii.z - n0], (double)v.z);
+  if ((unsigned)(ii.w - n0) < span) atomicAdd(&acc[ii.w - n0], (double)v.w);
 }
 
-template <int W>
-__global__ __launch_bounds__(64 * W) void group_bwd_lds_kernel(const float *__restrict__ grad_out,
-                                                              const int *__restrict__ idx, int C,
-                                                              int N, int MK, int T,
-                                                              float *__restrict__ grad_points) {
-  extern __shared__ AccSlot acc[];  // [W][T]: this block owns support indices [n0, n0+T)
+__global__ __launch_bounds__(256) void group_bwd_lds_kernel(const float *__restrict__ grad_out,
+                                                            const int *__restrict__ idx, int C, int N,
+                                                            int MK, int T,
+                                                            float *__restrict__ grad_points) {
+  extern __shared__ double acc[];  // [T]: this block owns support indices [n0, n0+T)
   const int bc = blockIdx.x;
   const int b = bc / C;
-  const int wave = threadIdx.x >> 6;
-  const int lane = threadIdx.x & 63;
   const int n0 = blockIdx.y * T;
   const unsigned span = (unsigned)(N - n0 < T ? N - n0 : T);
-  for (int i = threadIdx.x; i < W * T; i += 64 * W) {
-    acc[i].sum = 0.0f;
-    acc[i].tag = 0xffffffffu;
-  }
+  for (int i = threadIdx.x; i < T; i += 256) acc[i] = 0.0;
   __syncthreads();
 
-  AccSlot *mine = acc + (size_t)wave * T;
   const float *g = grad_out + (size_t)bc * MK;
   const int *ib = idx + (size_t)b * MK;
-  // fixed slice per wave, multiple of 4 elements
-  int per = ((MK + W - 1) / W + 3) & ~3;
-  const int e0 = wave * per;
-  int e1 = e0 + per;
-  e1 = e1 < MK ? e1 : MK;
-  unsigned tag = (unsigned)lane << 2;  // unique per (lane, component); bumped by 256 per use
   if ((MK & 3) == 0) {
     const int4 *i4 = reinterpret_cast<const int4 *>(ib);
     const float4 *g4 = reinterpret_cast<const float4 *>(g);
-    const int q1 = e1 >> 2;
-    int q = (e0 >> 2) + lane;
-    // 2*kUnroll independent 16-byte loads in flight per lane (the stream comes from HBM)
-    for (; q + (kUnroll - 1) * 64 < q1; q += kUnroll * 64) {
-      int4 ii[kUnroll];
-      float4 vv[kUnroll];
+    const int nq = MK >> 2;
+    constexpr int kStride = 256 * kBwdStage;
+    int4 ci[kBwdStage], ni[kBwdStage];
+    float4 cv[kBwdStage], nv[kBwdStage];
+    const int4 none = make_int4(-1, -1, -1, -1);
+    int q = threadIdx.x;
 #pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        ii[u] = i4[q + u * 64];
-        vv[u] = g4[q + u * 64];
-      }
-#pragma unroll
-      for (int u = 0; u < kUnroll; ++u) {
-        scatter_add4(mine, n0, span, ii[u], vv[u], tag);
-        tag += 256;
-      }
+    for (int u = 0; u < kBwdStage; ++u) {
+      const int qq = q + u * 256;
+      const int qc = qq < nq ? qq : nq - 1;  // always a valid address; out-of-range lanes are disabled via idx
+      ci[u] = i4[qc];
+      cv[u] = g4[qc];
+      if (qq >= nq) ci[u] = none;
     }
-    for (; q < q1; q += 64) {
-      scatter_add4(mine, n0, span, i4[q], g4[q], tag);
-      tag += 256;
+    for (; q < nq; q += kStride) {
+#pragma unroll
+      for (int u = 0; u < kBwdStage; ++u) {  // next stage's loads are in flight while this one is summed
+        const int qq = q + kStride + u * 256;
+        const int qc = qq < nq ? qq : nq - 1;
+        ni[u] = i4[qc];
+        nv[u] = g4[qc];
+        if (qq >= nq) ni[u] = none;
+      }
+#pragma unroll
+      for (int u = 0; u < kBwdStage; ++u) add4(acc, n0, span, ci[u], cv[u]);
+#pragma unroll
+      for (int u = 0; u < kBwdStage; ++u) {
+        ci[u] = ni[u];
+        cv[u] = nv[u];
+      }
     }
   } else {
-    for (int e = e0 + lane; e < e1; e += 64) {
-      const int4 ii = make_int4(ib[e], -1, -1, -1);
-      scatter_add4(mine, n0, span, ii, make_float4(g[e], 0.f, 0.f, 0.f), tag);
-      tag += 256;
+    for (int e = threadIdx.x; e < MK; e += 256) {
+      const int i = ib[e];
+      if ((unsigned)(i - n0) < span) atomicAdd(&acc[i - n0], (double)g[e]);
     }
   }
   __syncthreads();
   float *dst = grad_points + (size_t)bc * N + n0;
-  for (int i = threadIdx.x; i < (int)span; i += 64 * W) {
-    float s = acc[i].sum;
-#pragma unroll
-    for (int w = 1; w < W; ++w) s += acc[(size_t)w * T + i].sum;
-    dst[i] = s;
-  }
+  for (int i = threadIdx.x; i < (int)span; i += 256) dst[i] = (float)acc[i];
 }
 
 // -------------------------------------------------- fused relative-position + feature gather
@@ -288,18 +258,12 @@ extern "C" int cl3d_group_points_grad(const float *grad_out, const int32_t *idx,
   // private LDS rows (one per wave, combined in a fixed order).  N <= 16384: a single tile; larger
   // clouds sweep the grad_out row once per tile (still no global atomics, still order-fixed).
   CL3D_REQUIRE((long long)B * C <= 0x7fffffffLL, "group_points_grad: B*C too large");
-  const int kTile = 8192;  // accumulators per wave: 64 KiB of {sum, tag} pairs
+  const int kTile = 8192;  // doubles per block: 64 KiB, the no-opt-in dynamic LDS limit
   const int T = N <= kTile ? N : kTile;
   const int ntiles = cl3d::ceil_div(N, T);
   CL3D_REQUIRE(ntiles <= 65535, "group_points_grad: N too large");
-  const size_t row = (size_t)T * sizeof(cl3d::AccSlot);
-  const dim3 grid(B * C, ntiles);
-  // one wave per block unless the row is small: occupancy comes from many resident blocks, and every
-  // wave keeps 2*kUnroll 16-byte loads in flight
-  if (row * 2 <= 32 * 1024 && MK >= 2048)
-    hipLaunchKernelGGL(cl3d::group_bwd_lds_kernel<2>, grid, dim3(128), row * 2, st, grad_out, idx, C, N, MK, T, grad_points);
-  else
-    hipLaunchKernelGGL(cl3d::group_bwd_lds_kernel<1>, grid, dim3(64), row, st, grad_out, idx, C, N, MK, T, grad_points);
+  hipLaunchKernelGGL(cl3d::group_bwd_lds_kernel, dim3(B * C, ntiles), dim3(256), (size_t)T * sizeof(double), st,
+                     grad_out, idx, C, N, MK, T, grad_points);
   return cl3d::check_launch("cl3d_group_points_grad");
 }
 

@@ -75,8 +75,9 @@ int cl3d_group_points(const float *points, const int32_t *idx, int B, int C, int
                       float *out, cl3d_stream_t stream);
 
 /* replaces group_points_grad (group_points.cpp:42-65 + group_points_gpu.cu:48-69).
- * grad_out [B,C,M,K], idx [B,M,K] -> grad_points [B,C,N] (sum over all (j,k) with idx==i;
- * summed in a fixed order, so repeatable run to run, unlike the reference's atomicAdd). */
+ * grad_out [B,C,M,K], idx [B,M,K] -> grad_points [B,C,N] (sum over all (j,k) with idx==i,
+ * accumulated in double and rounded once: order-independent up to the final rounding, where the
+ * reference's float atomicAdd depends on scheduling). */
 int cl3d_group_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int M,
                            int K, float *grad_points, void *ws, size_t ws_bytes,
                            cl3d_stream_t stream);
@@ -110,7 +111,7 @@ int cl3d_group_xyz_features(const float *query_xyz, const float *support_xyz,
  * ft [B,N,C], out_t [B,M,C] (the Python layer transposes at the operator boundary). */
 
 /* CSR inverse of a neighbour-index tensor: inv_off [B,N+1], inv_slots [B,MK] (ascending slot ids per
- * support point).  ws: (B*N + B*MK) * 4 bytes.  Used by every fused backward pass (ordered gather
+ * support point).  ws: B*N*4 bytes.  Used by every fused backward pass (ordered gather
  * instead of the reference's atomicAdd scatter, group_points_gpu.cu:65). */
 int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK, int32_t *inv_off,
                              int32_t *inv_slots, void *ws, size_t ws_bytes, cl3d_stream_t stream);
