@@ -23,6 +23,7 @@
 namespace cl3d {
 
 constexpr int kCsrRows = 32;  // support rows per wave
+constexpr int kCsrUnroll = 8;
 
 __global__ __launch_bounds__(256) void csr_count_kernel(const int *__restrict__ idx, int B, int N, int MK,
                                                         int *__restrict__ cnt) {
@@ -37,7 +38,18 @@ __global__ __launch_bounds__(256) void csr_count_kernel(const int *__restrict__ 
   __syncthreads();
   if (r0 < N) {
     const int *ib = idx + (size_t)b * MK;
-    for (int base = 0; base < MK; base += 64) {
+    // kCsrUnroll independent loads in flight per lane: the loop is otherwise bound by one L2 round trip
+    // per 64 slots
+    int base = 0;
+    for (; base + kCsrUnroll * 64 <= MK; base += kCsrUnroll * 64) {
+      int d[kCsrUnroll];
+#pragma unroll
+      for (int u = 0; u < kCsrUnroll; ++u) d[u] = ib[base + u * 64 + lane] - r0;
+#pragma unroll
+      for (int u = 0; u < kCsrUnroll; ++u)
+        if ((unsigned)d[u] < (unsigned)kCsrRows) atomicAdd(&s_cnt[wave][d[u]], 1u);
+    }
+    for (; base < MK; base += 64) {
       const int e = base + lane;
       const int d = (e < MK ? ib[e] : -1) - r0;
       if ((unsigned)d < (unsigned)kCsrRows) atomicAdd(&s_cnt[wave][d], 1u);
@@ -93,9 +105,7 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int *__restrict__ i
   int *sb = slots + (size_t)b * MK;
   // lane r (< 32) carries the next write position of row r0 + r
   int pos = (lane < kCsrRows && r0 + lane < N) ? off[(size_t)b * (N + 1) + r0 + lane] : 0;
-  for (int base = 0; base < MK; base += 64) {
-    const int e = base + lane;
-    const int d = (e < MK ? ib[e] : -1) - r0;
+  auto emit = [&](int d, int base) {
     unsigned long long m = __ballot((unsigned)d < (unsigned)kCsrRows);
     while (m) {  // wave-uniform: hits in ascending slot order
       const int t = __builtin_ctzll(m);
@@ -105,6 +115,18 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int *__restrict__ i
       if (lane == row) pos += 1;
       if (lane == 0) sb[p] = base + t;
     }
+  };
+  int base = 0;
+  for (; base + kCsrUnroll * 64 <= MK; base += kCsrUnroll * 64) {
+    int d[kCsrUnroll];
+#pragma unroll
+    for (int u = 0; u < kCsrUnroll; ++u) d[u] = ib[base + u * 64 + lane] - r0;
+#pragma unroll
+    for (int u = 0; u < kCsrUnroll; ++u) emit(d[u], base + u * 64);
+  }
+  for (; base < MK; base += 64) {
+    const int e = base + lane;
+    emit((e < MK ? ib[e] : -1) - r0, base);
   }
 }
 

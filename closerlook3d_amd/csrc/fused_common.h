@@ -94,4 +94,23 @@ __device__ __forceinline__ void store_row(float *p, const Vec<V> &r) {
   }
 }
 
+// Walk the K neighbour slots of one query in batches of KB: KB slot records are read from LDS, then KB
+// row gathers are issued back to back, and only then consumed -- KB independent global loads in flight
+// per lane (the compiler does not build this batching out of a plain unrolled loop).
+template <int V, int KB, class F>
+__device__ __forceinline__ void for_each_slot(const float4 *myslots, int K, const float *rows, int row_stride,
+                                              int c0, F &&f) {
+  for (int k0 = 0; k0 < K; k0 += KB) {
+    float4 sr[KB];
+    Vec<V> gr[KB];
+#pragma unroll
+    for (int u = 0; u < KB; ++u) sr[u] = myslots[k0 + u < K ? k0 + u : K - 1];
+#pragma unroll
+    for (int u = 0; u < KB; ++u) gr[u] = load_row<V>(rows + (size_t)__float_as_int(sr[u].x) * row_stride + c0);
+#pragma unroll
+    for (int u = 0; u < KB; ++u)
+      if (k0 + u < K) f(k0 + u, sr[u], gr[u]);
+  }
+}
+
 }  // namespace cl3d

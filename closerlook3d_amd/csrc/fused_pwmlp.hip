@@ -26,6 +26,7 @@
 namespace cl3d {
 
 enum { PW_STATS = 0, PW_FWD = 1, PW_BWD_SPARSE = 2, PW_BWD_QUERY = 3 };
+constexpr int kSlotBatch = 8;  // row gathers in flight per lane
 
 struct PwArgs {
   const float *query_xyz, *support_xyz;
@@ -56,13 +57,11 @@ __device__ __forceinline__ float pw_preact(const float w[3], float rx, float ry,
   return (t + hc) + g;
 }
 
+// V == 4 is only used when C % 4 == 0 and V == 1 rows are single elements, so a lane with c0 < C always
+// owns a full vector: every row access is one global_load_dwordx4 / dword.
 template <int V>
-__device__ __forceinline__ Vec<V> load_row_tail(const float *p, int c0, int C) {
-  if (c0 + V <= C) return load_row<V>(p);
-  Vec<V> r;
-#pragma unroll
-  for (int v = 0; v < V; ++v) r.v[v] = c0 + v < C ? p[v] : 0.f;
-  return r;
+__device__ __forceinline__ Vec<V> load_row_tail(const float *p, int, int) {
+  return load_row<V>(p);
 }
 
 // query-major passes.  Persistent blocks: tile = 4*QW queries of one cloud.
@@ -93,7 +92,7 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
     float w[V][3], c_v0[V], c_v1[V], c_v2[V], c_v3[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const int c = (chan_on && c0 + v < Co) ? c0 + v : 0;
+      const int c = chan_on ? c0 + v : 0;
       w[v][0] = a.wr[c * 3 + 0];
       w[v][1] = a.wr[c * 3 + 1];
       w[v][2] = a.wr[c * 3 + 2];
@@ -119,7 +118,9 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
           const int i = a.idx[e];
           r = make_float4(__int_as_float(i), (s[i * 3 + 0] - q[j * 3 + 0]) * a.inv_radius,
                           (s[i * 3 + 1] - q[j * 3 + 1]) * a.inv_radius, (s[i * 3 + 2] - q[j * 3 + 2]) * a.inv_radius);
-          if (MODE == PW_FWD && ch == 0 && a.slotrec != nullptr) a.slotrec[e] = make_float4(r.y, r.z, r.w, 0.f);
+          // slotrec = {rel, centre index of the query}: one dependent load less per slot in the support-major pass
+          if (MODE == PW_FWD && ch == 0 && a.slotrec != nullptr)
+            a.slotrec[e] = make_float4(r.y, r.z, r.w, __int_as_float(a.idx[((size_t)b * M + j) * K]));
         }
         slot4[t] = r;
       }
@@ -137,17 +138,14 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
         float s1[V], s2[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) s1[v] = s2[v] = 0.f;
-#pragma unroll 4
-        for (int k = 0; k < K; ++k) {
-          const float4 sr = myslots[k];
-          const Vec<V> gr = load_row_tail<V>(rows + (size_t)__float_as_int(sr.x) * row + c0, c0, Co);
+        for_each_slot<V, kSlotBatch>(myslots, K, rows, row, c0, [&](int, const float4 &sr, const Vec<V> &gr) {
 #pragma unroll
           for (int v = 0; v < V; ++v) {
             const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gr.v[v]);
             s1[v] += y;
             s2[v] = __builtin_fmaf(y, y, s2[v]);
           }
-        }
+        });
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           dacc[0][v] += (double)s1[v];
@@ -161,10 +159,7 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
           best[v] = 0.f;
           kb[v] = 0;
         }
-#pragma unroll 4
-        for (int k = 0; k < K; ++k) {
-          const float4 sr = myslots[k];
-          const Vec<V> gr = load_row_tail<V>(rows + (size_t)__float_as_int(sr.x) * row + c0, c0, Co);
+        for_each_slot<V, kSlotBatch>(myslots, K, rows, row, c0, [&](int k, const float4 &sr, const Vec<V> &gr) {
 #pragma unroll
           for (int v = 0; v < V; ++v) {
             const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gr.v[v]);
@@ -175,13 +170,13 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
               kb[v] = k;
             }
           }
-        }
-        _Pragma("unroll") for (int v = 0; v < V; ++v) if (c0 + v < Co) {
+        });
+        _Pragma("unroll") for (int v = 0; v < V; ++v) {
           a.out_t[orow + v] = best[v];
           if (a.kstar_out) a.kstar_out[orow + v] = (unsigned char)kb[v];
         }
       } else if constexpr (MODE == PW_BWD_SPARSE) {
-        _Pragma("unroll") for (int v = 0; v < V; ++v) if (c0 + v < Co) {
+        _Pragma("unroll") for (int v = 0; v < V; ++v) {
           const int ks = a.kstar_in[orow + v];
           const float4 sr = myslots[ks];
           const float gi = rows[(size_t)__float_as_int(sr.x) * row + c0 + v];
@@ -197,15 +192,12 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
         int ks[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          const bool on = c0 + v < Co;
+          const bool on = true;
           dzA[v] = on ? a.dzs_in[orow + v] * c_v0[v] : 0.f;
           ks[v] = on ? (int)a.kstar_in[orow + v] : -1;
           sdy[v] = dw0[v] = dw1[v] = dw2[v] = 0.f;
         }
-#pragma unroll 4
-        for (int k = 0; k < K; ++k) {
-          const float4 sr = myslots[k];
-          const Vec<V> gr = load_row_tail<V>(rows + (size_t)__float_as_int(sr.x) * row + c0, c0, Co);
+        for_each_slot<V, kSlotBatch>(myslots, K, rows, row, c0, [&](int k, const float4 &sr, const Vec<V> &gr) {
 #pragma unroll
           for (int v = 0; v < V; ++v) {
             const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gr.v[v]);
@@ -216,8 +208,8 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
             dw1[v] = __builtin_fmaf(dy, sr.z, dw1[v]);
             dw2[v] = __builtin_fmaf(dy, sr.w, dw2[v]);
           }
-        }
-        _Pragma("unroll") for (int v = 0; v < V; ++v) if (c0 + v < Co) a.sq_t[orow + v] = sdy[v];
+        });
+        _Pragma("unroll") for (int v = 0; v < V; ++v) a.sq_t[orow + v] = sdy[v];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           dacc[0][v] += (double)dw0[v];
@@ -269,7 +261,7 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
     float w[V][3], cA[V], cB[V], cD[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const int c = c0 + v < Co ? c0 + v : 0;
+      const int c = c0 + v;
       w[v][0] = a.wr[c * 3 + 0];
       w[v][1] = a.wr[c * 3 + 1];
       w[v][2] = a.wr[c * 3 + 2];
@@ -283,7 +275,6 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
       const int i = tr * TR + wave * QW + g;
       if (i >= N) continue;
       const float *rows = a.ght + (size_t)b * N * row;
-      const int *ib = a.idx + (size_t)b * MK;
       const int *off = a.inv_off + (size_t)b * (N + 1);
       const int *slots = a.inv_slots + (size_t)b * MK;
       const float4 *rec = a.slotrec + (size_t)b * MK;
@@ -292,22 +283,38 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
 #pragma unroll
       for (int v = 0; v < V; ++v) acc[v] = acch[v] = 0.f;
       const int s0 = off[i], s1 = off[i + 1];
-      for (int e = s0; e < s1; ++e) {
-        const int slot = slots[e];
-        const int j = slot / K;
-        const int k = slot - j * K;
-        const float4 r = rec[slot];
-        const int ic = ib[(size_t)j * K];
-        const Vec<V> hc = load_row_tail<V>(rows + (size_t)ic * row + Co + c0, c0, Co);
-        const size_t orow = ((size_t)b * M + j) * Co + c0;
-        const Vec<V> dz = load_row_tail<V>(a.dzs_in + orow, c0, Co);
+      const float *dzrow = a.dzs_in + (size_t)b * M * Co + c0;
+      const unsigned char *ksrow = a.kstar_in + (size_t)b * M * Co + c0;
+      constexpr int SB = 4;  // slots per batch: 3*SB independent row gathers in flight per lane
+      for (int e = s0; e < s1; e += SB) {
+        int sl[SB];
+        float4 r[SB];
+        Vec<V> hc[SB], dz[SB];
+        unsigned ksw[SB];
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
-          const int ks = c0 + v < Co ? (int)a.kstar_in[orow + v] : -1;
-          const float y = pw_preact(w[v], r.x, r.y, r.z, hc.v[v], gi.v[v]);
-          float dy = __builtin_fmaf(cD[v], y, cB[v]);
-          dy += (k == ks) ? dz.v[v] * cA[v] : 0.f;
-          acc[v] += dy;
+        for (int u = 0; u < SB; ++u) sl[u] = slots[e + u < s1 ? e + u : s1 - 1];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) r[u] = rec[sl[u]];
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          const int j = sl[u] / K;
+          hc[u] = load_row<V>(rows + (size_t)__float_as_int(r[u].w) * row + Co + c0);
+          dz[u] = load_row<V>(dzrow + (size_t)j * Co);
+          if constexpr (V == 4) ksw[u] = *reinterpret_cast<const unsigned *>(ksrow + (size_t)j * Co);
+          else ksw[u] = ksrow[(size_t)j * Co];
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+          if (e + u >= s1) continue;
+          const int k = sl[u] - (sl[u] / K) * K;
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            const int ks = (int)((ksw[u] >> (8 * v)) & 0xffu);
+            const float y = pw_preact(w[v], r[u].x, r[u].y, r[u].z, hc[u].v[v], gi.v[v]);
+            float dy = __builtin_fmaf(cD[v], y, cB[v]);
+            dy += (k == ks) ? dz[u].v[v] * cA[v] : 0.f;
+            acc[v] += dy;
+          }
         }
       }
       const int *coff = a.cen_off + (size_t)b * (N + 1);
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
         for (int v = 0; v < V; ++v) acch[v] += sq.v[v];
       }
       float *dst = a.dght + ((size_t)b * N + i) * row + c0;
-      _Pragma("unroll") for (int v = 0; v < V; ++v) if (c0 + v < Co) {
+      _Pragma("unroll") for (int v = 0; v < V; ++v) {
         dst[v] = acc[v];
         dst[Co + v] = acch[v];
       }

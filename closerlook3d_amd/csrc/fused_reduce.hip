@@ -59,7 +59,7 @@ struct ChannelWeights {
   __device__ __forceinline__ void init(const ReduceArgs &a, int c0) {
 #pragma unroll
     for (int v = 0; v < V; ++v) {
-      const int c = c0 + v < a.C ? c0 + v : a.C - 1;
+      const int c = c0 + v;
       if constexpr (OP == OP_POSPOOL_XYZ) {
         axis[v] = c % 3;
       } else if constexpr (OP == OP_POSPOOL_SINCOS) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
 #pragma unroll
       for (int v = 0; v < V; ++v) {
         float o = 0.f;
-        const int c = c0 + v < C ? c0 + v : C - 1;
+        const int c = c0 + v;
 #pragma unroll
         for (int p = 0; p < kMaxKP; ++p)
           if (p < a.pint) o += wf[p][v] * a.p1[(size_t)p * C + c];
@@ -211,27 +211,18 @@ __global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
       float acc[V];
 #pragma unroll
       for (int v = 0; v < V; ++v) acc[v] = 0.f;
-#pragma unroll 4
-      for (int k = 0; k < K; ++k) {
-        const float4 sr = myslots[k];
-        const int i = __float_as_int(sr.x);
-        const Vec<V> f = load_row<V>(frow + (size_t)i * C + c0);
+      for_each_slot<V, 8>(myslots, K, frow, C, c0, [&](int k, const float4 &sr, const Vec<V> &f) {
         const float m = mycoef[k];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           const float t = cw.weight(v, sr.y, sr.z, sr.w) * f.v[v];  // (embedding * feature) ...
           acc[v] += t * m;                                           // ... * mask, as the reference orders it
         }
-      }
+      });
 #pragma unroll
       for (int v = 0; v < V; ++v) out.v[v] = a.reduction == RED_AVG ? acc[v] / n : acc[v];
     }
-    float *dst = a.out_t + ((size_t)b * M + j) * C + c0;
-    if (c0 + V <= C) {
-      store_row<V>(dst, out);
-    } else {
-      _Pragma("unroll") for (int v = 0; v < V; ++v) if (c0 + v < C) dst[v] = out.v[v];
-    }
+    store_row<V>(a.out_t + ((size_t)b * M + j) * C + c0, out);  // V==4 => C%4==0: always a full vector
   }
 }
 
@@ -274,7 +265,7 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
         for (int p = 0; p < kMaxKP; ++p)
 #pragma unroll
           for (int v = 0; v < V; ++v)
-            kw[p][v] = (p < a.pint && c0 + v < C) ? a.p1[(size_t)p * C + c0 + v] : 0.f;
+            kw[p][v] = p < a.pint ? a.p1[(size_t)p * C + c0 + v] : 0.f;
       }
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -289,66 +280,62 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
       const int s0 = off[i], s1 = off[i + 1];
       Vec<V> fown;
       if constexpr (NP > 0) {
-        if (c0 + V <= C) {
-          fown = load_row<V>(a.ft + ((size_t)b * N + i) * C + c0);
-        } else {
-#pragma unroll
-          for (int v = 0; v < V; ++v) fown.v[v] = c0 + v < C ? a.ft[((size_t)b * N + i) * C + c0 + v] : 0.f;
-        }
+        fown = load_row<V>(a.ft + ((size_t)b * N + i) * C + c0);
       }
       float acc[V];
 #pragma unroll
       for (int v = 0; v < V; ++v) acc[v] = 0.f;
-      for (int e = s0; e < s1; ++e) {
-        const int slot = slots[e];
-        const int j = slot / K;
-        const float4 r = rec[slot];
-        Vec<V> go;
-        if (c0 + V <= C) {
-          go = load_row<V>(grow + (size_t)j * C);
-        } else {
+      constexpr int SB = 4;  // slots per batch: SB independent (slot -> record -> row) chains in flight
+      for (int e = s0; e < s1; e += SB) {
+        int sl[SB];
+        float4 rr[SB];
+        Vec<V> gg[SB];
 #pragma unroll
-          for (int v = 0; v < V; ++v) go.v[v] = c0 + v < C ? grow[(size_t)j * C + v] : 0.f;
-        }
-        if constexpr (OP == OP_PSEUDOGRID) {
-          float h[kMaxKP];
+        for (int u = 0; u < SB; ++u) sl[u] = slots[e + u < s1 ? e + u : s1 - 1];
 #pragma unroll
-          for (int p = 0; p < kMaxKP; ++p)
-            h[p] = p < a.pint ? kp_influence(r.x, r.y, r.z, a.p0 + p * 3, a.pfloat, a.constant_influence) * r.w : 0.f;
+        for (int u = 0; u < SB; ++u) rr[u] = rec[sl[u]];
 #pragma unroll
-          for (int v = 0; v < V; ++v) {
-            float w = 0.f;
+        for (int u = 0; u < SB; ++u) gg[u] = load_row<V>(grow + (size_t)(sl[u] / K) * C);
 #pragma unroll
-            for (int p = 0; p < kMaxKP; ++p) {
-              w = __builtin_fmaf(kw[p][v], h[p], w);
-              pacc[p][v] = __builtin_fmaf(h[p] * fown.v[v], go.v[v], pacc[p][v]);
+        for (int u = 0; u < SB; ++u) {
+          if (e + u >= s1) continue;
+          const float4 r = rr[u];
+          const Vec<V> &go = gg[u];
+          if constexpr (OP == OP_PSEUDOGRID) {
+            float h[kMaxKP];
+#pragma unroll
+            for (int p = 0; p < kMaxKP; ++p)
+              h[p] = p < a.pint ? kp_influence(r.x, r.y, r.z, a.p0 + p * 3, a.pfloat, a.constant_influence) * r.w : 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              float w = 0.f;
+#pragma unroll
+              for (int p = 0; p < kMaxKP; ++p) {
+                w = __builtin_fmaf(kw[p][v], h[p], w);
+                pacc[p][v] = __builtin_fmaf(h[p] * fown.v[v], go.v[v], pacc[p][v]);
+              }
+              acc[v] = __builtin_fmaf(w, go.v[v], acc[v]);
             }
-            acc[v] = __builtin_fmaf(w, go.v[v], acc[v]);
-          }
-        } else {
+          } else {
 #pragma unroll
-          for (int v = 0; v < V; ++v) {
-            const float gm = go.v[v] * r.w;  // d out * (mask / count)
-            acc[v] = __builtin_fmaf(cw.weight(v, r.x, r.y, r.z), gm, acc[v]);
-            if constexpr (OP == OP_ADAPTIVE) {
-              const float gf = gm * fown.v[v];
-              pacc[0][v] = __builtin_fmaf(gf, r.x, pacc[0][v]);
-              pacc[1][v] = __builtin_fmaf(gf, r.y, pacc[1][v]);
-              pacc[2][v] = __builtin_fmaf(gf, r.z, pacc[2][v]);
-              pacc[3][v] += gf;
+            for (int v = 0; v < V; ++v) {
+              const float gm = go.v[v] * r.w;  // d out * (mask / count)
+              acc[v] = __builtin_fmaf(cw.weight(v, r.x, r.y, r.z), gm, acc[v]);
+              if constexpr (OP == OP_ADAPTIVE) {
+                const float gf = gm * fown.v[v];
+                pacc[0][v] = __builtin_fmaf(gf, r.x, pacc[0][v]);
+                pacc[1][v] = __builtin_fmaf(gf, r.y, pacc[1][v]);
+                pacc[2][v] = __builtin_fmaf(gf, r.z, pacc[2][v]);
+                pacc[3][v] += gf;
+              }
             }
           }
         }
       }
-      float *dst = a.dft + ((size_t)b * N + i) * C + c0;
-      if (c0 + V <= C) {
-        Vec<V> o;
+      Vec<V> o;
 #pragma unroll
-        for (int v = 0; v < V; ++v) o.v[v] = acc[v];
-        store_row<V>(dst, o);
-      } else {
-        _Pragma("unroll") for (int v = 0; v < V; ++v) if (c0 + v < C) dst[v] = acc[v];
-      }
+      for (int v = 0; v < V; ++v) o.v[v] = acc[v];
+      store_row<V>(a.dft + ((size_t)b * N + i) * C + c0, o);
     }
     // ---- fixed-order block reduction of the parameter partials for this channel chunk
     if constexpr (NP > 0) {
