@@ -67,10 +67,14 @@ def masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, 
     N = support_xyz.shape[1]
     idx = torch.empty((B, M, int(nsample)), dtype=torch.int32, device=query_xyz.device)
     idx_mask = torch.empty_like(idx)
+    lib = _lib.lib()
+    ws_bytes = lib.cl3d_workspace_bytes(1, B, N, M, int(nsample), 0)  # CL3D_OP_BALL_QUERY
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=query_xyz.device) if ws_bytes else None
     with torch.cuda.device(query_xyz.device):
-        _lib.check(_lib.lib().cl3d_masked_ordered_ball_query(
+        _lib.check(lib.cl3d_masked_ordered_ball_query(
             _p(query_xyz), _p(support_xyz), _p(query_mask), _p(support_mask), B, M, N, float(radius),
-            int(nsample), _p(idx), _p(idx_mask), None, 0, _lib.stream_ptr(query_xyz.device)))
+            int(nsample), _p(idx), _p(idx_mask), _p(ws) if ws is not None else None, ws_bytes,
+            _lib.stream_ptr(query_xyz.device)))
     return [idx, idx_mask]
 
 

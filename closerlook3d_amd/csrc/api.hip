@@ -1,17 +1,16 @@
 // api.hip -- version / error / workspace entry points of libcl3d.
-#include "cl3d_common.h"
+#include "ball_query.h"
 
 extern "C" int cl3d_abi_version(void) { return CL3D_ABI_VERSION; }
 
 extern "C" const char *cl3d_last_error_string(void) { return cl3d::err_buf(); }
 
 extern "C" size_t cl3d_workspace_bytes(int op, int B, int N, int M, int K, int C) {
-  (void)B; (void)N; (void)M; (void)K; (void)C;
+  (void)C;
   switch (op) {
-    // every op of ABI v1 keeps its scratch in LDS; the parameter exists so that the
-    // multi-workgroup paths (large-N sort, cell lists) can ask for device scratch without an
-    // ABI change.
-    default:
+    case CL3D_OP_BALL_QUERY:  // cell grid: sorted support copy, cell starts, query order, task table, flags
+      return cl3d::ball_query_cells_applicable(M, N, K) ? cl3d::ball_query_cells_workspace(B, N, M) : 0;
+    default:  // every other op of ABI v1 keeps its scratch in LDS
       return 0;
   }
 }

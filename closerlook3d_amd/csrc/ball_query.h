@@ -1,0 +1,20 @@
+// ball_query.h -- internal interface between the exhaustive and the cell-grid ball query.
+#pragma once
+#include "cl3d_common.h"
+
+namespace cl3d {
+
+// exhaustive scan (ball_query.hip).  only_flagged == nullptr: every query; otherwise only queries j with
+// only_flagged[b*M + j] != 0 are computed and written (workgroups without a flagged query exit at once).
+int ball_query_exhaustive(const float *query_xyz, const float *support_xyz, const int *query_mask,
+                          const int *support_mask, int B, int M, int N, float radius, int K, int *idx,
+                          int *idx_mask, const int *only_flagged, hipStream_t st);
+
+// cell-grid search (ball_query_cells.hip)
+size_t ball_query_cells_workspace(int B, int N, int M);
+bool ball_query_cells_applicable(int M, int N, int K);
+int ball_query_cells(const float *query_xyz, const float *support_xyz, const int *query_mask,
+                     const int *support_mask, int B, int M, int N, float radius, int K, int *idx,
+                     int *idx_mask, void *ws, size_t ws_bytes, hipStream_t st);
+
+}  // namespace cl3d

@@ -18,7 +18,7 @@
 //
 // Results are bit-identical to the reference semantics (tests/test_native_gpu.py); the
 // distance uses cl3d::dist2's canonical operation order.
-#include "cl3d_common.h"
+#include "ball_query.h"
 
 namespace cl3d {
 
@@ -28,7 +28,8 @@ template <int QW>
 __global__ __launch_bounds__(256) void ball_query_kernel(
     const float *__restrict__ query_xyz, const float *__restrict__ support_xyz,
     const int *__restrict__ query_mask, const int *__restrict__ support_mask, int M, int N,
-    float radius2, int K, int *__restrict__ idx, int *__restrict__ idx_mask) {
+    float radius2, int K, int *__restrict__ idx, int *__restrict__ idx_mask,
+    const int *__restrict__ only_flagged) {
   extern __shared__ int smem[];
   __shared__ int s_nv;
   const int cap = 3 * K;
@@ -36,6 +37,14 @@ __global__ __launch_bounds__(256) void ball_query_kernel(
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nq_block = kWavesPerBlock * QW;
+  if (only_flagged != nullptr) {  // redo pass after the cell-grid search: most workgroups have nothing to do
+    int any = 0;
+    for (int t = threadIdx.x; t < nq_block; t += 256) {
+      const int j = blockIdx.x * nq_block + t;
+      if (j < M && only_flagged[(size_t)b * M + j] != 0) any = 1;
+    }
+    if (!__syncthreads_or(any)) return;
+  }
 
   // LDS carve: candidate distances, candidate indices, sorted indices
   float *cand_d = reinterpret_cast<float *>(smem) + (size_t)wave * QW * cap;
@@ -137,6 +146,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(
   for (int t = 0; t < QW; ++t) {
     const int j = j0 + t;
     if (j >= M) break;
+    if (only_flagged != nullptr && only_flagged[(size_t)b * M + j] == 0) continue;
     const int c = cnt[t];
     const int qmk = qm[j];
     int *oi = idx + ((size_t)b * M + j) * K;
@@ -212,13 +222,28 @@ __global__ __launch_bounds__(256) void nearest_query_kernel(
 template <int QW>
 static int launch_ball_query(const float *q, const float *s, const int *qm, const int *sm, int B,
                              int M, int N, float radius, int K, int *idx, int *idx_mask,
-                             hipStream_t st) {
+                             const int *only_flagged, hipStream_t st) {
   const int nq_block = kWavesPerBlock * QW;
   const size_t lds = (size_t)nq_block * (2 * 3 * K + K) * sizeof(int);
   dim3 grid(ceil_div(M, nq_block), B);
   hipLaunchKernelGGL(ball_query_kernel<QW>, grid, dim3(256), lds, st, q, s, qm, sm, M, N,
-                     radius * radius, K, idx, idx_mask);
+                     radius * radius, K, idx, idx_mask, only_flagged);
   return check_launch("cl3d_masked_ordered_ball_query");
+}
+
+int ball_query_exhaustive(const float *query_xyz, const float *support_xyz, const int *query_mask,
+                          const int *support_mask, int B, int M, int N, float radius, int K, int *idx,
+                          int *idx_mask, const int *only_flagged, hipStream_t st) {
+  // LDS per block = 4*QW*7K ints; stay within the 64 KiB a kernel gets without opting in.
+  const size_t per_q = (size_t)7 * K * sizeof(int);
+  const size_t budget = 64 * 1024;
+  if (4 * 8 * per_q <= budget && M >= 64)
+    return launch_ball_query<8>(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, K, idx, idx_mask, only_flagged, st);
+  if (4 * 4 * per_q <= budget && M >= 16)
+    return launch_ball_query<4>(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, K, idx, idx_mask, only_flagged, st);
+  if (4 * 1 * per_q <= budget)
+    return launch_ball_query<1>(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, K, idx, idx_mask, only_flagged, st);
+  return fail(CL3D_E_UNSUPPORTED, "ball_query: nsample=%d needs more than 64 KiB of LDS", K);
 }
 
 }  // namespace cl3d
@@ -229,22 +254,18 @@ extern "C" int cl3d_masked_ordered_ball_query(const float *query_xyz, const floa
                                               float radius, int nsample, int32_t *idx,
                                               int32_t *idx_mask, void *ws, size_t ws_bytes,
                                               cl3d_stream_t stream) {
-  (void)ws;
-  (void)ws_bytes;
   CL3D_REQUIRE(B >= 0 && M >= 0 && N >= 1 && nsample >= 1, "ball_query: bad sizes B=%d M=%d N=%d K=%d", B, M, N, nsample);
   if (B == 0 || M == 0) return CL3D_OK;
   CL3D_REQUIRE(query_xyz && support_xyz && query_mask && support_mask && idx && idx_mask, "ball_query: null pointer");
+  CL3D_REQUIRE(B <= 65535, "ball_query: B exceeds grid.y limit");
   hipStream_t st = (hipStream_t)stream;
-  // LDS per block = 4*QW*7K ints; stay within the 64 KiB a kernel gets without opting in.
-  const size_t per_q = (size_t)7 * nsample * sizeof(int);
-  const size_t budget = 64 * 1024;
-  if (4 * 8 * per_q <= budget && M >= 64)
-    return cl3d::launch_ball_query<8>(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx, idx_mask, st);
-  if (4 * 4 * per_q <= budget && M >= 16)
-    return cl3d::launch_ball_query<4>(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx, idx_mask, st);
-  if (4 * 1 * per_q <= budget)
-    return cl3d::launch_ball_query<1>(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx, idx_mask, st);
-  return cl3d::fail(CL3D_E_UNSUPPORTED, "ball_query: nsample=%d needs more than 64 KiB of LDS", nsample);
+  // cell-grid search when scratch is provided and the problem is large enough to pay for the prep pass;
+  // otherwise (and for queries too dense for its LDS lists) the exhaustive scan
+  if (ws != nullptr && cl3d::ball_query_cells_applicable(M, N, nsample))
+    return cl3d::ball_query_cells(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx,
+                                  idx_mask, ws, ws_bytes, st);
+  return cl3d::ball_query_exhaustive(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx,
+                                     idx_mask, nullptr, st);
 }
 
 extern "C" int cl3d_masked_nearest_query(const float *query_xyz, const float *support_xyz,

@@ -1,0 +1,492 @@
+// ball_query_cells.hip -- masked ordered ball query through a uniform cell grid (gfx950).
+//
+// Same results, bit for bit, as ball_query.hip's exhaustive scan (and therefore as the reference,
+// masked_ordered_ball_query_gpu.cu:11-96), but a query only looks at the support points of the 27
+// cells around it instead of all N:
+//
+//   prep   (one workgroup per cloud)  bounding box of the valid support points, cell size h >= radius
+//          (grown until the grid has <= kMaxCells cells), counting sort of the support points by cell
+//          into `sorted` (float4 {x,y,z, original index}), counting sort of the query indices by cell,
+//          and a task table: every task = up to QW queries of ONE cell.
+//   query  (persistent waves)  a wave takes a task; its QW queries share the same 9 contiguous runs
+//          of `sorted` (3 cells in x are adjacent in the cell order), so lanes stream candidates as
+//          coalesced float4 and every candidate is tested against all QW queries, exactly like the
+//          exhaustive kernel -- with ~N/13 candidates instead of N at the metric shape.
+//
+// The reference's semantics depend on the ORIGINAL index order ("first 3*nsample in-radius points by
+// support index", strict running minimum patched into the last slot, stable sort by distance), and the
+// cell order is not the index order.  So the wave collects ALL in-radius candidates S (distance,
+// original index) in LDS and then restates the rule order-independently:
+//   |S| <= 3K : the candidate list is S;
+//   |S| >  3K : the 3K smallest original indices of S (rank by index), and if the (first-occurrence)
+//               minimum of S is not among them it replaces the one with the largest index;
+//   result    : the list ranked by (distance, original index) -- what a stable sort of the
+//               index-ordered list by distance gives -- first K, wrap-around padding.
+// |S| > kCap*K candidates do not fit the LDS list: the query is flagged and redone by the exhaustive
+// kernel (ball_query.hip, flag-filtered launch), so the result is exact for any density.
+//
+// A support point with float d2 < r^2 can never fall outside the 27 cells: h = r*(1+2e-4) leaves four
+// orders of magnitude more slack than the rounding of the cell coordinates (grid <= kMaxCells cells).
+#include "ball_query.h"
+
+namespace cl3d {
+
+constexpr int kMaxCells = 8192;
+constexpr int kBqQW = 4;   // queries per task / wave
+constexpr int kCapMul = 6; // LDS candidate list holds kCapMul*K entries per query
+
+struct BqGrid {
+  float ox, oy, oz, inv_h;
+  int nx, ny, nz, ncells;
+  int ntasks, nv, pad0, pad1;
+};
+
+struct BqTask {
+  int cell, q0, n, pad;
+};
+
+// workspace layout (per call), see cl3d_workspace_bytes(CL3D_OP_BALL_QUERY)
+struct BqWorkspace {
+  BqGrid *grid;        // [B]
+  float4 *sorted;      // [B,N]
+  int *cell_start;     // [B,kMaxCells+1]
+  int *qorder;         // [B,M]
+  BqTask *tasks;       // [B, M/QW + kMaxCells + 1]
+  int *overflow;       // [B,M]
+  int max_tasks;
+};
+
+__host__ __device__ inline size_t bq_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+inline size_t bq_workspace_bytes(int B, int N, int M) {
+  const size_t max_tasks = (size_t)(M + kBqQW - 1) / kBqQW + kMaxCells + 1;
+  return bq_align(sizeof(BqGrid) * B) + bq_align(sizeof(float4) * (size_t)B * N) +
+         bq_align(sizeof(int) * (size_t)B * (kMaxCells + 1)) + bq_align(sizeof(int) * (size_t)B * M) +
+         bq_align(sizeof(BqTask) * (size_t)B * max_tasks) + bq_align(sizeof(int) * (size_t)B * M);
+}
+
+inline BqWorkspace bq_carve(void *ws, int B, int N, int M) {
+  BqWorkspace w;
+  char *p = static_cast<char *>(ws);
+  w.max_tasks = (M + kBqQW - 1) / kBqQW + kMaxCells + 1;
+  w.grid = reinterpret_cast<BqGrid *>(p); p += bq_align(sizeof(BqGrid) * B);
+  w.sorted = reinterpret_cast<float4 *>(p); p += bq_align(sizeof(float4) * (size_t)B * N);
+  w.cell_start = reinterpret_cast<int *>(p); p += bq_align(sizeof(int) * (size_t)B * (kMaxCells + 1));
+  w.qorder = reinterpret_cast<int *>(p); p += bq_align(sizeof(int) * (size_t)B * M);
+  w.tasks = reinterpret_cast<BqTask *>(p); p += bq_align(sizeof(BqTask) * (size_t)B * w.max_tasks);
+  w.overflow = reinterpret_cast<int *>(p);
+  return w;
+}
+
+__device__ __forceinline__ int cell_coord(float x, float o, float inv_h) { return (int)floorf((x - o) * inv_h); }
+
+// block-wide exclusive scan of s_data[0..n) in place (n <= kMaxCells), returns the total; 1024 threads
+__device__ __forceinline__ int block_exclusive_scan(int *s_data, int n, int *s_wave) {
+  const int per = (n + 1023) / 1024;
+  const int t0 = threadIdx.x * per;
+  int sum = 0;
+  for (int i = 0; i < per; ++i)
+    if (t0 + i < n) sum += s_data[t0 + i];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int woff = 0, total = 0;
+  for (int w = 0; w < 16; ++w) {
+    if (w < wave) woff += s_wave[w];
+    total += s_wave[w];
+  }
+  int run = woff + incl - sum;
+  for (int i = 0; i < per; ++i) {
+    if (t0 + i < n) {
+      const int v = s_data[t0 + i];
+      s_data[t0 + i] = run;
+      run += v;
+    }
+  }
+  __syncthreads();
+  return total;
+}
+
+__global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__ query_xyz,
+                                                       const float *__restrict__ support_xyz,
+                                                       const int *__restrict__ support_mask, int M, int N,
+                                                       float radius, BqWorkspace w) {
+  __shared__ int s_cnt[kMaxCells];
+  __shared__ float s_red[6][16];
+  __shared__ int s_wave[16];
+  __shared__ int s_tmp;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float *s = support_xyz + (size_t)b * N * 3;
+  const float *q = query_xyz + (size_t)b * M * 3;
+  const int nv = block_first_zero(support_mask + (size_t)b * N, N, &s_tmp);
+
+  // bounding box of the valid support points
+  float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+  for (int i = tid; i < nv; i += 1024) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = s[i * 3 + a];
+      mn[a] = v < mn[a] ? v : mn[a];
+      mx[a] = v > mx[a] ? v : mx[a];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float omn = __shfl_xor(mn[a], o, 64), omx = __shfl_xor(mx[a], o, 64);
+      mn[a] = omn < mn[a] ? omn : mn[a];
+      mx[a] = omx > mx[a] ? omx : mx[a];
+    }
+    if (lane == 0) {
+      s_red[a][wave] = mn[a];
+      s_red[3 + a][wave] = mx[a];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = s_red[a][0];
+    mx[a] = s_red[3 + a][0];
+    for (int ww = 1; ww < 16; ++ww) {
+      mn[a] = s_red[a][ww] < mn[a] ? s_red[a][ww] : mn[a];
+      mx[a] = s_red[3 + a][ww] > mx[a] ? s_red[3 + a][ww] : mx[a];
+    }
+  }
+  // cell size: >= radius with slack, grown until the grid fits kMaxCells (every thread computes the same)
+  float h = radius * 1.0002f;
+  if (!(h > 0.f)) h = 1.0f;
+  int nx = 1, ny = 1, nz = 1;
+  if (nv > 0) {
+    for (int it = 0; it < 64; ++it) {
+      const float inv = 1.0f / h;
+      nx = (int)floorf((mx[0] - mn[0]) * inv) + 1;
+      ny = (int)floorf((mx[1] - mn[1]) * inv) + 1;
+      nz = (int)floorf((mx[2] - mn[2]) * inv) + 1;
+      if (nx > 0 && ny > 0 && nz > 0 && (long long)nx * ny * nz <= kMaxCells) break;
+      h *= 1.3f;
+    }
+    if (!(nx > 0 && ny > 0 && nz > 0 && (long long)nx * ny * nz <= kMaxCells)) {  // degenerate (inf/nan): one cell
+      nx = ny = nz = 1;
+      h = 3.0e38f;
+    }
+  }
+  const float inv_h = 1.0f / h;
+  const int ncells = nx * ny * nz;
+
+  // ---- counting sort of the valid support points by cell
+  for (int c = tid; c < ncells; c += 1024) s_cnt[c] = 0;
+  __syncthreads();
+  auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v >= hi ? hi - 1 : v); };
+  for (int i = tid; i < nv; i += 1024) {
+    const int cx = clampi(cell_coord(s[i * 3 + 0], mn[0], inv_h), nx);
+    const int cy = clampi(cell_coord(s[i * 3 + 1], mn[1], inv_h), ny);
+    const int cz = clampi(cell_coord(s[i * 3 + 2], mn[2], inv_h), nz);
+    atomicAdd(&s_cnt[cx + nx * (cy + ny * cz)], 1);
+  }
+  __syncthreads();
+  block_exclusive_scan(s_cnt, ncells, s_wave);
+  int *cs = w.cell_start + (size_t)b * (kMaxCells + 1);
+  for (int c = tid; c < ncells; c += 1024) cs[c] = s_cnt[c];
+  if (tid == 0) cs[ncells] = nv;
+  __syncthreads();
+  float4 *sorted = w.sorted + (size_t)b * N;
+  for (int i = tid; i < nv; i += 1024) {
+    const float x = s[i * 3 + 0], y = s[i * 3 + 1], z = s[i * 3 + 2];
+    const int cx = clampi(cell_coord(x, mn[0], inv_h), nx);
+    const int cy = clampi(cell_coord(y, mn[1], inv_h), ny);
+    const int cz = clampi(cell_coord(z, mn[2], inv_h), nz);
+    const int p = atomicAdd(&s_cnt[cx + nx * (cy + ny * cz)], 1);  // order inside a cell is irrelevant
+    sorted[p] = make_float4(x, y, z, __int_as_float(i));
+  }
+  __syncthreads();
+
+  // ---- queries by cell (clamped into the grid for grouping only) + task table
+  for (int c = tid; c < ncells; c += 1024) s_cnt[c] = 0;
+  __syncthreads();
+  for (int j = tid; j < M; j += 1024) {
+    const int cx = clampi(cell_coord(q[j * 3 + 0], mn[0], inv_h), nx);
+    const int cy = clampi(cell_coord(q[j * 3 + 1], mn[1], inv_h), ny);
+    const int cz = clampi(cell_coord(q[j * 3 + 2], mn[2], inv_h), nz);
+    atomicAdd(&s_cnt[cx + nx * (cy + ny * cz)], 1);
+  }
+  __syncthreads();
+  // tasks per cell and their prefix (kept in registers across the in-place scan of the query counts)
+  const int per = (ncells + 1023) / 1024;
+  const int t0 = tid * per;
+  int my_tasks = 0;
+  for (int i = 0; i < per; ++i)
+    if (t0 + i < ncells) my_tasks += (s_cnt[t0 + i] + kBqQW - 1) / kBqQW;
+  int incl = my_tasks;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  __syncthreads();
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  int task_off = 0, ntasks = 0;
+  for (int ww = 0; ww < 16; ++ww) {
+    if (ww < wave) task_off += s_wave[ww];
+    ntasks += s_wave[ww];
+  }
+  task_off += incl - my_tasks;
+  __syncthreads();
+  // query counts of my cells, before the scan overwrites them
+  // (per <= 8 for kMaxCells = 8192 and 1024 threads)
+  int nq_mine[8];
+  for (int i = 0; i < 8; ++i) nq_mine[i] = (i < per && t0 + i < ncells) ? s_cnt[t0 + i] : 0;
+  __syncthreads();
+  block_exclusive_scan(s_cnt, ncells, s_wave);
+  BqTask *tasks = w.tasks + (size_t)b * w.max_tasks;
+  {
+    int t = task_off;
+    for (int i = 0; i < 8; ++i) {
+      if (i < per && t0 + i < ncells) {
+        const int qs = s_cnt[t0 + i];
+        for (int k = 0; k < nq_mine[i]; k += kBqQW) {
+          BqTask tk;
+          tk.cell = t0 + i;
+          tk.q0 = qs + k;
+          tk.n = nq_mine[i] - k < kBqQW ? nq_mine[i] - k : kBqQW;
+          tk.pad = 0;
+          tasks[t++] = tk;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  int *qorder = w.qorder + (size_t)b * M;
+  for (int j = tid; j < M; j += 1024) {
+    const int cx = clampi(cell_coord(q[j * 3 + 0], mn[0], inv_h), nx);
+    const int cy = clampi(cell_coord(q[j * 3 + 1], mn[1], inv_h), ny);
+    const int cz = clampi(cell_coord(q[j * 3 + 2], mn[2], inv_h), nz);
+    qorder[atomicAdd(&s_cnt[cx + nx * (cy + ny * cz)], 1)] = j;
+  }
+  if (tid == 0) {
+    BqGrid g;
+    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_h = inv_h;
+    g.nx = nx; g.ny = ny; g.nz = nz; g.ncells = ncells;
+    g.ntasks = ntasks; g.nv = nv; g.pad0 = g.pad1 = 0;
+    w.grid[b] = g;
+  }
+}
+
+__global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__ query_xyz,
+                                                       const int *__restrict__ query_mask, int M, int N,
+                                                       float radius2, int K, BqWorkspace w,
+                                                       int *__restrict__ idx, int *__restrict__ idx_mask) {
+  extern __shared__ int smem[];
+  const int cap3 = 3 * K;
+  const int cap = kCapMul * K;
+  const int b = blockIdx.y;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // LDS carve per wave: cand_d[QW][cap], cand_i[QW][cap], sel_d[QW][cap3], sel_i[QW][cap3], out_i[QW][K]
+  const int per_wave = kBqQW * (2 * cap + 2 * cap3 + K);
+  int *base = smem + (size_t)wave * per_wave;
+  float *cand_d = reinterpret_cast<float *>(base);
+  int *cand_i = base + kBqQW * cap;
+  float *sel_d = reinterpret_cast<float *>(base + 2 * kBqQW * cap);
+  int *sel_i = base + 2 * kBqQW * cap + kBqQW * cap3;
+  int *out_i = base + 2 * kBqQW * cap + 2 * kBqQW * cap3;
+
+  const BqGrid g = w.grid[b];
+  const float *q = query_xyz + (size_t)b * M * 3;
+  const int *qm = query_mask + (size_t)b * M;
+  const float4 *sorted = w.sorted + (size_t)b * N;
+  const int *cs = w.cell_start + (size_t)b * (kMaxCells + 1);
+  const int *qorder = w.qorder + (size_t)b * M;
+  const BqTask *tasks = w.tasks + (size_t)b * w.max_tasks;
+  int *oflow = w.overflow + (size_t)b * M;
+
+  for (int t = blockIdx.x * 4 + wave; t < g.ntasks; t += gridDim.x * 4) {
+    const BqTask tk = tasks[t];
+    const int n = tk.n;
+    int jq[kBqQW];
+    float qx[kBqQW], qy[kBqQW], qz[kBqQW], lmin[kBqQW];
+    int lidx[kBqQW], cnt[kBqQW];
+#pragma unroll
+    for (int u = 0; u < kBqQW; ++u) {
+      const int j = qorder[tk.q0 + (u < n ? u : 0)];
+      jq[u] = j;
+      qx[u] = q[j * 3 + 0];
+      qy[u] = q[j * 3 + 1];
+      qz[u] = q[j * 3 + 2];
+      lmin[u] = radius2;
+      lidx[u] = 0;
+      cnt[u] = 0;
+    }
+    // the queries' TRUE cell (queries outside the support box were clamped for grouping only; every query
+    // of a task has the same clamped cell, and a query whose true cell differs from it lies outside the
+    // grid, where looking one cell inwards from the true coordinate is what matters)
+    const int ccx = tk.cell % g.nx, ccy = (tk.cell / g.nx) % g.ny, ccz = tk.cell / (g.nx * g.ny);
+    // candidate window: cells within one of ANY of the task's queries' true cells.  All queries share
+    // the clamped cell; true cells can only differ from it outwards, so [min true - 1, max true + 1]
+    // clipped to the grid covers every query (a few extra cells for far-outside queries, never fewer).
+    int lo[3] = {ccx, ccy, ccz}, hi[3] = {ccx, ccy, ccz};
+#pragma unroll
+    for (int u = 0; u < kBqQW; ++u) {
+      if (u < n) {
+        const int tx = cell_coord(qx[u], g.ox, g.inv_h), ty = cell_coord(qy[u], g.oy, g.inv_h),
+                  tz = cell_coord(qz[u], g.oz, g.inv_h);
+        lo[0] = tx < lo[0] ? tx : lo[0]; hi[0] = tx > hi[0] ? tx : hi[0];
+        lo[1] = ty < lo[1] ? ty : lo[1]; hi[1] = ty > hi[1] ? ty : hi[1];
+        lo[2] = tz < lo[2] ? tz : lo[2]; hi[2] = tz > hi[2] ? tz : hi[2];
+      }
+    }
+    const int x0 = lo[0] - 1 < 0 ? 0 : lo[0] - 1, x1 = hi[0] + 1 >= g.nx ? g.nx - 1 : hi[0] + 1;
+    const int y0 = lo[1] - 1 < 0 ? 0 : lo[1] - 1, y1 = hi[1] + 1 >= g.ny ? g.ny - 1 : hi[1] + 1;
+    const int z0 = lo[2] - 1 < 0 ? 0 : lo[2] - 1, z1 = hi[2] + 1 >= g.nz ? g.nz - 1 : hi[2] + 1;
+
+    for (int cz = z0; cz <= z1; ++cz) {
+      for (int cy = y0; cy <= y1; ++cy) {
+        if (x0 > x1) continue;
+        const int row = g.nx * (cy + g.ny * cz);
+        const int ra = cs[row + x0], rb = cs[row + x1 + 1];
+        for (int p0 = ra; p0 < rb; p0 += CL3D_WAVE) {
+          const int p = p0 + lane;
+          const bool valid = p < rb;
+          const float4 sp = sorted[valid ? p : rb - 1];
+          const int orig = __float_as_int(sp.w);
+#pragma unroll
+          for (int u = 0; u < kBqQW; ++u) {
+            const float d2 = dist2(qx[u], qy[u], qz[u], sp.x, sp.y, sp.z);
+            const bool hit = valid && u < n && (d2 < radius2);
+            const unsigned long long m = __ballot(hit);
+            if (m != 0ull) {
+              // first-occurrence strict minimum == smallest (d2, original index)
+              if (hit && (d2 < lmin[u] || (d2 == lmin[u] && orig < lidx[u]))) {
+                lmin[u] = d2;
+                lidx[u] = orig;
+              }
+              const int c = cnt[u];
+              const int pos = c + prefix_popc(m);
+              if (hit && pos < cap) {
+                cand_d[u * cap + pos] = d2;
+                cand_i[u * cap + pos] = orig;
+              }
+              cnt[u] = c + (int)__popcll(m);
+            }
+          }
+        }
+      }
+    }
+    // LDS traffic below is wave-private and in program order; the fence keeps the compiler from reordering
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+    for (int u = 0; u < kBqQW; ++u) {
+      if (u >= n) continue;
+      const int j = jq[u];
+      const int S = __builtin_amdgcn_readfirstlane(cnt[u]);
+      int *oi = idx + ((size_t)b * M + j) * K;
+      int *om = idx_mask + ((size_t)b * M + j) * K;
+      if (S > cap) {  // too dense for the LDS list: the exhaustive kernel redoes this query
+        if (lane == 0) oflow[j] = 1;
+        continue;
+      }
+      if (lane == 0) oflow[j] = 0;
+      float *ld = cand_d + u * cap;
+      int *li = cand_i + u * cap;
+      int c = S;
+      if (S > cap3) {
+        // the 3K smallest original indices, written in index order
+        unsigned long long key = ((unsigned long long)__float_as_uint(lmin[u]) << 32) | (unsigned)lidx[u];
+        key = wave_min_u64(key);
+        const int gidx = (int)(unsigned)(key & 0xffffffffull);
+        float *sd = sel_d + u * cap3;
+        int *si = sel_i + u * cap3;
+        for (int e = lane; e < S; e += CL3D_WAVE) {
+          const int ie = li[e];
+          int r = 0;
+          for (int f = 0; f < S; ++f) r += (li[f] < ie) ? 1 : 0;
+          if (r < cap3) {
+            sd[r] = ld[e];
+            si[r] = ie;
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (gidx > si[cap3 - 1]) {  // uniform: the minimum was cut off -> it takes the last slot
+          if (lane == 0) {
+            si[cap3 - 1] = gidx;
+            sd[cap3 - 1] = __uint_as_float((unsigned)(key >> 32));
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        ld = sd;
+        li = si;
+        c = cap3;
+      }
+      // rank by (distance, original index) == stable sort by distance of the index-ordered list
+      int *so = out_i + u * K;
+      for (int e = lane; e < c; e += CL3D_WAVE) {
+        const float de = ld[e];
+        const int ie = li[e];
+        int rank = 0;
+        for (int f = 0; f < c; ++f) {
+          const float df = ld[f];
+          rank += (df < de || (df == de && li[f] < ie)) ? 1 : 0;
+        }
+        if (rank < K) so[rank] = ie;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int qmk = qm[j];
+      for (int i = lane; i < K; i += CL3D_WAVE) {
+        int v = 0, mk = 0;
+        if (c > 0) {
+          v = so[i < c ? i : i % c];
+          mk = (i < c && qmk != 0) ? 1 : 0;
+        }
+        oi[i] = v;
+        om[i] = mk;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+}  // namespace cl3d
+
+namespace cl3d {
+
+size_t ball_query_cells_workspace(int B, int N, int M) { return bq_workspace_bytes(B, N, M); }
+
+bool ball_query_cells_applicable(int M, int N, int K) {
+  const size_t lds = (size_t)4 * kBqQW * (2 * kCapMul * K + 2 * 3 * K + K) * sizeof(int);
+  return N >= 512 && M >= 64 && lds <= 64 * 1024;
+}
+
+int ball_query_cells(const float *query_xyz, const float *support_xyz, const int *query_mask,
+                     const int *support_mask, int B, int M, int N, float radius, int K, int *idx,
+                     int *idx_mask, void *ws, size_t ws_bytes, hipStream_t st) {
+  if (ws == nullptr || ws_bytes < bq_workspace_bytes(B, N, M))
+    return fail(CL3D_E_WORKSPACE, "ball_query: workspace %zu < %zu", ws_bytes, bq_workspace_bytes(B, N, M));
+  if (B > 65535) return fail(CL3D_E_UNSUPPORTED, "ball_query: B exceeds grid.y limit");
+  BqWorkspace w = bq_carve(ws, B, N, M);
+  hipLaunchKernelGGL(bq_prep_kernel, dim3(B), dim3(1024), 0, st, query_xyz, support_xyz, support_mask, M, N, radius, w);
+  const size_t lds = (size_t)4 * kBqQW * (2 * kCapMul * K + 2 * 3 * K + K) * sizeof(int);
+  int gx = ceil_div(ceil_div(M, kBqQW) + 64, 4);  // ~one task per wave at typical occupancy; persistent loop beyond
+  gx = gx > 512 ? 512 : gx;
+  hipLaunchKernelGGL(bq_query_kernel, dim3(gx, B), dim3(256), lds, st, query_xyz, query_mask, M, N, radius * radius, K, w, idx, idx_mask);
+  int rc = check_launch("cl3d_masked_ordered_ball_query(cells)");
+  if (rc != CL3D_OK) return rc;
+  // queries too dense for the LDS list were flagged; the exhaustive kernel redoes exactly those
+  return ball_query_exhaustive(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, K, idx, idx_mask,
+                               w.overflow, st);
+}
+
+}  // namespace cl3d

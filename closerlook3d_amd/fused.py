@@ -246,6 +246,38 @@ class _PointwiseMLP(Function):
         return (dght, dwr, dgamma64.float(), dbeta64.float()) + (None,) * 10
 
 
+class _PointGemm(Function):
+    """rows[b,i,:] = W f[b,:,i]  (features channel-major [B,C,N], W [R,C]) -> point-major [B,N,R].
+
+    Plain library GEMMs (rocBLAS/hipBLASLt through torch.matmul).  The weight gradient is a reduction over
+    all B*N points into an R x C matrix; left to the library as one GEMM it gets a handful of workgroups
+    (207 us at the metric shape), so it is issued split-K: a batched GEMM over row chunks + a fixed-order sum.
+    """
+
+    @staticmethod
+    def forward(ctx, features, weight):
+        ctx.save_for_backward(features, weight)
+        return torch.matmul(features.transpose(1, 2), weight.t())
+
+    @staticmethod
+    def backward(ctx, grows):
+        features, weight = ctx.saved_tensors
+        B, C, N = features.shape
+        R = weight.shape[0]
+        dfeat = dweight = None
+        if ctx.needs_input_grad[0]:
+            dfeat = torch.matmul(grows, weight).transpose(1, 2)  # [B,C,N] view of [B,N,C]
+        if ctx.needs_input_grad[1]:
+            chunk = 1024
+            if N % chunk == 0:
+                g = grows.reshape(B * (N // chunk), chunk, R)
+                f = features.reshape(B, C, N // chunk, chunk).permute(0, 2, 3, 1).reshape(B * (N // chunk), chunk, C)
+                dweight = torch.bmm(g.transpose(1, 2), f).sum(0)
+            else:
+                dweight = torch.matmul(grows.reshape(B * N, R).t(), features.transpose(1, 2).reshape(B * N, C))
+        return dfeat, dweight
+
+
 def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps, reduction,
                   training):
     assert reduction == 'max'
@@ -257,7 +289,7 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
     wr = W[:, :3].contiguous()
     wc, wd = W[:, 3:3 + C], W[:, 3 + C:]
     # once per point instead of once per (point, neighbour): rows [W_d f_i | (W_c - W_d) f_i]
-    ght = torch.matmul(features.transpose(1, 2), torch.cat([wd, wc - wd], 0).t())
+    ght = _PointGemm.apply(features, torch.cat([wd, wc - wd], 0))
     use_batch_stats = training or bn.running_mean is None
     if use_batch_stats and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
