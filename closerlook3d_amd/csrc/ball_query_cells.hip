@@ -34,6 +34,7 @@ namespace cl3d {
 constexpr int kMaxCells = 8192;
 constexpr int kBqQW = 4;   // queries per task / wave
 constexpr int kCapMul = 6; // LDS candidate list holds kCapMul*K entries per query
+constexpr int kBqBatch = 3;  // candidate float4 loads in flight per lane
 
 struct BqGrid {
   float ox, oy, oz, inv_h;
@@ -347,35 +348,65 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
     const int y0 = lo[1] - 1 < 0 ? 0 : lo[1] - 1, y1 = hi[1] + 1 >= g.ny ? g.ny - 1 : hi[1] + 1;
     const int z0 = lo[2] - 1 < 0 ? 0 : lo[2] - 1, z1 = hi[2] + 1 >= g.nz ? g.nz - 1 : hi[2] + 1;
 
-    for (int cz = z0; cz <= z1; ++cz) {
-      for (int cy = y0; cy <= y1; ++cy) {
-        if (x0 > x1) continue;
+    // The window is at most 3x3 (y,z) rows of cells; in the cell order the <= 3 cells of a row are one
+    // contiguous run of `sorted`.  Lanes 0..8 fetch the nine run bounds at once, the runs are laid end
+    // to end into one candidate index space, and lanes walk that space fully packed, kBqBatch float4
+    // loads in flight per lane (instead of nine dependent cs -> sorted round trips with half-empty waves).
+    int my_ra = 0, my_len = 0;
+    if (lane < 9) {
+      const int cy = y0 + lane % 3, cz = z0 + lane / 3;
+      if (cy <= y1 && cz <= z1 && x0 <= x1) {
         const int row = g.nx * (cy + g.ny * cz);
-        const int ra = cs[row + x0], rb = cs[row + x1 + 1];
-        for (int p0 = ra; p0 < rb; p0 += CL3D_WAVE) {
-          const int p = p0 + lane;
-          const bool valid = p < rb;
-          const float4 sp = sorted[valid ? p : rb - 1];
-          const int orig = __float_as_int(sp.w);
+        my_ra = cs[row + x0];
+        my_len = cs[row + x1 + 1] - my_ra;
+      }
+    }
+    int incl = my_len;
 #pragma unroll
-          for (int u = 0; u < kBqQW; ++u) {
-            const float d2 = dist2(qx[u], qy[u], qz[u], sp.x, sp.y, sp.z);
-            const bool hit = valid && u < n && (d2 < radius2);
-            const unsigned long long m = __ballot(hit);
-            if (m != 0ull) {
-              // first-occurrence strict minimum == smallest (d2, original index)
-              if (hit && (d2 < lmin[u] || (d2 == lmin[u] && orig < lidx[u]))) {
-                lmin[u] = d2;
-                lidx[u] = orig;
-              }
-              const int c = cnt[u];
-              const int pos = c + prefix_popc(m);
-              if (hit && pos < cap) {
-                cand_d[u * cap + pos] = d2;
-                cand_i[u * cap + pos] = orig;
-              }
-              cnt[u] = c + (int)__popcll(m);
+    for (int o = 1; o < 16; o <<= 1) {
+      const int v = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += v;
+    }
+    const int T = __builtin_amdgcn_readlane(incl, 8);
+    int run_pe[9], run_delta[9];  // exclusive prefix and (start - prefix) of every run, wave-uniform
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      run_pe[r] = __builtin_amdgcn_readlane(incl - my_len, r);
+      run_delta[r] = __builtin_amdgcn_readlane(my_ra - (incl - my_len), r);
+    }
+    for (int p0 = 0; p0 < T; p0 += CL3D_WAVE * kBqBatch) {
+      float4 sp[kBqBatch];
+      bool ok[kBqBatch];
+#pragma unroll
+      for (int v = 0; v < kBqBatch; ++v) {
+        const int p = p0 + v * CL3D_WAVE + lane;
+        ok[v] = p < T;
+        int delta = run_delta[0];
+#pragma unroll
+        for (int r = 1; r < 9; ++r) delta = p >= run_pe[r] ? run_delta[r] : delta;
+        sp[v] = sorted[ok[v] ? p + delta : 0];
+      }
+#pragma unroll
+      for (int v = 0; v < kBqBatch; ++v) {
+        const int orig = __float_as_int(sp[v].w);
+#pragma unroll
+        for (int u = 0; u < kBqQW; ++u) {
+          const float d2 = dist2(qx[u], qy[u], qz[u], sp[v].x, sp[v].y, sp[v].z);
+          const bool hit = ok[v] && u < n && (d2 < radius2);
+          const unsigned long long m = __ballot(hit);
+          if (m != 0ull) {
+            // first-occurrence strict minimum == smallest (d2, original index)
+            if (hit && (d2 < lmin[u] || (d2 == lmin[u] && orig < lidx[u]))) {
+              lmin[u] = d2;
+              lidx[u] = orig;
             }
+            const int c = cnt[u];
+            const int pos = c + prefix_popc(m);
+            if (hit && pos < cap) {
+              cand_d[u * cap + pos] = d2;
+              cand_i[u * cap + pos] = orig;
+            }
+            cnt[u] = c + (int)__popcll(m);
           }
         }
       }

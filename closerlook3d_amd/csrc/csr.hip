@@ -9,21 +9,23 @@
 // atomics, summation order fixed).  It depends on idx only, so one build serves the backward of every
 // operator that shares the ball query.
 //
-// Build = two scans of idx + one prefix sum, no global atomics and no sort:
-//   count  a block owns 128 consecutive support rows (32 per wave).  The cloud's slot array (0.5 MB at
+// Build = two LDS-fed scans of idx + a prefix sum + a per-row sort, no global atomics:
+//   count  a block owns 256 consecutive support rows (64 per wave).  The cloud's slot array (0.5 MB at
 //          the metric shape) is streamed through LDS in 16 KiB chunks -- loaded once per block,
 //          coalesced, then scanned by all four waves with ds_read_b128 -- and every wave counts the slots
 //          that land in its rows (LDS integer atomics: exact, 8 op/clk/CU);
 //   scan   per-cloud exclusive prefix sum of the counts;
-//   fill   the same stream again; hits are handled one at a time in slot order (wave-uniform loop over
-//          the ballots), so each row's list comes out ascending by construction.
-// History: global integer atomics + per-segment rank sort took 270 us per build at the metric shape;
-// per-wave scans straight from L2 took 330 us (1 GB of L2 reads per pass); this version is LDS-fed.
+//   fill   the same stream again; every hit takes its position from an LDS cursor of its row
+//          (ds_add_rtn_u32) -- all hit lanes at once, so the order inside a row is arbitrary;
+//   sort   one wave per row rank-sorts its segment (slot ids are unique) => ascending, deterministic.
+// History (metric shape, per build): global integer atomics + sort 270 us; per-wave scans straight from
+// L2 330 us (1 GB of L2 reads per pass); LDS-fed scans with a wave-uniform ordered hit loop 350 us (2.1 M
+// hits x ~60 cycles of serial scalar code); this version ~100 us.
 #include "fused_common.h"
 
 namespace cl3d {
 
-constexpr int kCsrRows = 32;      // support rows per wave
+constexpr int kCsrRows = 64;      // support rows per wave
 constexpr int kCsrChunk = 4096;   // slots staged in LDS per step (16 KiB)
 
 // cooperative, coalesced load of idx[base .. base+kCsrChunk) into LDS (-1 beyond MK)
@@ -105,8 +107,9 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(const int *__restrict__ 
 }
 
 __global__ __launch_bounds__(256) void csr_fill_kernel(const int *__restrict__ idx, const int *__restrict__ off,
-                                                       int B, int N, int MK, int *__restrict__ slots) {
+                                                       int B, int N, int MK, int *__restrict__ tmp) {
   __shared__ __attribute__((aligned(16))) int s_idx[kCsrChunk];
+  __shared__ unsigned s_cur[4][kCsrRows];
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int tiles_per_cloud = (N + 4 * kCsrRows - 1) / (4 * kCsrRows);
@@ -114,34 +117,46 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int *__restrict__ i
   decode_tile(blockIdx.x, B, tiles_per_cloud, b, tile);
   const int r0 = (tile * 4 + wave) * kCsrRows;
   const int *ib = idx + (size_t)b * MK;
-  int *sb = slots + (size_t)b * MK;
-  // lane r (< 32) carries the next write position of row r0 + r
-  int pos = (lane < kCsrRows && r0 + lane < N) ? off[(size_t)b * (N + 1) + r0 + lane] : 0;
+  int *tb = tmp + (size_t)b * MK;
+  s_cur[wave][lane] = (r0 + lane < N) ? (unsigned)off[(size_t)b * (N + 1) + r0 + lane] : 0u;
   for (int base = 0; base < MK; base += kCsrChunk) {
     __syncthreads();
     csr_stage(ib, MK, base, s_idx);
     __syncthreads();
-    // 256 slots per step: lane l holds slots 4l .. 4l+3, so ascending slot order = (lane, component)
-    for (int sub = 0; sub < kCsrChunk / 256; ++sub) {
-      const int4 v = reinterpret_cast<const int4 *>(s_idx)[sub * 64 + lane];
+    for (int t = lane; t < kCsrChunk / 4; t += 64) {
+      const int4 v = reinterpret_cast<const int4 *>(s_idx)[t];
       const int d[4] = {v.x - r0, v.y - r0, v.z - r0, v.w - r0};
-      unsigned long long m[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) m[c] = __ballot((unsigned)d[c] < (unsigned)kCsrRows);
-      unsigned long long any = m[0] | m[1] | m[2] | m[3];
-      while (any) {  // wave-uniform
-        const int t = __builtin_ctzll(any);
-        any &= any - 1;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if ((m[c] >> t) & 1ull) {
-            const int row = __builtin_amdgcn_readlane(d[c], t);
-            const int p = __builtin_amdgcn_readlane(pos, row);
-            if (lane == row) pos += 1;
-            if (lane == 0) sb[p] = base + sub * 256 + 4 * t + c;
-          }
-        }
-      }
+      for (int c = 0; c < 4; ++c)
+        if ((unsigned)d[c] < (unsigned)kCsrRows) tb[atomicAdd(&s_cur[wave][d[c]], 1u)] = base + 4 * t + c;
+    }
+  }
+}
+
+// one wave per row: rank sort of its segment (values are unique slot ids)
+__global__ __launch_bounds__(256) void csr_sort_kernel(const int *__restrict__ off, const int *__restrict__ tmp,
+                                                       int B, int N, int MK, int *__restrict__ slots) {
+  const int lane = lane_id();
+  const int tiles_per_cloud = (N + 3) / 4;
+  int b, tile;
+  decode_tile(blockIdx.x, B, tiles_per_cloud, b, tile);
+  const int i = tile * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const int *ob = off + (size_t)b * (N + 1);
+  const int s0 = ob[i], len = ob[i + 1] - s0;
+  const int *tb = tmp + (size_t)b * MK + s0;
+  int *sb = slots + (size_t)b * MK + s0;
+  if (len <= 64) {
+    const int v = lane < len ? tb[lane] : 0x7fffffff;
+    int rank = 0;
+    for (int t = 0; t < len; ++t) rank += (__shfl(v, t, 64) < v) ? 1 : 0;
+    if (lane < len) sb[rank] = v;
+  } else {
+    for (int e = lane; e < len; e += 64) {
+      const int v = tb[e];
+      int rank = 0;
+      for (int t = 0; t < len; ++t) rank += (tb[t] < v) ? 1 : 0;
+      sb[rank] = v;
     }
   }
 }
@@ -155,16 +170,21 @@ extern "C" int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK
   if (B == 0) return CL3D_OK;
   CL3D_REQUIRE(idx || MK == 0, "build_inverse_index: null idx");
   CL3D_REQUIRE(inv_off && (inv_slots || MK == 0), "build_inverse_index: null output");
-  const size_t need = (size_t)B * N * sizeof(int);
+  const size_t need = ((size_t)B * N + (size_t)B * MK) * sizeof(int);
   if (ws_bytes < need || !ws) return cl3d::fail(CL3D_E_WORKSPACE, "build_inverse_index: workspace %zu < %zu", ws_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   int *cnt = static_cast<int *>(ws);
+  int *tmp = cnt + (size_t)B * N;
   const int tiles_per_cloud = cl3d::ceil_div(N, 4 * cl3d::kCsrRows);
   const long long blocks = (long long)B * tiles_per_cloud;
   CL3D_REQUIRE(blocks <= 0x7fffffffLL, "build_inverse_index: too many rows");
   hipLaunchKernelGGL(cl3d::csr_count_kernel, dim3((unsigned)blocks), dim3(256), 0, st, idx, B, N, MK, cnt);
   hipLaunchKernelGGL(cl3d::csr_scan_kernel, dim3(B), dim3(1024), 0, st, cnt, N, inv_off);
-  if (MK > 0)
-    hipLaunchKernelGGL(cl3d::csr_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, idx, inv_off, B, N, MK, inv_slots);
+  if (MK > 0) {
+    hipLaunchKernelGGL(cl3d::csr_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, idx, inv_off, B, N, MK, tmp);
+    const long long sort_blocks = (long long)B * cl3d::ceil_div(N, 4);
+    CL3D_REQUIRE(sort_blocks <= 0x7fffffffLL, "build_inverse_index: too many rows");
+    hipLaunchKernelGGL(cl3d::csr_sort_kernel, dim3((unsigned)sort_blocks), dim3(256), 0, st, inv_off, tmp, B, N, MK, inv_slots);
+  }
   return cl3d::check_launch("cl3d_build_inverse_index");
 }

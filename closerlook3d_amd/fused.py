@@ -59,7 +59,7 @@ def inverse_index(idx, n_support):
     MK = idx[0].numel()
     off = torch.empty((B, n_support + 1), dtype=torch.int32, device=idx.device)
     slots = torch.empty((B, MK), dtype=torch.int32, device=idx.device)
-    ws = torch.empty((B * n_support,), dtype=torch.int32, device=idx.device)
+    ws = torch.empty((B * n_support + B * MK,), dtype=torch.int32, device=idx.device)
     with torch.cuda.device(idx.device):
         _lib.check(_lib.lib().cl3d_build_inverse_index(_p(idx), B, n_support, MK, _p(off), _p(slots), _p(ws),
                                                        ws.numel() * 4, _stream(idx)))
