@@ -132,6 +132,7 @@ __global__ __launch_bounds__(256) void ball_query_kernel(
     for (int e = lane; e < c; e += CL3D_WAVE) {
       const float de = cd[e];
       int rank = 0;
+#pragma unroll 8
       for (int f = 0; f < c; ++f) {
         const float df = cd[f];
         rank += (df < de || (df == de && f < e)) ? 1 : 0;

@@ -51,7 +51,7 @@ struct BqWorkspace {
   BqGrid *grid;        // [B]
   float4 *sorted;      // [B,N]
   int *cell_start;     // [B,kMaxCells+1]
-  int *qorder;         // [B,M]
+  float4 *qsorted;     // [B,M] queries grouped by cell: {x,y,z, original query index}
   BqTask *tasks;       // [B, M/QW + kMaxCells + 1]
   int *overflow;       // [B,M]
   int max_tasks;
@@ -62,7 +62,7 @@ __host__ __device__ inline size_t bq_align(size_t x) { return (x + 255) & ~(size
 inline size_t bq_workspace_bytes(int B, int N, int M) {
   const size_t max_tasks = (size_t)(M + kBqQW - 1) / kBqQW + kMaxCells + 1;
   return bq_align(sizeof(BqGrid) * B) + bq_align(sizeof(float4) * (size_t)B * N) +
-         bq_align(sizeof(int) * (size_t)B * (kMaxCells + 1)) + bq_align(sizeof(int) * (size_t)B * M) +
+         bq_align(sizeof(int) * (size_t)B * (kMaxCells + 1)) + bq_align(sizeof(float4) * (size_t)B * M) +
          bq_align(sizeof(BqTask) * (size_t)B * max_tasks) + bq_align(sizeof(int) * (size_t)B * M);
 }
 
@@ -73,7 +73,7 @@ inline BqWorkspace bq_carve(void *ws, int B, int N, int M) {
   w.grid = reinterpret_cast<BqGrid *>(p); p += bq_align(sizeof(BqGrid) * B);
   w.sorted = reinterpret_cast<float4 *>(p); p += bq_align(sizeof(float4) * (size_t)B * N);
   w.cell_start = reinterpret_cast<int *>(p); p += bq_align(sizeof(int) * (size_t)B * (kMaxCells + 1));
-  w.qorder = reinterpret_cast<int *>(p); p += bq_align(sizeof(int) * (size_t)B * M);
+  w.qsorted = reinterpret_cast<float4 *>(p); p += bq_align(sizeof(float4) * (size_t)B * M);
   w.tasks = reinterpret_cast<BqTask *>(p); p += bq_align(sizeof(BqTask) * (size_t)B * w.max_tasks);
   w.overflow = reinterpret_cast<int *>(p);
   return w;
@@ -265,12 +265,13 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
     }
   }
   __syncthreads();
-  int *qorder = w.qorder + (size_t)b * M;
+  float4 *qsorted = w.qsorted + (size_t)b * M;
   for (int j = tid; j < M; j += 1024) {
-    const int cx = clampi(cell_coord(q[j * 3 + 0], mn[0], inv_h), nx);
-    const int cy = clampi(cell_coord(q[j * 3 + 1], mn[1], inv_h), ny);
-    const int cz = clampi(cell_coord(q[j * 3 + 2], mn[2], inv_h), nz);
-    qorder[atomicAdd(&s_cnt[cx + nx * (cy + ny * cz)], 1)] = j;
+    const float x = q[j * 3 + 0], y = q[j * 3 + 1], z = q[j * 3 + 2];
+    const int cx = clampi(cell_coord(x, mn[0], inv_h), nx);
+    const int cy = clampi(cell_coord(y, mn[1], inv_h), ny);
+    const int cz = clampi(cell_coord(z, mn[2], inv_h), nz);
+    qsorted[atomicAdd(&s_cnt[cx + nx * (cy + ny * cz)], 1)] = make_float4(x, y, z, __int_as_float(j));
   }
   if (tid == 0) {
     BqGrid g;
@@ -301,11 +302,10 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
   int *out_i = base + 2 * kBqQW * cap + 2 * kBqQW * cap3;
 
   const BqGrid g = w.grid[b];
-  const float *q = query_xyz + (size_t)b * M * 3;
   const int *qm = query_mask + (size_t)b * M;
   const float4 *sorted = w.sorted + (size_t)b * N;
   const int *cs = w.cell_start + (size_t)b * (kMaxCells + 1);
-  const int *qorder = w.qorder + (size_t)b * M;
+  const float4 *qsorted = w.qsorted + (size_t)b * M;
   const BqTask *tasks = w.tasks + (size_t)b * w.max_tasks;
   int *oflow = w.overflow + (size_t)b * M;
 
@@ -317,11 +317,11 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
     int lidx[kBqQW], cnt[kBqQW];
 #pragma unroll
     for (int u = 0; u < kBqQW; ++u) {
-      const int j = qorder[tk.q0 + (u < n ? u : 0)];
-      jq[u] = j;
-      qx[u] = q[j * 3 + 0];
-      qy[u] = q[j * 3 + 1];
-      qz[u] = q[j * 3 + 2];
+      const float4 qq = qsorted[tk.q0 + (u < n ? u : 0)];
+      jq[u] = __float_as_int(qq.w);
+      qx[u] = qq.x;
+      qy[u] = qq.y;
+      qz[u] = qq.z;
       lmin[u] = radius2;
       lidx[u] = 0;
       cnt[u] = 0;
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
         for (int e = lane; e < S; e += CL3D_WAVE) {
           const int ie = li[e];
           int r = 0;
+#pragma unroll 8
           for (int f = 0; f < S; ++f) r += (li[f] < ie) ? 1 : 0;
           if (r < cap3) {
             sd[r] = ld[e];
@@ -466,6 +467,7 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
         const float de = ld[e];
         const int ie = li[e];
         int rank = 0;
+#pragma unroll 8
         for (int f = 0; f < c; ++f) {
           const float df = ld[f];
           rank += (df < de || (df == de && li[f] < ie)) ? 1 : 0;

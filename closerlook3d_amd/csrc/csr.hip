@@ -25,24 +25,38 @@
 
 namespace cl3d {
 
-constexpr int kCsrRows = 64;      // support rows per wave
+constexpr int kCsrRows = 32;      // support rows per wave
 constexpr int kCsrChunk = 4096;   // slots staged in LDS per step (16 KiB)
 
-// cooperative, coalesced load of idx[base .. base+kCsrChunk) into LDS (-1 beyond MK)
-__device__ __forceinline__ void csr_stage(const int *__restrict__ ib, int MK, int base, int *s_idx) {
+// Cooperative, coalesced staging of idx[base .. base+kCsrChunk) into LDS (-1 beyond MK), split in two
+// halves -- global loads into registers, registers into LDS -- so that the loads of chunk i+1 are in
+// flight while chunk i is scanned (with one or two workgroups per CU nothing else hides that latency).
+struct CsrStage {
+  int4 v[4];
+};
+__device__ __forceinline__ void csr_stage_load(const int *__restrict__ ib, int MK, int base, CsrStage &st) {
+  if (base >= MK) return;
   if ((MK & 3) == 0) {
-    int4 v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = base + (u * 256 + (int)threadIdx.x) * 4;
-      v[u] = *reinterpret_cast<const int4 *>(ib + (e < MK ? e : 0));  // always a valid address
-      if (e >= MK) v[u] = make_int4(-1, -1, -1, -1);
+      st.v[u] = *reinterpret_cast<const int4 *>(ib + (e < MK ? e : 0));  // always a valid address
+      if (e >= MK) st.v[u] = make_int4(-1, -1, -1, -1);
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) reinterpret_cast<int4 *>(s_idx)[u * 256 + threadIdx.x] = v[u];
   } else {
-    for (int t = threadIdx.x; t < kCsrChunk; t += 256) s_idx[t] = base + t < MK ? ib[base + t] : -1;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = base + (u * 256 + (int)threadIdx.x) * 4;
+      st.v[u].x = e + 0 < MK ? ib[e + 0] : -1;
+      st.v[u].y = e + 1 < MK ? ib[e + 1] : -1;
+      st.v[u].z = e + 2 < MK ? ib[e + 2] : -1;
+      st.v[u].w = e + 3 < MK ? ib[e + 3] : -1;
+    }
   }
+}
+__device__ __forceinline__ void csr_stage_commit(const CsrStage &st, int *s_idx) {
+#pragma unroll
+  for (int u = 0; u < 4; ++u) reinterpret_cast<int4 *>(s_idx)[u * 256 + threadIdx.x] = st.v[u];
 }
 
 __global__ __launch_bounds__(256) void csr_count_kernel(const int *__restrict__ idx, int B, int N, int MK,
@@ -57,10 +71,13 @@ __global__ __launch_bounds__(256) void csr_count_kernel(const int *__restrict__ 
   const int r0 = (tile * 4 + wave) * kCsrRows;
   if (lane < kCsrRows) s_cnt[wave][lane] = 0u;
   const int *ib = idx + (size_t)b * MK;
+  CsrStage st;
+  csr_stage_load(ib, MK, 0, st);
   for (int base = 0; base < MK; base += kCsrChunk) {
     __syncthreads();
-    csr_stage(ib, MK, base, s_idx);
+    csr_stage_commit(st, s_idx);
     __syncthreads();
+    csr_stage_load(ib, MK, base + kCsrChunk, st);
     for (int t = lane; t < kCsrChunk / 4; t += 64) {
       const int4 v = reinterpret_cast<const int4 *>(s_idx)[t];
       const int d[4] = {v.x - r0, v.y - r0, v.z - r0, v.w - r0};
@@ -118,11 +135,14 @@ __global__ __launch_bounds__(256) void csr_fill_kernel(const int *__restrict__ i
   const int r0 = (tile * 4 + wave) * kCsrRows;
   const int *ib = idx + (size_t)b * MK;
   int *tb = tmp + (size_t)b * MK;
-  s_cur[wave][lane] = (r0 + lane < N) ? (unsigned)off[(size_t)b * (N + 1) + r0 + lane] : 0u;
+  if (lane < kCsrRows) s_cur[wave][lane] = (r0 + lane < N) ? (unsigned)off[(size_t)b * (N + 1) + r0 + lane] : 0u;
+  CsrStage st;
+  csr_stage_load(ib, MK, 0, st);
   for (int base = 0; base < MK; base += kCsrChunk) {
     __syncthreads();
-    csr_stage(ib, MK, base, s_idx);
+    csr_stage_commit(st, s_idx);
     __syncthreads();
+    csr_stage_load(ib, MK, base + kCsrChunk, st);
     for (int t = lane; t < kCsrChunk / 4; t += 64) {
       const int4 v = reinterpret_cast<const int4 *>(s_idx)[t];
       const int d[4] = {v.x - r0, v.y - r0, v.z - r0, v.w - r0};
