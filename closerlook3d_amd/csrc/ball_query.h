@@ -17,4 +17,7 @@ int ball_query_cells(const float *query_xyz, const float *support_xyz, const int
                      const int *support_mask, int B, int M, int N, float radius, int K, int *idx,
                      int *idx_mask, void *ws, size_t ws_bytes, hipStream_t st);
 
+// csr.hip
+size_t inverse_index_workspace(int B, int N, int MK);
+
 }  // namespace cl3d

@@ -59,10 +59,12 @@ def inverse_index(idx, n_support):
     MK = idx[0].numel()
     off = torch.empty((B, n_support + 1), dtype=torch.int32, device=idx.device)
     slots = torch.empty((B, MK), dtype=torch.int32, device=idx.device)
-    ws = torch.empty((B * n_support + B * MK,), dtype=torch.int32, device=idx.device)
+    lib = _lib.lib()
+    ws_bytes = lib.cl3d_workspace_bytes(11, B, n_support, MK, 1, 0)  # CL3D_OP_INVERSE_INDEX
+    ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=idx.device)
     with torch.cuda.device(idx.device):
-        _lib.check(_lib.lib().cl3d_build_inverse_index(_p(idx), B, n_support, MK, _p(off), _p(slots), _p(ws),
-                                                       ws.numel() * 4, _stream(idx)))
+        _lib.check(lib.cl3d_build_inverse_index(_p(idx), B, n_support, MK, _p(off), _p(slots), _p(ws), ws_bytes,
+                                                _stream(idx)))
     idx._cl3d_inverse = (n_support, off, slots)
     return off, slots
 

@@ -53,6 +53,7 @@ typedef void *cl3d_stream_t; /* hipStream_t */
 #define CL3D_OP_ADAPTIVE_WEIGHT 8
 #define CL3D_OP_PSEUDO_GRID 9
 #define CL3D_OP_POINTWISE_MLP 10
+#define CL3D_OP_INVERSE_INDEX 11 /* cl3d_build_inverse_index: pass M*K slots as (M, K) */
 
 int cl3d_abi_version(void);
 const char *cl3d_last_error_string(void);
@@ -111,7 +112,7 @@ int cl3d_group_xyz_features(const float *query_xyz, const float *support_xyz,
  * ft [B,N,C], out_t [B,M,C] (the Python layer transposes at the operator boundary). */
 
 /* CSR inverse of a neighbour-index tensor: inv_off [B,N+1], inv_slots [B,MK] (ascending slot ids per
- * support point).  ws: (B*N + B*MK) * 4 bytes.  Used by every fused backward pass (ordered gather
+ * support point).  ws: cl3d_workspace_bytes(CL3D_OP_INVERSE_INDEX, B, N, M, K, 0).  Used by every fused backward pass (ordered gather
  * instead of the reference's atomicAdd scatter, group_points_gpu.cu:65). */
 int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK, int32_t *inv_off,
                              int32_t *inv_slots, void *ws, size_t ws_bytes, cl3d_stream_t stream);
