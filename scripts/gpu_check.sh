@@ -16,11 +16,12 @@ echo "refpin rc=$?" | tee -a $OUT/summary.txt; tail -5 $OUT/pytest_refpin.log | 
 echo "== native golden from the reference kernels" | tee -a $OUT/summary.txt
 timeout 600 python tests/golden/make_native_golden.py $OUT/native_golden > $OUT/native_golden.log 2>&1; echo "golden rc=$?" | tee -a $OUT/summary.txt
 echo "== bench" | tee -a $OUT/summary.txt
-timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
+timeout 900 python bench.py --steps 50 --warmup 10 > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
 cat $OUT/bench.json | tee -a $OUT/summary.txt
 echo "== rocprofv3 kernel trace of the same bench command" | tee -a $OUT/summary.txt
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/rocprof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
 find $OUT/prof -name '*stats*' | head -5 | tee -a $OUT/summary.txt
+python scripts/kstats.py $OUT/prof/bench_kernel_stats.csv 60 30 | tee -a $OUT/summary.txt
 # keep the merged output small: drop raw traces, keep stats
 find $OUT/prof -type f ! -name "*stats*" -size +1M -delete 2>/dev/null
 echo "== done" | tee -a $OUT/summary.txt
