@@ -16,6 +16,7 @@ the timed region.  Prints ONE JSON line on rank 0 with the contract fields plus
                 sample of the same workload, rank 0, N=1 only.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -62,19 +63,22 @@ def synth_batch(B, N, C, seed, pad_frac=0.0):
     return xyz, mask, feats
 
 
-def event_time_ms(fn, iters, warmup=3):
-    """Average duration of fn() in ms, HIP events on the current (= launch) stream."""
+def event_time_ms(fn, iters, warmup=3, burst=8):
+    """Average duration of one fn() in ms: HIP events on the current (= launch) stream around bursts of
+    `burst` back-to-back launches, so the device stays busy and host launch latency is not counted."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    start = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
-    stop = [torch.cuda.Event(enable_timing=True) for _ in range(iters)]
-    for i in range(iters):
+    rounds = max(1, iters // burst)
+    start = [torch.cuda.Event(enable_timing=True) for _ in range(rounds)]
+    stop = [torch.cuda.Event(enable_timing=True) for _ in range(rounds)]
+    for i in range(rounds):
         start[i].record()
-        fn()
+        for _ in range(burst):
+            fn()
         stop[i].record()
     torch.cuda.synchronize()
-    return float(np.mean([s.elapsed_time(e) for s, e in zip(start, stop)]))
+    return float(np.mean([s.elapsed_time(e) for s, e in zip(start, stop)])) / burst
 
 
 def kernel_rooflines(xyz, mask, feats, radius, K, iters):
@@ -110,6 +114,21 @@ def kernel_rooflines(xyz, mask, feats, radius, K, iters):
                 "frac": round(B * (fwd + bwd) / (total_ms * 1e-3) / HBM_PEAK, 4),
                 "frac_of_measured_copy_peak": round(B * (fwd + bwd) / (total_ms * 1e-3) / HBM_MEASURED, 4)}
     return out, boundary
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (scripts/pmc_kernels.py; rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 FETCH_SIZE correction applied), or None."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json"))):
+        try:
+            data = json.load(open(path))["kernels"]
+        except Exception:
+            continue
+        for name, rec in data.items():
+            if name.replace("cl3d::", "").startswith(kernel):
+                best = rec["hbm_bytes"]
+    return best
 
 
 def cpu_baseline(kind, N, K, C, radius, clouds, iters):
@@ -238,9 +257,9 @@ def main():
             dom = max((k for k in per_kernel if "+" not in k), key=lambda k: per_kernel[k]["ms"])
             line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["achieved_GBps"],
                                 "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": per_kernel[dom]["frac"],
-                                "traffic": None, "per_kernel": per_kernel, "ball_query_group": boundary}
+                                "traffic": pmc_traffic(dom), "per_kernel": per_kernel, "ball_query_group": boundary}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(kind, N, K, C, radius, clouds=2, iters=3)
+            line["cpu_baseline"] = cpu_baseline(kind, N, K, C, radius, clouds=4, iters=5)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
