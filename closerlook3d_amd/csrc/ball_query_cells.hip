@@ -42,8 +42,14 @@ struct BqGrid {
   int ntasks, nv, pad0, pad1;
 };
 
+// One task = up to kBqQW queries of one cell, together with that cell's candidate window: the <= 9
+// contiguous runs of `sorted` (3x3 (y,z) rows, <= 3 x-adjacent cells each) laid end to end.  run_pe[r] is
+// the exclusive prefix of run r in that index space, run_delta[r] = start(r) - run_pe[r].  Everything a
+// wave needs to start streaming candidates arrives with one 96-byte uniform load.
 struct BqTask {
-  int cell, q0, n, pad;
+  int q0, n, total, cell;
+  int run_pe[9], run_delta[9];
+  int pad[2];
 };
 
 // workspace layout (per call), see cl3d_workspace_bytes(CL3D_OP_BALL_QUERY)
@@ -253,12 +259,34 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
     for (int i = 0; i < 8; ++i) {
       if (i < per && t0 + i < ncells) {
         const int qs = s_cnt[t0 + i];
+        if (nq_mine[i] == 0) continue;
+        // candidate window of this cell (queries that were clamped into the grid get a superset of what
+        // their true position needs: outside the grid only the boundary cells can be within reach)
+        BqTask tk;
+        const int cell = t0 + i;
+        const int cx = cell % nx, cy = (cell / nx) % ny, cz = cell / (nx * ny);
+        const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < nx ? cx + 1 : nx - 1;
+        const int y0 = cy > 0 ? cy - 1 : 0, y1 = cy + 1 < ny ? cy + 1 : ny - 1;
+        const int z0 = cz > 0 ? cz - 1 : 0, z1 = cz + 1 < nz ? cz + 1 : nz - 1;
+        int acc = 0;
+        for (int r = 0; r < 9; ++r) {
+          const int yy = y0 + r % 3, zz = z0 + r / 3;
+          int ra = 0, len = 0;
+          if (yy <= y1 && zz <= z1) {
+            const int row = nx * (yy + ny * zz);
+            ra = cs[row + x0];
+            len = cs[row + x1 + 1] - ra;
+          }
+          tk.run_pe[r] = acc;
+          tk.run_delta[r] = ra - acc;
+          acc += len;
+        }
+        tk.total = acc;
+        tk.cell = cell;
+        tk.pad[0] = tk.pad[1] = 0;
         for (int k = 0; k < nq_mine[i]; k += kBqQW) {
-          BqTask tk;
-          tk.cell = t0 + i;
           tk.q0 = qs + k;
           tk.n = nq_mine[i] - k < kBqQW ? nq_mine[i] - k : kBqQW;
-          tk.pad = 0;
           tasks[t++] = tk;
         }
       }
@@ -301,15 +329,14 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
   int *sel_i = base + 2 * kBqQW * cap + kBqQW * cap3;
   int *out_i = base + 2 * kBqQW * cap + 2 * kBqQW * cap3;
 
-  const BqGrid g = w.grid[b];
+  const int ntasks = w.grid[b].ntasks;
   const int *qm = query_mask + (size_t)b * M;
   const float4 *sorted = w.sorted + (size_t)b * N;
-  const int *cs = w.cell_start + (size_t)b * (kMaxCells + 1);
   const float4 *qsorted = w.qsorted + (size_t)b * M;
   const BqTask *tasks = w.tasks + (size_t)b * w.max_tasks;
   int *oflow = w.overflow + (size_t)b * M;
 
-  for (int t = blockIdx.x * 4 + wave; t < g.ntasks; t += gridDim.x * 4) {
+  for (int t = blockIdx.x * 4 + wave; t < ntasks; t += gridDim.x * 4) {
     const BqTask tk = tasks[t];
     const int n = tk.n;
     int jq[kBqQW];
@@ -326,53 +353,12 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
       lidx[u] = 0;
       cnt[u] = 0;
     }
-    // the queries' TRUE cell (queries outside the support box were clamped for grouping only; every query
-    // of a task has the same clamped cell, and a query whose true cell differs from it lies outside the
-    // grid, where looking one cell inwards from the true coordinate is what matters)
-    const int ccx = tk.cell % g.nx, ccy = (tk.cell / g.nx) % g.ny, ccz = tk.cell / (g.nx * g.ny);
-    // candidate window: cells within one of ANY of the task's queries' true cells.  All queries share
-    // the clamped cell; true cells can only differ from it outwards, so [min true - 1, max true + 1]
-    // clipped to the grid covers every query (a few extra cells for far-outside queries, never fewer).
-    int lo[3] = {ccx, ccy, ccz}, hi[3] = {ccx, ccy, ccz};
-#pragma unroll
-    for (int u = 0; u < kBqQW; ++u) {
-      if (u < n) {
-        const int tx = cell_coord(qx[u], g.ox, g.inv_h), ty = cell_coord(qy[u], g.oy, g.inv_h),
-                  tz = cell_coord(qz[u], g.oz, g.inv_h);
-        lo[0] = tx < lo[0] ? tx : lo[0]; hi[0] = tx > hi[0] ? tx : hi[0];
-        lo[1] = ty < lo[1] ? ty : lo[1]; hi[1] = ty > hi[1] ? ty : hi[1];
-        lo[2] = tz < lo[2] ? tz : lo[2]; hi[2] = tz > hi[2] ? tz : hi[2];
-      }
-    }
-    const int x0 = lo[0] - 1 < 0 ? 0 : lo[0] - 1, x1 = hi[0] + 1 >= g.nx ? g.nx - 1 : hi[0] + 1;
-    const int y0 = lo[1] - 1 < 0 ? 0 : lo[1] - 1, y1 = hi[1] + 1 >= g.ny ? g.ny - 1 : hi[1] + 1;
-    const int z0 = lo[2] - 1 < 0 ? 0 : lo[2] - 1, z1 = hi[2] + 1 >= g.nz ? g.nz - 1 : hi[2] + 1;
-
-    // The window is at most 3x3 (y,z) rows of cells; in the cell order the <= 3 cells of a row are one
-    // contiguous run of `sorted`.  Lanes 0..8 fetch the nine run bounds at once, the runs are laid end
-    // to end into one candidate index space, and lanes walk that space fully packed, kBqBatch float4
-    // loads in flight per lane (instead of nine dependent cs -> sorted round trips with half-empty waves).
-    int my_ra = 0, my_len = 0;
-    if (lane < 9) {
-      const int cy = y0 + lane % 3, cz = z0 + lane / 3;
-      if (cy <= y1 && cz <= z1 && x0 <= x1) {
-        const int row = g.nx * (cy + g.ny * cz);
-        my_ra = cs[row + x0];
-        my_len = cs[row + x1 + 1] - my_ra;
-      }
-    }
-    int incl = my_len;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      const int v = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += v;
-    }
-    const int T = __builtin_amdgcn_readlane(incl, 8);
-    int run_pe[9], run_delta[9];  // exclusive prefix and (start - prefix) of every run, wave-uniform
+    const int T = tk.total;
+    int run_pe[9], run_delta[9];
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
-      run_pe[r] = __builtin_amdgcn_readlane(incl - my_len, r);
-      run_delta[r] = __builtin_amdgcn_readlane(my_ra - (incl - my_len), r);
+      run_pe[r] = tk.run_pe[r];
+      run_delta[r] = tk.run_delta[r];
     }
     for (int p0 = 0; p0 < T; p0 += CL3D_WAVE * kBqBatch) {
       float4 sp[kBqBatch];

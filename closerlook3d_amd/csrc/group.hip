@@ -22,6 +22,24 @@ namespace cl3d {
 constexpr int kMaxLdsRow = 16384;  // floats: 64 KiB, the no-opt-in dynamic LDS limit
 constexpr int kUnroll = 4;
 
+// The gathered tensor is written once and never re-read by this kernel: a non-temporal store keeps the
+// 537 MB stream from evicting the index stream and feature rows other workgroups are reading from L2.
+__device__ __forceinline__ void store_stream(float4 *p, const float4 &v) {
+  __builtin_nontemporal_store(v.x, &p->x);
+  __builtin_nontemporal_store(v.y, &p->y);
+  __builtin_nontemporal_store(v.z, &p->z);
+  __builtin_nontemporal_store(v.w, &p->w);
+}
+
+__device__ __forceinline__ float4 load_stream(const float4 *p) {  // read-once stream (grad_out)
+  float4 v;
+  v.x = __builtin_nontemporal_load(&p->x);
+  v.y = __builtin_nontemporal_load(&p->y);
+  v.z = __builtin_nontemporal_load(&p->z);
+  v.w = __builtin_nontemporal_load(&p->w);
+  return v;
+}
+
 // ------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void group_fwd_lds_kernel(const float *__restrict__ points,
                                                             const int *__restrict__ idx, int C,
@@ -57,7 +75,7 @@ __global__ __launch_bounds__(256) void group_fwd_lds_kernel(const float *__restr
         v.y = row[ii[u].y];
         v.z = row[ii[u].z];
         v.w = row[ii[u].w];
-        o4[g + u * 256] = v;
+        store_stream(&o4[g + u * 256], v);
       }
     }
     for (; g < g1; g += 256) {
@@ -67,7 +85,7 @@ __global__ __launch_bounds__(256) void group_fwd_lds_kernel(const float *__restr
       v.y = row[ii.y];
       v.z = row[ii.z];
       v.w = row[ii.w];
-      o4[g] = v;
+      store_stream(&o4[g], v);
     }
   } else {
     for (int e = e0 + threadIdx.x; e < e1; e += 256) ob[e] = row[ib[e]];
@@ -134,7 +152,7 @@ __global__ __launch_bounds__(256) void group_bwd_lds_kernel(const float *__restr
       const int qq = q + u * 256;
       const int qc = qq < nq ? qq : nq - 1;  // always a valid address; out-of-range lanes are disabled via idx
       ci[u] = i4[qc];
-      cv[u] = g4[qc];
+      cv[u] = load_stream(&g4[qc]);
       if (qq >= nq) ci[u] = none;
     }
     for (; q < nq; q += kStride) {
@@ -143,7 +161,7 @@ __global__ __launch_bounds__(256) void group_bwd_lds_kernel(const float *__restr
         const int qq = q + kStride + u * 256;
         const int qc = qq < nq ? qq : nq - 1;
         ni[u] = i4[qc];
-        nv[u] = g4[qc];
+        nv[u] = load_stream(&g4[qc]);
         if (qq >= nq) ni[u] = none;
       }
 #pragma unroll
