@@ -447,18 +447,35 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
         li = si;
         c = cap3;
       }
-      // rank by (distance, original index) == stable sort by distance of the index-ordered list
+      // rank by (distance, original index) == stable sort by distance of the index-ordered list.
+      // d2 >= 0, so its bit pattern orders like the value and (d2 bits << 32 | index) is one 64-bit key.
       int *so = out_i + u * K;
-      for (int e = lane; e < c; e += CL3D_WAVE) {
-        const float de = ld[e];
-        const int ie = li[e];
+      if (c <= CL3D_WAVE) {
+        // one element per lane; every key is broadcast through SGPRs (v_readlane) and compared as u64:
+        // 4 instructions per pair, no LDS traffic
+        const bool on = lane < c;
+        const unsigned long long mykey =
+            on ? (((unsigned long long)__float_as_uint(ld[lane]) << 32) | (unsigned)li[lane]) : ~0ull;
+        const unsigned klo = (unsigned)mykey, khi = (unsigned)(mykey >> 32);
         int rank = 0;
-#pragma unroll 8
         for (int f = 0; f < c; ++f) {
-          const float df = ld[f];
-          rank += (df < de || (df == de && li[f] < ie)) ? 1 : 0;
+          const unsigned long long kf = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi, f) << 32) |
+                                        (unsigned)__builtin_amdgcn_readlane((int)klo, f);
+          rank += kf < mykey ? 1 : 0;
         }
-        if (rank < K) so[rank] = ie;
+        if (on && rank < K) so[rank] = (int)klo;
+      } else {
+        for (int e = lane; e < c; e += CL3D_WAVE) {
+          const float de = ld[e];
+          const int ie = li[e];
+          int rank = 0;
+#pragma unroll 8
+          for (int f = 0; f < c; ++f) {
+            const float df = ld[f];
+            rank += (df < de || (df == de && li[f] < ie)) ? 1 : 0;
+          }
+          if (rank < K) so[rank] = ie;
+        }
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();

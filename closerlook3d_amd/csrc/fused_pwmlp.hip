@@ -34,7 +34,8 @@ struct PwArgs {
   const float *ght;  // [B,N,2Co]
   const float *wr;   // [Co,3]
   const float *v0, *v1, *v2, *v3;  // per-channel vectors: FWD scale,shift | SPARSE scale,shift,mean,invstd | QUERY/SUPPORT A,Bc,D
-  const float *gout_t;             // [B,M,Co]
+  const float *gout_t;             // [B,M,Co] (point-major) or, with gout_channel_major, [B,Co,M]
+  int out_channel_major, gout_channel_major;
   const float *dzs_in;             // [B,M,Co]
   const unsigned char *kstar_in;   // [B,M,Co]
   float *out_t;                    // FWD
@@ -171,8 +172,11 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
             }
           }
         });
+        // the operator's output is channel-major [B,Co,M] at the API boundary: written directly (4-byte
+        // stores, merged in L2 across the 16 neighbouring queries of the tile) instead of a transpose pass
         _Pragma("unroll") for (int v = 0; v < V; ++v) {
-          a.out_t[orow + v] = best[v];
+          if (a.out_channel_major) a.out_t[((size_t)b * Co + c0 + v) * M + j] = best[v];
+          else a.out_t[orow + v] = best[v];
           if (a.kstar_out) a.kstar_out[orow + v] = (unsigned char)kb[v];
         }
       } else if constexpr (MODE == PW_BWD_SPARSE) {
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
           const float gi = rows[(size_t)__float_as_int(sr.x) * row + c0 + v];
           const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gi);
           const float z = __builtin_fmaf(y, c_v0[v], c_v1[v]);
-          const float dz = z > 0.f ? a.gout_t[orow + v] : 0.f;
+          const float dz = z > 0.f ? (a.gout_channel_major ? a.gout_t[((size_t)b * Co + c0 + v) * M + j] : a.gout_t[orow + v]) : 0.f;
           a.dzs_out[orow + v] = dz;
           dacc[0][v] += (double)dz;
           dacc[1][v] += (double)(dz * ((y - c_v2[v]) * c_v3[v]));
@@ -335,6 +339,75 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
   }
 }
 
+// ---- fixed-order reduction of the per-block double partials + the per-channel BatchNorm algebra.
+// One block per channel; replaces ~30 tiny element-wise launches the same math costs in PyTorch.
+enum { FIN_STATS = 0, FIN_COEFFS = 1, FIN_DWR = 2 };
+
+struct FinArgs {
+  const double *partial;  // [G, Co, 4]
+  int G, Co;
+  double count;
+  float eps, momentum;
+  const float *gamma, *beta, *mean_in, *invstd_in;
+  float *running_mean, *running_var;
+  float *o0, *o1, *o2, *o3, *o4;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
+  __shared__ double s_red[4][256];
+  const int c = blockIdx.x;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int g = threadIdx.x; g < a.G; g += 256) {
+    const double *p = a.partial + ((size_t)g * a.Co + c) * 4;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc[k] += p[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) s_red[k][threadIdx.x] = acc[k];
+  __syncthreads();
+  for (int w = 128; w >= 1; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) s_red[k][threadIdx.x] += s_red[k][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x != 0) return;
+  const double s0 = s_red[0][0], s1 = s_red[1][0], s2 = s_red[2][0];
+  if constexpr (MODE == FIN_STATS) {
+    const double mean = s0 / a.count;
+    double var = s1 / a.count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)a.eps);
+    const double scale = (double)a.gamma[c] * invstd;
+    a.o0[c] = (float)scale;
+    a.o1[c] = (float)((double)a.beta[c] - mean * scale);
+    a.o2[c] = (float)mean;
+    a.o3[c] = (float)invstd;
+    if (a.running_mean != nullptr) {  // nn.BatchNorm2d: running = (1-m) running + m batch, unbiased variance
+      const double unbiased = var * (a.count / (a.count > 1.0 ? a.count - 1.0 : 1.0));
+      a.running_mean[c] = a.running_mean[c] * (1.0f - a.momentum) + a.momentum * (float)mean;
+      a.running_var[c] = a.running_var[c] * (1.0f - a.momentum) + a.momentum * (float)unbiased;
+    }
+  } else if constexpr (MODE == FIN_COEFFS) {
+    // BatchNorm backward, affine in y:  dy = A dz + Bc + D y   (s0 = sum dz = d beta, s1 = sum dz*xhat = d gamma)
+    const double invstd = (double)a.invstd_in[c], mean = (double)a.mean_in[c];
+    const double A = (double)a.gamma[c] * invstd;
+    const double D = -A * invstd * s1 / a.count;
+    const double Bc = -A * s0 / a.count - D * mean;
+    a.o0[c] = (float)A;
+    a.o1[c] = (float)Bc;
+    a.o2[c] = (float)D;
+    a.o3[c] = (float)s1;  // d gamma
+    a.o4[c] = (float)s0;  // d beta
+  } else {
+    a.o0[c * 3 + 0] = (float)s0;
+    a.o0[c * 3 + 1] = (float)s1;
+    a.o0[c * 3 + 2] = (float)s2;
+  }
+}
+
 static int pw_check(const PwArgs &a, const char *who) {
   if (a.B < 0 || a.N < 1 || a.M < 1 || a.K < 1 || a.Co < 1) return fail(CL3D_E_INVALID, "%s: bad sizes", who);
   if (a.K > 255) return fail(CL3D_E_UNSUPPORTED, "%s: nsample=%d > 255 (arg-max is stored in a byte)", who, a.K);
@@ -378,7 +451,43 @@ static int launch_query(PwArgs &a, int nacc, int n_partials, hipStream_t st, con
 
 extern "C" int cl3d_pwmlp_partials(int B, int M, int Co) {
   (void)Co;
-  return cl3d::round_grid(((long long)B * M + 15) / 16, 2048);
+  return cl3d::round_grid(((long long)B * M + 15) / 16, 1024);
+}
+
+extern "C" int cl3d_pwmlp_finalize_stats(const double *partial, int n_partials, int Co, double count, float eps,
+                                         float momentum, const float *gamma, const float *beta,
+                                         float *running_mean, float *running_var, float *scale, float *shift,
+                                         float *mean, float *invstd, cl3d_stream_t stream) {
+  CL3D_REQUIRE(partial && gamma && beta && scale && shift && mean && invstd && n_partials > 0 && Co > 0 && count > 0,
+               "pwmlp_finalize_stats: bad arguments");
+  cl3d::FinArgs a{};
+  a.partial = partial; a.G = n_partials; a.Co = Co; a.count = count; a.eps = eps; a.momentum = momentum;
+  a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+  a.o0 = scale; a.o1 = shift; a.o2 = mean; a.o3 = invstd;
+  hipLaunchKernelGGL((cl3d::pwmlp_finalize_kernel<cl3d::FIN_STATS>), dim3(Co), dim3(256), 0, (hipStream_t)stream, a);
+  return cl3d::check_launch("cl3d_pwmlp_finalize_stats");
+}
+
+extern "C" int cl3d_pwmlp_bn_backward_coeffs(const double *partial, int n_partials, int Co, double count,
+                                             const float *gamma, const float *mean, const float *invstd, float *cA,
+                                             float *cB, float *cD, float *dgamma, float *dbeta,
+                                             cl3d_stream_t stream) {
+  CL3D_REQUIRE(partial && gamma && mean && invstd && cA && cB && cD && dgamma && dbeta && n_partials > 0 && Co > 0 && count > 0,
+               "pwmlp_bn_backward_coeffs: bad arguments");
+  cl3d::FinArgs a{};
+  a.partial = partial; a.G = n_partials; a.Co = Co; a.count = count; a.gamma = gamma; a.mean_in = mean;
+  a.invstd_in = invstd; a.o0 = cA; a.o1 = cB; a.o2 = cD; a.o3 = dgamma; a.o4 = dbeta;
+  hipLaunchKernelGGL((cl3d::pwmlp_finalize_kernel<cl3d::FIN_COEFFS>), dim3(Co), dim3(256), 0, (hipStream_t)stream, a);
+  return cl3d::check_launch("cl3d_pwmlp_bn_backward_coeffs");
+}
+
+extern "C" int cl3d_pwmlp_reduce_dwr(const double *partial, int n_partials, int Co, float *dwr,
+                                     cl3d_stream_t stream) {
+  CL3D_REQUIRE(partial && dwr && n_partials > 0 && Co > 0, "pwmlp_reduce_dwr: bad arguments");
+  cl3d::FinArgs a{};
+  a.partial = partial; a.G = n_partials; a.Co = Co; a.count = 1.0; a.o0 = dwr;
+  hipLaunchKernelGGL((cl3d::pwmlp_finalize_kernel<cl3d::FIN_DWR>), dim3(Co), dim3(256), 0, (hipStream_t)stream, a);
+  return cl3d::check_launch("cl3d_pwmlp_reduce_dwr");
 }
 
 extern "C" int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
@@ -398,16 +507,18 @@ extern "C" int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz
 
 extern "C" int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, const int32_t *idx,
                               const float *ght, const float *wr, const float *scale, const float *shift,
-                              int B, int N, int M, int K, int Co, float radius, float *out_t,
-                              unsigned char *kstar_t, float *slotrec, cl3d_stream_t stream) {
+                              int B, int N, int M, int K, int Co, float radius, float *out,
+                              int out_channel_major, unsigned char *kstar_t, float *slotrec,
+                              cl3d_stream_t stream) {
   using namespace cl3d;
   PwArgs a{};
   a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr;
-  a.v0 = scale; a.v1 = shift; a.out_t = out_t; a.kstar_out = kstar_t; a.slotrec = reinterpret_cast<float4 *>(slotrec);
+  a.v0 = scale; a.v1 = shift; a.out_t = out; a.out_channel_major = out_channel_major; a.kstar_out = kstar_t;
+  a.slotrec = reinterpret_cast<float4 *>(slotrec);
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
   int rc = pw_check(a, "pwmlp_fwd");
   if (rc != CL3D_OK) return rc;
-  CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && scale && shift && out_t, "pwmlp_fwd: null pointer");
+  CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && scale && shift && out, "pwmlp_fwd: null pointer");
   if (B == 0) return CL3D_OK;
   return launch_query<PW_FWD>(a, 0, 0, (hipStream_t)stream, "cl3d_pwmlp_fwd");
 }
@@ -415,18 +526,19 @@ extern "C" int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, 
 extern "C" int cl3d_pwmlp_bwd_sparse(const float *query_xyz, const float *support_xyz, const int32_t *idx,
                                      const float *ght, const float *wr, const float *scale,
                                      const float *shift, const float *mean, const float *invstd,
-                                     const float *gout_t, const unsigned char *kstar_t, int B, int N, int M,
-                                     int K, int Co, float radius, float *dzs_t, double *partial,
-                                     int n_partials, cl3d_stream_t stream) {
+                                     const float *gout, int gout_channel_major, const unsigned char *kstar_t,
+                                     int B, int N, int M, int K, int Co, float radius, float *dzs_t,
+                                     double *partial, int n_partials, cl3d_stream_t stream) {
   using namespace cl3d;
   PwArgs a{};
   a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr;
-  a.v0 = scale; a.v1 = shift; a.v2 = mean; a.v3 = invstd; a.gout_t = gout_t; a.kstar_in = kstar_t;
+  a.v0 = scale; a.v1 = shift; a.v2 = mean; a.v3 = invstd; a.gout_t = gout; a.gout_channel_major = gout_channel_major;
+  a.kstar_in = kstar_t;
   a.dzs_out = dzs_t; a.partial = partial;
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
   int rc = pw_check(a, "pwmlp_bwd_sparse");
   if (rc != CL3D_OK) return rc;
-  CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && scale && shift && mean && invstd && gout_t && kstar_t && dzs_t && partial,
+  CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && scale && shift && mean && invstd && gout && kstar_t && dzs_t && partial,
                "pwmlp_bwd_sparse: null pointer");
   CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_bwd_sparse: wrong partial block count");
   if (B == 0) return CL3D_OK;

@@ -173,38 +173,38 @@ class _PointwiseMLP(Function):
         n = B * M * K
         nparts = lib.cl3d_pwmlp_partials(B, M, Co)
         with torch.cuda.device(dev):
+            scale = torch.empty((Co,), dtype=torch.float32, device=dev)
+            shift, mean, invstd = torch.empty_like(scale), torch.empty_like(scale), torch.empty_like(scale)
             if training:
                 partial = torch.empty((nparts, Co, 4), dtype=torch.float64, device=dev)
                 _lib.check(lib.cl3d_pwmlp_stats(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), B, N, M, K,
                                                 Co, float(radius), _p(partial), nparts, _stream(ght)))
-                sums = partial[:, :, :2].sum(0)
-                mean64 = sums[:, 0] / n
-                var64 = (sums[:, 1] / n - mean64 * mean64).clamp_min(0.0)
-                invstd64 = torch.rsqrt(var64 + eps)
-                if running_mean is not None:
-                    with torch.no_grad():
-                        running_mean.mul_(1 - momentum).add_(mean64.float(), alpha=momentum)
-                        running_var.mul_(1 - momentum).add_((var64 * (n / max(n - 1, 1))).float(), alpha=momentum)
+                # batch statistics, scale/shift and the running-statistics update in one small launch
+                _lib.check(lib.cl3d_pwmlp_finalize_stats(_p(partial), nparts, Co, float(n), float(eps), float(momentum),
+                                                         _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                                         _p(scale), _p(shift), _p(mean), _p(invstd), _stream(ght)))
             else:
                 mean64 = running_mean.double()
                 invstd64 = torch.rsqrt(running_var.double() + eps)
-            scale64 = gamma.double() * invstd64
-            scale = scale64.float()
-            shift = (beta.double() - mean64 * scale64).float()
-            out_t = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
+                scale64 = gamma.double() * invstd64
+                scale.copy_(scale64)
+                shift.copy_(beta.double() - mean64 * scale64)
+                mean.copy_(mean64)
+                invstd.copy_(invstd64)
+            out = torch.empty((B, Co, M), dtype=torch.float32, device=dev)  # channel-major, written by the kernel
             kstar = torch.empty((B, M, Co), dtype=torch.uint8, device=dev) if need_grad else None
             slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev) if need_grad else None
             _lib.check(lib.cl3d_pwmlp_fwd(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(scale),
-                                          _p(shift), B, N, M, K, Co, float(radius), _p(out_t), _p(kstar), _p(slotrec),
+                                          _p(shift), B, N, M, K, Co, float(radius), _p(out), 1, _p(kstar), _p(slotrec),
                                           _stream(ght)))
         if need_grad:
             if not training:
                 raise NotImplementedError("fused PointWiseMLP backward needs training-mode BatchNorm")
-            ctx.save_for_backward(ght, wr, gamma, scale, shift, mean64.float(), invstd64.float(), kstar, slotrec,
+            ctx.save_for_backward(ght, wr, gamma, scale, shift, mean, invstd, kstar, slotrec,
                                   query_xyz, support_xyz)
             ctx.idx = idx
             ctx.meta = (B, N, M, K, Co, float(radius), nparts)
-        return out_t.transpose(1, 2).contiguous()
+        return out
 
     @staticmethod
     def backward(ctx, gout):
@@ -214,27 +214,26 @@ class _PointwiseMLP(Function):
         dev = gout.device
         lib = _lib.lib()
         n = B * M * K
-        gout_t = gout.transpose(1, 2).contiguous()
+        gout = gout.contiguous()  # channel-major [B,Co,M], read directly by the kernel
         with torch.cuda.device(dev):
             st = _stream(gout)
             dzs = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
             partial = torch.empty((nparts, Co, 4), dtype=torch.float64, device=dev)
             _lib.check(lib.cl3d_pwmlp_bwd_sparse(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(scale),
-                                                 _p(shift), _p(mean), _p(invstd), _p(gout_t), _p(kstar), B, N, M, K,
-                                                 Co, radius, _p(dzs), _p(partial), nparts, st))
-            sums = partial[:, :, :2].sum(0)
-            dbeta64, dgamma64 = sums[:, 0], sums[:, 1]
-            # BatchNorm backward is affine in y:  dy = A dz + Bc + D y
-            A64 = gamma.double() * invstd.double()
-            D64 = -A64 * invstd.double() * dgamma64 / n
-            Bc64 = -A64 * dbeta64 / n - D64 * mean.double()
-            cA, cB, cD = A64.float(), Bc64.float(), D64.float()
+                                                 _p(shift), _p(mean), _p(invstd), _p(gout), 1, _p(kstar), B, N, M,
+                                                 K, Co, radius, _p(dzs), _p(partial), nparts, st))
+            # d gamma, d beta and the coefficients of  dy = A dz + Bc + D y  (BatchNorm backward is affine in y)
+            cA = torch.empty((Co,), dtype=torch.float32, device=dev)
+            cB, cD, dgamma, dbeta = (torch.empty_like(cA) for _ in range(4))
+            _lib.check(lib.cl3d_pwmlp_bn_backward_coeffs(_p(partial), nparts, Co, float(n), _p(gamma), _p(mean),
+                                                         _p(invstd), _p(cA), _p(cB), _p(cD), _p(dgamma), _p(dbeta), st))
             sq = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
             partial2 = torch.empty((nparts, Co, 4), dtype=torch.float64, device=dev)
             _lib.check(lib.cl3d_pwmlp_bwd_query(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(cA),
                                                 _p(cB), _p(cD), _p(dzs), _p(kstar), B, N, M, K, Co, radius, _p(sq),
                                                 _p(partial2), nparts, st))
-            dwr = partial2[:, :, :3].sum(0).float()
+            dwr = torch.empty((Co, 3), dtype=torch.float32, device=dev)
+            _lib.check(lib.cl3d_pwmlp_reduce_dwr(_p(partial2), nparts, Co, _p(dwr), st))
             off, slots = inverse_index(idx, N)
             centre = getattr(idx, '_cl3d_centre', None)
             if centre is None:
@@ -245,7 +244,7 @@ class _PointwiseMLP(Function):
             _lib.check(lib.cl3d_pwmlp_bwd_support(_p(idx), _p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(dzs), _p(kstar),
                                                   _p(slotrec), _p(sq), _p(off), _p(slots), _p(coff), _p(cslots), B, N,
                                                   M, K, Co, _p(dght), st))
-        return (dght, dwr, dgamma64.float(), dbeta64.float()) + (None,) * 10
+        return (dght, dwr, dgamma, dbeta) + (None,) * 10
 
 
 class _PointGemm(Function):

@@ -145,15 +145,27 @@ int cl3d_pwmlp_partials(int B, int M, int Co);
 int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
                      const float *ght, const float *wr, int B, int N, int M, int K, int Co, float radius,
                      double *partial, int n_partials, cl3d_stream_t stream);
+/* fixed-order reduction of the double partials + per-channel BatchNorm2d algebra (batch mean/variance,
+ * scale/shift, running-statistics update with nn.BatchNorm2d's rule; backward coefficients of
+ * dy = A dz + Bc + D y together with d gamma / d beta; d W_r [Co,3]). */
+int cl3d_pwmlp_finalize_stats(const double *partial, int n_partials, int Co, double count, float eps,
+                              float momentum, const float *gamma, const float *beta, float *running_mean,
+                              float *running_var, float *scale, float *shift, float *mean, float *invstd,
+                              cl3d_stream_t stream);
+int cl3d_pwmlp_bn_backward_coeffs(const double *partial, int n_partials, int Co, double count,
+                                  const float *gamma, const float *mean, const float *invstd, float *cA,
+                                  float *cB, float *cD, float *dgamma, float *dbeta, cl3d_stream_t stream);
+int cl3d_pwmlp_reduce_dwr(const double *partial, int n_partials, int Co, float *dwr, cl3d_stream_t stream);
 int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, const int32_t *idx,
                    const float *ght, const float *wr, const float *scale, const float *shift, int B,
-                   int N, int M, int K, int Co, float radius, float *out_t, unsigned char *kstar_t,
-                   float *slotrec, cl3d_stream_t stream);
+                   int N, int M, int K, int Co, float radius, float *out, int out_channel_major,
+                   unsigned char *kstar_t, float *slotrec, cl3d_stream_t stream);
 int cl3d_pwmlp_bwd_sparse(const float *query_xyz, const float *support_xyz, const int32_t *idx,
                           const float *ght, const float *wr, const float *scale, const float *shift,
-                          const float *mean, const float *invstd, const float *gout_t,
-                          const unsigned char *kstar_t, int B, int N, int M, int K, int Co, float radius,
-                          float *dzs_t, double *partial, int n_partials, cl3d_stream_t stream);
+                          const float *mean, const float *invstd, const float *gout,
+                          int gout_channel_major, const unsigned char *kstar_t, int B, int N, int M, int K,
+                          int Co, float radius, float *dzs_t, double *partial, int n_partials,
+                          cl3d_stream_t stream);
 int cl3d_pwmlp_bwd_query(const float *query_xyz, const float *support_xyz, const int32_t *idx,
                          const float *ght, const float *wr, const float *cA, const float *cB,
                          const float *cD, const float *dzs_t, const unsigned char *kstar_t, int B, int N,
