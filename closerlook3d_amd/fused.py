@@ -250,32 +250,28 @@ class _PointwiseMLP(Function):
 class _PointGemm(Function):
     """rows[b,i,:] = W f[b,:,i]  (features channel-major [B,C,N], W [R,C]) -> point-major [B,N,R].
 
-    Plain library GEMMs (rocBLAS/hipBLASLt through torch.matmul).  The weight gradient is a reduction over
-    all B*N points into an R x C matrix; left to the library as one GEMM it gets a handful of workgroups
-    (207 us at the metric shape), so it is issued split-K: a batched GEMM over row chunks + a fixed-order sum.
+    Plain library GEMMs (rocBLAS/hipBLASLt through torch.bmm), arranged so that every operand is consumed
+    through its strides (no transposed copies): forward  F[b]^T W^T;  d features  W^T grows[b]^T, which lands
+    channel-major as the caller needs it;  d W^T = sum_b F[b] grows[b]  (a batched GEMM + a fixed-order sum
+    over the batch: left to the library as ONE [R, B*N] x [B*N, C] GEMM it gets four workgroups and took
+    207 us at the metric shape).
     """
 
     @staticmethod
     def forward(ctx, features, weight):
         ctx.save_for_backward(features, weight)
-        return torch.matmul(features.transpose(1, 2), weight.t())
+        B = features.shape[0]
+        return torch.bmm(features.transpose(1, 2), weight.t().unsqueeze(0).expand(B, -1, -1))
 
     @staticmethod
     def backward(ctx, grows):
         features, weight = ctx.saved_tensors
-        B, C, N = features.shape
-        R = weight.shape[0]
+        B = features.shape[0]
         dfeat = dweight = None
         if ctx.needs_input_grad[0]:
-            dfeat = torch.matmul(grows, weight).transpose(1, 2)  # [B,C,N] view of [B,N,C]
+            dfeat = torch.bmm(weight.t().unsqueeze(0).expand(B, -1, -1), grows.transpose(1, 2))  # [B,C,N]
         if ctx.needs_input_grad[1]:
-            chunk = 1024
-            if N % chunk == 0:
-                g = grows.reshape(B * (N // chunk), chunk, R)
-                f = features.reshape(B, C, N // chunk, chunk).permute(0, 2, 3, 1).reshape(B * (N // chunk), chunk, C)
-                dweight = torch.bmm(g.transpose(1, 2), f).sum(0)
-            else:
-                dweight = torch.matmul(grows.reshape(B * N, R).t(), features.transpose(1, 2).reshape(B * N, C))
+            dweight = torch.bmm(features, grows).sum(0).t()  # [R,C]
         return dfeat, dweight
 
 
