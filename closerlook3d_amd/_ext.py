@@ -85,10 +85,13 @@ def masked_grid_subsampling(points, mask, nsamples, sampleDl):
     B, N, _ = points.shape
     sub = torch.empty((B, int(nsamples), 3), dtype=torch.float32, device=points.device)
     sub_mask = torch.empty((B, int(nsamples)), dtype=torch.int32, device=points.device)
+    lib = _lib.lib()
+    ws_bytes = lib.cl3d_workspace_bytes(4, B, N, 0, 0, 0)  # CL3D_OP_GRID_SUBSAMPLING (non-zero for N > 16384)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=points.device) if ws_bytes else None
     with torch.cuda.device(points.device):
-        _lib.check(_lib.lib().cl3d_masked_grid_subsampling(
-            _p(points), _p(mask), B, N, int(nsamples), float(sampleDl), _p(sub), _p(sub_mask), None, 0,
-            _lib.stream_ptr(points.device)))
+        _lib.check(lib.cl3d_masked_grid_subsampling(
+            _p(points), _p(mask), B, N, int(nsamples), float(sampleDl), _p(sub), _p(sub_mask),
+            _p(ws) if ws is not None else None, ws_bytes, _lib.stream_ptr(points.device)))
     return [sub, sub_mask]
 
 

@@ -10,6 +10,8 @@ extern "C" size_t cl3d_workspace_bytes(int op, int B, int N, int M, int K, int C
   switch (op) {
     case CL3D_OP_BALL_QUERY:  // cell grid: sorted support copy, cell starts, query order, task table, flags
       return cl3d::ball_query_cells_applicable(M, N, K) ? cl3d::ball_query_cells_workspace(B, N, M) : 0;
+    case CL3D_OP_GRID_SUBSAMPLING:  // clouds beyond the in-LDS sort: 64-bit keys (x2) + rocPRIM temporary storage
+      return cl3d::grid_subsampling_workspace(B, N);
     case CL3D_OP_INVERSE_INDEX:  // sort keys/values + rocPRIM temporary storage; M*K slots per cloud
       return cl3d::inverse_index_workspace(B, N, M * K);
     default:  // every other op of ABI v1 keeps its scratch in LDS

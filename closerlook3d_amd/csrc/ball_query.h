@@ -17,6 +17,8 @@ int ball_query_cells(const float *query_xyz, const float *support_xyz, const int
                      const int *support_mask, int B, int M, int N, float radius, int K, int *idx,
                      int *idx_mask, void *ws, size_t ws_bytes, hipStream_t st);
 
+// grid_subsample.hip
+size_t grid_subsampling_workspace(int B, int N);
 // csr.hip
 size_t inverse_index_workspace(int B, int N, int MK);
 

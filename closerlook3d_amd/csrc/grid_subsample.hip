@@ -18,7 +18,11 @@
 //      barycentre i in the shuffled order is computed in closed form from a 512-entry table
 //      instead of sorting; each barycentre is written straight to its final slot;
 //   5. wrap-around padding with mask 0 (:146-151).
-#include "cl3d_common.h"
+#include <cstring>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "ball_query.h"
 
 namespace cl3d {
 
@@ -30,10 +34,25 @@ __device__ __forceinline__ int key_cell(unsigned long long k) {
 }
 __device__ __forceinline__ int key_orig(unsigned long long k) { return (int)(unsigned)(k & 0xffffffffull); }
 
+// Large clouds (N > kSubMaxN): the (cell, index) keys do not fit LDS.  A first kernel writes them to HBM as
+// {cloud:8 | biased cell:32 | index:24}, one device-wide radix sort (rocPRIM) orders all clouds at once, and
+// the same per-cloud kernel runs with PRESORTED = true, reading its cloud's slice instead of sorting in LDS.
+__device__ __forceinline__ unsigned long long big_key(int b, int cell, int i, bool valid) {
+  const unsigned long long c = valid ? (unsigned long long)(((unsigned)cell) ^ 0x80000000u) : 0xffffffffull;
+  return ((unsigned long long)(unsigned)b << 56) | (c << 24) | (unsigned long long)(unsigned)i;
+}
+
+struct SubParams {
+  int nv;
+  int pad[3];
+};
+
+template <bool PRESORTED, bool KEYS_ONLY>
 __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
     const float *__restrict__ xyz, const int *__restrict__ mask, int N, int m, float dl, int P,
-    float *__restrict__ sub_xyz, int *__restrict__ sub_mask) {
-  extern __shared__ unsigned long long keys[];  // [P]
+    float *__restrict__ sub_xyz, int *__restrict__ sub_mask, unsigned long long *__restrict__ gkeys,
+    SubParams *__restrict__ params) {
+  extern __shared__ unsigned long long lds_keys[];  // [P] (in-LDS path only)
   __shared__ float s_red[6][kSubThreads / 64];
   __shared__ int s_scan[kSubThreads / 64];
   __shared__ int s_tmp;
@@ -52,10 +71,23 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
   float *o = sub_xyz + (size_t)b * m * 3;
   int *om = sub_mask + (size_t)b * m;
 
-  const int nv = block_first_zero(mk, N, &s_tmp);
+  const unsigned long long *skeys = PRESORTED ? gkeys + (size_t)b * N : lds_keys;
+  auto key_at = [&](int pos) -> unsigned long long {
+    if constexpr (PRESORTED) {  // strip the cloud byte, bring {cell, index} back to the 32|32 layout
+      const unsigned long long k = skeys[pos];
+      return (((k >> 24) & 0xffffffffull) << 32) | (k & 0xffffffull);
+    } else {
+      return skeys[pos];
+    }
+  };
+  int nv;
+  float mn[3], mx[3];
+  if constexpr (PRESORTED) {
+    nv = params[b].nv;
+  } else {
+  nv = block_first_zero(mk, N, &s_tmp);
 
   // ---- 1. bounding box over all N points
-  float mn[3], mx[3];
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     mn[a] = p[a];
@@ -111,7 +143,15 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
       const int cell = iX + NX * iY + NX * NY * iZ;
       key = ((unsigned long long)(((unsigned)cell) ^ 0x80000000u) << 32) | (unsigned)i;
     }
-    keys[i] = key;
+    if constexpr (KEYS_ONLY) {
+      if (i < N) gkeys[(size_t)b * N + i] = big_key(b, (int)(((unsigned)(key >> 32)) ^ 0x80000000u), i, i < nv);
+    } else {
+      lds_keys[i] = key;
+    }
+  }
+  if constexpr (KEYS_ONLY) {
+    if (tid == 0) params[b].nv = nv;
+    return;
   }
   __syncthreads();
   for (int k = 2; k <= P; k <<= 1) {
@@ -119,16 +159,18 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
       for (int t = tid; t < (P >> 1); t += kSubThreads) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
         const int l = i | j;
-        const unsigned long long a = keys[i], c = keys[l];
+        const unsigned long long a = lds_keys[i], c = lds_keys[l];
         const bool up = (i & k) == 0;
         if ((a > c) == up) {
-          keys[i] = c;
-          keys[l] = a;
+          lds_keys[i] = c;
+          lds_keys[l] = a;
         }
       }
       __syncthreads();
     }
   }
+
+  }  // !PRESORTED
 
   // ---- 3. heads: contiguous run per thread, block scan of head counts
   const int run = (P + kSubThreads - 1) / kSubThreads;
@@ -137,7 +179,7 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
   r1 = r1 < nv ? r1 : nv;
   int heads = 0;
   for (int pos = r0; pos < r1; ++pos)
-    heads += (pos == 0 || key_cell(keys[pos]) != key_cell(keys[pos - 1])) ? 1 : 0;
+    heads += (pos == 0 || key_cell(key_at(pos)) != key_cell(key_at(pos - 1))) ? 1 : 0;
   // exclusive scan over threads
   int incl = heads;
 #pragma unroll
@@ -159,7 +201,7 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
 
   // ---- 4. shuffle position tables
   if (tid == 0) {
-    int k0 = nv > 0 ? key_cell(keys[0]) % 256 : 0;
+    int k0 = nv > 0 ? key_cell(key_at(0)) % 256 : 0;
     s_T[0] = k0;
     for (int i = 1; i < 512; ++i) {
       k0 = (17 * k0 + 139) % 256;
@@ -215,13 +257,13 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
     }
   } else {
     for (int pos = r0; pos < r1; ++pos) {
-      const int cell = key_cell(keys[pos]);
-      if (!(pos == 0 || cell != key_cell(keys[pos - 1]))) continue;
-      int j = key_orig(keys[pos]);
+      const int cell = key_cell(key_at(pos));
+      if (!(pos == 0 || cell != key_cell(key_at(pos - 1)))) continue;
+      int j = key_orig(key_at(pos));
       float xs = p[j * 3 + 0], ys = p[j * 3 + 1], zs = p[j * 3 + 2];
       float pnum = 1.0f;
       for (int pp = pos + 1; pp < nv; ++pp) {
-        const unsigned long long kk = keys[pp];
+        const unsigned long long kk = key_at(pp);
         if (key_cell(kk) != cell) break;
         j = key_orig(kk);
         xs += p[j * 3 + 0];
@@ -253,28 +295,59 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
 
 }  // namespace cl3d
 
+namespace cl3d {
+size_t grid_subsampling_workspace(int B, int N) {
+  if (N <= kSubMaxN) return 0;
+  const size_t n = (size_t)B * N;
+  size_t temp = 0;
+  (void)rocprim::radix_sort_keys(nullptr, temp, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
+                                 (unsigned)n, 0, 64, (hipStream_t)0);
+  return 256 * ((sizeof(SubParams) * B + 255) / 256) + 2 * ((n * 8 + 255) & ~(size_t)255) + temp;
+}
+}  // namespace cl3d
+
 extern "C" int cl3d_masked_grid_subsampling(const float *xyz, const int32_t *mask, int B, int N,
                                             int m, float sampleDl, float *sub_xyz,
                                             int32_t *sub_mask, void *ws, size_t ws_bytes,
                                             cl3d_stream_t stream) {
-  (void)ws;
-  (void)ws_bytes;
   CL3D_REQUIRE(B >= 0 && N >= 1 && m >= 0, "grid_subsampling: bad sizes B=%d N=%d m=%d", B, N, m);
   if (B == 0 || m == 0) return CL3D_OK;
   CL3D_REQUIRE(xyz && mask && sub_xyz && sub_mask, "grid_subsampling: null pointer");
-  if (N > cl3d::kSubMaxN)
-    return cl3d::fail(CL3D_E_UNSUPPORTED, "grid_subsampling: N=%d > %d (multi-workgroup sort path not built yet)", N, cl3d::kSubMaxN);
+  hipStream_t st = (hipStream_t)stream;
+  if (N > cl3d::kSubMaxN) {
+    // large clouds: keys to HBM, one device-wide radix sort, then the same per-cloud kernel on sorted keys
+    CL3D_REQUIRE(B <= 256 && N < (1 << 24), "grid_subsampling: large-N path supports B <= 256, N < 2^24");
+    const size_t need = cl3d::grid_subsampling_workspace(B, N);
+    if (!ws || ws_bytes < need) return cl3d::fail(CL3D_E_WORKSPACE, "grid_subsampling: workspace %zu < %zu", ws_bytes, need);
+    const size_t n = (size_t)B * N;
+    char *p = static_cast<char *>(ws);
+    cl3d::SubParams *params = reinterpret_cast<cl3d::SubParams *>(p);
+    p += 256 * ((sizeof(cl3d::SubParams) * B + 255) / 256);
+    unsigned long long *keys_in = reinterpret_cast<unsigned long long *>(p);
+    p += (n * 8 + 255) & ~(size_t)255;
+    unsigned long long *keys_out = reinterpret_cast<unsigned long long *>(p);
+    p += (n * 8 + 255) & ~(size_t)255;
+    size_t temp_bytes = ws_bytes - (size_t)(p - static_cast<char *>(ws));
+    hipLaunchKernelGGL((cl3d::grid_subsample_kernel<false, true>), dim3(B), dim3(cl3d::kSubThreads), 0, st, xyz, mask, N,
+                       m, sampleDl, N, sub_xyz, sub_mask, keys_in, params);
+    hipError_t e = rocprim::radix_sort_keys(p, temp_bytes, (const unsigned long long *)keys_in, keys_out, (unsigned)n,
+                                            0, 64, st);
+    if (e != hipSuccess) return cl3d::fail(CL3D_E_LAUNCH, "grid_subsampling: radix sort: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL((cl3d::grid_subsample_kernel<true, false>), dim3(B), dim3(cl3d::kSubThreads), 0, st, xyz, mask, N,
+                       m, sampleDl, N, sub_xyz, sub_mask, keys_out, params);
+    return cl3d::check_launch("cl3d_masked_grid_subsampling(large)");
+  }
   int P = 2;
   while (P < N) P <<= 1;
   const size_t lds = (size_t)P * sizeof(unsigned long long);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cl3d::grid_subsample_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cl3d::grid_subsample_kernel<false, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) return cl3d::fail(CL3D_E_LAUNCH, "grid_subsampling: LDS opt-in: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL(cl3d::grid_subsample_kernel, dim3(B), dim3(cl3d::kSubThreads), lds, (hipStream_t)stream,
-                     xyz, mask, N, m, sampleDl, P, sub_xyz, sub_mask);
+  hipLaunchKernelGGL((cl3d::grid_subsample_kernel<false, false>), dim3(B), dim3(cl3d::kSubThreads), lds, st, xyz, mask, N,
+                     m, sampleDl, P, sub_xyz, sub_mask, (unsigned long long *)nullptr, (cl3d::SubParams *)nullptr);
   return cl3d::check_launch("cl3d_masked_grid_subsampling");
 }

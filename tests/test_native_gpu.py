@@ -31,6 +31,7 @@ BQ_CASES = [
     (1, 64, 5, 3, 8.0, "uniform", 0.0),             # tiny M -> small-QW kernel
     (2, 512, None, 42, 1.0, "uniform", 0.0),        # largest nsample in the reference cfgs
     (1, 300, None, 100, 0.5, "uniform", 0.0),       # K large -> QW=1 kernel, heavy wrap padding
+    (1, 40960, 8192, 26, 1.5, "uniform", 0.05),     # scene-sized cloud (BASELINE config 3), cell grid at its cell cap
 ]
 
 
@@ -112,6 +113,8 @@ SUB_CASES = [
     (1, 5000, 700, 0.05, "planes", 0.3),     # N not a power of two, > 4096 (LDS opt-in path)
     (1, 15000, 4000, 0.04, "uniform", 0.05), # S3DIS crop size
     (2, 17, 5, 0.5, "uniform", 0.0),
+    (2, 20000, 5000, 0.05, "planes", 0.1),    # beyond the in-LDS sort: device-wide radix sort path
+    (1, 40960, 10240, 0.04, "uniform", 0.05), # S3DIS-scene size (BASELINE config 3)
 ]
 
 

@@ -104,6 +104,7 @@ FUSED_CASES = [
                       "pointwisemlp__reduction": "max"}, 18, 9, 300, 4.0),                              # V=1 path
     ("pseudo_grid", {"pseudo_grid__KP_influence": "linear"}, 64, 26, 1024, 1.5),
     ("pseudo_grid", {"pseudo_grid__KP_influence": "constant"}, 36, 16, 400, 4.0),
+    ("pseudo_grid", {"pseudo_grid__KP_influence": "linear"}, 12, 26, 20000, 1.5),   # scene-sized support set
 ]
 
 
