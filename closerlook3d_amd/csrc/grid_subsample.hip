@@ -35,11 +35,15 @@ __device__ __forceinline__ int key_cell(unsigned long long k) {
 __device__ __forceinline__ int key_orig(unsigned long long k) { return (int)(unsigned)(k & 0xffffffffull); }
 
 // Large clouds (N > kSubMaxN): the (cell, index) keys do not fit LDS.  A first kernel writes them to HBM as
-// {cloud:8 | biased cell:32 | index:24}, one device-wide radix sort (rocPRIM) orders all clouds at once, and
+// {cloud:6 | biased cell:32 | index:26}, one device-wide radix sort (rocPRIM) orders all clouds at once, and
 // the same per-cloud kernel runs with PRESORTED = true, reading its cloud's slice instead of sorting in LDS.
+// (The index field is deliberately wider than 24 bits: hipcc 7.2 for gfx950 drops an `x & 0xffffff` in front
+// of an address multiply -- `p[(k & 0xffffff) * 3]` compiles to v_mad_u64_u32 on the unmasked dword -- which
+// showed up here as a memory fault; masks wider than 24 bits are compiled correctly.)
+constexpr int kBigIdxBits = 26;
 __device__ __forceinline__ unsigned long long big_key(int b, int cell, int i, bool valid) {
   const unsigned long long c = valid ? (unsigned long long)(((unsigned)cell) ^ 0x80000000u) : 0xffffffffull;
-  return ((unsigned long long)(unsigned)b << 56) | (c << 24) | (unsigned long long)(unsigned)i;
+  return ((unsigned long long)(unsigned)b << (32 + kBigIdxBits)) | (c << kBigIdxBits) | (unsigned long long)(unsigned)i;
 }
 
 struct SubParams {
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
   auto key_at = [&](int pos) -> unsigned long long {
     if constexpr (PRESORTED) {  // strip the cloud byte, bring {cell, index} back to the 32|32 layout
       const unsigned long long k = skeys[pos];
-      return (((k >> 24) & 0xffffffffull) << 32) | (k & 0xffffffull);
+      return (((k >> kBigIdxBits) & 0xffffffffull) << 32) | (k & ((1ull << kBigIdxBits) - 1));
     } else {
       return skeys[pos];
     }
@@ -316,7 +320,7 @@ extern "C" int cl3d_masked_grid_subsampling(const float *xyz, const int32_t *mas
   hipStream_t st = (hipStream_t)stream;
   if (N > cl3d::kSubMaxN) {
     // large clouds: keys to HBM, one device-wide radix sort, then the same per-cloud kernel on sorted keys
-    CL3D_REQUIRE(B <= 256 && N < (1 << 24), "grid_subsampling: large-N path supports B <= 256, N < 2^24");
+    CL3D_REQUIRE(B <= 64 && N < (1 << cl3d::kBigIdxBits), "grid_subsampling: large-N path supports B <= 64, N < 2^26");
     const size_t need = cl3d::grid_subsampling_workspace(B, N);
     if (!ws || ws_bytes < need) return cl3d::fail(CL3D_E_WORKSPACE, "grid_subsampling: workspace %zu < %zu", ws_bytes, need);
     const size_t n = (size_t)B * N;
