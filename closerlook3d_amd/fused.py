@@ -159,6 +159,43 @@ def pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, features, radi
                               _wants_grad(features, kernel_weights))
 
 
+class _MaxPool(Function):
+    """out[b,c,j] = max_k f[b,c,idx[b,j,k]] with max_pool2d's gradient routing (first maximum)."""
+
+    @staticmethod
+    def forward(ctx, features, idx, need_grad):
+        B, C, N = features.shape
+        _, M, K = idx.shape
+        ft = features.transpose(1, 2).contiguous()
+        out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)
+        kstar = torch.empty((B, M, C), dtype=torch.uint8, device=features.device) if need_grad else None
+        with torch.cuda.device(features.device):
+            _lib.check(_lib.lib().cl3d_maxpool_fwd(_p(idx), _p(ft), B, N, M, K, C, _p(out), _p(kstar),
+                                                   _stream(features)))
+        ctx.save_for_backward(kstar)
+        ctx.idx = idx
+        ctx.meta = (B, N, M, K, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        (kstar,) = ctx.saved_tensors
+        B, N, M, K, C = ctx.meta
+        gout_t = gout.transpose(1, 2).contiguous()
+        off, slots = inverse_index(ctx.idx, N)
+        dft = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
+        with torch.cuda.device(gout.device):
+            _lib.check(_lib.lib().cl3d_maxpool_bwd(_p(gout_t), _p(kstar), _p(off), _p(slots), B, N, M, K, C, _p(dft),
+                                                   _stream(gout)))
+        return dft.transpose(1, 2), None, None
+
+
+def max_pool(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample):
+    """MaskedMaxPool's pooling step on the fused path (nsample <= 255)."""
+    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+    return _MaxPool.apply(features.contiguous(), idx, _wants_grad(features))
+
+
 class _PointwiseMLP(Function):
     """max_k ReLU(BN(W_r rel + H[centre] + G[nbr])) on point-major rows; see csrc/fused_pwmlp.hip."""
 

@@ -207,12 +207,17 @@ class MaskedMaxPool(nn.Module):
         self.radius = radius
         self.nsample = nsample
         self.sampleDl = sampleDl
+        self.fused = True  # set False to run the reference's gather + max_pool2d dataflow
         self.grouper = MaskedQueryAndGroup(radius, nsample, use_xyz=False, ret_grouped_xyz=True)
 
     def forward(self, xyz, mask, features):
         sub_xyz, sub_mask = masked_grid_subsampling(xyz, mask, self.npoint, self.sampleDl)
         sub_xyz = sub_xyz.contiguous()
         sub_mask = sub_mask.contiguous()
+        if self.fused and features.is_cuda and self.nsample <= 255:
+            # one kernel, no [B,C,npoint,K] tensor (same values; same first-maximum gradient routing)
+            from . import fused
+            return sub_xyz, sub_mask, fused.max_pool(sub_xyz, xyz, sub_mask, mask, features, self.radius, self.nsample)
         neighborhood_features, _, _ = self.grouper(sub_xyz, xyz, sub_mask, mask, features)
         # max_pool2d, not amax: on ties its backward routes the gradient to the first maximum, as the
         # reference does; amax would split it evenly (ties are common: ReLU zeros, wrap-around padding)

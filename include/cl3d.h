@@ -138,6 +138,15 @@ int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *ft, const fl
                           int constant_influence, float *dft, float *dparam, int n_partials,
                           cl3d_stream_t stream);
 
+/* MaskedMaxPool's pooling step (pt_utils.py:194-201: gather + F.max_pool2d over K) without the gathered
+ * tensor.  ft [B,N,C] point-major; out [B,C,M] channel-major; kstar_t [B,M,C] = arg-max slot (first
+ * maximum) per (query, channel), nullable when no gradient is needed; backward through the CSR inverse. */
+int cl3d_maxpool_fwd(const int32_t *idx, const float *ft, int B, int N, int M, int K, int C, float *out,
+                     unsigned char *kstar_t, cl3d_stream_t stream);
+int cl3d_maxpool_bwd(const float *gout_t, const unsigned char *kstar_t, const int32_t *inv_off,
+                     const int32_t *inv_slots, int B, int N, int M, int K, int C, float *dft,
+                     cl3d_stream_t stream);
+
 /* PointWiseMLP 'dp_fi_df', one Conv2d+BatchNorm2d+ReLU layer, max reduction
  * (local_aggregation_operators.py:288-301).  ght [B,N,2*Co]: row i = [W_d f_i | (W_c - W_d) f_i];
  * wr [Co,3] = the conv weight's columns for the relative position.  See csrc/fused_pwmlp.hip. */

@@ -186,3 +186,30 @@ def test_eval_mode_inference_paths_agree():
         b.load_state_dict(a.state_dict())
         with torch.no_grad():
             assert_close(a(*t).cpu().numpy(), b(*t).cpu().numpy(), 1e-5, f"{kind} eval fused vs grouped")
+
+
+@pytest.mark.parametrize("C,K,N,npoint", [(24, 16, 512, 128), (144, 32, 2048, 512), (10, 9, 300, 77)])
+def test_fused_max_pool_matches_reference_dataflow(C, K, N, npoint):
+    """MaskedMaxPool: fused kernel == gather + F.max_pool2d (values and gradient routing, incl. ReLU-zero ties)."""
+    from closerlook3d_amd.pt_utils import MaskedMaxPool
+    from oracle import operators as oo
+    rng = np.random.default_rng(C + K)
+    B = 2
+    xyz, mask = oo.make_cloud(rng, B, N, pad_frac=0.15)
+    feats = np.maximum(rng.standard_normal((B, C, N)), 0).astype(np.float32)  # many exact ties at 0
+    t_xyz, t_mask = torch.from_numpy(xyz).cuda(), torch.from_numpy(mask).cuda()
+    outs = []
+    for fused in (True, False):
+        pool = MaskedMaxPool(npoint, 0.15, K, 0.08).cuda()
+        pool.fused = fused
+        f = torch.from_numpy(feats).cuda().requires_grad_(True)
+        sub_xyz, sub_mask, y = pool(t_xyz, t_mask, f)
+        probe = torch.from_numpy(rng.standard_normal((B, C, npoint)).astype(np.float32)).cuda() if not outs else outs[0][3]
+        (y * probe).sum().backward()
+        outs.append((y.detach(), f.grad.clone(), sub_xyz, probe))
+    assert torch.equal(outs[0][2], outs[1][2])
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert_close(outs[0][1].cpu().numpy(), outs[1][1].cpu().numpy(), 1e-5, "max-pool input gradient")
+    # and against the CPU oracle
+    want = oo.masked_max_pool(torch.from_numpy(xyz), torch.from_numpy(mask), torch.from_numpy(feats), npoint, 0.15, K, 0.08)
+    assert np.array_equal(outs[0][0].cpu().numpy(), want[2].numpy())
