@@ -32,7 +32,7 @@
 namespace cl3d {
 
 constexpr int kMaxCells = 8192;
-constexpr int kBqQW = 2;   // queries per task / wave (2: 127 us, 1: 137 us, 4: 178 us at the metric shape)
+constexpr int kBqQW = 2;   // queries per task / wave (measured at the metric shape: 2 -> 102 us, 4 -> 122 us, 1 -> 137 us)
 constexpr int kCapMul = 6; // LDS candidate list holds kCapMul*K entries per query
 constexpr int kBqBatch = 3;  // candidate float4 loads in flight per lane
 
@@ -87,56 +87,38 @@ inline BqWorkspace bq_carve(void *ws, int B, int N, int M) {
 
 __device__ __forceinline__ int cell_coord(float x, float o, float inv_h) { return (int)floorf((x - o) * inv_h); }
 
-// block-wide exclusive scan of s_data[0..n) in place (n <= kMaxCells), returns the total; 1024 threads
-__device__ __forceinline__ int block_exclusive_scan(int *s_data, int n, int *s_wave) {
-  const int per = (n + 1023) / 1024;
-  const int t0 = threadIdx.x * per;
-  int sum = 0;
-  for (int i = 0; i < per; ++i)
-    if (t0 + i < n) sum += s_data[t0 + i];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int incl = sum;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += v;
-  }
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  int woff = 0, total = 0;
-  for (int w = 0; w < 16; ++w) {
-    if (w < wave) woff += s_wave[w];
-    total += s_wave[w];
-  }
-  int run = woff + incl - sum;
-  for (int i = 0; i < per; ++i) {
-    if (t0 + i < n) {
-      const int v = s_data[t0 + i];
-      s_data[t0 + i] = run;
-      run += v;
-    }
-  }
-  __syncthreads();
-  return total;
-}
-
+// prep: one 1024-thread workgroup per cloud.  The work is tiny (tens of KB) and entirely latency: every
+// __syncthreads-separated phase costs a global round trip, so the phases are merged as far as the data
+// dependences allow -- (1) one sweep over the support cloud gives the number of leading valid points and
+// the bounding box; (2) support AND query histograms over the cells, side by side in LDS; (3) both
+// exclusive scans share their barriers (the third column scanned is "tasks per cell"); (4) cell starts,
+// the task table (with each cell's candidate runs) and both scatters.
 __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__ query_xyz,
                                                        const float *__restrict__ support_xyz,
                                                        const int *__restrict__ support_mask, int M, int N,
                                                        float radius, BqWorkspace w) {
-  __shared__ int s_cnt[kMaxCells];
+  extern __shared__ int lds_cells[];  // [2][kMaxCells]: support counts/starts/cursors, query counts/starts/cursors
   __shared__ float s_red[6][16];
-  __shared__ int s_wave[16];
-  __shared__ int s_tmp;
+  __shared__ int s_wave[3][16];
+  __shared__ int s_nv;
+  int *s_sup = lds_cells, *s_qry = lds_cells + kMaxCells;
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float *s = support_xyz + (size_t)b * N * 3;
   const float *q = query_xyz + (size_t)b * M * 3;
-  const int nv = block_first_zero(support_mask + (size_t)b * N, N, &s_tmp);
+  const int *sm = support_mask + (size_t)b * N;
 
-  // bounding box of the valid support points
+  // ---- (1) first zero of the mask + bounding box of the unmasked points (a superset of the valid prefix
+  // is fine for a search grid; masked-out coordinates never enter it)
+  if (tid == 0) s_nv = N;
+  for (int c = tid; c < 2 * kMaxCells; c += 1024) lds_cells[c] = 0;
   float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
-  for (int i = tid; i < nv; i += 1024) {
+  int first0 = N;
+  for (int i = tid; i < N; i += 1024) {
+    if (sm[i] == 0) {
+      first0 = i < first0 ? i : first0;
+      continue;
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float v = s[i * 3 + a];
@@ -157,7 +139,10 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
       s_red[3 + a][wave] = mx[a];
     }
   }
+  __syncthreads();  // s_nv / lds_cells initialised, s_red written
+  if (first0 < N) atomicMin(&s_nv, first0);
   __syncthreads();
+  const int nv = s_nv;
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     mn[a] = s_red[a][0];
@@ -171,141 +156,143 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
   float h = radius * 1.0002f;
   if (!(h > 0.f)) h = 1.0f;
   int nx = 1, ny = 1, nz = 1;
-  if (nv > 0) {
-    for (int it = 0; it < 64; ++it) {
+  bool ok = false;
+  if (nv > 0 && mn[0] <= mx[0]) {
+    for (int it = 0; it < 64 && !ok; ++it) {
       const float inv = 1.0f / h;
       nx = (int)floorf((mx[0] - mn[0]) * inv) + 1;
       ny = (int)floorf((mx[1] - mn[1]) * inv) + 1;
       nz = (int)floorf((mx[2] - mn[2]) * inv) + 1;
-      if (nx > 0 && ny > 0 && nz > 0 && (long long)nx * ny * nz <= kMaxCells) break;
-      h *= 1.3f;
+      ok = nx > 0 && ny > 0 && nz > 0 && (long long)nx * ny * nz <= kMaxCells;
+      if (!ok) h *= 1.3f;
     }
-    if (!(nx > 0 && ny > 0 && nz > 0 && (long long)nx * ny * nz <= kMaxCells)) {  // degenerate (inf/nan): one cell
-      nx = ny = nz = 1;
-      h = 3.0e38f;
-    }
+  }
+  if (!ok) {  // empty or degenerate (inf/nan) cloud: one cell holding everything
+    nx = ny = nz = 1;
+    h = 3.0e38f;
+    mn[0] = mn[1] = mn[2] = 0.f;
   }
   const float inv_h = 1.0f / h;
   const int ncells = nx * ny * nz;
+  auto cell_of = [&](float x, float y, float z) {
+    int cx = cell_coord(x, mn[0], inv_h), cy = cell_coord(y, mn[1], inv_h), cz = cell_coord(z, mn[2], inv_h);
+    cx = cx < 0 ? 0 : (cx >= nx ? nx - 1 : cx);
+    cy = cy < 0 ? 0 : (cy >= ny ? ny - 1 : cy);
+    cz = cz < 0 ? 0 : (cz >= nz ? nz - 1 : cz);
+    return cx + nx * (cy + ny * cz);
+  };
 
-  // ---- counting sort of the valid support points by cell
-  for (int c = tid; c < ncells; c += 1024) s_cnt[c] = 0;
-  __syncthreads();
-  auto clampi = [](int v, int hi) { return v < 0 ? 0 : (v >= hi ? hi - 1 : v); };
-  for (int i = tid; i < nv; i += 1024) {
-    const int cx = clampi(cell_coord(s[i * 3 + 0], mn[0], inv_h), nx);
-    const int cy = clampi(cell_coord(s[i * 3 + 1], mn[1], inv_h), ny);
-    const int cz = clampi(cell_coord(s[i * 3 + 2], mn[2], inv_h), nz);
-    atomicAdd(&s_cnt[cx + nx * (cy + ny * cz)], 1);
-  }
-  __syncthreads();
-  block_exclusive_scan(s_cnt, ncells, s_wave);
-  int *cs = w.cell_start + (size_t)b * (kMaxCells + 1);
-  for (int c = tid; c < ncells; c += 1024) cs[c] = s_cnt[c];
-  if (tid == 0) cs[ncells] = nv;
-  __syncthreads();
-  float4 *sorted = w.sorted + (size_t)b * N;
-  for (int i = tid; i < nv; i += 1024) {
-    const float x = s[i * 3 + 0], y = s[i * 3 + 1], z = s[i * 3 + 2];
-    const int cx = clampi(cell_coord(x, mn[0], inv_h), nx);
-    const int cy = clampi(cell_coord(y, mn[1], inv_h), ny);
-    const int cz = clampi(cell_coord(z, mn[2], inv_h), nz);
-    const int p = atomicAdd(&s_cnt[cx + nx * (cy + ny * cz)], 1);  // order inside a cell is irrelevant
-    sorted[p] = make_float4(x, y, z, __int_as_float(i));
-  }
+  // ---- (2) both histograms
+  for (int i = tid; i < nv; i += 1024) atomicAdd(&s_sup[cell_of(s[i * 3 + 0], s[i * 3 + 1], s[i * 3 + 2])], 1);
+  for (int j = tid; j < M; j += 1024) atomicAdd(&s_qry[cell_of(q[j * 3 + 0], q[j * 3 + 1], q[j * 3 + 2])], 1);
   __syncthreads();
 
-  // ---- queries by cell (clamped into the grid for grouping only) + task table
-  for (int c = tid; c < ncells; c += 1024) s_cnt[c] = 0;
-  __syncthreads();
-  for (int j = tid; j < M; j += 1024) {
-    const int cx = clampi(cell_coord(q[j * 3 + 0], mn[0], inv_h), nx);
-    const int cy = clampi(cell_coord(q[j * 3 + 1], mn[1], inv_h), ny);
-    const int cz = clampi(cell_coord(q[j * 3 + 2], mn[2], inv_h), nz);
-    atomicAdd(&s_cnt[cx + nx * (cy + ny * cz)], 1);
-  }
-  __syncthreads();
-  // tasks per cell and their prefix (kept in registers across the in-place scan of the query counts)
-  const int per = (ncells + 1023) / 1024;
+  // ---- (3) three exclusive scans over the cells with shared barriers: support counts, query counts,
+  // tasks per cell.  Thread t owns cells [t*per, (t+1)*per).
+  const int per = (ncells + 1023) / 1024;  // <= 8
   const int t0 = tid * per;
-  int my_tasks = 0;
-  for (int i = 0; i < per; ++i)
-    if (t0 + i < ncells) my_tasks += (s_cnt[t0 + i] + kBqQW - 1) / kBqQW;
-  int incl = my_tasks;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int v = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += v;
-  }
-  __syncthreads();
-  if (lane == 63) s_wave[wave] = incl;
-  __syncthreads();
-  int task_off = 0, ntasks = 0;
-  for (int ww = 0; ww < 16; ++ww) {
-    if (ww < wave) task_off += s_wave[ww];
-    ntasks += s_wave[ww];
-  }
-  task_off += incl - my_tasks;
-  __syncthreads();
-  // query counts of my cells, before the scan overwrites them
-  // (per <= 8 for kMaxCells = 8192 and 1024 threads)
   int nq_mine[8];
-  for (int i = 0; i < 8; ++i) nq_mine[i] = (i < per && t0 + i < ncells) ? s_cnt[t0 + i] : 0;
+  int sum[3] = {0, 0, 0};
+  for (int i = 0; i < 8; ++i) {
+    nq_mine[i] = 0;
+    if (i < per && t0 + i < ncells) {
+      nq_mine[i] = s_qry[t0 + i];
+      sum[0] += s_sup[t0 + i];
+      sum[1] += nq_mine[i];
+      sum[2] += (nq_mine[i] + kBqQW - 1) / kBqQW;
+    }
+  }
+  int incl[3] = {sum[0], sum[1], sum[2]};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl[k], o, 64);
+      if (lane >= o) incl[k] += v;
+    }
+    if (lane == 63) s_wave[k][wave] = incl[k];
+  }
   __syncthreads();
-  block_exclusive_scan(s_cnt, ncells, s_wave);
-  BqTask *tasks = w.tasks + (size_t)b * w.max_tasks;
-  {
-    int t = task_off;
-    for (int i = 0; i < 8; ++i) {
-      if (i < per && t0 + i < ncells) {
-        const int qs = s_cnt[t0 + i];
-        if (nq_mine[i] == 0) continue;
-        // candidate window of this cell (queries that were clamped into the grid get a superset of what
-        // their true position needs: outside the grid only the boundary cells can be within reach)
-        BqTask tk;
-        const int cell = t0 + i;
-        const int cx = cell % nx, cy = (cell / nx) % ny, cz = cell / (nx * ny);
-        const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < nx ? cx + 1 : nx - 1;
-        const int y0 = cy > 0 ? cy - 1 : 0, y1 = cy + 1 < ny ? cy + 1 : ny - 1;
-        const int z0 = cz > 0 ? cz - 1 : 0, z1 = cz + 1 < nz ? cz + 1 : nz - 1;
-        int acc = 0;
-        for (int r = 0; r < 9; ++r) {
-          const int yy = y0 + r % 3, zz = z0 + r / 3;
-          int ra = 0, len = 0;
-          if (yy <= y1 && zz <= z1) {
-            const int row = nx * (yy + ny * zz);
-            ra = cs[row + x0];
-            len = cs[row + x1 + 1] - ra;
-          }
-          tk.run_pe[r] = acc;
-          tk.run_delta[r] = ra - acc;
-          acc += len;
-        }
-        tk.total = acc;
-        tk.cell = cell;
-        tk.pad[0] = tk.pad[1] = 0;
-        for (int k = 0; k < nq_mine[i]; k += kBqQW) {
-          tk.q0 = qs + k;
-          tk.n = nq_mine[i] - k < kBqQW ? nq_mine[i] - k : kBqQW;
-          tasks[t++] = tk;
-        }
-      }
+  int run[3], total[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    int woff = 0, tot = 0;
+    for (int ww = 0; ww < 16; ++ww) {
+      if (ww < wave) woff += s_wave[k][ww];
+      tot += s_wave[k][ww];
+    }
+    run[k] = woff + incl[k] - sum[k];
+    total[k] = tot;
+  }
+  for (int i = 0; i < 8; ++i) {
+    if (i < per && t0 + i < ncells) {
+      const int cs_ = s_sup[t0 + i];
+      s_sup[t0 + i] = run[0];
+      run[0] += cs_;
+      s_qry[t0 + i] = run[1];
+      run[1] += nq_mine[i];
     }
   }
   __syncthreads();
+
+  // ---- (4) cell starts, task table, scatters
+  int *cs = w.cell_start + (size_t)b * (kMaxCells + 1);
+  for (int c = tid; c < ncells; c += 1024) cs[c] = s_sup[c];
+  if (tid == 0) cs[ncells] = nv;
+  auto start_of = [&](int c) { return c < ncells ? s_sup[c] : nv; };
+  BqTask *tasks = w.tasks + (size_t)b * w.max_tasks;
+  {
+    int t = run[2];
+    for (int i = 0; i < 8; ++i) {
+      if (!(i < per && t0 + i < ncells) || nq_mine[i] == 0) continue;
+      // candidate window of this cell (queries that were clamped into the grid get a superset of what
+      // their true position needs: outside the grid only the boundary cells can be within reach)
+      BqTask tk;
+      const int cell = t0 + i;
+      const int cx = cell % nx, cy = (cell / nx) % ny, cz = cell / (nx * ny);
+      const int x0 = cx > 0 ? cx - 1 : 0, x1 = cx + 1 < nx ? cx + 1 : nx - 1;
+      const int y0 = cy > 0 ? cy - 1 : 0, y1 = cy + 1 < ny ? cy + 1 : ny - 1;
+      const int z0 = cz > 0 ? cz - 1 : 0, z1 = cz + 1 < nz ? cz + 1 : nz - 1;
+      int acc = 0;
+      for (int r = 0; r < 9; ++r) {
+        const int yy = y0 + r % 3, zz = z0 + r / 3;
+        int ra = 0, len = 0;
+        if (yy <= y1 && zz <= z1) {
+          const int row = nx * (yy + ny * zz);
+          ra = start_of(row + x0);
+          len = start_of(row + x1 + 1) - ra;
+        }
+        tk.run_pe[r] = acc;
+        tk.run_delta[r] = ra - acc;
+        acc += len;
+      }
+      tk.total = acc;
+      tk.cell = cell;
+      tk.pad[0] = tk.pad[1] = 0;
+      const int qs = s_qry[cell];
+      for (int k = 0; k < nq_mine[i]; k += kBqQW) {
+        tk.q0 = qs + k;
+        tk.n = nq_mine[i] - k < kBqQW ? nq_mine[i] - k : kBqQW;
+        tasks[t++] = tk;
+      }
+    }
+  }
+  __syncthreads();  // every reader of the start values is done: the arrays become scatter cursors
+  float4 *sorted = w.sorted + (size_t)b * N;
+  for (int i = tid; i < nv; i += 1024) {
+    const float x = s[i * 3 + 0], y = s[i * 3 + 1], z = s[i * 3 + 2];
+    sorted[atomicAdd(&s_sup[cell_of(x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(i));  // order inside a cell is irrelevant
+  }
   float4 *qsorted = w.qsorted + (size_t)b * M;
   for (int j = tid; j < M; j += 1024) {
     const float x = q[j * 3 + 0], y = q[j * 3 + 1], z = q[j * 3 + 2];
-    const int cx = clampi(cell_coord(x, mn[0], inv_h), nx);
-    const int cy = clampi(cell_coord(y, mn[1], inv_h), ny);
-    const int cz = clampi(cell_coord(z, mn[2], inv_h), nz);
-    qsorted[atomicAdd(&s_cnt[cx + nx * (cy + ny * cz)], 1)] = make_float4(x, y, z, __int_as_float(j));
+    qsorted[atomicAdd(&s_qry[cell_of(x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(j));
   }
   if (tid == 0) {
     BqGrid g;
     g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_h = inv_h;
     g.nx = nx; g.ny = ny; g.nz = nz; g.ncells = ncells;
-    g.ntasks = ntasks; g.nv = nv; g.pad0 = g.pad1 = 0;
+    g.ntasks = total[2]; g.nv = nv; g.pad0 = g.pad1 = 0;
     w.grid[b] = g;
   }
 }
@@ -513,7 +500,15 @@ int ball_query_cells(const float *query_xyz, const float *support_xyz, const int
     return fail(CL3D_E_WORKSPACE, "ball_query: workspace %zu < %zu", ws_bytes, bq_workspace_bytes(B, N, M));
   if (B > 65535) return fail(CL3D_E_UNSUPPORTED, "ball_query: B exceeds grid.y limit");
   BqWorkspace w = bq_carve(ws, B, N, M);
-  hipLaunchKernelGGL(bq_prep_kernel, dim3(B), dim3(1024), 0, st, query_xyz, support_xyz, support_mask, M, N, radius, w);
+  static bool prep_attr = false;
+  if (!prep_attr) {  // 64 KiB of cell arrays + the static reduction scratch: above the 64 KiB a kernel gets by default
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bq_prep_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMaxCells * (int)sizeof(int));
+    if (e != hipSuccess) return fail(CL3D_E_LAUNCH, "ball_query: LDS opt-in: %s", hipGetErrorString(e));
+    prep_attr = true;
+  }
+  hipLaunchKernelGGL(bq_prep_kernel, dim3(B), dim3(1024), 2 * kMaxCells * sizeof(int), st, query_xyz, support_xyz,
+                     support_mask, M, N, radius, w);
   const size_t lds = (size_t)4 * kBqQW * (2 * kCapMul * K + 2 * 3 * K + K) * sizeof(int);
   int gx = ceil_div(ceil_div(M, kBqQW) + 64, 4);  // ~one task per wave at typical occupancy; persistent loop beyond
   gx = gx > 512 ? 512 : gx;
