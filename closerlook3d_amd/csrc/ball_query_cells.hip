@@ -35,6 +35,7 @@ constexpr int kMaxCells = 8192;
 constexpr int kBqQW = 2;   // queries per task / wave (measured at the metric shape: 2 -> 102 us, 4 -> 122 us, 1 -> 137 us)
 constexpr int kCapMul = 6; // LDS candidate list holds kCapMul*K entries per query
 constexpr int kBqBatch = 3;  // candidate float4 loads in flight per lane
+constexpr int kPrepU = 4;    // point sweeps in flight per thread in the prep kernel
 
 struct BqGrid {
   float ox, oy, oz, inv_h;
@@ -114,16 +115,31 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
   for (int c = tid; c < 2 * kMaxCells; c += 1024) lds_cells[c] = 0;
   float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
   int first0 = N;
-  for (int i = tid; i < N; i += 1024) {
-    if (sm[i] == 0) {
-      first0 = i < first0 ? i : first0;
-      continue;
+  // loads are issued kPrepU sweeps at a time and unconditionally (clamped index), so a sweep costs one
+  // memory round trip instead of one per dependent load
+  for (int base = 0; base < N; base += 1024 * kPrepU) {
+    int mk[kPrepU];
+    float px[kPrepU], py[kPrepU], pz[kPrepU];
+#pragma unroll
+    for (int u = 0; u < kPrepU; ++u) {
+      const int i = base + u * 1024 + tid;
+      const int ic = i < N ? i : N - 1;
+      mk[u] = sm[ic];
+      px[u] = s[ic * 3 + 0];
+      py[u] = s[ic * 3 + 1];
+      pz[u] = s[ic * 3 + 2];
     }
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const float v = s[i * 3 + a];
-      mn[a] = v < mn[a] ? v : mn[a];
-      mx[a] = v > mx[a] ? v : mx[a];
+    for (int u = 0; u < kPrepU; ++u) {
+      const int i = base + u * 1024 + tid;
+      if (i >= N) continue;
+      if (mk[u] == 0) {
+        first0 = i < first0 ? i : first0;
+        continue;
+      }
+      mn[0] = px[u] < mn[0] ? px[u] : mn[0]; mx[0] = px[u] > mx[0] ? px[u] : mx[0];
+      mn[1] = py[u] < mn[1] ? py[u] : mn[1]; mx[1] = py[u] > mx[1] ? py[u] : mx[1];
+      mn[2] = pz[u] < mn[2] ? pz[u] : mn[2]; mx[2] = pz[u] > mx[2] ? pz[u] : mx[2];
     }
   }
 #pragma unroll
@@ -183,8 +199,26 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
   };
 
   // ---- (2) both histograms
-  for (int i = tid; i < nv; i += 1024) atomicAdd(&s_sup[cell_of(s[i * 3 + 0], s[i * 3 + 1], s[i * 3 + 2])], 1);
-  for (int j = tid; j < M; j += 1024) atomicAdd(&s_qry[cell_of(q[j * 3 + 0], q[j * 3 + 1], q[j * 3 + 2])], 1);
+  auto sweep = [&](const float *pts, int n, auto &&fn) {  // batched point loads, see (1)
+    for (int base = 0; base < n; base += 1024 * kPrepU) {
+      float px[kPrepU], py[kPrepU], pz[kPrepU];
+#pragma unroll
+      for (int u = 0; u < kPrepU; ++u) {
+        const int i = base + u * 1024 + tid;
+        const int ic = i < n ? i : n - 1;
+        px[u] = pts[ic * 3 + 0];
+        py[u] = pts[ic * 3 + 1];
+        pz[u] = pts[ic * 3 + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < kPrepU; ++u) {
+        const int i = base + u * 1024 + tid;
+        if (i < n) fn(i, px[u], py[u], pz[u]);
+      }
+    }
+  };
+  sweep(s, nv, [&](int, float x, float y, float z) { atomicAdd(&s_sup[cell_of(x, y, z)], 1); });
+  sweep(q, M, [&](int, float x, float y, float z) { atomicAdd(&s_qry[cell_of(x, y, z)], 1); });
   __syncthreads();
 
   // ---- (3) three exclusive scans over the cells with shared barriers: support counts, query counts,
@@ -279,15 +313,13 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
   }
   __syncthreads();  // every reader of the start values is done: the arrays become scatter cursors
   float4 *sorted = w.sorted + (size_t)b * N;
-  for (int i = tid; i < nv; i += 1024) {
-    const float x = s[i * 3 + 0], y = s[i * 3 + 1], z = s[i * 3 + 2];
-    sorted[atomicAdd(&s_sup[cell_of(x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(i));  // order inside a cell is irrelevant
-  }
   float4 *qsorted = w.qsorted + (size_t)b * M;
-  for (int j = tid; j < M; j += 1024) {
-    const float x = q[j * 3 + 0], y = q[j * 3 + 1], z = q[j * 3 + 2];
+  sweep(s, nv, [&](int i, float x, float y, float z) {  // order inside a cell is irrelevant
+    sorted[atomicAdd(&s_sup[cell_of(x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(i));
+  });
+  sweep(q, M, [&](int j, float x, float y, float z) {
     qsorted[atomicAdd(&s_qry[cell_of(x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(j));
-  }
+  });
   if (tid == 0) {
     BqGrid g;
     g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_h = inv_h;
