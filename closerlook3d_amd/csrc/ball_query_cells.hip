@@ -288,6 +288,7 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
       const int y0 = cy > 0 ? cy - 1 : 0, y1 = cy + 1 < ny ? cy + 1 : ny - 1;
       const int z0 = cz > 0 ? cz - 1 : 0, z1 = cz + 1 < nz ? cz + 1 : nz - 1;
       int acc = 0;
+#pragma unroll  // keeps the task record in registers (a dynamic index would put it in scratch memory)
       for (int r = 0; r < 9; ++r) {
         const int yy = y0 + r % 3, zz = z0 + r / 3;
         int ra = 0, len = 0;
@@ -314,12 +315,28 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
   __syncthreads();  // every reader of the start values is done: the arrays become scatter cursors
   float4 *sorted = w.sorted + (size_t)b * N;
   float4 *qsorted = w.qsorted + (size_t)b * M;
-  sweep(s, nv, [&](int i, float x, float y, float z) {  // order inside a cell is irrelevant
-    sorted[atomicAdd(&s_sup[cell_of(x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(i));
-  });
-  sweep(q, M, [&](int j, float x, float y, float z) {
-    qsorted[atomicAdd(&s_qry[cell_of(x, y, z)], 1)] = make_float4(x, y, z, __int_as_float(j));
-  });
+  auto scatter = [&](const float *pts, int n, int *cursor, float4 *dst) {  // order inside a cell is irrelevant
+    for (int base = 0; base < n; base += 1024 * kPrepU) {
+      float px[kPrepU], py[kPrepU], pz[kPrepU];
+      int pos[kPrepU];
+#pragma unroll
+      for (int u = 0; u < kPrepU; ++u) {
+        const int i = base + u * 1024 + tid;
+        const int ic = i < n ? i : n - 1;
+        px[u] = pts[ic * 3 + 0];
+        py[u] = pts[ic * 3 + 1];
+        pz[u] = pts[ic * 3 + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < kPrepU; ++u)  // all cursor atomics of the batch first, then all stores
+        pos[u] = base + u * 1024 + tid < n ? atomicAdd(&cursor[cell_of(px[u], py[u], pz[u])], 1) : -1;
+#pragma unroll
+      for (int u = 0; u < kPrepU; ++u)
+        if (pos[u] >= 0) dst[pos[u]] = make_float4(px[u], py[u], pz[u], __int_as_float(base + u * 1024 + tid));
+    }
+  };
+  scatter(s, nv, s_sup, sorted);
+  scatter(q, M, s_qry, qsorted);
   if (tid == 0) {
     BqGrid g;
     g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_h = inv_h;
