@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
 // NP parameter-gradient accumulators per channel: adaptive 4 (3 weights + bias), pseudo grid kMaxKP.
 template <int OP>
 struct ParamCount {
-  static constexpr int value = OP == OP_ADAPTIVE ? 4 : (OP == OP_PSEUDOGRID ? kMaxKP : 0);
+  static constexpr int value = OP == OP_ADAPTIVE ? 4 : 0;  // PseudoGrid: d kernel_weights comes from pg_dkw_kernel
 };
 
 template <int OP, int V>
@@ -302,18 +302,25 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
           const float4 r = rr[u];
           const Vec<V> &go = gg[u];
           if constexpr (OP == OP_PSEUDOGRID) {
+            // influence of the P kernel points on this slot.  The L lanes of the group look at the same slot:
+            // lane cl evaluates kernel point cl and the group exchanges the values (ds_bpermute), instead
+            // of every lane evaluating all P (15 x ~12 VALU each).
             float h[kMaxKP];
+            if (L >= a.pint && (ch + 1) * L * V <= C) {  // every lane of the group is live in this channel chunk
+              const int pm = cl < a.pint ? cl : 0;
+              const float mine = kp_influence(r.x, r.y, r.z, a.p0 + pm * 3, a.pfloat, a.constant_influence) * r.w;
 #pragma unroll
-            for (int p = 0; p < kMaxKP; ++p)
-              h[p] = p < a.pint ? kp_influence(r.x, r.y, r.z, a.p0 + p * 3, a.pfloat, a.constant_influence) * r.w : 0.f;
+              for (int p = 0; p < kMaxKP; ++p) h[p] = p < a.pint ? __shfl(mine, g * L + p, 64) : 0.f;
+            } else {
+#pragma unroll
+              for (int p = 0; p < kMaxKP; ++p)
+                h[p] = p < a.pint ? kp_influence(r.x, r.y, r.z, a.p0 + p * 3, a.pfloat, a.constant_influence) * r.w : 0.f;
+            }
 #pragma unroll
             for (int v = 0; v < V; ++v) {
               float w = 0.f;
 #pragma unroll
-              for (int p = 0; p < kMaxKP; ++p) {
-                w = __builtin_fmaf(kw[p][v], h[p], w);
-                pacc[p][v] = __builtin_fmaf(h[p] * fown.v[v], go.v[v], pacc[p][v]);
-              }
+              for (int p = 0; p < kMaxKP; ++p) w = __builtin_fmaf(kw[p][v], h[p], w);
               acc[v] = __builtin_fmaf(w, go.v[v], acc[v]);
             }
           } else {
@@ -360,6 +367,108 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
         __syncthreads();
       }
     }
+  }
+}
+
+// ---- PseudoGrid: d kernel_weights[p,c] = sum_{b,j} g[b,c,j] * (sum_k h_p(rel_jk) mask f[b,c,idx_jk])
+// The inner sum is exactly the forward's per-query intermediate, so this is the forward loop again
+// (query-major, influences prepared once per slot in LDS) with the query's output gradient folded in.
+// Persistent blocks; per-lane accumulators live across tiles; one fixed-order block reduction at the end.
+template <int V>
+__global__ __launch_bounds__(256) void pg_dkw_kernel(ReduceArgs a) {
+  extern __shared__ float4 lds4[];
+  const int K = a.K, C = a.C, M = a.M, N = a.N, L = a.L, QW = a.QW;
+  const int TQ = 4 * QW;
+  int *sidx = reinterpret_cast<int *>(lds4);              // [TQ*K]
+  float *hbuf = reinterpret_cast<float *>(sidx + TQ * K);  // [TQ*K][kMaxKP]
+  float *red = reinterpret_cast<float *>(lds4);            // reused after the tile loop
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / L, cl = lane - g * L;
+  const bool lane_on = g < QW;
+  const int tiles_per_cloud = (M + TQ - 1) / TQ;
+  const int ntiles = a.B * tiles_per_cloud;
+  for (int ch = 0; ch < a.chunks; ++ch) {
+    const int c0 = (ch * L + cl) * V;
+    const bool chan_on = lane_on && c0 < C;
+    float pacc[kMaxKP][V];
+#pragma unroll
+    for (int p = 0; p < kMaxKP; ++p)
+#pragma unroll
+      for (int v = 0; v < V; ++v) pacc[p][v] = 0.f;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+      int b, tq;
+      decode_tile(tile, a.B, tiles_per_cloud, b, tq);
+      const int j0 = tq * TQ;
+      __syncthreads();
+      for (int t = threadIdx.x; t < TQ * K; t += 256) {
+        const int j = j0 + t / K;
+        int i = 0;
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < M) {
+          const size_t e = ((size_t)b * M + j) * K + (t - (t / K) * K);
+          i = a.idx[e];
+          r = a.slotrec[e];  // {rel, mask}
+        }
+        sidx[t] = i;
+        for (int p = 0; p < kMaxKP; ++p)
+          hbuf[(size_t)t * kMaxKP + p] =
+              (j < M && p < a.pint) ? kp_influence(r.x, r.y, r.z, a.p0 + p * 3, a.pfloat, a.constant_influence) * r.w : 0.f;
+      }
+      __syncthreads();
+      const int jq = wave * QW + g;
+      const int j = j0 + jq;
+      if (!chan_on || j >= M) continue;
+      const float *frow = a.ft + (size_t)b * N * C;
+      float wf[kMaxKP][V];
+#pragma unroll
+      for (int p = 0; p < kMaxKP; ++p)
+#pragma unroll
+        for (int v = 0; v < V; ++v) wf[p][v] = 0.f;
+#pragma unroll 2
+      for (int k = 0; k < K; ++k) {
+        const Vec<V> f = load_row<V>(frow + (size_t)sidx[jq * K + k] * C + c0);
+        const float4 *h4 = reinterpret_cast<const float4 *>(hbuf + (size_t)(jq * K + k) * kMaxKP);
+#pragma unroll
+        for (int p4 = 0; p4 < kMaxKP / 4; ++p4) {
+          const float4 h = h4[p4];
+#pragma unroll
+          for (int v = 0; v < V; ++v) {
+            wf[p4 * 4 + 0][v] = __builtin_fmaf(h.x, f.v[v], wf[p4 * 4 + 0][v]);
+            wf[p4 * 4 + 1][v] = __builtin_fmaf(h.y, f.v[v], wf[p4 * 4 + 1][v]);
+            wf[p4 * 4 + 2][v] = __builtin_fmaf(h.z, f.v[v], wf[p4 * 4 + 2][v]);
+            wf[p4 * 4 + 3][v] = __builtin_fmaf(h.w, f.v[v], wf[p4 * 4 + 3][v]);
+          }
+        }
+      }
+      const Vec<V> go = load_row<V>(a.gout_t + ((size_t)b * M + j) * C + c0);
+#pragma unroll
+      for (int p = 0; p < kMaxKP; ++p)
+#pragma unroll
+        for (int v = 0; v < V; ++v) pacc[p][v] = __builtin_fmaf(wf[p][v], go.v[v], pacc[p][v]);
+    }
+    // fixed-order block reduction, eight kernel points at a time (keeps the LDS slices at 32 KiB)
+    const int LV = L * V;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int slice = LV * 8;
+      __syncthreads();
+      if (lane_on) {
+        float *mine = red + (size_t)(wave * QW + g) * slice + cl * V * 8;
+#pragma unroll
+        for (int v = 0; v < V; ++v)
+#pragma unroll
+          for (int p = 0; p < 8; ++p) mine[v * 8 + p] = chan_on ? pacc[half * 8 + p][v] : 0.f;
+      }
+      __syncthreads();
+      for (int t = threadIdx.x; t < slice; t += 256) {
+        float sum = 0.f;
+        for (int sl = 0; sl < 4 * QW; ++sl) sum += red[(size_t)sl * slice + t];
+        const int c = ch * LV + t / 8;
+        if (c < C) a.dparam[((size_t)blockIdx.x * C + c) * kMaxKP + half * 8 + (t & 7)] = sum;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -469,7 +578,7 @@ extern "C" int cl3d_fused_reduce_fwd(int op, const float *query_xyz, const float
 }
 
 extern "C" int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *ft,
-                                     const float *slotrec, const int32_t *inv_off,
+                                     const float *slotrec, const int32_t *idx, const int32_t *inv_off,
                                      const int32_t *inv_slots, int B, int N, int M, int K, int C,
                                      const float *p0, const float *p1, int pint, float pfloat,
                                      int constant_influence, float *dft, float *dparam,
@@ -477,7 +586,7 @@ extern "C" int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *f
   using namespace cl3d;
   ReduceArgs a{};
   a.gout_t = gout_t; a.ft = ft; a.slotrec = reinterpret_cast<float4 *>(const_cast<float *>(slotrec));
-  a.inv_off = inv_off; a.inv_slots = inv_slots; a.p0 = p0; a.p1 = p1; a.dft = dft; a.dparam = dparam;
+  a.idx = idx; a.inv_off = inv_off; a.inv_slots = inv_slots; a.p0 = p0; a.p1 = p1; a.dft = dft; a.dparam = dparam;
   a.B = B; a.N = N; a.M = M; a.K = K; a.C = C; a.pint = pint; a.pfloat = pfloat; a.constant_influence = constant_influence;
   int rc = check_common(a, "fused_reduce_bwd");
   if (rc != CL3D_OK) return rc;
@@ -492,13 +601,26 @@ extern "C" int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *f
   const int V = (C % 4 == 0) ? 4 : 1;
   LaneMap m = pick_lane_map(C, V);
   // PseudoGrid carries 2*kMaxKP*V accumulators per lane: two waves per block keep the LDS slice at 32 KiB
-  const int waves = op == OP_PSEUDOGRID ? 2 : 4;
-  const int NP = op == OP_ADAPTIVE ? 4 : (op == OP_PSEUDOGRID ? kMaxKP : 0);
+  const int waves = 4;
+  const int NP = op == OP_ADAPTIVE ? 4 : 0;  // PseudoGrid's parameter gradient has its own kernel below
   const size_t lds = (size_t)waves * m.QW * m.L * V * NP * sizeof(float);
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)B * ceil_div(N, waves * m.QW);
   const int gx = has_params ? n_partials : round_grid(tiles, 4096);
   if (V == 4) launch_bwd<4>(op, a, dim3(gx), dim3(64 * waves), lds, (hipStream_t)stream);
   else launch_bwd<1>(op, a, dim3(gx), dim3(64 * waves), lds, (hipStream_t)stream);
-  return check_launch("cl3d_fused_reduce_bwd");
+  rc = check_launch("cl3d_fused_reduce_bwd");
+  if (rc != CL3D_OK || op != OP_PSEUDOGRID) return rc;
+  // d kernel_weights: query-major pass (the forward loop with the output gradient folded in)
+  CL3D_REQUIRE(idx, "fused_reduce_bwd: PseudoGrid needs idx");
+  size_t lds_fwd = 0;
+  const LaneMap mf = fwd_lane_map(op, C, K, V, &lds_fwd);
+  a.L = mf.L; a.QW = mf.QW; a.chunks = mf.chunks;
+  const size_t tile = 4 * (size_t)mf.QW * K * (sizeof(int) + kMaxKP * sizeof(float));
+  const size_t red = 4 * (size_t)mf.QW * mf.L * V * 8 * sizeof(float);
+  const size_t lds_dkw = tile > red ? tile : red;
+  if (lds_dkw > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "fused_reduce_bwd: nsample=%d needs %zu B of LDS", K, lds_dkw);
+  if (V == 4) hipLaunchKernelGGL((pg_dkw_kernel<4>), dim3(n_partials), dim3(256), lds_dkw, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((pg_dkw_kernel<1>), dim3(n_partials), dim3(256), lds_dkw, (hipStream_t)stream, a);
+  return check_launch("cl3d_fused_reduce_bwd(dkw)");
 }

@@ -102,7 +102,7 @@ class _FusedReduce(Function):
         npar = {OP_ADAPTIVE: 4, OP_PSEUDOGRID: 16}.get(op, 0)
         dparam = torch.empty((nparts, C, npar), dtype=torch.float32, device=gout.device) if nparts else None
         with torch.cuda.device(gout.device):
-            _lib.check(lib.cl3d_fused_reduce_bwd(op, _p(gout_t), _p(ft), _p(slotrec), _p(off), _p(slots), B, N, M, K,
+            _lib.check(lib.cl3d_fused_reduce_bwd(op, _p(gout_t), _p(ft), _p(slotrec), _p(ctx.idx), _p(off), _p(slots), B, N, M, K,
                                                  C, _p(p0), _p(p1), pint, float(pfloat), int(constant), _p(dft),
                                                  _p(dparam), nparts, _stream(gout)))
         g0 = g1 = None

@@ -133,7 +133,8 @@ int cl3d_fused_reduce_fwd(int op, const float *query_xyz, const float *support_x
  * dW[:,0..2], dbias; 16 pseudo grid: d kernel_weights[p]); 0 for operators without parameters. */
 int cl3d_fused_param_partials(int op, int B, int N, int C);
 int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *ft, const float *slotrec,
-                          const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K,
+                          const int32_t *idx, const int32_t *inv_off, const int32_t *inv_slots, int B, int N,
+                          int M, int K,
                           int C, const float *p0, const float *p1, int pint, float pfloat,
                           int constant_influence, float *dft, float *dparam, int n_partials,
                           cl3d_stream_t stream);
