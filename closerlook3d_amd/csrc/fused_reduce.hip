@@ -35,7 +35,7 @@ struct ReduceArgs {
   int B, N, M, K, C;
   int L, QW, chunks;
   int reduction, normalize, pint;  // pint: S (adaptive) / P (pseudo grid)
-  int constant_influence;
+  int constant_influence, out_channel_major;
   float inv_radius, pfloat;        // pfloat: 1/extent (pseudo grid)
 };
 
@@ -222,7 +222,12 @@ __global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
 #pragma unroll
       for (int v = 0; v < V; ++v) out.v[v] = a.reduction == RED_AVG ? acc[v] / n : acc[v];
     }
-    store_row<V>(a.out_t + ((size_t)b * M + j) * C + c0, out);  // V==4 => C%4==0: always a full vector
+    if (a.out_channel_major) {  // the API layout [B,C,M], written directly instead of a transpose pass
+#pragma unroll
+      for (int v = 0; v < V; ++v) a.out_t[((size_t)b * C + c0 + v) * M + j] = out.v[v];
+    } else {
+      store_row<V>(a.out_t + ((size_t)b * M + j) * C + c0, out);  // V==4 => C%4==0: always a full vector
+    }
   }
 }
 
@@ -549,12 +554,13 @@ extern "C" int cl3d_fused_reduce_fwd(int op, const float *query_xyz, const float
                                      const int32_t *idx_mask, const float *ft, int B, int N, int M,
                                      int K, int C, float radius, int normalize_xyz, int reduction,
                                      const float *p0, const float *p1, int pint, float pfloat,
-                                     int constant_influence, float *out_t, float *slotrec,
-                                     cl3d_stream_t stream) {
+                                     int constant_influence, float *out, int out_channel_major,
+                                     float *slotrec, cl3d_stream_t stream) {
   using namespace cl3d;
   ReduceArgs a{};
   a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.query_mask = query_mask; a.idx = idx; a.idx_mask = idx_mask;
-  a.ft = ft; a.p0 = p0; a.p1 = p1; a.out_t = out_t; a.slotrec = reinterpret_cast<float4 *>(slotrec);
+  a.ft = ft; a.p0 = p0; a.p1 = p1; a.out_t = out; a.out_channel_major = out_channel_major;
+  a.slotrec = reinterpret_cast<float4 *>(slotrec);
   a.B = B; a.N = N; a.M = M; a.K = K; a.C = C;
   a.reduction = reduction; a.normalize = normalize_xyz; a.pint = pint; a.constant_influence = constant_influence;
   a.inv_radius = 1.0f / radius; a.pfloat = pfloat;
@@ -564,7 +570,7 @@ extern "C" int cl3d_fused_reduce_fwd(int op, const float *query_xyz, const float
   if (rc != CL3D_OK) return rc;
   CL3D_REQUIRE(reduction == RED_SUM || reduction == RED_AVG, "fused_reduce_fwd: reduction must be sum or avg");
   if (B == 0 || M == 0) return CL3D_OK;
-  CL3D_REQUIRE(query_xyz && support_xyz && query_mask && idx && idx_mask && ft && out_t, "fused_reduce_fwd: null pointer");
+  CL3D_REQUIRE(query_xyz && support_xyz && query_mask && idx && idx_mask && ft && out, "fused_reduce_fwd: null pointer");
   CL3D_REQUIRE(op == OP_POSPOOL_XYZ || p0, "fused_reduce_fwd: missing operator parameters");
   const int V = (C % 4 == 0) ? 4 : 1;
   size_t lds = 0;

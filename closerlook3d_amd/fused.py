@@ -78,17 +78,17 @@ class _FusedReduce(Function):
         B, C, N = features.shape
         _, M, K = idx.shape
         ft = features.transpose(1, 2).contiguous()
-        out_t = torch.empty((B, M, C), dtype=torch.float32, device=features.device)
+        out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)  # channel-major, written by the kernel
         slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=features.device) if need_grad else None
         with torch.cuda.device(features.device):
             _lib.check(_lib.lib().cl3d_fused_reduce_fwd(
                 op, _p(query_xyz), _p(support_xyz), _p(query_mask), _p(idx), _p(idx_mask), _p(ft), B, N, M, K, C,
                 float(radius), int(normalize), reduction, _p(p0), _p(p1), pint, float(pfloat), int(constant),
-                _p(out_t), _p(slotrec), _stream(features)))
+                _p(out), 1, _p(slotrec), _stream(features)))
         ctx.save_for_backward(ft, slotrec, p0, p1)
         ctx.idx = idx
         ctx.meta = (op, B, N, M, K, C, pint, pfloat, constant)
-        return out_t.transpose(1, 2).contiguous()
+        return out
 
     @staticmethod
     def backward(ctx, gout):
