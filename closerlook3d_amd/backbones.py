@@ -1,7 +1,7 @@
 """Residual backbone and segmentation decode that call the hot path.
 
-`ResNet` / `Bottleneck` follow `pytorch/models/backbones/resnet.py:22-188` and `SceneSegHeadResNet`
-follows `pytorch/models/heads/segmentation_head.py:15-77`: same constructor arguments, same
+`ResNet` / `Bottleneck` follow `pytorch/models/backbones/resnet.py:22-188`; `SceneSegHeadResNet` and
+`MultiPartSegHeadResNet` follow `pytorch/models/heads/segmentation_head.py:15-149`: same constructor arguments, same
 sub-module names (so reference checkpoints load), same `end_points` dictionary.  They exist here so
 the integration tests and the backbone benchmark can run on the GPU box, where the reference tree is
 absent; the reference's own files run unchanged on this engine through `drop_in/`.
@@ -92,10 +92,11 @@ class ResNet(nn.Module):
         return end_points
 
 
-class SceneSegHeadResNet(nn.Module):
-    def __init__(self, num_classes, width, base_radius, nsamples):
-        super().__init__()
-        self.num_classes, self.base_radius, self.nsamples = num_classes, base_radius, nsamples
+class _UpsampleDecoder(nn.Module):
+    """Nearest-neighbour up-sampling decode shared by the two segmentation heads
+    (reference heads/segmentation_head.py:32-48,55-73 and :99-115,125-143)."""
+
+    def _make_decoder(self, width, base_radius, nsamples):
         for lvl in range(4):
             setattr(self, f"up{lvl}", MaskedUpsample(radius=(8 >> lvl) * base_radius, nsample=nsamples[3 - lvl],
                                                      mode='nearest'))
@@ -104,15 +105,45 @@ class SceneSegHeadResNet(nn.Module):
         self.up_conv1 = _conv_bn(8 * width, 2 * width, bn, relu=True)
         self.up_conv2 = _conv_bn(4 * width, width, bn, relu=True)
         self.up_conv3 = _conv_bn(2 * width, width // 2, bn, relu=True)
-        self.head = nn.Sequential(nn.Conv1d(width // 2, width // 2, kernel_size=1, bias=False),
-                                  nn.BatchNorm1d(width // 2), nn.ReLU(inplace=True),
-                                  nn.Conv1d(width // 2, num_classes, kernel_size=1, bias=True))
 
-    def forward(self, end_points):
+    def _decode(self, end_points):
         feats = end_points['res5_features']
         for lvl, (fine, coarse) in enumerate(((4, 5), (3, 4), (2, 3), (1, 2))):
             feats = getattr(self, f"up{lvl}")(end_points[f'res{fine}_xyz'], end_points[f'res{coarse}_xyz'],
                                               end_points[f'res{fine}_mask'], end_points[f'res{coarse}_mask'], feats)
             feats = torch.cat([feats, end_points[f'res{fine}_features']], 1)
             feats = getattr(self, f"up_conv{lvl}")(feats)
-        return self.head(feats)
+        return feats
+
+
+def _seg_classifier(width, nout):
+    return nn.Sequential(nn.Conv1d(width // 2, width // 2, kernel_size=1, bias=False),
+                         nn.BatchNorm1d(width // 2), nn.ReLU(inplace=True),
+                         nn.Conv1d(width // 2, nout, kernel_size=1, bias=True))
+
+
+class SceneSegHeadResNet(_UpsampleDecoder):
+    """logits (B, num_classes, N).  Reference: heads/segmentation_head.py:15-77."""
+
+    def __init__(self, num_classes, width, base_radius, nsamples):
+        super().__init__()
+        self.num_classes, self.base_radius, self.nsamples = num_classes, base_radius, nsamples
+        self._make_decoder(width, base_radius, nsamples)
+        self.head = _seg_classifier(width, num_classes)
+
+    def forward(self, end_points):
+        return self.head(self._decode(end_points))
+
+
+class MultiPartSegHeadResNet(_UpsampleDecoder):
+    """One part-logit tensor per shape category: [(B, num_parts[i], N)].  Reference: :80-149."""
+
+    def __init__(self, num_classes, width, base_radius, nsamples, num_parts):
+        super().__init__()
+        self.num_classes, self.base_radius, self.nsamples, self.num_parts = num_classes, base_radius, nsamples, num_parts
+        self._make_decoder(width, base_radius, nsamples)
+        self.multi_shape_heads = nn.ModuleList(_seg_classifier(width, num_parts[i]) for i in range(num_classes))
+
+    def forward(self, end_points):
+        feats = self._decode(end_points)
+        return [head(feats) for head in self.multi_shape_heads]

@@ -215,5 +215,13 @@ def main():
         print("resnet", kind, rec["out"].shape, float(np.abs(rec["out"]).mean()))
 
 
+    # parameter/buffer names and shapes of the remaining caller (no forward needed): checkpoint compatibility
+    from models.heads.segmentation_head import MultiPartSegHeadResNet
+    import json
+    mp = MultiPartSegHeadResNet(3, 12, 0.1, [16] * 5, [4, 2, 6])
+    with open(os.path.join(OUT, "state_dict_multipart_head.json"), "w") as fh:
+        json.dump({k: list(v.shape) for k, v in mp.state_dict().items()}, fh, indent=0)
+
+
 if __name__ == "__main__":
     main()

@@ -62,3 +62,12 @@ def test_oracle_native_matches_reference_kernels(path):
     assert np.array_equal(g.view(np.uint32), z["grouped"].view(np.uint32))
     gg = on.group_points_grad(z["grad_out"], z["bq_idx"], s.shape[1])
     assert_close(gg, z["grad_points"], 1e-5, "group_points_grad")
+
+
+def test_multipart_head_state_dict_matches_reference():
+    """Checkpoint compatibility of the one caller without a forward fixture: same names, same shapes."""
+    import json
+    from closerlook3d_amd.backbones import MultiPartSegHeadResNet
+    want = json.load(open(os.path.join(GOLDEN, "state_dict_multipart_head.json")))
+    got = {k: list(v.shape) for k, v in MultiPartSegHeadResNet(3, 12, 0.1, [16] * 5, [4, 2, 6]).state_dict().items()}
+    assert got == want
