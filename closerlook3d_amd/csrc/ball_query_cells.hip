@@ -57,7 +57,6 @@ struct BqTask {
 struct BqWorkspace {
   BqGrid *grid;        // [B]
   float4 *sorted;      // [B,N]
-  int *cell_start;     // [B,kMaxCells+1]
   float4 *qsorted;     // [B,M] queries grouped by cell: {x,y,z, original query index}
   BqTask *tasks;       // [B, M/QW + kMaxCells + 1]
   int *overflow;       // [B,M]
@@ -69,7 +68,7 @@ __host__ __device__ inline size_t bq_align(size_t x) { return (x + 255) & ~(size
 inline size_t bq_workspace_bytes(int B, int N, int M) {
   const size_t max_tasks = (size_t)(M + kBqQW - 1) / kBqQW + kMaxCells + 1;
   return bq_align(sizeof(BqGrid) * B) + bq_align(sizeof(float4) * (size_t)B * N) +
-         bq_align(sizeof(int) * (size_t)B * (kMaxCells + 1)) + bq_align(sizeof(float4) * (size_t)B * M) +
+         bq_align(sizeof(float4) * (size_t)B * M) +
          bq_align(sizeof(BqTask) * (size_t)B * max_tasks) + bq_align(sizeof(int) * (size_t)B * M);
 }
 
@@ -79,7 +78,6 @@ inline BqWorkspace bq_carve(void *ws, int B, int N, int M) {
   w.max_tasks = (M + kBqQW - 1) / kBqQW + kMaxCells + 1;
   w.grid = reinterpret_cast<BqGrid *>(p); p += bq_align(sizeof(BqGrid) * B);
   w.sorted = reinterpret_cast<float4 *>(p); p += bq_align(sizeof(float4) * (size_t)B * N);
-  w.cell_start = reinterpret_cast<int *>(p); p += bq_align(sizeof(int) * (size_t)B * (kMaxCells + 1));
   w.qsorted = reinterpret_cast<float4 *>(p); p += bq_align(sizeof(float4) * (size_t)B * M);
   w.tasks = reinterpret_cast<BqTask *>(p); p += bq_align(sizeof(BqTask) * (size_t)B * w.max_tasks);
   w.overflow = reinterpret_cast<int *>(p);
@@ -88,12 +86,16 @@ inline BqWorkspace bq_carve(void *ws, int B, int N, int M) {
 
 __device__ __forceinline__ int cell_coord(float x, float o, float inv_h) { return (int)floorf((x - o) * inv_h); }
 
-// prep: one 1024-thread workgroup per cloud.  The work is tiny (tens of KB) and entirely latency: every
-// __syncthreads-separated phase costs a global round trip, so the phases are merged as far as the data
-// dependences allow -- (1) one sweep over the support cloud gives the number of leading valid points and
-// the bounding box; (2) support AND query histograms over the cells, side by side in LDS; (3) both
-// exclusive scans share their barriers (the third column scanned is "tasks per cell"); (4) cell starts,
-// the task table (with each cell's candidate runs) and both scatters.
+// prep: gridDim.x 1024-thread workgroups per cloud.  The work is tiny (tens of KB) and entirely latency:
+// every __syncthreads-separated phase costs a global round trip, so the phases are merged as far as the
+// data dependences allow -- (1) one sweep over the support cloud gives the number of leading valid points
+// and the bounding box; (2) support AND query histograms over the cells, side by side in LDS; (3) both
+// exclusive scans share their barriers (the third column scanned is "tasks per cell"); (4) the task table
+// (with each cell's candidate runs) and both scatters.
+// Phases (1)-(3) are cheap and every workgroup of a cloud repeats them (same inputs, same arithmetic, so
+// all of them hold the same grid and the same cell starts in LDS -- no inter-block communication); the
+// expensive phase (4) is split: workgroup r owns the contiguous cell range that holds the r-th share of
+// the points (resp. queries) and writes only those cells' records and tasks.
 __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__ query_xyz,
                                                        const float *__restrict__ support_xyz,
                                                        const int *__restrict__ support_mask, int M, int N,
@@ -102,8 +104,10 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
   __shared__ float s_red[6][16];
   __shared__ int s_wave[3][16];
   __shared__ int s_nv;
+  __shared__ int s_share[2][2];  // [support|query][first cell, end cell) owned by this workgroup
   int *s_sup = lds_cells, *s_qry = lds_cells + kMaxCells;
-  const int b = blockIdx.x;
+  const int b = blockIdx.y;
+  const int part = blockIdx.x, nparts = gridDim.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float *s = support_xyz + (size_t)b * N * 3;
   const float *q = query_xyz + (size_t)b * M * 3;
@@ -269,16 +273,37 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
   }
   __syncthreads();
 
-  // ---- (4) cell starts, task table, scatters
-  int *cs = w.cell_start + (size_t)b * (kMaxCells + 1);
-  for (int c = tid; c < ncells; c += 1024) cs[c] = s_sup[c];
-  if (tid == 0) cs[ncells] = nv;
+  // ---- (4) task table and scatters of this workgroup's share of the cells
+  if (tid < 4) {  // first cell whose start reaches the share boundary (starts are non-decreasing)
+    const int col = tid >> 1, end = tid & 1;
+    const int *starts = col == 0 ? s_sup : s_qry;
+    const long long tot = col == 0 ? nv : M;
+    const int pr = part + end;
+    int lo = 0, hi = ncells;
+    if (pr <= 0) hi = 0;
+    else if (pr >= nparts) lo = ncells;
+    else {
+      const int target = (int)(tot * pr / nparts);
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (starts[mid] >= target) hi = mid;
+        else lo = mid + 1;
+      }
+    }
+    s_share[col][end] = pr <= 0 ? 0 : lo;
+  }
+  __syncthreads();
+  const int sup_lo = s_share[0][0], sup_hi = s_share[0][1], qry_lo = s_share[1][0], qry_hi = s_share[1][1];
   auto start_of = [&](int c) { return c < ncells ? s_sup[c] : nv; };
   BqTask *tasks = w.tasks + (size_t)b * w.max_tasks;
   {
     int t = run[2];
     for (int i = 0; i < 8; ++i) {
       if (!(i < per && t0 + i < ncells) || nq_mine[i] == 0) continue;
+      if (t0 + i < qry_lo || t0 + i >= qry_hi) {
+        t += (nq_mine[i] + kBqQW - 1) / kBqQW;
+        continue;
+      }
       // candidate window of this cell (queries that were clamped into the grid get a superset of what
       // their true position needs: outside the grid only the boundary cells can be within reach)
       BqTask tk;
@@ -315,7 +340,7 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
   __syncthreads();  // every reader of the start values is done: the arrays become scatter cursors
   float4 *sorted = w.sorted + (size_t)b * N;
   float4 *qsorted = w.qsorted + (size_t)b * M;
-  auto scatter = [&](const float *pts, int n, int *cursor, float4 *dst) {  // order inside a cell is irrelevant
+  auto scatter = [&](const float *pts, int n, int *cursor, float4 *dst, int c_lo, int c_hi) {  // order inside a cell is irrelevant
     for (int base = 0; base < n; base += 1024 * kPrepU) {
       float px[kPrepU], py[kPrepU], pz[kPrepU];
       int pos[kPrepU];
@@ -329,20 +354,44 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
       }
 #pragma unroll
       for (int u = 0; u < kPrepU; ++u)  // all cursor atomics of the batch first, then all stores
-        pos[u] = base + u * 1024 + tid < n ? atomicAdd(&cursor[cell_of(px[u], py[u], pz[u])], 1) : -1;
+      {
+        const int cell = cell_of(px[u], py[u], pz[u]);
+        pos[u] = (base + u * 1024 + tid < n && cell >= c_lo && cell < c_hi) ? atomicAdd(&cursor[cell], 1) : -1;
+      }
 #pragma unroll
       for (int u = 0; u < kPrepU; ++u)
         if (pos[u] >= 0) dst[pos[u]] = make_float4(px[u], py[u], pz[u], __int_as_float(base + u * 1024 + tid));
     }
   };
-  scatter(s, nv, s_sup, sorted);
-  scatter(q, M, s_qry, qsorted);
-  if (tid == 0) {
+  scatter(s, nv, s_sup, sorted, sup_lo, sup_hi);
+  scatter(q, M, s_qry, qsorted, qry_lo, qry_hi);
+  if (tid == 0 && part == 0) {
     BqGrid g;
     g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_h = inv_h;
     g.nx = nx; g.ny = ny; g.nz = nz; g.ncells = ncells;
     g.ntasks = total[2]; g.nv = nv; g.pad0 = g.pad1 = 0;
     w.grid[b] = g;
+  }
+}
+
+// LDS strides of the per-query lists, rounded so every list starts 16-byte aligned (ds_read_b128 in the ranking)
+__host__ __device__ inline int bq_pad4(int x) { return (x + 3) & ~3; }
+__host__ __device__ inline int bq_lds_ints_per_wave(int K) {
+  return kBqQW * (2 * bq_pad4(kCapMul * K) + 2 * bq_pad4(3 * K) + bq_pad4(K + 1));
+}
+
+// rank of every list element by (distance, original index), exact for any list: 64-bit keys from LDS
+__device__ __forceinline__ void bq_rank_exact(const float *ld, const int *li, int c, int K, int *so, int lane) {
+  for (int e = lane; e < c; e += CL3D_WAVE) {
+    const float de = ld[e];
+    const int ie = li[e];
+    int rank = 0;
+#pragma unroll 8
+    for (int f = 0; f < c; ++f) {
+      const float df = ld[f];
+      rank += (df < de || (df == de && li[f] < ie)) ? 1 : 0;
+    }
+    if (rank <= K) so[rank] = ie;
   }
 }
 
@@ -353,17 +402,17 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
   extern __shared__ int smem[];
   const int cap3 = 3 * K;
   const int cap = kCapMul * K;
+  const int capS = bq_pad4(cap), cap3S = bq_pad4(cap3), outS = bq_pad4(K + 1);
   const int b = blockIdx.y;
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // LDS carve per wave: cand_d[QW][cap], cand_i[QW][cap], sel_d[QW][cap3], sel_i[QW][cap3], out_i[QW][K]
-  const int per_wave = kBqQW * (2 * cap + 2 * cap3 + K);
-  int *base = smem + (size_t)wave * per_wave;
+  // LDS carve per wave: cand_d[QW][capS], cand_i[QW][capS], sel_d[QW][cap3S], sel_i[QW][cap3S], out_i[QW][outS]
+  int *base = smem + (size_t)wave * bq_lds_ints_per_wave(K);
   float *cand_d = reinterpret_cast<float *>(base);
-  int *cand_i = base + kBqQW * cap;
-  float *sel_d = reinterpret_cast<float *>(base + 2 * kBqQW * cap);
-  int *sel_i = base + 2 * kBqQW * cap + kBqQW * cap3;
-  int *out_i = base + 2 * kBqQW * cap + 2 * kBqQW * cap3;
+  int *cand_i = base + kBqQW * capS;
+  float *sel_d = reinterpret_cast<float *>(base + 2 * kBqQW * capS);
+  int *sel_i = base + 2 * kBqQW * capS + kBqQW * cap3S;
+  int *out_i = base + 2 * kBqQW * capS + 2 * kBqQW * cap3S;
 
   const int ntasks = w.grid[b].ntasks;
   const int *qm = query_mask + (size_t)b * M;
@@ -376,17 +425,16 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
     const BqTask tk = tasks[t];
     const int n = tk.n;
     int jq[kBqQW];
-    float qx[kBqQW], qy[kBqQW], qz[kBqQW], lmin[kBqQW];
-    int lidx[kBqQW], cnt[kBqQW];
+    float qx[kBqQW], qy[kBqQW], qz[kBqQW];
+    int cnt[kBqQW];
 #pragma unroll
     for (int u = 0; u < kBqQW; ++u) {
       const float4 qq = qsorted[tk.q0 + (u < n ? u : 0)];
       jq[u] = __float_as_int(qq.w);
-      qx[u] = qq.x;
+      // an unused query slot of the task gets a NaN coordinate: its distances are NaN and never "in radius"
+      qx[u] = u < n ? qq.x : __builtin_nanf("");
       qy[u] = qq.y;
       qz[u] = qq.z;
-      lmin[u] = radius2;
-      lidx[u] = 0;
       cnt[u] = 0;
     }
     const int T = tk.total;
@@ -396,40 +444,39 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
       run_pe[r] = tk.run_pe[r];
       run_delta[r] = tk.run_delta[r];
     }
+    // ---- candidates: every in-radius (distance, original index) pair of the window goes to the LDS list.
+    // Lists are unordered (the ranking below restates the reference's order-dependent rule), so a batch of
+    // 64 candidates costs one ballot + prefix count per query and nothing else.
     for (int p0 = 0; p0 < T; p0 += CL3D_WAVE * kBqBatch) {
       float4 sp[kBqBatch];
-      bool ok[kBqBatch];
 #pragma unroll
       for (int v = 0; v < kBqBatch; ++v) {
-        const int p = p0 + v * CL3D_WAVE + lane;
-        ok[v] = p < T;
+        if (p0 + v * CL3D_WAVE >= T) break;  // uniform
+        int p = p0 + v * CL3D_WAVE + lane;
+        p = p < T ? p : T - 1;
         int delta = run_delta[0];
 #pragma unroll
         for (int r = 1; r < 9; ++r) delta = p >= run_pe[r] ? run_delta[r] : delta;
-        sp[v] = sorted[ok[v] ? p + delta : 0];
+        sp[v] = sorted[p + delta];
       }
 #pragma unroll
       for (int v = 0; v < kBqBatch; ++v) {
+        if (p0 + v * CL3D_WAVE >= T) break;  // uniform
+        const bool live = p0 + v * CL3D_WAVE + lane < T;
         const int orig = __float_as_int(sp[v].w);
 #pragma unroll
         for (int u = 0; u < kBqQW; ++u) {
           const float d2 = dist2(qx[u], qy[u], qz[u], sp[v].x, sp[v].y, sp[v].z);
-          const bool hit = ok[v] && u < n && (d2 < radius2);
+          const bool hit = live && (d2 < radius2);
           const unsigned long long m = __ballot(hit);
-          if (m != 0ull) {
-            // first-occurrence strict minimum == smallest (d2, original index)
-            if (hit && (d2 < lmin[u] || (d2 == lmin[u] && orig < lidx[u]))) {
-              lmin[u] = d2;
-              lidx[u] = orig;
-            }
-            const int c = cnt[u];
-            const int pos = c + prefix_popc(m);
-            if (hit && pos < cap) {
-              cand_d[u * cap + pos] = d2;
-              cand_i[u * cap + pos] = orig;
-            }
-            cnt[u] = c + (int)__popcll(m);
+          const int c0 = cnt[u];
+          const int c1 = c0 + (int)__popcll(m);  // wave-uniform
+          if (c1 <= cap && hit) {  // a list that would overflow is abandoned: that query is redone exhaustively
+            const int pos = c0 + prefix_popc(m);
+            cand_d[u * capS + pos] = d2;
+            cand_i[u * capS + pos] = orig;
           }
+          cnt[u] = c1;
         }
       }
     }
@@ -449,16 +496,21 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
         continue;
       }
       if (lane == 0) oflow[j] = 0;
-      float *ld = cand_d + u * cap;
-      int *li = cand_i + u * cap;
+      float *ld = cand_d + u * capS;
+      int *li = cand_i + u * capS;
       int c = S;
       if (S > cap3) {
-        // the 3K smallest original indices, written in index order
-        unsigned long long key = ((unsigned long long)__float_as_uint(lmin[u]) << 32) | (unsigned)lidx[u];
+        // first-occurrence strict minimum == smallest (d2, original index) of S
+        unsigned long long key = ~0ull;
+        for (int e = lane; e < S; e += CL3D_WAVE) {
+          const unsigned long long ke = ((unsigned long long)__float_as_uint(ld[e]) << 32) | (unsigned)li[e];
+          key = ke < key ? ke : key;
+        }
         key = wave_min_u64(key);
         const int gidx = (int)(unsigned)(key & 0xffffffffull);
-        float *sd = sel_d + u * cap3;
-        int *si = sel_i + u * cap3;
+        // the 3K smallest original indices, written in index order
+        float *sd = sel_d + u * cap3S;
+        int *si = sel_i + u * cap3S;
         for (int e = lane; e < S; e += CL3D_WAVE) {
           const int ie = li[e];
           int r = 0;
@@ -483,38 +535,42 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
         li = si;
         c = cap3;
       }
-      // rank by (distance, original index) == stable sort by distance of the index-ordered list.
-      // d2 >= 0, so its bit pattern orders like the value and (d2 bits << 32 | index) is one 64-bit key.
-      int *so = out_i + u * K;
-      if (c <= CL3D_WAVE) {
-        // one element per lane; every key is broadcast through SGPRs (v_readlane) and compared as u64:
-        // 4 instructions per pair, no LDS traffic
-        const bool on = lane < c;
-        const unsigned long long mykey =
-            on ? (((unsigned long long)__float_as_uint(ld[lane]) << 32) | (unsigned)li[lane]) : ~0ull;
-        const unsigned klo = (unsigned)mykey, khi = (unsigned)(mykey >> 32);
+      // ---- rank by (distance, original index) == stable sort by distance of the index-ordered list.
+      // Fast path: rank by the distance alone (d2 >= 0, so its bit pattern orders like the value): keys are
+      // broadcast four at a time from LDS, 2 VALU instructions per comparison.  Equal distances give equal
+      // ranks and leave a hole in ranks [0, min(c, K+1)); a hole is detected below and the exact 64-bit
+      // ranking redoes the (rare) list.
+      int *so = out_i + u * outS;
+      const int need = c < K + 1 ? c : K + 1;
+      for (int i = lane; i < need; i += CL3D_WAVE) so[i] = -1;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const unsigned *lb = reinterpret_cast<const unsigned *>(ld);
+      const int c4 = c & ~3;
+      for (int e0 = 0; e0 < c; e0 += CL3D_WAVE) {
+        const int e = e0 + lane;
+        const bool on = e < c;
+        const unsigned my = on ? lb[e] : 0u;
         int rank = 0;
-        for (int f = 0; f < c; ++f) {
-          const unsigned long long kf = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)khi, f) << 32) |
-                                        (unsigned)__builtin_amdgcn_readlane((int)klo, f);
-          rank += kf < mykey ? 1 : 0;
+        for (int f = 0; f < c4; f += 4) {
+          const uint4 k4 = *reinterpret_cast<const uint4 *>(lb + f);
+          rank += k4.x < my ? 1 : 0;
+          rank += k4.y < my ? 1 : 0;
+          rank += k4.z < my ? 1 : 0;
+          rank += k4.w < my ? 1 : 0;
         }
-        if (on && rank < K) so[rank] = (int)klo;
-      } else {
-        for (int e = lane; e < c; e += CL3D_WAVE) {
-          const float de = ld[e];
-          const int ie = li[e];
-          int rank = 0;
-#pragma unroll 8
-          for (int f = 0; f < c; ++f) {
-            const float df = ld[f];
-            rank += (df < de || (df == de && li[f] < ie)) ? 1 : 0;
-          }
-          if (rank < K) so[rank] = ie;
-        }
+        for (int f = c4; f < c; ++f) rank += lb[f] < my ? 1 : 0;
+        if (on && rank <= K) so[rank] = li[e];
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
+      bool hole = false;
+      for (int i = lane; i < need; i += CL3D_WAVE) hole = hole || so[i] < 0;
+      if (__ballot(hole) != 0ull) {  // uniform
+        bq_rank_exact(ld, li, c, K, so, lane);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+      }
       const int qmk = qm[j];
       for (int i = lane; i < K; i += CL3D_WAVE) {
         int v = 0, mk = 0;
@@ -538,7 +594,7 @@ namespace cl3d {
 size_t ball_query_cells_workspace(int B, int N, int M) { return bq_workspace_bytes(B, N, M); }
 
 bool ball_query_cells_applicable(int M, int N, int K) {
-  const size_t lds = (size_t)4 * kBqQW * (2 * kCapMul * K + 2 * 3 * K + K) * sizeof(int);
+  const size_t lds = (size_t)4 * bq_lds_ints_per_wave(K) * sizeof(int);
   return N >= 512 && M >= 64 && lds <= 64 * 1024;
 }
 
@@ -556,9 +612,12 @@ int ball_query_cells(const float *query_xyz, const float *support_xyz, const int
     if (e != hipSuccess) return fail(CL3D_E_LAUNCH, "ball_query: LDS opt-in: %s", hipGetErrorString(e));
     prep_attr = true;
   }
-  hipLaunchKernelGGL(bq_prep_kernel, dim3(B), dim3(1024), 2 * kMaxCells * sizeof(int), st, query_xyz, support_xyz,
+  // workgroups per cloud in the prep kernel: enough to split the scatter / task-table work without flooding the chip
+  int parts = 256 / (B > 0 ? B : 1);
+  parts = parts < 1 ? 1 : (parts > 8 ? 8 : parts);
+  hipLaunchKernelGGL(bq_prep_kernel, dim3(parts, B), dim3(1024), 2 * kMaxCells * sizeof(int), st, query_xyz, support_xyz,
                      support_mask, M, N, radius, w);
-  const size_t lds = (size_t)4 * kBqQW * (2 * kCapMul * K + 2 * 3 * K + K) * sizeof(int);
+  const size_t lds = (size_t)4 * bq_lds_ints_per_wave(K) * sizeof(int);
   int gx = ceil_div(ceil_div(M, kBqQW) + 64, 4);  // ~one task per wave at typical occupancy; persistent loop beyond
   gx = gx > 512 ? 512 : gx;
   hipLaunchKernelGGL(bq_query_kernel, dim3(gx, B), dim3(256), lds, st, query_xyz, query_mask, M, N, radius * radius, K, w, idx, idx_mask);
