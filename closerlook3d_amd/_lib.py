@@ -40,7 +40,7 @@ SIGNATURES = {
     "cl3d_pwmlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P],
     "cl3d_pwmlp_bwd_sparse": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P],
     "cl3d_pwmlp_bwd_query": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _I, _P],
-    "cl3d_pwmlp_bwd_support": [_P] * 14 + [_I] * 5 + [_P, _P],
+    "cl3d_pwmlp_bwd_support": [_P] * 12 + [_I] * 5 + [_P, _P],
 }
 
 

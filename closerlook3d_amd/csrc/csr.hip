@@ -1,21 +1,30 @@
-// csr.hip -- CSR inverse of a neighbour-index tensor: for every support point, the ascending list of
+// csr.hip -- CSR inverse of a neighbour-index tensor: for every support point, the list of
 // (query, neighbour-slot) positions that reference it.
 //
 // idx [B, MK] (MK = M*K flattened slots) with values in [0,N)  ->
 //   inv_off   [B, N+1]   segment starts (inv_off[b][N] = number of valid slots of cloud b)
-//   inv_slots [B, MK]    slot ids, ascending inside each segment (invalid indices sort to the tail)
+//   inv_slots [B, MK]    slot ids of each segment (slots with an index outside [0,N) are dropped)
 //
 // This is what turns every backward scatter of the fused operators into an ordered gather (no float
-// atomics, summation order fixed).  It depends on idx only, so one build serves the backward of every
-// operator that shares the ball query.
+// atomics, summation order fixed by the table).  It depends on idx only, so one build serves the backward
+// of every operator that shares the ball query.
 //
-// Build = one stable LSD radix sort of (key = cloud*(N+1) + idx, value = slot) pairs + a binary search
-// per row for the segment starts.  The sort is rocPRIM's device radix sort (a generic primitive, like
-// the library GEMM); stability gives ascending slot ids inside a segment, hence a deterministic order.
-// History (metric shape, 2.1 M slots, per build): global integer atomics + per-segment rank sort
-// 270 us; row-ownership scans (every wave streams the whole slot array for its 32-64 rows, from L2 or
-// through LDS, ordered or cursor-based fill) 230-350 us -- the work is O(MK * N/rows) compare
-// instructions however it is staged.  A radix sort is O(MK).
+// Build (N <= 32768) = a three-kernel counting sort with WAVE-PRIVATE counters:
+//   count  the slots of a cloud are cut into G contiguous ranges, one per wave; a wave histograms its range
+//          into its own N counters in LDS (integer LDS atomics: 8 lane-ops/clk/CU measured); the waves of
+//          a workgroup add their histograms in wave order -> table[b][workgroup][:]
+//   scan   one workgroup per cloud: row totals over the workgroups, exclusive scan over the support
+//          points (= inv_off); table[b][wg][i] becomes the first output position of wg inside row i
+//   fill   the same waves histogram the same ranges again, turn the counters into cursors (wave w of a
+//          workgroup starts after waves < w), and every slot takes the position a returning LDS atomic
+//          hands out
+// No counter is ever shared between waves, so the table is a pure function of idx (ranges are ordered by
+// g, a wave issues its batches in program order, and one LDS instruction resolves its lanes in hardware
+// order): the same input gives the same table on every run -- and the fused backward passes the same bits.
+// Larger N (counters do not fit LDS) use a stable LSD radix sort of (key = cloud*(N+1) + idx, value =
+// slot) pairs (rocPRIM, a generic primitive like the library GEMM) + a binary search per row.
+// History (metric shape, 2.1 M slots, per build): global integer atomics + per-segment rank sort 270 us;
+// row-ownership scans 230-350 us; radix sort 113 us; wave-private counting sort: see DESIGN.md.
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -53,6 +62,180 @@ __global__ __launch_bounds__(256) void csr_offsets_kernel(const unsigned *__rest
   }
 }
 
+// ---- counting sort with wave-private LDS counters -------------------------------------------------
+constexpr int kCsrBatch = 8;  // slot loads in flight per lane
+
+struct CsrPlan {
+  int wpb;    // waves per workgroup (each owns N ints of LDS)
+  int G;      // slot ranges (= waves) per cloud, a multiple of wpb
+  int per;    // slots per range, a multiple of 64
+  size_t lds;
+};
+
+static bool csr_plan(int B, int N, int MK, CsrPlan *p) {
+  const size_t row = (size_t)N * sizeof(int);
+  if (row > 128 * 1024 || MK <= 0 || B <= 0 || B > 65535) return false;
+  int wpb = (int)((64 * 1024) / row);
+  wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
+  int G = 2048 / B;
+  G = G < wpb ? wpb : (G > 64 ? 64 : G);
+  int per = (MK + G - 1) / G;
+  per = (per + 63) & ~63;
+  G = (MK + per - 1) / per;              // drop empty ranges
+  G = ((G + wpb - 1) / wpb) * wpb;       // whole workgroups (trailing ranges may be empty)
+  p->wpb = wpb; p->G = G; p->per = per; p->lds = (size_t)wpb * row;
+  return true;
+}
+
+// COUNT: per-wave histograms of the workgroup's slot ranges, merged (fixed wave order) into table[b][gb][:].
+// FILL:  the same histograms again, turned into per-wave cursors (table[b][gb][i] now holds the first output
+//        position of this workgroup inside row i; wave w starts after waves < w), then the scatter.
+template <bool FILL>
+__global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restrict__ idx, int N, int MK, int GB, int per,
+                                                             int *__restrict__ table, int *__restrict__ inv_slots) {
+  extern __shared__ int lds_cnt[];
+  const int lane = lane_id();
+  const int wpb = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int g = blockIdx.x * wpb + wave;
+  const int b = blockIdx.y;
+  int *h = lds_cnt + (size_t)wave * N;
+  int *row = table + ((size_t)b * GB + blockIdx.x) * N;
+  for (int i = lane; i < N; i += CL3D_WAVE) h[i] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int *src = idx + (size_t)b * MK;
+  const int s0 = g * per;
+  const int s1 = s0 + per < MK ? s0 + per : MK;
+  for (int s = s0; s < s1; s += CL3D_WAVE * kCsrBatch) {
+    int key[kCsrBatch];
+#pragma unroll
+    for (int u = 0; u < kCsrBatch; ++u) {
+      const int p = s + u * CL3D_WAVE + lane;
+      key[u] = src[p < s1 ? p : s1 - 1];
+    }
+#pragma unroll
+    for (int u = 0; u < kCsrBatch; ++u) {
+      const int p = s + u * CL3D_WAVE + lane;
+      if (p < s1 && (unsigned)key[u] < (unsigned)N) atomicAdd(&h[key[u]], 1);
+    }
+  }
+  __syncthreads();
+  if constexpr (!FILL) {
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      int tot = 0;
+      for (int w = 0; w < wpb; ++w) tot += lds_cnt[(size_t)w * N + i];
+      row[i] = tot;
+    }
+  } else {
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+      int run = row[i];
+      for (int w = 0; w < wpb; ++w) {
+        const int t = lds_cnt[(size_t)w * N + i];
+        lds_cnt[(size_t)w * N + i] = run;
+        run += t;
+      }
+    }
+    __syncthreads();
+    int *dst = inv_slots + (size_t)b * MK;
+    for (int s = s0; s < s1; s += CL3D_WAVE * kCsrBatch) {
+      int key[kCsrBatch];
+#pragma unroll
+      for (int u = 0; u < kCsrBatch; ++u) {
+        const int p = s + u * CL3D_WAVE + lane;
+        key[u] = src[p < s1 ? p : s1 - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < kCsrBatch; ++u) {  // batches in slot order, lanes in slot order inside a batch
+        const int p = s + u * CL3D_WAVE + lane;
+        if (p < s1 && (unsigned)key[u] < (unsigned)N) dst[atomicAdd(&h[key[u]], 1)] = p;
+      }
+    }
+  }
+}
+
+// one workgroup per cloud: counts [GB][N] -> first positions [GB][N] (in place) and inv_off [N+1].
+// A thread owns kScanR support points 1024 apart, so one sweep over 4096 points costs ONE global round
+// trip (all kScanR*8 loads in flight), one barrier, and the stores.
+constexpr int kScanR = 4;
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int N, int GB, int *__restrict__ table, int *__restrict__ inv_off) {
+  __shared__ int s_wave[kScanR][16];
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int *c = table + (size_t)b * GB * N;
+  int *off = inv_off + (size_t)b * (N + 1);
+  int carry = 0;
+  for (int base = 0; base < N; base += 1024 * kScanR) {
+    int v[kScanR][8], tot[kScanR], incl[kScanR];
+#pragma unroll
+    for (int r = 0; r < kScanR; ++r) {
+      const int i = base + r * 1024 + tid;
+      const int ic = i < N ? i : N - 1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[r][u] = c[(size_t)(u < GB ? u : GB - 1) * N + ic];
+    }
+#pragma unroll
+    for (int r = 0; r < kScanR; ++r) {
+      const int i = base + r * 1024 + tid;
+      const int ic = i < N ? i : N - 1;
+      tot[r] = 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) tot[r] += u < GB ? v[r][u] : 0;
+      for (int g0 = 8; g0 < GB; g0 += 8) {
+        int w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = c[(size_t)(g0 + u < GB ? g0 + u : GB - 1) * N + ic];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tot[r] += g0 + u < GB ? w[u] : 0;
+      }
+      if (i >= N) tot[r] = 0;
+      incl[r] = tot[r];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl[r], o, 64);
+        if (lane >= o) incl[r] += t;
+      }
+      if (lane == 63) s_wave[r][wave] = incl[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kScanR; ++r) {
+      int woff = 0, total = 0;
+      for (int ww = 0; ww < 16; ++ww) {
+        if (ww < wave) woff += s_wave[r][ww];
+        total += s_wave[r][ww];
+      }
+      const int i = base + r * 1024 + tid;
+      int run = carry + woff + incl[r] - tot[r];
+      if (i < N) {
+        off[i] = run;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (u < GB) {
+            c[(size_t)u * N + i] = run;
+            run += v[r][u];
+          }
+        }
+        for (int g0 = 8; g0 < GB; g0 += 8) {
+          int w[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) w[u] = c[(size_t)(g0 + u < GB ? g0 + u : GB - 1) * N + i];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (g0 + u < GB) {
+              c[(size_t)(g0 + u) * N + i] = run;
+              run += w[u];
+            }
+          }
+        }
+      }
+      carry += total;
+    }
+    __syncthreads();  // s_wave is reused by the next sweep
+  }
+  if (tid == 0) off[N] = carry;
+}
+
 static unsigned key_bits(int B, int N) {
   const unsigned long long maxkey = (unsigned long long)B * (unsigned long long)(N + 1);
   unsigned bits = 1;
@@ -71,6 +254,8 @@ static size_t sort_temp_bytes(int B, int N, int MK) {
 size_t inverse_index_workspace(int B, int N, int MK) {
   const size_t n = (size_t)B * MK;
   if (n == 0) return 0;
+  CsrPlan plan;
+  if (csr_plan(B, N, MK, &plan)) return (((size_t)B * (plan.G / plan.wpb) * N * sizeof(int)) + 255) & ~(size_t)255;
   return 3 * ((n * 4 + 255) & ~(size_t)255) + sort_temp_bytes(B, N, MK);
 }
 
@@ -92,6 +277,27 @@ extern "C" int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK
   }
   const size_t need = cl3d::inverse_index_workspace(B, N, MK);
   if (ws_bytes < need || !ws) return cl3d::fail(CL3D_E_WORKSPACE, "build_inverse_index: workspace %zu < %zu", ws_bytes, need);
+  cl3d::CsrPlan plan;
+  if (cl3d::csr_plan(B, N, MK, &plan)) {
+    static bool attr_done = false;
+    if (!attr_done) {  // N > 16384: one wave's counters exceed the 64 KiB a kernel gets by default
+      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<false>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e1 != hipSuccess || e2 != hipSuccess) return cl3d::fail(CL3D_E_LAUNCH, "build_inverse_index: LDS opt-in failed");
+      attr_done = true;
+    }
+    int *table = static_cast<int *>(ws);
+    const dim3 grid(plan.G / plan.wpb, B), block(64 * plan.wpb);
+    const int GB = plan.G / plan.wpb;
+    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<false>), grid, block, plan.lds, st, idx, N, MK, GB, plan.per,
+                       table, (int *)nullptr);
+    hipLaunchKernelGGL(cl3d::csr_scan_kernel, dim3(B), dim3(1024), 0, st, N, GB, table, inv_off);
+    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true>), grid, block, plan.lds, st, idx, N, MK, GB, plan.per,
+                       table, inv_slots);
+    return cl3d::check_launch("cl3d_build_inverse_index");
+  }
   const size_t n = (size_t)B * MK;
   const size_t stride = (n * 4 + 255) & ~(size_t)255;
   char *p = static_cast<char *>(ws);

@@ -44,7 +44,7 @@ struct PwArgs {
   float *dzs_out;                  // SPARSE
   float *sq_t;                     // QUERY writes, SUPPORT reads
   double *partial;                 // [gridDim.x, Co, 4]
-  const int *inv_off, *inv_slots, *cen_off, *cen_slots;
+  const int *inv_off, *inv_slots;
   float *dght;                     // SUPPORT: [B,N,2Co]
   int B, N, M, K, Co;
   int L, QW, chunks;
@@ -289,11 +289,12 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
       const int s0 = off[i], s1 = off[i + 1];
       const float *dzrow = a.dzs_in + (size_t)b * M * Co + c0;
       const unsigned char *ksrow = a.kstar_in + (size_t)b * M * Co + c0;
+      const float *sqrow = a.sq_t + (size_t)b * M * Co + c0;
       constexpr int SB = 4;  // slots per batch: 3*SB independent row gathers in flight per lane
       for (int e = s0; e < s1; e += SB) {
         int sl[SB];
         float4 r[SB];
-        Vec<V> hc[SB], dz[SB];
+        Vec<V> hc[SB], dz[SB], sqv[SB];
         unsigned ksw[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) sl[u] = slots[e + u < s1 ? e + u : s1 - 1];
@@ -306,6 +307,11 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
           dz[u] = load_row<V>(dzrow + (size_t)j * Co);
           if constexpr (V == 4) ksw[u] = *reinterpret_cast<const unsigned *>(ksrow + (size_t)j * Co);
           else ksw[u] = ksrow[(size_t)j * Co];
+          // slot 0 of a query is its centre (reference :290): the rows whose slot list holds (j, 0) are exactly
+          // the queries centred on this point, so the centre-feature gradient needs no table of its own
+#pragma unroll
+          for (int v = 0; v < V; ++v) sqv[u].v[v] = 0.f;
+          if (sl[u] - j * K == 0) sqv[u] = load_row<V>(sqrow + (size_t)j * Co);
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
@@ -318,17 +324,9 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
             float dy = __builtin_fmaf(cD[v], y, cB[v]);
             dy += (k == ks) ? dz[u].v[v] * cA[v] : 0.f;
             acc[v] += dy;
+            acch[v] += sqv[u].v[v];
           }
         }
-      }
-      const int *coff = a.cen_off + (size_t)b * (N + 1);
-      const int *cslots = a.cen_slots + (size_t)b * M;
-      const int t0 = coff[i], t1 = coff[i + 1];
-      for (int e = t0; e < t1; ++e) {
-        const int j = cslots[e];
-        const Vec<V> sq = load_row_tail<V>(a.sq_t + ((size_t)b * M + j) * Co + c0, c0, Co);
-#pragma unroll
-        for (int v = 0; v < V; ++v) acch[v] += sq.v[v];
       }
       float *dst = a.dght + ((size_t)b * N + i) * row + c0;
       _Pragma("unroll") for (int v = 0; v < V; ++v) {
@@ -567,18 +565,17 @@ extern "C" int cl3d_pwmlp_bwd_query(const float *query_xyz, const float *support
 extern "C" int cl3d_pwmlp_bwd_support(const int32_t *idx, const float *ght, const float *wr, const float *cA,
                                       const float *cB, const float *cD, const float *dzs_t,
                                       const unsigned char *kstar_t, const float *slotrec, const float *sq_t,
-                                      const int32_t *inv_off, const int32_t *inv_slots, const int32_t *cen_off,
-                                      const int32_t *cen_slots, int B, int N, int M, int K, int Co, float *dght,
-                                      cl3d_stream_t stream) {
+                                      const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M,
+                                      int K, int Co, float *dght, cl3d_stream_t stream) {
   using namespace cl3d;
   PwArgs a{};
   a.idx = idx; a.ght = ght; a.wr = wr; a.v0 = cA; a.v1 = cB; a.v2 = cD; a.dzs_in = dzs_t; a.kstar_in = kstar_t;
   a.slotrec = reinterpret_cast<float4 *>(const_cast<float *>(slotrec)); a.sq_t = const_cast<float *>(sq_t);
-  a.inv_off = inv_off; a.inv_slots = inv_slots; a.cen_off = cen_off; a.cen_slots = cen_slots; a.dght = dght;
+  a.inv_off = inv_off; a.inv_slots = inv_slots; a.dght = dght;
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co;
   int rc = pw_check(a, "pwmlp_bwd_support");
   if (rc != CL3D_OK) return rc;
-  CL3D_REQUIRE(idx && ght && wr && cA && cB && cD && dzs_t && kstar_t && slotrec && sq_t && inv_off && inv_slots && cen_off && cen_slots && dght,
+  CL3D_REQUIRE(idx && ght && wr && cA && cB && cD && dzs_t && kstar_t && slotrec && sq_t && inv_off && inv_slots && dght,
                "pwmlp_bwd_support: null pointer");
   if (B == 0) return CL3D_OK;
   const int V = (Co % 4 == 0) ? 4 : 1;

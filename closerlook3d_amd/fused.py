@@ -272,15 +272,10 @@ class _PointwiseMLP(Function):
             dwr = torch.empty((Co, 3), dtype=torch.float32, device=dev)
             _lib.check(lib.cl3d_pwmlp_reduce_dwr(_p(partial2), nparts, Co, _p(dwr), st))
             off, slots = inverse_index(idx, N)
-            centre = getattr(idx, '_cl3d_centre', None)
-            if centre is None:
-                centre = idx[:, :, 0].contiguous()
-                idx._cl3d_centre = centre
-            coff, cslots = inverse_index(centre, N)
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
             _lib.check(lib.cl3d_pwmlp_bwd_support(_p(idx), _p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(dzs), _p(kstar),
-                                                  _p(slotrec), _p(sq), _p(off), _p(slots), _p(coff), _p(cslots), B, N,
-                                                  M, K, Co, _p(dght), st))
+                                                  _p(slotrec), _p(sq), _p(off), _p(slots), B, N, M, K, Co,
+                                                  _p(dght), st))
         return (dght, dwr, dgamma, dbeta) + (None,) * 10
 
 

@@ -111,9 +111,11 @@ int cl3d_group_xyz_features(const float *query_xyz, const float *support_xyz,
  * in models/local_aggregation_operators.py.  Features and outputs are POINT-MAJOR here:
  * ft [B,N,C], out_t [B,M,C] (the Python layer transposes at the operator boundary). */
 
-/* CSR inverse of a neighbour-index tensor: inv_off [B,N+1], inv_slots [B,MK] (ascending slot ids per
- * support point).  ws: cl3d_workspace_bytes(CL3D_OP_INVERSE_INDEX, B, N, M, K, 0).  Used by every fused backward pass (ordered gather
- * instead of the reference's atomicAdd scatter, group_points_gpu.cu:65). */
+/* CSR inverse of a neighbour-index tensor: inv_off [B,N+1], inv_slots [B,MK] (the slot ids of each
+ * support point's row, in a fixed order that depends on idx only; slots whose index is outside [0,N)
+ * are dropped and inv_off[b][N] counts the kept ones).  ws: cl3d_workspace_bytes(CL3D_OP_INVERSE_INDEX,
+ * B, N, M, K, 0).  Used by every fused backward pass: an ordered gather instead of the reference's
+ * atomicAdd scatter (group_points_gpu.cu:65), so gradients are bit-reproducible run to run. */
 int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK, int32_t *inv_off,
                              int32_t *inv_slots, void *ws, size_t ws_bytes, cl3d_stream_t stream);
 
@@ -185,9 +187,8 @@ int cl3d_pwmlp_bwd_query(const float *query_xyz, const float *support_xyz, const
 int cl3d_pwmlp_bwd_support(const int32_t *idx, const float *ght, const float *wr, const float *cA,
                            const float *cB, const float *cD, const float *dzs_t,
                            const unsigned char *kstar_t, const float *slotrec, const float *sq_t,
-                           const int32_t *inv_off, const int32_t *inv_slots, const int32_t *cen_off,
-                           const int32_t *cen_slots, int B, int N, int M, int K, int Co, float *dght,
-                           cl3d_stream_t stream);
+                           const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K,
+                           int Co, float *dght, cl3d_stream_t stream);
 
 #ifdef __cplusplus
 }

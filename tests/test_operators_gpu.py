@@ -153,20 +153,31 @@ def test_fused_operator_matches_oracle(kind, over, C, K, N, mult):
     assert torch.equal(out, out2) and torch.equal(f.grad, f2.grad)
 
 
-def test_inverse_index_matches_numpy():
+@pytest.mark.parametrize("B,N,M,K", [(3, 500, 321, 17), (2, 4096, 4096, 32), (1, 20000, 5000, 16), (1, 40000, 3000, 8)])
+def test_inverse_index_matches_numpy(B, N, M, K):
+    """CSR inverse (wave-private counting sort for N <= 32768, radix sort beyond) == numpy's stable argsort;
+    indices outside [0,N) are dropped; the table is identical build after build."""
     from closerlook3d_amd.fused import inverse_index
     rng = np.random.default_rng(4)
-    B, N, M, K = 3, 500, 321, 17
     idx = rng.integers(0, N, (B, M, K)).astype(np.int32)
-    idx[0, :, :] = 7  # one support point referenced by every slot of cloud 0 (segment of 5457 entries)
-    off, slots = inverse_index(torch.from_numpy(idx).cuda(), N)
-    off, slots = off.cpu().numpy(), slots.cpu().numpy()
+    idx[0, :, :] = 7  # one support point referenced by every slot of cloud 0 (one very long segment)
+    if B > 1:
+        idx[1, ::5, 3] = -1  # invalid indices are not part of any row
+        idx[1, 1::7, 0] = N
+    tables = []
+    for _ in range(2):
+        off, slots = inverse_index(torch.from_numpy(idx).cuda(), N)
+        tables.append((off.cpu().numpy(), slots.cpu().numpy()))
+    assert np.array_equal(tables[0][0], tables[1][0]) and all(
+        np.array_equal(tables[0][1][b, :tables[0][0][b, N]], tables[1][1][b, :tables[1][0][b, N]]) for b in range(B))
+    off, slots = tables[0]
     for b in range(B):
         flat = idx[b].reshape(-1)
-        order = np.argsort(flat, kind="stable")
-        assert np.array_equal(slots[b], order.astype(np.int32))
-        counts = np.bincount(flat, minlength=N)
+        valid = np.nonzero((flat >= 0) & (flat < N))[0]
+        order = valid[np.argsort(flat[valid], kind="stable")]
+        counts = np.bincount(flat[valid], minlength=N)
         assert np.array_equal(off[b], np.concatenate([[0], np.cumsum(counts)]).astype(np.int32))
+        assert np.array_equal(slots[b, :off[b, N]], order.astype(np.int32))
 
 
 def test_eval_mode_inference_paths_agree():
