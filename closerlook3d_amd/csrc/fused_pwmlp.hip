@@ -12,38 +12,45 @@
 //     y[b,o,j,k] = W_r[o,:] . rel[b,j,k] + H[b, idx[b,j,0], o] + G[b, idx[b,j,k], o]
 // i.e. one point-major row gather + 3 FMAs.  `ght` is [B, N, 2*C_out]: row i = [G_i | H_i].
 //
-// Passes (all recompute y from rows; nothing of size B*C*M*K is ever stored):
-//   STATS      sum y, sum y^2 per channel (double partials)          -> batch mean / variance
-//   FWD        z = y*scale + shift, ReLU, max over k with first arg-max -> out_t [B,M,Co], kstar_t (uint8)
-//   BWD_SPARSE dz at the arg-max only (ReLU + max route the gradient to one slot per (b,o,j));
-//              d beta = sum dz, d gamma = sum dz * xhat (double partials); dzs_t [B,M,Co]
-//   BWD_QUERY  dense: dy = A dz + Bc + D y (the BatchNorm backward, affine in y);  per-query
-//              sum_k dy (-> dH through the centre index) and dW_r partials
-//   BWD_SUPPORT dense, support-major through the CSR inverse of idx: dG_i = sum over slots -> i of dy,
-//              dH_i = sum over queries centred on i of the per-query sums.  Ordered gathers, no atomics.
+// Nothing of size B*C*M*K is ever stored, and in training the rows are gathered only TWICE (once
+// query-major, once support-major), because everything else is algebra on per-(query, channel) values:
+//   * BN+ReLU is monotone in y (z = scale*y + shift, sign(scale) = sign(gamma) is known before the batch
+//     statistics are), so max_k ReLU(z) = ReLU(z(y*)) with y* = max_k y (min_k y for gamma < 0): the pass
+//     that accumulates the batch statistics also finds y* and its slot k*;
+//   * the BatchNorm backward is affine in y (dy = A dz [k = k*] + Bc + D y), so sum_k dy and
+//     sum_k dy * rel follow from sum_k y, dz and the per-channel sums S_a = sum y*rel_a, R_a = sum rel_a.
+// Passes:
+//   TRAIN     (gather, query-major) per channel: sum y, sum y^2, S_a, R_a (double partials);
+//             per (query, channel): y*, k*, sum_k y;  per slot: slotrec {rel, centre index}
+//   APPLY     (element-wise) out = ReLU(scale*y* + shift), transposed to channel-major through LDS
+//   FWD       (gather; inference with running statistics) the same output in one pass
+//   BWD_ROWS  (element-wise) dz at the arg-max (ReLU gate), d beta = sum dz, d gamma = sum dz*xhat,
+//             T_a = sum dz*rel_a(k*) (double partials); then d W_r = A T + Bc R + D S per channel
+//   BWD_SUPPORT (gather, support-major through the CSR inverse of idx) dG_i = sum over slots -> i of dy,
+//             dH_i = sum over queries centred on i of (D sum_k y + K Bc + A dz).  Ordered, no atomics.
 #include "fused_common.h"
 
 namespace cl3d {
 
-enum { PW_STATS = 0, PW_FWD = 1, PW_BWD_SPARSE = 2, PW_BWD_QUERY = 3 };
+enum { PW_TRAIN = 0, PW_FWD = 1 };
 constexpr int kSlotBatch = 8;  // row gathers in flight per lane
+constexpr int kPartialW = 8;   // doubles per (block, channel) in the partial-sum buffers
 
 struct PwArgs {
   const float *query_xyz, *support_xyz;
   const int *idx;
   const float *ght;  // [B,N,2Co]
   const float *wr;   // [Co,3]
-  const float *v0, *v1, *v2, *v3;  // per-channel vectors: FWD scale,shift | SPARSE scale,shift,mean,invstd | QUERY/SUPPORT A,Bc,D
-  const float *gout_t;             // [B,M,Co] (point-major) or, with gout_channel_major, [B,Co,M]
-  int out_channel_major, gout_channel_major;
+  const float *v0, *v1, *v2;  // per-channel vectors: TRAIN gamma | FWD scale,shift | SUPPORT A,Bc,D
   const float *dzs_in;             // [B,M,Co]
   const unsigned char *kstar_in;   // [B,M,Co]
+  const float *sy_in;              // [B,M,Co]
   float *out_t;                    // FWD
-  unsigned char *kstar_out;        // FWD
-  float4 *slotrec;                 // FWD writes {rel, 0} (may be null); SUPPORT reads
-  float *dzs_out;                  // SPARSE
-  float *sq_t;                     // QUERY writes, SUPPORT reads
-  double *partial;                 // [gridDim.x, Co, 4]
+  int out_channel_major;
+  float *ystar_t, *sy_t;           // TRAIN: [B,M,Co]
+  unsigned char *kstar_out;        // TRAIN / FWD
+  float4 *slotrec;                 // TRAIN / FWD write {rel, centre index} (may be null); SUPPORT reads
+  double *partial;                 // [gridDim.x, Co, kPartialW]
   const int *inv_off, *inv_slots;
   float *dght;                     // SUPPORT: [B,N,2Co]
   int B, N, M, K, Co;
@@ -58,14 +65,9 @@ __device__ __forceinline__ float pw_preact(const float w[3], float rx, float ry,
   return (t + hc) + g;
 }
 
-// V == 4 is only used when C % 4 == 0 and V == 1 rows are single elements, so a lane with c0 < C always
+// query-major gather passes.  Persistent blocks: tile = 4*QW queries of one cloud.
+// V == 4 is only used when Co % 4 == 0 and V == 1 rows are single elements, so a lane with c0 < Co always
 // owns a full vector: every row access is one global_load_dwordx4 / dword.
-template <int V>
-__device__ __forceinline__ Vec<V> load_row_tail(const float *p, int, int) {
-  return load_row<V>(p);
-}
-
-// query-major passes.  Persistent blocks: tile = 4*QW queries of one cloud.
 template <int MODE, int V>
 __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
   extern __shared__ float4 lds4[];
@@ -73,24 +75,26 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
   const int TQ = 4 * QW;
   const int row = 2 * Co;
   float4 *slot4 = lds4;  // [TQ*K] {idx, rx, ry, rz}
-  double *red = reinterpret_cast<double *>(slot4 + TQ * K);  // partial-sum slices
+  double *red = reinterpret_cast<double *>(slot4 + TQ * K);  // [4 waves][L*V*NACC]
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int g = lane / L, cl = lane - g * L;
   const bool lane_on = g < QW;
   const int tiles_per_cloud = (M + TQ - 1) / TQ;
   const int ntiles = a.B * tiles_per_cloud;
-  constexpr int NACC = MODE == PW_STATS ? 2 : (MODE == PW_BWD_SPARSE ? 2 : (MODE == PW_BWD_QUERY ? 3 : 0));
+  constexpr int NACC = MODE == PW_TRAIN ? 8 : 0;
 
   for (int ch = 0; ch < a.chunks; ++ch) {
     const int c0 = (ch * L + cl) * V;
     const bool chan_on = lane_on && c0 < Co;
-    double dacc[NACC > 0 ? NACC : 1][V];
+    // sum y, sum y^2, S_0..2 per channel; R_0..2 (sum rel) is the same for every channel of the lane
+    constexpr int NCH = NACC > 0 ? 5 : 1;
+    double dacc[NCH][V], drel[3] = {0.0, 0.0, 0.0};
 #pragma unroll
-    for (int p = 0; p < (NACC > 0 ? NACC : 1); ++p)
+    for (int p = 0; p < NCH; ++p)
 #pragma unroll
       for (int v = 0; v < V; ++v) dacc[p][v] = 0.0;
-    float w[V][3], c_v0[V], c_v1[V], c_v2[V], c_v3[V];
+    float w[V][3], c_v0[V], c_v1[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       const int c = chan_on ? c0 + v : 0;
@@ -99,8 +103,6 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
       w[v][2] = a.wr[c * 3 + 2];
       c_v0[v] = a.v0 ? a.v0[c] : 0.f;
       c_v1[v] = a.v1 ? a.v1[c] : 0.f;
-      c_v2[v] = a.v2 ? a.v2[c] : 0.f;
-      c_v3[v] = a.v3 ? a.v3[c] : 0.f;
     }
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -120,7 +122,7 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
           r = make_float4(__int_as_float(i), (s[i * 3 + 0] - q[j * 3 + 0]) * a.inv_radius,
                           (s[i * 3 + 1] - q[j * 3 + 1]) * a.inv_radius, (s[i * 3 + 2] - q[j * 3 + 2]) * a.inv_radius);
           // slotrec = {rel, centre index of the query}: one dependent load less per slot in the support-major pass
-          if (MODE == PW_FWD && ch == 0 && a.slotrec != nullptr)
+          if (ch == 0 && a.slotrec != nullptr)
             a.slotrec[e] = make_float4(r.y, r.z, r.w, __int_as_float(a.idx[((size_t)b * M + j) * K]));
         }
         slot4[t] = r;
@@ -132,27 +134,61 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
       const float4 *myslots = slot4 + jq * K;
       const float *rows = a.ght + (size_t)b * N * row;
       const int ic = __float_as_int(myslots[0].x);  // centre = nearest neighbour (reference :290)
-      const Vec<V> hc = load_row_tail<V>(rows + (size_t)ic * row + Co + c0, c0, Co);
+      const Vec<V> hc = load_row<V>(rows + (size_t)ic * row + Co + c0);
       const size_t orow = ((size_t)b * M + j) * Co + c0;
 
-      if constexpr (MODE == PW_STATS) {
-        float s1[V], s2[V];
+      if constexpr (MODE == PW_TRAIN) {
+        float s1[V], s2[V], sr0[V], sr1[V], sr2[V], best[V], sgn[V];
+        int kb[V];
+        float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f;
 #pragma unroll
-        for (int v = 0; v < V; ++v) s1[v] = s2[v] = 0.f;
-        for_each_slot<V, kSlotBatch>(myslots, K, rows, row, c0, [&](int, const float4 &sr, const Vec<V> &gr) {
+        for (int v = 0; v < V; ++v) {
+          s1[v] = s2[v] = sr0[v] = sr1[v] = sr2[v] = best[v] = 0.f;
+          kb[v] = 0;
+          sgn[v] = c_v0[v] < 0.f ? -1.f : 1.f;  // sign(gamma) = sign(scale): which extreme of y wins the max
+        }
+        for_each_slot<V, kSlotBatch>(myslots, K, rows, row, c0, [&](int k, const float4 &sr, const Vec<V> &gr) {
+          rs0 += sr.y;
+          rs1 += sr.z;
+          rs2 += sr.w;
 #pragma unroll
           for (int v = 0; v < V; ++v) {
             const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gr.v[v]);
             s1[v] += y;
             s2[v] = __builtin_fmaf(y, y, s2[v]);
+            sr0[v] = __builtin_fmaf(y, sr.y, sr0[v]);
+            sr1[v] = __builtin_fmaf(y, sr.z, sr1[v]);
+            sr2[v] = __builtin_fmaf(y, sr.w, sr2[v]);
+            const float yy = sgn[v] * y;
+            if (k == 0 || yy > best[v]) {  // first extreme
+              best[v] = yy;
+              kb[v] = k;
+            }
           }
         });
+        Vec<V> ys, sy;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
+          ys.v[v] = sgn[v] * best[v];
+          sy.v[v] = s1[v];
           dacc[0][v] += (double)s1[v];
           dacc[1][v] += (double)s2[v];
+          dacc[2][v] += (double)sr0[v];
+          dacc[3][v] += (double)sr1[v];
+          dacc[4][v] += (double)sr2[v];
         }
-      } else if constexpr (MODE == PW_FWD) {
+        drel[0] += (double)rs0;
+        drel[1] += (double)rs1;
+        drel[2] += (double)rs2;
+        store_row<V>(a.ystar_t + orow, ys);
+        store_row<V>(a.sy_t + orow, sy);
+        if constexpr (V == 4) {
+          *reinterpret_cast<unsigned *>(a.kstar_out + orow) =
+              (unsigned)kb[0] | ((unsigned)kb[1] << 8) | ((unsigned)kb[2] << 16) | ((unsigned)kb[3] << 24);
+        } else {
+          a.kstar_out[orow] = (unsigned char)kb[0];
+        }
+      } else {  // PW_FWD
         float best[V];
         int kb[V];
 #pragma unroll
@@ -179,67 +215,39 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
           else a.out_t[orow + v] = best[v];
           if (a.kstar_out) a.kstar_out[orow + v] = (unsigned char)kb[v];
         }
-      } else if constexpr (MODE == PW_BWD_SPARSE) {
-        _Pragma("unroll") for (int v = 0; v < V; ++v) {
-          const int ks = a.kstar_in[orow + v];
-          const float4 sr = myslots[ks];
-          const float gi = rows[(size_t)__float_as_int(sr.x) * row + c0 + v];
-          const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gi);
-          const float z = __builtin_fmaf(y, c_v0[v], c_v1[v]);
-          const float dz = z > 0.f ? (a.gout_channel_major ? a.gout_t[((size_t)b * Co + c0 + v) * M + j] : a.gout_t[orow + v]) : 0.f;
-          a.dzs_out[orow + v] = dz;
-          dacc[0][v] += (double)dz;
-          dacc[1][v] += (double)(dz * ((y - c_v2[v]) * c_v3[v]));
-        }
-      } else {  // PW_BWD_QUERY
-        float dzA[V], sdy[V], dw0[V], dw1[V], dw2[V];
-        int ks[V];
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-          const bool on = true;
-          dzA[v] = on ? a.dzs_in[orow + v] * c_v0[v] : 0.f;
-          ks[v] = on ? (int)a.kstar_in[orow + v] : -1;
-          sdy[v] = dw0[v] = dw1[v] = dw2[v] = 0.f;
-        }
-        for_each_slot<V, kSlotBatch>(myslots, K, rows, row, c0, [&](int k, const float4 &sr, const Vec<V> &gr) {
-#pragma unroll
-          for (int v = 0; v < V; ++v) {
-            const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gr.v[v]);
-            float dy = __builtin_fmaf(c_v2[v], y, c_v1[v]);
-            dy += (k == ks[v]) ? dzA[v] : 0.f;
-            sdy[v] += dy;
-            dw0[v] = __builtin_fmaf(dy, sr.y, dw0[v]);
-            dw1[v] = __builtin_fmaf(dy, sr.z, dw1[v]);
-            dw2[v] = __builtin_fmaf(dy, sr.w, dw2[v]);
-          }
-        });
-        _Pragma("unroll") for (int v = 0; v < V; ++v) a.sq_t[orow + v] = sdy[v];
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-          dacc[0][v] += (double)dw0[v];
-          dacc[1][v] += (double)dw1[v];
-          dacc[2][v] += (double)dw2[v];
-        }
       }
     }
 
-    if constexpr (NACC > 0) {  // fixed-order block reduction of the double partials of this chunk
+    if constexpr (NACC > 0) {
+      // fixed-order reduction of the double partials of this chunk: lane groups of a wave by shuffles
+      // (lanes that own no query hold zeros), the four waves through LDS
+      // (lane group gg of the wave = lanes [gg*L, gg*L+L); L need not be a power of two)
+      auto fold_groups = [&](double x) {
+        double tot = x;
+        for (int gg = 1; gg * L + L <= CL3D_WAVE; ++gg) tot += __shfl(x, cl + gg * L, CL3D_WAVE);
+        return tot;  // meaningful in group 0
+      };
+#pragma unroll
+      for (int p = 0; p < NCH; ++p)
+#pragma unroll
+        for (int v = 0; v < V; ++v) dacc[p][v] = fold_groups(dacc[p][v]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) drel[p] = fold_groups(drel[p]);
       const int LV = L * V;
       const int slice = LV * NACC;
       __syncthreads();
-      if (lane_on) {
-        double *mine = red + (size_t)(wave * QW + g) * slice + cl * V * NACC;
+      if (g == 0) {
+        double *mine = red + (size_t)wave * slice + cl * V * NACC;
 #pragma unroll
         for (int v = 0; v < V; ++v)
 #pragma unroll
-          for (int p = 0; p < NACC; ++p) mine[v * NACC + p] = chan_on ? dacc[p][v] : 0.0;
+          for (int p = 0; p < NACC; ++p) mine[v * NACC + p] = p < NCH ? dacc[p < NCH ? p : 0][v] : drel[p >= NCH ? p - NCH : 0];
       }
       __syncthreads();
       for (int t = threadIdx.x; t < slice; t += 256) {
-        double sum = 0.0;
-        for (int sl = 0; sl < 4 * QW; ++sl) sum += red[(size_t)sl * slice + t];
+        const double sum = ((red[t] + red[slice + t]) + red[2 * slice + t]) + red[3 * slice + t];
         const int c = ch * LV + t / NACC;
-        if (c < Co) a.partial[((size_t)blockIdx.x * Co + c) * 4 + (t - (t / NACC) * NACC)] = sum;
+        if (c < Co) a.partial[((size_t)blockIdx.x * Co + c) * kPartialW + (t - (t / NACC) * NACC)] = sum;
       }
       __syncthreads();
     }
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
   for (int ch = 0; ch < a.chunks; ++ch) {
     const int c0 = (ch * L + cl) * V;
     if (c0 >= Co) continue;
-    float w[V][3], cA[V], cB[V], cD[V];
+    float w[V][3], cA[V], cB[V], cD[V], kBc[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
       const int c = c0 + v;
@@ -272,6 +280,7 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
       cA[v] = a.v0[c];
       cB[v] = a.v1[c];
       cD[v] = a.v2[c];
+      kBc[v] = (float)K * cB[v];
     }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       int b, tr;
@@ -282,20 +291,21 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
       const int *off = a.inv_off + (size_t)b * (N + 1);
       const int *slots = a.inv_slots + (size_t)b * MK;
       const float4 *rec = a.slotrec + (size_t)b * MK;
-      const Vec<V> gi = load_row_tail<V>(rows + (size_t)i * row + c0, c0, Co);
+      const Vec<V> gi = load_row<V>(rows + (size_t)i * row + c0);
       float acc[V], acch[V];
 #pragma unroll
       for (int v = 0; v < V; ++v) acc[v] = acch[v] = 0.f;
       const int s0 = off[i], s1 = off[i + 1];
       const float *dzrow = a.dzs_in + (size_t)b * M * Co + c0;
       const unsigned char *ksrow = a.kstar_in + (size_t)b * M * Co + c0;
-      const float *sqrow = a.sq_t + (size_t)b * M * Co + c0;
+      const float *syrow = a.sy_in + (size_t)b * M * Co + c0;
       constexpr int SB = 4;  // slots per batch: 3*SB independent row gathers in flight per lane
       for (int e = s0; e < s1; e += SB) {
         int sl[SB];
         float4 r[SB];
         Vec<V> hc[SB], dz[SB], sqv[SB];
         unsigned ksw[SB];
+        bool centre[SB];
 #pragma unroll
         for (int u = 0; u < SB; ++u) sl[u] = slots[e + u < s1 ? e + u : s1 - 1];
 #pragma unroll
@@ -308,10 +318,12 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
           if constexpr (V == 4) ksw[u] = *reinterpret_cast<const unsigned *>(ksrow + (size_t)j * Co);
           else ksw[u] = ksrow[(size_t)j * Co];
           // slot 0 of a query is its centre (reference :290): the rows whose slot list holds (j, 0) are exactly
-          // the queries centred on this point, so the centre-feature gradient needs no table of its own
+          // the queries centred on this point, so the centre-feature gradient needs no table of its own.
+          // sum_k dy of that query = D sum_k y + K Bc + A dz  (sum_k y was left behind by the forward pass)
 #pragma unroll
           for (int v = 0; v < V; ++v) sqv[u].v[v] = 0.f;
-          if (sl[u] - j * K == 0) sqv[u] = load_row<V>(sqrow + (size_t)j * Co);
+          centre[u] = sl[u] - j * K == 0;
+          if (centre[u]) sqv[u] = load_row<V>(syrow + (size_t)j * Co);
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
             float dy = __builtin_fmaf(cD[v], y, cB[v]);
             dy += (k == ks) ? dz[u].v[v] * cA[v] : 0.f;
             acc[v] += dy;
-            acch[v] += sqv[u].v[v];
+            if (centre[u]) acch[v] += __builtin_fmaf(cD[v], sqv[u].v[v], __builtin_fmaf(cA[v], dz[u].v[v], kBc[v]));
           }
         }
       }
@@ -337,43 +349,182 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
   }
 }
 
+// ---- element-wise passes over the per-(query, channel) rows ------------------------------------------
+// Tile = 64 queries x CW channels (CW a power of two <= 128: Co is walked in its binary decomposition, so a
+// thread keeps ONE channel for the whole pass and its partial sums stay in registers).  The channel-major
+// side of the transposition ([B,Co,M] output / upstream gradient) goes through an LDS tile, so both sides
+// are read and written in full 256-byte rows.
+enum { ROWS_APPLY = 0, ROWS_BWD = 1 };
+constexpr int kRowsBatch = 4;
+
+struct RowArgs {
+  const float *ystar_t;           // [B,M,Co]
+  const unsigned char *kstar_t;   // [B,M,Co]
+  const float4 *slotrec;          // [B,M,K]
+  const float *gout;              // [B,Co,M] (channel-major) or [B,M,Co]
+  int gout_channel_major;
+  const float *scale, *shift, *mean, *invstd;
+  float *out;                     // APPLY: [B,Co,M]
+  float *dzs_t;                   // BWD: [B,M,Co]
+  double *partial;                // BWD: [gridDim.x, Co, kPartialW]
+  int B, M, K, Co;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
+  __shared__ float tile[128 * 65];
+  __shared__ double red[MODE == ROWS_BWD ? 256 * 5 : 1];
+  const int M = a.M, Co = a.Co, K = a.K;
+  const int tid = threadIdx.x;
+  const int tiles_per_cloud = (M + 63) / 64;
+  const int ntiles = a.B * tiles_per_cloud;
+  for (int cbase = 0; cbase < Co;) {
+    int CW = 128;
+    while (CW > Co - cbase) CW >>= 1;
+    const int cl = tid & (CW - 1), r0 = tid / CW, RS = 256 / CW;
+    const int c = cbase + cl;
+    const float scale = a.scale[c], shift = a.shift[c];
+    float mean = 0.f, invstd = 0.f;
+    if constexpr (MODE == ROWS_BWD) {
+      mean = a.mean[c];
+      invstd = a.invstd[c];
+    }
+    double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+      const int b = t / tiles_per_cloud;
+      const int j0 = (t - b * tiles_per_cloud) * 64;
+      const int nj = M - j0 < 64 ? M - j0 : 64;
+      if constexpr (MODE == ROWS_BWD) {
+        if (a.gout_channel_major) {
+          for (int e0 = 0; e0 < CW * 64; e0 += 256 * kRowsBatch) {
+            float gv[kRowsBatch];
+#pragma unroll
+            for (int u = 0; u < kRowsBatch; ++u) {
+              const int e = e0 + u * 256 + tid;
+              const int cc = (e >> 6) < CW ? (e >> 6) : CW - 1, jq = e & 63;
+              gv[u] = a.gout[((size_t)b * Co + cbase + cc) * M + j0 + (jq < nj ? jq : nj - 1)];
+            }
+#pragma unroll
+            for (int u = 0; u < kRowsBatch; ++u) {
+              const int e = e0 + u * 256 + tid;
+              if ((e >> 6) < CW) tile[(e >> 6) * 65 + (e & 63)] = gv[u];
+            }
+          }
+          __syncthreads();
+        }
+        for (int jb = r0; jb < nj; jb += RS * kRowsBatch) {
+          float y[kRowsBatch], gq[kRowsBatch];
+          int ks[kRowsBatch];
+          float4 rel[kRowsBatch];
+#pragma unroll
+          for (int u = 0; u < kRowsBatch; ++u) {
+            const int jq = jb + u * RS < nj ? jb + u * RS : nj - 1;
+            const size_t e = ((size_t)b * M + j0 + jq) * Co + c;
+            y[u] = a.ystar_t[e];
+            ks[u] = a.kstar_t[e];
+            gq[u] = a.gout_channel_major ? tile[cl * 65 + jq] : a.gout[e];
+          }
+#pragma unroll
+          for (int u = 0; u < kRowsBatch; ++u) {
+            const int jq = jb + u * RS < nj ? jb + u * RS : nj - 1;
+            rel[u] = a.slotrec[((size_t)b * M + j0 + jq) * K + ks[u]];
+          }
+#pragma unroll
+          for (int u = 0; u < kRowsBatch; ++u) {
+            const int jq = jb + u * RS;
+            if (jq >= nj) continue;
+            const float z = __builtin_fmaf(y[u], scale, shift);
+            const float dz = z > 0.f ? gq[u] : 0.f;
+            a.dzs_t[((size_t)b * M + j0 + jq) * Co + c] = dz;
+            acc[0] += (double)dz;
+            acc[1] += (double)(dz * ((y[u] - mean) * invstd));
+            acc[2] += (double)(dz * rel[u].x);
+            acc[3] += (double)(dz * rel[u].y);
+            acc[4] += (double)(dz * rel[u].z);
+          }
+        }
+        if (a.gout_channel_major) __syncthreads();  // the tile is overwritten by the next iteration
+      } else {
+        for (int jb = r0; jb < nj; jb += RS * kRowsBatch) {
+          float y[kRowsBatch];
+#pragma unroll
+          for (int u = 0; u < kRowsBatch; ++u) {
+            const int jq = jb + u * RS < nj ? jb + u * RS : nj - 1;
+            y[u] = a.ystar_t[((size_t)b * M + j0 + jq) * Co + c];
+          }
+#pragma unroll
+          for (int u = 0; u < kRowsBatch; ++u) {
+            const int jq = jb + u * RS;
+            if (jq >= nj) continue;
+            const float z = __builtin_fmaf(y[u], scale, shift);
+            tile[cl * 65 + jq] = z > 0.f ? z : 0.f;
+          }
+        }
+        __syncthreads();
+        for (int e = tid; e < CW * 64; e += 256) {
+          const int cc = e >> 6, jq = e & 63;
+          if (jq < nj) a.out[((size_t)b * Co + cbase + cc) * M + j0 + jq] = tile[cc * 65 + jq];
+        }
+        __syncthreads();
+      }
+    }
+    if constexpr (MODE == ROWS_BWD) {  // fixed-order reduction over the RS threads that share a channel
+#pragma unroll
+      for (int p = 0; p < 5; ++p) red[tid * 5 + p] = acc[p];
+      __syncthreads();
+      for (int e = tid; e < CW * 5; e += 256) {
+        const int cc = e / 5, p = e - cc * 5;
+        double sum = 0.0;
+        for (int r = 0; r < RS; ++r) sum += red[(r * CW + cc) * 5 + p];
+        a.partial[((size_t)blockIdx.x * Co + cbase + cc) * kPartialW + p] = sum;
+      }
+      __syncthreads();
+    }
+    cbase += CW;
+  }
+}
+
 // ---- fixed-order reduction of the per-block double partials + the per-channel BatchNorm algebra.
 // One block per channel; replaces ~30 tiny element-wise launches the same math costs in PyTorch.
-enum { FIN_STATS = 0, FIN_COEFFS = 1, FIN_DWR = 2 };
+enum { FIN_STATS = 0, FIN_COEFFS = 1 };
 
 struct FinArgs {
-  const double *partial;  // [G, Co, 4]
+  const double *partial;  // [G, Co, kPartialW]
   int G, Co;
   double count;
   float eps, momentum;
   const float *gamma, *beta, *mean_in, *invstd_in;
   float *running_mean, *running_var;
-  float *o0, *o1, *o2, *o3, *o4;
+  double *sums;           // [Co,6]: S_a = sum y*rel_a, R_a = sum rel_a  (STATS writes, COEFFS reads)
+  float *o0, *o1, *o2, *o3, *o4, *o5;
 };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
-  __shared__ double s_red[4][256];
+  constexpr int NS = MODE == FIN_STATS ? 8 : 5;
+  __shared__ double s_red[NS][256];
   const int c = blockIdx.x;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int g = threadIdx.x; g < a.G; g += 256) {
-    const double *p = a.partial + ((size_t)g * a.Co + c) * 4;
+  double acc[NS];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) acc[k] += p[k];
+  for (int k = 0; k < NS; ++k) acc[k] = 0.0;
+  for (int g = threadIdx.x; g < a.G; g += 256) {
+    const double *p = a.partial + ((size_t)g * a.Co + c) * kPartialW;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) acc[k] += p[k];
   }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) s_red[k][threadIdx.x] = acc[k];
+  for (int k = 0; k < NS; ++k) s_red[k][threadIdx.x] = acc[k];
   __syncthreads();
   for (int w = 128; w >= 1; w >>= 1) {
     if ((int)threadIdx.x < w) {
 #pragma unroll
-      for (int k = 0; k < 3; ++k) s_red[k][threadIdx.x] += s_red[k][threadIdx.x + w];
+      for (int k = 0; k < NS; ++k) s_red[k][threadIdx.x] += s_red[k][threadIdx.x + w];
     }
     __syncthreads();
   }
   if (threadIdx.x != 0) return;
-  const double s0 = s_red[0][0], s1 = s_red[1][0], s2 = s_red[2][0];
   if constexpr (MODE == FIN_STATS) {
+    const double s0 = s_red[0][0], s1 = s_red[1][0];
     const double mean = s0 / a.count;
     double var = s1 / a.count - mean * mean;
     var = var > 0.0 ? var : 0.0;
@@ -383,13 +534,16 @@ __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
     a.o1[c] = (float)((double)a.beta[c] - mean * scale);
     a.o2[c] = (float)mean;
     a.o3[c] = (float)invstd;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.sums[c * 6 + k] = s_red[2 + k][0];
     if (a.running_mean != nullptr) {  // nn.BatchNorm2d: running = (1-m) running + m batch, unbiased variance
       const double unbiased = var * (a.count / (a.count > 1.0 ? a.count - 1.0 : 1.0));
       a.running_mean[c] = a.running_mean[c] * (1.0f - a.momentum) + a.momentum * (float)mean;
       a.running_var[c] = a.running_var[c] * (1.0f - a.momentum) + a.momentum * (float)unbiased;
     }
-  } else if constexpr (MODE == FIN_COEFFS) {
-    // BatchNorm backward, affine in y:  dy = A dz + Bc + D y   (s0 = sum dz = d beta, s1 = sum dz*xhat = d gamma)
+  } else {
+    // BatchNorm backward, affine in y:  dy = A dz [k = k*] + Bc + D y   (s0 = sum dz = d beta, s1 = sum dz*xhat = d gamma)
+    const double s0 = s_red[0][0], s1 = s_red[1][0];
     const double invstd = (double)a.invstd_in[c], mean = (double)a.mean_in[c];
     const double A = (double)a.gamma[c] * invstd;
     const double D = -A * invstd * s1 / a.count;
@@ -399,10 +553,10 @@ __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
     a.o2[c] = (float)D;
     a.o3[c] = (float)s1;  // d gamma
     a.o4[c] = (float)s0;  // d beta
-  } else {
-    a.o0[c * 3 + 0] = (float)s0;
-    a.o0[c * 3 + 1] = (float)s1;
-    a.o0[c * 3 + 2] = (float)s2;
+    // d W_r[c][a] = sum_{slots} dy * rel_a = A T_a + Bc R_a + D S_a
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      a.o5[c * 3 + k] = (float)(A * s_red[2 + k][0] + Bc * a.sums[c * 6 + 3 + k] + D * a.sums[c * 6 + k]);
   }
 }
 
@@ -422,7 +576,7 @@ static LaneMap pw_lane_map(int Co, int K, int V, int nacc, size_t *lds_out) {
   }
   for (;;) {
     const size_t tq = 4 * (size_t)m.QW;
-    const size_t lds = tq * K * sizeof(float4) + tq * m.L * V * nacc * sizeof(double);
+    const size_t lds = tq * K * sizeof(float4) + (size_t)4 * m.L * V * nacc * sizeof(double);
     if (lds <= 60 * 1024 || m.QW == 1) {
       *lds_out = lds;
       return m;
@@ -452,55 +606,66 @@ extern "C" int cl3d_pwmlp_partials(int B, int M, int Co) {
   return cl3d::round_grid(((long long)B * M + 15) / 16, 1024);
 }
 
+extern "C" int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
+                                const float *ght, const float *wr, const float *gamma, int B, int N, int M,
+                                int K, int Co, float radius, float *ystar_t, unsigned char *kstar_t,
+                                float *sy_t, float *slotrec, double *partial, int n_partials,
+                                cl3d_stream_t stream) {
+  using namespace cl3d;
+  PwArgs a{};
+  a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr; a.v0 = gamma;
+  a.ystar_t = ystar_t; a.kstar_out = kstar_t; a.sy_t = sy_t; a.slotrec = reinterpret_cast<float4 *>(slotrec);
+  a.partial = partial;
+  a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
+  int rc = pw_check(a, "pwmlp_stats");
+  if (rc != CL3D_OK) return rc;
+  CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && gamma && ystar_t && kstar_t && sy_t && partial,
+               "pwmlp_stats: null pointer");
+  CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_stats: partial buffer must have cl3d_pwmlp_partials() blocks");
+  if (B == 0) return CL3D_OK;
+  return launch_query<PW_TRAIN>(a, 8, n_partials, (hipStream_t)stream, "cl3d_pwmlp_stats");
+}
+
 extern "C" int cl3d_pwmlp_finalize_stats(const double *partial, int n_partials, int Co, double count, float eps,
                                          float momentum, const float *gamma, const float *beta,
                                          float *running_mean, float *running_var, float *scale, float *shift,
-                                         float *mean, float *invstd, cl3d_stream_t stream) {
-  CL3D_REQUIRE(partial && gamma && beta && scale && shift && mean && invstd && n_partials > 0 && Co > 0 && count > 0,
+                                         float *mean, float *invstd, double *sums, cl3d_stream_t stream) {
+  CL3D_REQUIRE(partial && gamma && beta && scale && shift && mean && invstd && sums && n_partials > 0 && Co > 0 && count > 0,
                "pwmlp_finalize_stats: bad arguments");
   cl3d::FinArgs a{};
   a.partial = partial; a.G = n_partials; a.Co = Co; a.count = count; a.eps = eps; a.momentum = momentum;
   a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
-  a.o0 = scale; a.o1 = shift; a.o2 = mean; a.o3 = invstd;
+  a.o0 = scale; a.o1 = shift; a.o2 = mean; a.o3 = invstd; a.sums = sums;
   hipLaunchKernelGGL((cl3d::pwmlp_finalize_kernel<cl3d::FIN_STATS>), dim3(Co), dim3(256), 0, (hipStream_t)stream, a);
   return cl3d::check_launch("cl3d_pwmlp_finalize_stats");
 }
 
+extern "C" int cl3d_pwmlp_apply(const float *ystar_t, const float *scale, const float *shift, int B, int M,
+                                int Co, float *out, cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(B >= 0 && M >= 1 && Co >= 1, "pwmlp_apply: bad sizes");
+  CL3D_REQUIRE(ystar_t && scale && shift && out, "pwmlp_apply: null pointer");
+  if (B == 0) return CL3D_OK;
+  RowArgs a{};
+  a.ystar_t = ystar_t; a.scale = scale; a.shift = shift; a.out = out; a.B = B; a.M = M; a.Co = Co; a.K = 1;
+  const int gx = round_grid((long long)B * ceil_div(M, 64), 8192);
+  hipLaunchKernelGGL((pwmlp_rows_kernel<ROWS_APPLY>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("cl3d_pwmlp_apply");
+}
+
 extern "C" int cl3d_pwmlp_bn_backward_coeffs(const double *partial, int n_partials, int Co, double count,
-                                             const float *gamma, const float *mean, const float *invstd, float *cA,
-                                             float *cB, float *cD, float *dgamma, float *dbeta,
-                                             cl3d_stream_t stream) {
-  CL3D_REQUIRE(partial && gamma && mean && invstd && cA && cB && cD && dgamma && dbeta && n_partials > 0 && Co > 0 && count > 0,
+                                             const float *gamma, const float *mean, const float *invstd,
+                                             const double *sums, float *cA, float *cB, float *cD, float *dgamma,
+                                             float *dbeta, float *dwr, cl3d_stream_t stream) {
+  CL3D_REQUIRE(partial && gamma && mean && invstd && sums && cA && cB && cD && dgamma && dbeta && dwr && n_partials > 0 &&
+                   Co > 0 && count > 0,
                "pwmlp_bn_backward_coeffs: bad arguments");
   cl3d::FinArgs a{};
   a.partial = partial; a.G = n_partials; a.Co = Co; a.count = count; a.gamma = gamma; a.mean_in = mean;
-  a.invstd_in = invstd; a.o0 = cA; a.o1 = cB; a.o2 = cD; a.o3 = dgamma; a.o4 = dbeta;
+  a.invstd_in = invstd; a.sums = const_cast<double *>(sums);
+  a.o0 = cA; a.o1 = cB; a.o2 = cD; a.o3 = dgamma; a.o4 = dbeta; a.o5 = dwr;
   hipLaunchKernelGGL((cl3d::pwmlp_finalize_kernel<cl3d::FIN_COEFFS>), dim3(Co), dim3(256), 0, (hipStream_t)stream, a);
   return cl3d::check_launch("cl3d_pwmlp_bn_backward_coeffs");
-}
-
-extern "C" int cl3d_pwmlp_reduce_dwr(const double *partial, int n_partials, int Co, float *dwr,
-                                     cl3d_stream_t stream) {
-  CL3D_REQUIRE(partial && dwr && n_partials > 0 && Co > 0, "pwmlp_reduce_dwr: bad arguments");
-  cl3d::FinArgs a{};
-  a.partial = partial; a.G = n_partials; a.Co = Co; a.count = 1.0; a.o0 = dwr;
-  hipLaunchKernelGGL((cl3d::pwmlp_finalize_kernel<cl3d::FIN_DWR>), dim3(Co), dim3(256), 0, (hipStream_t)stream, a);
-  return cl3d::check_launch("cl3d_pwmlp_reduce_dwr");
-}
-
-extern "C" int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
-                                const float *ght, const float *wr, int B, int N, int M, int K, int Co,
-                                float radius, double *partial, int n_partials, cl3d_stream_t stream) {
-  using namespace cl3d;
-  PwArgs a{};
-  a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr; a.partial = partial;
-  a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
-  int rc = pw_check(a, "pwmlp_stats");
-  if (rc != CL3D_OK) return rc;
-  CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && partial, "pwmlp_stats: null pointer");
-  CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_stats: partial buffer must have cl3d_pwmlp_partials() blocks");
-  if (B == 0) return CL3D_OK;
-  return launch_query<PW_STATS>(a, 2, n_partials, (hipStream_t)stream, "cl3d_pwmlp_stats");
 }
 
 extern "C" int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, const int32_t *idx,
@@ -521,61 +686,39 @@ extern "C" int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, 
   return launch_query<PW_FWD>(a, 0, 0, (hipStream_t)stream, "cl3d_pwmlp_fwd");
 }
 
-extern "C" int cl3d_pwmlp_bwd_sparse(const float *query_xyz, const float *support_xyz, const int32_t *idx,
-                                     const float *ght, const float *wr, const float *scale,
-                                     const float *shift, const float *mean, const float *invstd,
-                                     const float *gout, int gout_channel_major, const unsigned char *kstar_t,
-                                     int B, int N, int M, int K, int Co, float radius, float *dzs_t,
-                                     double *partial, int n_partials, cl3d_stream_t stream) {
+extern "C" int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, const float *ystar_t,
+                                   const unsigned char *kstar_t, const float *slotrec, const float *scale,
+                                   const float *shift, const float *mean, const float *invstd, int B, int M,
+                                   int K, int Co, float *dzs_t, double *partial, int n_partials,
+                                   cl3d_stream_t stream) {
   using namespace cl3d;
-  PwArgs a{};
-  a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr;
-  a.v0 = scale; a.v1 = shift; a.v2 = mean; a.v3 = invstd; a.gout_t = gout; a.gout_channel_major = gout_channel_major;
-  a.kstar_in = kstar_t;
-  a.dzs_out = dzs_t; a.partial = partial;
-  a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
-  int rc = pw_check(a, "pwmlp_bwd_sparse");
-  if (rc != CL3D_OK) return rc;
-  CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && scale && shift && mean && invstd && gout && kstar_t && dzs_t && partial,
-               "pwmlp_bwd_sparse: null pointer");
-  CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_bwd_sparse: wrong partial block count");
+  CL3D_REQUIRE(B >= 0 && M >= 1 && K >= 1 && K <= 255 && Co >= 1, "pwmlp_bwd_rows: bad sizes");
+  CL3D_REQUIRE(gout && ystar_t && kstar_t && slotrec && scale && shift && mean && invstd && dzs_t && partial,
+               "pwmlp_bwd_rows: null pointer");
+  CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_bwd_rows: wrong partial block count");
   if (B == 0) return CL3D_OK;
-  return launch_query<PW_BWD_SPARSE>(a, 2, n_partials, (hipStream_t)stream, "cl3d_pwmlp_bwd_sparse");
-}
-
-extern "C" int cl3d_pwmlp_bwd_query(const float *query_xyz, const float *support_xyz, const int32_t *idx,
-                                    const float *ght, const float *wr, const float *cA, const float *cB,
-                                    const float *cD, const float *dzs_t, const unsigned char *kstar_t, int B,
-                                    int N, int M, int K, int Co, float radius, float *sq_t, double *partial,
-                                    int n_partials, cl3d_stream_t stream) {
-  using namespace cl3d;
-  PwArgs a{};
-  a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr;
-  a.v0 = cA; a.v1 = cB; a.v2 = cD; a.dzs_in = dzs_t; a.kstar_in = kstar_t; a.sq_t = sq_t; a.partial = partial;
-  a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
-  int rc = pw_check(a, "pwmlp_bwd_query");
-  if (rc != CL3D_OK) return rc;
-  CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && cA && cB && cD && dzs_t && kstar_t && sq_t && partial,
-               "pwmlp_bwd_query: null pointer");
-  CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_bwd_query: wrong partial block count");
-  if (B == 0) return CL3D_OK;
-  return launch_query<PW_BWD_QUERY>(a, 3, n_partials, (hipStream_t)stream, "cl3d_pwmlp_bwd_query");
+  RowArgs a{};
+  a.gout = gout; a.gout_channel_major = gout_channel_major; a.ystar_t = ystar_t; a.kstar_t = kstar_t;
+  a.slotrec = reinterpret_cast<const float4 *>(slotrec); a.scale = scale; a.shift = shift; a.mean = mean;
+  a.invstd = invstd; a.dzs_t = dzs_t; a.partial = partial; a.B = B; a.M = M; a.K = K; a.Co = Co;
+  hipLaunchKernelGGL((pwmlp_rows_kernel<ROWS_BWD>), dim3(n_partials), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("cl3d_pwmlp_bwd_rows");
 }
 
 extern "C" int cl3d_pwmlp_bwd_support(const int32_t *idx, const float *ght, const float *wr, const float *cA,
                                       const float *cB, const float *cD, const float *dzs_t,
-                                      const unsigned char *kstar_t, const float *slotrec, const float *sq_t,
+                                      const unsigned char *kstar_t, const float *slotrec, const float *sy_t,
                                       const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M,
                                       int K, int Co, float *dght, cl3d_stream_t stream) {
   using namespace cl3d;
   PwArgs a{};
   a.idx = idx; a.ght = ght; a.wr = wr; a.v0 = cA; a.v1 = cB; a.v2 = cD; a.dzs_in = dzs_t; a.kstar_in = kstar_t;
-  a.slotrec = reinterpret_cast<float4 *>(const_cast<float *>(slotrec)); a.sq_t = const_cast<float *>(sq_t);
+  a.slotrec = reinterpret_cast<float4 *>(const_cast<float *>(slotrec)); a.sy_in = sy_t;
   a.inv_off = inv_off; a.inv_slots = inv_slots; a.dght = dght;
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co;
   int rc = pw_check(a, "pwmlp_bwd_support");
   if (rc != CL3D_OK) return rc;
-  CL3D_REQUIRE(idx && ght && wr && cA && cB && cD && dzs_t && kstar_t && slotrec && sq_t && inv_off && inv_slots && dght,
+  CL3D_REQUIRE(idx && ght && wr && cA && cB && cD && dzs_t && kstar_t && slotrec && sy_t && inv_off && inv_slots && dght,
                "pwmlp_bwd_support: null pointer");
   if (B == 0) return CL3D_OK;
   const int V = (Co % 4 == 0) ? 4 : 1;

@@ -209,44 +209,47 @@ class _PointwiseMLP(Function):
         lib = _lib.lib()
         n = B * M * K
         nparts = lib.cl3d_pwmlp_partials(B, M, Co)
+        out = torch.empty((B, Co, M), dtype=torch.float32, device=dev)  # channel-major, written by the kernels
         with torch.cuda.device(dev):
-            scale = torch.empty((Co,), dtype=torch.float32, device=dev)
-            shift, mean, invstd = torch.empty_like(scale), torch.empty_like(scale), torch.empty_like(scale)
+            st = _stream(ght)
             if training:
-                partial = torch.empty((nparts, Co, 4), dtype=torch.float64, device=dev)
-                _lib.check(lib.cl3d_pwmlp_stats(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), B, N, M, K,
-                                                Co, float(radius), _p(partial), nparts, _stream(ght)))
+                # one gather pass: batch statistics AND, per (query, channel), the pre-activation that wins the
+                # max, its slot and sum_k y -- the rest of forward and most of backward is algebra on those
+                vec = torch.empty((4, Co), dtype=torch.float32, device=dev)
+                scale, shift, mean, invstd = vec[0], vec[1], vec[2], vec[3]
+                rows = torch.empty((2, B, M, Co), dtype=torch.float32, device=dev)
+                ystar, sy = rows[0], rows[1]
+                kstar = torch.empty((B, M, Co), dtype=torch.uint8, device=dev)
+                slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev) if need_grad else None
+                partial = torch.empty((nparts, Co, 8), dtype=torch.float64, device=dev)
+                sums = torch.empty((Co, 6), dtype=torch.float64, device=dev)
+                _lib.check(lib.cl3d_pwmlp_stats(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(gamma),
+                                                B, N, M, K, Co, float(radius), _p(ystar), _p(kstar), _p(sy),
+                                                _p(slotrec), _p(partial), nparts, st))
                 # batch statistics, scale/shift and the running-statistics update in one small launch
                 _lib.check(lib.cl3d_pwmlp_finalize_stats(_p(partial), nparts, Co, float(n), float(eps), float(momentum),
                                                          _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                                         _p(scale), _p(shift), _p(mean), _p(invstd), _stream(ght)))
+                                                         _p(scale), _p(shift), _p(mean), _p(invstd), _p(sums), st))
+                _lib.check(lib.cl3d_pwmlp_apply(_p(ystar), _p(scale), _p(shift), B, M, Co, _p(out), st))
+                if need_grad:
+                    ctx.save_for_backward(ght, wr, gamma, vec, ystar, sy, kstar, slotrec, sums)
+                    ctx.idx = idx
+                    ctx.meta = (B, N, M, K, Co, nparts)
             else:
-                mean64 = running_mean.double()
+                if need_grad:
+                    raise NotImplementedError("fused PointWiseMLP backward needs training-mode BatchNorm")
                 invstd64 = torch.rsqrt(running_var.double() + eps)
                 scale64 = gamma.double() * invstd64
-                scale.copy_(scale64)
-                shift.copy_(beta.double() - mean64 * scale64)
-                mean.copy_(mean64)
-                invstd.copy_(invstd64)
-            out = torch.empty((B, Co, M), dtype=torch.float32, device=dev)  # channel-major, written by the kernel
-            kstar = torch.empty((B, M, Co), dtype=torch.uint8, device=dev) if need_grad else None
-            slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev) if need_grad else None
-            _lib.check(lib.cl3d_pwmlp_fwd(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(scale),
-                                          _p(shift), B, N, M, K, Co, float(radius), _p(out), 1, _p(kstar), _p(slotrec),
-                                          _stream(ght)))
-        if need_grad:
-            if not training:
-                raise NotImplementedError("fused PointWiseMLP backward needs training-mode BatchNorm")
-            ctx.save_for_backward(ght, wr, gamma, scale, shift, mean, invstd, kstar, slotrec,
-                                  query_xyz, support_xyz)
-            ctx.idx = idx
-            ctx.meta = (B, N, M, K, Co, float(radius), nparts)
+                scale = scale64.float()
+                shift = (beta.double() - running_mean.double() * scale64).float()
+                _lib.check(lib.cl3d_pwmlp_fwd(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(scale),
+                                              _p(shift), B, N, M, K, Co, float(radius), _p(out), 1, None, None, st))
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        ght, wr, gamma, scale, shift, mean, invstd, kstar, slotrec, query_xyz, support_xyz = ctx.saved_tensors
-        B, N, M, K, Co, radius, nparts = ctx.meta
+        ght, wr, gamma, vec, ystar, sy, kstar, slotrec, sums = ctx.saved_tensors
+        B, N, M, K, Co, nparts = ctx.meta
         idx = ctx.idx
         dev = gout.device
         lib = _lib.lib()
@@ -255,26 +258,20 @@ class _PointwiseMLP(Function):
         with torch.cuda.device(dev):
             st = _stream(gout)
             dzs = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
-            partial = torch.empty((nparts, Co, 4), dtype=torch.float64, device=dev)
-            _lib.check(lib.cl3d_pwmlp_bwd_sparse(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(scale),
-                                                 _p(shift), _p(mean), _p(invstd), _p(gout), 1, _p(kstar), B, N, M,
-                                                 K, Co, radius, _p(dzs), _p(partial), nparts, st))
-            # d gamma, d beta and the coefficients of  dy = A dz + Bc + D y  (BatchNorm backward is affine in y)
-            cA = torch.empty((Co,), dtype=torch.float32, device=dev)
-            cB, cD, dgamma, dbeta = (torch.empty_like(cA) for _ in range(4))
-            _lib.check(lib.cl3d_pwmlp_bn_backward_coeffs(_p(partial), nparts, Co, float(n), _p(gamma), _p(mean),
-                                                         _p(invstd), _p(cA), _p(cB), _p(cD), _p(dgamma), _p(dbeta), st))
-            sq = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
-            partial2 = torch.empty((nparts, Co, 4), dtype=torch.float64, device=dev)
-            _lib.check(lib.cl3d_pwmlp_bwd_query(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(cA),
-                                                _p(cB), _p(cD), _p(dzs), _p(kstar), B, N, M, K, Co, radius, _p(sq),
-                                                _p(partial2), nparts, st))
+            partial = torch.empty((nparts, Co, 8), dtype=torch.float64, device=dev)
+            _lib.check(lib.cl3d_pwmlp_bwd_rows(_p(gout), 1, _p(ystar), _p(kstar), _p(slotrec), _p(vec[0]), _p(vec[1]),
+                                               _p(vec[2]), _p(vec[3]), B, M, K, Co, _p(dzs), _p(partial), nparts, st))
+            # d gamma, d beta, d W_r and the coefficients of  dy = A dz + Bc + D y  (BatchNorm backward is affine in y)
+            coef = torch.empty((5, Co), dtype=torch.float32, device=dev)
+            cA, cB, cD, dgamma, dbeta = coef[0], coef[1], coef[2], coef[3], coef[4]
             dwr = torch.empty((Co, 3), dtype=torch.float32, device=dev)
-            _lib.check(lib.cl3d_pwmlp_reduce_dwr(_p(partial2), nparts, Co, _p(dwr), st))
+            _lib.check(lib.cl3d_pwmlp_bn_backward_coeffs(_p(partial), nparts, Co, float(n), _p(gamma), _p(vec[2]),
+                                                         _p(vec[3]), _p(sums), _p(cA), _p(cB), _p(cD), _p(dgamma),
+                                                         _p(dbeta), _p(dwr), st))
             off, slots = inverse_index(idx, N)
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
             _lib.check(lib.cl3d_pwmlp_bwd_support(_p(idx), _p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(dzs), _p(kstar),
-                                                  _p(slotrec), _p(sq), _p(off), _p(slots), B, N, M, K, Co,
+                                                  _p(slotrec), _p(sy), _p(off), _p(slots), B, N, M, K, Co,
                                                   _p(dght), st))
         return (dght, dwr, dgamma, dbeta) + (None,) * 10
 
@@ -307,6 +304,30 @@ class _PointGemm(Function):
         return dfeat, dweight
 
 
+class _SplitWeight(Function):
+    """W [Co, 3+2C] = [W_r | W_c | W_d]  ->  W_r [Co,3] and the per-point GEMM weight [W_d ; W_c - W_d] [2Co, C].
+
+    One autograd node instead of three slices, a subtraction and a cat: the backward of those is ten
+    launch-latency-sized kernels (zero-filled W-shaped buffers and accumulations)."""
+
+    @staticmethod
+    def forward(ctx, W, C):
+        ctx.C = C
+        wc, wd = W[:, 3:3 + C], W[:, 3 + C:]
+        return W[:, :3].contiguous(), torch.cat([wd, wc - wd], 0)
+
+    @staticmethod
+    def backward(ctx, dwr, dwcat):
+        C = ctx.C
+        Co = dwr.shape[0] if dwr is not None else dwcat.shape[0] // 2
+        if dwcat is None:
+            dwcat = dwr.new_zeros((2 * Co, C))
+        if dwr is None:
+            dwr = dwcat.new_zeros((Co, 3))
+        top, bot = dwcat[:Co], dwcat[Co:]
+        return torch.cat([dwr, bot, top - bot], 1), None
+
+
 def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps, reduction,
                   training):
     assert reduction == 'max'
@@ -315,10 +336,9 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
     C = features.shape[1]
     Co = conv.weight.shape[0]
     W = conv.weight.view(Co, 3 + 2 * C)
-    wr = W[:, :3].contiguous()
-    wc, wd = W[:, 3:3 + C], W[:, 3 + C:]
     # once per point instead of once per (point, neighbour): rows [W_d f_i | (W_c - W_d) f_i]
-    ght = _PointGemm.apply(features, torch.cat([wd, wc - wd], 0))
+    wr, wcat = _SplitWeight.apply(W, C)
+    ght = _PointGemm.apply(features, wcat)
     use_batch_stats = training or bn.running_mean is None
     if use_batch_stats and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)

@@ -153,40 +153,46 @@ int cl3d_maxpool_bwd(const float *gout_t, const unsigned char *kstar_t, const in
 
 /* PointWiseMLP 'dp_fi_df', one Conv2d+BatchNorm2d+ReLU layer, max reduction
  * (local_aggregation_operators.py:288-301).  ght [B,N,2*Co]: row i = [W_d f_i | (W_c - W_d) f_i];
- * wr [Co,3] = the conv weight's columns for the relative position.  See csrc/fused_pwmlp.hip. */
+ * wr [Co,3] = the conv weight's columns for the relative position.  See csrc/fused_pwmlp.hip.
+ * Training forward = stats -> finalize_stats -> apply; inference forward = fwd (running statistics);
+ * backward = bwd_rows -> bn_backward_coeffs -> bwd_support (+ cl3d_build_inverse_index).
+ * Per-(query, channel) arrays are point-major [B,M,Co]; partial buffers are
+ * [cl3d_pwmlp_partials(B,M,Co), Co, 8] doubles. */
 int cl3d_pwmlp_partials(int B, int M, int Co);
+/* the training gather pass: per channel sum y, sum y^2, sum y*rel, sum rel (partial); per (query, channel)
+ * the extreme pre-activation ystar_t that wins the max (max_k y if gamma >= 0 else min_k y), its slot
+ * kstar_t (first one) and sy_t = sum_k y; slotrec [B,M,K,4] = {rel, centre index} per slot. */
 int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
-                     const float *ght, const float *wr, int B, int N, int M, int K, int Co, float radius,
-                     double *partial, int n_partials, cl3d_stream_t stream);
+                     const float *ght, const float *wr, const float *gamma, int B, int N, int M, int K,
+                     int Co, float radius, float *ystar_t, unsigned char *kstar_t, float *sy_t,
+                     float *slotrec, double *partial, int n_partials, cl3d_stream_t stream);
 /* fixed-order reduction of the double partials + per-channel BatchNorm2d algebra (batch mean/variance,
- * scale/shift, running-statistics update with nn.BatchNorm2d's rule; backward coefficients of
- * dy = A dz + Bc + D y together with d gamma / d beta; d W_r [Co,3]). */
+ * scale/shift, running-statistics update with nn.BatchNorm2d's rule; sums [Co,6] doubles kept for the
+ * backward pass).  bn_backward_coeffs: coefficients of dy = A dz [k = k*] + Bc + D y together with
+ * d gamma, d beta and d W_r [Co,3]. */
 int cl3d_pwmlp_finalize_stats(const double *partial, int n_partials, int Co, double count, float eps,
                               float momentum, const float *gamma, const float *beta, float *running_mean,
                               float *running_var, float *scale, float *shift, float *mean, float *invstd,
-                              cl3d_stream_t stream);
-int cl3d_pwmlp_bn_backward_coeffs(const double *partial, int n_partials, int Co, double count,
-                                  const float *gamma, const float *mean, const float *invstd, float *cA,
-                                  float *cB, float *cD, float *dgamma, float *dbeta, cl3d_stream_t stream);
-int cl3d_pwmlp_reduce_dwr(const double *partial, int n_partials, int Co, float *dwr, cl3d_stream_t stream);
+                              double *sums, cl3d_stream_t stream);
+/* out [B,Co,M] = ReLU(scale * ystar + shift)  (== max_k ReLU(BN(y)): the affine map is monotone) */
+int cl3d_pwmlp_apply(const float *ystar_t, const float *scale, const float *shift, int B, int M, int Co,
+                     float *out, cl3d_stream_t stream);
 int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, const int32_t *idx,
                    const float *ght, const float *wr, const float *scale, const float *shift, int B,
                    int N, int M, int K, int Co, float radius, float *out, int out_channel_major,
                    unsigned char *kstar_t, float *slotrec, cl3d_stream_t stream);
-int cl3d_pwmlp_bwd_sparse(const float *query_xyz, const float *support_xyz, const int32_t *idx,
-                          const float *ght, const float *wr, const float *scale, const float *shift,
-                          const float *mean, const float *invstd, const float *gout,
-                          int gout_channel_major, const unsigned char *kstar_t, int B, int N, int M, int K,
-                          int Co, float radius, float *dzs_t, double *partial, int n_partials,
-                          cl3d_stream_t stream);
-int cl3d_pwmlp_bwd_query(const float *query_xyz, const float *support_xyz, const int32_t *idx,
-                         const float *ght, const float *wr, const float *cA, const float *cB,
-                         const float *cD, const float *dzs_t, const unsigned char *kstar_t, int B, int N,
-                         int M, int K, int Co, float radius, float *sq_t, double *partial, int n_partials,
-                         cl3d_stream_t stream);
+/* dzs_t = gout gated by the ReLU at the arg-max; partial: sum dz, sum dz*xhat, sum dz*rel(k*) */
+int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, const float *ystar_t,
+                        const unsigned char *kstar_t, const float *slotrec, const float *scale,
+                        const float *shift, const float *mean, const float *invstd, int B, int M, int K,
+                        int Co, float *dzs_t, double *partial, int n_partials, cl3d_stream_t stream);
+int cl3d_pwmlp_bn_backward_coeffs(const double *partial, int n_partials, int Co, double count,
+                                  const float *gamma, const float *mean, const float *invstd,
+                                  const double *sums, float *cA, float *cB, float *cD, float *dgamma,
+                                  float *dbeta, float *dwr, cl3d_stream_t stream);
 int cl3d_pwmlp_bwd_support(const int32_t *idx, const float *ght, const float *wr, const float *cA,
                            const float *cB, const float *cD, const float *dzs_t,
-                           const unsigned char *kstar_t, const float *slotrec, const float *sq_t,
+                           const unsigned char *kstar_t, const float *slotrec, const float *sy_t,
                            const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K,
                            int Co, float *dght, cl3d_stream_t stream);
 
