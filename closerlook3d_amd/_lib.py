@@ -33,11 +33,12 @@ SIGNATURES = {
     "cl3d_maxpool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cl3d_maxpool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_partials": [_I, _I, _I],
-    "cl3d_pwmlp_stats": [_P] * 6 + [_I] * 5 + [_F, _P, _P, _P, _P, _P, _I, _P],
+    "cl3d_pwmlp_stats": [_P] * 6 + [_I] * 5 + [_F, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "cl3d_pwmlp_finalize_stats": [_P, _I, _I, ctypes.c_double, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "cl3d_pwmlp_apply": [_P, _P, _P, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P],
-    "cl3d_pwmlp_bwd_rows": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _I, _P],
+    "cl3d_pwmlp_bwd_rows": [_P, _I] + [_P] * 8 + [_I] * 4 + [_P, _P, _P, _I, _P],
+    "cl3d_pwmlp_bwd_hits": [_P, _P, _I, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_bn_backward_coeffs": [_P, _I, _I, ctypes.c_double] + [_P] * 11,
     "cl3d_pwmlp_bwd_support": [_P] * 12 + [_I] * 5 + [_P, _P],
 }

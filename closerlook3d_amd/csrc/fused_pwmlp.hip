@@ -33,7 +33,6 @@
 namespace cl3d {
 
 enum { PW_TRAIN = 0, PW_FWD = 1 };
-constexpr int kSlotBatch = 8;  // row gathers in flight per lane
 constexpr int kPartialW = 8;   // doubles per (block, channel) in the partial-sum buffers
 
 struct PwArgs {
@@ -42,14 +41,16 @@ struct PwArgs {
   const float *ght;  // [B,N,2Co]
   const float *wr;   // [Co,3]
   const float *v0, *v1, *v2;  // per-channel vectors: TRAIN gamma | FWD scale,shift | SUPPORT A,Bc,D
-  const float *dzs_in;             // [B,M,Co]
-  const unsigned char *kstar_in;   // [B,M,Co]
-  const float *sy_in;              // [B,M,Co]
   float *out_t;                    // FWD
   int out_channel_major;
   float *ystar_t, *sy_t;           // TRAIN: [B,M,Co]
   unsigned char *kstar_out;        // TRAIN / FWD
   float4 *slotrec;                 // TRAIN / FWD write {rel, centre index} (may be null); SUPPORT reads
+  float *hq_t;                     // TRAIN: [B,M,Co] H row of each query's centre (may be null); SUPPORT reads
+  int *tstar_t;                    // TRAIN: [B,M,Co] support index of the arg-max slot (may be null)
+  const float *hit_cm;             // SUPPORT: [B,Co,N] sum of arg-max dz per support point (channel-major)
+  const float *dz_cm;              // SUPPORT: [B,Co,M] gated upstream gradient (channel-major)
+  const float *sy_in;              // SUPPORT: [B,M,Co]
   double *partial;                 // [gridDim.x, Co, kPartialW]
   const int *inv_off, *inv_slots;
   float *dght;                     // SUPPORT: [B,N,2Co]
@@ -68,8 +69,8 @@ __device__ __forceinline__ float pw_preact(const float w[3], float rx, float ry,
 // query-major gather passes.  Persistent blocks: tile = 4*QW queries of one cloud.
 // V == 4 is only used when Co % 4 == 0 and V == 1 rows are single elements, so a lane with c0 < Co always
 // owns a full vector: every row access is one global_load_dwordx4 / dword.
-template <int MODE, int V>
-__global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
+template <int MODE, int V, int KB, int WPE>  // KB = row gathers in flight per lane, WPE = waves per SIMD to fit
+__global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
   extern __shared__ float4 lds4[];
   const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
   const int TQ = 4 * QW;
@@ -87,13 +88,56 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
   for (int ch = 0; ch < a.chunks; ++ch) {
     const int c0 = (ch * L + cl) * V;
     const bool chan_on = lane_on && c0 < Co;
-    // sum y, sum y^2, S_0..2 per channel; R_0..2 (sum rel) is the same for every channel of the lane
-    constexpr int NCH = NACC > 0 ? 5 : 1;
-    double dacc[NCH][V], drel[3] = {0.0, 0.0, 0.0};
+    // TRAIN: a lane sums its queries' {sum y, sum y^2, S_0..2, R_0..2} in float (a few hundred terms at most
+    // between flushes); every kFlushTiles tiles the lane groups of a wave are folded in a fixed order and
+    // group 0 adds the result to the wave's double accumulators in LDS, one slot per (wave, channel) -- no
+    // atomics, and half the VGPRs of double register accumulators, which the gather loop's occupancy needs
+    constexpr int kFlushTiles = 16;
+    constexpr int NF = NACC > 0 ? 5 : 1;
+    float accf[NF][V], accr[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int p = 0; p < NCH; ++p)
+    for (int p = 0; p < NF; ++p)
 #pragma unroll
-      for (int v = 0; v < V; ++v) dacc[p][v] = 0.0;
+      for (int v = 0; v < V; ++v) accf[p][v] = 0.f;
+    int since_flush = 0;
+    const int LVN = L * V * NACC;
+    if constexpr (NACC > 0) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < 4 * LVN; t += 256) red[t] = 0.0;
+      __syncthreads();
+    }
+    // lane group gg of the wave = lanes [gg*L, gg*L+L); L need not be a power of two
+    auto fold_groups = [&](float x) {
+      float tot = x;
+      for (int gg = 1; gg * L + L <= CL3D_WAVE; ++gg) tot += __shfl(x, cl + gg * L, CL3D_WAVE);
+      return tot;  // meaningful in group 0
+    };
+    auto flush = [&]() {  // every lane of the wave takes part in the shuffles
+      float f[NF][V], fr[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fr[p] = fold_groups(accr[p]);
+#pragma unroll
+      for (int p = 0; p < NF; ++p)
+#pragma unroll
+        for (int v = 0; v < V; ++v) f[p][v] = fold_groups(accf[p][v]);
+      if (g == 0) {
+        double *mine = red + (size_t)wave * LVN + cl * V * NACC;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+#pragma unroll
+          for (int p = 0; p < NF; ++p) mine[v * NACC + p] += (double)f[p][v];
+#pragma unroll
+          for (int p = 0; p < 3; ++p) mine[v * NACC + NF + p] += (double)fr[p];
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) accr[p] = 0.f;
+#pragma unroll
+      for (int p = 0; p < NF; ++p)
+#pragma unroll
+        for (int v = 0; v < V; ++v) accf[p][v] = 0.f;
+      since_flush = 0;
+    };
     float w[V][3], c_v0[V], c_v1[V];
 #pragma unroll
     for (int v = 0; v < V; ++v) {
@@ -130,11 +174,15 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
       __syncthreads();
       const int jq = wave * QW + g;
       const int j = j0 + jq;
-      if (!chan_on || j >= M) continue;
-      const float4 *myslots = slot4 + jq * K;
+      const bool q_on = chan_on && j < M;
+      if (MODE != PW_TRAIN && !q_on) continue;
+      const float4 *myslots = slot4 + (q_on ? jq : 0) * K;
       const float *rows = a.ght + (size_t)b * N * row;
       const int ic = __float_as_int(myslots[0].x);  // centre = nearest neighbour (reference :290)
-      const Vec<V> hc = load_row<V>(rows + (size_t)ic * row + Co + c0);
+      Vec<V> hc;
+#pragma unroll
+      for (int v = 0; v < V; ++v) hc.v[v] = 0.f;
+      if (q_on) hc = load_row<V>(rows + (size_t)ic * row + Co + c0);
       const size_t orow = ((size_t)b * M + j) * Co + c0;
 
       if constexpr (MODE == PW_TRAIN) {
@@ -147,7 +195,8 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
           kb[v] = 0;
           sgn[v] = c_v0[v] < 0.f ? -1.f : 1.f;  // sign(gamma) = sign(scale): which extreme of y wins the max
         }
-        for_each_slot<V, kSlotBatch>(myslots, K, rows, row, c0, [&](int k, const float4 &sr, const Vec<V> &gr) {
+        if (q_on) {
+        for_each_slot<V, KB>(myslots, K, rows, row, c0, [&](int k, const float4 &sr, const Vec<V> &gr) {
           rs0 += sr.y;
           rs1 += sr.z;
           rs2 += sr.w;
@@ -171,15 +220,7 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
         for (int v = 0; v < V; ++v) {
           ys.v[v] = sgn[v] * best[v];
           sy.v[v] = s1[v];
-          dacc[0][v] += (double)s1[v];
-          dacc[1][v] += (double)s2[v];
-          dacc[2][v] += (double)sr0[v];
-          dacc[3][v] += (double)sr1[v];
-          dacc[4][v] += (double)sr2[v];
         }
-        drel[0] += (double)rs0;
-        drel[1] += (double)rs1;
-        drel[2] += (double)rs2;
         store_row<V>(a.ystar_t + orow, ys);
         store_row<V>(a.sy_t + orow, sy);
         if constexpr (V == 4) {
@@ -188,6 +229,24 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
         } else {
           a.kstar_out[orow] = (unsigned char)kb[0];
         }
+        if (a.hq_t != nullptr) store_row<V>(a.hq_t + orow, hc);
+        if (a.tstar_t != nullptr) {
+#pragma unroll
+          for (int v = 0; v < V; ++v) a.tstar_t[orow + v] = __float_as_int(myslots[kb[v]].x);
+        }
+        }  // q_on
+        accr[0] += rs0;
+        accr[1] += rs1;
+        accr[2] += rs2;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          accf[0][v] += s1[v];
+          accf[1][v] += s2[v];
+          accf[2][v] += sr0[v];
+          accf[3][v] += sr1[v];
+          accf[4][v] += sr2[v];
+        }
+        if (++since_flush == kFlushTiles) flush();  // uniform: every thread of the block walks the same tiles
       } else {  // PW_FWD
         float best[V];
         int kb[V];
@@ -196,7 +255,7 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
           best[v] = 0.f;
           kb[v] = 0;
         }
-        for_each_slot<V, kSlotBatch>(myslots, K, rows, row, c0, [&](int k, const float4 &sr, const Vec<V> &gr) {
+        for_each_slot<V, KB>(myslots, K, rows, row, c0, [&](int k, const float4 &sr, const Vec<V> &gr) {
 #pragma unroll
           for (int v = 0; v < V; ++v) {
             const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gr.v[v]);
@@ -218,35 +277,12 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
       }
     }
 
-    if constexpr (NACC > 0) {
-      // fixed-order reduction of the double partials of this chunk: lane groups of a wave by shuffles
-      // (lanes that own no query hold zeros), the four waves through LDS
-      // (lane group gg of the wave = lanes [gg*L, gg*L+L); L need not be a power of two)
-      auto fold_groups = [&](double x) {
-        double tot = x;
-        for (int gg = 1; gg * L + L <= CL3D_WAVE; ++gg) tot += __shfl(x, cl + gg * L, CL3D_WAVE);
-        return tot;  // meaningful in group 0
-      };
-#pragma unroll
-      for (int p = 0; p < NCH; ++p)
-#pragma unroll
-        for (int v = 0; v < V; ++v) dacc[p][v] = fold_groups(dacc[p][v]);
-#pragma unroll
-      for (int p = 0; p < 3; ++p) drel[p] = fold_groups(drel[p]);
-      const int LV = L * V;
-      const int slice = LV * NACC;
+    if constexpr (NACC > 0) {  // the four waves' banks, in wave order
+      if (since_flush > 0) flush();
       __syncthreads();
-      if (g == 0) {
-        double *mine = red + (size_t)wave * slice + cl * V * NACC;
-#pragma unroll
-        for (int v = 0; v < V; ++v)
-#pragma unroll
-          for (int p = 0; p < NACC; ++p) mine[v * NACC + p] = p < NCH ? dacc[p < NCH ? p : 0][v] : drel[p >= NCH ? p - NCH : 0];
-      }
-      __syncthreads();
-      for (int t = threadIdx.x; t < slice; t += 256) {
-        const double sum = ((red[t] + red[slice + t]) + red[2 * slice + t]) + red[3 * slice + t];
-        const int c = ch * LV + t / NACC;
+      for (int t = threadIdx.x; t < LVN; t += 256) {
+        const double sum = ((red[t] + red[LVN + t]) + red[2 * LVN + t]) + red[3 * LVN + t];
+        const int c = ch * L * V + t / NACC;
         if (c < Co) a.partial[((size_t)blockIdx.x * Co + c) * kPartialW + (t - (t / NACC) * NACC)] = sum;
       }
       __syncthreads();
@@ -254,9 +290,82 @@ __global__ __launch_bounds__(256) void pwmlp_query_kernel(PwArgs a) {
   }
 }
 
-// support-major dense backward pass through the CSR inverse
-template <int V>
-__global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
+// ---- the arg-max term of the backward pass.  ReLU + max route dz(j,c) to ONE slot per (query, channel),
+// i.e. to support point tstar(j,c): a scatter with one target per element.  A workgroup owns (cloud, 4
+// channels, a range of T support points), streams those channels' (dz, tstar) rows -- channel-major, so
+// fully coalesced -- and accumulates in LDS in double (ds_add_f64: sums of a few dozen floats are exact in
+// 53 bits unless their magnitudes span more than ~2^22, so the result does not depend on the order the
+// adds arrive in).  Same structure as group_bwd_lds_kernel.
+struct HitArgs {
+  const float *dz_cm;   // [B,Co,M]
+  const int *ts_cm;     // [B,Co,M]
+  float *hit_cm;        // [B,Co,N]
+  int B, N, M, Co, T;
+};
+
+__global__ __launch_bounds__(1024) void pwmlp_hit_kernel(HitArgs a) {
+  extern __shared__ double hacc[];  // [4][T]
+  const int c0 = blockIdx.x * 4;
+  const int n0 = blockIdx.y * a.T;
+  const int b = blockIdx.z;
+  const int M = a.M, T = a.T;
+  const int nch = a.Co - c0 < 4 ? a.Co - c0 : 4;
+  const unsigned span = (unsigned)(a.N - n0 < T ? a.N - n0 : T);
+  for (int t = threadIdx.x; t < 4 * T; t += 1024) hacc[t] = 0.0;
+  __syncthreads();
+  const float *dz = a.dz_cm + ((size_t)b * a.Co + c0) * M;
+  const int *ts = a.ts_cm + ((size_t)b * a.Co + c0) * M;
+  if ((M & 3) == 0) {
+    for (int j = threadIdx.x * 4; j < M; j += 4096) {
+      float4 d[4];
+      int4 t[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const size_t o = (size_t)(v < nch ? v : 0) * M + j;
+        d[v] = *reinterpret_cast<const float4 *>(dz + o);
+        t[v] = *reinterpret_cast<const int4 *>(ts + o);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        if (v >= nch) break;
+        double *hv = hacc + (size_t)v * T;
+        if (d[v].x != 0.f && (unsigned)(t[v].x - n0) < span) atomicAdd(&hv[t[v].x - n0], (double)d[v].x);
+        if (d[v].y != 0.f && (unsigned)(t[v].y - n0) < span) atomicAdd(&hv[t[v].y - n0], (double)d[v].y);
+        if (d[v].z != 0.f && (unsigned)(t[v].z - n0) < span) atomicAdd(&hv[t[v].z - n0], (double)d[v].z);
+        if (d[v].w != 0.f && (unsigned)(t[v].w - n0) < span) atomicAdd(&hv[t[v].w - n0], (double)d[v].w);
+      }
+    }
+  } else {
+    for (int j = threadIdx.x; j < M; j += 1024)
+      for (int v = 0; v < nch; ++v) {
+        const float d = dz[(size_t)v * M + j];
+        const int t = ts[(size_t)v * M + j];
+        if (d != 0.f && (unsigned)(t - n0) < span) atomicAdd(&hacc[(size_t)v * T + t - n0], (double)d);
+      }
+  }
+  __syncthreads();
+  for (int v = 0; v < nch; ++v)
+    for (int i = threadIdx.x; i < (int)span; i += 1024)
+      a.hit_cm[((size_t)b * a.Co + c0 + v) * a.N + n0 + i] = (float)hacc[(size_t)v * T + i];
+}
+
+// support-major backward pass through the CSR inverse of idx.  For support point i with slot list S_i:
+//   dG_i = sum_{s in S_i} dy_s,  dy_s = D y_s + Bc + A dz [slot s is the arg-max],  y_s = W_r rel_s + H[centre_s] + G_i
+//        = D (W_r . sum rel_s + sum H[centre_s] + |S_i| G_i) + |S_i| Bc + A hit_i
+// so a slot costs its slotrec (rel) and one row of hq_t (= H[centre] per query, left behind by the forward
+// pass); hit_i = the arg-max term from pwmlp_hit_kernel.
+// dH_i = sum over the queries centred on i (= the slots (j,0) of S_i, reference :290) of
+//        D sum_k y + K Bc + A dz  (sum_k y was left behind by the forward pass).
+// Staged like the forward kernels: the slot lists of a tile's TR consecutive points are ONE contiguous range
+// of inv_slots, so the whole block loads it (and the slotrec of every slot) coalesced / fully parallel into
+// LDS records {rel, query id | centre flag}; the lane groups then walk their rows out of LDS and the only
+// global loads left in the loop are batches of independent hq-row gathers.
+constexpr int kSupCap = 1024;  // slot records staged per round (16 KiB)
+constexpr unsigned kCentreFlag = 0x80000000u;
+
+template <int V, int SB, int WPE>  // SB = hq rows in flight per lane, WPE = waves per SIMD the register budget allows
+__global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
+  __shared__ float4 srec[kSupCap];
   const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
   const int row = 2 * Co;
   const int MK = M * K;
@@ -264,93 +373,130 @@ __global__ __launch_bounds__(256) void pwmlp_support_kernel(PwArgs a) {
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int g = lane / L, cl = lane - g * L;
-  if (g >= QW) return;
   const int tiles_per_cloud = (N + TR - 1) / TR;
   const int ntiles = a.B * tiles_per_cloud;
   for (int ch = 0; ch < a.chunks; ++ch) {
     const int c0 = (ch * L + cl) * V;
-    if (c0 >= Co) continue;
-    float w[V][3], cA[V], cB[V], cD[V], kBc[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const int c = c0 + v;
-      w[v][0] = a.wr[c * 3 + 0];
-      w[v][1] = a.wr[c * 3 + 1];
-      w[v][2] = a.wr[c * 3 + 2];
-      cA[v] = a.v0[c];
-      cB[v] = a.v1[c];
-      cD[v] = a.v2[c];
-      kBc[v] = (float)K * cB[v];
-    }
+    const bool chan_on = g < QW && c0 < Co;
+    // per-channel constants are (re)loaded where they are used -- the row epilogue and the rare centre
+    // term -- instead of being held across the gather loop: the loop's occupancy is what this pass lives on
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       int b, tr;
       decode_tile(tile, a.B, tiles_per_cloud, b, tr);
-      const int i = tr * TR + wave * QW + g;
-      if (i >= N) continue;
-      const float *rows = a.ght + (size_t)b * N * row;
+      const int i0 = tr * TR;
+      const int i = i0 + wave * QW + g;
+      const bool row_on = chan_on && i < N;
       const int *off = a.inv_off + (size_t)b * (N + 1);
       const int *slots = a.inv_slots + (size_t)b * MK;
       const float4 *rec = a.slotrec + (size_t)b * MK;
-      const Vec<V> gi = load_row<V>(rows + (size_t)i * row + c0);
-      float acc[V], acch[V];
-#pragma unroll
-      for (int v = 0; v < V; ++v) acc[v] = acch[v] = 0.f;
-      const int s0 = off[i], s1 = off[i + 1];
-      const float *dzrow = a.dzs_in + (size_t)b * M * Co + c0;
-      const unsigned char *ksrow = a.kstar_in + (size_t)b * M * Co + c0;
+      const float *hqrow = a.hq_t + (size_t)b * M * Co + c0;
       const float *syrow = a.sy_in + (size_t)b * M * Co + c0;
-      constexpr int SB = 4;  // slots per batch: 3*SB independent row gathers in flight per lane
-      for (int e = s0; e < s1; e += SB) {
-        int sl[SB];
-        float4 r[SB];
-        Vec<V> hc[SB], dz[SB], sqv[SB];
-        unsigned ksw[SB];
-        bool centre[SB];
+      const float *dzcol = a.dz_cm + ((size_t)b * Co + c0) * M;
+      const int e_lo = off[i0], e_hi = off[i0 + TR < N ? i0 + TR : N];
+      const int ic = i < N ? i : N - 1;
+      const int s0 = off[ic], s1 = off[ic + 1];
+      float shc[V], csy[V], cdz[V];  // sum of H rows; sum_k y and dz summed over the queries centred here
+      float r0 = 0.f, r1 = 0.f, r2 = 0.f, ncen = 0.f;
 #pragma unroll
-        for (int u = 0; u < SB; ++u) sl[u] = slots[e + u < s1 ? e + u : s1 - 1];
+      for (int v = 0; v < V; ++v) shc[v] = csy[v] = cdz[v] = 0.f;
+      for (int cbeg = e_lo; cbeg < e_hi; cbeg += kSupCap) {
+        const int cn = e_hi - cbeg < kSupCap ? e_hi - cbeg : kSupCap;
+        __syncthreads();  // the previous round's records have been consumed
+        for (int t0 = 0; t0 < cn; t0 += 256 * 4) {
+          int sl[4];
+          float4 rr[4];
 #pragma unroll
-        for (int u = 0; u < SB; ++u) r[u] = rec[sl[u]];
+          for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * 256 + (int)threadIdx.x;
+            sl[u] = slots[cbeg + (t < cn ? t : cn - 1)];
+          }
 #pragma unroll
-        for (int u = 0; u < SB; ++u) {
-          const int j = sl[u] / K;
-          hc[u] = load_row<V>(rows + (size_t)__float_as_int(r[u].w) * row + Co + c0);
-          dz[u] = load_row<V>(dzrow + (size_t)j * Co);
-          if constexpr (V == 4) ksw[u] = *reinterpret_cast<const unsigned *>(ksrow + (size_t)j * Co);
-          else ksw[u] = ksrow[(size_t)j * Co];
-          // slot 0 of a query is its centre (reference :290): the rows whose slot list holds (j, 0) are exactly
-          // the queries centred on this point, so the centre-feature gradient needs no table of its own.
-          // sum_k dy of that query = D sum_k y + K Bc + A dz  (sum_k y was left behind by the forward pass)
+          for (int u = 0; u < 4; ++u) rr[u] = rec[sl[u]];
 #pragma unroll
-          for (int v = 0; v < V; ++v) sqv[u].v[v] = 0.f;
-          centre[u] = sl[u] - j * K == 0;
-          if (centre[u]) sqv[u] = load_row<V>(syrow + (size_t)j * Co);
+          for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * 256 + (int)threadIdx.x;
+            if (t < cn) {
+              const int j = sl[u] / K;
+              const unsigned tag = (unsigned)j | (sl[u] - j * K == 0 ? kCentreFlag : 0u);
+              srec[t] = make_float4(rr[u].x, rr[u].y, rr[u].z, __uint_as_float(tag));
+            }
+          }
         }
+        __syncthreads();
+        if (!row_on) continue;
+        const int lo = s0 > cbeg ? s0 : cbeg;
+        const int hi = s1 < cbeg + cn ? s1 : cbeg + cn;
+        for (int e = lo; e < hi; e += SB) {
+          unsigned tags[SB];
+          Vec<V> hc[SB];
+          int jc = -1, ncb = 0;
 #pragma unroll
-        for (int u = 0; u < SB; ++u) {
-          if (e + u >= s1) continue;
-          const int k = sl[u] - (sl[u] / K) * K;
+          for (int u = 0; u < SB; ++u) {  // rel is summed straight out of LDS; only the query ids stay in registers
+            const float4 rr = srec[(e + u < hi ? e + u : hi - 1) - cbeg];
+            const bool live = e + u < hi;
+            r0 += live ? rr.x : 0.f;
+            r1 += live ? rr.y : 0.f;
+            r2 += live ? rr.z : 0.f;
+            tags[u] = __float_as_uint(rr.w);
+            if ((tags[u] & kCentreFlag) != 0u && live) {
+              if (jc < 0) jc = (int)(tags[u] & ~kCentreFlag);  // first centred query of the batch
+              ++ncb;
+            }
+          }
 #pragma unroll
-          for (int v = 0; v < V; ++v) {
-            const int ks = (int)((ksw[u] >> (8 * v)) & 0xffu);
-            const float y = pw_preact(w[v], r[u].x, r[u].y, r[u].z, hc[u].v[v], gi.v[v]);
-            float dy = __builtin_fmaf(cD[v], y, cB[v]);
-            dy += (k == ks) ? dz[u].v[v] * cA[v] : 0.f;
-            acc[v] += dy;
-            if (centre[u]) acch[v] += __builtin_fmaf(cD[v], sqv[u].v[v], __builtin_fmaf(cA[v], dz[u].v[v], kBc[v]));
+          for (int u = 0; u < SB; ++u) hc[u] = load_row<V>(hqrow + (size_t)(tags[u] & ~kCentreFlag) * Co);
+          if (jc >= 0) {  // about one slot per row: its loads ride along with the batch
+            const Vec<V> sy = load_row<V>(syrow + (size_t)jc * Co);
+            ncen += 1.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              csy[v] += sy.v[v];
+              cdz[v] += dzcol[(size_t)v * M + jc];
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < SB; ++u) {
+            if (e + u >= hi) continue;
+#pragma unroll
+            for (int v = 0; v < V; ++v) shc[v] += hc[u].v[v];
+          }
+          if (ncb > 1) {  // several queries centred on this point inside one batch (duplicate points): rare, slow path
+            int seen = 0;
+            for (int u = 0; u < SB && e + u < hi; ++u) {
+              const unsigned tag = __float_as_uint(srec[e + u - cbeg].w);
+              if ((tag & kCentreFlag) == 0u || seen++ == 0) continue;
+              const int j2 = (int)(tag & ~kCentreFlag);
+              const Vec<V> sy = load_row<V>(syrow + (size_t)j2 * Co);
+              ncen += 1.f;
+#pragma unroll
+              for (int v = 0; v < V; ++v) {
+                csy[v] += sy.v[v];
+                cdz[v] += dzcol[(size_t)v * M + j2];
+              }
+            }
           }
         }
       }
+      if (!row_on) continue;
+      const float cnt = (float)(s1 - s0);
+      const Vec<V> gi = load_row<V>(a.ght + ((size_t)b * N + i) * row + c0);
       float *dst = a.dght + ((size_t)b * N + i) * row + c0;
       _Pragma("unroll") for (int v = 0; v < V; ++v) {
-        dst[v] = acc[v];
-        dst[Co + v] = acch[v];
+        const int c = c0 + v;
+        const float hit = a.hit_cm[((size_t)b * Co + c) * N + i];
+        float t = a.wr[c * 3 + 0] * r0;
+        t = __builtin_fmaf(a.wr[c * 3 + 1], r1, t);
+        t = __builtin_fmaf(a.wr[c * 3 + 2], r2, t);
+        const float ysum = (t + shc[v]) + cnt * gi.v[v];
+        dst[v] = __builtin_fmaf(a.v2[c], ysum, __builtin_fmaf(a.v0[c], hit, cnt * a.v1[c]));
+        dst[Co + v] = __builtin_fmaf(a.v2[c], csy[v], __builtin_fmaf(a.v0[c], cdz[v], ncen * ((float)K * a.v1[c])));
       }
     }
   }
 }
 
 // ---- element-wise passes over the per-(query, channel) rows ------------------------------------------
-// Tile = 64 queries x CW channels (CW a power of two <= 128: Co is walked in its binary decomposition, so a
+// Tile = 64 queries x CW channels (CW a power of two <= 64: Co is walked in its binary decomposition, so a
 // thread keeps ONE channel for the whole pass and its partial sums stay in registers).  The channel-major
 // side of the transposition ([B,Co,M] output / upstream gradient) goes through an LDS tile, so both sides
 // are read and written in full 256-byte rows.
@@ -360,26 +506,29 @@ constexpr int kRowsBatch = 4;
 struct RowArgs {
   const float *ystar_t;           // [B,M,Co]
   const unsigned char *kstar_t;   // [B,M,Co]
+  const int *tstar_t;             // [B,M,Co]
   const float4 *slotrec;          // [B,M,K]
   const float *gout;              // [B,Co,M] (channel-major) or [B,M,Co]
   int gout_channel_major;
   const float *scale, *shift, *mean, *invstd;
   float *out;                     // APPLY: [B,Co,M]
-  float *dzs_t;                   // BWD: [B,M,Co]
+  float *dz_cm;                   // BWD: [B,Co,M] gated upstream gradient
+  int *ts_cm;                     // BWD: [B,Co,M] tstar, transposed for the hit pass
   double *partial;                // BWD: [gridDim.x, Co, kPartialW]
   int B, M, K, Co;
 };
 
 template <int MODE>
 __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
-  __shared__ float tile[128 * 65];
+  __shared__ float tile[64 * 65];
+  __shared__ int tile2[MODE == ROWS_BWD ? 64 * 65 : 1];
   __shared__ double red[MODE == ROWS_BWD ? 256 * 5 : 1];
   const int M = a.M, Co = a.Co, K = a.K;
   const int tid = threadIdx.x;
   const int tiles_per_cloud = (M + 63) / 64;
   const int ntiles = a.B * tiles_per_cloud;
   for (int cbase = 0; cbase < Co;) {
-    int CW = 128;
+    int CW = 64;
     while (CW > Co - cbase) CW >>= 1;
     const int cl = tid & (CW - 1), r0 = tid / CW, RS = 256 / CW;
     const int c = cbase + cl;
@@ -414,7 +563,7 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
         }
         for (int jb = r0; jb < nj; jb += RS * kRowsBatch) {
           float y[kRowsBatch], gq[kRowsBatch];
-          int ks[kRowsBatch];
+          int ks[kRowsBatch], ts[kRowsBatch];
           float4 rel[kRowsBatch];
 #pragma unroll
           for (int u = 0; u < kRowsBatch; ++u) {
@@ -422,6 +571,7 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
             const size_t e = ((size_t)b * M + j0 + jq) * Co + c;
             y[u] = a.ystar_t[e];
             ks[u] = a.kstar_t[e];
+            ts[u] = a.tstar_t[e];
             gq[u] = a.gout_channel_major ? tile[cl * 65 + jq] : a.gout[e];
           }
 #pragma unroll
@@ -435,7 +585,8 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
             if (jq >= nj) continue;
             const float z = __builtin_fmaf(y[u], scale, shift);
             const float dz = z > 0.f ? gq[u] : 0.f;
-            a.dzs_t[((size_t)b * M + j0 + jq) * Co + c] = dz;
+            tile[cl * 65 + jq] = dz;  // own element of the tile: overwritten in place, transposed out below
+            tile2[cl * 65 + jq] = ts[u];
             acc[0] += (double)dz;
             acc[1] += (double)(dz * ((y[u] - mean) * invstd));
             acc[2] += (double)(dz * rel[u].x);
@@ -443,7 +594,16 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
             acc[4] += (double)(dz * rel[u].z);
           }
         }
-        if (a.gout_channel_major) __syncthreads();  // the tile is overwritten by the next iteration
+        __syncthreads();
+        for (int e = tid; e < CW * 64; e += 256) {  // dz and its target, channel-major, for the hit pass
+          const int cc = e >> 6, jq = e & 63;
+          if (jq < nj) {
+            const size_t o = ((size_t)b * Co + cbase + cc) * M + j0 + jq;
+            a.dz_cm[o] = tile[cc * 65 + jq];
+            a.ts_cm[o] = tile2[cc * 65 + jq];
+          }
+        }
+        __syncthreads();  // the tile is overwritten by the next iteration
       } else {
         for (int jb = r0; jb < nj; jb += RS * kRowsBatch) {
           float y[kRowsBatch];
@@ -594,8 +754,10 @@ static int launch_query(PwArgs &a, int nacc, int n_partials, hipStream_t st, con
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)a.B * ceil_div(a.M, 4 * m.QW);
   const int gx = nacc > 0 ? n_partials : round_grid(tiles, 8192);
-  if (V == 4) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4>), dim3(gx), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1>), dim3(gx), dim3(256), lds, st, a);
+  // measured at the metric shape (TRAIN): 8 gathers in flight at 3 waves/SIMD 87 us, 6 at 3 89 us, 4 at 4 76 us:
+  // occupancy buys more than depth per wave
+  if (V == 4) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4>), dim3(gx), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1, 8, 4>), dim3(gx), dim3(256), lds, st, a);
   return check_launch(who);
 }
 
@@ -609,12 +771,13 @@ extern "C" int cl3d_pwmlp_partials(int B, int M, int Co) {
 extern "C" int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
                                 const float *ght, const float *wr, const float *gamma, int B, int N, int M,
                                 int K, int Co, float radius, float *ystar_t, unsigned char *kstar_t,
-                                float *sy_t, float *slotrec, double *partial, int n_partials,
-                                cl3d_stream_t stream) {
+                                int32_t *tstar_t, float *sy_t, float *slotrec, float *hq_t, double *partial,
+                                int n_partials, cl3d_stream_t stream) {
   using namespace cl3d;
   PwArgs a{};
   a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr; a.v0 = gamma;
   a.ystar_t = ystar_t; a.kstar_out = kstar_t; a.sy_t = sy_t; a.slotrec = reinterpret_cast<float4 *>(slotrec);
+  a.hq_t = hq_t; a.tstar_t = tstar_t;
   a.partial = partial;
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
   int rc = pw_check(a, "pwmlp_stats");
@@ -687,38 +850,65 @@ extern "C" int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, 
 }
 
 extern "C" int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, const float *ystar_t,
-                                   const unsigned char *kstar_t, const float *slotrec, const float *scale,
-                                   const float *shift, const float *mean, const float *invstd, int B, int M,
-                                   int K, int Co, float *dzs_t, double *partial, int n_partials,
-                                   cl3d_stream_t stream) {
+                                   const unsigned char *kstar_t, const int32_t *tstar_t, const float *slotrec,
+                                   const float *scale, const float *shift, const float *mean, const float *invstd,
+                                   int B, int M, int K, int Co, float *dz_cm, int32_t *ts_cm, double *partial,
+                                   int n_partials, cl3d_stream_t stream) {
   using namespace cl3d;
   CL3D_REQUIRE(B >= 0 && M >= 1 && K >= 1 && K <= 255 && Co >= 1, "pwmlp_bwd_rows: bad sizes");
-  CL3D_REQUIRE(gout && ystar_t && kstar_t && slotrec && scale && shift && mean && invstd && dzs_t && partial,
+  CL3D_REQUIRE(gout && ystar_t && kstar_t && tstar_t && slotrec && scale && shift && mean && invstd && dz_cm && ts_cm &&
+                   partial,
                "pwmlp_bwd_rows: null pointer");
   CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_bwd_rows: wrong partial block count");
   if (B == 0) return CL3D_OK;
   RowArgs a{};
+  a.tstar_t = tstar_t; a.dz_cm = dz_cm; a.ts_cm = ts_cm;
   a.gout = gout; a.gout_channel_major = gout_channel_major; a.ystar_t = ystar_t; a.kstar_t = kstar_t;
   a.slotrec = reinterpret_cast<const float4 *>(slotrec); a.scale = scale; a.shift = shift; a.mean = mean;
-  a.invstd = invstd; a.dzs_t = dzs_t; a.partial = partial; a.B = B; a.M = M; a.K = K; a.Co = Co;
+  a.invstd = invstd; a.partial = partial; a.B = B; a.M = M; a.K = K; a.Co = Co;
   hipLaunchKernelGGL((pwmlp_rows_kernel<ROWS_BWD>), dim3(n_partials), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_bwd_rows");
 }
 
-extern "C" int cl3d_pwmlp_bwd_support(const int32_t *idx, const float *ght, const float *wr, const float *cA,
-                                      const float *cB, const float *cD, const float *dzs_t,
-                                      const unsigned char *kstar_t, const float *slotrec, const float *sy_t,
-                                      const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M,
-                                      int K, int Co, float *dght, cl3d_stream_t stream) {
+extern "C" int cl3d_pwmlp_bwd_hits(const float *dz_cm, const int32_t *ts_cm, int B, int N, int M, int Co,
+                                   float *hit_cm, cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(B >= 0 && N >= 1 && M >= 1 && Co >= 1, "pwmlp_bwd_hits: bad sizes");
+  CL3D_REQUIRE(dz_cm && ts_cm && hit_cm, "pwmlp_bwd_hits: null pointer");
+  if (B == 0) return CL3D_OK;
+  CL3D_REQUIRE(B <= 65535, "pwmlp_bwd_hits: B exceeds grid.z limit");
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pwmlp_hit_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e != hipSuccess) return fail(CL3D_E_LAUNCH, "pwmlp_bwd_hits: LDS opt-in: %s", hipGetErrorString(e));
+    attr_done = true;
+  }
+  HitArgs a{};
+  a.dz_cm = dz_cm; a.ts_cm = ts_cm; a.hit_cm = hit_cm; a.B = B; a.N = N; a.M = M; a.Co = Co;
+  a.T = N < 4096 ? N : 4096;  // 4 channels x T doubles = 128 KiB
+  const int ntiles = ceil_div(N, a.T);
+  CL3D_REQUIRE(ntiles <= 65535, "pwmlp_bwd_hits: N too large");
+  hipLaunchKernelGGL(pwmlp_hit_kernel, dim3(ceil_div(Co, 4), ntiles, B), dim3(1024), (size_t)4 * a.T * sizeof(double),
+                     (hipStream_t)stream, a);
+  return check_launch("cl3d_pwmlp_bwd_hits");
+}
+
+extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const float *cA, const float *cB,
+                                      const float *cD, const float *hit_cm, const float *dz_cm, const float *sy_t,
+                                      const float *hq_t, const float *slotrec, const int32_t *inv_off,
+                                      const int32_t *inv_slots, int B, int N, int M, int K, int Co, float *dght,
+                                      cl3d_stream_t stream) {
   using namespace cl3d;
   PwArgs a{};
-  a.idx = idx; a.ght = ght; a.wr = wr; a.v0 = cA; a.v1 = cB; a.v2 = cD; a.dzs_in = dzs_t; a.kstar_in = kstar_t;
-  a.slotrec = reinterpret_cast<float4 *>(const_cast<float *>(slotrec)); a.sy_in = sy_t;
+  a.ght = ght; a.wr = wr; a.v0 = cA; a.v1 = cB; a.v2 = cD; a.hit_cm = hit_cm; a.dz_cm = dz_cm; a.sy_in = sy_t;
+  a.hq_t = const_cast<float *>(hq_t);
+  a.slotrec = reinterpret_cast<float4 *>(const_cast<float *>(slotrec));
   a.inv_off = inv_off; a.inv_slots = inv_slots; a.dght = dght;
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co;
   int rc = pw_check(a, "pwmlp_bwd_support");
   if (rc != CL3D_OK) return rc;
-  CL3D_REQUIRE(idx && ght && wr && cA && cB && cD && dzs_t && kstar_t && slotrec && sy_t && inv_off && inv_slots && dght,
+  CL3D_REQUIRE(ght && wr && cA && cB && cD && hit_cm && dz_cm && sy_t && hq_t && slotrec && inv_off && inv_slots && dght,
                "pwmlp_bwd_support: null pointer");
   if (B == 0) return CL3D_OK;
   const int V = (Co % 4 == 0) ? 4 : 1;
@@ -726,7 +916,8 @@ extern "C" int cl3d_pwmlp_bwd_support(const int32_t *idx, const float *ght, cons
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
   const int gx = round_grid(tiles, 8192);
-  if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((pwmlp_support_kernel<1>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
+  // measured at the metric shape: 8 rows in flight at 3 waves/SIMD 93 us, 6 at 3 93 us, 5 at 4 87 us, 4 at 4 86 us
+  if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4, 4, 4>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((pwmlp_support_kernel<1, 8, 4>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_bwd_support");
 }

@@ -55,6 +55,24 @@ def test_ball_query_bit_exact(B, N, M, K, mult, kind, pad):
     assert np.array_equal(got_msk.cpu().numpy(), want_msk)
 
 
+@pytest.mark.parametrize("N,K,mult,kind", [(1024, 16, 2.5, "uniform"), (2048, 32, 3.0, "planes"), (4096, 32, 1.5, "uniform"),
+                                           (512, 16, 4.0, "uniform")])
+def test_ball_query_repeatable_under_stress(N, K, mult, kind):
+    """The cell-grid path places points inside a cell in whatever order its LDS atomics resolve; the result
+    must not depend on it: 40 launches on the same input, every one identical to the oracle's answer.
+    mult 2.5-4 puts most neighbourhoods between 3K and 6K candidates (index-rank branch) or above (redo)."""
+    from closerlook3d_amd import _ext
+    rng = np.random.default_rng(N + K)
+    s, sm = oo.make_cloud(rng, 4, N, kind=kind, pad_frac=0.1)
+    r = _radius(N, K, mult)
+    want_idx, want_msk = on.masked_ordered_ball_query(s, s, sm, sm, r, K)
+    dev = _dev(s, s, sm, sm)
+    for it in range(40):
+        got_idx, got_msk = _ext.masked_ordered_ball_query(*dev, r, K)
+        assert np.array_equal(got_idx.cpu().numpy(), want_idx), f"launch {it}"
+        assert np.array_equal(got_msk.cpu().numpy(), want_msk), f"launch {it}"
+
+
 def test_ball_query_ties_and_duplicates():
     """Exact distance ties (lattice), duplicated points and an all-duplicates cloud: stable order."""
     from closerlook3d_amd import _ext
