@@ -32,6 +32,7 @@ SIGNATURES = {
     "cl3d_fused_reduce_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _F, _I, _P, _P, _I, _P],
     "cl3d_maxpool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cl3d_maxpool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "cl3d_transpose": [_P, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_partials": [_I, _I, _I],
     "cl3d_pwmlp_stats": [_P] * 6 + [_I] * 5 + [_F, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "cl3d_pwmlp_finalize_stats": [_P, _I, _I, ctypes.c_double, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -238,9 +238,13 @@ struct ParamCount {
   static constexpr int value = OP == OP_ADAPTIVE ? 4 : 0;  // PseudoGrid: d kernel_weights comes from pg_dkw_kernel
 };
 
+constexpr int kBwdCap = 1024;  // slot records staged per round
+
 template <int OP, int V>
 __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
   extern __shared__ float lds[];
+  __shared__ float4 s_rec[kBwdCap];
+  __shared__ int s_qry[kBwdCap];
   constexpr int NP = ParamCount<OP>::value;
   const int K = a.K, C = a.C, M = a.M, N = a.N, L = a.L, QW = a.QW;
   const int waves = blockDim.x >> 6;
@@ -276,34 +280,67 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       int b, tr;
       decode_tile(tile, a.B, tiles_per_cloud, b, tr);
-      const int i = tr * TR + wave * QW + g;
-      if (!chan_on || i >= N) continue;
+      const int i0 = tr * TR;
+      const int i = i0 + wave * QW + g;
+      const bool row_on = chan_on && i < N;
       const int *off = a.inv_off + (size_t)b * (N + 1);
       const int *slots = a.inv_slots + (size_t)b * MK;
       const float4 *rec = a.slotrec + (size_t)b * MK;
       const float *grow = a.gout_t + (size_t)b * M * C + c0;
-      const int s0 = off[i], s1 = off[i + 1];
+      // the slot lists of the tile's TR consecutive points are one contiguous range of inv_slots: the block
+      // stages it (slot -> slotrec, query id) in LDS with every thread loading, and the lane groups walk
+      // their rows out of LDS; the only global loads left in the row loop are the gout-row gathers
+      const int e_lo = off[i0], e_hi = off[i0 + TR < N ? i0 + TR : N];
+      const int ic = i < N ? i : N - 1;
+      const int s0 = off[ic], s1 = off[ic + 1];
       Vec<V> fown;
+#pragma unroll
+      for (int v = 0; v < V; ++v) fown.v[v] = 0.f;
       if constexpr (NP > 0) {
-        fown = load_row<V>(a.ft + ((size_t)b * N + i) * C + c0);
+        if (row_on) fown = load_row<V>(a.ft + ((size_t)b * N + i) * C + c0);
       }
       float acc[V];
 #pragma unroll
       for (int v = 0; v < V; ++v) acc[v] = 0.f;
-      constexpr int SB = 4;  // slots per batch: SB independent (slot -> record -> row) chains in flight
-      for (int e = s0; e < s1; e += SB) {
-        int sl[SB];
+      constexpr int SB = 4;  // gout rows in flight per lane
+      for (int cbeg = e_lo; cbeg < e_hi; cbeg += kBwdCap) {
+        const int cn = e_hi - cbeg < kBwdCap ? e_hi - cbeg : kBwdCap;
+        __syncthreads();  // the previous round's records have been consumed
+        for (int t0 = 0; t0 < cn; t0 += (int)blockDim.x * 4) {
+          int sl[4];
+          float4 rr[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * (int)blockDim.x + (int)threadIdx.x;
+            sl[u] = slots[cbeg + (t < cn ? t : cn - 1)];
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) rr[u] = rec[sl[u]];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int t = t0 + u * (int)blockDim.x + (int)threadIdx.x;
+            if (t < cn) {
+              s_rec[t] = rr[u];
+              s_qry[t] = sl[u] / K;
+            }
+          }
+        }
+        __syncthreads();
+        if (!row_on) continue;
+        const int lo = s0 > cbeg ? s0 : cbeg;
+        const int hi = s1 < cbeg + cn ? s1 : cbeg + cn;
+      for (int e = lo; e < hi; e += SB) {
         float4 rr[SB];
         Vec<V> gg[SB];
 #pragma unroll
-        for (int u = 0; u < SB; ++u) sl[u] = slots[e + u < s1 ? e + u : s1 - 1];
-#pragma unroll
-        for (int u = 0; u < SB; ++u) rr[u] = rec[sl[u]];
-#pragma unroll
-        for (int u = 0; u < SB; ++u) gg[u] = load_row<V>(grow + (size_t)(sl[u] / K) * C);
+        for (int u = 0; u < SB; ++u) {
+          const int t = (e + u < hi ? e + u : hi - 1) - cbeg;
+          rr[u] = s_rec[t];
+          gg[u] = load_row<V>(grow + (size_t)s_qry[t] * C);
+        }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-          if (e + u >= s1) continue;
+          if (e + u >= hi) continue;
           const float4 r = rr[u];
           const Vec<V> &go = gg[u];
           if constexpr (OP == OP_PSEUDOGRID) {
@@ -344,6 +381,8 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
           }
         }
       }
+      }  // staged rounds
+      if (!row_on) continue;
       Vec<V> o;
 #pragma unroll
       for (int v = 0; v < V; ++v) o.v[v] = acc[v];

@@ -69,6 +69,16 @@ def inverse_index(idx, n_support):
     return off, slots
 
 
+def _transposed(t):
+    """[B,R,C] -> contiguous [B,C,R] through the engine's tiled transpose (channel-major <-> point-major rows)."""
+    t = t.contiguous()
+    B, R, C = t.shape
+    out = torch.empty((B, C, R), dtype=t.dtype, device=t.device)
+    with torch.cuda.device(t.device):
+        _lib.check(_lib.lib().cl3d_transpose(_p(t), B, R, C, _p(out), _stream(t)))
+    return out
+
+
 class _FusedReduce(Function):
     """out[b,c,j] = reduce_k w_c(rel) * mask * f[b,c,idx]  (PosPool / AdaptiveWeight / PseudoGrid)."""
 
@@ -77,7 +87,7 @@ class _FusedReduce(Function):
                 normalize, reduction, pint, pfloat, constant, need_grad):
         B, C, N = features.shape
         _, M, K = idx.shape
-        ft = features.transpose(1, 2).contiguous()
+        ft = _transposed(features)
         out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)  # channel-major, written by the kernel
         slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=features.device) if need_grad else None
         with torch.cuda.device(features.device):
@@ -94,7 +104,7 @@ class _FusedReduce(Function):
     def backward(ctx, gout):
         ft, slotrec, p0, p1 = ctx.saved_tensors
         op, B, N, M, K, C, pint, pfloat, constant = ctx.meta
-        gout_t = gout.transpose(1, 2).contiguous()
+        gout_t = _transposed(gout)
         off, slots = inverse_index(ctx.idx, N)
         dft = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
         lib = _lib.lib()
@@ -111,7 +121,7 @@ class _FusedReduce(Function):
             g0, g1 = d[:, :3].contiguous(), d[:, 3].contiguous()
         elif op == OP_PSEUDOGRID:
             g1 = dparam.sum(0)[:, :pint].t().contiguous()
-        return (dft.transpose(1, 2), g0, g1) + (None,) * 13
+        return (_transposed(dft), g0, g1) + (None,) * 13
 
 
 def _wants_grad(*tensors):
@@ -166,7 +176,7 @@ class _MaxPool(Function):
     def forward(ctx, features, idx, need_grad):
         B, C, N = features.shape
         _, M, K = idx.shape
-        ft = features.transpose(1, 2).contiguous()
+        ft = _transposed(features)
         out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)
         kstar = torch.empty((B, M, C), dtype=torch.uint8, device=features.device) if need_grad else None
         with torch.cuda.device(features.device):
@@ -181,13 +191,13 @@ class _MaxPool(Function):
     def backward(ctx, gout):
         (kstar,) = ctx.saved_tensors
         B, N, M, K, C = ctx.meta
-        gout_t = gout.transpose(1, 2).contiguous()
+        gout_t = _transposed(gout)
         off, slots = inverse_index(ctx.idx, N)
         dft = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
         with torch.cuda.device(gout.device):
             _lib.check(_lib.lib().cl3d_maxpool_bwd(_p(gout_t), _p(kstar), _p(off), _p(slots), B, N, M, K, C, _p(dft),
                                                    _stream(gout)))
-        return dft.transpose(1, 2), None, None
+        return _transposed(dft), None, None
 
 
 def max_pool(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample):

@@ -106,6 +106,10 @@ int cl3d_group_xyz_features(const float *query_xyz, const float *support_xyz,
                             int K, float radius, int normalize_xyz, float *rel, float *grouped,
                             cl3d_stream_t stream);
 
+/* [B,R,C] -> [B,C,R] float32: the layout change at the fused operators' boundary (channel-major
+ * reference tensors <-> point-major rows). */
+int cl3d_transpose(const float *src, int B, int R, int C, float *dst, cl3d_stream_t stream);
+
 /* ---- fused local-aggregation operators (no [B,C,M,K] tensor) -----------------------------------
  * These replace, each in one or a few launches, what the reference's Python does after the grouper
  * in models/local_aggregation_operators.py.  Features and outputs are POINT-MAJOR here:
