@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--impl", default="auto")
     ap.add_argument("--no-cache", action="store_true", help="disable the per-forward ball-query memo")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python")
     args = ap.parse_args()
     kind, B, N, radius, dl, nsamples, npoints, width = CONFIGS[args.config]
     from closerlook3d_amd.backbones import ResNet
@@ -62,15 +63,35 @@ def main():
         ep["res5_features"].square().mean().backward()
         opt.step()
 
+    # the step is hundreds of short kernels: replayed as one HIP graph unless --no-graph (same kernels, same work)
+    graph = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                step()
+        except Exception as e:
+            print(f"bench_backbone: HIP graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+    run = graph.replay if graph is not None else step
     for _ in range(args.warmup):
-        step()
+        run()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"config": args.config, "operator": kind, "clouds": B, "points": N, "width": width,
+                      "launch": "hip_graph" if graph is not None else "eager",
                       "ms_per_step": round(dt * 1e3, 3), "input_points_per_s": round(B * N / dt, 1),
                       "params_M": round(sum(p.numel() for p in net.parameters()) / 1e6, 2),
                       "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}))
