@@ -13,7 +13,8 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
-from .pt_utils import _ball_query
+from . import pt_utils
+from .pt_utils import _ball_query, wait_ready
 
 OP_POSPOOL_XYZ, OP_POSPOOL_SINCOS, OP_ADAPTIVE, OP_PSEUDOGRID = 0, 1, 2, 3
 _RED = {'sum': 0, 'avg': 1, 'mean': 1}
@@ -50,11 +51,7 @@ def _stream(t):
     return _lib.stream_ptr(t.device)
 
 
-def inverse_index(idx, n_support):
-    """CSR inverse of idx [B,M,K] (or [B,M]) -> (off [B,N+1], slots [B,MK]); memoised on the tensor."""
-    cached = getattr(idx, '_cl3d_inverse', None)
-    if cached is not None and cached[0] == n_support:
-        return cached[1], cached[2]
+def _build_inverse(idx, n_support):
     B = idx.shape[0]
     MK = idx[0].numel()
     off = torch.empty((B, n_support + 1), dtype=torch.int32, device=idx.device)
@@ -65,8 +62,46 @@ def inverse_index(idx, n_support):
     with torch.cuda.device(idx.device):
         _lib.check(lib.cl3d_build_inverse_index(_p(idx), B, n_support, MK, _p(off), _p(slots), _p(ws), ws_bytes,
                                                 _stream(idx)))
-    idx._cl3d_inverse = (n_support, off, slots)
     return off, slots
+
+
+def inverse_index(idx, n_support, prefetch=False):
+    """CSR inverse of idx [B,M,K] (or [B,M]) -> (off [B,N+1], slots [B,MK]); memoised on the tensor.
+
+    prefetch=True (forward pass, when a backward will follow): start the build on the index stream right
+    behind the ball query and return nothing; the later call waits for it."""
+    cached = getattr(idx, '_cl3d_inverse', None)
+    if cached is not None and cached[0] == n_support:
+        if not prefetch and cached[3] is not None:
+            torch.cuda.current_stream(idx.device).wait_event(cached[3])
+        return cached[1], cached[2]
+    ev = None
+    if prefetch and pt_utils.async_index():
+        main, side = torch.cuda.current_stream(idx.device), pt_utils.index_stream(idx.device, 1)
+        with torch.cuda.stream(side):
+            wait_ready(idx)  # the ball query ran on this stream already; this covers a cached idx too
+            off, slots = _build_inverse(idx, n_support)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        if not torch.cuda.is_current_stream_capturing():
+            off.record_stream(main)
+            slots.record_stream(main)
+    elif prefetch:
+        return None
+    else:
+        wait_ready(idx)
+        off, slots = _build_inverse(idx, n_support)
+    idx._cl3d_inverse = (n_support, off, slots, ev)
+    return off, slots
+
+
+def _join_inverse(idx):
+    """End of a forward pass: the caller's stream picks up the CSR build that ran beside it (joined in the same
+    thread that forked it; the backward then finds a finished table)."""
+    cached = getattr(idx, '_cl3d_inverse', None)
+    if cached is not None and cached[3] is not None:
+        torch.cuda.current_stream(idx.device).wait_event(cached[3])
+        idx._cl3d_inverse = cached[:3] + (None,)
 
 
 def _transposed(t):
@@ -88,6 +123,7 @@ class _FusedReduce(Function):
         B, C, N = features.shape
         _, M, K = idx.shape
         ft = _transposed(features)
+        wait_ready(idx)  # ball query ran on the index stream
         out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)  # channel-major, written by the kernel
         slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=features.device) if need_grad else None
         with torch.cuda.device(features.device):
@@ -98,6 +134,7 @@ class _FusedReduce(Function):
         ctx.save_for_backward(ft, slotrec, p0, p1)
         ctx.idx = idx
         ctx.meta = (op, B, N, M, K, C, pint, pfloat, constant)
+        _join_inverse(idx)
         return out
 
     @staticmethod
@@ -128,13 +165,18 @@ def _wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample):
-    return _ball_query(query_xyz.contiguous(), support_xyz.contiguous(), query_mask.contiguous(),
-                       support_mask.contiguous(), radius, nsample)
+def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad=False):
+    """Ball query (and, when a backward will follow, the CSR inverse) on the index stream; the fused
+    Functions wait_ready() the result right before their first kernel that reads it."""
+    idx, idx_mask = _ball_query(query_xyz.contiguous(), support_xyz.contiguous(), query_mask.contiguous(),
+                                support_mask.contiguous(), radius, nsample, defer=True)
+    if need_grad:
+        inverse_index(idx, support_xyz.shape[1], prefetch=True)
+    return idx, idx_mask
 
 
 def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, embedding, reduction):
-    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, _wants_grad(features))
     C = features.shape[1]
     if embedding == 'xyz':
         if C % 3:
@@ -152,9 +194,10 @@ def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, 
 
 def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps,
                     shared_channels, reduction):
-    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
     conv = mlps.conv0
     w = conv.weight.view(conv.weight.shape[0], 3)
+    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
+                           _wants_grad(features, w, conv.bias))
     return _FusedReduce.apply(features, w, conv.bias, OP_ADAPTIVE, query_xyz, support_xyz, query_mask, idx,
                               idx_mask, radius, True, _RED[reduction], int(shared_channels), 0.0, False,
                               _wants_grad(features, w, conv.bias))
@@ -162,7 +205,8 @@ def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, 
 
 def pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, k_points,
                 kernel_weights, extent, influence):
-    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
+                           _wants_grad(features, kernel_weights))
     return _FusedReduce.apply(features, k_points.contiguous(), kernel_weights, OP_PSEUDOGRID, query_xyz,
                               support_xyz, query_mask, idx, idx_mask, radius, False, _RED['sum'],
                               int(k_points.shape[0]), 1.0 / float(extent), influence == 'constant',
@@ -177,6 +221,7 @@ class _MaxPool(Function):
         B, C, N = features.shape
         _, M, K = idx.shape
         ft = _transposed(features)
+        wait_ready(idx)
         out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)
         kstar = torch.empty((B, M, C), dtype=torch.uint8, device=features.device) if need_grad else None
         with torch.cuda.device(features.device):
@@ -185,6 +230,7 @@ class _MaxPool(Function):
         ctx.save_for_backward(kstar)
         ctx.idx = idx
         ctx.meta = (B, N, M, K, C)
+        _join_inverse(idx)
         return out
 
     @staticmethod
@@ -202,7 +248,7 @@ class _MaxPool(Function):
 
 def max_pool(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample):
     """MaskedMaxPool's pooling step on the fused path (nsample <= 255)."""
-    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, _wants_grad(features))
     return _MaxPool.apply(features.contiguous(), idx, _wants_grad(features))
 
 
@@ -219,6 +265,7 @@ class _PointwiseMLP(Function):
         lib = _lib.lib()
         n = B * M * K
         nparts = lib.cl3d_pwmlp_partials(B, M, Co)
+        wait_ready(idx)  # ball query ran on the index stream while the per-point GEMM ran here
         out = torch.empty((B, Co, M), dtype=torch.float32, device=dev)  # channel-major, written by the kernels
         with torch.cuda.device(dev):
             st = _stream(ght)
@@ -256,6 +303,7 @@ class _PointwiseMLP(Function):
                 shift = (beta.double() - running_mean.double() * scale64).float()
                 _lib.check(lib.cl3d_pwmlp_fwd(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(scale),
                                               _p(shift), B, N, M, K, Co, float(radius), _p(out), 1, None, None, st))
+        _join_inverse(idx)
         return out
 
     @staticmethod
@@ -346,8 +394,9 @@ class _SplitWeight(Function):
 def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps, reduction,
                   training):
     assert reduction == 'max'
-    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
     conv, bn = mlps.conv0[0], mlps.conv0[1]
+    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
+                    training and _wants_grad(features, conv.weight, bn.weight, bn.bias))
     C = features.shape[1]
     Co = conv.weight.shape[0]
     W = conv.weight.view(Co, 3 + 2 * C)
