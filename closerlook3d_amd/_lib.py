@@ -34,6 +34,8 @@ SIGNATURES = {
     "cl3d_maxpool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "cl3d_transpose": [_P, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_partials": [_I, _I, _I],
+    "cl3d_pwmlp_split_weight": [_P, _I, _I, _P, _P, _P],
+    "cl3d_pwmlp_merge_weight_grad": [_P, _P, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_stats": [_P] * 6 + [_I] * 5 + [_F, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "cl3d_pwmlp_finalize_stats": [_P, _I, _I, ctypes.c_double, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "cl3d_pwmlp_apply": [_P, _P, _P, _I, _I, _I, _P, _P],

@@ -761,7 +761,68 @@ static int launch_query(PwArgs &a, int nacc, int n_partials, hipStream_t st, con
   return check_launch(who);
 }
 
+// ---- weight plumbing of the factored contraction (replaces ~8 launch-latency-sized PyTorch kernels per step)
+// W [Co, 3+2C] = [W_r | W_c | W_d]  ->  wr [Co,3]  and the per-point GEMM weight  wcat [2Co, C] = [W_d ; W_c - W_d]
+__global__ __launch_bounds__(256) void pwmlp_split_weight_kernel(const float *__restrict__ W, int Co, int C,
+                                                                 float *__restrict__ wr, float *__restrict__ wcat) {
+  const int ld = 3 + 2 * C;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < Co * ld; e += gridDim.x * 256) {
+    const int o = e / ld, k = e - o * ld;
+    const float v = W[e];
+    if (k < 3) {
+      wr[o * 3 + k] = v;
+    } else if (k < 3 + C) {                       // W_c: lower half of wcat is W_c - W_d
+      wcat[(size_t)(Co + o) * C + (k - 3)] = v - W[(size_t)o * ld + k + C];
+    } else {                                      // W_d: upper half
+      wcat[(size_t)o * C + (k - 3 - C)] = v;
+    }
+  }
+}
+
+// d W [Co, 3+2C] from d wr [Co,3] and the per-cloud products dwb [B, C, 2Co] (= F_b G_b, summed over b in
+// order here):  d W_c = bot,  d W_d = top - bot  with  top = d wcat[:Co], bot = d wcat[Co:]
+__global__ __launch_bounds__(256) void pwmlp_merge_weight_grad_kernel(const float *__restrict__ dwr,
+                                                                      const float *__restrict__ dwb, int B, int Co, int C,
+                                                                      float *__restrict__ dW) {
+  const int ld = 3 + 2 * C;
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < Co * ld; e += gridDim.x * 256) {
+    const int o = e / ld, k = e - o * ld;
+    float v;
+    if (k < 3) {
+      v = dwr ? dwr[o * 3 + k] : 0.f;
+    } else {
+      const int c = k < 3 + C ? k - 3 : k - 3 - C;
+      float top = 0.f, bot = 0.f;
+      for (int b = 0; b < B; ++b) {
+        const float *row = dwb + ((size_t)b * C + c) * 2 * Co;
+        top += row[o];
+        bot += row[Co + o];
+      }
+      v = k < 3 + C ? bot : top - bot;
+    }
+    dW[e] = v;
+  }
+}
+
 }  // namespace cl3d
+
+extern "C" int cl3d_pwmlp_split_weight(const float *W, int Co, int C, float *wr, float *wcat, cl3d_stream_t stream) {
+  CL3D_REQUIRE(W && wr && wcat && Co >= 1 && C >= 1, "pwmlp_split_weight: bad arguments");
+  const int n = Co * (3 + 2 * C);
+  hipLaunchKernelGGL(cl3d::pwmlp_split_weight_kernel, dim3(cl3d::ceil_div(n, 256) < 1024 ? cl3d::ceil_div(n, 256) : 1024),
+                     dim3(256), 0, (hipStream_t)stream, W, Co, C, wr, wcat);
+  return cl3d::check_launch("cl3d_pwmlp_split_weight");
+}
+
+extern "C" int cl3d_pwmlp_merge_weight_grad(const float *dwr, const float *dwb, int B, int Co, int C, float *dW,
+                                            cl3d_stream_t stream) {
+  CL3D_REQUIRE(dwb && dW && B >= 1 && Co >= 1 && C >= 1, "pwmlp_merge_weight_grad: bad arguments");
+  const int n = Co * (3 + 2 * C);
+  hipLaunchKernelGGL(cl3d::pwmlp_merge_weight_grad_kernel,
+                     dim3(cl3d::ceil_div(n, 256) < 1024 ? cl3d::ceil_div(n, 256) : 1024), dim3(256), 0,
+                     (hipStream_t)stream, dwr, dwb, B, Co, C, dW);
+  return cl3d::check_launch("cl3d_pwmlp_merge_weight_grad");
+}
 
 extern "C" int cl3d_pwmlp_partials(int B, int M, int Co) {
   (void)Co;

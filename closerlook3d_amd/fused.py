@@ -339,56 +339,49 @@ class _PointwiseMLP(Function):
         return (dght, dwr, dgamma, dbeta) + (None,) * 10
 
 
-class _PointGemm(Function):
-    """rows[b,i,:] = W f[b,:,i]  (features channel-major [B,C,N], W [R,C]) -> point-major [B,N,R].
+class _PointRows(Function):
+    """(features [B,C,N], W [Co,3+2C] = [W_r | W_c | W_d])  ->  ght [B,N,2Co] with rows [W_d f_i | (W_c - W_d) f_i]
+    (once per point instead of once per (point, neighbour)), and W_r [Co,3].
 
-    Plain library GEMMs (rocBLAS/hipBLASLt through torch.bmm), arranged so that every operand is consumed
-    through its strides (no transposed copies): forward  F[b]^T W^T;  d features  W^T grows[b]^T, which lands
-    channel-major as the caller needs it;  d W^T = sum_b F[b] grows[b]  (a batched GEMM + a fixed-order sum
-    over the batch: left to the library as ONE [R, B*N] x [B*N, C] GEMM it gets four workgroups and took
-    207 us at the metric shape).
+    The contraction itself is a plain library GEMM (rocBLAS/hipBLASLt through torch.bmm), arranged so that every
+    operand is consumed through its strides: forward F[b]^T wcat^T; d features = wcat^T G[b]^T lands channel-major
+    as the caller needs it; d wcat^T = sum_b F[b] G[b] as a batched GEMM whose per-cloud products are summed by
+    the merge kernel (left to the library as ONE [2Co, B*N] x [B*N, C] GEMM it gets four workgroups: 207 us).
+    A hand-written fp32-MFMA version (32x32x2, operands staged in LDS / register fragments) was built and
+    measured at the metric shape: 23.7 / 19.6 / 19.7+5.6 us against the library's 18.9 / 17.1 / 18.5+4.3 us --
+    no gain, so the library stays.  The weight split / gradient merge around it are two small engine kernels
+    instead of the ~10 launch-latency-sized kernels autograd makes of slices, a subtraction and a cat.
     """
 
     @staticmethod
-    def forward(ctx, features, weight):
-        ctx.save_for_backward(features, weight)
-        B = features.shape[0]
-        return torch.bmm(features.transpose(1, 2), weight.t().unsqueeze(0).expand(B, -1, -1))
+    def forward(ctx, features, W):
+        B, C, N = features.shape
+        Co = W.shape[0]
+        W = W.contiguous()
+        wr = torch.empty((Co, 3), dtype=torch.float32, device=W.device)
+        wcat = torch.empty((2 * Co, C), dtype=torch.float32, device=W.device)
+        with torch.cuda.device(W.device):
+            _lib.check(_lib.lib().cl3d_pwmlp_split_weight(_p(W), Co, C, _p(wr), _p(wcat), _stream(W)))
+        ctx.save_for_backward(features, wcat)
+        ght = torch.bmm(features.transpose(1, 2), wcat.t().unsqueeze(0).expand(B, -1, -1))
+        return ght, wr
 
     @staticmethod
-    def backward(ctx, grows):
-        features, weight = ctx.saved_tensors
-        B = features.shape[0]
-        dfeat = dweight = None
-        if ctx.needs_input_grad[0]:
-            dfeat = torch.bmm(weight.t().unsqueeze(0).expand(B, -1, -1), grows.transpose(1, 2))  # [B,C,N]
+    def backward(ctx, dght, dwr):
+        features, wcat = ctx.saved_tensors
+        B, C, N = features.shape
+        Co = wcat.shape[0] // 2
+        dfeat = dW = None
+        if dght is not None and ctx.needs_input_grad[0]:
+            dfeat = torch.bmm(wcat.t().unsqueeze(0).expand(B, -1, -1), dght.transpose(1, 2))  # [B,C,N]
         if ctx.needs_input_grad[1]:
-            dweight = torch.bmm(features, grows).sum(0).t()  # [R,C]
-        return dfeat, dweight
-
-
-class _SplitWeight(Function):
-    """W [Co, 3+2C] = [W_r | W_c | W_d]  ->  W_r [Co,3] and the per-point GEMM weight [W_d ; W_c - W_d] [2Co, C].
-
-    One autograd node instead of three slices, a subtraction and a cat: the backward of those is ten
-    launch-latency-sized kernels (zero-filled W-shaped buffers and accumulations)."""
-
-    @staticmethod
-    def forward(ctx, W, C):
-        ctx.C = C
-        wc, wd = W[:, 3:3 + C], W[:, 3 + C:]
-        return W[:, :3].contiguous(), torch.cat([wd, wc - wd], 0)
-
-    @staticmethod
-    def backward(ctx, dwr, dwcat):
-        C = ctx.C
-        Co = dwr.shape[0] if dwr is not None else dwcat.shape[0] // 2
-        if dwcat is None:
-            dwcat = dwr.new_zeros((2 * Co, C))
-        if dwr is None:
-            dwr = dwcat.new_zeros((Co, 3))
-        top, bot = dwcat[:Co], dwcat[Co:]
-        return torch.cat([dwr, bot, top - bot], 1), None
+            dwb = (torch.bmm(features, dght) if dght is not None
+                   else torch.zeros((B, C, 2 * Co), dtype=torch.float32, device=features.device))
+            dW = torch.empty((Co, 3 + 2 * C), dtype=torch.float32, device=features.device)
+            dwr = dwr.contiguous() if dwr is not None else None
+            with torch.cuda.device(features.device):
+                _lib.check(_lib.lib().cl3d_pwmlp_merge_weight_grad(_p(dwr), _p(dwb), B, Co, C, _p(dW), _stream(dwb)))
+        return dfeat, dW
 
 
 def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps, reduction,
@@ -400,9 +393,7 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
     C = features.shape[1]
     Co = conv.weight.shape[0]
     W = conv.weight.view(Co, 3 + 2 * C)
-    # once per point instead of once per (point, neighbour): rows [W_d f_i | (W_c - W_d) f_i]
-    wr, wcat = _SplitWeight.apply(W, C)
-    ght = _PointGemm.apply(features, wcat)
+    ght, wr = _PointRows.apply(features, W)
     use_batch_stats = training or bn.running_mean is None
     if use_batch_stats and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)

@@ -163,6 +163,11 @@ int cl3d_maxpool_bwd(const float *gout_t, const unsigned char *kstar_t, const in
  * Per-(query, channel) arrays are point-major [B,M,Co]; partial buffers are
  * [cl3d_pwmlp_partials(B,M,Co), Co, 8] doubles. */
 int cl3d_pwmlp_partials(int B, int M, int Co);
+/* weight plumbing of the factored contraction: W [Co,3+2C] = [W_r | W_c | W_d] -> wr [Co,3], wcat [2Co,C] =
+ * [W_d ; W_c - W_d];  d W from d wr (nullable) and the per-cloud products dwb [B,C,2Co] = F_b G_b. */
+int cl3d_pwmlp_split_weight(const float *W, int Co, int C, float *wr, float *wcat, cl3d_stream_t stream);
+int cl3d_pwmlp_merge_weight_grad(const float *dwr, const float *dwb, int B, int Co, int C, float *dW,
+                                 cl3d_stream_t stream);
 /* the training gather pass: per channel sum y, sum y^2, sum y*rel, sum rel (partial); per (query, channel)
  * the extreme pre-activation ystar_t that wins the max (max_k y if gamma >= 0 else min_k y), its slot
  * kstar_t (first one), the support index tstar_t = idx[j, kstar] and sy_t = sum_k y; slotrec
