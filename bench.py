@@ -171,8 +171,8 @@ def cpu_baseline(kind, N, K, C, radius, clouds, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--operator", default="pointwisemlp", choices=["pointwisemlp", "pospool", "adaptive_weight", "pseudo_grid"])
     ap.add_argument("--impl", default="auto", choices=["auto", "fused", "grouped"])
     ap.add_argument("--batch", type=int, default=16, help="clouds per GPU")
