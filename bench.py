@@ -189,13 +189,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world == 1 and args.gpus > 1:
         raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
+    # CL3D_BENCH_ONE_DEVICE=1: every rank on GPU 0 over gloo -- only to exercise the N>1 code path on a 1-GPU box
+    one_dev = os.environ.get("CL3D_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
-    from closerlook3d_amd.dp import allreduce_gradients
+    from closerlook3d_amd.dp import FlatGradients
     from closerlook3d_amd.local_aggregation_operators import LocalAggregation
 
     kind = args.operator
@@ -212,35 +219,46 @@ def main():
     feats.requires_grad_(True)
     probe = torch.randn(B, C, N, device=dev)
 
+    # N > 1: the parameter gradients live in one flat buffer (zeroed inside the captured step, exchanged with a
+    # single in-place RCCL all-reduce) and the update is a second, tiny graph -- three host calls per step
+    flat = FlatGradients(params) if (world > 1 and params) else None
+
     def compute():  # forward + backward (+ the parameter update when there is no gradient exchange)
         feats.grad = None
-        if opt is not None:
+        if flat is not None:
+            flat.zero_()
+        elif opt is not None:
             opt.zero_grad(set_to_none=True)
         out = module(xyz, xyz, mask, mask, feats)
         out.backward(probe)  # upstream gradient handed in directly: nothing but the operator is timed
         if world == 1 and opt is not None:
             opt.step()
 
+    def capture(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
+
     # A step is ~60 short kernels: launched one by one from Python the host, not the GPU, sets the pace
     # (measured: 0.65 ms of kernels in a 0.81 ms step).  So the whole step is captured once into a HIP graph
-    # and replayed -- same kernels, same work, one launch.  The RCCL gradient exchange and the update that
-    # depends on it stay outside the graph when N > 1.
-    graph = None
+    # and replayed -- same kernels, same work, one launch.  The RCCL gradient exchange stays outside the graphs.
+    graph = update_graph = None
     if not args.no_graph:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    compute()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                compute()
+            graph = capture(compute)
+            if world > 1 and opt is not None:
+                update_graph = capture(opt.step)
         except Exception as e:  # capture not possible: launch eagerly, say so in the JSON line
             print(f"bench: HIP graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
-            graph = None
+            graph = update_graph = None
             torch.cuda.synchronize()
 
     def step():
@@ -249,8 +267,11 @@ def main():
         else:
             compute()
         if world > 1:
-            allreduce_gradients(params, world)
-            if opt is not None:
+            if flat is not None:
+                flat.allreduce_mean(world)
+            if update_graph is not None:
+                update_graph.replay()
+            elif opt is not None:
                 opt.step()
 
     for _ in range(args.warmup):

@@ -50,6 +50,35 @@ def allreduce_gradients(params, world, group=None):
         off += n
 
 
+class FlatGradients:
+    """All gradients of `params` as views of ONE flat fp32 buffer (assigned as `.grad`), so the exchange is a
+    single in-place all-reduce with no packing and the buffer can be zeroed inside a captured step.
+
+        flat = FlatGradients(params)
+        # step:  flat.zero_()  ...forward/backward accumulate in place...  flat.allreduce_mean(world)
+    """
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        total = sum(p.numel() for p in self.params)
+        dev = self.params[0].device if self.params else None
+        self.buffer = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            p.grad = self.buffer[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def zero_(self):
+        self.buffer.zero_()
+
+    def allreduce_mean(self, world, group=None):
+        if world == 1 or self.buffer.numel() == 0:
+            return
+        _, need_div = _mean_inplace(self.buffer, world, group)
+        if need_div:
+            self.buffer.div_(world)
+
+
 class GradientSynchronizer:
     """Bucketed, backward-overlapped gradient averaging.
 

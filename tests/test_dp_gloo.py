@@ -9,7 +9,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from closerlook3d_amd.dp import GradientSynchronizer, allreduce_gradients, shard_range
+from closerlook3d_amd.dp import FlatGradients, GradientSynchronizer, allreduce_gradients, shard_range
 
 
 def test_shard_range_partitions():
@@ -49,6 +49,14 @@ def _worker(rank, world, port, mode, out):
             model.zero_grad()
             model(x).square().sum().backward()  # second step reuses the buckets
             sync.finish()
+        elif mode == "flat":
+            flat = FlatGradients(params)
+            for _ in range(2):  # the second step must land in the same views again
+                flat.zero_()
+                model(x).square().sum().backward()
+                assert all(p.grad.data_ptr() >= flat.buffer.data_ptr() and
+                           p.grad.data_ptr() < flat.buffer.data_ptr() + 4 * flat.buffer.numel() for p in params)
+                flat.allreduce_mean(world)
         else:
             model(x).square().sum().backward()
             allreduce_gradients(params, world)
@@ -58,7 +66,7 @@ def _worker(rank, world, port, mode, out):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["bucketed", "oneshot"])
+@pytest.mark.parametrize("mode", ["bucketed", "oneshot", "flat"])
 def test_gradient_mean_world2(tmp_path, mode):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
