@@ -39,12 +39,21 @@ struct ReduceArgs {
   float inv_radius, pfloat;        // pfloat: 1/extent (pseudo grid)
 };
 
+// Packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of fp32 per VALU slot).  PseudoGrid spends
+// P x V = 15 x 4 FMAs per (slot, lane); with the V = 4 channels of a lane held as two float pairs the same
+// arithmetic (each product and sum rounded exactly as before) issues half as many instructions.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 pk_splat(float x) { return (f2)(x); }
+
 __device__ __forceinline__ float kp_influence(float rx, float ry, float rz, const float *kp, float inv_extent,
                                               int constant) {
   if (constant) return 1.0f;
   const float dx = rx - kp[0], dy = ry - kp[1], dz = rz - kp[2];
   const float sq = dx * dx + dy * dy + dz * dz;
-  const float h = 1.0f - sqrtf(sq) * inv_extent;
+  // v_sqrt_f32 (1 ulp) instead of the IEEE-exact sequence: 15 of these per slot, three passes per step, and the
+  // influence feeds sums compared at 1e-5
+  const float h = 1.0f - __builtin_amdgcn_sqrtf(sq) * inv_extent;
   return h > 0.0f ? h : 0.0f;
 }
 
@@ -98,10 +107,13 @@ __global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
   extern __shared__ float4 lds4[];
   const int K = a.K, C = a.C, M = a.M, N = a.N, L = a.L, QW = a.QW;
   const int TQ = 4 * QW;
-  float4 *slot4 = lds4;                                   // [TQ*K] {idx, rx, ry, rz}
-  float *coef = reinterpret_cast<float *>(slot4 + TQ * K);  // [TQ*K] mask weight
-  float *cntq = coef + TQ * K;                            // [TQ]
-  float *hbuf = cntq + TQ;                                // PseudoGrid: [TQ*K][kMaxKP]
+  // per-query rows are K+1 long: the lane groups of a wave read the same slot of different queries at once, and
+  // rows of K float4 (512 B at K = 32) would put them all in the same LDS banks
+  const int KS = K + 1;
+  float4 *slot4 = lds4;                                    // [TQ][KS] {idx, rx, ry, rz}
+  float4 *hbuf4 = slot4 + TQ * KS;                         // PseudoGrid: [kMaxKP/4][TQ][KS] influences, 4 kernel points each
+  float *coef = reinterpret_cast<float *>(hbuf4 + (OP == OP_PSEUDOGRID ? (kMaxKP / 4) * TQ * KS : 0));  // [TQ][KS] mask weight
+  float *cntq = coef + TQ * KS;                            // [TQ]
   int b, tq;
   decode_tile(blockIdx.x, a.B, (M + TQ - 1) / TQ, b, tq);
   const int j0 = tq * TQ;
@@ -127,21 +139,24 @@ __global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
         dz *= a.inv_radius;
       }
       r = make_float4(__int_as_float(i), dx, dy, dz);
-      if constexpr (OP == OP_PSEUDOGRID) {
-        for (int p = 0; p < kMaxKP; ++p)
-          hbuf[(size_t)t * kMaxKP + p] =
-              p < a.pint ? kp_influence(dx, dy, dz, a.p0 + p * 3, a.pfloat, a.constant_influence) * m : 0.f;
-      }
-    } else if constexpr (OP == OP_PSEUDOGRID) {
-      for (int p = 0; p < kMaxKP; ++p) hbuf[(size_t)t * kMaxKP + p] = 0.f;
     }
-    slot4[t] = r;
-    coef[t] = m;
+    const int ts = jq * KS + (t - jq * K);
+    if constexpr (OP == OP_PSEUDOGRID) {
+      float h[kMaxKP];
+#pragma unroll
+      for (int p = 0; p < kMaxKP; ++p)
+        h[p] = (j < M && p < a.pint) ? kp_influence(r.y, r.z, r.w, a.p0 + p * 3, a.pfloat, a.constant_influence) * m : 0.f;
+#pragma unroll
+      for (int p4 = 0; p4 < kMaxKP / 4; ++p4)
+        hbuf4[p4 * TQ * KS + ts] = make_float4(h[4 * p4], h[4 * p4 + 1], h[4 * p4 + 2], h[4 * p4 + 3]);
+    }
+    slot4[ts] = r;
+    coef[ts] = m;
   }
   __syncthreads();
   if ((int)threadIdx.x < TQ) {
     float n = 0.f;
-    for (int k = 0; k < K; ++k) n += coef[threadIdx.x * K + k];
+    for (int k = 0; k < K; ++k) n += coef[threadIdx.x * KS + k];
     cntq[threadIdx.x] = n;
   }
   __syncthreads();
@@ -150,8 +165,9 @@ __global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
       const int jq = t / K;
       const int j = j0 + jq;
       if (j < M) {
-        const float4 r = slot4[t];
-        const float cf = a.reduction == RED_AVG ? coef[t] / cntq[jq] : coef[t];
+        const int ts = jq * KS + (t - jq * K);
+        const float4 r = slot4[ts];
+        const float cf = a.reduction == RED_AVG ? coef[ts] / cntq[jq] : coef[ts];
         a.slotrec[((size_t)b * M + j) * K + (t - jq * K)] = make_float4(r.y, r.z, r.w, cf);
       }
     }
@@ -166,33 +182,51 @@ __global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
   const int j = j0 + jq;
   if (j >= M) return;
   const float n = cntq[jq];
-  const float4 *myslots = slot4 + jq * K;
-  const float *mycoef = coef + jq * K;
+  const float4 *myslots = slot4 + jq * KS;
+  const float *mycoef = coef + jq * KS;
   const float *frow = a.ft + (size_t)b * N * C;
   for (int ch = 0; ch < a.chunks; ++ch) {
     const int c0 = (ch * L + cl) * V;
     if (c0 >= C) continue;
     Vec<V> out;
     if constexpr (OP == OP_PSEUDOGRID) {
-      float wf[kMaxKP][V];
+      constexpr int H = V == 4 ? 2 : 1;   // V == 4: two packed pairs per lane; V == 1: scalar
+      constexpr int KB = 4;               // row gathers in flight per lane
+      f2 wf2[kMaxKP][H];
+      float wf1[kMaxKP];
 #pragma unroll
-      for (int p = 0; p < kMaxKP; ++p)
+      for (int p = 0; p < kMaxKP; ++p) {
+        wf1[p] = 0.f;
 #pragma unroll
-        for (int v = 0; v < V; ++v) wf[p][v] = 0.f;
-#pragma unroll 2
-      for (int k = 0; k < K; ++k) {
-        const int i = __float_as_int(myslots[k].x);
-        const Vec<V> f = load_row<V>(frow + (size_t)i * C + c0);
-        const float4 *h4 = reinterpret_cast<const float4 *>(hbuf + (size_t)(jq * K + k) * kMaxKP);
+        for (int h = 0; h < H; ++h) wf2[p][h] = pk_splat(0.f);
+      }
+      for (int k0 = 0; k0 < K; k0 += KB) {
+        Vec<V> f[KB];
 #pragma unroll
-        for (int p4 = 0; p4 < kMaxKP / 4; ++p4) {
-          const float4 h = h4[p4];
+        for (int u = 0; u < KB; ++u)
+          f[u] = load_row<V>(frow + (size_t)__float_as_int(myslots[k0 + u < K ? k0 + u : K - 1].x) * C + c0);
 #pragma unroll
-          for (int v = 0; v < V; ++v) {
-            wf[p4 * 4 + 0][v] = __builtin_fmaf(h.x, f.v[v], wf[p4 * 4 + 0][v]);
-            wf[p4 * 4 + 1][v] = __builtin_fmaf(h.y, f.v[v], wf[p4 * 4 + 1][v]);
-            wf[p4 * 4 + 2][v] = __builtin_fmaf(h.z, f.v[v], wf[p4 * 4 + 2][v]);
-            wf[p4 * 4 + 3][v] = __builtin_fmaf(h.w, f.v[v], wf[p4 * 4 + 3][v]);
+        for (int u = 0; u < KB; ++u) {
+          if (k0 + u >= K) continue;
+#pragma unroll
+          for (int p4 = 0; p4 < kMaxKP / 4; ++p4) {
+            const float4 h = hbuf4[p4 * TQ * KS + jq * KS + k0 + u];
+            if constexpr (V == 4) {
+              const f2 flo = {f[u].v[0], f[u].v[1]}, fhi = {f[u].v[2], f[u].v[3]};
+              wf2[p4 * 4 + 0][0] = pk_fma(pk_splat(h.x), flo, wf2[p4 * 4 + 0][0]);
+              wf2[p4 * 4 + 0][1] = pk_fma(pk_splat(h.x), fhi, wf2[p4 * 4 + 0][1]);
+              wf2[p4 * 4 + 1][0] = pk_fma(pk_splat(h.y), flo, wf2[p4 * 4 + 1][0]);
+              wf2[p4 * 4 + 1][1] = pk_fma(pk_splat(h.y), fhi, wf2[p4 * 4 + 1][1]);
+              wf2[p4 * 4 + 2][0] = pk_fma(pk_splat(h.z), flo, wf2[p4 * 4 + 2][0]);
+              wf2[p4 * 4 + 2][1] = pk_fma(pk_splat(h.z), fhi, wf2[p4 * 4 + 2][1]);
+              wf2[p4 * 4 + 3][0] = pk_fma(pk_splat(h.w), flo, wf2[p4 * 4 + 3][0]);
+              wf2[p4 * 4 + 3][1] = pk_fma(pk_splat(h.w), fhi, wf2[p4 * 4 + 3][1]);
+            } else {
+              wf1[p4 * 4 + 0] = __builtin_fmaf(h.x, f[u].v[0], wf1[p4 * 4 + 0]);
+              wf1[p4 * 4 + 1] = __builtin_fmaf(h.y, f[u].v[0], wf1[p4 * 4 + 1]);
+              wf1[p4 * 4 + 2] = __builtin_fmaf(h.z, f[u].v[0], wf1[p4 * 4 + 2]);
+              wf1[p4 * 4 + 3] = __builtin_fmaf(h.w, f[u].v[0], wf1[p4 * 4 + 3]);
+            }
           }
         }
       }
@@ -201,8 +235,10 @@ __global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
         float o = 0.f;
         const int c = c0 + v;
 #pragma unroll
-        for (int p = 0; p < kMaxKP; ++p)
-          if (p < a.pint) o += wf[p][v] * a.p1[(size_t)p * C + c];
+        for (int p = 0; p < kMaxKP; ++p) {
+          const float wfv = V == 4 ? wf2[p][v >> 1][v & 1] : wf1[p];
+          if (p < a.pint) o += wfv * a.p1[(size_t)p * C + c];
+        }
         out.v[v] = o;
       }
     } else {
@@ -269,6 +305,10 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
       for (int v = 0; v < V; ++v) pacc[p][v] = 0.f;
     ChannelWeights<OP, V> cw;
     float kw[OP == OP_PSEUDOGRID ? kMaxKP : 1][V];
+#pragma unroll
+    for (int p = 0; p < (OP == OP_PSEUDOGRID ? kMaxKP : 1); ++p)
+#pragma unroll
+      for (int v = 0; v < V; ++v) kw[p][v] = 0.f;
     if (chan_on) {
       cw.init(a, c0);
       if constexpr (OP == OP_PSEUDOGRID) {
@@ -365,12 +405,26 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
                 h[4 * p4] = hv.x; h[4 * p4 + 1] = hv.y; h[4 * p4 + 2] = hv.z; h[4 * p4 + 3] = hv.w;
               }
             }
+            if constexpr (V == 4) {
+              f2 wlo = pk_splat(0.f), whi = pk_splat(0.f);
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-              float w = 0.f;
+              for (int p = 0; p < kMaxKP; ++p) {
+                const f2 klo = {kw[p][0], kw[p][1]}, khi = {kw[p][2], kw[p][3]};
+                wlo = pk_fma(klo, pk_splat(h[p]), wlo);
+                whi = pk_fma(khi, pk_splat(h[p]), whi);
+              }
+              acc[0] = __builtin_fmaf(wlo[0], go.v[0], acc[0]);
+              acc[1] = __builtin_fmaf(wlo[1], go.v[1], acc[1]);
+              acc[2] = __builtin_fmaf(whi[0], go.v[2], acc[2]);
+              acc[3] = __builtin_fmaf(whi[1], go.v[3], acc[3]);
+            } else {
 #pragma unroll
-              for (int p = 0; p < kMaxKP; ++p) w = __builtin_fmaf(kw[p][v], h[p], w);
-              acc[v] = __builtin_fmaf(w, go.v[v], acc[v]);
+              for (int v = 0; v < V; ++v) {
+                float w = 0.f;
+#pragma unroll
+                for (int p = 0; p < kMaxKP; ++p) w = __builtin_fmaf(kw[p][v], h[p], w);
+                acc[v] = __builtin_fmaf(w, go.v[v], acc[v]);
+              }
             }
           } else {
 #pragma unroll
@@ -430,8 +484,9 @@ __global__ __launch_bounds__(256) void pg_dkw_kernel(ReduceArgs a) {
   extern __shared__ float4 lds4[];
   const int K = a.K, C = a.C, M = a.M, N = a.N, L = a.L, QW = a.QW;
   const int TQ = 4 * QW;
-  int *sidx = reinterpret_cast<int *>(lds4);              // [TQ*K]
-  float *hbuf = reinterpret_cast<float *>(sidx + TQ * K);  // [TQ*K][kMaxKP]
+  const int KS = K + 1;  // padded per-query rows, see fused_reduce_fwd_kernel
+  float4 *hbuf4 = lds4;                                    // [kMaxKP/4][TQ][KS] influences, 4 kernel points each
+  int *sidx = reinterpret_cast<int *>(hbuf4 + (kMaxKP / 4) * TQ * KS);  // [TQ][KS]
   float *red = reinterpret_cast<float *>(lds4);            // reused after the tile loop
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
@@ -461,10 +516,15 @@ __global__ __launch_bounds__(256) void pg_dkw_kernel(ReduceArgs a) {
           i = a.idx[e];
           r = a.slotrec[e];  // {rel, mask}
         }
-        sidx[t] = i;
+        const int ts = (t / K) * KS + (t - (t / K) * K);
+        sidx[ts] = i;
+        float h[kMaxKP];
+#pragma unroll
         for (int p = 0; p < kMaxKP; ++p)
-          hbuf[(size_t)t * kMaxKP + p] =
-              (j < M && p < a.pint) ? kp_influence(r.x, r.y, r.z, a.p0 + p * 3, a.pfloat, a.constant_influence) * r.w : 0.f;
+          h[p] = (j < M && p < a.pint) ? kp_influence(r.x, r.y, r.z, a.p0 + p * 3, a.pfloat, a.constant_influence) * r.w : 0.f;
+#pragma unroll
+        for (int p4 = 0; p4 < kMaxKP / 4; ++p4)
+          hbuf4[p4 * TQ * KS + ts] = make_float4(h[4 * p4], h[4 * p4 + 1], h[4 * p4 + 2], h[4 * p4 + 3]);
       }
       __syncthreads();
       const int jq = wave * QW + g;
@@ -479,23 +539,35 @@ __global__ __launch_bounds__(256) void pg_dkw_kernel(ReduceArgs a) {
       for (int k0 = 0; k0 < K; k0 += KB) {
         Vec<V> f[KB];
 #pragma unroll
-        for (int u = 0; u < KB; ++u) f[u] = load_row<V>(frow + (size_t)sidx[jq * K + (k0 + u < K ? k0 + u : K - 1)] * C);
+        for (int u = 0; u < KB; ++u) f[u] = load_row<V>(frow + (size_t)sidx[jq * KS + (k0 + u < K ? k0 + u : K - 1)] * C);
 #pragma unroll
         for (int u = 0; u < KB; ++u) {
           if (k0 + u >= K) continue;
           float t[V];
 #pragma unroll
           for (int v = 0; v < V; ++v) t[v] = f[u].v[v] * go.v[v];
-          const float4 *h4 = reinterpret_cast<const float4 *>(hbuf + (size_t)(jq * K + k0 + u) * kMaxKP);
 #pragma unroll
           for (int p4 = 0; p4 < kMaxKP / 4; ++p4) {
-            const float4 h = h4[p4];
+            const float4 h = hbuf4[p4 * TQ * KS + jq * KS + k0 + u];
+            if constexpr (V == 4) {
+              const f2 tlo = {t[0], t[1]}, thi = {t[2], t[3]};
+              const float hs[4] = {h.x, h.y, h.z, h.w};
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-              pacc[p4 * 4 + 0][v] = __builtin_fmaf(h.x, t[v], pacc[p4 * 4 + 0][v]);
-              pacc[p4 * 4 + 1][v] = __builtin_fmaf(h.y, t[v], pacc[p4 * 4 + 1][v]);
-              pacc[p4 * 4 + 2][v] = __builtin_fmaf(h.z, t[v], pacc[p4 * 4 + 2][v]);
-              pacc[p4 * 4 + 3][v] = __builtin_fmaf(h.w, t[v], pacc[p4 * 4 + 3][v]);
+              for (int q = 0; q < 4; ++q) {
+                f2 plo = {pacc[p4 * 4 + q][0], pacc[p4 * 4 + q][1]}, phi = {pacc[p4 * 4 + q][2], pacc[p4 * 4 + q][3]};
+                plo = pk_fma(pk_splat(hs[q]), tlo, plo);
+                phi = pk_fma(pk_splat(hs[q]), thi, phi);
+                pacc[p4 * 4 + q][0] = plo[0]; pacc[p4 * 4 + q][1] = plo[1];
+                pacc[p4 * 4 + q][2] = phi[0]; pacc[p4 * 4 + q][3] = phi[1];
+              }
+            } else {
+#pragma unroll
+              for (int v = 0; v < V; ++v) {
+                pacc[p4 * 4 + 0][v] = __builtin_fmaf(h.x, t[v], pacc[p4 * 4 + 0][v]);
+                pacc[p4 * 4 + 1][v] = __builtin_fmaf(h.y, t[v], pacc[p4 * 4 + 1][v]);
+                pacc[p4 * 4 + 2][v] = __builtin_fmaf(h.z, t[v], pacc[p4 * 4 + 2][v]);
+                pacc[p4 * 4 + 3][v] = __builtin_fmaf(h.w, t[v], pacc[p4 * 4 + 3][v]);
+              }
             }
           }
         }
@@ -580,8 +652,8 @@ static LaneMap fwd_lane_map(int op, int C, int K, int V, size_t *lds_out) {
   }
   for (;;) {
     const size_t tq = 4 * (size_t)m.QW;
-    size_t lds = tq * K * (sizeof(float4) + sizeof(float)) + tq * sizeof(float);
-    if (op == OP_PSEUDOGRID) lds += tq * K * kMaxKP * sizeof(float);
+    size_t lds = tq * (K + 1) * (sizeof(float4) + sizeof(float)) + tq * sizeof(float);
+    if (op == OP_PSEUDOGRID) lds += tq * (K + 1) * kMaxKP * sizeof(float);
     if (lds <= 60 * 1024 || m.QW == 1) {
       *lds_out = lds;
       return m;
@@ -671,7 +743,7 @@ extern "C" int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *f
   size_t lds_fwd = 0;
   const LaneMap mf = fwd_lane_map(op, C, K, V, &lds_fwd);
   a.L = mf.L; a.QW = mf.QW; a.chunks = mf.chunks;
-  const size_t tile = 4 * (size_t)mf.QW * K * (sizeof(int) + kMaxKP * sizeof(float));
+  const size_t tile = 4 * (size_t)mf.QW * (K + 1) * (sizeof(int) + kMaxKP * sizeof(float));
   const size_t red = 4 * (size_t)mf.QW * mf.L * V * 8 * sizeof(float);
   const size_t lds_dkw = tile > red ? tile : red;
   if (lds_dkw > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "fused_reduce_bwd: nsample=%d needs %zu B of LDS", K, lds_dkw);
