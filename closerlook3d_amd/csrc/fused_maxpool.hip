@@ -24,15 +24,16 @@ struct MaxArgs {
 
 template <int V>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxArgs a) {
-  extern __shared__ int sidx[];  // [TQ*K]
+  extern __shared__ int sidx[];  // [TQ][K+1]: odd row stride keeps the lane groups of a wave on different LDS banks
   const int K = a.K, C = a.C, M = a.M, N = a.N, L = a.L, QW = a.QW;
   const int TQ = 4 * QW;
+  const int KS = K + 1;
   int b, tq;
   decode_tile(blockIdx.x, a.B, (M + TQ - 1) / TQ, b, tq);
   const int j0 = tq * TQ;
   for (int t = threadIdx.x; t < TQ * K; t += 256) {
     const int j = j0 + t / K;
-    sidx[t] = j < M ? a.idx[((size_t)b * M + j) * K + (t - (t / K) * K)] : 0;
+    sidx[(t / K) * KS + (t - (t / K) * K)] = j < M ? a.idx[((size_t)b * M + j) * K + (t - (t / K) * K)] : 0;
   }
   __syncthreads();
   const int lane = lane_id();
@@ -42,7 +43,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxArgs a) {
   const int jq = wave * QW + g;
   const int j = j0 + jq;
   if (j >= M) return;
-  const int *my = sidx + jq * K;
+  const int *my = sidx + jq * KS;
   const float *rows = a.ft + (size_t)b * N * C;
   constexpr int KB = 8;
   for (int ch = 0; ch < a.chunks; ++ch) {
@@ -156,7 +157,7 @@ extern "C" int cl3d_maxpool_fwd(const int32_t *idx, const float *ft, int B, int 
   if (4 * (size_t)m.QW * K * sizeof(int) > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "maxpool_fwd: nsample too large for LDS");
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const dim3 grid(virtual_tiles(B, ceil_div(M, 4 * m.QW)));
-  const size_t lds = 4 * (size_t)m.QW * K * sizeof(int);
+  const size_t lds = 4 * (size_t)m.QW * (K + 1) * sizeof(int);
   if (V == 4) hipLaunchKernelGGL((maxpool_fwd_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((maxpool_fwd_kernel<1>), grid, dim3(256), lds, (hipStream_t)stream, a);
   return check_launch("cl3d_maxpool_fwd");

@@ -75,8 +75,11 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
   const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
   const int TQ = 4 * QW;
   const int row = 2 * Co;
-  float4 *slot4 = lds4;  // [TQ*K] {idx, rx, ry, rz}
-  double *red = reinterpret_cast<double *>(slot4 + TQ * K);  // [4 waves][L*V*NACC]
+  // per-query rows are K+1 records long: the lane groups of a wave read the same slot of different queries at
+  // once, and rows of K float4 (512 B at K = 32) would put all of them in the same LDS banks
+  const int KS = K + 1;
+  float4 *slot4 = lds4;  // [TQ][KS] {idx, rx, ry, rz}
+  double *red = reinterpret_cast<double *>(slot4 + TQ * KS);  // [4 waves][L*V*NACC]
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int g = lane / L, cl = lane - g * L;
@@ -169,14 +172,14 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
           if (ch == 0 && a.slotrec != nullptr)
             a.slotrec[e] = make_float4(r.y, r.z, r.w, __int_as_float(a.idx[((size_t)b * M + j) * K]));
         }
-        slot4[t] = r;
+        slot4[jq * KS + (t - jq * K)] = r;
       }
       __syncthreads();
       const int jq = wave * QW + g;
       const int j = j0 + jq;
       const bool q_on = chan_on && j < M;
       if (MODE != PW_TRAIN && !q_on) continue;
-      const float4 *myslots = slot4 + (q_on ? jq : 0) * K;
+      const float4 *myslots = slot4 + (q_on ? jq : 0) * KS;
       const float *rows = a.ght + (size_t)b * N * row;
       const int ic = __float_as_int(myslots[0].x);  // centre = nearest neighbour (reference :290)
       Vec<V> hc;
@@ -736,7 +739,7 @@ static LaneMap pw_lane_map(int Co, int K, int V, int nacc, size_t *lds_out) {
   }
   for (;;) {
     const size_t tq = 4 * (size_t)m.QW;
-    const size_t lds = tq * K * sizeof(float4) + (size_t)4 * m.L * V * nacc * sizeof(double);
+    const size_t lds = tq * (K + 1) * sizeof(float4) + (size_t)4 * m.L * V * nacc * sizeof(double);
     if (lds <= 60 * 1024 || m.QW == 1) {
       *lds_out = lds;
       return m;
