@@ -33,6 +33,10 @@ SIGNATURES = {
     "cl3d_maxpool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cl3d_maxpool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "cl3d_transpose": [_P, _I, _I, _I, _P, _P],
+    "cl3d_bn_partials": [_I, _I, _I],
+    "cl3d_bn_relu_stats": [_P, _I, _I, _I, _P, _I, ctypes.c_double, _F, _F] + [_P] * 9,
+    "cl3d_bn_relu_apply": [_P, _P, _P, _I, _I, _I, _P, _P],
+    "cl3d_bn_relu_bwd": [_P] * 7 + [_I, _I, _I, ctypes.c_double, _P, _I, _P, _P, _P],
     "cl3d_pwmlp_partials": [_I, _I, _I],
     "cl3d_pwmlp_split_weight": [_P, _I, _I, _P, _P, _P],
     "cl3d_pwmlp_merge_weight_grad": [_P, _P, _I, _I, _I, _P, _P],

@@ -1,0 +1,248 @@
+// bn_relu.hip -- BatchNorm1d + ReLU on channel-major [B,C,N] tensors: the output transform every
+// LocalAggregation operator ends in (reference: local_aggregation_operators.py:40-45 `out_transform`, and the
+// BN+ReLU halves of `out_conv`).  Streaming, HBM-bound (19 MB per tensor at the metric shape):
+//   training forward   STATS (sum x, sum x^2 per (cloud, channel) row, double)  ->  FINALIZE (batch mean /
+//                      variance, scale / shift, running-statistics update with nn.BatchNorm1d's rule)  ->
+//                      APPLY  out = ReLU(scale * x + shift)
+//   inference forward  APPLY with scale / shift from the running statistics
+//   backward           BWD_STATS (dz = g gated by the ReLU, recomputed from x; sum dz, sum dz * xhat)  ->
+//                      COEFFS (dx = A dz + Bc + D x: the BatchNorm backward is affine in x)  ->  BWD_APPLY
+// Three launches each way instead of the library's BatchNorm + a separate ReLU (+ their backward kernels),
+// and x is the only tensor kept for the backward pass (the ReLU mask and xhat are recomputed from it).
+#include "cl3d_common.h"
+
+namespace cl3d {
+
+struct BnArgs {
+  const float *x, *g;          // [B,C,N]
+  const float *scale, *shift, *mean, *invstd, *cA, *cB, *cD;
+  float *out;                  // [B,C,N]
+  double *partial;             // [B*chunks, C, 2]
+  int B, C, N, chunks, span;   // a block reduces `span` points of one (cloud, channel) row
+};
+
+__device__ __forceinline__ double block_sum(double v, double *scratch) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[wave] = v;
+  __syncthreads();
+  return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+// MODE 0: forward statistics of x;  MODE 1: backward statistics (dz, dz*xhat)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_stats_kernel(BnArgs a) {
+  __shared__ double scratch[4];
+  const int c = blockIdx.x, part = blockIdx.y;
+  const int b = part / a.chunks, n0 = (part - b * a.chunks) * a.span;
+  const int n1 = n0 + a.span < a.N ? n0 + a.span : a.N;
+  const float *xr = a.x + ((size_t)b * a.C + c) * a.N;
+  const float *gr = MODE == 1 ? a.g + ((size_t)b * a.C + c) * a.N : nullptr;
+  float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
+  if (MODE == 1) {
+    sc = a.scale[c]; sh = a.shift[c]; mu = a.mean[c]; is = a.invstd[c];
+  }
+  float s0 = 0.f, s1 = 0.f;  // <= 64 terms per thread between the double folds below
+  double d0 = 0.0, d1 = 0.0;
+  auto item = [&](float xv, float gv) {
+    if (MODE == 0) {
+      s0 += xv;
+      s1 = __builtin_fmaf(xv, xv, s1);
+    } else {
+      const float dz = __builtin_fmaf(xv, sc, sh) > 0.f ? gv : 0.f;
+      s0 += dz;
+      s1 = __builtin_fmaf(dz, (xv - mu) * is, s1);
+    }
+  };
+  if ((a.N & 3) == 0) {
+    int it = 0;
+    for (int n = n0 + 4 * (int)threadIdx.x; n < n1; n += 1024) {
+      const float4 xv = *reinterpret_cast<const float4 *>(xr + n);
+      float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (MODE == 1) gv = *reinterpret_cast<const float4 *>(gr + n);
+      item(xv.x, gv.x); item(xv.y, gv.y); item(xv.z, gv.z); item(xv.w, gv.w);
+      if (++it == 16) {
+        d0 += (double)s0; d1 += (double)s1; s0 = s1 = 0.f; it = 0;
+      }
+    }
+  } else {
+    int it = 0;
+    for (int n = n0 + (int)threadIdx.x; n < n1; n += 256) {
+      item(xr[n], MODE == 1 ? gr[n] : 0.f);
+      if (++it == 64) {
+        d0 += (double)s0; d1 += (double)s1; s0 = s1 = 0.f; it = 0;
+      }
+    }
+  }
+  d0 += (double)s0;
+  d1 += (double)s1;
+  const double t0 = block_sum(d0, scratch);
+  const double t1 = block_sum(d1, scratch);
+  if (threadIdx.x == 0) {
+    double *p = a.partial + ((size_t)part * a.C + c) * 2;
+    p[0] = t0;
+    p[1] = t1;
+  }
+}
+
+// MODE 0: out = ReLU(scale x + shift);  MODE 1: dx = A dz + Bc + D x with dz = g gated by the ReLU
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_apply_kernel(BnArgs a) {
+  const long long rows = (long long)a.B * a.C;
+  const int per_row = (a.N + 1023) / 1024;  // 1024 elements per block-iteration
+  for (long long t = blockIdx.x; t < rows * per_row; t += gridDim.x) {
+    const long long r = t / per_row;
+    const int c = (int)(r % a.C);
+    const int n = (int)(t - r * per_row) * 1024 + 4 * (int)threadIdx.x;
+    const float sc = a.scale[c], sh = a.shift[c];
+    const float *xr = a.x + (size_t)r * a.N;
+    float *orow = a.out + (size_t)r * a.N;
+    float cA = 0.f, cB = 0.f, cD = 0.f;
+    if (MODE == 1) {
+      cA = a.cA[c]; cB = a.cB[c]; cD = a.cD[c];
+    }
+    auto f = [&](float xv, float gv) {
+      const float z = __builtin_fmaf(xv, sc, sh);
+      if (MODE == 0) return z > 0.f ? z : 0.f;
+      const float dz = z > 0.f ? gv : 0.f;
+      return __builtin_fmaf(cA, dz, __builtin_fmaf(cD, xv, cB));
+    };
+    if ((a.N & 3) == 0) {
+      if (n < a.N) {
+        const float4 xv = *reinterpret_cast<const float4 *>(xr + n);
+        float4 gv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 1) gv = *reinterpret_cast<const float4 *>(a.g + (size_t)r * a.N + n);
+        *reinterpret_cast<float4 *>(orow + n) = make_float4(f(xv.x, gv.x), f(xv.y, gv.y), f(xv.z, gv.z), f(xv.w, gv.w));
+      }
+    } else {
+      for (int u = 0; u < 4; ++u)
+        if (n + u < a.N) orow[n + u] = f(xr[n + u], MODE == 1 ? a.g[(size_t)r * a.N + n + u] : 0.f);
+    }
+  }
+}
+
+struct BnFinArgs {
+  const double *partial;  // [G, C, 2]
+  int G, C;
+  double count;
+  float eps, momentum;
+  const float *gamma, *beta, *mean_in, *invstd_in;
+  float *running_mean, *running_var;
+  float *o0, *o1, *o2, *o3, *o4;
+};
+
+// MODE 0: batch statistics -> scale, shift, mean, invstd (+ running update);  MODE 1: backward coefficients
+template <int MODE>
+__global__ __launch_bounds__(64) void bn_finalize_kernel(BnFinArgs a) {
+  const int c = blockIdx.x;
+  double s0 = 0.0, s1 = 0.0;
+  for (int g = threadIdx.x; g < a.G; g += 64) {
+    const double *p = a.partial + ((size_t)g * a.C + c) * 2;
+    s0 += p[0];
+    s1 += p[1];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    s0 += __shfl_xor(s0, o, 64);
+    s1 += __shfl_xor(s1, o, 64);
+  }
+  if (threadIdx.x != 0) return;
+  if (MODE == 0) {
+    const double mean = s0 / a.count;
+    double var = s1 / a.count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)a.eps);
+    const double scale = (double)a.gamma[c] * invstd;
+    a.o0[c] = (float)scale;
+    a.o1[c] = (float)((double)a.beta[c] - mean * scale);
+    a.o2[c] = (float)mean;
+    a.o3[c] = (float)invstd;
+    if (a.running_mean != nullptr) {  // nn.BatchNorm1d: running = (1-m) running + m batch, unbiased variance
+      const double unbiased = var * (a.count / (a.count > 1.0 ? a.count - 1.0 : 1.0));
+      a.running_mean[c] = a.running_mean[c] * (1.0f - a.momentum) + a.momentum * (float)mean;
+      a.running_var[c] = a.running_var[c] * (1.0f - a.momentum) + a.momentum * (float)unbiased;
+    }
+  } else {  // dx = A dz + Bc + D x   (s0 = sum dz = d beta, s1 = sum dz * xhat = d gamma)
+    const double invstd = (double)a.invstd_in[c], mean = (double)a.mean_in[c];
+    const double A = (double)a.gamma[c] * invstd;
+    const double D = -A * invstd * s1 / a.count;
+    const double Bc = -A * s0 / a.count - D * mean;
+    a.o0[c] = (float)A;
+    a.o1[c] = (float)Bc;
+    a.o2[c] = (float)D;
+    a.o3[c] = (float)s1;
+    a.o4[c] = (float)s0;
+  }
+}
+
+static void bn_shape(BnArgs &a) {
+  a.span = 16384;
+  a.chunks = ceil_div(a.N, a.span);
+}
+
+}  // namespace cl3d
+
+extern "C" int cl3d_bn_partials(int B, int C, int N) {
+  (void)C;
+  return B * cl3d::ceil_div(N > 0 ? N : 1, 16384);
+}
+
+extern "C" int cl3d_bn_relu_stats(const float *x, int B, int C, int N, double *partial, int n_partials, double count,
+                                  float eps, float momentum, const float *gamma, const float *beta,
+                                  float *running_mean, float *running_var, float *scale, float *shift, float *mean,
+                                  float *invstd, cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(B >= 1 && C >= 1 && N >= 1 && count > 0, "bn_relu_stats: bad sizes");
+  CL3D_REQUIRE(x && partial && gamma && beta && scale && shift && mean && invstd, "bn_relu_stats: null pointer");
+  CL3D_REQUIRE(n_partials == cl3d_bn_partials(B, C, N) && n_partials <= 65535, "bn_relu_stats: wrong partial count");
+  BnArgs a{};
+  a.x = x; a.partial = partial; a.B = B; a.C = C; a.N = N;
+  bn_shape(a);
+  hipLaunchKernelGGL((bn_stats_kernel<0>), dim3(C, n_partials), dim3(256), 0, (hipStream_t)stream, a);
+  BnFinArgs f{};
+  f.partial = partial; f.G = n_partials; f.C = C; f.count = count; f.eps = eps; f.momentum = momentum;
+  f.gamma = gamma; f.beta = beta; f.running_mean = running_mean; f.running_var = running_var;
+  f.o0 = scale; f.o1 = shift; f.o2 = mean; f.o3 = invstd;
+  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(C), dim3(64), 0, (hipStream_t)stream, f);
+  return check_launch("cl3d_bn_relu_stats");
+}
+
+extern "C" int cl3d_bn_relu_apply(const float *x, const float *scale, const float *shift, int B, int C, int N,
+                                  float *out, cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(B >= 0 && C >= 1 && N >= 0, "bn_relu_apply: bad sizes");
+  if (B == 0 || N == 0) return CL3D_OK;
+  CL3D_REQUIRE(x && scale && shift && out, "bn_relu_apply: null pointer");
+  BnArgs a{};
+  a.x = x; a.scale = scale; a.shift = shift; a.out = out; a.B = B; a.C = C; a.N = N;
+  const long long work = (long long)B * C * ceil_div(N, 1024);
+  hipLaunchKernelGGL((bn_apply_kernel<0>), dim3((unsigned)(work < 65536 ? work : 65536)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  return check_launch("cl3d_bn_relu_apply");
+}
+
+extern "C" int cl3d_bn_relu_bwd(const float *g, const float *x, const float *scale, const float *shift,
+                                const float *mean, const float *invstd, const float *gamma, int B, int C, int N,
+                                double count, double *partial, int n_partials, float *coef, float *dx,
+                                cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(B >= 1 && C >= 1 && N >= 1 && count > 0, "bn_relu_bwd: bad sizes");
+  CL3D_REQUIRE(g && x && scale && shift && mean && invstd && gamma && partial && coef && dx, "bn_relu_bwd: null pointer");
+  CL3D_REQUIRE(n_partials == cl3d_bn_partials(B, C, N) && n_partials <= 65535, "bn_relu_bwd: wrong partial count");
+  BnArgs a{};
+  a.x = x; a.g = g; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.partial = partial;
+  a.B = B; a.C = C; a.N = N;
+  bn_shape(a);
+  hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(C, n_partials), dim3(256), 0, (hipStream_t)stream, a);
+  BnFinArgs f{};
+  f.partial = partial; f.G = n_partials; f.C = C; f.count = count; f.gamma = gamma; f.mean_in = mean; f.invstd_in = invstd;
+  f.o0 = coef; f.o1 = coef + C; f.o2 = coef + 2 * C; f.o3 = coef + 3 * C; f.o4 = coef + 4 * C;  // A, Bc, D, d gamma, d beta
+  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(C), dim3(64), 0, (hipStream_t)stream, f);
+  a.cA = coef; a.cB = coef + C; a.cD = coef + 2 * C; a.out = dx;
+  const long long work = (long long)B * C * ceil_div(N, 1024);
+  hipLaunchKernelGGL((bn_apply_kernel<1>), dim3((unsigned)(work < 65536 ? work : 65536)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  return check_launch("cl3d_bn_relu_bwd");
+}

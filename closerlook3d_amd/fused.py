@@ -252,6 +252,68 @@ def max_pool(query_xyz, support_xyz, query_mask, support_mask, features, radius,
     return _MaxPool.apply(features.contiguous(), idx, _wants_grad(features))
 
 
+class _BnRelu(Function):
+    """ReLU(BatchNorm1d(x)) on channel-major x [B,C,N]; csrc/bn_relu.hip.  x is the only tensor kept for backward."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps):
+        x = x.contiguous()
+        B, C, N = x.shape
+        dev = x.device
+        lib = _lib.lib()
+        out = torch.empty_like(x)
+        with torch.cuda.device(dev):
+            st = _stream(x)
+            if training:
+                vec = torch.empty((4, C), dtype=torch.float32, device=dev)
+                nparts = lib.cl3d_bn_partials(B, C, N)
+                partial = torch.empty((nparts, C, 2), dtype=torch.float64, device=dev)
+                _lib.check(lib.cl3d_bn_relu_stats(_p(x), B, C, N, _p(partial), nparts, float(B * N), float(eps),
+                                                  float(momentum), _p(gamma), _p(beta), _p(running_mean),
+                                                  _p(running_var), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), st))
+                scale, shift = vec[0], vec[1]
+                ctx.save_for_backward(x, vec, gamma)
+                ctx.meta = (B, C, N, nparts)
+            else:
+                invstd64 = torch.rsqrt(running_var.double() + eps)
+                scale64 = gamma.double() * invstd64
+                scale = scale64.float()
+                shift = (beta.double() - running_mean.double() * scale64).float()
+            _lib.check(lib.cl3d_bn_relu_apply(_p(x), _p(scale), _p(shift), B, C, N, _p(out), st))
+        ctx.training = training
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if not ctx.training:
+            raise NotImplementedError("fused BatchNorm+ReLU backward needs training-mode statistics")
+        x, vec, gamma = ctx.saved_tensors
+        B, C, N, nparts = ctx.meta
+        g = g.contiguous()
+        dev = g.device
+        dx = torch.empty_like(x)
+        coef = torch.empty((5, C), dtype=torch.float32, device=dev)
+        partial = torch.empty((nparts, C, 2), dtype=torch.float64, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().cl3d_bn_relu_bwd(_p(g), _p(x), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _p(gamma),
+                                                  B, C, N, float(B * N), _p(partial), nparts, _p(coef), _p(dx),
+                                                  _stream(g)))
+        return dx, coef[3], coef[4], None, None, None, None, None
+
+
+def bn_relu(x, bn):
+    """The engine's BatchNorm1d + ReLU with an nn.BatchNorm1d module's parameters, buffers and semantics; returns
+    None when the configuration is outside what the kernels cover (the caller then runs the nn modules)."""
+    training = bn.training or bn.running_mean is None
+    if (not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3 or not bn.affine or bn.momentum is None
+            or not bn.track_running_stats or (not training and torch.is_grad_enabled() and
+                                              _wants_grad(x, bn.weight, bn.bias))):
+        return None
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BnRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps)
+
+
 class _PointwiseMLP(Function):
     """max_k ReLU(BN(W_r rel + H[centre] + G[nbr])) on point-major rows; see csrc/fused_pwmlp.hip."""
 

@@ -62,6 +62,14 @@ class _OutputTransform(nn.Module):
                 nn.ReLU(inplace=True))
 
     def _output(self, x):
+        # fused path: BatchNorm1d + ReLU through the engine's streaming kernels (same parameters / buffers /
+        # running-statistics rule); 'grouped' keeps the reference's module-by-module dataflow
+        if getattr(self, 'impl', 'auto') != 'grouped' and x.is_cuda:
+            from . import fused
+            seq = self.out_conv if self.output_conv else self.out_transform
+            y = fused.bn_relu(seq[0](x) if self.output_conv else x, seq[-2])
+            if y is not None:
+                return y
         return self.out_conv(x) if self.output_conv else self.out_transform(x)
 
 

@@ -106,6 +106,23 @@ int cl3d_group_xyz_features(const float *query_xyz, const float *support_xyz,
                             int K, float radius, int normalize_xyz, float *rel, float *grouped,
                             cl3d_stream_t stream);
 
+/* BatchNorm1d + ReLU on channel-major x [B,C,N]: the output transform of every LocalAggregation operator
+ * (local_aggregation_operators.py:40-45) as streaming kernels.  Training forward = stats (batch statistics ->
+ * scale/shift/mean/invstd [C] each, running statistics updated with nn.BatchNorm1d's rule; count = B*N;
+ * partial: scratch [cl3d_bn_partials(B,C,N), C, 2] doubles) then apply; inference forward = apply with
+ * scale/shift from the running statistics; bwd: coef [5,C] receives A, Bc, D (dx = A dz + Bc + D x), d gamma,
+ * d beta; the ReLU mask and xhat are recomputed from x. */
+int cl3d_bn_partials(int B, int C, int N);
+int cl3d_bn_relu_stats(const float *x, int B, int C, int N, double *partial, int n_partials, double count,
+                       float eps, float momentum, const float *gamma, const float *beta, float *running_mean,
+                       float *running_var, float *scale, float *shift, float *mean, float *invstd,
+                       cl3d_stream_t stream);
+int cl3d_bn_relu_apply(const float *x, const float *scale, const float *shift, int B, int C, int N, float *out,
+                       cl3d_stream_t stream);
+int cl3d_bn_relu_bwd(const float *g, const float *x, const float *scale, const float *shift, const float *mean,
+                     const float *invstd, const float *gamma, int B, int C, int N, double count, double *partial,
+                     int n_partials, float *coef, float *dx, cl3d_stream_t stream);
+
 /* [B,R,C] -> [B,C,R] float32: the layout change at the fused operators' boundary (channel-major
  * reference tensors <-> point-major rows). */
 int cl3d_transpose(const float *src, int B, int R, int C, float *dst, cl3d_stream_t stream);

@@ -226,3 +226,43 @@ def test_fused_max_pool_matches_reference_dataflow(C, K, N, npoint):
     # and against the CPU oracle
     want = oo.masked_max_pool(torch.from_numpy(xyz), torch.from_numpy(mask), torch.from_numpy(feats), npoint, 0.15, K, 0.08)
     assert np.array_equal(outs[0][0].cpu().numpy(), want[2].numpy())
+
+
+@pytest.mark.parametrize("B,C,N", [(16, 72, 4096), (2, 10, 301), (1, 3, 20000), (3, 144, 64)])
+@pytest.mark.parametrize("training", [True, False])
+def test_bn_relu_matches_torch_modules(B, C, N, training):
+    """The engine's BatchNorm1d + ReLU against nn.BatchNorm1d + nn.ReLU: output, gradients (training), running
+    statistics and num_batches_tracked."""
+    from closerlook3d_amd import fused
+    torch.manual_seed(B * 100 + C)
+    ref = torch.nn.BatchNorm1d(C, momentum=0.1).cuda()
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5)
+        ref.weight[0] = -0.7  # a negative gamma
+        ref.bias.normal_(0, 0.3)
+        ref.running_mean.normal_(0, 0.2)
+        ref.running_var.uniform_(0.5, 2.0)
+    mine = torch.nn.BatchNorm1d(C, momentum=0.1).cuda()
+    mine.load_state_dict(ref.state_dict())
+    ref.train(training)
+    mine.train(training)
+    x = (torch.randn(B, C, N, device="cuda") * 1.7 + 0.4)
+    g = torch.randn(B, C, N, device="cuda")
+    xr = x.clone().requires_grad_(training)
+    xm = x.clone().requires_grad_(training)
+    with torch.set_grad_enabled(training):
+        want = torch.relu(ref(xr))
+        got = fused.bn_relu(xm, mine)
+    assert got is not None
+    assert_close(got.detach().cpu().numpy(), want.detach().cpu().numpy(), 1e-5, "bn_relu out")
+    if training:
+        want.backward(g)
+        got.backward(g)
+        scale = float(xr.grad.abs().max())
+        assert_close(xm.grad.cpu().numpy() / scale, xr.grad.cpu().numpy() / scale, 2e-5, "bn_relu dx")
+        for name in ("weight", "bias"):
+            a, b = getattr(mine, name).grad, getattr(ref, name).grad
+            assert ((a - b).norm() / b.norm()).item() < 1e-4, name
+        assert_close(mine.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), 1e-5, "running_mean")
+        assert_close(mine.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), 1e-5, "running_var")
+        assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 1
