@@ -147,3 +147,29 @@ class MultiPartSegHeadResNet(_UpsampleDecoder):
     def forward(self, end_points):
         feats = self._decode(end_points)
         return [head(feats) for head in self.multi_shape_heads]
+
+
+class MaskedGlobalAvgPool1d(nn.Module):
+    """Mean over the valid points of every cloud.  Reference: heads/classifier.py:6-14."""
+
+    def forward(self, mask, features):
+        return features.sum(-1) / mask.sum(-1)[:, None]
+
+
+class ClassifierResNet(nn.Module):
+    """logits (B, num_classes) from `res5_features`.  Reference: heads/classifier.py:17-54 (same layer indices
+    inside `classifier`, so checkpoints load unchanged)."""
+
+    def __init__(self, num_classes, width):
+        super().__init__()
+        self.num_classes = num_classes
+        self.pool = MaskedGlobalAvgPool1d()
+        layers, cin = [], 16 * width
+        for cout in (8 * width, 4 * width, 2 * width):
+            layers += [nn.Linear(cin, cout), nn.BatchNorm1d(cout), nn.ReLU(inplace=True), nn.Dropout(0.5)]
+            cin = cout
+        layers.append(nn.Linear(cin, num_classes))
+        self.classifier = nn.Sequential(*layers)
+
+    def forward(self, end_points):
+        return self.classifier(self.pool(end_points['res5_mask'], end_points['res5_features']))

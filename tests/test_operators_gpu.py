@@ -266,3 +266,39 @@ def test_bn_relu_matches_torch_modules(B, C, N, training):
         assert_close(mine.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy(), 1e-5, "running_mean")
         assert_close(mine.running_var.cpu().numpy(), ref.running_var.cpu().numpy(), 1e-5, "running_var")
         assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("rel,B,N", [("modelnet/pointwisemlp_dp_fi_df_fc1.yaml", 2, 2048),
+                                     ("partnet/adaptiveweight_dp_fc1_avg.yaml", 2, 2500),
+                                     ("s3dis/pseudo_grid.yaml", 1, 8000)])
+def test_reference_configs_build_and_train_one_step(rel, B, N):
+    """compat.build_model on the reference's own option trees (golden JSON of its YAML files): one forward +
+    backward + SGD step on the GPU for each task's model wrapper, at the configuration's own K / stage sizes."""
+    import json
+    import os
+    from closerlook3d_amd import compat
+    from closerlook3d_amd.pt_utils import ball_query_cache
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_configs.json")) as fh:
+        cfg = compat.Config(json.load(fh)["merged"][rel])
+    if rel.startswith("partnet"):
+        cfg.num_parts, cfg.num_classes = [4, 2, 6], 3
+    cfg.width = 36  # narrower than the shipped 144 to keep the test quick; everything else as configured
+    cfg.npoints = [max(16, n * N // cfg.num_points) for n in cfg.npoints]
+    torch.manual_seed(0)
+    model = compat.build_model(cfg).cuda().train(True)
+    model.init_weights()
+    opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+    rng = np.random.default_rng(3)
+    scale = 1.0 if rel.startswith("modelnet") or rel.startswith("partnet") else 3.0
+    xyz = torch.from_numpy((rng.random((B, N, 3)) * scale).astype(np.float32)).cuda()
+    mask = torch.ones(B, N, dtype=torch.int32, device="cuda")
+    feats = torch.randn(B, cfg.input_features_dim, N, device="cuda")
+    with ball_query_cache():
+        out = model(xyz, mask, feats)
+    outs = out if isinstance(out, list) else [out]
+    want = {"resnet_cls": [(B, cfg.num_classes)], "resnet_scene_seg": [(B, cfg.num_classes, N)],
+            "resnet_part_seg": [(B, p, N) for p in (cfg.num_parts if isinstance(cfg.num_parts, list) else [])]}[cfg.head]
+    assert [tuple(o.shape) for o in outs] == want
+    sum(o.square().mean() for o in outs).backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+    opt.step()
