@@ -21,13 +21,19 @@
 //     sum_k dy * rel follow from sum_k y, dz and the per-channel sums S_a = sum y*rel_a, R_a = sum rel_a.
 // Passes:
 //   TRAIN     (gather, query-major) per channel: sum y, sum y^2, S_a, R_a (double partials);
-//             per (query, channel): y*, k*, sum_k y;  per slot: slotrec {rel, centre index}
+//             per (query, channel): y*, k*, the support index t* of that slot, sum_k y, the centre's H row;
+//             per slot: slotrec {rel, centre index}
 //   APPLY     (element-wise) out = ReLU(scale*y* + shift), transposed to channel-major through LDS
 //   FWD       (gather; inference with running statistics) the same output in one pass
 //   BWD_ROWS  (element-wise) dz at the arg-max (ReLU gate), d beta = sum dz, d gamma = sum dz*xhat,
-//             T_a = sum dz*rel_a(k*) (double partials); then d W_r = A T + Bc R + D S per channel
-//   BWD_SUPPORT (gather, support-major through the CSR inverse of idx) dG_i = sum over slots -> i of dy,
-//             dH_i = sum over queries centred on i of (D sum_k y + K Bc + A dz).  Ordered, no atomics.
+//             T_a = sum dz*rel_a(k*) (double partials); then d W_r = A T + Bc R + D S per channel;
+//             dz and t* leave channel-major for the next pass
+//   HIT       (stream + LDS scatter) hit[i,c] = sum of dz over the (query, channel) pairs with t* = i
+//   BWD_SUPPORT (gather, support-major through the LDS-staged CSR inverse of idx)
+//             dG_i = D (W_r . sum rel + sum H[centre] + |S_i| G_i) + |S_i| Bc + A hit_i,
+//             dH_i = sum over queries centred on i of (D sum_k y + K Bc + A dz).  Ordered, no float atomics
+//             in global memory.
+//   plus the weight plumbing around the per-point library GEMM (split_weight / merge_weight_grad).
 #include "fused_common.h"
 
 namespace cl3d {
