@@ -14,6 +14,8 @@ extern "C" size_t cl3d_workspace_bytes(int op, int B, int N, int M, int K, int C
       return cl3d::grid_subsampling_workspace(B, N);
     case CL3D_OP_INVERSE_INDEX:  // sort keys/values + rocPRIM temporary storage; M*K slots per cloud
       return cl3d::inverse_index_workspace(B, N, M * K);
+    case CL3D_OP_DATASET_GRID:  // keys and order (x2), heads, ranks, rocPRIM temporary storage; one cloud of N points
+      return cl3d::dataset_grid_workspace(N);
     default:  // every other op of ABI v1 keeps its scratch in LDS
       return 0;
   }

@@ -21,5 +21,6 @@ int ball_query_cells(const float *query_xyz, const float *support_xyz, const int
 size_t grid_subsampling_workspace(int B, int N);
 // csr.hip
 size_t inverse_index_workspace(int B, int N, int MK);
+size_t dataset_grid_workspace(int n);
 
 }  // namespace cl3d

@@ -54,6 +54,7 @@ typedef void *cl3d_stream_t; /* hipStream_t */
 #define CL3D_OP_PSEUDO_GRID 9
 #define CL3D_OP_POINTWISE_MLP 10
 #define CL3D_OP_INVERSE_INDEX 11 /* cl3d_build_inverse_index: pass M*K slots as (M, K) */
+#define CL3D_OP_DATASET_GRID 12  /* cl3d_dataset_grid_subsampling: N = points of the cloud (B, M, K, C unused) */
 
 int cl3d_abi_version(void);
 const char *cl3d_last_error_string(void);
@@ -105,6 +106,18 @@ int cl3d_group_xyz_features(const float *query_xyz, const float *support_xyz,
                             const float *features, const int32_t *idx, int B, int C, int N, int M,
                             int K, float radius, int normalize_xyz, float *rel, float *grouped,
                             cl3d_stream_t stream);
+
+/* Dataset-side grid subsampling of ONE cloud (datasets/data_utils.py:12-30 -> ops/cpp_wrappers/cpp_subsampling/
+ * grid_subsampling/grid_subsampling.cpp:5-106): voxel barycentres [*,3], feature means [*,fdim] (features
+ * nullable with fdim = 0) and majority labels [*,ldim] (labels nullable with ldim = 0) of points [N,3]; outputs
+ * need room for N rows, *count receives the number of voxels.  Same float arithmetic as the reference (sums in
+ * original point order); voxels come out in ascending (iz,iy,ix) order and label ties go to the smallest label
+ * (the reference's order and tie-break are those of an unordered_map walk, i.e. unspecified).
+ * ws: cl3d_workspace_bytes(CL3D_OP_DATASET_GRID, 1, N, 0, 0, 0). */
+int cl3d_dataset_grid_subsampling(const float *points, const float *features, const int32_t *labels, int N,
+                                  int fdim, int ldim, float sampleDl, float *sub_points, float *sub_features,
+                                  int32_t *sub_labels, int32_t *count, void *ws, size_t ws_bytes,
+                                  cl3d_stream_t stream);
 
 /* BatchNorm1d + ReLU on channel-major x [B,C,N]: the output transform of every LocalAggregation operator
  * (local_aggregation_operators.py:40-45) as streaming kernels.  Training forward = stats (batch statistics ->

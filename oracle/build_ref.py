@@ -56,6 +56,39 @@ def build(verbose=False):
     return os.path.join(OUT_DIR, "ref_ext.so")
 
 
+REF_GRID_SRC = "/root/reference/pytorch/ops/cpp_wrappers"
+
+
+def grid_available():
+    return os.path.isdir(os.path.join(REF_GRID_SRC, "cpp_subsampling"))
+
+
+def build_grid():
+    """oracle/_ref/libgrid_dataset_ref.so: the reference's dataset-side grid_subsampling.cpp + cloud.cpp (compiled
+    from where they lie, g++ -std=c++11 like the reference's setup.py) behind oracle/grid_dataset_shim.cpp."""
+    import subprocess
+    if not grid_available():
+        raise RuntimeError("reference tree not present")
+    os.makedirs(OUT_DIR, exist_ok=True)
+    out = os.path.join(OUT_DIR, "libgrid_dataset_ref.so")
+    sub = os.path.join(REF_GRID_SRC, "cpp_subsampling")
+    cmd = ["g++", "-std=c++11", "-O2", "-fPIC", "-shared", "-I", sub,
+           os.path.join(HERE, "grid_dataset_shim.cpp"), os.path.join(sub, "grid_subsampling", "grid_subsampling.cpp"),
+           os.path.join(REF_GRID_SRC, "cpp_utils", "cloud", "cloud.cpp"), "-o", out]
+    subprocess.run(cmd, check=True)
+    return out
+
+
+def load_grid():
+    """ctypes handle of oracle/_ref/libgrid_dataset_ref.so (CPU code: runs anywhere the file travels to)."""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(OUT_DIR, "libgrid_dataset_ref.so"))
+    lib.cl3d_ref_dataset_grid_subsampling.restype = ctypes.c_int
+    lib.cl3d_ref_dataset_grid_subsampling.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_float] + \
+        [ctypes.c_void_p] * 3
+    return lib
+
+
 def load():
     """Import oracle/_ref/ref_ext.so as a Python module (needs torch; GPU needed to call it)."""
     import importlib.util

@@ -305,3 +305,77 @@ int oracle_masked_nearest_query(const float *query_xyz, const float *support_xyz
   }
   return 0;
 }
+
+/* dataset-side grid subsampling (reference: ops/cpp_wrappers/cpp_subsampling/
+ * grid_subsampling/grid_subsampling.cpp:5-106, grid_subsampling.h:11-80, cpp_utils/cloud/cloud.h,cloud.cpp).
+ * Voxel of a point: floor((p - origin)/dl) per axis in float, origin = floor(min * (1/dl)) * dl (:25-27,52-56);
+ * per voxel, in ORIGINAL POINT ORDER: count, float sums of the coordinates and of the features, label
+ * histograms (:59-66); output = sum * (float)(1.0/count) for the coordinates (:86: double reciprocal narrowed to
+ * the float operand of PointXYZ*float), feature sum / (float)count (:89-93), most frequent label per label
+ * column (:100-101).
+ * The reference walks an unordered_map, so its output ORDER (and which of several equally frequent labels wins)
+ * is implementation-defined; this restatement emits voxels in ascending (iz, iy, ix) and takes the smallest of the
+ * most frequent labels.  Returns the number of voxels. */
+typedef struct { long long key; int idx; } dkv;
+static int dkv_cmp(const void *a, const void *b) {
+  const dkv *x = (const dkv *)a, *y = (const dkv *)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx);
+}
+
+int oracle_dataset_grid_subsampling(const float *points, const float *features, const int *labels, int n, int fdim,
+                                    int ldim, float dl, float *sub_points, float *sub_features, int *sub_labels) {
+  if (n <= 0) return 0;
+  float mn[3], mx[3];
+  for (int a = 0; a < 3; ++a) mn[a] = mx[a] = points[a];
+  for (int i = 0; i < n; ++i)
+    for (int a = 0; a < 3; ++a) {
+      const float v = points[3 * i + a];
+      if (v < mn[a]) mn[a] = v;
+      if (v > mx[a]) mx[a] = v;
+    }
+  const float inv = 1 / dl; /* (1/sampleDl): int / float -> float */
+  float org[3];
+  for (int a = 0; a < 3; ++a) org[a] = floorf(mn[a] * inv) * dl;
+  const long long nx = (long long)floorf((mx[0] - org[0]) / dl) + 1;
+  const long long ny = (long long)floorf((mx[1] - org[1]) / dl) + 1;
+  dkv *kv = (dkv *)malloc(sizeof(dkv) * (size_t)n);
+  for (int i = 0; i < n; ++i) {
+    const long long ix = (long long)floorf((points[3 * i] - org[0]) / dl);
+    const long long iy = (long long)floorf((points[3 * i + 1] - org[1]) / dl);
+    const long long iz = (long long)floorf((points[3 * i + 2] - org[2]) / dl);
+    kv[i].key = ix + nx * iy + nx * ny * iz;
+    kv[i].idx = i;
+  }
+  qsort(kv, (size_t)n, sizeof(dkv), dkv_cmp); /* by (voxel, original index): the fold below runs in point order */
+  int m = 0;
+  for (int s = 0; s < n;) {
+    int e = s;
+    while (e < n && kv[e].key == kv[s].key) ++e;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int f = 0; f < fdim; ++f) sub_features[(size_t)m * fdim + f] = 0.f;
+    for (int t = s; t < e; ++t) {
+      const int i = kv[t].idx;
+      sx += points[3 * i]; sy += points[3 * i + 1]; sz += points[3 * i + 2];
+      for (int f = 0; f < fdim; ++f) sub_features[(size_t)m * fdim + f] += features[(size_t)i * fdim + f];
+    }
+    const int count = e - s;
+    const float r = (float)(1.0 / count);
+    sub_points[3 * m] = sx * r; sub_points[3 * m + 1] = sy * r; sub_points[3 * m + 2] = sz * r;
+    for (int f = 0; f < fdim; ++f) sub_features[(size_t)m * fdim + f] /= (float)count;
+    for (int c = 0; c < ldim; ++c) {
+      int best = 0, best_cnt = 0;
+      for (int t = s; t < e; ++t) {
+        const int lab = labels[(size_t)kv[t].idx * ldim + c];
+        int cnt = 0;
+        for (int u = s; u < e; ++u) cnt += labels[(size_t)kv[u].idx * ldim + c] == lab;
+        if (cnt > best_cnt || (cnt == best_cnt && lab < best)) { best = lab; best_cnt = cnt; }
+      }
+      sub_labels[(size_t)m * ldim + c] = best;
+    }
+    ++m;
+    s = e;
+  }
+  free(kv);
+  return m;
+}

@@ -103,3 +103,22 @@ def masked_nearest_query(query_xyz, support_xyz, query_mask, support_mask):
         idx.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), msk.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
     assert rc == 0
     return idx, msk
+
+
+def dataset_grid_subsampling(points, features=None, labels=None, sampleDl=0.1):
+    """Dataset-side grid subsampling (datasets/data_utils.py:12-30 -> grid_subsampling.cpp), voxels in ascending
+    (iz, iy, ix) order.  Returns (sub_points [m,3], sub_features [m,fdim] | None, sub_labels [m,ldim] | None)."""
+    p, pp = _f32(points)
+    n = p.shape[0]
+    fdim = 0 if features is None else np.asarray(features).shape[1]
+    ldim = 0 if labels is None else np.asarray(labels).shape[1]
+    f, fp = _f32(features if features is not None else np.zeros((1, 1)))
+    l, lp = _i32(labels if labels is not None else np.zeros((1, 1)))
+    sp = np.zeros((n, 3), np.float32)
+    sf = np.zeros((n, max(fdim, 1)), np.float32)
+    sl = np.zeros((n, max(ldim, 1)), np.int32)
+    fn = lib().oracle_dataset_grid_subsampling
+    fn.restype = ctypes.c_int
+    m = fn(pp, fp, lp, n, fdim, ldim, ctypes.c_float(sampleDl), sp.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+           sf.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), sl.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+    return sp[:m], (sf[:m, :fdim] if fdim else None), (sl[:m, :ldim] if ldim else None)

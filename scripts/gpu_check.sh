@@ -35,6 +35,8 @@ echo "== backbone steps (scripts/bench_backbone.py)" | tee -a $OUT/summary.txt
 for c in modelnet_small modelnet_pointwisemlp s3dis_pseudogrid partnet_adaptive s3dis_pospool_deep; do
   timeout 600 python scripts/bench_backbone.py --config $c 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
 done
+echo "== dataset-side grid subsampling (SURVEY 8(f) rank 2): engine vs the reference's C++ on the host" | tee -a $OUT/summary.txt
+timeout 600 python scripts/bench_dataset_grid.py 2>/dev/null | tee $OUT/bench_dataset_grid.json | tee -a $OUT/summary.txt
 # keep the merged output small: drop raw traces, keep stats and counter tables
 find $OUT -type f -name "*kernel_trace*" -delete 2>/dev/null
 find $OUT -type f -size +3M -delete 2>/dev/null
