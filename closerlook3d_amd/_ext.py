@@ -39,7 +39,7 @@ def group_points(points, idx):
     B, C, N = points.shape
     _, M, K = idx.shape
     out = torch.empty((B, C, M, K), dtype=torch.float32, device=points.device)
-    with torch.cuda.device(points.device):
+    with _lib.on_device(points.device):
         _lib.check(_lib.lib().cl3d_group_points(_p(points), _p(idx), B, C, N, M, K, _p(out),
                                                 _lib.stream_ptr(points.device)))
     return out
@@ -51,7 +51,7 @@ def group_points_grad(grad_out, idx, n):
     _check_dev(grad_out, idx=idx)
     B, C, M, K = grad_out.shape
     out = torch.empty((B, C, int(n)), dtype=torch.float32, device=grad_out.device)
-    with torch.cuda.device(grad_out.device):
+    with _lib.on_device(grad_out.device):
         _lib.check(_lib.lib().cl3d_group_points_grad(_p(grad_out), _p(idx), B, C, int(n), M, K, _p(out),
                                                      None, 0, _lib.stream_ptr(grad_out.device)))
     return out
@@ -70,7 +70,7 @@ def masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, 
     lib = _lib.lib()
     ws_bytes = lib.cl3d_workspace_bytes(1, B, N, M, int(nsample), 0)  # CL3D_OP_BALL_QUERY
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=query_xyz.device) if ws_bytes else None
-    with torch.cuda.device(query_xyz.device):
+    with _lib.on_device(query_xyz.device):
         _lib.check(lib.cl3d_masked_ordered_ball_query(
             _p(query_xyz), _p(support_xyz), _p(query_mask), _p(support_mask), B, M, N, float(radius),
             int(nsample), _p(idx), _p(idx_mask), _p(ws) if ws is not None else None, ws_bytes,
@@ -88,7 +88,7 @@ def masked_grid_subsampling(points, mask, nsamples, sampleDl):
     lib = _lib.lib()
     ws_bytes = lib.cl3d_workspace_bytes(4, B, N, 0, 0, 0)  # CL3D_OP_GRID_SUBSAMPLING (non-zero for N > 16384)
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=points.device) if ws_bytes else None
-    with torch.cuda.device(points.device):
+    with _lib.on_device(points.device):
         _lib.check(lib.cl3d_masked_grid_subsampling(
             _p(points), _p(mask), B, N, int(nsamples), float(sampleDl), _p(sub), _p(sub_mask),
             _p(ws) if ws is not None else None, ws_bytes, _lib.stream_ptr(points.device)))
@@ -105,7 +105,7 @@ def masked_nearest_query(query_xyz, support_xyz, query_mask, support_mask):
     N = support_xyz.shape[1]
     idx = torch.empty((B, M, 1), dtype=torch.int32, device=query_xyz.device)
     idx_mask = torch.empty_like(idx)
-    with torch.cuda.device(query_xyz.device):
+    with _lib.on_device(query_xyz.device):
         _lib.check(_lib.lib().cl3d_masked_nearest_query(
             _p(query_xyz), _p(support_xyz), _p(query_mask), _p(support_mask), B, M, N, _p(idx),
             _p(idx_mask), _lib.stream_ptr(query_xyz.device)))
@@ -129,7 +129,7 @@ def group_xyz_features(query_xyz, support_xyz, features, idx, radius, normalize_
         C = features.shape[1]
         grouped = torch.empty((B, C, M, K), dtype=torch.float32, device=idx.device)
         fptr, gptr = _p(features), _p(grouped)
-    with torch.cuda.device(idx.device):
+    with _lib.on_device(idx.device):
         _lib.check(_lib.lib().cl3d_group_xyz_features(
             _p(query_xyz), _p(support_xyz), fptr, _p(idx), B, C, N, M, K, float(radius),
             1 if normalize_xyz else 0, _p(rel), gptr, _lib.stream_ptr(idx.device)))

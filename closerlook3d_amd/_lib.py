@@ -91,3 +91,23 @@ def check(rc):
 
 def stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _NoOp:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NOOP = _NoOp()
+
+
+def on_device(device):
+    """`with on_device(t.device):` -- torch.cuda.device(...) only when it would actually switch devices (the
+    context manager costs ~5 us of host time per use, and a step makes dozens of engine calls)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NOOP
+    return torch.cuda.device(device)

@@ -42,7 +42,7 @@ def grid_subsampling(points, features=None, labels=None, sampleDl=0.1, verbose=0
     ws_bytes = lib.cl3d_workspace_bytes(12, 1, N, 0, 0, 0)  # CL3D_OP_DATASET_GRID
     ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
     ptr = lambda t: None if t is None else t.data_ptr()  # noqa: E731
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(lib.cl3d_dataset_grid_subsampling(ptr(p), ptr(f), ptr(lb), N, fdim, ldim, float(sampleDl), ptr(sp),
                                                      ptr(sf), ptr(sl), ptr(count), ptr(ws), ws_bytes,
                                                      _lib.stream_ptr(dev)))

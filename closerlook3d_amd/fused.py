@@ -59,7 +59,7 @@ def _build_inverse(idx, n_support):
     lib = _lib.lib()
     ws_bytes = lib.cl3d_workspace_bytes(11, B, n_support, MK, 1, 0)  # CL3D_OP_INVERSE_INDEX
     ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=idx.device)
-    with torch.cuda.device(idx.device):
+    with _lib.on_device(idx.device):
         _lib.check(lib.cl3d_build_inverse_index(_p(idx), B, n_support, MK, _p(off), _p(slots), _p(ws), ws_bytes,
                                                 _stream(idx)))
     return off, slots
@@ -109,7 +109,7 @@ def _transposed(t):
     t = t.contiguous()
     B, R, C = t.shape
     out = torch.empty((B, C, R), dtype=t.dtype, device=t.device)
-    with torch.cuda.device(t.device):
+    with _lib.on_device(t.device):
         _lib.check(_lib.lib().cl3d_transpose(_p(t), B, R, C, _p(out), _stream(t)))
     return out
 
@@ -126,7 +126,7 @@ class _FusedReduce(Function):
         wait_ready(idx)  # ball query ran on the index stream
         out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)  # channel-major, written by the kernel
         slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=features.device) if need_grad else None
-        with torch.cuda.device(features.device):
+        with _lib.on_device(features.device):
             _lib.check(_lib.lib().cl3d_fused_reduce_fwd(
                 op, _p(query_xyz), _p(support_xyz), _p(query_mask), _p(idx), _p(idx_mask), _p(ft), B, N, M, K, C,
                 float(radius), int(normalize), reduction, _p(p0), _p(p1), pint, float(pfloat), int(constant),
@@ -148,7 +148,7 @@ class _FusedReduce(Function):
         nparts = lib.cl3d_fused_param_partials(op, B, N, C)
         npar = {OP_ADAPTIVE: 4, OP_PSEUDOGRID: 16}.get(op, 0)
         dparam = torch.empty((nparts, C, npar), dtype=torch.float32, device=gout.device) if nparts else None
-        with torch.cuda.device(gout.device):
+        with _lib.on_device(gout.device):
             _lib.check(lib.cl3d_fused_reduce_bwd(op, _p(gout_t), _p(ft), _p(slotrec), _p(ctx.idx), _p(off), _p(slots), B, N, M, K,
                                                  C, _p(p0), _p(p1), pint, float(pfloat), int(constant), _p(dft),
                                                  _p(dparam), nparts, _stream(gout)))
@@ -224,7 +224,7 @@ class _MaxPool(Function):
         wait_ready(idx)
         out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)
         kstar = torch.empty((B, M, C), dtype=torch.uint8, device=features.device) if need_grad else None
-        with torch.cuda.device(features.device):
+        with _lib.on_device(features.device):
             _lib.check(_lib.lib().cl3d_maxpool_fwd(_p(idx), _p(ft), B, N, M, K, C, _p(out), _p(kstar),
                                                    _stream(features)))
         ctx.save_for_backward(kstar)
@@ -240,7 +240,7 @@ class _MaxPool(Function):
         gout_t = _transposed(gout)
         off, slots = inverse_index(ctx.idx, N)
         dft = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
-        with torch.cuda.device(gout.device):
+        with _lib.on_device(gout.device):
             _lib.check(_lib.lib().cl3d_maxpool_bwd(_p(gout_t), _p(kstar), _p(off), _p(slots), B, N, M, K, C, _p(dft),
                                                    _stream(gout)))
         return _transposed(dft), None, None
@@ -262,7 +262,7 @@ class _BnRelu(Function):
         dev = x.device
         lib = _lib.lib()
         out = torch.empty_like(x)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             st = _stream(x)
             if training:
                 vec = torch.empty((4, C), dtype=torch.float32, device=dev)
@@ -294,7 +294,7 @@ class _BnRelu(Function):
         dx = torch.empty_like(x)
         coef = torch.empty((5, C), dtype=torch.float32, device=dev)
         partial = torch.empty((nparts, C, 2), dtype=torch.float64, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.check(_lib.lib().cl3d_bn_relu_bwd(_p(g), _p(x), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _p(gamma),
                                                   B, C, N, float(B * N), _p(partial), nparts, _p(coef), _p(dx),
                                                   _stream(g)))
@@ -329,7 +329,7 @@ class _PointwiseMLP(Function):
         nparts = lib.cl3d_pwmlp_partials(B, M, Co)
         wait_ready(idx)  # ball query ran on the index stream while the per-point GEMM ran here
         out = torch.empty((B, Co, M), dtype=torch.float32, device=dev)  # channel-major, written by the kernels
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             st = _stream(ght)
             if training:
                 # one gather pass: batch statistics AND, per (query, channel), the pre-activation that wins the
@@ -377,7 +377,7 @@ class _PointwiseMLP(Function):
         lib = _lib.lib()
         n = B * M * K
         gout = gout.contiguous()  # channel-major [B,Co,M], read directly by the kernel
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             st = _stream(gout)
             dz_cm = torch.empty((B, Co, M), dtype=torch.float32, device=dev)
             ts_cm = torch.empty((B, Co, M), dtype=torch.int32, device=dev)
@@ -422,7 +422,7 @@ class _PointRows(Function):
         W = W.contiguous()
         wr = torch.empty((Co, 3), dtype=torch.float32, device=W.device)
         wcat = torch.empty((2 * Co, C), dtype=torch.float32, device=W.device)
-        with torch.cuda.device(W.device):
+        with _lib.on_device(W.device):
             _lib.check(_lib.lib().cl3d_pwmlp_split_weight(_p(W), Co, C, _p(wr), _p(wcat), _stream(W)))
         ctx.save_for_backward(features, wcat)
         ght = torch.bmm(features.transpose(1, 2), wcat.t().unsqueeze(0).expand(B, -1, -1))
@@ -441,7 +441,7 @@ class _PointRows(Function):
                    else torch.zeros((B, C, 2 * Co), dtype=torch.float32, device=features.device))
             dW = torch.empty((Co, 3 + 2 * C), dtype=torch.float32, device=features.device)
             dwr = dwr.contiguous() if dwr is not None else None
-            with torch.cuda.device(features.device):
+            with _lib.on_device(features.device):
                 _lib.check(_lib.lib().cl3d_pwmlp_merge_weight_grad(_p(dwr), _p(dwb), B, Co, C, _p(dW), _stream(dwb)))
         return dfeat, dW
 
