@@ -124,27 +124,29 @@ __device__ __forceinline__ void add4(double *acc, int n0, unsigned span, const i
   if ((unsigned)(ii.w - n0) < span) atomicAdd(&acc[ii.w - n0], (double)v.w);
 }
 
+// CH channel rows of one cloud per block share every index load (the cloud's index stream is re-read once per
+// block: at C = 64 that is as many L2 bytes as the gradient itself when CH = 1).
+template <int CH>
 __global__ __launch_bounds__(256) void group_bwd_lds_kernel(const float *__restrict__ grad_out,
                                                             const int *__restrict__ idx, int C, int N,
                                                             int MK, int T,
                                                             float *__restrict__ grad_points) {
-  extern __shared__ double acc[];  // [T]: this block owns support indices [n0, n0+T)
-  const int bc = blockIdx.x;
+  extern __shared__ double acc[];  // [CH][T]: this block owns support indices [n0, n0+T) of CH channels
+  const int bc = blockIdx.x * CH;  // first (cloud, channel) row; C % CH == 0, so all CH rows are of one cloud
   const int b = bc / C;
   const int n0 = blockIdx.y * T;
   const unsigned span = (unsigned)(N - n0 < T ? N - n0 : T);
-  for (int i = threadIdx.x; i < T; i += 256) acc[i] = 0.0;
+  for (int i = threadIdx.x; i < CH * T; i += 256) acc[i] = 0.0;
   __syncthreads();
 
   const float *g = grad_out + (size_t)bc * MK;
   const int *ib = idx + (size_t)b * MK;
   if ((MK & 3) == 0) {
     const int4 *i4 = reinterpret_cast<const int4 *>(ib);
-    const float4 *g4 = reinterpret_cast<const float4 *>(g);
     const int nq = MK >> 2;
     constexpr int kStride = 256 * kBwdStage;
     int4 ci[kBwdStage], ni[kBwdStage];
-    float4 cv[kBwdStage], nv[kBwdStage];
+    float4 cv[kBwdStage][CH], nv[kBwdStage][CH];
     const int4 none = make_int4(-1, -1, -1, -1);
     int q = threadIdx.x;
 #pragma unroll
@@ -152,7 +154,8 @@ __global__ __launch_bounds__(256) void group_bwd_lds_kernel(const float *__restr
       const int qq = q + u * 256;
       const int qc = qq < nq ? qq : nq - 1;  // always a valid address; out-of-range lanes are disabled via idx
       ci[u] = i4[qc];
-      cv[u] = load_stream(&g4[qc]);
+#pragma unroll
+      for (int c = 0; c < CH; ++c) cv[u][c] = load_stream(reinterpret_cast<const float4 *>(g + (size_t)c * MK) + qc);
       if (qq >= nq) ci[u] = none;
     }
     for (; q < nq; q += kStride) {
@@ -161,26 +164,33 @@ __global__ __launch_bounds__(256) void group_bwd_lds_kernel(const float *__restr
         const int qq = q + kStride + u * 256;
         const int qc = qq < nq ? qq : nq - 1;
         ni[u] = i4[qc];
-        nv[u] = load_stream(&g4[qc]);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) nv[u][c] = load_stream(reinterpret_cast<const float4 *>(g + (size_t)c * MK) + qc);
         if (qq >= nq) ni[u] = none;
       }
 #pragma unroll
-      for (int u = 0; u < kBwdStage; ++u) add4(acc, n0, span, ci[u], cv[u]);
+      for (int u = 0; u < kBwdStage; ++u)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) add4(acc + (size_t)c * T, n0, span, ci[u], cv[u][c]);
 #pragma unroll
       for (int u = 0; u < kBwdStage; ++u) {
         ci[u] = ni[u];
-        cv[u] = nv[u];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) cv[u][c] = nv[u][c];
       }
     }
   } else {
     for (int e = threadIdx.x; e < MK; e += 256) {
       const int i = ib[e];
-      if ((unsigned)(i - n0) < span) atomicAdd(&acc[i - n0], (double)g[e]);
+      if ((unsigned)(i - n0) < span)
+        for (int c = 0; c < CH; ++c) atomicAdd(&acc[(size_t)c * T + i - n0], (double)g[(size_t)c * MK + e]);
     }
   }
   __syncthreads();
-  float *dst = grad_points + (size_t)bc * N + n0;
-  for (int i = threadIdx.x; i < (int)span; i += 256) dst[i] = (float)acc[i];
+  for (int c = 0; c < CH; ++c) {
+    float *dst = grad_points + (size_t)(bc + c) * N + n0;
+    for (int i = threadIdx.x; i < (int)span; i += 256) dst[i] = (float)acc[(size_t)c * T + i];
+  }
 }
 
 // -------------------------------------------------- fused relative-position + feature gather
@@ -212,6 +222,45 @@ __global__ __launch_bounds__(256) void group_rel_kernel(const float *__restrict_
     r[e] = dx;
     r[MK + e] = dy;
     r[2 * MK + e] = dz;
+  }
+}
+
+// Same output, for clouds whose coordinates fit LDS (N <= 5461): the support cloud is staged once per block
+// (it is gathered 3*MK times), a thread owns four consecutive slots -- one int4 index load, three float4 stores.
+constexpr int kRelSlotsPerBlock = 8192;
+__global__ __launch_bounds__(256) void group_rel_lds_kernel(const float *__restrict__ query_xyz,
+                                                            const float *__restrict__ support_xyz,
+                                                            const int *__restrict__ idx, int N, int M, int K,
+                                                            float inv, int normalize, float *__restrict__ rel) {
+  extern __shared__ float sxyz[];  // [N*3]
+  const int b = blockIdx.y;
+  const int MK = M * K;
+  const float *q = query_xyz + (size_t)b * M * 3;
+  const float *s = support_xyz + (size_t)b * N * 3;
+  for (int t = threadIdx.x; t < N * 3; t += 256) sxyz[t] = s[t];
+  __syncthreads();
+  const int4 *ib4 = reinterpret_cast<const int4 *>(idx + (size_t)b * MK);
+  float *r = rel + (size_t)b * 3 * MK;
+  const int e_begin = blockIdx.x * kRelSlotsPerBlock;
+  const int e_end = e_begin + kRelSlotsPerBlock < MK ? e_begin + kRelSlotsPerBlock : MK;
+  for (int e = e_begin + 4 * (int)threadIdx.x; e < e_end; e += 1024) {
+    const int4 ii = ib4[e >> 2];
+    const int iv[4] = {ii.x, ii.y, ii.z, ii.w};
+    float o[3][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = (e + u) / K;
+      const int i = (unsigned)iv[u] < (unsigned)N ? iv[u] : 0;  // an index outside the cloud (failed nearest query) reads point 0
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        float d = sxyz[i * 3 + a] - q[j * 3 + a];
+        if (normalize) d *= inv;
+        o[a][u] = d;
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+      store_stream(reinterpret_cast<float4 *>(r + (size_t)a * MK + e), make_float4(o[a][0], o[a][1], o[a][2], o[a][3]));
   }
 }
 
@@ -280,8 +329,12 @@ extern "C" int cl3d_group_points_grad(const float *grad_out, const int32_t *idx,
   const int T = N <= kTile ? N : kTile;
   const int ntiles = cl3d::ceil_div(N, T);
   CL3D_REQUIRE(ntiles <= 65535, "group_points_grad: N too large");
-  hipLaunchKernelGGL(cl3d::group_bwd_lds_kernel, dim3(B * C, ntiles), dim3(256), (size_t)T * sizeof(double), st,
-                     grad_out, idx, C, N, MK, T, grad_points);
+  if ((C & 1) == 0 && T <= 4096)  // two channel rows per block share the index stream (2 x 32 KiB of LDS)
+    hipLaunchKernelGGL(cl3d::group_bwd_lds_kernel<2>, dim3(B * C / 2, ntiles), dim3(256), (size_t)2 * T * sizeof(double), st,
+                       grad_out, idx, C, N, MK, T, grad_points);
+  else
+    hipLaunchKernelGGL(cl3d::group_bwd_lds_kernel<1>, dim3(B * C, ntiles), dim3(256), (size_t)T * sizeof(double), st,
+                       grad_out, idx, C, N, MK, T, grad_points);
   return cl3d::check_launch("cl3d_group_points_grad");
 }
 
@@ -301,7 +354,12 @@ extern "C" int cl3d_group_xyz_features(const float *query_xyz, const float *supp
   // the reference computes grouped_xyz /= radius through ATen's scalar-divide, which on the GPU
   // multiplies by the float reciprocal (BinaryDivTrueKernel) -- same here.
   const float inv = 1.0f / radius;
-  hipLaunchKernelGGL(cl3d::group_rel_kernel, dim3(gx, B), dim3(256), 0, st, query_xyz, support_xyz, idx, N, M, K, inv, normalize_xyz, rel);
+  if ((size_t)N * 12 <= 64 * 1024 && (MKll & 3) == 0) {
+    hipLaunchKernelGGL(cl3d::group_rel_lds_kernel, dim3(cl3d::ceil_div((int)MKll, cl3d::kRelSlotsPerBlock), B), dim3(256),
+                       (size_t)N * 12, st, query_xyz, support_xyz, idx, N, M, K, inv, normalize_xyz, rel);
+  } else {
+    hipLaunchKernelGGL(cl3d::group_rel_kernel, dim3(gx, B), dim3(256), 0, st, query_xyz, support_xyz, idx, N, M, K, inv, normalize_xyz, rel);
+  }
   int rc = cl3d::check_launch("cl3d_group_xyz_features(rel)");
   if (rc != CL3D_OK) return rc;
   if (features != nullptr && C > 0) {
