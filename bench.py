@@ -316,6 +316,7 @@ def main():
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()  # rank 0 measured the per-kernel rooflines after the timed region: leave together
         dist.destroy_process_group()
 
 
