@@ -1,0 +1,23 @@
+"""GPU: the C ABI used from plain C++ (examples/abi_host.cpp): hipMalloc'd buffers, a caller-owned stream, no Python
+and no torch in the process -- compiled with hipcc on the box and run as a separate program."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_host_program_runs_against_the_library(tmp_path):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib_dir = os.path.join(ROOT, "closerlook3d_amd")
+    assert os.path.exists(os.path.join(lib_dir, "libcl3d.so")), "libcl3d.so not built"
+    exe = str(tmp_path / "abi_host")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O2", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "abi_host.cpp"), "-L", lib_dir, "-lcl3d",
+                    f"-Wl,-rpath,{lib_dir}", "-o", exe], check=True, timeout=300)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "violations 0" in out.stdout and "null input -> rc -1" in out.stdout
