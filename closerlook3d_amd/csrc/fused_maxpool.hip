@@ -17,7 +17,8 @@ struct MaxArgs {
   unsigned char *kstar_t;     // [B,M,C]
   const float *gout_t;        // bwd: [B,M,C]
   const int *inv_off, *inv_slots;
-  float *dft;                 // bwd: [B,N,C]
+  float *dft;                 // bwd: [B,N,C], or [B,C,N] when dft_channel_major
+  int dft_channel_major;
   int B, N, M, K, C;
   int L, QW, chunks;
 };
@@ -135,7 +136,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxArgs a) {
       Vec<V> o;
 #pragma unroll
       for (int v = 0; v < V; ++v) o.v[v] = acc[v];
-      store_row<V>(a.dft + ((size_t)b * N + i) * C + c0, o);
+      if (a.dft_channel_major) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) a.dft[((size_t)b * C + c0 + v) * N + i] = o.v[v];
+      } else {
+        store_row<V>(a.dft + ((size_t)b * N + i) * C + c0, o);
+      }
     }
   }
 }
@@ -153,8 +159,8 @@ extern "C" int cl3d_maxpool_fwd(const int32_t *idx, const float *ft, int B, int 
   a.idx = idx; a.ft = ft; a.out = out; a.kstar_t = kstar_t; a.B = B; a.N = N; a.M = M; a.K = K; a.C = C;
   const int V = (C % 4 == 0) ? 4 : 1;
   LaneMap m = pick_lane_map(C, V);
-  while (4 * (size_t)m.QW * K * sizeof(int) > 48 * 1024 && m.QW > 1) m.QW -= 1;
-  if (4 * (size_t)m.QW * K * sizeof(int) > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "maxpool_fwd: nsample too large for LDS");
+  while (4 * (size_t)m.QW * (K + 1) * sizeof(int) > 48 * 1024 && m.QW > 1) m.QW -= 1;
+  if (4 * (size_t)m.QW * (K + 1) * sizeof(int) > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "maxpool_fwd: nsample too large for LDS");
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const dim3 grid(virtual_tiles(B, ceil_div(M, 4 * m.QW)));
   const size_t lds = 4 * (size_t)m.QW * (K + 1) * sizeof(int);
@@ -165,6 +171,7 @@ extern "C" int cl3d_maxpool_fwd(const int32_t *idx, const float *ft, int B, int 
 
 extern "C" int cl3d_maxpool_bwd(const float *gout_t, const unsigned char *kstar_t, const int32_t *inv_off,
                                 const int32_t *inv_slots, int B, int N, int M, int K, int C, float *dft,
+                                int dft_channel_major,
                                 cl3d_stream_t stream) {
   using namespace cl3d;
   CL3D_REQUIRE(B >= 0 && N >= 1 && M >= 0 && K >= 1 && K <= 255 && C >= 1, "maxpool_bwd: bad sizes");
@@ -172,7 +179,7 @@ extern "C" int cl3d_maxpool_bwd(const float *gout_t, const unsigned char *kstar_
   CL3D_REQUIRE(gout_t && kstar_t && inv_off && inv_slots && dft, "maxpool_bwd: null pointer");
   MaxArgs a{};
   a.gout_t = gout_t; a.kstar_t = const_cast<unsigned char *>(kstar_t); a.inv_off = inv_off; a.inv_slots = inv_slots;
-  a.dft = dft; a.B = B; a.N = N; a.M = M; a.K = K; a.C = C;
+  a.dft = dft; a.dft_channel_major = dft_channel_major; a.B = B; a.N = N; a.M = M; a.K = K; a.C = C;
   const int V = (C % 4 == 0) ? 4 : 1;
   const LaneMap m = pick_lane_map(C, V);
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;

@@ -30,7 +30,8 @@ struct ReduceArgs {
   float *out_t;          // fwd: [B,M,C]
   float4 *slotrec;       // [B,M,K]  {rel.x, rel.y, rel.z, coef}; fwd writes (may be null), bwd reads
   const int *inv_off, *inv_slots;
-  float *dft;            // bwd: [B,N,C]
+  float *dft;            // bwd: [B,N,C], or [B,C,N] when dft_channel_major
+  int dft_channel_major;
   float *dparam;         // bwd: [gridDim.x, C, NP] partial parameter gradients (may be null)
   int B, N, M, K, C;
   int L, QW, chunks;
@@ -447,7 +448,12 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
       Vec<V> o;
 #pragma unroll
       for (int v = 0; v < V; ++v) o.v[v] = acc[v];
-      store_row<V>(a.dft + ((size_t)b * N + i) * C + c0, o);
+      if (a.dft_channel_major) {  // the API layout [B,C,N], written directly instead of a transpose pass
+#pragma unroll
+        for (int v = 0; v < V; ++v) a.dft[((size_t)b * C + c0 + v) * N + i] = o.v[v];
+      } else {
+        store_row<V>(a.dft + ((size_t)b * N + i) * C + c0, o);
+      }
     }
     // ---- fixed-order block reduction of the parameter partials for this channel chunk
     if constexpr (NP > 0) {
@@ -708,12 +714,12 @@ extern "C" int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *f
                                      const float *slotrec, const int32_t *idx, const int32_t *inv_off,
                                      const int32_t *inv_slots, int B, int N, int M, int K, int C,
                                      const float *p0, const float *p1, int pint, float pfloat,
-                                     int constant_influence, float *dft, float *dparam,
+                                     int constant_influence, float *dft, int dft_channel_major, float *dparam,
                                      int n_partials, cl3d_stream_t stream) {
   using namespace cl3d;
   ReduceArgs a{};
   a.gout_t = gout_t; a.ft = ft; a.slotrec = reinterpret_cast<float4 *>(const_cast<float *>(slotrec));
-  a.idx = idx; a.inv_off = inv_off; a.inv_slots = inv_slots; a.p0 = p0; a.p1 = p1; a.dft = dft; a.dparam = dparam;
+  a.idx = idx; a.inv_off = inv_off; a.inv_slots = inv_slots; a.p0 = p0; a.p1 = p1; a.dft = dft; a.dft_channel_major = dft_channel_major; a.dparam = dparam;
   a.B = B; a.N = N; a.M = M; a.K = K; a.C = C; a.pint = pint; a.pfloat = pfloat; a.constant_influence = constant_influence;
   int rc = check_common(a, "fused_reduce_bwd");
   if (rc != CL3D_OK) return rc;

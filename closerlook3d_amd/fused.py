@@ -143,14 +143,14 @@ class _FusedReduce(Function):
         op, B, N, M, K, C, pint, pfloat, constant = ctx.meta
         gout_t = _transposed(gout)
         off, slots = inverse_index(ctx.idx, N)
-        dft = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
+        dfeat = torch.empty((B, C, N), dtype=torch.float32, device=gout.device)  # channel-major, written by the kernel
         lib = _lib.lib()
         nparts = lib.cl3d_fused_param_partials(op, B, N, C)
         npar = {OP_ADAPTIVE: 4, OP_PSEUDOGRID: 16}.get(op, 0)
         dparam = torch.empty((nparts, C, npar), dtype=torch.float32, device=gout.device) if nparts else None
         with _lib.on_device(gout.device):
             _lib.check(lib.cl3d_fused_reduce_bwd(op, _p(gout_t), _p(ft), _p(slotrec), _p(ctx.idx), _p(off), _p(slots), B, N, M, K,
-                                                 C, _p(p0), _p(p1), pint, float(pfloat), int(constant), _p(dft),
+                                                 C, _p(p0), _p(p1), pint, float(pfloat), int(constant), _p(dfeat), 1,
                                                  _p(dparam), nparts, _stream(gout)))
         g0 = g1 = None
         if op == OP_ADAPTIVE:
@@ -158,7 +158,7 @@ class _FusedReduce(Function):
             g0, g1 = d[:, :3].contiguous(), d[:, 3].contiguous()
         elif op == OP_PSEUDOGRID:
             g1 = dparam.sum(0)[:, :pint].t().contiguous()
-        return (_transposed(dft), g0, g1) + (None,) * 13
+        return (dfeat, g0, g1) + (None,) * 13
 
 
 def _wants_grad(*tensors):
@@ -239,11 +239,11 @@ class _MaxPool(Function):
         B, N, M, K, C = ctx.meta
         gout_t = _transposed(gout)
         off, slots = inverse_index(ctx.idx, N)
-        dft = torch.empty((B, N, C), dtype=torch.float32, device=gout.device)
+        dfeat = torch.empty((B, C, N), dtype=torch.float32, device=gout.device)  # channel-major, written by the kernel
         with _lib.on_device(gout.device):
-            _lib.check(_lib.lib().cl3d_maxpool_bwd(_p(gout_t), _p(kstar), _p(off), _p(slots), B, N, M, K, C, _p(dft),
+            _lib.check(_lib.lib().cl3d_maxpool_bwd(_p(gout_t), _p(kstar), _p(off), _p(slots), B, N, M, K, C, _p(dfeat), 1,
                                                    _stream(gout)))
-        return _transposed(dft), None, None
+        return dfeat, None, None
 
 
 def max_pool(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample):

@@ -173,8 +173,8 @@ int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *ft, const fl
                           const int32_t *idx, const int32_t *inv_off, const int32_t *inv_slots, int B, int N,
                           int M, int K,
                           int C, const float *p0, const float *p1, int pint, float pfloat,
-                          int constant_influence, float *dft, float *dparam, int n_partials,
-                          cl3d_stream_t stream);
+                          int constant_influence, float *dft, int dft_channel_major, float *dparam,
+                          int n_partials, cl3d_stream_t stream);
 
 /* MaskedMaxPool's pooling step (pt_utils.py:194-201: gather + F.max_pool2d over K) without the gathered
  * tensor.  ft [B,N,C] point-major; out [B,C,M] channel-major; kstar_t [B,M,C] = arg-max slot (first
@@ -183,7 +183,7 @@ int cl3d_maxpool_fwd(const int32_t *idx, const float *ft, int B, int N, int M, i
                      unsigned char *kstar_t, cl3d_stream_t stream);
 int cl3d_maxpool_bwd(const float *gout_t, const unsigned char *kstar_t, const int32_t *inv_off,
                      const int32_t *inv_slots, int B, int N, int M, int K, int C, float *dft,
-                     cl3d_stream_t stream);
+                     int dft_channel_major, cl3d_stream_t stream);
 
 /* PointWiseMLP 'dp_fi_df', one Conv2d+BatchNorm2d+ReLU layer, max reduction
  * (local_aggregation_operators.py:288-301).  ght [B,N,2*Co]: row i = [W_d f_i | (W_c - W_d) f_i];
