@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
   const int ntiles = a.B * tiles_per_cloud;
   constexpr int NACC = MODE == PW_TRAIN ? 8 : 0;
 
-  for (int ch = 0; ch < a.chunks; ++ch) {
+  // channel chunks are spread over gridDim.y: the deep layers of a backbone have few queries and many channels
+  // (16 clouds x 16 queries x 1152 channels), and a grid over query tiles alone leaves the chip empty there
+  for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {
     const int c0 = (ch * L + cl) * V;
     const bool chan_on = lane_on && c0 < Co;
     // TRAIN: a lane sums its queries' {sum y, sum y^2, S_0..2, R_0..2} in float (a few hundred terms at most
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
   const int g = lane / L, cl = lane - g * L;
   const int tiles_per_cloud = (N + TR - 1) / TR;
   const int ntiles = a.B * tiles_per_cloud;
-  for (int ch = 0; ch < a.chunks; ++ch) {
+  for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {  // channel chunks over gridDim.y, see pwmlp_query_kernel
     const int c0 = (ch * L + cl) * V;
     const bool chan_on = g < QW && c0 < Co;
     // per-channel constants are (re)loaded where they are used -- the row epilogue and the rare centre
@@ -536,9 +538,14 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
   const int tid = threadIdx.x;
   const int tiles_per_cloud = (M + 63) / 64;
   const int ntiles = a.B * tiles_per_cloud;
-  for (int cbase = 0; cbase < Co;) {
-    int CW = 64;
-    while (CW > Co - cbase) CW >>= 1;
+  // channel chunks: Co / 64 full ones, then the binary decomposition of the remainder; spread over gridDim.y
+  const int nfull = Co >> 6, nchunks = nfull + __builtin_popcount(Co & 63);
+  for (int q = blockIdx.y; q < nchunks; q += gridDim.y) {
+    int cbase = (q < nfull ? q : nfull) * 64, CW = 64;
+    for (int r = q - nfull; r >= 0; --r) {
+      while (CW > Co - cbase) CW >>= 1;
+      if (r > 0) cbase += CW;
+    }
     const int cl = tid & (CW - 1), r0 = tid / CW, RS = 256 / CW;
     const int c = cbase + cl;
     const float scale = a.scale[c], shift = a.shift[c];
@@ -649,7 +656,6 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
       }
       __syncthreads();
     }
-    cbase += CW;
   }
 }
 
@@ -729,6 +735,8 @@ __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
   }
 }
 
+static int rows_chunks(int Co) { return (Co >> 6) + __builtin_popcount(Co & 63); }
+
 static int pw_check(const PwArgs &a, const char *who) {
   if (a.B < 0 || a.N < 1 || a.M < 1 || a.K < 1 || a.Co < 1) return fail(CL3D_E_INVALID, "%s: bad sizes", who);
   if (a.K > 255) return fail(CL3D_E_UNSUPPORTED, "%s: nsample=%d > 255 (arg-max is stored in a byte)", who, a.K);
@@ -765,8 +773,8 @@ static int launch_query(PwArgs &a, int nacc, int n_partials, hipStream_t st, con
   const int gx = nacc > 0 ? n_partials : round_grid(tiles, 8192);
   // measured at the metric shape (TRAIN): 8 gathers in flight at 3 waves/SIMD 87 us, 6 at 3 89 us, 4 at 4 76 us:
   // occupancy buys more than depth per wave
-  if (V == 4) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4>), dim3(gx), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1, 8, 4>), dim3(gx), dim3(256), lds, st, a);
+  if (V == 4) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4>), dim3(gx, m.chunks), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1, 8, 4>), dim3(gx, m.chunks), dim3(256), lds, st, a);
   return check_launch(who);
 }
 
@@ -790,26 +798,58 @@ __global__ __launch_bounds__(256) void pwmlp_split_weight_kernel(const float *__
 
 // d W [Co, 3+2C] from d wr [Co,3] and the per-cloud products dwb [B, C, 2Co] (= F_b G_b, summed over b in
 // order here):  d W_c = bot,  d W_d = top - bot  with  top = d wcat[:Co], bot = d wcat[Co:]
-__global__ __launch_bounds__(256) void pwmlp_merge_weight_grad_kernel(const float *__restrict__ dwr,
-                                                                      const float *__restrict__ dwb, int B, int Co, int C,
-                                                                      float *__restrict__ dW) {
+// A block owns a 64(o) x TC(c) tile: rows of dwb are read along o (coalesced; an element-per-thread walk along
+// dW's rows reads dwb with a 2Co stride and took 764 us on the widest layer, C = Co = 1152, B = 16), summed over
+// b in order, turned through LDS and written along c.  TC trades write segment length (4 TC bytes) for the number
+// of blocks; the reads are B times the writes, so blocks win: measured B = 16, C = Co = 72/144/288/576/1152:
+// TC=4  4.1 / 4.0 / 4.5 / 10.0 / 33.6 us,  TC=16  9.9 / 9.9 / 10.2 / 22.8 / 29.0 us (5.9 TB/s).
+constexpr int kMergeO = 64;
+template <int TC>
+__global__ __launch_bounds__(256) void pwmlp_merge_weight_grad_tiled_kernel(const float *__restrict__ dwr,
+                                                                            const float *__restrict__ dwb, int B, int Co,
+                                                                            int C, float *__restrict__ dW) {
+  __shared__ float s_top[TC][kMergeO + 1];
+  __shared__ float s_bot[TC][kMergeO + 1];
   const int ld = 3 + 2 * C;
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < Co * ld; e += gridDim.x * 256) {
-    const int o = e / ld, k = e - o * ld;
-    float v;
-    if (k < 3) {
-      v = dwr ? dwr[o * 3 + k] : 0.f;
-    } else {
-      const int c = k < 3 + C ? k - 3 : k - 3 - C;
-      float top = 0.f, bot = 0.f;
-      for (int b = 0; b < B; ++b) {
-        const float *row = dwb + ((size_t)b * C + c) * 2 * Co;
-        top += row[o];
-        bot += row[Co + o];
+  const int o0 = blockIdx.x * kMergeO, c0 = blockIdx.y * TC;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // ty in 0..3
+  constexpr int R = TC / 4;                                        // c rows per thread
+  float top[R], bot[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) top[i] = bot[i] = 0.f;
+  const int o = o0 + tx;
+  if (o < Co) {
+    for (int b = 0; b < B; ++b) {
+#pragma unroll
+      for (int i = 0; i < R; ++i) {
+        const int c = c0 + ty + 4 * i;
+        if (c < C) {
+          const float *row = dwb + ((size_t)b * C + c) * 2 * Co;
+          top[i] += row[o];
+          bot[i] += row[Co + o];
+        }
       }
-      v = k < 3 + C ? bot : top - bot;
     }
-    dW[e] = v;
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    s_top[ty + 4 * i][tx] = top[i];
+    s_bot[ty + 4 * i][tx] = bot[i];
+  }
+  __syncthreads();
+  const int cl = threadIdx.x % TC, c = c0 + cl;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int ol = threadIdx.x / TC + (256 / TC) * j, oo = o0 + ol;
+    if (oo < Co && c < C) {
+      const float t = s_top[cl][ol], bt = s_bot[cl][ol];
+      dW[(size_t)oo * ld + 3 + c] = bt;
+      dW[(size_t)oo * ld + 3 + C + c] = t - bt;
+    }
+  }
+  if (blockIdx.y == 0 && threadIdx.x < 3 * kMergeO) {
+    const int oo = o0 + threadIdx.x / 3, k = threadIdx.x % 3;
+    if (oo < Co) dW[(size_t)oo * ld + k] = dwr ? dwr[oo * 3 + k] : 0.f;
   }
 }
 
@@ -826,16 +866,20 @@ extern "C" int cl3d_pwmlp_split_weight(const float *W, int Co, int C, float *wr,
 extern "C" int cl3d_pwmlp_merge_weight_grad(const float *dwr, const float *dwb, int B, int Co, int C, float *dW,
                                             cl3d_stream_t stream) {
   CL3D_REQUIRE(dwb && dW && B >= 1 && Co >= 1 && C >= 1, "pwmlp_merge_weight_grad: bad arguments");
-  const int n = Co * (3 + 2 * C);
-  hipLaunchKernelGGL(cl3d::pwmlp_merge_weight_grad_kernel,
-                     dim3(cl3d::ceil_div(n, 256) < 1024 ? cl3d::ceil_div(n, 256) : 1024), dim3(256), 0,
-                     (hipStream_t)stream, dwr, dwb, B, Co, C, dW);
+  const int gx = cl3d::ceil_div(Co, cl3d::kMergeO);
+  const hipStream_t st = (hipStream_t)stream;
+  if ((long long)gx * cl3d::ceil_div(C, 16) >= 1024)
+    hipLaunchKernelGGL(cl3d::pwmlp_merge_weight_grad_tiled_kernel<16>, dim3(gx, cl3d::ceil_div(C, 16)), dim3(256), 0,
+                       st, dwr, dwb, B, Co, C, dW);
+  else
+    hipLaunchKernelGGL(cl3d::pwmlp_merge_weight_grad_tiled_kernel<4>, dim3(gx, cl3d::ceil_div(C, 4)), dim3(256), 0, st,
+                       dwr, dwb, B, Co, C, dW);
   return cl3d::check_launch("cl3d_pwmlp_merge_weight_grad");
 }
 
 extern "C" int cl3d_pwmlp_partials(int B, int M, int Co) {
   (void)Co;
-  return cl3d::round_grid(((long long)B * M + 15) / 16, 1024);
+  return cl3d::round_grid(((long long)B * M + 7) / 8, 1024);
 }
 
 extern "C" int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
@@ -882,7 +926,7 @@ extern "C" int cl3d_pwmlp_apply(const float *ystar_t, const float *scale, const 
   RowArgs a{};
   a.ystar_t = ystar_t; a.scale = scale; a.shift = shift; a.out = out; a.B = B; a.M = M; a.Co = Co; a.K = 1;
   const int gx = round_grid((long long)B * ceil_div(M, 64), 8192);
-  hipLaunchKernelGGL((pwmlp_rows_kernel<ROWS_APPLY>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((pwmlp_rows_kernel<ROWS_APPLY>), dim3(gx, rows_chunks(Co)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_apply");
 }
 
@@ -936,7 +980,8 @@ extern "C" int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, co
   a.gout = gout; a.gout_channel_major = gout_channel_major; a.ystar_t = ystar_t; a.kstar_t = kstar_t;
   a.slotrec = reinterpret_cast<const float4 *>(slotrec); a.scale = scale; a.shift = shift; a.mean = mean;
   a.invstd = invstd; a.partial = partial; a.B = B; a.M = M; a.K = K; a.Co = Co;
-  hipLaunchKernelGGL((pwmlp_rows_kernel<ROWS_BWD>), dim3(n_partials), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((pwmlp_rows_kernel<ROWS_BWD>), dim3(n_partials, rows_chunks(Co)), dim3(256), 0, (hipStream_t)stream,
+                     a);
   return check_launch("cl3d_pwmlp_bwd_rows");
 }
 
@@ -987,7 +1032,7 @@ extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const f
   const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
   const int gx = round_grid(tiles, 8192);
   // measured at the metric shape: 8 rows in flight at 3 waves/SIMD 93 us, 6 at 3 93 us, 5 at 4 87 us, 4 at 4 86 us
-  if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4, 4, 4>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((pwmlp_support_kernel<1, 8, 4>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
+  if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4, 4, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((pwmlp_support_kernel<1, 8, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_bwd_support");
 }

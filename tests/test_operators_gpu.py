@@ -230,6 +230,31 @@ def test_fused_max_pool_matches_reference_dataflow(C, K, N, npoint):
     assert np.array_equal(outs[0][0].cpu().numpy(), want[2].numpy())
 
 
+@pytest.mark.parametrize("B,C,N,Co", [(4, 64, 512, 64), (3, 10, 77, 7), (8, 300, 40, 300), (16, 576, 32, 576)])
+def test_point_rows_weight_plumbing_matches_autograd(B, C, N, Co):
+    """The per-point GEMM of PointWiseMLP with its split / merge kernels (both the element-per-thread merge and
+    the tiled one used once the per-cloud products outgrow the L2s) against the same algebra in plain autograd."""
+    from closerlook3d_amd.fused import _PointRows
+    torch.manual_seed(C + Co)
+    f = torch.randn(B, C, N, device="cuda")
+    W = torch.randn(Co, 3 + 2 * C, device="cuda") / np.sqrt(C)
+    g_rows = torch.randn(B, N, 2 * Co, device="cuda")
+    g_wr = torch.randn(Co, 3, device="cuda")
+    res = []
+    for mine in (True, False):
+        fi, Wi = f.clone().requires_grad_(True), W.clone().requires_grad_(True)
+        if mine:
+            rows, wr = _PointRows.apply(fi, Wi)
+        else:
+            wr, wc, wd = Wi[:, :3], Wi[:, 3:3 + C], Wi[:, 3 + C:]
+            rows = torch.einsum("bcn,oc->bno", fi, torch.cat([wd, wc - wd], 0))
+        ((rows * g_rows).sum() + (wr * g_wr).sum()).backward()
+        res.append((rows.detach(), wr.detach(), fi.grad, Wi.grad))
+    for name, a, b in zip(("rows", "wr", "dfeat", "dW"), *res):
+        scale = float(b.abs().max())
+        assert_close(a.cpu().numpy() / scale, b.cpu().numpy() / scale, 2e-5, f"point rows {name}")
+
+
 @pytest.mark.parametrize("B,C,N", [(16, 72, 4096), (2, 10, 301), (1, 3, 20000), (3, 144, 64)])
 @pytest.mark.parametrize("training", [True, False])
 def test_bn_relu_matches_torch_modules(B, C, N, training):
