@@ -52,6 +52,14 @@ inline int round_grid(long long want, int cap) {
   if (g >= 8) g &= ~7LL;
   return (int)(g < 1 ? 1 : g);
 }
+// Channel chunks go over gridDim.y when the tile grid alone would leave the chip under-filled: the deep layers
+// of a backbone have few points and many channels (one 160-point cloud x 1152 channels).  Every kernel walks
+// `for (ch = blockIdx.y; ch < chunks; ch += gridDim.y)`, so any value in [1, chunks] is correct.
+inline int chunk_grid(long long tiles, int chunks) {
+  if (tiles >= 2048 || chunks <= 1) return 1;
+  const long long want = (2048 + tiles - 1) / (tiles > 0 ? tiles : 1);
+  return (int)(want < chunks ? want : chunks);
+}
 inline int virtual_tiles(int B, int tiles_per_cloud) {
   return B * tiles_per_cloud;
 }

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxArgs a) {
   const int *my = sidx + jq * KS;
   const float *rows = a.ft + (size_t)b * N * C;
   constexpr int KB = 8;
-  for (int ch = 0; ch < a.chunks; ++ch) {
+  for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {
     const int c0 = (ch * L + cl) * V;
     if (c0 >= C) continue;
     float best[V];
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxArgs a) {
   const int tiles_per_cloud = (N + TR - 1) / TR;
   const int ntiles = a.B * tiles_per_cloud;
   constexpr int SB = 4;
-  for (int ch = 0; ch < a.chunks; ++ch) {
+  for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {
     const int c0 = (ch * L + cl) * V;
     if (c0 >= C) continue;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -162,7 +162,8 @@ extern "C" int cl3d_maxpool_fwd(const int32_t *idx, const float *ft, int B, int 
   while (4 * (size_t)m.QW * (K + 1) * sizeof(int) > 48 * 1024 && m.QW > 1) m.QW -= 1;
   if (4 * (size_t)m.QW * (K + 1) * sizeof(int) > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "maxpool_fwd: nsample too large for LDS");
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
-  const dim3 grid(virtual_tiles(B, ceil_div(M, 4 * m.QW)));
+  const int tiles_fwd = virtual_tiles(B, ceil_div(M, 4 * m.QW));
+  const dim3 grid(tiles_fwd, chunk_grid(tiles_fwd, m.chunks));
   const size_t lds = 4 * (size_t)m.QW * (K + 1) * sizeof(int);
   if (V == 4) hipLaunchKernelGGL((maxpool_fwd_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((maxpool_fwd_kernel<1>), grid, dim3(256), lds, (hipStream_t)stream, a);
@@ -185,7 +186,8 @@ extern "C" int cl3d_maxpool_bwd(const float *gout_t, const unsigned char *kstar_
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
   const int gx = round_grid(tiles, 8192);
-  if (V == 4) hipLaunchKernelGGL((maxpool_bwd_kernel<4>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((maxpool_bwd_kernel<1>), dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
+  const dim3 grid(gx, chunk_grid(gx, m.chunks));
+  if (V == 4) hipLaunchKernelGGL((maxpool_bwd_kernel<4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((maxpool_bwd_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_maxpool_bwd");
 }

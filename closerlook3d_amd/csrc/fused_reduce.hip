@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
     cntq[threadIdx.x] = n;
   }
   __syncthreads();
-  if (a.slotrec != nullptr) {
+  if (a.slotrec != nullptr && blockIdx.y == 0) {
     for (int t = threadIdx.x; t < TQ * K; t += 256) {
       const int jq = t / K;
       const int j = j0 + jq;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void fused_reduce_fwd_kernel(ReduceArgs a) {
   const float4 *myslots = slot4 + jq * KS;
   const float *mycoef = coef + jq * KS;
   const float *frow = a.ft + (size_t)b * N * C;
-  for (int ch = 0; ch < a.chunks; ++ch) {
+  for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {
     const int c0 = (ch * L + cl) * V;
     if (c0 >= C) continue;
     Vec<V> out;
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
   const int tiles_per_cloud = (N + TR - 1) / TR;
   const int ntiles = a.B * tiles_per_cloud;
 
-  for (int ch = 0; ch < a.chunks; ++ch) {
+  for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {
     const int c0 = (ch * L + cl) * V;
     const bool chan_on = lane_on && c0 < C;
     float pacc[NP > 0 ? NP : 1][V];
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void pg_dkw_kernel(ReduceArgs a) {
   const bool lane_on = g < QW;
   const int tiles_per_cloud = (M + TQ - 1) / TQ;
   const int ntiles = a.B * tiles_per_cloud;
-  for (int ch = 0; ch < a.chunks; ++ch) {
+  for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {
     const int c0 = (ch * L + cl) * V;
     const bool chan_on = lane_on && c0 < C;
     float pacc[kMaxKP][V];
@@ -704,7 +704,8 @@ extern "C" int cl3d_fused_reduce_fwd(int op, const float *query_xyz, const float
   const LaneMap m = fwd_lane_map(op, C, K, V, &lds);
   if (lds > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "fused_reduce_fwd: nsample=%d needs %zu B of LDS per block", K, lds);
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
-  dim3 grid(virtual_tiles(B, ceil_div(M, 4 * m.QW)));
+  const int tiles_fwd = virtual_tiles(B, ceil_div(M, 4 * m.QW));
+  dim3 grid(tiles_fwd, chunk_grid(tiles_fwd, m.chunks));
   if (V == 4) launch_fwd<4>(op, a, grid, lds, (hipStream_t)stream);
   else launch_fwd<1>(op, a, grid, lds, (hipStream_t)stream);
   return check_launch("cl3d_fused_reduce_fwd");
@@ -740,8 +741,9 @@ extern "C" int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *f
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)B * ceil_div(N, waves * m.QW);
   const int gx = has_params ? n_partials : round_grid(tiles, 4096);
-  if (V == 4) launch_bwd<4>(op, a, dim3(gx), dim3(64 * waves), lds, (hipStream_t)stream);
-  else launch_bwd<1>(op, a, dim3(gx), dim3(64 * waves), lds, (hipStream_t)stream);
+  const int gy = chunk_grid(tiles < gx ? tiles : gx, m.chunks);
+  if (V == 4) launch_bwd<4>(op, a, dim3(gx, gy), dim3(64 * waves), lds, (hipStream_t)stream);
+  else launch_bwd<1>(op, a, dim3(gx, gy), dim3(64 * waves), lds, (hipStream_t)stream);
   rc = check_launch("cl3d_fused_reduce_bwd");
   if (rc != CL3D_OK || op != OP_PSEUDOGRID) return rc;
   // d kernel_weights: query-major pass (the forward loop with the output gradient folded in)
@@ -753,7 +755,9 @@ extern "C" int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *f
   const size_t red = 4 * (size_t)mf.QW * mf.L * V * 8 * sizeof(float);
   const size_t lds_dkw = tile > red ? tile : red;
   if (lds_dkw > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "fused_reduce_bwd: nsample=%d needs %zu B of LDS", K, lds_dkw);
-  if (V == 4) hipLaunchKernelGGL((pg_dkw_kernel<4>), dim3(n_partials), dim3(256), lds_dkw, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((pg_dkw_kernel<1>), dim3(n_partials), dim3(256), lds_dkw, (hipStream_t)stream, a);
+  const long long tiles_q = (long long)B * ceil_div(M, 4 * mf.QW);
+  const dim3 grid_dkw(n_partials, chunk_grid(tiles_q < n_partials ? tiles_q : n_partials, mf.chunks));
+  if (V == 4) hipLaunchKernelGGL((pg_dkw_kernel<4>), grid_dkw, dim3(256), lds_dkw, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((pg_dkw_kernel<1>), grid_dkw, dim3(256), lds_dkw, (hipStream_t)stream, a);
   return check_launch("cl3d_fused_reduce_bwd(dkw)");
 }
