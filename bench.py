@@ -243,7 +243,9 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # N > 1: RCCL's watchdog thread polls events while this thread captures; thread-local capture mode keeps
+        # another thread's event query from invalidating the capture (this thread makes no unsafe call itself)
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
             fn()
         return g
 

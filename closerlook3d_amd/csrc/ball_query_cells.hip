@@ -605,13 +605,10 @@ int ball_query_cells(const float *query_xyz, const float *support_xyz, const int
     return fail(CL3D_E_WORKSPACE, "ball_query: workspace %zu < %zu", ws_bytes, bq_workspace_bytes(B, N, M));
   if (B > 65535) return fail(CL3D_E_UNSUPPORTED, "ball_query: B exceeds grid.y limit");
   BqWorkspace w = bq_carve(ws, B, N, M);
-  static bool prep_attr = false;
-  if (!prep_attr) {  // 64 KiB of cell arrays + the static reduction scratch: above the 64 KiB a kernel gets by default
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(bq_prep_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kMaxCells * (int)sizeof(int));
-    if (e != hipSuccess) return fail(CL3D_E_LAUNCH, "ball_query: LDS opt-in: %s", hipGetErrorString(e));
-    prep_attr = true;
-  }
+  // 64 KiB of cell arrays + the static reduction scratch: above the 64 KiB a kernel gets by default
+  static std::atomic<unsigned long long> prep_granted{0};
+  int rc_lds = lds_opt_in(prep_granted, reinterpret_cast<const void *>(bq_prep_kernel), 2 * kMaxCells * sizeof(int), "ball_query");
+  if (rc_lds != CL3D_OK) return rc_lds;
   // workgroups per cloud in the prep kernel: enough to split the scatter / task-table work without flooding the chip
   int parts = 256 / (B > 0 ? B : 1);
   parts = parts < 1 ? 1 : (parts > 8 ? 8 : parts);

@@ -1,6 +1,7 @@
 // cl3d_common.h -- shared device/host helpers of libcl3d (gfx950 only; no portability layer).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -34,6 +35,19 @@ inline int check_launch(const char *what) {
   } while (0)
 
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// Dynamic LDS above 64 KiB has to be granted per kernel AND per device (the code object is loaded once per
+// device).  `granted` is the call site's own bit mask of devices already done; safe to race (idempotent).
+inline int lds_opt_in(std::atomic<unsigned long long> &granted, const void *kernel, size_t bytes, const char *who) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return fail(CL3D_E_LAUNCH, "%s: no current device", who);
+  const bool tracked = dev >= 0 && dev < 64;
+  if (tracked && ((granted.load(std::memory_order_relaxed) >> dev) & 1ull)) return CL3D_OK;
+  hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return fail(CL3D_E_LAUNCH, "%s: LDS opt-in (%zu B): %s", who, bytes, hipGetErrorString(e));
+  if (tracked) granted.fetch_or(1ull << dev, std::memory_order_relaxed);
+  return CL3D_OK;
+}
 
 // ---- device helpers -------------------------------------------------------------------
 // Squared distance in the canonical operation order (see DESIGN.md "floating-point canon"):

@@ -279,15 +279,14 @@ extern "C" int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK
   if (ws_bytes < need || !ws) return cl3d::fail(CL3D_E_WORKSPACE, "build_inverse_index: workspace %zu < %zu", ws_bytes, need);
   cl3d::CsrPlan plan;
   if (cl3d::csr_plan(B, N, MK, &plan)) {
-    static bool attr_done = false;
-    if (!attr_done) {  // N > 16384: one wave's counters exceed the 64 KiB a kernel gets by default
-      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<false>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<true>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-      if (e1 != hipSuccess || e2 != hipSuccess) return cl3d::fail(CL3D_E_LAUNCH, "build_inverse_index: LDS opt-in failed");
-      attr_done = true;
-    }
+    // N > 16384: one wave's counters exceed the 64 KiB a kernel gets by default
+    static std::atomic<unsigned long long> count_granted{0}, fill_granted{0};
+    int rc_lds = cl3d::lds_opt_in(count_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<false>),
+                                  128 * 1024, "build_inverse_index");
+    if (rc_lds == CL3D_OK)
+      rc_lds = cl3d::lds_opt_in(fill_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<true>),
+                                128 * 1024, "build_inverse_index");
+    if (rc_lds != CL3D_OK) return rc_lds;
     int *table = static_cast<int *>(ws);
     const dim3 grid(plan.G / plan.wpb, B), block(64 * plan.wpb);
     const int GB = plan.G / plan.wpb;

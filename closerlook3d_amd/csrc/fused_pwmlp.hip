@@ -992,13 +992,9 @@ extern "C" int cl3d_pwmlp_bwd_hits(const float *dz_cm, const int32_t *ts_cm, int
   CL3D_REQUIRE(dz_cm && ts_cm && hit_cm, "pwmlp_bwd_hits: null pointer");
   if (B == 0) return CL3D_OK;
   CL3D_REQUIRE(B <= 65535, "pwmlp_bwd_hits: B exceeds grid.z limit");
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(pwmlp_hit_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (e != hipSuccess) return fail(CL3D_E_LAUNCH, "pwmlp_bwd_hits: LDS opt-in: %s", hipGetErrorString(e));
-    attr_done = true;
-  }
+  static std::atomic<unsigned long long> hit_granted{0};
+  int rc_lds = lds_opt_in(hit_granted, reinterpret_cast<const void *>(pwmlp_hit_kernel), 128 * 1024, "pwmlp_bwd_hits");
+  if (rc_lds != CL3D_OK) return rc_lds;
   HitArgs a{};
   a.dz_cm = dz_cm; a.ts_cm = ts_cm; a.hit_cm = hit_cm; a.B = B; a.N = N; a.M = M; a.Co = Co;
   a.T = N < 4096 ? N : 4096;  // 4 channels x T doubles = 128 KiB

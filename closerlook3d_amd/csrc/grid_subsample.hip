@@ -344,13 +344,10 @@ extern "C" int cl3d_masked_grid_subsampling(const float *xyz, const int32_t *mas
   int P = 2;
   while (P < N) P <<= 1;
   const size_t lds = (size_t)P * sizeof(unsigned long long);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cl3d::grid_subsample_kernel<false, false>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (e != hipSuccess) return cl3d::fail(CL3D_E_LAUNCH, "grid_subsampling: LDS opt-in: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> sort_granted{0};
+  int rc_lds = cl3d::lds_opt_in(sort_granted, reinterpret_cast<const void *>(cl3d::grid_subsample_kernel<false, false>),
+                                128 * 1024, "grid_subsampling");
+  if (rc_lds != CL3D_OK) return rc_lds;
   hipLaunchKernelGGL((cl3d::grid_subsample_kernel<false, false>), dim3(B), dim3(cl3d::kSubThreads), lds, st, xyz, mask, N,
                      m, sampleDl, P, sub_xyz, sub_mask, (unsigned long long *)nullptr, (cl3d::SubParams *)nullptr);
   return cl3d::check_launch("cl3d_masked_grid_subsampling");
