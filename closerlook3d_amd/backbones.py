@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from .local_aggregation_operators import LocalAggregation
+from . import pt_utils
 from .pt_utils import MaskedMaxPool, MaskedUpsample
 
 
@@ -60,6 +61,7 @@ class ResNet(nn.Module):
                  width=144, depth=2, bottleneck_ratio=2):
         super().__init__()
         self.input_features_dim = input_features_dim
+        self._geometry = (radius, sampleDl, list(nsamples), list(npoints), depth > 1)
         self.conv1 = _conv_bn(input_features_dim, width // 2, config.bn_momentum, relu=True)
         self.la1 = LocalAggregation(width // 2, width // 2, radius, nsamples[0], config)
         self.btnk1 = Bottleneck(width // 2, width, bottleneck_ratio, radius, nsamples[0], config)
@@ -80,6 +82,9 @@ class ResNet(nn.Module):
     def forward(self, xyz, mask, features, end_points=None):
         if not end_points:
             end_points = {}
+        # coordinates-only products (subsampled clouds, ball queries) go ahead on the index stream
+        pt_utils.prefetch_geometry(xyz, mask, *self._geometry)
+        device = xyz.device
         features = self.conv1(features)
         features = self.la1(xyz, xyz, mask, mask, features)
         xyz, mask, features = self.btnk1(xyz, mask, features)
@@ -89,6 +94,7 @@ class ResNet(nn.Module):
             end_points[f'res{stage + 2}_xyz'] = xyz
             end_points[f'res{stage + 2}_mask'] = mask
             end_points[f'res{stage + 2}_features'] = features
+        pt_utils.join_index_stream(device)
         return end_points
 
 

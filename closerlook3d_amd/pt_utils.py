@@ -151,7 +151,8 @@ def _run_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, ns
         return _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
     dev = query_xyz.device
     main, side = torch.cuda.current_stream(dev), index_stream(dev)
-    side.wait_stream(main)  # the coordinates were produced on the caller's stream
+    if main != side:  # (called from prefetch_geometry the caller is already on the index stream)
+        side.wait_stream(main)  # the coordinates were produced on the caller's stream
     with torch.cuda.stream(side):
         out = _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
         ev = torch.cuda.Event()
@@ -180,6 +181,73 @@ def _ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsampl
     if not defer:
         wait_ready(out[0])
     return out
+
+
+# 'auto': prefetch when there are fewer than 8 clouds per GPU (see prefetch_geometry); CL3D_PREFETCH=1 / 0 force it.
+# Same-box A/B of whole backbone steps, off -> on: one 40 960-point scene 7.64 -> 7.34 ms, 4 x 10 000 points
+# 7.19 -> 6.97 ms, one 81 920-point scene (width 288) 20.36 -> 20.06 ms; 16 x 4096 points 8.31 -> 8.52 ms (with 16
+# clouds the one-workgroup-per-cloud kernels already fill 16 CUs and the early, heaviest layers lose more to the
+# contention than the late ones gain).
+PREFETCH_GEOMETRY = {'1': True, '0': False}.get(os.environ.get('CL3D_PREFETCH', ''), 'auto')
+
+
+def _subsample(xyz, mask, npoint, sampleDl):
+    """masked_grid_subsampling through the per-forward memo (a prefetched pyramid level is picked up here)."""
+    if _BQ_CACHE is None:
+        return masked_grid_subsampling(xyz, mask, npoint, sampleDl)
+    key = ('sub', xyz.data_ptr(), xyz._version, tuple(xyz.shape), mask.data_ptr(), mask._version, int(npoint),
+           float(sampleDl))
+    hit = _BQ_CACHE.get(key)
+    if hit is None:
+        hit = (masked_grid_subsampling(xyz, mask, npoint, sampleDl), (xyz, mask))
+        _BQ_CACHE[key] = hit
+    wait_ready(hit[0][0])
+    return hit[0]
+
+
+def prefetch_geometry(xyz, mask, radius, sampleDl, nsamples, npoints, self_queries=True):
+    """Everything a strided 5-stage backbone will ask for that depends on coordinates only -- the four subsampled
+    clouds, the ball query of every stage onto itself and of every strided stage onto its parent -- built on the
+    index stream ahead of the feature pass, in the order the backbone consumes them.  Subsampling and the
+    ball-query preparation are one-workgroup-per-cloud kernels: beside the feature kernels they cost nothing,
+    in line they leave the chip idle (a 40 960-point scene: ~0.7 ms of a 7.7 ms step).  The products land in the
+    `ball_query_cache()` memo, where `MaskedMaxPool` / `LocalAggregation` find them and wait on their events.
+    No-op without the memo or when the index streams are off (eager mode by default, see ASYNC_INDEX)."""
+    if _BQ_CACHE is None or not (xyz.is_cuda and async_index()):
+        return
+    if not (PREFETCH_GEOMETRY if PREFETCH_GEOMETRY != 'auto' else xyz.shape[0] < 8):
+        return
+    dev = xyz.device
+    main, side = torch.cuda.current_stream(dev), index_stream(dev)
+    side.wait_stream(main)  # the input coordinates were produced on the caller's stream
+    capturing = torch.cuda.is_current_stream_capturing()
+    xyz, mask = xyz.contiguous(), mask.contiguous()
+    with torch.cuda.stream(side):
+        def query(q, s, qm, sm, r, k):
+            _ball_query(q, s, qm, sm, r, k, defer=True)
+
+        query(xyz, xyz, mask, mask, radius, nsamples[0])
+        for stage in range(4):
+            sampleDl *= 2
+            sub_xyz, sub_mask = _subsample(xyz, mask, npoints[stage], sampleDl)
+            ev = torch.cuda.Event()
+            ev.record(side)
+            for t in (sub_xyz, sub_mask):
+                if not capturing:
+                    t.record_stream(main)
+                t._cl3d_ready = ev
+            query(sub_xyz, xyz, sub_mask, mask, radius, nsamples[stage])
+            radius *= 2
+            if self_queries:
+                query(sub_xyz, sub_xyz, sub_mask, sub_mask, radius, nsamples[stage + 1])
+            xyz, mask = sub_xyz, sub_mask
+
+
+def join_index_stream(device):
+    """The caller's stream picks up whatever is still running on the ball-query stream (end of a forward pass
+    that prefetched: a capture must not end with an unjoined branch)."""
+    if device.type == 'cuda' and async_index() and (device, 0) in _INDEX_STREAMS:
+        torch.cuda.current_stream(device).wait_stream(_INDEX_STREAMS[(device, 0)])
 
 
 class _GroupXyzFeatures(Function):
@@ -269,7 +337,7 @@ class MaskedMaxPool(nn.Module):
         self.grouper = MaskedQueryAndGroup(radius, nsample, use_xyz=False, ret_grouped_xyz=True)
 
     def forward(self, xyz, mask, features):
-        sub_xyz, sub_mask = masked_grid_subsampling(xyz, mask, self.npoint, self.sampleDl)
+        sub_xyz, sub_mask = _subsample(xyz, mask, self.npoint, self.sampleDl)
         sub_xyz = sub_xyz.contiguous()
         sub_mask = sub_mask.contiguous()
         if self.fused and features.is_cuda and self.nsample <= 255:

@@ -91,6 +91,45 @@ def test_resnet_and_seg_head_match_reference(kind):
     assert rel < 2e-2, f"relative L2 error of d logits / d input features: {rel:.3e}"
 
 
+@pytest.mark.parametrize("kind", ["pospool", "pointwisemlp"])
+def test_geometry_prefetch_on_index_streams_changes_nothing(kind, monkeypatch):
+    """The backbone with the coordinates-only work (subsampling pyramid, ball queries, CSR builds) forked onto the
+    index streams -- the mode a captured step runs in -- against the same step on one stream: identical bits, and
+    every prefetched product is the one the layers ask for (no second search under another key)."""
+    from closerlook3d_amd import pt_utils
+    from closerlook3d_amd.backbones import ResNet
+    fx = load_fixture(f"operators_resnet_seg_{kind}.npz")
+    cfg = default_config(kind, fx["over"])
+    K = 16
+    net = ResNet(cfg, 3, 0.1, 0.05, [K] * 5, [128, 48, 16, 8], width=12, depth=2, bottleneck_ratio=2)
+    net.load_state_dict(state_of(fx, "backbone."), strict=True)
+    net = net.cuda().train(True)
+    xyz, mask = torch.from_numpy(fx["xyz"]).cuda(), torch.from_numpy(fx["mask"]).cuda()
+    probe = None
+    res = {}
+    for mode in (False, True):
+        monkeypatch.setattr(pt_utils, "ASYNC_INDEX", mode)
+        monkeypatch.setattr(pt_utils, "PREFETCH_GEOMETRY", True)
+        net.zero_grad(set_to_none=True)
+        feats = torch.from_numpy(fx["features"]).cuda().requires_grad_(True)
+        with pt_utils.ball_query_cache():
+            ep = net(xyz, mask, feats)
+            entries = len(pt_utils._BQ_CACHE)
+        out = ep["res5_features"]
+        if probe is None:
+            probe = torch.randn_like(out)
+        out.backward(probe)
+        torch.cuda.synchronize()
+        res[mode] = (entries, out.detach().clone(), ep["res5_xyz"].clone(), feats.grad.clone(),
+                     [p.grad.clone() for p in net.parameters() if p.grad is not None])
+    assert res[True][0] == res[False][0] == 9 + 4, "prefetch keys must be the keys the layers look up"
+    for a, b in zip(res[True][1:3], res[False][1:3]):
+        assert torch.equal(a, b)
+    # the callers' library convolutions may sum their weight gradients in a run-dependent order
+    for a, b in zip([res[True][3]] + res[True][4], [res[False][3]] + res[False][4]):
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
+
+
 # ---------------------------------------------------------------- fused kernels at realistic widths
 FUSED_CASES = [
     # kind, overrides, C, K, N, in-radius multiple
