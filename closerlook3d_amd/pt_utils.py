@@ -132,7 +132,7 @@ _INDEX_STREAMS = {}
 
 
 def index_stream(device, which=0):
-    """which=0: ball queries; which=1: CSR builds (its own stream: each fork is joined exactly once)."""
+    """which=0: ball queries (and the prefetched pyramid); which=1: CSR builds (each joined through its own event)."""
     st = _INDEX_STREAMS.get((device, which))
     if st is None:
         st = _INDEX_STREAMS[(device, which)] = torch.cuda.Stream(device=device)
