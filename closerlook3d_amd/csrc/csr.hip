@@ -77,8 +77,8 @@ static bool csr_plan(int B, int N, int MK, CsrPlan *p) {
   if (row > 128 * 1024 || MK <= 0 || B <= 0 || B > 65535) return false;
   int wpb = (int)((64 * 1024) / row);
   wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
-  int G = 2048 / B;
-  G = G < wpb ? wpb : (G > 64 ? 64 : G);
+  int G = 1024 / B;  // ~1024 waves on the chip: 64 ranges per cloud at B = 16, up to 256 for a single scene
+  G = G < wpb ? wpb : (G > 256 ? 256 : G);
   int per = (MK + G - 1) / G;
   per = (per + 63) & ~63;
   G = (MK + per - 1) / per;              // drop empty ranges
@@ -92,7 +92,8 @@ static bool csr_plan(int B, int N, int MK, CsrPlan *p) {
 //        position of this workgroup inside row i; wave w starts after waves < w), then the scatter.
 template <bool FILL>
 __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restrict__ idx, int N, int MK, int GB, int per,
-                                                             int *__restrict__ table, int *__restrict__ inv_slots) {
+                                                             int *__restrict__ table, const int *__restrict__ inv_off,
+                                                             int *__restrict__ inv_slots) {
   extern __shared__ int lds_cnt[];
   const int lane = lane_id();
   const int wpb = blockDim.x >> 6;
@@ -128,8 +129,9 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restri
       row[i] = tot;
     }
   } else {
+    const int *off = inv_off + (size_t)b * (N + 1);
     for (int i = threadIdx.x; i < N; i += blockDim.x) {
-      int run = row[i];
+      int run = off[i] + row[i];
       for (int w = 0; w < wpb; ++w) {
         const int t = lds_cnt[(size_t)w * N + i];
         lds_cnt[(size_t)w * N + i] = run;
@@ -154,41 +156,64 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restri
   }
 }
 
-// one workgroup per cloud: counts [GB][N] -> first positions [GB][N] (in place) and inv_off [N+1].
-// A thread owns kScanR support points 1024 apart, so one sweep over 4096 points costs ONE global round
-// trip (all kScanR*8 loads in flight), one barrier, and the stores.
+// counts [GB][N] -> each workgroup's first position inside its row (in place, relative to the row start) and the
+// row totals (left in inv_off[i] for the scan below).  A workgroup owns 64 support points; its four waves split
+// the GB workgroup rows between them, so a single large scene (GB = 256, N = 10 240: 10 MB of counters) is
+// spread over N/64 workgroups instead of streaming through one.
+__global__ __launch_bounds__(256) void csr_rows_kernel(int N, int GB, int *__restrict__ table, int *__restrict__ inv_off) {
+  __shared__ int s_part[4][64];
+  const int b = blockIdx.y;
+  const int lane = lane_id(), part = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + lane;
+  const int ic = i < N ? i : N - 1;
+  int *c = table + (size_t)b * GB * N;
+  const int gq = (GB + 3) / 4;
+  const int g_lo = part * gq, g_hi = g_lo + gq < GB ? g_lo + gq : GB;
+  int sum = 0;
+  for (int g0 = g_lo; g0 < g_hi; g0 += 8) {
+    int w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = c[(size_t)(g0 + u < g_hi ? g0 + u : g_hi - 1) * N + ic];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum += g0 + u < g_hi ? w[u] : 0;
+  }
+  s_part[part][lane] = sum;
+  __syncthreads();
+  if (i >= N) return;
+  int run = 0;
+  for (int p = 0; p < part; ++p) run += s_part[p][lane];
+  if (part == 0) inv_off[(size_t)b * (N + 1) + i] = ((s_part[0][lane] + s_part[1][lane]) + s_part[2][lane]) + s_part[3][lane];
+  for (int g0 = g_lo; g0 < g_hi; g0 += 8) {  // second visit: the counters are still in L2
+    int w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = c[(size_t)(g0 + u < g_hi ? g0 + u : g_hi - 1) * N + i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (g0 + u < g_hi) {
+        c[(size_t)(g0 + u) * N + i] = run;
+        run += w[u];
+      }
+    }
+  }
+}
+
+// row totals -> row offsets, in place: inv_off[b][0..N] = exclusive scan.  One workgroup per cloud (N ints).
 constexpr int kScanR = 4;
-__global__ __launch_bounds__(1024) void csr_scan_kernel(int N, int GB, int *__restrict__ table, int *__restrict__ inv_off) {
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int N, int *__restrict__ inv_off) {
   __shared__ int s_wave[kScanR][16];
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int *c = table + (size_t)b * GB * N;
   int *off = inv_off + (size_t)b * (N + 1);
   int carry = 0;
   for (int base = 0; base < N; base += 1024 * kScanR) {
-    int v[kScanR][8], tot[kScanR], incl[kScanR];
+    int tot[kScanR], incl[kScanR];
 #pragma unroll
     for (int r = 0; r < kScanR; ++r) {
       const int i = base + r * 1024 + tid;
-      const int ic = i < N ? i : N - 1;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[r][u] = c[(size_t)(u < GB ? u : GB - 1) * N + ic];
+      tot[r] = i < N ? off[i] : 0;
     }
 #pragma unroll
     for (int r = 0; r < kScanR; ++r) {
-      const int i = base + r * 1024 + tid;
-      const int ic = i < N ? i : N - 1;
-      tot[r] = 0;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) tot[r] += u < GB ? v[r][u] : 0;
-      for (int g0 = 8; g0 < GB; g0 += 8) {
-        int w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = c[(size_t)(g0 + u < GB ? g0 + u : GB - 1) * N + ic];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) tot[r] += g0 + u < GB ? w[u] : 0;
-      }
-      if (i >= N) tot[r] = 0;
       incl[r] = tot[r];
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -206,29 +231,7 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int N, int GB, int *__re
         total += s_wave[r][ww];
       }
       const int i = base + r * 1024 + tid;
-      int run = carry + woff + incl[r] - tot[r];
-      if (i < N) {
-        off[i] = run;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          if (u < GB) {
-            c[(size_t)u * N + i] = run;
-            run += v[r][u];
-          }
-        }
-        for (int g0 = 8; g0 < GB; g0 += 8) {
-          int w[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) w[u] = c[(size_t)(g0 + u < GB ? g0 + u : GB - 1) * N + i];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            if (g0 + u < GB) {
-              c[(size_t)(g0 + u) * N + i] = run;
-              run += w[u];
-            }
-          }
-        }
-      }
+      if (i < N) off[i] = carry + woff + incl[r] - tot[r];
       carry += total;
     }
     __syncthreads();  // s_wave is reused by the next sweep
@@ -291,10 +294,11 @@ extern "C" int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK
     const dim3 grid(plan.G / plan.wpb, B), block(64 * plan.wpb);
     const int GB = plan.G / plan.wpb;
     hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<false>), grid, block, plan.lds, st, idx, N, MK, GB, plan.per,
-                       table, (int *)nullptr);
-    hipLaunchKernelGGL(cl3d::csr_scan_kernel, dim3(B), dim3(1024), 0, st, N, GB, table, inv_off);
+                       table, (const int *)nullptr, (int *)nullptr);
+    hipLaunchKernelGGL(cl3d::csr_rows_kernel, dim3(cl3d::ceil_div(N, 64), B), dim3(256), 0, st, N, GB, table, inv_off);
+    hipLaunchKernelGGL(cl3d::csr_scan_kernel, dim3(B), dim3(1024), 0, st, N, inv_off);
     hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true>), grid, block, plan.lds, st, idx, N, MK, GB, plan.per,
-                       table, inv_slots);
+                       table, (const int *)inv_off, inv_slots);
     return cl3d::check_launch("cl3d_build_inverse_index");
   }
   const size_t n = (size_t)B * MK;
