@@ -143,6 +143,8 @@ FUSED_CASES = [
                       "pointwisemlp__reduction": "max"}, 64, 32, 1024, 1.5),
     ("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df", "pointwisemlp__num_mlps": 1,
                       "pointwisemlp__reduction": "max"}, 18, 9, 300, 4.0),                              # V=1 path
+    ("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df", "pointwisemlp__num_mlps": 1,
+                      "pointwisemlp__reduction": "max"}, 288, 16, 256, 4.0),   # deep-stage width: channel chunks over gridDim.y
     ("pseudo_grid", {"pseudo_grid__KP_influence": "linear"}, 64, 26, 1024, 1.5),
     ("pseudo_grid", {"pseudo_grid__KP_influence": "constant"}, 36, 16, 400, 4.0),
     ("pseudo_grid", {"pseudo_grid__KP_influence": "linear"}, 12, 26, 20000, 1.5),   # scene-sized support set
@@ -269,7 +271,8 @@ def test_fused_max_pool_matches_reference_dataflow(C, K, N, npoint):
     assert np.array_equal(outs[0][0].cpu().numpy(), want[2].numpy())
 
 
-@pytest.mark.parametrize("B,C,N,Co", [(4, 64, 512, 64), (3, 10, 77, 7), (8, 300, 40, 300), (16, 576, 32, 576)])
+@pytest.mark.parametrize("B,C,N,Co", [(4, 64, 512, 64), (3, 10, 77, 7), (8, 300, 40, 300), (16, 576, 32, 576),
+                                      (2, 1152, 8, 1152)])   # the last one takes the 64 x 16 merge tiles
 def test_point_rows_weight_plumbing_matches_autograd(B, C, N, Co):
     """The per-point GEMM of PointWiseMLP with its split / merge kernels (both the element-per-thread merge and
     the tiled one used once the per-cloud products outgrow the L2s) against the same algebra in plain autograd."""
