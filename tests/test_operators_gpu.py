@@ -147,6 +147,7 @@ FUSED_CASES = [
                       "pointwisemlp__reduction": "max"}, 288, 16, 256, 4.0),   # deep-stage width: channel chunks over gridDim.y
     ("pseudo_grid", {"pseudo_grid__KP_influence": "linear"}, 64, 26, 1024, 1.5),
     ("pseudo_grid", {"pseudo_grid__KP_influence": "constant"}, 36, 16, 400, 4.0),
+    ("pseudo_grid", {"pseudo_grid__KP_influence": "linear"}, 144, 20, 256, 4.0),    # channel chunks over gridDim.y
     ("pseudo_grid", {"pseudo_grid__KP_influence": "linear"}, 12, 26, 20000, 1.5),   # scene-sized support set
 ]
 
