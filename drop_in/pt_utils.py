@@ -5,5 +5,6 @@ from closerlook3d_amd.pt_utils import *  # noqa: F401,F403
 from closerlook3d_amd.pt_utils import (GroupingOperation, MaskedGridSubsampling, MaskedMaxPool,  # noqa: F401
                                        MaskedNearestQuery, MaskedNearestQueryAndGroup,
                                        MaskedOrderedBallQuery, MaskedQueryAndGroup, MaskedUpsample,
-                                       ball_query_cache, grouping_operation, masked_grid_subsampling,
-                                       masked_nearest_query, masked_ordered_ball_query)
+                                       ball_query_cache, grouping_operation, join_index_stream,
+                                       masked_grid_subsampling, masked_nearest_query, masked_ordered_ball_query,
+                                       prefetch_geometry)
