@@ -37,6 +37,9 @@ for c in modelnet_small modelnet_pointwisemlp s3dis_pseudogrid partnet_adaptive 
 done
 echo "== dataset-side grid subsampling (SURVEY 8(f) rank 2): engine vs the reference's C++ on the host" | tee -a $OUT/summary.txt
 timeout 600 python scripts/bench_dataset_grid.py 2>/dev/null | tee $OUT/bench_dataset_grid.json | tee -a $OUT/summary.txt
+echo "== vote bookkeeping and sphere crops on the device (SURVEY 8(f) ranks 3 and 2)" | tee -a $OUT/summary.txt
+timeout 300 python scripts/bench_voting.py 2>/dev/null | tee $OUT/bench_voting.json | tee -a $OUT/summary.txt
+timeout 300 python scripts/bench_sphere_crop.py 2>/dev/null | tee $OUT/bench_sphere_crop.json | tee -a $OUT/summary.txt
 # keep the merged output small: drop raw traces, keep stats and counter tables
 find $OUT -type f -name "*kernel_trace*" -delete 2>/dev/null
 find $OUT -type f -size +3M -delete 2>/dev/null
