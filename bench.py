@@ -168,6 +168,37 @@ def cpu_baseline(kind, N, K, C, radius, clouds, iters):
                       f"median {med * 1e3:.1f} ms; host has {os.cpu_count()} logical cores"}
 
 
+# ---- cpu_baseline legs of the auxiliary benches (scripts/bench_dataset_grid.py, scripts/bench_voting.py): like
+# cpu_baseline() above, the only places outside tests/ where the oracle / the reference build is timed
+def cpu_baseline_dataset_grid(points, features, labels, dl):
+    """The reference's own grid_subsampling.cpp (oracle/_ref/libgrid_dataset_ref.so) on one host thread:
+    (seconds, voxels), or None when the library has not been built."""
+    from oracle import build_ref
+    try:
+        lib = build_ref.load_grid()
+    except OSError:
+        return None
+    n = points.shape[0]
+    sp = np.empty((n, 3), np.float32)
+    sf = np.empty((n, features.shape[1]), np.float32)
+    sl = np.empty((n, labels.shape[1]), np.int32)
+    t0 = time.perf_counter()
+    m = lib.cl3d_ref_dataset_grid_subsampling(points.ctypes.data, features.ctypes.data, labels.ctypes.data, n,
+                                              features.shape[1], labels.shape[1], dl, sp.ctypes.data, sf.ctypes.data,
+                                              sl.ctypes.data)
+    return time.perf_counter() - t0, int(m)
+
+
+def cpu_baseline_voting(batches, num_classes, cloud_sizes):
+    """The reference's per-element host loop (restated in oracle/voting.py) over `batches`: seconds per batch."""
+    from oracle import voting as ov
+    arrays = ov.new_arrays(num_classes, cloud_sizes)
+    t0 = time.perf_counter()
+    for pred, mask, inds, label in batches:
+        ov.collect(arrays, pred, mask, inds, label)
+    return (time.perf_counter() - t0) / len(batches)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)

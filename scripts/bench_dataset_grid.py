@@ -36,18 +36,14 @@ def main():
     gpu = (time.perf_counter() - t0) / args.iters
     line = {"op": "dataset grid_subsampling (xyz + 4 features + 1 label column)", "points": n, "sampleDl": args.dl,
             "voxels": int(out[0].shape[0]), "gpu_ms": round(gpu * 1e3, 3), "gpu_points_per_s": round(n / gpu, 1)}
-    try:
-        from oracle import build_ref  # bench-only use of the reference build, like bench.py's cpu_baseline
-        lib = build_ref.load_grid()
-        sp = np.empty((n, 3), np.float32); sf = np.empty((n, 4), np.float32); sl = np.empty((n, 1), np.int32)
-        t0 = time.perf_counter()
-        m = lib.cl3d_ref_dataset_grid_subsampling(p.ctypes.data, f.ctypes.data, l.ctypes.data, n, 4, 1, args.dl,
-                                                  sp.ctypes.data, sf.ctypes.data, sl.ctypes.data)
-        cpu = time.perf_counter() - t0
-        line.update(reference_cpu_ms=round(cpu * 1e3, 1), reference_cpu_points_per_s=round(n / cpu, 1),
-                    reference_voxels=int(m), speedup=round(cpu / gpu, 1))
-    except OSError:
+    from bench import cpu_baseline_dataset_grid   # the reference build is timed by bench.py's cpu_baseline leg only
+    ref = cpu_baseline_dataset_grid(p, f, l, args.dl)
+    if ref is None:
         line["reference_cpu_ms"] = None
+    else:
+        cpu, m = ref
+        line.update(reference_cpu_ms=round(cpu * 1e3, 1), reference_cpu_points_per_s=round(n / cpu, 1),
+                    reference_voxels=m, speedup=round(cpu / gpu, 1))
     print(json.dumps(line))
 
 

@@ -77,6 +77,14 @@ def test_product_never_imports_oracle():
         text = open(os.path.join(ROOT, f)).read()
         if re.search(r"\boracle\b", text):
             bad.append(f)
+    # measurement helpers go through bench.py's cpu_baseline legs, never to the oracle themselves
+    for sub in ("scripts", "examples"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, sub)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".sh")):
+                    text = open(os.path.join(dirpath, f)).read()
+                    if re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M) or "libcl3d_oracle" in text:
+                        bad.append(os.path.join(dirpath, f))
     assert not bad, f"product files reference the oracle: {bad}"
 
 
