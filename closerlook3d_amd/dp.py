@@ -35,18 +35,25 @@ def _mean_inplace(flat, world, group, async_op=False):
 
 
 def allreduce_gradients(params, world, group=None):
-    """Average .grad of `params` across ranks with a single flat all-reduce."""
-    grads = [p.grad for p in params if p.grad is not None]
-    if not grads or world == 1:
+    """Average .grad of `params` across ranks with a single flat all-reduce.
+
+    The flat buffer covers EVERY parameter that requires a gradient, with zeros where this rank produced none
+    (a head that saw no sample of its shape), so its length is the same on all ranks; afterwards every such
+    parameter has a .grad (the mean), as DistributedDataParallel leaves it -- otherwise only some replicas
+    would step that parameter and they would drift apart silently."""
+    params = [p for p in params if p.requires_grad]
+    if not params or world == 1:
         return
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in params])
     _, need_div = _mean_inplace(flat, world, group)
     if need_div:
         flat.div_(world)
     off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
+    for p in params:
+        n = p.numel()
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+        p.grad.copy_(flat[off:off + n].view_as(p))
         off += n
 
 
@@ -85,12 +92,19 @@ class GradientSynchronizer:
         sync = GradientSynchronizer(model.parameters(), world)
         loss.backward()      # hooks launch async all-reduces bucket by bucket
         sync.finish()        # wait, scale, scatter back into .grad
+
+    Collectives must be issued in the same order on every rank.  Which parameters receive a gradient may differ
+    between ranks (per-shape heads), so "bucket complete" is a rank-local event; the launch order is therefore
+    FIXED: bucket b is launched only once buckets 0..b-1 have been, from a hook when that happens during the
+    backward pass (the usual case: buckets fill in backward order) and otherwise from finish(), which launches
+    whatever is left in index order with zeros standing in for absent gradients.  finish() gives every parameter
+    a .grad (the mean over ranks), as DistributedDataParallel does.
     """
 
     def __init__(self, params, world, bucket_bytes=32 << 20, group=None):
         self.world, self.group = world, group
         self.params = [p for p in params if p.requires_grad]
-        self.buckets = []  # each: dict(params, offsets, flat, pending, handle)
+        self.buckets = []  # each: dict(params, offsets, flat, filled, pending, handle)
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
             nbytes = p.numel() * 4
@@ -107,6 +121,7 @@ class GradientSynchronizer:
                 self._slot_of[id(p)] = (bi, i)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if world > 1 else []
         self._need_div = False
+        self._next = 0  # index of the next bucket to launch (launch order == bucket order on every rank)
 
     def _close(self, plist):
         total = sum(p.numel() for p in plist)
@@ -116,39 +131,48 @@ class GradientSynchronizer:
             o += p.numel()
         self.buckets.append(dict(params=list(plist), offsets=offs,
                                  flat=torch.zeros(total, dtype=torch.float32, device=plist[0].device),
-                                 pending=len(plist), handle=None))
+                                 filled=[False] * len(plist), pending=len(plist), handle=None))
+
+    def _launch_ready(self, force=False):
+        while self._next < len(self.buckets):
+            b = self.buckets[self._next]
+            if b["pending"] != 0:
+                if not force:
+                    return
+                for i, p in enumerate(b["params"]):  # no gradient on this rank this step: contribute zeros
+                    if not b["filled"][i]:
+                        b["flat"][b["offsets"][i]:b["offsets"][i] + p.numel()].zero_()
+            b["handle"], self._need_div = _mean_inplace(b["flat"], self.world, self.group, async_op=True)
+            self._next += 1
 
     def _on_grad(self, p):
         bi, i = self._slot_of[id(p)]
         b = self.buckets[bi]
+        if b["handle"] is not None or b["filled"][i]:
+            raise RuntimeError("GradientSynchronizer: a gradient arrived for a bucket that is already in flight; "
+                               "call finish() once per backward pass")
         n = p.numel()
         b["flat"][b["offsets"][i]:b["offsets"][i] + n].copy_(p.grad.reshape(-1))
+        b["filled"][i] = True
         b["pending"] -= 1
         if b["pending"] == 0:
-            b["handle"], self._need_div = _mean_inplace(b["flat"], self.world, self.group, async_op=True)
+            self._launch_ready()
 
     def finish(self):
         if self.world == 1:
             return
+        self._launch_ready(force=True)
         for b in self.buckets:
-            if b["pending"] != 0:  # parameters that received no gradient this step: reduce what we have
-                for i, p in enumerate(b["params"]):
-                    n = p.numel()
-                    sl = b["flat"][b["offsets"][i]:b["offsets"][i] + n]
-                    if p.grad is None:
-                        sl.zero_()
-                    elif b["handle"] is None:
-                        sl.copy_(p.grad.reshape(-1))
-                if b["handle"] is None:
-                    b["handle"], self._need_div = _mean_inplace(b["flat"], self.world, self.group, async_op=True)
             b["handle"].wait()
             if self._need_div:
                 b["flat"].div_(self.world)
             for i, p in enumerate(b["params"]):
                 n = p.numel()
-                if p.grad is not None:
-                    p.grad.copy_(b["flat"][b["offsets"][i]:b["offsets"][i] + n].view_as(p.grad))
-            b["pending"], b["handle"] = len(b["params"]), None
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                p.grad.copy_(b["flat"][b["offsets"][i]:b["offsets"][i] + n].view_as(p.grad))
+            b["pending"], b["handle"], b["filled"] = len(b["params"]), None, [False] * len(b["params"])
+        self._next = 0
 
     def remove(self):
         for h in self._hooks:

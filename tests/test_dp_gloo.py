@@ -83,3 +83,60 @@ def test_gradient_mean_world2(tmp_path, mode):
         want = g if want is None else [a + b for a, b in zip(want, g)]
     for a, b in zip(got, want):
         assert torch.allclose(a, b / 2, atol=1e-6, rtol=1e-5)
+
+
+class _TwoHeads(torch.nn.Module):
+    """Shared trunk + per-shape heads: a rank whose shard holds only one shape gives the other head no gradient."""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.trunk = torch.nn.Conv1d(6, 12, 1)
+        self.heads = torch.nn.ModuleList([torch.nn.Conv1d(12, 3, 1), torch.nn.Conv1d(12, 5, 1)])
+
+    def forward(self, x, shape):
+        return self.heads[shape](torch.relu(self.trunk(x)))
+
+
+def _heads_worker(rank, world, port, mode, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        model = _TwoHeads()
+        params = list(model.parameters())
+        x = _batch()[4 * rank:4 * rank + 4]
+        if mode == "bucketed":
+            sync = GradientSynchronizer(params, world, bucket_bytes=128)  # heads and trunk in different buckets
+            for _ in range(2):
+                model.zero_grad(set_to_none=True)
+                model(x, rank).square().sum().backward()  # rank r only touches head r
+                sync.finish()
+        else:
+            model(x, rank).square().sum().backward()
+            allreduce_gradients(params, world)
+        assert all(p.grad is not None for p in params)  # every replica steps every parameter
+        torch.save([p.grad.clone() for p in params], f"{out}.{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["bucketed", "oneshot"])
+def test_gradient_mean_when_a_rank_skips_a_head(tmp_path, mode):
+    """parameters without a gradient on one rank -- collectives stay in one order on all ranks, the
+    absent gradient counts as zero, and both replicas end up with the same .grad for every parameter."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "grads.pt")
+    mp.spawn(_heads_worker, args=(2, port, mode, out), nprocs=2, join=True)
+    got = [torch.load(f"{out}.{r}") for r in range(2)]
+    want = None
+    for r in range(2):
+        model = _TwoHeads()
+        model(_batch()[4 * r:4 * r + 4], r).square().sum().backward()
+        g = [p.grad if p.grad is not None else torch.zeros_like(p) for p in model.parameters()]
+        want = g if want is None else [a + b for a, b in zip(want, g)]
+    for a, b, w in zip(got[0], got[1], want):
+        assert torch.equal(a, b)
+        assert torch.allclose(a, w / 2, atol=1e-6, rtol=1e-5)
