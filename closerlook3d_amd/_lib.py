@@ -9,7 +9,8 @@ import os
 import torch  # noqa: F401  -- imported first so libcl3d binds to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_PATH = os.path.join(_HERE, "libcl3d.so")
+_D2_FORM = int(os.environ.get("CL3D_D2_FORM", "0") or 0)  # build-time distance canon, see closerlook3d_amd/build.py
+_PATH = os.path.join(_HERE, "libcl3d.so" if _D2_FORM == 0 else f"libcl3d_d2form{_D2_FORM}.so")
 _lib = None
 
 _P = ctypes.c_void_p  # device pointers travel as void*
@@ -21,6 +22,7 @@ _Z = ctypes.c_size_t
 # that every symbol declared in the header is exported by the library and listed here).
 SIGNATURES = {
     "cl3d_masked_ordered_ball_query": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _Z, _P],
+    "cl3d_fused_supported": [_I, _I, _I],
     "cl3d_group_points": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     "cl3d_group_points_grad": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_masked_grid_subsampling": [_P, _P, _I, _I, _I, _F, _P, _P, _P, _Z, _P],
@@ -59,6 +61,8 @@ class Cl3dError(RuntimeError):
 def _declare(handle):
     handle.cl3d_abi_version.restype = _I
     handle.cl3d_abi_version.argtypes = []
+    handle.cl3d_d2_form.restype = _I
+    handle.cl3d_d2_form.argtypes = []
     handle.cl3d_last_error_string.restype = ctypes.c_char_p
     handle.cl3d_last_error_string.argtypes = []
     handle.cl3d_workspace_bytes.restype = _Z
@@ -80,6 +84,8 @@ def lib():
         _declare(handle)
         if handle.cl3d_abi_version() != 1:
             raise ImportError("libcl3d.so ABI version mismatch")
+        if handle.cl3d_d2_form() != _D2_FORM:
+            raise ImportError(f"{_PATH} was built with CL3D_D2_FORM={handle.cl3d_d2_form()}, expected {_D2_FORM}")
         _lib = handle
     return _lib
 

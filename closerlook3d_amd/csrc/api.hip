@@ -1,7 +1,21 @@
 // api.hip -- version / error / workspace entry points of libcl3d.
 #include "ball_query.h"
+#include "fused_common.h"
 
 extern "C" int cl3d_abi_version(void) { return CL3D_ABI_VERSION; }
+
+extern "C" int cl3d_d2_form(void) { return CL3D_D2_FORM; }
+
+extern "C" int cl3d_fused_supported(int op, int K, int C) {
+  switch (op) {
+    case CL3D_OP_POSPOOL: return cl3d::fused_reduce_supported(0, K, C) && cl3d::fused_reduce_supported(1, K, C);
+    case CL3D_OP_ADAPTIVE_WEIGHT: return cl3d::fused_reduce_supported(2, K, C);
+    case CL3D_OP_PSEUDO_GRID: return cl3d::fused_reduce_supported(3, K, C);
+    case CL3D_OP_POINTWISE_MLP: return cl3d::pwmlp_supported(K, C);
+    case CL3D_OP_MAX_POOL: return cl3d::maxpool_supported(K, C);
+    default: return 0;
+  }
+}
 
 extern "C" const char *cl3d_last_error_string(void) { return cl3d::err_buf(); }
 

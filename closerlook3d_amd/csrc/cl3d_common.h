@@ -50,15 +50,31 @@ inline int lds_opt_in(std::atomic<unsigned long long> &granted, const void *kern
 }
 
 // ---- device helpers -------------------------------------------------------------------
-// Squared distance in the canonical operation order (see DESIGN.md "floating-point canon"):
-// what hipcc -O2 makes of the reference expression on gfx950,
-//   d2 = fadd(fma(dy,dy, fmul(dx,dx)), fmul(dz,dz)).
+// Squared distance in the canonical operation order (see DESIGN.md "floating-point canon").  Form 0 is what
+// hipcc -O2 makes of the reference expression (masked_ordered_ball_query_gpu.cu:56-57) on gfx950,
+//   d2 = fadd(fma(dy,dy, fmul(dx,dx)), fmul(dz,dz)),
+// and is the default.  CL3D_D2_FORM (a build-time switch, same numbering as the oracle's) selects the two other
+// plausible contractions, for a maintainer who has to match indices produced by another compiler:
+//   1 = no contraction, 2 = the full left-to-right fma chain (what nvcc normally emits).
 // The library is compiled with -ffp-contract=off, so nothing here is re-fused.
+#ifndef CL3D_D2_FORM
+#define CL3D_D2_FORM 0
+#endif
 __device__ __forceinline__ float dist2(float qx, float qy, float qz, float x, float y, float z) {
   const float dx = qx - x, dy = qy - y, dz = qz - z;
+#if CL3D_D2_FORM == 0
   const float xx = dx * dx;
   const float zz = dz * dz;
   return __builtin_fmaf(dy, dy, xx) + zz;
+#elif CL3D_D2_FORM == 1
+  const float xx = dx * dx;
+  const float yy = dy * dy;
+  const float zz = dz * dz;
+  return (xx + yy) + zz;
+#else
+  const float xx = dx * dx;
+  return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, xx));
+#endif
 }
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }

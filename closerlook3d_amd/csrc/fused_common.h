@@ -40,6 +40,12 @@ inline LaneMap pick_lane_map(int C, int V) {
   return m;
 }
 
+// host-side capability queries behind cl3d_fused_supported(): each is defined next to the launch code that
+// enforces the same limit (LDS needed by the per-block slot tile grows with nsample)
+bool fused_reduce_supported(int op, int K, int C);  // fused_reduce.hip
+bool pwmlp_supported(int K, int Co);                // fused_pwmlp.hip
+bool maxpool_supported(int K, int C);               // fused_maxpool.hip
+
 // ---- XCD-aware tile order.  The fused kernels gather point-major rows of one cloud over and over
 // (C*4 bytes per neighbour); a cloud's rows (1-2 MB) fit the 4 MiB L2 of one XCD, all clouds together
 // do not.  The dispatcher is observed to place workgroup b on XCD b % 8 (MI355X_MICROARCH.md), so the

@@ -146,6 +146,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxArgs a) {
   }
 }
 
+bool maxpool_supported(int K, int C) {
+  if (K < 1 || K > 255 || C < 1) return false;
+  LaneMap m = pick_lane_map(C, (C % 4 == 0) ? 4 : 1);
+  while (4 * (size_t)m.QW * (K + 1) * sizeof(int) > 48 * 1024 && m.QW > 1) m.QW -= 1;
+  return 4 * (size_t)m.QW * (K + 1) * sizeof(int) <= 64 * 1024;
+}
+
 }  // namespace cl3d
 
 extern "C" int cl3d_maxpool_fwd(const int32_t *idx, const float *ft, int B, int N, int M, int K, int C, float *out,

@@ -762,6 +762,14 @@ static LaneMap pw_lane_map(int Co, int K, int V, int nacc, size_t *lds_out) {
   }
 }
 
+bool pwmlp_supported(int K, int Co) {
+  if (K < 1 || K > 255 || Co < 1) return false;
+  const int V = (Co % 4 == 0) ? 4 : 1;
+  size_t lds = 0;
+  pw_lane_map(Co, K, V, 8, &lds);  // the training pass carries the most accumulators
+  return lds <= 64 * 1024;
+}
+
 template <int MODE>
 static int launch_query(PwArgs &a, int nacc, int n_partials, hipStream_t st, const char *who) {
   const int V = (a.Co % 4 == 0) ? 4 : 1;

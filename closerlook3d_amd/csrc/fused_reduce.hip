@@ -668,6 +668,20 @@ static LaneMap fwd_lane_map(int op, int C, int K, int V, size_t *lds_out) {
   }
 }
 
+bool fused_reduce_supported(int op, int K, int C) {
+  if (op < OP_POSPOOL_XYZ || op > OP_PSEUDOGRID || K < 1 || C < 1) return false;
+  const int V = (C % 4 == 0) ? 4 : 1;
+  size_t lds = 0;
+  const LaneMap mf = fwd_lane_map(op, C, K, V, &lds);
+  if (lds > 64 * 1024) return false;
+  if (op == OP_PSEUDOGRID) {  // the d kernel_weights pass of the backward (same formula as cl3d_fused_reduce_bwd)
+    const size_t tile = 4 * (size_t)mf.QW * (K + 1) * (sizeof(int) + kMaxKP * sizeof(float));
+    const size_t red = 4 * (size_t)mf.QW * mf.L * V * 8 * sizeof(float);
+    if ((tile > red ? tile : red) > 64 * 1024) return false;
+  }
+  return true;
+}
+
 }  // namespace cl3d
 
 extern "C" int cl3d_fused_param_partials(int op, int B, int N, int C) {

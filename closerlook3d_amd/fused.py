@@ -20,15 +20,32 @@ OP_POSPOOL_XYZ, OP_POSPOOL_SINCOS, OP_ADAPTIVE, OP_PSEUDOGRID = 0, 1, 2, 3
 _RED = {'sum': 0, 'avg': 1, 'mean': 1}
 
 
+_OP_ID = {'pospool': 7, 'adaptive_weight': 8, 'pseudo_grid': 9, 'pointwisemlp': 10, 'max_pool': 13}  # CL3D_OP_*
+
+
+def kernels_cover(kind, nsample, channels):
+    """The fused kernels keep a block's slot tile in LDS, which grows with nsample: ask the library."""
+    return bool(_lib.lib().cl3d_fused_supported(_OP_ID[kind], int(nsample), int(channels)))
+
+
+def _bn_ok(bn):
+    # momentum=None means a cumulative moving average in PyTorch; the kernels implement the exponential rule only
+    return bn.momentum is not None
+
+
 def _supported(kind, m):
     if kind == 'pospool':
-        return m.position_embedding in ('xyz', 'sin_cos') and m.reduction in _RED
+        ok = m.position_embedding in ('xyz', 'sin_cos') and m.reduction in _RED
+        return ok and kernels_cover(kind, m.nsample, m.in_channels)
     if kind == 'adaptive_weight':
-        return m.weight_type == 'dp' and m.num_mlps == 1 and m.reduction in _RED
+        ok = m.weight_type == 'dp' and m.num_mlps == 1 and m.reduction in _RED
+        return ok and kernels_cover(kind, m.nsample, m.in_channels)
     if kind == 'pointwisemlp':
-        return m.feature_type == 'dp_fi_df' and m.num_mlps == 1 and m.reduction == 'max' and m.nsample <= 255
+        ok = m.feature_type == 'dp_fi_df' and m.num_mlps == 1 and m.reduction == 'max' and m.nsample <= 255
+        return ok and _bn_ok(m.mlps.conv0[1]) and kernels_cover(kind, m.nsample, m.out_channels)
     if kind == 'pseudo_grid':
-        return m.KP_influence in ('linear', 'constant') and m.num_kernel_points <= 16 and m.convolution_mode == 'sum'
+        ok = m.KP_influence in ('linear', 'constant') and m.num_kernel_points <= 16 and m.convolution_mode == 'sum'
+        return ok and kernels_cover(kind, m.nsample, m.in_channels)
     return False
 
 
@@ -459,7 +476,7 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
     use_batch_stats = training or bn.running_mean is None
     if use_batch_stats and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    momentum = bn.momentum if bn.momentum is not None else 0.1
+    momentum = bn.momentum  # never None here: use_fused() sends that configuration to the grouped path
     return _PointwiseMLP.apply(ght.contiguous(), wr, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                query_xyz.contiguous(), support_xyz.contiguous(), idx, radius, use_batch_stats,
                                momentum, bn.eps, _wants_grad(features, conv.weight, bn.weight, bn.bias))

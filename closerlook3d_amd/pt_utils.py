@@ -336,11 +336,15 @@ class MaskedMaxPool(nn.Module):
         self.fused = True  # set False to run the reference's gather + max_pool2d dataflow
         self.grouper = MaskedQueryAndGroup(radius, nsample, use_xyz=False, ret_grouped_xyz=True)
 
+    def _fused_covers(self, channels):
+        from . import fused
+        return fused.kernels_cover('max_pool', self.nsample, channels)
+
     def forward(self, xyz, mask, features):
         sub_xyz, sub_mask = _subsample(xyz, mask, self.npoint, self.sampleDl)
         sub_xyz = sub_xyz.contiguous()
         sub_mask = sub_mask.contiguous()
-        if self.fused and features.is_cuda and self.nsample <= 255:
+        if self.fused and features.is_cuda and self._fused_covers(features.shape[1]):
             # one kernel, no [B,C,npoint,K] tensor (same values; same first-maximum gradient routing)
             from . import fused
             return sub_xyz, sub_mask, fused.max_pool(sub_xyz, xyz, sub_mask, mask, features, self.radius, self.nsample)

@@ -55,9 +55,19 @@ typedef void *cl3d_stream_t; /* hipStream_t */
 #define CL3D_OP_POINTWISE_MLP 10
 #define CL3D_OP_INVERSE_INDEX 11 /* cl3d_build_inverse_index: pass M*K slots as (M, K) */
 #define CL3D_OP_DATASET_GRID 12  /* cl3d_dataset_grid_subsampling: N = points of the cloud (B, M, K, C unused) */
+#define CL3D_OP_MAX_POOL 13      /* cl3d_maxpool_fwd/bwd (only meaningful for cl3d_fused_supported) */
 
 int cl3d_abi_version(void);
 const char *cl3d_last_error_string(void);
+/* operation order of the squared distance this build compares against radius^2 (build-time CL3D_D2_FORM, see
+ * closerlook3d_amd/build.py): 0 = fadd(fma(dy,dy,dx*dx), dz*dz) -- hipcc's contraction of
+ * masked_ordered_ball_query_gpu.cu:56-57 on gfx950 (default); 1 = no contraction; 2 = full fma chain. */
+int cl3d_d2_form(void);
+/* 1 when the fused kernels of operator `op` (CL3D_OP_POSPOOL / _ADAPTIVE_WEIGHT / _PSEUDO_GRID / _POINTWISE_MLP /
+ * _MAX_POOL) take this nsample K and channel count C (output channels for the PointWiseMLP): their per-block slot
+ * tile lives in LDS and grows with K.  0 -> the caller runs the grouped dataflow on the five native ops instead
+ * (the fused entry points would return CL3D_E_UNSUPPORTED). */
+int cl3d_fused_supported(int op, int K, int C);
 /* bytes of device scratch the op needs for these sizes (0 if none). Unused dims: pass 0. */
 size_t cl3d_workspace_bytes(int op, int B, int N, int M, int K, int C);
 

@@ -12,12 +12,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "libcl3d_oracle.so")
+def d2_form():
+    """CL3D_D2_FORM of this process (0 = the canon; see cl3d_oracle.c and closerlook3d_amd/build.py)."""
+    return int(os.environ.get("CL3D_D2_FORM", "0") or 0)
+
+
+def build(force=False, form=None):
+    form = d2_form() if form is None else form
+    name = "libcl3d_oracle.so" if form == 0 else f"libcl3d_oracle_d2form{form}.so"
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "cl3d_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libcl3d_oracle.so"],
-                              stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
     return so
 
 

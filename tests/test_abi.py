@@ -43,6 +43,21 @@ def test_library_loads_and_reports_version(libpath):
     assert isinstance(h.cl3d_last_error_string(), bytes)
     h.cl3d_workspace_bytes.restype = ctypes.c_size_t
     assert h.cl3d_workspace_bytes(1, 16, 4096, 4096, 32, 64) >= 0
+    assert h.cl3d_d2_form() == 0  # the default library carries hipcc's contraction of the reference expression
+
+
+def test_fused_capability_query(libpath):
+    """cl3d_fused_supported answers without a GPU: every shipped (nsample, width) is covered, absurd nsample is not
+    -- `impl='auto'` asks before it commits to the fused kernels."""
+    import torch  # noqa: F401
+    from closerlook3d_amd import _lib
+    h = _lib.lib()
+    for op in (7, 8, 9, 10, 13):
+        for K in (16, 26, 32, 42):
+            for C in (36, 64, 72, 144, 1152):
+                assert h.cl3d_fused_supported(op, K, C) == 1, (op, K, C)
+        assert h.cl3d_fused_supported(op, 5000, 64) == 0
+    assert h.cl3d_fused_supported(1, 16, 64) == 0  # not an operator id
 
 
 def test_invalid_arguments_return_codes_not_exit(libpath):
@@ -60,7 +75,7 @@ def test_invalid_arguments_return_codes_not_exit(libpath):
 
 def test_python_binding_table_covers_header():
     from closerlook3d_amd import _lib
-    names = set(_declared()) - {"cl3d_abi_version", "cl3d_last_error_string", "cl3d_workspace_bytes"}
+    names = set(_declared()) - {"cl3d_abi_version", "cl3d_last_error_string", "cl3d_workspace_bytes", "cl3d_d2_form"}
     assert names == set(_lib.SIGNATURES), (names ^ set(_lib.SIGNATURES))
 
 
