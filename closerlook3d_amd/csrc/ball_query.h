@@ -22,5 +22,7 @@ size_t grid_subsampling_workspace(int B, int N);
 // csr.hip
 size_t inverse_index_workspace(int B, int N, int MK);
 size_t dataset_grid_workspace(int n);
+// mfma_gemm.hip: scratch of a weight-gradient contraction D[I][J] over nb batches of K points (split-K partials)
+size_t gemm_wgrad_workspace(int nb, int K, int I, int J);
 
 }  // namespace cl3d

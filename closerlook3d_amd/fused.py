@@ -418,19 +418,67 @@ class _PointwiseMLP(Function):
         return (dght, dwr, dgamma, dbeta) + (None,) * 10
 
 
+PRECISIONS = {'f32': 0, 'bf16': 1}  # CL3D_PRECISION_*: arithmetic of the dense contraction only
+POINT_GEMM = 'mfma'  # 'mfma': csrc/mfma_gemm.hip; 'bmm': the library GEMM (kept for scripts/bench_point_gemm.py's A/B)
+
+
 class _PointRows(Function):
     """(features [B,C,N], W [Co,3+2C] = [W_r | W_c | W_d])  ->  ght [B,N,2Co] with rows [W_d f_i | (W_c - W_d) f_i]
     (once per point instead of once per (point, neighbour)), and W_r [Co,3].
 
-    The contraction itself is a plain library GEMM (rocBLAS/hipBLASLt through torch.bmm), arranged so that every
-    operand is consumed through its strides: forward F[b]^T wcat^T; d features = wcat^T G[b]^T lands channel-major
-    as the caller needs it; d wcat^T = sum_b F[b] G[b] as a batched GEMM whose per-cloud products are summed by
-    the merge kernel (left to the library as ONE [2Co, B*N] x [B*N, C] GEMM it gets four workgroups: 207 us).
-    A hand-written fp32-MFMA version (32x32x2, operands staged in LDS / register fragments) was built and
-    measured at the metric shape: 23.7 / 19.6 / 19.7+5.6 us against the library's 18.9 / 17.1 / 18.5+4.3 us --
-    no gain, so the library stays.  The weight split / gradient merge around it are two small engine kernels
-    instead of the ~10 launch-latency-sized kernels autograd makes of slices, a subtraction and a cat.
+    This is what is left of the reference's dense contraction (local_aggregation_operators.py:253-257,288-295) and
+    it runs on the matrix cores through the engine's own kernel (csrc/mfma_gemm.hip: channel-major features in,
+    point-major rows out, f32 or bf16 inputs with f32 accumulation); the backward pass is the same kernel twice
+    (d features channel-major as the caller needs it; d W summed over all points in a fixed slice order and
+    written in the Conv2d weight's own layout).
     """
+
+    @staticmethod
+    def forward(ctx, features, W, precision):
+        features = features.contiguous()
+        W = W.contiguous()
+        B, C, N = features.shape
+        Co = W.shape[0]
+        dev = features.device
+        wr = torch.empty((Co, 3), dtype=torch.float32, device=dev)
+        wcat = torch.empty((2 * Co, C), dtype=torch.float32, device=dev)
+        ght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().cl3d_pwmlp_point_gemm_fwd(_p(features), _p(W), B, C, N, Co, precision, _p(ght), _p(wr),
+                                                            _p(wcat), _stream(features)))
+        ctx.save_for_backward(features, wcat)
+        ctx.precision = precision
+        return ght, wr
+
+    @staticmethod
+    def backward(ctx, dght, dwr):
+        features, wcat = ctx.saved_tensors
+        B, C, N = features.shape
+        Co = wcat.shape[0] // 2
+        dev = features.device
+        lib = _lib.lib()
+        dfeat = dW = None
+        if dght is None:
+            dght = torch.zeros((B, N, 2 * Co), dtype=torch.float32, device=dev)
+        dght = dght.contiguous()
+        with _lib.on_device(dev):
+            st = _stream(features)
+            if ctx.needs_input_grad[0]:
+                dfeat = torch.empty((B, C, N), dtype=torch.float32, device=dev)
+                _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_data(_p(dght), _p(wcat), B, C, N, Co, ctx.precision, _p(dfeat), st))
+            if ctx.needs_input_grad[1]:
+                dW = torch.empty((Co, 3 + 2 * C), dtype=torch.float32, device=dev)
+                ws_bytes = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)  # CL3D_OP_POINT_GEMM
+                ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
+                dwr = dwr.contiguous() if dwr is not None else None
+                _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_weight(_p(features), _p(dght), _p(dwr), B, C, N, Co,
+                                                                ctx.precision, _p(dW), _p(ws), ws_bytes, st))
+        return dfeat, dW, None
+
+
+class _PointRowsLibrary(Function):
+    """The same contraction through the vendor library (torch.bmm -> rocBLAS / hipBLASLt) with the engine's two
+    weight-plumbing kernels around it: the baseline of scripts/bench_point_gemm.py, not used by the operators."""
 
     @staticmethod
     def forward(ctx, features, W):
@@ -463,8 +511,16 @@ class _PointRows(Function):
         return dfeat, dW
 
 
+def point_rows(features, W, precision='f32'):
+    """[G | H] rows and W_r of the factored PointWiseMLP contraction; precision 'f32' or 'bf16' (inputs of the
+    contraction rounded to bf16, f32 accumulation; coordinates, indices and BatchNorm statistics stay f32)."""
+    if POINT_GEMM == 'bmm':
+        return _PointRowsLibrary.apply(features, W)
+    return _PointRows.apply(features, W, PRECISIONS[precision])
+
+
 def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps, reduction,
-                  training):
+                  training, precision='f32'):
     assert reduction == 'max'
     conv, bn = mlps.conv0[0], mlps.conv0[1]
     idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
@@ -472,7 +528,7 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
     C = features.shape[1]
     Co = conv.weight.shape[0]
     W = conv.weight.view(Co, 3 + 2 * C)
-    ght, wr = _PointRows.apply(features, W)
+    ght, wr = point_rows(features, W, precision)
     use_batch_stats = training or bn.running_mean is None
     if use_batch_stats and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)

@@ -166,6 +166,9 @@ class PointWiseMLP(nn.Module):
         self.num_mlps = pw.num_mlps
         self.reduction = pw.reduction
         self.impl = _cfg(config, 'cl3d_impl', 'auto')
+        # arithmetic of the dense contraction on the fused path: 'f32' (the reference's) or 'bf16' (BASELINE config 2:
+        # bf16 inputs to the matrix cores, f32 accumulation; everything else stays f32)
+        self.precision = _cfg(config, 'cl3d_precision', 'f32')
         self.grouper = MaskedQueryAndGroup(radius, nsample, use_xyz=False, ret_grouped_xyz=True, normalize_xyz=True)
 
         def block(cin, cout):
@@ -189,7 +192,8 @@ class PointWiseMLP(nn.Module):
         from . import fused
         if fused.use_fused(self.impl, 'pointwisemlp', self):
             return fused.pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, support_features,
-                                       self.radius, self.nsample, self.mlps, self.reduction, self.training)
+                                       self.radius, self.nsample, self.mlps, self.reduction, self.training,
+                                       getattr(self, 'precision', 'f32'))
         feats, rel, nmask = self.grouper(query_xyz, support_xyz, query_mask, support_mask, support_features)
         center = feats[..., :1].expand(-1, -1, -1, self.nsample)
         agg = self.mlps(torch.cat([rel, center, feats - center], 1))

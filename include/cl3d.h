@@ -56,6 +56,8 @@ typedef void *cl3d_stream_t; /* hipStream_t */
 #define CL3D_OP_INVERSE_INDEX 11 /* cl3d_build_inverse_index: pass M*K slots as (M, K) */
 #define CL3D_OP_DATASET_GRID 12  /* cl3d_dataset_grid_subsampling: N = points of the cloud (B, M, K, C unused) */
 #define CL3D_OP_MAX_POOL 13      /* cl3d_maxpool_fwd/bwd (only meaningful for cl3d_fused_supported) */
+#define CL3D_OP_POINT_GEMM 14    /* cl3d_pwmlp_point_gemm_bwd_weight: (B, N, M = Co, K unused, C) */
+#define CL3D_OP_CONV1X1 15       /* cl3d_conv1x1_bwd_weight: (B, N, M = Cout, K unused, C = Cin) */
 
 int cl3d_abi_version(void);
 const char *cl3d_last_error_string(void);
@@ -203,6 +205,35 @@ int cl3d_maxpool_bwd(const float *gout_t, const unsigned char *kstar_t, const in
  * Per-(query, channel) arrays are point-major [B,M,Co]; partial buffers are
  * [cl3d_pwmlp_partials(B,M,Co), Co, 8] doubles. */
 int cl3d_pwmlp_partials(int B, int M, int Co);
+
+/* The dense contraction of the PointWiseMLP (local_aggregation_operators.py:253-257,288-295) on the matrix cores
+ * (csrc/mfma_gemm.hip).  Factored per POINT: ght[b][i] = [W_d f_i | (W_c - W_d) f_i] with W [Co, 3+2C] =
+ * [W_r | W_c | W_d] the Conv2d weight; features stay channel-major [B,C,N] as the reference hands them over, ght
+ * is point-major [B,N,2Co] (the layout change happens while the tiles go through LDS).  precision: 0 = f32 inputs, v_mfma_f32_32x32x2_f32 (bit-for-bit an fmaf chain); 1 = inputs
+ * rounded to bf16 (RNE) while staged, v_mfma_f32_32x32x16_bf16, f32 accumulation and f32 results.
+ *   fwd:        ght; also leaves wr [Co,3] = W_r (nullable) and wcat [2Co,C] = [W_d ; W_c - W_d] (one small launch);
+ *   bwd_data:   d features [B,C,N] from d ght and the wcat the forward call produced;
+ *   bwd_weight: d W [Co, 3+2C] from features, d ght and d wr [Co,3] (nullable: zeros); the sum over all B*N points
+ *               is cut into slices summed in a fixed order (bit-reproducible);
+ *               ws: cl3d_workspace_bytes(CL3D_OP_POINT_GEMM, B, N, Co, 0, C). */
+#define CL3D_PRECISION_F32 0
+#define CL3D_PRECISION_BF16 1
+int cl3d_pwmlp_point_gemm_fwd(const float *features, const float *W, int B, int C, int N, int Co, int precision,
+                              float *ght, float *wr, float *wcat, cl3d_stream_t stream);
+int cl3d_pwmlp_point_gemm_bwd_data(const float *dght, const float *wcat, int B, int C, int N, int Co, int precision,
+                                   float *dfeatures, cl3d_stream_t stream);
+int cl3d_pwmlp_point_gemm_bwd_weight(const float *features, const float *dght, const float *dwr, int B, int C,
+                                     int N, int Co, int precision, float *dW, void *ws, size_t ws_bytes,
+                                     cl3d_stream_t stream);
+/* The 1x1 Conv1d layers either side of the operator (backbones/resnet.py:32-39,58-66; bias-free), same kernel:
+ * y [B,Co,N] = W [Co,C] x [B,C,N], its input gradient and its weight gradient
+ * (ws: cl3d_workspace_bytes(CL3D_OP_CONV1X1, B, N, Co, 0, C)). */
+int cl3d_conv1x1_fwd(const float *x, const float *W, int B, int C, int N, int Co, int precision, float *y,
+                     cl3d_stream_t stream);
+int cl3d_conv1x1_bwd_data(const float *dy, const float *W, int B, int C, int N, int Co, int precision, float *dx,
+                          cl3d_stream_t stream);
+int cl3d_conv1x1_bwd_weight(const float *x, const float *dy, int B, int C, int N, int Co, int precision, float *dW,
+                            void *ws, size_t ws_bytes, cl3d_stream_t stream);
 /* weight plumbing of the factored contraction: W [Co,3+2C] = [W_r | W_c | W_d] -> wr [Co,3], wcat [2Co,C] =
  * [W_d ; W_c - W_d];  d W from d wr (nullable) and the per-cloud products dwb [B,C,2Co] = F_b G_b. */
 int cl3d_pwmlp_split_weight(const float *W, int Co, int C, float *wr, float *wcat, cl3d_stream_t stream);

@@ -1,0 +1,143 @@
+"""The hand-written MFMA contraction (csrc/mfma_gemm.hip) against float64 references.
+
+f32 (v_mfma_f32_32x32x2_f32) must hold north_star's 1e-5; bf16 (v_mfma_f32_32x32x16_bf16, f32 accumulation) is
+checked two ways: against a float64 product of the SAME bf16-rounded inputs (tight: proves the kernel) and against
+the unrounded product at the declared bf16 tolerance (BF16_TOL, relative to the largest output magnitude).
+Random, asymmetric operands: a transposed or mis-tiled result cannot pass.
+Reference semantics: the PointWiseMLP's Conv2d (local_aggregation_operators.py:253-257,288-295) in the engine's
+factored form, and the 1x1 Conv1d layers of the bottleneck (backbones/resnet.py:32-39,58-66).
+"""
+import pytest
+import torch
+
+from closerlook3d_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5       # f32 path, relative to the largest magnitude of the result
+BF16_TOL = 1e-2  # bf16 inputs (8-bit mantissa), f32 accumulation, K <= 2304, relative to the largest magnitude
+
+SHAPES = [  # B, C, N, Co
+    (2, 64, 4096, 64),     # the metric shape's operator
+    (3, 72, 1000, 36),     # N not a multiple of the point tile, C not a multiple of the K chunk
+    (1, 36, 250, 20),      # N % 4 != 0: the scalar staging fallback
+    (2, 288, 512, 288),    # several output tiles and K chunks
+    (1, 8, 64, 4),         # smaller than one tile in every direction
+]
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _st():
+    return _lib.stream_ptr(_dev())
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+def _rel(got, want):
+    return float((got.double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+def _wcat64(W, Co, C):
+    W = W.double()
+    wc, wd = W[:, 3:3 + C], W[:, 3 + C:]
+    return torch.cat([wd, wc - wd], 0)  # [2Co, C]
+
+
+def _inputs(B, C, N, Co, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    f = torch.randn(B, C, N, generator=g).to(_dev())
+    W = (torch.randn(Co, 3 + 2 * C, generator=g) / (C ** 0.5)).to(_dev())
+    dght = torch.randn(B, N, 2 * Co, generator=g).to(_dev())
+    dwr = torch.randn(Co, 3, generator=g).to(_dev())
+    return f, W, dght, dwr
+
+
+@pytest.mark.parametrize("B,C,N,Co", SHAPES)
+@pytest.mark.parametrize("prec", [0, 1])
+def test_point_gemm_forward_and_gradients(B, C, N, Co, prec):
+    lib = _lib.lib()
+    f, W, dght, dwr = _inputs(B, C, N, Co, seed=B * 1000 + C)
+    wr = torch.empty(Co, 3, device=_dev())
+    wcat = torch.empty(2 * Co, C, device=_dev())
+    ght = torch.full((B, N, 2 * Co), float("nan"), device=_dev())
+    _lib.check(lib.cl3d_pwmlp_point_gemm_fwd(_p(f), _p(W), B, C, N, Co, prec, _p(ght), _p(wr), _p(wcat), _st()))
+    wc64 = _wcat64(W, Co, C)
+    assert torch.equal(wr, W[:, :3].contiguous())
+    assert torch.equal(wcat.double(), torch.cat([W[:, 3 + C:], W[:, 3:3 + C] - W[:, 3 + C:]], 0).double())  # f32 subtraction
+    want = torch.einsum("bcn,oc->bno", f.double(), wc64)
+    dfeat = torch.full((B, C, N), float("nan"), device=_dev())
+    _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_data(_p(dght), _p(wcat), B, C, N, Co, prec, _p(dfeat), _st()))
+    want_df = torch.einsum("bno,oc->bcn", dght.double(), wc64)
+    ws_bytes = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=_dev())
+    dW = torch.full((Co, 3 + 2 * C), float("nan"), device=_dev())
+    _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_weight(_p(f), _p(dght), _p(dwr), B, C, N, Co, prec, _p(dW), _p(ws), ws_bytes, _st()))
+    dwcat = torch.einsum("bno,bcn->oc", dght.double(), f.double())
+    want_dW = torch.cat([dwr.double(), dwcat[Co:], dwcat[:Co] - dwcat[Co:]], 1)
+    if prec == 0:
+        assert _rel(ght, want) <= TOL
+        assert _rel(dfeat, want_df) <= TOL
+        assert _rel(dW, want_dW) <= 2e-5  # B*N-term sums
+    else:
+        # the kernel proper: same rounded inputs, exact products, f32 accumulation
+        fr, wr_, gr = _bf16_round(f), _bf16_round(wcat), _bf16_round(dght)
+        assert _rel(ght, torch.einsum("bcn,oc->bno", fr, wr_)) <= TOL
+        assert _rel(dfeat, torch.einsum("bno,oc->bcn", gr, wr_)) <= TOL
+        dwc_r = torch.einsum("bno,bcn->oc", gr, fr)
+        assert _rel(dW[:, 3:], torch.cat([dwc_r[Co:], dwc_r[:Co] - dwc_r[Co:]], 1)) <= 2e-5
+        # and the declared tolerance against the unrounded contraction
+        assert _rel(ght, want) <= BF16_TOL
+        assert _rel(dfeat, want_df) <= BF16_TOL
+        assert _rel(dW, want_dW) <= BF16_TOL
+    assert torch.equal(dW[:, :3], dwr)
+    # fixed slice order: bit-identical run to run
+    dW2 = torch.empty_like(dW)
+    _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_weight(_p(f), _p(dght), _p(dwr), B, C, N, Co, prec, _p(dW2), _p(ws), ws_bytes, _st()))
+    assert torch.equal(dW, dW2)
+
+
+@pytest.mark.parametrize("B,C,N,Co", [(2, 72, 4096, 144), (4, 144, 1000, 36), (1, 3, 130, 72), (2, 1152, 64, 576),
+                                      (1, 288, 10000, 288)])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_conv1x1_matches_conv1d(B, C, N, Co, prec):
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(C + Co)
+    x = torch.randn(B, C, N, generator=g).to(_dev())
+    W = (torch.randn(Co, C, generator=g) / (C ** 0.5)).to(_dev())
+    dy = torch.randn(B, Co, N, generator=g).to(_dev())
+    y = torch.full((B, Co, N), float("nan"), device=_dev())
+    dx = torch.full((B, C, N), float("nan"), device=_dev())
+    dW = torch.full((Co, C), float("nan"), device=_dev())
+    ws_bytes = lib.cl3d_workspace_bytes(15, B, N, Co, 0, C)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=_dev())
+    _lib.check(lib.cl3d_conv1x1_fwd(_p(x), _p(W), B, C, N, Co, prec, _p(y), _st()))
+    _lib.check(lib.cl3d_conv1x1_bwd_data(_p(dy), _p(W), B, C, N, Co, prec, _p(dx), _st()))
+    _lib.check(lib.cl3d_conv1x1_bwd_weight(_p(x), _p(dy), B, C, N, Co, prec, _p(dW), _p(ws), ws_bytes, _st()))
+    rnd = (lambda t: t.double()) if prec == 0 else _bf16_round
+    xr, wr, gr = rnd(x), rnd(W), rnd(dy)
+    assert _rel(y, torch.einsum("oc,bcn->bon", wr, xr)) <= TOL
+    assert _rel(dx, torch.einsum("oc,bon->bcn", wr, gr)) <= TOL
+    assert _rel(dW, torch.einsum("bon,bcn->oc", gr, xr)) <= 2e-5
+    if prec == 1:
+        assert _rel(y, torch.einsum("oc,bcn->bon", W.double(), x.double())) <= BF16_TOL
+        assert _rel(dW, torch.einsum("bon,bcn->oc", dy.double(), x.double())) <= BF16_TOL
+    else:  # the library's conv agrees too (what the bottleneck ran before)
+        ref = torch.nn.functional.conv1d(x, W[:, :, None])
+        assert _rel(y, ref.double()) <= 2e-5
+
+
+def test_bad_arguments_are_refused():
+    lib = _lib.lib()
+    assert lib.cl3d_pwmlp_point_gemm_fwd(None, None, 1, 8, 16, 4, 0, None, None, None, None) == -1
+    assert lib.cl3d_conv1x1_fwd(None, None, 1, 8, 16, 4, 7, None, None) == -1  # precision 7
+    x = torch.zeros(1, 8, 16, device=_dev())
+    assert lib.cl3d_conv1x1_bwd_weight(_p(x), _p(x), 1, 8, 16, 8, 0, _p(x), None, 0, None) == -3  # workspace

@@ -372,3 +372,95 @@ def test_reference_configs_build_and_train_one_step(rel, B, N):
     sum(o.square().mean() for o in outs).backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     opt.step()
+
+
+# ---------------------------------------------------------------- bf16 contraction (BASELINE config 2)
+# Declared tolerance of the bf16 variant: the inputs of the dense contraction (features and the [W_d ; W_c - W_d]
+# weight, K = C terms per output) are rounded to bf16 (8-bit mantissa, relative step 2^-8) on their way to the matrix
+# cores; products and sums are f32; coordinates, indices, W_r * rel, BatchNorm statistics and the max stay f32.
+BF16_REL_L2 = 1e-2     # relative L2 error of an operator's output / gradients against the f32 reference values
+BF16_MAX = 4e-2        # largest element error relative to the largest magnitude
+BF16_NET_REL_L2 = 5e-2  # five stages / ten BatchNorm layers deep
+
+
+def _rel_l2(got, want):
+    got, want = got.astype(np.float64), want.astype(np.float64)
+    return float(np.linalg.norm(got - want) / max(np.linalg.norm(want), 1e-30))
+
+
+def _rel_max(got, want):
+    return float(np.abs(got.astype(np.float64) - want).max() / max(np.abs(want).max(), 1e-30))
+
+
+def test_pointwisemlp_bf16_contraction_against_f32_reference():
+    """config 2's operator with the contraction in bf16 against the reference-generated f32 fixture."""
+    name = "operators_pointwisemlp_fc1_max_train.npz"
+    fx = load_fixture(name)
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    C = fx["features"].shape[1]
+    cfg = default_config(fx["kind"], fx["over"], cl3d_impl="fused", cl3d_precision="bf16")
+    mod = LocalAggregation(C, C, float(fx["radius"]), int(fx["nsample"]), cfg)
+    mod.load_state_dict(state_of(fx), strict=True)
+    mod = mod.cuda().train(True)
+    xyz, mask = torch.from_numpy(fx["xyz"]).cuda(), torch.from_numpy(fx["mask"]).cuda()
+    feats = torch.from_numpy(fx["features"]).cuda().requires_grad_(True)
+    out = mod(xyz, xyz, mask, mask, feats)
+    (out * torch.from_numpy(fx["probe"]).cuda()).sum().backward()
+    got = out.detach().cpu().numpy()
+    assert not np.array_equal(got, fx["out"]), "bf16 path produced f32-identical values: it did not run"
+    assert _rel_l2(got, fx["out"]) <= BF16_REL_L2 and _rel_max(got, fx["out"]) <= BF16_MAX
+    assert _rel_l2(feats.grad.cpu().numpy(), fx["grad_features"]) <= 3 * BF16_REL_L2  # arg-max routing may flip
+    for k, p in mod.named_parameters():
+        if "grad__" + k in fx:
+            assert _rel_l2(p.grad.cpu().numpy(), fx["grad__" + k]) <= 3 * BF16_REL_L2, k
+
+
+def test_pointwisemlp_bf16_at_the_metric_shape_against_f32_engine():
+    """B=4 clouds of the metric shape (N=4096, K=32, C=64): bf16 contraction vs the f32 engine on the same weights."""
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    from oracle import operators as oo
+    rng = np.random.default_rng(11)
+    B, N, K, C = 4, 4096, 32, 64
+    xyz_np, mask_np = oo.make_cloud(rng, B, N, pad_frac=0.1)
+    xyz, mask = torch.from_numpy(xyz_np).cuda(), torch.from_numpy(mask_np).cuda()
+    f_np = rng.standard_normal((B, C, N)).astype(np.float32)
+    probe = torch.from_numpy(rng.standard_normal((B, C, N)).astype(np.float32)).cuda()
+    res = {}
+    for prec in ("f32", "bf16"):
+        torch.manual_seed(5)
+        cfg = default_config("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df"}, cl3d_impl="fused",
+                             cl3d_precision=prec)
+        mod = LocalAggregation(C, C, 0.14, K, cfg).cuda().train(True)
+        feats = torch.from_numpy(f_np).cuda().requires_grad_(True)
+        out = mod(xyz, xyz, mask, mask, feats)
+        (out * probe).sum().backward()
+        res[prec] = (out.detach().cpu().numpy(), feats.grad.cpu().numpy(),
+                     {k: p.grad.cpu().numpy() for k, p in mod.named_parameters()})
+    assert _rel_l2(res["bf16"][0], res["f32"][0]) <= BF16_REL_L2
+    assert _rel_max(res["bf16"][0], res["f32"][0]) <= BF16_MAX
+    assert _rel_l2(res["bf16"][1], res["f32"][1]) <= 3 * BF16_REL_L2
+    for k in res["f32"][2]:
+        assert _rel_l2(res["bf16"][2][k], res["f32"][2][k]) <= 3 * BF16_REL_L2, k
+
+
+def test_resnet_pointwisemlp_bf16_against_reference_fixture():
+    """The 5-stage backbone + decode fixture with every PointWiseMLP contraction in bf16 (config 2's arithmetic)."""
+    from closerlook3d_amd.backbones import ResNet, SceneSegHeadResNet
+    from closerlook3d_amd.pt_utils import ball_query_cache
+    fx = load_fixture("operators_resnet_seg_pointwisemlp.npz")
+    cfg = default_config("pointwisemlp", fx["over"], cl3d_precision="bf16")
+    K = 16
+    net = ResNet(cfg, 3, 0.1, 0.05, [K] * 5, [128, 48, 16, 8], width=12, depth=2, bottleneck_ratio=2)
+    head = SceneSegHeadResNet(5, 12, 0.1, [K] * 5)
+    net.load_state_dict(state_of(fx, "backbone."), strict=True)
+    head.load_state_dict(state_of(fx, "head."), strict=True)
+    net, head = net.cuda().train(True), head.cuda().train(True)
+    feats = torch.from_numpy(fx["features"]).cuda()
+    with ball_query_cache(), torch.no_grad():
+        ep = net(torch.from_numpy(fx["xyz"]).cuda(), torch.from_numpy(fx["mask"]).cuda(), feats)
+        logits = head(ep)
+    # geometry does not depend on the precision of the contraction: still bit-exact
+    assert np.array_equal(ep["res5_xyz"].cpu().numpy().view(np.uint32), fx["out0"].view(np.uint32))
+    assert np.array_equal(ep["res5_mask"].cpu().numpy(), fx["out1"])
+    assert _rel_l2(ep["res5_features"].cpu().numpy(), fx["out2"]) <= BF16_NET_REL_L2
+    assert _rel_l2(logits.cpu().numpy(), fx["out"]) <= BF16_NET_REL_L2
