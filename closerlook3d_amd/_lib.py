@@ -79,8 +79,66 @@ def _declare(handle):
         fn.restype = _I
 
 
+class _Traced:
+    """Proxy around the library handle that brackets every stream-ordered entry point with a pair of HIP events on
+    the stream the call is enqueued on (`trace()` below): per-entry-point GPU time of a step, measured live."""
+
+    def __init__(self, handle, log):
+        self._h, self._log, self._cache = handle, log, {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            raw = getattr(self._h, name)
+            sig = SIGNATURES.get(name)
+            if sig is None or sig[-1] is not _P:  # size queries etc.: no stream, nothing to time
+                fn = raw
+            else:
+                log = self._log
+
+                def fn(*args, _raw=raw, _name=name):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    st = torch.cuda.current_stream()  # == the stream argument every caller passes (stream_ptr)
+                    e0.record(st)
+                    rc = _raw(*args)
+                    e1.record(st)
+                    log.append((_name, e0, e1))
+                    return rc
+            self._cache[name] = fn
+        return fn
+
+
+_tracer = None
+
+
+class trace:
+    """`with _lib.trace() as t: step()` then `t.summary()` -> {entry point: (calls, total microseconds)}.
+    Measurement only (bench.py's per-kernel table of the timed step); not for use under graph capture."""
+
+    def __enter__(self):
+        global _tracer
+        self.log = []
+        _tracer = _Traced(lib(), self.log)
+        return self
+
+    def __exit__(self, *exc):
+        global _tracer
+        _tracer = None
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1 in self.log:
+            calls, us = out.get(name, (0, 0.0))
+            out[name] = (calls + 1, us + e0.elapsed_time(e1) * 1e3)
+        return out
+
+
 def lib():
     global _lib
+    if _tracer is not None:
+        return _tracer
     if _lib is None:
         if not os.path.exists(_PATH):
             raise ImportError(

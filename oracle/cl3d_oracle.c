@@ -28,10 +28,24 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #ifndef CL3D_D2_FORM
 #define CL3D_D2_FORM 0
 #endif
+
+/* threads used by the OpenMP loops below (0 = leave the runtime's default); returns the count in effect */
+int oracle_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
 
 static inline float oracle_d2(float qx, float qy, float qz, float x, float y, float z) {
   volatile float dx = qx - x, dy = qy - y, dz = qz - z;
@@ -105,61 +119,73 @@ int oracle_masked_ordered_ball_query(const float *query_xyz, const float *suppor
                                      int B, int M, int N, float radius, int nsample,
                                      int *idx, int *idx_mask) {
   const int cap = 3 * nsample;
-  float *dists = (float *)malloc(sizeof(float) * (size_t)(cap > 0 ? cap : 1));
-  int *cand = (int *)malloc(sizeof(int) * (size_t)(cap > 0 ? cap : 1));
-  if (!dists || !cand) return -1;
   volatile float r2v = radius * radius;
   const float radius2 = r2v;
-  for (int b = 0; b < B; ++b) {
-    const float *q = query_xyz + (size_t)b * M * 3;
-    const float *s = support_xyz + (size_t)b * N * 3;
-    const int *qm = query_mask + (size_t)b * M;
-    const int *sm = support_mask + (size_t)b * N;
-    int *oi = idx + (size_t)b * M * nsample;
-    int *om = idx_mask + (size_t)b * M * nsample;
-    for (int j = 0; j < M; ++j) {
-      const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
-      int cnt = 0;
-      float min_dist = radius2;
-      int min_idx = 0;
-      memset(dists, 0, sizeof(float) * (size_t)cap);
-      memset(cand, 0, sizeof(int) * (size_t)cap);
-      for (int k = 0; k < N; ++k) {
-        if (sm[k] == 0) break;
-        float d2 = oracle_d2(qx, qy, qz, s[k * 3 + 0], s[k * 3 + 1], s[k * 3 + 2]);
-        if (d2 < radius2) {
-          if (d2 < min_dist) { min_dist = d2; min_idx = k; }
-          if (cnt >= cap) continue;
-          dists[cnt] = d2;
-          cand[cnt] = k;
-          cnt++;
+  int failed = 0;
+  /* OpenMP over batch x query (the CPU baseline's native ops use every host core; each query writes
+   * only its own output row, so the result does not depend on the thread count -- oracle_set_threads(1) is the
+   * literal one-thread-per-cloud structure of the reference kernel) */
+#pragma omp parallel
+  {
+    float *dists = (float *)malloc(sizeof(float) * (size_t)(cap > 0 ? cap : 1));
+    int *cand = (int *)malloc(sizeof(int) * (size_t)(cap > 0 ? cap : 1));
+    if (!dists || !cand) {
+#pragma omp atomic write
+      failed = 1;
+    } else {
+#pragma omp for schedule(static)
+      for (long long bj = 0; bj < (long long)B * M; ++bj) {
+        const int b = (int)(bj / M), j = (int)(bj % M);
+        const float *q = query_xyz + (size_t)b * M * 3;
+        const float *s = support_xyz + (size_t)b * N * 3;
+        const int *qm = query_mask + (size_t)b * M;
+        const int *sm = support_mask + (size_t)b * N;
+        int *oi = idx + (size_t)b * M * nsample;
+        int *om = idx_mask + (size_t)b * M * nsample;
+        const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
+        int cnt = 0;
+        float min_dist = radius2;
+        int min_idx = 0;
+        memset(dists, 0, sizeof(float) * (size_t)cap);
+        memset(cand, 0, sizeof(int) * (size_t)cap);
+        for (int k = 0; k < N; ++k) {
+          if (sm[k] == 0) break;
+          float d2 = oracle_d2(qx, qy, qz, s[k * 3 + 0], s[k * 3 + 1], s[k * 3 + 2]);
+          if (d2 < radius2) {
+            if (d2 < min_dist) { min_dist = d2; min_idx = k; }
+            if (cnt >= cap) continue;
+            dists[cnt] = d2;
+            cand[cnt] = k;
+            cnt++;
+          }
         }
+        if (cnt >= cap && cap > 0 && min_idx > cand[cnt - 1]) {
+          cand[cnt - 1] = min_idx;
+          dists[cnt - 1] = min_dist;
+        }
+        stable_sort_f32_i32(dists, cand, cnt);
+        for (int i = 0; i < cnt && i < nsample; ++i) {
+          oi[j * nsample + i] = cand[i];
+          om[j * nsample + i] = 1;
+        }
+        for (int i = cnt; i < nsample; ++i) {
+          oi[j * nsample + i] = cnt > 0 ? cand[i % cnt] : 0;
+          om[j * nsample + i] = 0;
+        }
+        if (qm[j] == 0)
+          for (int l = 0; l < nsample; ++l) om[j * nsample + l] = 0;
       }
-      if (cnt >= cap && cap > 0 && min_idx > cand[cnt - 1]) {
-        cand[cnt - 1] = min_idx;
-        dists[cnt - 1] = min_dist;
-      }
-      stable_sort_f32_i32(dists, cand, cnt);
-      for (int i = 0; i < cnt && i < nsample; ++i) {
-        oi[j * nsample + i] = cand[i];
-        om[j * nsample + i] = 1;
-      }
-      for (int i = cnt; i < nsample; ++i) {
-        oi[j * nsample + i] = cnt > 0 ? cand[i % cnt] : 0;
-        om[j * nsample + i] = 0;
-      }
-      if (qm[j] == 0)
-        for (int l = 0; l < nsample; ++l) om[j * nsample + l] = 0;
     }
+    free(dists);
+    free(cand);
   }
-  free(dists);
-  free(cand);
-  return 0;
+  return failed ? -1 : 0;
 }
 
 /* group_points (reference: group_points_gpu.cu:13-33) */
 int oracle_group_points(const float *points, const int *idx, int B, int C, int N, int M, int K,
                         float *out) {
+#pragma omp parallel for collapse(2) schedule(static)
   for (int b = 0; b < B; ++b)
     for (int l = 0; l < C; ++l)
       for (int j = 0; j < M; ++j)
@@ -175,20 +201,29 @@ int oracle_group_points(const float *points, const int *idx, int B, int C, int N
  * which is the tightest statement of "the sum"; parity tolerance 1e-5). */
 int oracle_group_points_grad(const float *grad_out, const int *idx, int B, int C, int N, int M,
                              int K, float *grad_points) {
-  double *acc = (double *)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1));
-  if (!acc) return -1;
-  for (int b = 0; b < B; ++b)
-    for (int l = 0; l < C; ++l) {
-      memset(acc, 0, sizeof(double) * (size_t)N);
-      for (int j = 0; j < M; ++j)
-        for (int k = 0; k < K; ++k) {
-          int ii = idx[((size_t)b * M + j) * K + k];
-          acc[ii] += (double)grad_out[(((size_t)b * C + l) * M + j) * K + k];
+  int failed = 0;
+#pragma omp parallel
+  {
+    double *acc = (double *)malloc(sizeof(double) * (size_t)(N > 0 ? N : 1));
+    if (!acc) {
+#pragma omp atomic write
+      failed = 1;
+    } else {
+#pragma omp for collapse(2) schedule(static)
+      for (int b = 0; b < B; ++b)
+        for (int l = 0; l < C; ++l) {
+          memset(acc, 0, sizeof(double) * (size_t)N);
+          for (int j = 0; j < M; ++j)
+            for (int k = 0; k < K; ++k) {
+              int ii = idx[((size_t)b * M + j) * K + k];
+              acc[ii] += (double)grad_out[(((size_t)b * C + l) * M + j) * K + k];
+            }
+          for (int i = 0; i < N; ++i) grad_points[((size_t)b * C + l) * N + i] = (float)acc[i];
         }
-      for (int i = 0; i < N; ++i) grad_points[((size_t)b * C + l) * N + i] = (float)acc[i];
     }
-  free(acc);
-  return 0;
+    free(acc);
+  }
+  return failed ? -1 : 0;
 }
 
 /* -------------------------------------------------------------------------
@@ -287,11 +322,12 @@ int oracle_masked_grid_subsampling(const float *xyz, const int *mask, int B, int
 int oracle_masked_nearest_query(const float *query_xyz, const float *support_xyz,
                                 const int *query_mask, const int *support_mask, int B, int M, int N,
                                 int *idx, int *idx_mask) {
+#pragma omp parallel for collapse(2) schedule(static)
   for (int b = 0; b < B; ++b) {
-    const float *q = query_xyz + (size_t)b * M * 3;
-    const float *s = support_xyz + (size_t)b * N * 3;
-    const int *sm = support_mask + (size_t)b * N;
     for (int j = 0; j < M; ++j) {
+      const float *q = query_xyz + (size_t)b * M * 3;
+      const float *s = support_xyz + (size_t)b * N * 3;
+      const int *sm = support_mask + (size_t)b * N;
       float min_dist = 100;
       int min_idx = -1;
       for (int k = 0; k < N; ++k) {

@@ -34,6 +34,14 @@ def lib():
     return _LIB
 
 
+def set_threads(n=0):
+    """OpenMP threads of the native-op loops (batch x query / batch x channel); 0 keeps the runtime default.
+    Returns the count in effect.  Results do not depend on it."""
+    fn = lib().oracle_set_threads
+    fn.restype = ctypes.c_int
+    return int(fn(int(n)))
+
+
 def _f32(a):
     a = np.ascontiguousarray(a, dtype=np.float32)
     return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))

@@ -74,3 +74,25 @@ def test_multipart_head_state_dict_matches_reference():
     want = json.load(open(os.path.join(GOLDEN, "state_dict_multipart_head.json")))
     got = {k: list(v.shape) for k, v in MultiPartSegHeadResNet(3, 12, 0.1, [16] * 5, [4, 2, 6]).state_dict().items()}
     assert got == want
+
+
+def test_native_oracle_does_not_depend_on_the_thread_count():
+    """The OpenMP loops of the C oracle (bench.py's all-cores CPU baseline) partition queries / channel rows; every
+    thread count must give the same bits as one thread (the reference's one-block-per-cloud structure)."""
+    from oracle import native as on
+    rng = np.random.default_rng(3)
+    xyz, mask = oo.make_cloud(rng, 3, 700, pad_frac=0.15)
+    feats = rng.standard_normal((3, 5, 700)).astype(np.float32)
+    res = []
+    try:
+        for nt in (1, 4):
+            on.set_threads(nt)
+            idx, msk = on.masked_ordered_ball_query(xyz, xyz, mask, mask, 0.2, 12)
+            grouped = on.group_points(feats, idx)
+            back = on.group_points_grad(grouped, idx, 700)
+            near = on.masked_nearest_query(xyz[:, ::3].copy(), xyz, mask[:, ::3].copy(), mask)
+            res.append((idx, msk, grouped, back, near[0], near[1]))
+    finally:
+        on.set_threads(os.cpu_count() or 1)
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
