@@ -21,9 +21,11 @@
 //     v_cvt_pk_bf16_f32 -- while they are staged; accumulation and everything outside the contraction stay f32);
 //   * which operand plays "A" decides the register layout of D (a lane holds one column j, 16 rows i), so the side
 //     whose index is contiguous in the OUTPUT is always put on j: every store instruction writes 128-byte runs;
-//   * a 256-thread workgroup = 2 x 2 waves, each wave a WI x WJ grid of 32x32 accumulators (64 x 64 per wave for
-//     the large shapes, 128 x 128 per workgroup); the next K chunk is prefetched into registers while the current
-//     one is multiplied out of LDS;
+//   * a 256-thread workgroup = 2 x 2 waves, each wave a WI x WJ grid of 32x32 accumulators (workgroup tiles 128x128,
+//     128x64, 64x128 or 64x64, picked per shape so that the chip is filled and little of a tile is padding); the next
+//     K chunk is prefetched into registers while the current one is multiplied out of LDS;
+//   * clouds are folded into the point axis: a tile of 128 points may span several small clouds of a channel-major
+//     tensor (the deep stages have 16 clouds x 16..64 points), index -> (cloud, point) per load;
 //   * weight gradients contract over ALL points (K = B*N): the (batch, point) axis is cut into contiguous slices,
 //     one workgroup each, partial products go to scratch and are summed in slice order by a second small kernel
 //     (no atomics: bit-reproducible), which also folds the PointWiseMLP weight plumbing
@@ -43,26 +45,36 @@ enum { STAGE_VEC_RC = 0, STAGE_VEC_KC = 1, STAGE_SCALAR = 2 };  // how an operan
 struct GemmOperand {
   const float *p;
   int sr, sk;            // element strides along the tile index r and the contraction index k
-  long long sb;          // ... and the batch
-  int R;                 // extent along r
+  int R;                 // extent along r (clouds folded in)
   int rc;                // 1: r is the contiguous axis (sr == 1), 0: k is (sk == 1)
   int vec;               // 16-byte loads along the contiguous axis are legal (alignment and extents)
+  int fold;              // 0: none; 1: r = cloud * fold_n + point; 2: k = cloud * fold_n + point  (channel-major tensors)
+  int fold_n;            // points per cloud
+  long long sb;          // cloud stride of a folded axis
 };
 
 struct GemmArgs {
   GemmOperand A, B;  // D[i][j] = sum_k A(i,k) B(j,k)
   float *D;
-  long long d_si, d_sj, d_sb;
-  int K;               // contraction extent per batch
-  int nb;              // batches
-  int split;           // 0: grid = tiles x batches; 1: (batch, k) folded, cut into nsplit slices, D += slice*I*J
-  int nsplit, chunks_per_split;
+  long long d_si, d_sj;
+  int d_fold_n;        // != 0: j = cloud * d_fold_n + point, cloud stride d_sb (channel-major output)
+  long long d_sb;
+  int K;               // contraction extent (clouds folded in for weight gradients)
+  int nsplit, chunks_per_split;  // nsplit > 1: K cut into slices, slice s writes its partial tile to D + s*I*J
   int tiles_i, tiles_j;
 };
 
-// element (r, k) of an operand relative to the tile origin `base` (wave-uniform: scalar base + 32-bit lane offset)
-__device__ __forceinline__ float gemm_fetch(const GemmOperand &s, const float *base, int r, int k) {
-  return base[(unsigned)(r * s.sr + k * s.sk)];
+// element offset of (r, k) of an operand; the pointer base is wave-uniform, the offset a 32-bit lane value
+__device__ __forceinline__ unsigned gemm_off(const GemmOperand &s, int r, int k) {
+  if (s.fold == 1) {
+    const int b = r / s.fold_n;
+    return (unsigned)(b * (int)s.sb + (r - b * s.fold_n) * s.sr + k * s.sk);
+  }
+  if (s.fold == 2) {
+    const int b = k / s.fold_n;
+    return (unsigned)(b * (int)s.sb + r * s.sr + (k - b * s.fold_n) * s.sk);
+  }
+  return (unsigned)(r * s.sr + k * s.sk);
 }
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -79,24 +91,20 @@ struct StageF32 {
   __device__ __forceinline__ static int stride(const GemmOperand &s) { return s.rc ? TR + 4 : TR + 1; }
 
   template <int MODE>
-  __device__ __forceinline__ void load(const GemmOperand &s, long long boff, int r0, int k0, int K) {
+  __device__ __forceinline__ void load(const GemmOperand &s, int r0, int k0, int K) {
     const int t = threadIdx.x;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float *base = s.p + boff + (long long)r0 * s.sr + (long long)k0 * s.sk;
-    const int Rl = s.R - r0, Kl = K - k0;  // what is left of the operand from the tile origin on
-    if (MODE != STAGE_SCALAR) {
-      if (MODE == STAGE_VEC_RC) {
+    if (MODE == STAGE_VEC_RC) {
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-          const int idx = q * 256 + t, r = 4 * (idx % (TR / 4)), k = idx / (TR / 4);
-          v[q] = (r < Rl && k < Kl) ? ld4(base + (unsigned)(k * s.sk + r)) : zero;
-        }
-      } else {
+      for (int q = 0; q < NV; ++q) {
+        const int idx = q * 256 + t, r = r0 + 4 * (idx % (TR / 4)), k = k0 + idx / (TR / 4);
+        v[q] = (r < s.R && k < K) ? ld4(s.p + gemm_off(s, r, k)) : zero;
+      }
+    } else if (MODE == STAGE_VEC_KC) {
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-          const int idx = q * 256 + t, k = 4 * (idx % (KC / 4)), r = idx / (KC / 4);
-          v[q] = (r < Rl && k < Kl) ? ld4(base + (unsigned)(r * s.sr + k)) : zero;
-        }
+      for (int q = 0; q < NV; ++q) {
+        const int idx = q * 256 + t, k = k0 + 4 * (idx % (KC / 4)), r = r0 + idx / (KC / 4);
+        v[q] = (r < s.R && k < K) ? ld4(s.p + gemm_off(s, r, k)) : zero;
       }
     } else {
 #pragma unroll
@@ -104,8 +112,8 @@ struct StageF32 {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int idx = (q * 4 + e) * 256 + t;
-          const int r = s.rc ? idx % TR : idx / KC, k = s.rc ? idx / TR : idx % KC;
-          comp(v[q], e) = (r < Rl && k < Kl) ? gemm_fetch(s, base, r, k) : 0.f;
+          const int r = r0 + (s.rc ? idx % TR : idx / KC), k = k0 + (s.rc ? idx / TR : idx % KC);
+          comp(v[q], e) = (r < s.R && k < K) ? s.p[gemm_off(s, r, k)] : 0.f;
         }
     }
   }
@@ -113,21 +121,19 @@ struct StageF32 {
   template <int MODE>
   __device__ __forceinline__ void store(const GemmOperand &s, float *T) const {
     const int t = threadIdx.x;
-    if (MODE != STAGE_SCALAR) {
-      if (MODE == STAGE_VEC_RC) {
+    if (MODE == STAGE_VEC_RC) {
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-          const int idx = q * 256 + t;
-          *reinterpret_cast<float4 *>(T + (idx / (TR / 4)) * (TR + 4) + 4 * (idx % (TR / 4))) = v[q];
-        }
-      } else {
+      for (int q = 0; q < NV; ++q) {
+        const int idx = q * 256 + t;
+        *reinterpret_cast<float4 *>(T + (idx / (TR / 4)) * (TR + 4) + 4 * (idx % (TR / 4))) = v[q];
+      }
+    } else if (MODE == STAGE_VEC_KC) {
 #pragma unroll
-        for (int q = 0; q < NV; ++q) {
-          const int idx = q * 256 + t, k = 4 * (idx % (KC / 4)), r = idx / (KC / 4);
-          float4 x = v[q];
+      for (int q = 0; q < NV; ++q) {
+        const int idx = q * 256 + t, k = 4 * (idx % (KC / 4)), r = idx / (KC / 4);
+        float4 x = v[q];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) T[(k + e) * (TR + 1) + r] = comp(x, e);
-        }
+        for (int e = 0; e < 4; ++e) T[(k + e) * (TR + 1) + r] = comp(x, e);
       }
     } else {
 #pragma unroll
@@ -152,36 +158,33 @@ struct StageBF16 {
   float4 v[8];
 
   template <int MODE>
-  __device__ __forceinline__ void load(const GemmOperand &s, long long boff, int r0, int k0, int K) {
+  __device__ __forceinline__ void load(const GemmOperand &s, int r0, int k0, int K) {
     const int t = threadIdx.x;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float *base = s.p + boff + (long long)r0 * s.sr + (long long)k0 * s.sk;
-    const int Rl = s.R - r0, Kl = K - k0;
     if (MODE == STAGE_VEC_RC) {  // one (k group, 4 rows) item per thread: 8 loads, each coalesced over the wave
-      const int g = t / (TR / 4), r = 4 * (t % (TR / 4));
+      const int g = t / (TR / 4), r = r0 + 4 * (t % (TR / 4));
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const int k = 8 * g + e;
-        v[e] = (g < G && r < Rl && k < Kl) ? ld4(base + (unsigned)(k * s.sk + r)) : zero;
+        const int k = k0 + 8 * g + e;
+        v[e] = (g < G && r < s.R && k < K) ? ld4(s.p + gemm_off(s, r, k)) : zero;
       }
-    } else if (MODE == STAGE_VEC_KC) {  // (row, k group) items: 32 contiguous bytes each, 8 lanes cover a 256-byte run of a row
+    } else if (MODE == STAGE_VEC_KC) {  // (row, k group) items: 32 contiguous bytes, 8 lanes cover 256 bytes of a row
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        const int idx = q * 256 + t, g = idx % G, r = idx / G, k = 8 * g;
-        const bool ok = idx < TR * G && r < Rl;
-        const float *src = base + (unsigned)(r * s.sr + k);
-        v[2 * q] = (ok && k < Kl) ? ld4(src) : zero;
-        v[2 * q + 1] = (ok && k + 4 < Kl) ? ld4(src + 4) : zero;
+        const int idx = q * 256 + t, g = idx % G, r = r0 + idx / G, k = k0 + 8 * g;
+        const bool ok = idx < TR * G && r < s.R;
+        v[2 * q] = (ok && k < K) ? ld4(s.p + gemm_off(s, r, k)) : zero;
+        v[2 * q + 1] = (ok && k + 4 < K) ? ld4(s.p + gemm_off(s, r, k + 4)) : zero;
       }
     } else {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int idx = q * 256 + t;
-        const int g = s.rc ? idx / TR : idx % G, r = s.rc ? idx % TR : idx / G;
+        const int g = s.rc ? idx / TR : idx % G, r = r0 + (s.rc ? idx % TR : idx / G);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int k = 8 * g + e;
-          comp(v[2 * q + e / 4], e % 4) = (idx < TR * G && r < Rl && k < Kl) ? gemm_fetch(s, base, r, k) : 0.f;
+          const int k = k0 + 8 * g + e;
+          comp(v[2 * q + e / 4], e % 4) = (idx < TR * G && r < s.R && k < K) ? s.p[gemm_off(s, r, k)] : 0.f;
         }
       }
     }
@@ -252,23 +255,19 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[SA::kLdsBytes + SB::kLdsBytes];
   unsigned char *ldsA = lds, *ldsB = lds + SA::kLdsBytes;
 
-  // tile / batch / slice of this workgroup
+  // tile / K slice of this workgroup
   int bid = blockIdx.x;
   const int tj = bid % a.tiles_j;
   bid /= a.tiles_j;
   const int ti = bid % a.tiles_i;
-  const int z = bid / a.tiles_i;  // batch (split == 0) or K slice (split == 1)
+  const int z = bid / a.tiles_i;  // K slice
   const int i0 = ti * TI, j0 = tj * TJ;
-  const int cpb = (a.K + KC - 1) / KC;  // chunks per batch
-  int g0, g1;
-  if (a.split) {
+  const int chunks = (a.K + KC - 1) / KC;
+  int g0 = 0, g1 = chunks;
+  if (a.nsplit > 1) {
     g0 = z * a.chunks_per_split;
     g1 = g0 + a.chunks_per_split;
-    const int total = cpb * a.nb;
-    if (g1 > total) g1 = total;
-  } else {
-    g0 = z * cpb;
-    g1 = g0 + cpb;
+    if (g1 > chunks) g1 = chunks;
   }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -286,9 +285,8 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
   typename SA::type sa;
   typename SB::type sb;
   if (g0 < g1) {
-    const int b = g0 / cpb, k0 = (g0 - b * cpb) * KC;
-    sa.template load<AM>(a.A, (long long)b * a.A.sb, i0, k0, a.K);
-    sb.template load<BM>(a.B, (long long)b * a.B.sb, j0, k0, a.K);
+    sa.template load<AM>(a.A, i0, g0 * KC, a.K);
+    sb.template load<BM>(a.B, j0, g0 * KC, a.K);
   }
   for (int g = g0; g < g1; ++g) {
     __syncthreads();  // the previous chunk has been multiplied out of LDS
@@ -301,9 +299,8 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
     }
     __syncthreads();
     if (g + 1 < g1) {  // next chunk's loads stay in flight while this one is multiplied
-      const int b = (g + 1) / cpb, k0 = (g + 1 - b * cpb) * KC;
-      sa.template load<AM>(a.A, (long long)b * a.A.sb, i0, k0, a.K);
-      sb.template load<BM>(a.B, (long long)b * a.B.sb, j0, k0, a.K);
+      sa.template load<AM>(a.A, i0, (g + 1) * KC, a.K);
+      sb.template load<BM>(a.B, j0, (g + 1) * KC, a.K);
     }
     if constexpr (PREC == PREC_F32) {
       const float *TA = reinterpret_cast<const float *>(ldsA), *TB = reinterpret_cast<const float *>(ldsB);
@@ -342,44 +339,67 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
 
   // D: a lane holds column j = lane & 31 and rows (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) of each 32x32 block
   const int I = a.A.R, J = a.B.R;
-  float *D = a.D + (a.split ? (long long)z * I * J : (long long)z * a.d_sb);
-  const long long si = a.split ? J : a.d_si, sj = a.split ? 1 : a.d_sj;
+  const bool part = a.nsplit > 1;
+  float *D = a.D + (part ? (long long)z * I * J : 0);
+  const long long si = part ? J : a.d_si, sj = part ? 1 : a.d_sj;
 #pragma unroll
   for (int x = 0; x < WI; ++x)
 #pragma unroll
     for (int y = 0; y < WJ; ++y) {
       const int j = j0 + wj0 + 32 * y + lr;
+      long long joff = j * sj;
+      if (!part && a.d_fold_n) {
+        const int b = j / a.d_fold_n;
+        joff = b * a.d_sb + (j - b * a.d_fold_n) * sj;
+      }
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = i0 + wi0 + 32 * x + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (i < I && j < J) D[i * si + j * sj] = acc[x][y][e];
+        if (i < I && j < J) D[i * si + joff] = acc[x][y][e];
       }
     }
 }
 
-// ---- slice-ordered sum of the split-K partials; MODE 1 also turns d wcat [2Co, C] (+ d W_r) into d W [Co, 3+2C] --
+// ---- slice-ordered sum of the split-K partials.  A workgroup owns 64 consecutive output elements; its four waves
+// take the slices s = w, w+4, w+8, ... (coalesced 256-byte rows), and the four sub-sums are added in wave order:
+// the summation order depends on nsplit only.  MODE 1 also turns d wcat [2Co, C] (+ d W_r) into d W [Co, 3+2C].
 template <int MODE>
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ part, int nsplit, int IJ,
                                                           float *__restrict__ out, const float *__restrict__ dwr,
                                                           int Co, int C) {
-  for (int e = blockIdx.x * 256 + threadIdx.x; e < IJ; e += gridDim.x * 256) {
-    if (MODE == 0) {
-      float s = 0.f;
-      for (int p = 0; p < nsplit; ++p) s += part[(size_t)p * IJ + e];
-      out[e] = s;
-    } else {  // e = (o, c) over [Co, C]: top = d wcat[o][c], bot = d wcat[Co + o][c]
-      if (e >= Co * C) continue;
-      const int o = e / C, c = e - o * C;
-      float top = 0.f, bot = 0.f;
-      for (int p = 0; p < nsplit; ++p) {
-        top += part[(size_t)p * IJ + (size_t)o * C + c];
-        bot += part[(size_t)p * IJ + (size_t)(Co + o) * C + c];
+  __shared__ float s_sum[2][4][64];
+  const int el = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n_el = MODE == 0 ? IJ : Co * C;
+  for (int e0 = blockIdx.x * 64; e0 < n_el; e0 += gridDim.x * 64) {
+    const int e = e0 + el;
+    float top = 0.f, bot = 0.f;
+    if (e < n_el) {
+      if (MODE == 0) {
+        for (int p = w; p < nsplit; p += 4) top += part[(size_t)p * IJ + e];
+      } else {  // e = (o, c) over [Co, C]: top = d wcat[o][c], bot = d wcat[Co + o][c]
+        for (int p = w; p < nsplit; p += 4) {
+          top += part[(size_t)p * IJ + e];
+          bot += part[(size_t)p * IJ + (size_t)Co * C + e];
+        }
       }
-      const int ld = 3 + 2 * C;
-      out[(size_t)o * ld + 3 + c] = bot;            // d W_c
-      out[(size_t)o * ld + 3 + C + c] = top - bot;  // d W_d
-      if (c < 3) out[(size_t)o * ld + c] = dwr ? dwr[o * 3 + c] : 0.f;
     }
+    s_sum[0][w][el] = top;
+    s_sum[1][w][el] = bot;
+    __syncthreads();
+    if (w == 0 && e < n_el) {
+      top = ((s_sum[0][0][el] + s_sum[0][1][el]) + s_sum[0][2][el]) + s_sum[0][3][el];
+      if (MODE == 0) {
+        out[e] = top;
+      } else {
+        bot = ((s_sum[1][0][el] + s_sum[1][1][el]) + s_sum[1][2][el]) + s_sum[1][3][el];
+        const int o = e / C, c = e - o * C;
+        const int ld = 3 + 2 * C;
+        out[(size_t)o * ld + 3 + c] = bot;            // d W_c
+        out[(size_t)o * ld + 3 + C + c] = top - bot;  // d W_d
+        if (c < 3) out[(size_t)o * ld + c] = dwr ? dwr[o * 3 + c] : 0.f;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -404,12 +424,27 @@ __global__ __launch_bounds__(256) void pwmlp_weights_kernel(const float *__restr
 // ---- host side -------------------------------------------------------------------------------------------------
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-static GemmOperand plain(const float *p, long long sr, long long sk, long long sb, int R, int K) {
+// operand whose r and k are plain strided axes
+static GemmOperand plain(const float *p, long long sr, long long sk, int R, int K) {
   GemmOperand s{};
-  s.p = p; s.sr = (int)sr; s.sk = (int)sk; s.sb = sb; s.R = R;
+  s.p = p; s.sr = (int)sr; s.sk = (int)sk; s.R = R;
   s.rc = (sr == 1) ? 1 : 0;
-  if (s.rc) s.vec = aligned16(p) && R % 4 == 0 && sk % 4 == 0 && sb % 4 == 0;
-  else s.vec = aligned16(p) && K % 4 == 0 && sr % 4 == 0 && sb % 4 == 0;
+  if (s.rc) s.vec = aligned16(p) && R % 4 == 0 && sk % 4 == 0;
+  else s.vec = aligned16(p) && K % 4 == 0 && sr % 4 == 0;
+  return s;
+}
+
+// channel-major tensor [nb, rows, n]: `point_on_r` puts the folded (cloud, point) axis on r and the rows on k, or
+// the other way round
+static GemmOperand channel_major(const float *p, int nb, int rows, int n, bool point_on_r) {
+  GemmOperand s{};
+  s.p = p; s.fold_n = n; s.sb = (long long)rows * n;
+  if (point_on_r) {
+    s.sr = 1; s.sk = n; s.R = nb * n; s.rc = 1; s.fold = nb > 1 ? 1 : 0;
+  } else {
+    s.sr = n; s.sk = 1; s.R = rows; s.rc = 0; s.fold = nb > 1 ? 2 : 0;
+  }
+  s.vec = aligned16(p) && n % 4 == 0;
   return s;
 }
 
@@ -419,7 +454,8 @@ template <int PREC, int AM, int BM>
 static void launch_shape(const GemmArgs &a, int wi, int wj, int blocks, hipStream_t st) {
   if (wi == 2 && wj == 2) hipLaunchKernelGGL((mfma_gemm_kernel<PREC, 2, 2, AM, BM>), dim3(blocks), dim3(256), 0, st, a);
   else if (wi == 2) hipLaunchKernelGGL((mfma_gemm_kernel<PREC, 2, 1, AM, BM>), dim3(blocks), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((mfma_gemm_kernel<PREC, 1, 2, AM, BM>), dim3(blocks), dim3(256), 0, st, a);
+  else if (wj == 2) hipLaunchKernelGGL((mfma_gemm_kernel<PREC, 1, 2, AM, BM>), dim3(blocks), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((mfma_gemm_kernel<PREC, 1, 1, AM, BM>), dim3(blocks), dim3(256), 0, st, a);
 }
 
 // the operand-mode pairs the entry points below produce (anything else, e.g. N % 4 != 0, takes the scalar pair)
@@ -437,26 +473,52 @@ static void launch_modes(GemmArgs &a, int wi, int wj, int blocks, hipStream_t st
   launch_shape<PREC, STAGE_SCALAR, STAGE_SCALAR>(a, wi, wj, blocks, st);
 }
 
-// number of K slices of a weight-gradient contraction over nb batches of K points each
-static int wgrad_slices(int nb, int K, int kc, int tiles, int *chunks_per_split) {
-  const long long total = (long long)nb * ceil_div(K, kc);
-  long long want = 1024 / (tiles > 0 ? tiles : 1);  // ~4 workgroups per CU over all output tiles
+constexpr int kCUs = 256;
+
+// Workgroup tile for an I x J output (x nsplit K slices).  A workgroup's four waves sit on the four SIMDs of a CU,
+// so a CU works through its workgroups' MFMA chains one after the other: time ~ rounds x (accumulators per wave),
+// rounds = workgroups / CUs.  Fractional rounds below one count as one (the chain is serial per wave); ties go to
+// the larger tile (fewer re-staged operand bytes).
+static void pick_tile(int I, int J, int nsplit, int *wi_out, int *wj_out) {
+  const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  double best = 1e300;
+  for (int c = 0; c < 4; ++c) {
+    const int wi = cand[c][0], wj = cand[c][1];
+    const long long blocks = (long long)ceil_div(I, 64 * wi) * ceil_div(J, 64 * wj) * (nsplit > 1 ? nsplit : 1);
+    double rounds = (double)blocks / kCUs;
+    if (rounds < 1.0) rounds = 1.0;
+    const double cost = rounds * wi * wj;
+    if (cost < best * 0.97) {
+      best = cost;
+      *wi_out = wi;
+      *wj_out = wj;
+    }
+  }
+}
+
+static int kc_of(int precision) { return precision == PREC_BF16 ? 64 : 32; }
+
+// K slices of a weight-gradient contraction: about one workgroup per CU over all output tiles, at least 8 chunks per
+// slice so that a partial tile is written once per >= 256 points
+static int wgrad_slices(long long K, int kc, int I, int J, int *chunks_per_split) {
+  const long long total = (K + kc - 1) / kc;
+  const int tiles = ceil_div(I, 128) * ceil_div(J, 64);  // the 128 x 64 tile, as run_gemm picks for small outputs
+  long long want = kCUs / (tiles > 0 ? tiles : 1);
   if (want < 1) want = 1;
   long long cps = (total + want - 1) / want;
-  if (cps < 4) cps = 4;  // at least 4 chunks per slice: the partial tile is written once per slice
-  if (cps > total) cps = total;
+  if (cps < 8) cps = 8;
+  if (cps > total) cps = total > 0 ? total : 1;
   *chunks_per_split = (int)cps;
   return (int)((total + cps - 1) / cps);
 }
 
-static int run_gemm(GemmArgs &a, int precision, bool split, hipStream_t st, const char *who) {
+static int run_gemm(GemmArgs &a, int precision, hipStream_t st, const char *who) {
   const int I = a.A.R, J = a.B.R;
-  int wi = I > 64 ? 2 : 1, wj = J > 64 ? 2 : 1;
-  if (wi == 1 && wj == 1) wi = 2;  // no 64 x 64 workgroup tile: small outputs ride in the 128 x 64 one
+  int wi = 2, wj = 2;
+  pick_tile(I, J, a.nsplit, &wi, &wj);
   a.tiles_i = ceil_div(I, 64 * wi);
   a.tiles_j = ceil_div(J, 64 * wj);
-  a.split = split ? 1 : 0;
-  const long long blocks = (long long)a.tiles_i * a.tiles_j * (split ? a.nsplit : a.nb);
+  const long long blocks = (long long)a.tiles_i * a.tiles_j * (a.nsplit > 1 ? a.nsplit : 1);
   if (blocks > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "%s: grid too large", who);
   if (blocks == 0) return CL3D_OK;
   if (precision == PREC_BF16) launch_modes<PREC_BF16>(a, wi, wj, (int)blocks, st);
@@ -469,24 +531,37 @@ static int round_up_grid(int n) {
   return g < 1 ? 1 : (g > 2048 ? 2048 : g);
 }
 
-static int kc_of(int precision) { return precision == PREC_BF16 ? 64 : 32; }
-
-static int out_tiles(int I, int J) {
-  int wi = I > 64 ? 2 : 1, wj = J > 64 ? 2 : 1;
-  if (wi == 1 && wj == 1) wi = 2;
-  return ceil_div(I, 64 * wi) * ceil_div(J, 64 * wj);
-}
-
 size_t gemm_wgrad_workspace(int nb, int K, int I, int J) {
   size_t worst = 0;
   for (int prec = 0; prec < 2; ++prec) {
     int cps = 0;
-    const int tiles = out_tiles(I, J);
-    const int ns = wgrad_slices(nb, K, kc_of(prec), tiles, &cps);
+    const int ns = wgrad_slices((long long)nb * K, kc_of(prec), I, J, &cps);
     const size_t bytes = (size_t)ns * I * J * sizeof(float);
     worst = bytes > worst ? bytes : worst;
   }
   return worst;
+}
+
+// weight gradient D[I][J] = sum over all nb*K points: slices to scratch, then the ordered reduce
+template <int MODE>
+static int run_wgrad(GemmArgs &a, int precision, int nb, int K, void *ws, size_t ws_bytes, float *out, const float *dwr,
+                     int Co, int C, hipStream_t st, const char *who) {
+  const int I = a.A.R, J = a.B.R;
+  const size_t need = gemm_wgrad_workspace(nb, K, I, J);
+  if (!ws || ws_bytes < need) return fail(CL3D_E_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, need);
+  a.K = nb * K;
+  a.nsplit = wgrad_slices((long long)nb * K, kc_of(precision), I, J, &a.chunks_per_split);
+  float *partial = static_cast<float *>(ws);
+  if (a.nsplit == 1) a.nsplit = 0;  // one slice: the "partial" is the result, still through the reduce for MODE 1
+  a.D = partial; a.d_si = J; a.d_sj = 1; a.d_fold_n = 0;
+  int rc = run_gemm(a, precision, st, who);
+  if (rc != CL3D_OK) return rc;
+  const int n_el = MODE == 0 ? I * J : Co * C;
+  int grid = ceil_div(n_el, 64);
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL((gemm_reduce_kernel<MODE>), dim3(grid), dim3(256), 0, st, partial, a.nsplit > 1 ? a.nsplit : 1, I * J,
+                     out, dwr, Co, C);
+  return check_launch(who);
 }
 
 }  // namespace cl3d
@@ -496,8 +571,8 @@ using namespace cl3d;
 #define GEMM_COMMON_CHECKS(who)                                                                       \
   CL3D_REQUIRE(B >= 0 && C >= 1 && N >= 1 && Co >= 1, who ": bad sizes");                            \
   CL3D_REQUIRE(precision == 0 || precision == 1, who ": precision must be 0 (f32) or 1 (bf16)");      \
-  if ((long long)B * N * (long long)(2 * Co > C ? 2 * Co : C) > 0x7fffffffffLL)                       \
-    return fail(CL3D_E_UNSUPPORTED, who ": tensor too large");
+  if ((long long)B * N * (long long)(2 * Co > C ? 2 * Co : C) > 0x7fffffffLL)                         \
+    return fail(CL3D_E_UNSUPPORTED, who ": tensor too large (32-bit element offsets)");
 
 extern "C" int cl3d_pwmlp_point_gemm_fwd(const float *features, const float *W, int B, int C, int N, int Co,
                                          int precision, float *ght, float *wr, float *wcat, cl3d_stream_t stream) {
@@ -507,12 +582,12 @@ extern "C" int cl3d_pwmlp_point_gemm_fwd(const float *features, const float *W, 
   hipLaunchKernelGGL(pwmlp_weights_kernel, dim3(round_up_grid(Co * (3 + 2 * C))), dim3(256), 0, st, W, Co, C, wr, wcat);
   const int rc = check_launch("cl3d_pwmlp_point_gemm_fwd(weights)");
   if (rc != CL3D_OK || B == 0) return rc;
-  GemmArgs a{};  // D[i = point][j = o] = sum_c F[c][point] wcat[o][c]  ->  ght [B, N, 2Co]
-  a.A = plain(features, 1, N, (long long)C * N, N, C);
-  a.B = plain(wcat, C, 1, 0, 2 * Co, C);
-  a.D = ght; a.d_si = 2 * Co; a.d_sj = 1; a.d_sb = (long long)N * 2 * Co;
-  a.K = C; a.nb = B;
-  return run_gemm(a, precision, false, st, "cl3d_pwmlp_point_gemm_fwd");
+  GemmArgs a{};  // D[i = (cloud, point)][j = o] = sum_c F[c][point] wcat[o][c]  ->  ght [B*N, 2Co]
+  a.A = channel_major(features, B, C, N, true);
+  a.B = plain(wcat, C, 1, 2 * Co, C);
+  a.D = ght; a.d_si = 2 * Co; a.d_sj = 1;
+  a.K = C;
+  return run_gemm(a, precision, st, "cl3d_pwmlp_point_gemm_fwd");
 }
 
 extern "C" int cl3d_pwmlp_point_gemm_bwd_data(const float *dght, const float *wcat, int B, int C, int N, int Co,
@@ -520,12 +595,12 @@ extern "C" int cl3d_pwmlp_point_gemm_bwd_data(const float *dght, const float *wc
   GEMM_COMMON_CHECKS("pwmlp_point_gemm_bwd_data");
   CL3D_REQUIRE(wcat && (B == 0 || (dght && dfeatures)), "pwmlp_point_gemm_bwd_data: null pointer");
   if (B == 0) return CL3D_OK;
-  GemmArgs a{};  // D[i = c][j = point] = sum_o wcat[o][c] dght[point][o]  ->  d features [B, C, N]
-  a.A = plain(wcat, 1, C, 0, C, 2 * Co);
-  a.B = plain(dght, 2 * Co, 1, (long long)N * 2 * Co, N, 2 * Co);
-  a.D = dfeatures; a.d_si = N; a.d_sj = 1; a.d_sb = (long long)C * N;
-  a.K = 2 * Co; a.nb = B;
-  return run_gemm(a, precision, false, (hipStream_t)stream, "cl3d_pwmlp_point_gemm_bwd_data");
+  GemmArgs a{};  // D[i = c][j = (cloud, point)] = sum_o wcat[o][c] dght[point][o]  ->  d features [B, C, N]
+  a.A = plain(wcat, 1, C, C, 2 * Co);
+  a.B = plain(dght, 2 * Co, 1, B * N, 2 * Co);
+  a.D = dfeatures; a.d_si = N; a.d_sj = 1; a.d_fold_n = B > 1 ? N : 0; a.d_sb = (long long)C * N;
+  a.K = 2 * Co;
+  return run_gemm(a, precision, (hipStream_t)stream, "cl3d_pwmlp_point_gemm_bwd_data");
 }
 
 extern "C" int cl3d_pwmlp_point_gemm_bwd_weight(const float *features, const float *dght, const float *dwr, int B,
@@ -533,21 +608,11 @@ extern "C" int cl3d_pwmlp_point_gemm_bwd_weight(const float *features, const flo
                                                 size_t ws_bytes, cl3d_stream_t stream) {
   GEMM_COMMON_CHECKS("pwmlp_point_gemm_bwd_weight");
   CL3D_REQUIRE(B >= 1 && features && dght && dW, "pwmlp_point_gemm_bwd_weight: null pointer");
-  const size_t need = gemm_wgrad_workspace(B, N, 2 * Co, C);
-  if (!ws || ws_bytes < need) return fail(CL3D_E_WORKSPACE, "pwmlp_point_gemm_bwd_weight: workspace %zu < %zu", ws_bytes, need);
-  hipStream_t st = (hipStream_t)stream;
-  GemmArgs a{};  // D[i = o][j = c] = sum_(b, point) dght[point][o] F[c][point]  ->  d wcat [2Co, C] per slice
-  a.A = plain(dght, 1, 2 * Co, (long long)N * 2 * Co, 2 * Co, N);
-  a.B = plain(features, N, 1, (long long)C * N, C, N);
-  a.D = static_cast<float *>(ws);
-  a.K = N; a.nb = B;
-  const int tiles = out_tiles(2 * Co, C);
-  a.nsplit = wgrad_slices(B, N, kc_of(precision), tiles, &a.chunks_per_split);
-  int rc = run_gemm(a, precision, true, st, "cl3d_pwmlp_point_gemm_bwd_weight");
-  if (rc != CL3D_OK) return rc;
-  hipLaunchKernelGGL((gemm_reduce_kernel<1>), dim3(round_up_grid(Co * C)), dim3(256), 0, st, static_cast<const float *>(ws),
-                     a.nsplit, 2 * Co * C, dW, dwr, Co, C);
-  return check_launch("cl3d_pwmlp_point_gemm_bwd_weight(reduce)");
+  GemmArgs a{};  // D[i = o][j = c] = sum_(cloud, point) dght[point][o] F[c][point]  ->  d wcat [2Co, C] per slice
+  a.A = plain(dght, 1, 2 * Co, 2 * Co, B * N);
+  a.B = channel_major(features, B, C, N, false);
+  return run_wgrad<1>(a, precision, B, N, ws, ws_bytes, dW, dwr, Co, C, (hipStream_t)stream,
+                      "cl3d_pwmlp_point_gemm_bwd_weight");
 }
 
 // ---- the 1x1 Conv1d layers around the operator (backbones/resnet.py:32-39,58-66), channel-major in and out ---------
@@ -556,12 +621,12 @@ extern "C" int cl3d_conv1x1_fwd(const float *x, const float *W, int B, int C, in
   GEMM_COMMON_CHECKS("conv1x1_fwd");
   CL3D_REQUIRE(W && (B == 0 || (x && y)), "conv1x1_fwd: null pointer");
   if (B == 0) return CL3D_OK;
-  GemmArgs a{};  // D[i = o][j = point] = sum_c W[o][c] x[c][point]
-  a.A = plain(W, C, 1, 0, Co, C);
-  a.B = plain(x, 1, N, (long long)C * N, N, C);
-  a.D = y; a.d_si = N; a.d_sj = 1; a.d_sb = (long long)Co * N;
-  a.K = C; a.nb = B;
-  return run_gemm(a, precision, false, (hipStream_t)stream, "cl3d_conv1x1_fwd");
+  GemmArgs a{};  // D[i = o][j = (cloud, point)] = sum_c W[o][c] x[c][point]
+  a.A = plain(W, C, 1, Co, C);
+  a.B = channel_major(x, B, C, N, true);
+  a.D = y; a.d_si = N; a.d_sj = 1; a.d_fold_n = B > 1 ? N : 0; a.d_sb = (long long)Co * N;
+  a.K = C;
+  return run_gemm(a, precision, (hipStream_t)stream, "cl3d_conv1x1_fwd");
 }
 
 extern "C" int cl3d_conv1x1_bwd_data(const float *dy, const float *W, int B, int C, int N, int Co, int precision,
@@ -569,31 +634,20 @@ extern "C" int cl3d_conv1x1_bwd_data(const float *dy, const float *W, int B, int
   GEMM_COMMON_CHECKS("conv1x1_bwd_data");
   CL3D_REQUIRE(W && (B == 0 || (dy && dx)), "conv1x1_bwd_data: null pointer");
   if (B == 0) return CL3D_OK;
-  GemmArgs a{};  // D[i = c][j = point] = sum_o W[o][c] dy[o][point]
-  a.A = plain(W, 1, C, 0, C, Co);
-  a.B = plain(dy, 1, N, (long long)Co * N, N, Co);
-  a.D = dx; a.d_si = N; a.d_sj = 1; a.d_sb = (long long)C * N;
-  a.K = Co; a.nb = B;
-  return run_gemm(a, precision, false, (hipStream_t)stream, "cl3d_conv1x1_bwd_data");
+  GemmArgs a{};  // D[i = c][j = (cloud, point)] = sum_o W[o][c] dy[o][point]
+  a.A = plain(W, 1, C, C, Co);
+  a.B = channel_major(dy, B, Co, N, true);
+  a.D = dx; a.d_si = N; a.d_sj = 1; a.d_fold_n = B > 1 ? N : 0; a.d_sb = (long long)C * N;
+  a.K = Co;
+  return run_gemm(a, precision, (hipStream_t)stream, "cl3d_conv1x1_bwd_data");
 }
 
 extern "C" int cl3d_conv1x1_bwd_weight(const float *x, const float *dy, int B, int C, int N, int Co, int precision,
                                        float *dW, void *ws, size_t ws_bytes, cl3d_stream_t stream) {
   GEMM_COMMON_CHECKS("conv1x1_bwd_weight");
   CL3D_REQUIRE(B >= 1 && x && dy && dW, "conv1x1_bwd_weight: null pointer");
-  const size_t need = gemm_wgrad_workspace(B, N, Co, C);
-  if (!ws || ws_bytes < need) return fail(CL3D_E_WORKSPACE, "conv1x1_bwd_weight: workspace %zu < %zu", ws_bytes, need);
-  hipStream_t st = (hipStream_t)stream;
-  GemmArgs a{};  // D[i = o][j = c] = sum_(b, point) dy[o][point] x[c][point]
-  a.A = plain(dy, N, 1, (long long)Co * N, Co, N);
-  a.B = plain(x, N, 1, (long long)C * N, C, N);
-  a.D = static_cast<float *>(ws);
-  a.K = N; a.nb = B;
-  const int tiles = out_tiles(Co, C);
-  a.nsplit = wgrad_slices(B, N, kc_of(precision), tiles, &a.chunks_per_split);
-  int rc = run_gemm(a, precision, true, st, "cl3d_conv1x1_bwd_weight");
-  if (rc != CL3D_OK) return rc;
-  hipLaunchKernelGGL((gemm_reduce_kernel<0>), dim3(round_up_grid(Co * C)), dim3(256), 0, st, static_cast<const float *>(ws),
-                     a.nsplit, Co * C, dW, nullptr, Co, C);
-  return check_launch("cl3d_conv1x1_bwd_weight(reduce)");
+  GemmArgs a{};  // D[i = o][j = c] = sum_(cloud, point) dy[o][point] x[c][point]
+  a.A = channel_major(dy, B, Co, N, false);
+  a.B = channel_major(x, B, C, N, false);
+  return run_wgrad<0>(a, precision, B, N, ws, ws_bytes, dW, nullptr, Co, C, (hipStream_t)stream, "cl3d_conv1x1_bwd_weight");
 }

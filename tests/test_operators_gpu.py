@@ -274,10 +274,13 @@ def test_fused_max_pool_matches_reference_dataflow(C, K, N, npoint):
 
 @pytest.mark.parametrize("B,C,N,Co", [(4, 64, 512, 64), (3, 10, 77, 7), (8, 300, 40, 300), (16, 576, 32, 576),
                                       (2, 1152, 8, 1152)])   # the last one takes the 64 x 16 merge tiles
-def test_point_rows_weight_plumbing_matches_autograd(B, C, N, Co):
-    """The per-point GEMM of PointWiseMLP with its split / merge kernels (both the element-per-thread merge and
-    the tiled one used once the per-cloud products outgrow the L2s) against the same algebra in plain autograd."""
-    from closerlook3d_amd.fused import _PointRows
+@pytest.mark.parametrize("engine", ["mfma", "library"])
+def test_point_rows_weight_plumbing_matches_autograd(B, C, N, Co, engine):
+    """The per-point GEMM of PointWiseMLP -- the engine's MFMA kernel with its weight split / ordered partial reduce,
+    and the vendor-library variant kept for the A/B script with its split / merge kernels (both the element-per-thread
+    merge and the tiled one used once the per-cloud products outgrow the L2s) -- against the same algebra in plain
+    autograd."""
+    from closerlook3d_amd.fused import _PointRows, _PointRowsLibrary
     torch.manual_seed(C + Co)
     f = torch.randn(B, C, N, device="cuda")
     W = torch.randn(Co, 3 + 2 * C, device="cuda") / np.sqrt(C)
@@ -287,7 +290,7 @@ def test_point_rows_weight_plumbing_matches_autograd(B, C, N, Co):
     for mine in (True, False):
         fi, Wi = f.clone().requires_grad_(True), W.clone().requires_grad_(True)
         if mine:
-            rows, wr = _PointRows.apply(fi, Wi)
+            rows, wr = _PointRows.apply(fi, Wi, 0) if engine == "mfma" else _PointRowsLibrary.apply(fi, Wi)
         else:
             wr, wc, wd = Wi[:, :3], Wi[:, 3:3 + C], Wi[:, 3 + C:]
             rows = torch.einsum("bcn,oc->bno", fi, torch.cat([wd, wc - wd], 0))
