@@ -9,7 +9,7 @@ absent; the reference's own files run unchanged on this engine through `drop_in/
 import torch
 import torch.nn as nn
 
-from .local_aggregation_operators import LocalAggregation
+from .local_aggregation_operators import LocalAggregation, _cfg
 from . import pt_utils
 from .pt_utils import MaskedMaxPool, MaskedUpsample
 
@@ -19,6 +19,25 @@ def _conv_bn(cin, cout, momentum, relu):
     if relu:
         layers.append(nn.ReLU(inplace=True))
     return nn.Sequential(*layers)
+
+
+def run_conv_bn(seq, x, impl='auto', precision='f32', residual=None, shortcut=None):
+    """A `_conv_bn` unit (Conv1d + BatchNorm1d [+ ReLU]) -- optionally the tail of a bottleneck: + residual (through the
+    `shortcut` unit when given), then ReLU -- through the engine's kernels (fused.conv_bn_act: MFMA convolutions, fused
+    BatchNorm / add / ReLU passes, BatchNorm folded into the convolution in inference), or module by module as the
+    reference runs it when impl == 'grouped' or the configuration is outside what the kernels cover."""
+    relu = len(seq) == 3 or residual is not None
+    if impl != 'grouped' and x.is_cuda:
+        from . import fused
+        y = fused.conv_bn_act(x, seq[0], seq[1], relu=relu, residual=residual,
+                              res_conv=shortcut[0] if shortcut is not None else None,
+                              res_bn=shortcut[1] if shortcut is not None else None, precision=precision)
+        if y is not None:
+            return y
+    y = seq(x)
+    if residual is not None:
+        y = torch.relu(y + (shortcut(residual) if shortcut is not None else residual))
+    return y
 
 
 class MultiInputSequential(nn.Sequential):
@@ -33,6 +52,8 @@ class Bottleneck(nn.Module):
                  downsample=False, sampleDl=None, npoint=None):
         super().__init__()
         self.in_channels, self.out_channels, self.downsample = in_channels, out_channels, downsample
+        self.impl = _cfg(config, 'cl3d_impl', 'auto')
+        self.precision = _cfg(config, 'cl3d_precision', 'f32')
         mid = out_channels // bottleneck_ratio
         if downsample:
             self.maxpool = MaskedMaxPool(npoint, radius, nsample, sampleDl)
@@ -48,12 +69,13 @@ class Bottleneck(nn.Module):
             query_xyz, query_mask, identity = self.maxpool(xyz, mask, features)
         else:
             query_xyz, query_mask, identity = xyz, mask, features
-        out = self.conv1(features)
+        # the whole bottleneck on the engine -- conv1+BN+ReLU, the operator, then conv2 + BN +
+        # shortcut (+ its conv and BN) + add + ReLU as MFMA convolutions and fused BatchNorm passes
+        out = run_conv_bn(self.conv1, features, self.impl, self.precision)
         out = self.local_aggregation(query_xyz, xyz, query_mask, mask, out)
-        out = self.conv2(out)
-        if self.in_channels != self.out_channels:
-            identity = self.shortcut(identity)
-        return query_xyz, query_mask, self.relu(out + identity)
+        out = run_conv_bn(self.conv2, out, self.impl, self.precision, residual=identity,
+                          shortcut=self.shortcut if self.in_channels != self.out_channels else None)
+        return query_xyz, query_mask, out
 
 
 class ResNet(nn.Module):
@@ -61,6 +83,8 @@ class ResNet(nn.Module):
                  width=144, depth=2, bottleneck_ratio=2):
         super().__init__()
         self.input_features_dim = input_features_dim
+        self.impl = _cfg(config, 'cl3d_impl', 'auto')
+        self.precision = _cfg(config, 'cl3d_precision', 'f32')
         self._geometry = (radius, sampleDl, list(nsamples), list(npoints), depth > 1)
         self.conv1 = _conv_bn(input_features_dim, width // 2, config.bn_momentum, relu=True)
         self.la1 = LocalAggregation(width // 2, width // 2, radius, nsamples[0], config)
@@ -85,7 +109,7 @@ class ResNet(nn.Module):
         # coordinates-only products (subsampled clouds, ball queries) go ahead on the index stream
         pt_utils.prefetch_geometry(xyz, mask, *self._geometry)
         device = xyz.device
-        features = self.conv1(features)
+        features = run_conv_bn(self.conv1, features, self.impl, self.precision)
         features = self.la1(xyz, xyz, mask, mask, features)
         xyz, mask, features = self.btnk1(xyz, mask, features)
         end_points['res1_xyz'], end_points['res1_mask'], end_points['res1_features'] = xyz, mask, features
@@ -118,7 +142,7 @@ class _UpsampleDecoder(nn.Module):
             feats = getattr(self, f"up{lvl}")(end_points[f'res{fine}_xyz'], end_points[f'res{coarse}_xyz'],
                                               end_points[f'res{fine}_mask'], end_points[f'res{coarse}_mask'], feats)
             feats = torch.cat([feats, end_points[f'res{fine}_features']], 1)
-            feats = getattr(self, f"up_conv{lvl}")(feats)
+            feats = run_conv_bn(getattr(self, f"up_conv{lvl}"), feats)
         return feats
 
 

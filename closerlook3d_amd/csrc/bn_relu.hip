@@ -177,6 +177,117 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(BnFinArgs a) {
   }
 }
 
+// ---- the tail of a bottleneck: out = ReLU(BN1(x1) + R),  R = 0 | x2 (identity shortcut) | BN2(x2) (conv shortcut)
+// (reference backbones/resnet.py:58-66: conv2's BatchNorm, the shortcut's BatchNorm, the add and the final ReLU --
+// four element-wise passes and two BatchNorm kernels in the reference, one streaming pass here), and its backward:
+// dz = g gated by the ReLU (mask read off the saved output), both BatchNorm backward reductions in ONE pass over
+// (g, out, x1, x2), then dx1 = A1 dz + B1 + D1 x1 and dx2 = A2 dz + B2 + D2 x2 (or dx2 = dz) in one more.
+struct Bn2Args {
+  const float *x1, *x2, *g, *out_ref;
+  const float *s1, *t1, *mu1, *is1, *s2, *t2, *mu2, *is2;
+  const float *c1, *c2;  // coefficient blocks [5,C]: A, Bc, D, d gamma, d beta
+  float *o1, *o2;
+  double *p1, *p2;       // [B*chunks, C, 2] each
+  int B, C, N, chunks, span;
+  int mode2;             // 0: no second branch, 1: identity, 2: affine (its own BatchNorm)
+  int relu;
+};
+
+__global__ __launch_bounds__(256) void bn2_apply_kernel(Bn2Args a) {
+  const long long rows = (long long)a.B * a.C;
+  const int per_row = (a.N + 1023) / 1024;
+  for (long long t = blockIdx.x; t < rows * per_row; t += gridDim.x) {
+    const long long r = t / per_row;
+    const int c = (int)(r % a.C);
+    const int n = (int)(t - r * per_row) * 1024 + 4 * (int)threadIdx.x;
+    const float s1 = a.s1[c], t1 = a.t1[c];
+    const float s2 = a.mode2 == 2 ? a.s2[c] : 1.f, t2 = a.mode2 == 2 ? a.t2[c] : 0.f;
+    const float *x1 = a.x1 + (size_t)r * a.N;
+    const float *x2 = a.mode2 ? a.x2 + (size_t)r * a.N : nullptr;
+    float *orow = a.o1 + (size_t)r * a.N;
+    auto f = [&](float u, float v) {
+      float z = __builtin_fmaf(u, s1, t1);
+      if (a.mode2 == 1) z += v;
+      else if (a.mode2 == 2) z += __builtin_fmaf(v, s2, t2);
+      return (a.relu && !(z > 0.f)) ? 0.f : z;
+    };
+    if ((a.N & 3) == 0) {
+      if (n < a.N) {
+        const float4 u = *reinterpret_cast<const float4 *>(x1 + n);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.mode2) v = *reinterpret_cast<const float4 *>(x2 + n);
+        *reinterpret_cast<float4 *>(orow + n) = make_float4(f(u.x, v.x), f(u.y, v.y), f(u.z, v.z), f(u.w, v.w));
+      }
+    } else {
+      for (int e = 0; e < 4; ++e)
+        if (n + e < a.N) orow[n + e] = f(x1[n + e], a.mode2 ? x2[n + e] : 0.f);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn2_bwd_stats_kernel(Bn2Args a) {
+  __shared__ double scratch[4];
+  const int c = blockIdx.x, part = blockIdx.y;
+  const int b = part / a.chunks, n0 = (part - b * a.chunks) * a.span;
+  const int n1 = n0 + a.span < a.N ? n0 + a.span : a.N;
+  const size_t row = ((size_t)b * a.C + c) * a.N;
+  const float *x1 = a.x1 + row, *g = a.g + row;
+  const float *x2 = a.mode2 == 2 ? a.x2 + row : nullptr;
+  const float *ref = a.relu ? a.out_ref + row : nullptr;
+  const float mu1 = a.mu1[c], is1 = a.is1[c];
+  const float mu2 = a.mode2 == 2 ? a.mu2[c] : 0.f, is2 = a.mode2 == 2 ? a.is2[c] : 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  double d0 = 0.0, d1 = 0.0, d2 = 0.0;
+  int it = 0;
+  for (int n = n0 + (int)threadIdx.x; n < n1; n += 256) {
+    const float dz = (a.relu && !(ref[n] > 0.f)) ? 0.f : g[n];
+    s0 += dz;
+    s1 = __builtin_fmaf(dz, (x1[n] - mu1) * is1, s1);
+    if (a.mode2 == 2) s2 = __builtin_fmaf(dz, (x2[n] - mu2) * is2, s2);
+    if (++it == 64) {
+      d0 += (double)s0; d1 += (double)s1; d2 += (double)s2; s0 = s1 = s2 = 0.f; it = 0;
+    }
+  }
+  d0 += (double)s0; d1 += (double)s1; d2 += (double)s2;
+  const double t0 = block_sum(d0, scratch);
+  const double t1 = block_sum(d1, scratch);
+  const double t2 = block_sum(d2, scratch);
+  if (threadIdx.x == 0) {
+    double *p = a.p1 + ((size_t)part * a.C + c) * 2;
+    p[0] = t0;
+    p[1] = t1;
+    if (a.mode2 == 2) {
+      double *q = a.p2 + ((size_t)part * a.C + c) * 2;
+      q[0] = t0;
+      q[1] = t2;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(Bn2Args a) {
+  const long long rows = (long long)a.B * a.C;
+  const int per_row = (a.N + 1023) / 1024;
+  for (long long t = blockIdx.x; t < rows * per_row; t += gridDim.x) {
+    const long long r = t / per_row;
+    const int c = (int)(r % a.C);
+    const int n = (int)(t - r * per_row) * 1024 + 4 * (int)threadIdx.x;
+    const float A1 = a.c1[c], B1 = a.c1[a.C + c], D1 = a.c1[2 * a.C + c];
+    float A2 = 1.f, B2 = 0.f, D2 = 0.f;
+    if (a.mode2 == 2) {
+      A2 = a.c2[c]; B2 = a.c2[a.C + c]; D2 = a.c2[2 * a.C + c];
+    }
+    const size_t row = (size_t)r * a.N;
+    for (int e = 0; e < 4; ++e) {
+      const int m = n + e;
+      if (m >= a.N) break;
+      const float dz = (a.relu && !(a.out_ref[row + m] > 0.f)) ? 0.f : a.g[row + m];
+      a.o1[row + m] = __builtin_fmaf(A1, dz, __builtin_fmaf(D1, a.x1[row + m], B1));
+      if (a.mode2 == 1) a.o2[row + m] = dz;
+      else if (a.mode2 == 2) a.o2[row + m] = __builtin_fmaf(A2, dz, __builtin_fmaf(D2, a.x2[row + m], B2));
+    }
+  }
+}
+
 static void bn_shape(BnArgs &a) {
   a.span = 16384;
   a.chunks = ceil_div(a.N, a.span);
@@ -245,4 +356,53 @@ extern "C" int cl3d_bn_relu_bwd(const float *g, const float *x, const float *sca
   hipLaunchKernelGGL((bn_apply_kernel<1>), dim3((unsigned)(work < 65536 ? work : 65536)), dim3(256), 0,
                      (hipStream_t)stream, a);
   return check_launch("cl3d_bn_relu_bwd");
+}
+
+extern "C" int cl3d_bn_add_relu_apply(const float *x1, const float *scale1, const float *shift1, const float *x2,
+                                      const float *scale2, const float *shift2, int relu, int B, int C, int N,
+                                      float *out, cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(B >= 0 && C >= 1 && N >= 0, "bn_add_relu_apply: bad sizes");
+  if (B == 0 || N == 0) return CL3D_OK;
+  CL3D_REQUIRE(x1 && scale1 && shift1 && out && (!scale2 || (x2 && shift2)), "bn_add_relu_apply: null pointer");
+  Bn2Args a{};
+  a.x1 = x1; a.s1 = scale1; a.t1 = shift1; a.x2 = x2; a.s2 = scale2; a.t2 = shift2; a.o1 = out;
+  a.B = B; a.C = C; a.N = N; a.relu = relu; a.mode2 = !x2 ? 0 : (scale2 ? 2 : 1);
+  const long long work = (long long)B * C * ceil_div(N, 1024);
+  hipLaunchKernelGGL(bn2_apply_kernel, dim3((unsigned)(work < 65536 ? work : 65536)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("cl3d_bn_add_relu_apply");
+}
+
+extern "C" int cl3d_bn_add_relu_bwd(const float *g, const float *out, const float *x1, const float *mean1,
+                                    const float *invstd1, const float *gamma1, const float *x2, const float *mean2,
+                                    const float *invstd2, const float *gamma2, int relu, int B, int C, int N,
+                                    double count, double *partial, int n_partials, float *coef1, float *coef2,
+                                    float *dx1, float *dx2, cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(B >= 1 && C >= 1 && N >= 1 && count > 0, "bn_add_relu_bwd: bad sizes");
+  CL3D_REQUIRE(g && x1 && mean1 && invstd1 && gamma1 && partial && coef1 && dx1 && (!relu || out), "bn_add_relu_bwd: null pointer");
+  CL3D_REQUIRE(!x2 || dx2, "bn_add_relu_bwd: second branch needs its gradient buffer");
+  CL3D_REQUIRE(!gamma2 || (x2 && mean2 && invstd2 && coef2), "bn_add_relu_bwd: second BatchNorm incomplete");
+  CL3D_REQUIRE(n_partials == cl3d_bn_partials(B, C, N) && n_partials <= 65535, "bn_add_relu_bwd: wrong partial count");
+  hipStream_t st = (hipStream_t)stream;
+  Bn2Args a{};
+  a.g = g; a.out_ref = out; a.x1 = x1; a.mu1 = mean1; a.is1 = invstd1; a.x2 = x2; a.mu2 = mean2; a.is2 = invstd2;
+  a.B = B; a.C = C; a.N = N; a.relu = relu; a.mode2 = !x2 ? 0 : (gamma2 ? 2 : 1);
+  a.p1 = partial; a.p2 = partial + (size_t)n_partials * C * 2;
+  a.span = 16384;
+  a.chunks = ceil_div(N, a.span);
+  hipLaunchKernelGGL(bn2_bwd_stats_kernel, dim3(C, n_partials), dim3(256), 0, st, a);
+  BnFinArgs f{};
+  f.partial = a.p1; f.G = n_partials; f.C = C; f.count = count; f.gamma = gamma1; f.mean_in = mean1; f.invstd_in = invstd1;
+  f.o0 = coef1; f.o1 = coef1 + C; f.o2 = coef1 + 2 * C; f.o3 = coef1 + 3 * C; f.o4 = coef1 + 4 * C;
+  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(C), dim3(64), 0, st, f);
+  if (a.mode2 == 2) {
+    f.partial = a.p2; f.gamma = gamma2; f.mean_in = mean2; f.invstd_in = invstd2;
+    f.o0 = coef2; f.o1 = coef2 + C; f.o2 = coef2 + 2 * C; f.o3 = coef2 + 3 * C; f.o4 = coef2 + 4 * C;
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(C), dim3(64), 0, st, f);
+  }
+  a.c1 = coef1; a.c2 = coef2; a.o1 = dx1; a.o2 = dx2;
+  const long long work = (long long)B * C * ceil_div(N, 1024);
+  hipLaunchKernelGGL(bn2_bwd_apply_kernel, dim3((unsigned)(work < 65536 ? work : 65536)), dim3(256), 0, st, a);
+  return check_launch("cl3d_bn_add_relu_bwd");
 }

@@ -33,6 +33,7 @@
 // The PointWiseMLP weight [Co, 3+2C] = [W_r | W_c | W_d] is turned into wcat = [W_d ; W_c - W_d] and W_r by one small
 // launch ahead of the forward GEMM (pwmlp_weights_kernel); the weight-gradient reduce writes d W directly.
 #include "cl3d_common.h"
+#include <stdlib.h>
 
 namespace cl3d {
 
@@ -62,6 +63,9 @@ struct GemmArgs {
   int K;               // contraction extent (clouds folded in for weight gradients)
   int nsplit, chunks_per_split;  // nsplit > 1: K cut into slices, slice s writes its partial tile to D + s*I*J
   int tiles_i, tiles_j;
+  // inference epilogue (BatchNorm folded to a per-row affine map, residual, ReLU): D = act(scale[i] * acc + shift[i] + res)
+  const float *ep_scale, *ep_shift, *ep_res;
+  int ep_relu;
 };
 
 // element offset of (r, k) of an operand; the pointer base is wave-uniform, the offset a 32-bit lane value
@@ -282,26 +286,22 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
 
-  typename SA::type sa;
-  typename SB::type sb;
-  if (g0 < g1) {
-    sa.template load<AM>(a.A, i0, g0 * KC, a.K);
-    sb.template load<BM>(a.B, j0, g0 * KC, a.K);
-  }
-  for (int g = g0; g < g1; ++g) {
-    __syncthreads();  // the previous chunk has been multiplied out of LDS
-    if constexpr (PREC == PREC_F32) {
-      sa.template store<AM>(a.A, reinterpret_cast<float *>(ldsA));
-      sb.template store<BM>(a.B, reinterpret_cast<float *>(ldsB));
+  // Two K chunks are kept in flight in registers (sets 0 and 1): a chunk is written to LDS two loop turns after its
+  // loads were issued, so the write never waits on HBM latency even with one wave per SIMD.
+  // (the widest register footprints -- bf16 at 128 x 128, the scalar fallback -- keep a single set)
+  constexpr int DEPTH = ((PREC == PREC_BF16 && WI * WJ == 4) || AM == STAGE_SCALAR) ? 1 : 2;
+  typename SA::type sa[DEPTH];
+  typename SB::type sb[DEPTH];
+  auto issue = [&](int set, int g) {
+    if (set == 0 || DEPTH == 1) {
+      sa[0].template load<AM>(a.A, i0, g * KC, a.K);
+      sb[0].template load<BM>(a.B, j0, g * KC, a.K);
     } else {
-      sa.template store<AM>(a.A, reinterpret_cast<uint4 *>(ldsA));
-      sb.template store<BM>(a.B, reinterpret_cast<uint4 *>(ldsB));
+      sa[DEPTH - 1].template load<AM>(a.A, i0, g * KC, a.K);
+      sb[DEPTH - 1].template load<BM>(a.B, j0, g * KC, a.K);
     }
-    __syncthreads();
-    if (g + 1 < g1) {  // next chunk's loads stay in flight while this one is multiplied
-      sa.template load<AM>(a.A, i0, (g + 1) * KC, a.K);
-      sb.template load<BM>(a.B, j0, (g + 1) * KC, a.K);
-    }
+  };
+  auto multiply = [&]() {
     if constexpr (PREC == PREC_F32) {
       const float *TA = reinterpret_cast<const float *>(ldsA), *TB = reinterpret_cast<const float *>(ldsB);
       const int strA = SA::type::stride(a.A), strB = SB::type::stride(a.B);
@@ -335,6 +335,47 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
                                                                 *reinterpret_cast<bf16x8 *>(&fb[y]), acc[x][y], 0, 0, 0);
       }
     }
+  };
+  auto to_lds = [&](int set) {
+    __syncthreads();  // the previous chunk has been multiplied out of LDS
+    if constexpr (PREC == PREC_F32) {
+      if (set == 0 || DEPTH == 1) {
+        sa[0].template store<AM>(a.A, reinterpret_cast<float *>(ldsA));
+        sb[0].template store<BM>(a.B, reinterpret_cast<float *>(ldsB));
+      } else {
+        sa[DEPTH - 1].template store<AM>(a.A, reinterpret_cast<float *>(ldsA));
+        sb[DEPTH - 1].template store<BM>(a.B, reinterpret_cast<float *>(ldsB));
+      }
+    } else {
+      if (set == 0 || DEPTH == 1) {
+        sa[0].template store<AM>(a.A, reinterpret_cast<uint4 *>(ldsA));
+        sb[0].template store<BM>(a.B, reinterpret_cast<uint4 *>(ldsB));
+      } else {
+        sa[DEPTH - 1].template store<AM>(a.A, reinterpret_cast<uint4 *>(ldsA));
+        sb[DEPTH - 1].template store<BM>(a.B, reinterpret_cast<uint4 *>(ldsB));
+      }
+    }
+    __syncthreads();
+  };
+  if (g0 < g1) issue(0, g0);
+  if constexpr (DEPTH == 2) {
+    if (g0 + 1 < g1) issue(1, g0 + 1);
+    for (int g = g0; g < g1; g += 2) {
+      to_lds(0);
+      if (g + 2 < g1) issue(0, g + 2);
+      multiply();
+      if (g + 1 < g1) {
+        to_lds(1);
+        if (g + 3 < g1) issue(1, g + 3);
+        multiply();
+      }
+    }
+  } else {
+    for (int g = g0; g < g1; ++g) {
+      to_lds(0);
+      if (g + 1 < g1) issue(0, g + 1);
+      multiply();
+    }
   }
 
   // D: a lane holds column j = lane & 31 and rows (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) of each 32x32 block
@@ -355,43 +396,55 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = i0 + wi0 + 32 * x + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (i < I && j < J) D[i * si + joff] = acc[x][y][e];
+        if (i < I && j < J) {
+          float v = acc[x][y][e];
+          if (a.ep_scale) v = __builtin_fmaf(v, a.ep_scale[i], a.ep_shift[i]);
+          if (a.ep_res) v += a.ep_res[i * si + joff];
+          if (a.ep_relu) v = v > 0.f ? v : 0.f;
+          D[i * si + joff] = v;
+        }
       }
     }
 }
 
-// ---- slice-ordered sum of the split-K partials.  A workgroup owns 64 consecutive output elements; its four waves
-// take the slices s = w, w+4, w+8, ... (coalesced 256-byte rows), and the four sub-sums are added in wave order:
-// the summation order depends on nsplit only.  MODE 1 also turns d wcat [2Co, C] (+ d W_r) into d W [Co, 3+2C].
+// ---- slice-ordered sum of the split-K partials.  A workgroup owns 16 consecutive output elements; its 16 thread
+// groups take the slices s = g, g+16, g+32, ... and the 16 sub-sums are added in group order through LDS: the
+// summation order depends on nsplit only (bit-reproducible), and 8 MB of partials are read by a few hundred
+// workgroups instead of a few dozen.  MODE 1 also turns d wcat [2Co, C] (+ d W_r) into d W [Co, 3+2C].
 template <int MODE>
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ part, int nsplit, int IJ,
                                                           float *__restrict__ out, const float *__restrict__ dwr,
                                                           int Co, int C) {
-  __shared__ float s_sum[2][4][64];
-  const int el = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __shared__ float s_sum[2][16][17];
+  const int el = threadIdx.x & 15, sg = threadIdx.x >> 4;
   const int n_el = MODE == 0 ? IJ : Co * C;
-  for (int e0 = blockIdx.x * 64; e0 < n_el; e0 += gridDim.x * 64) {
+  for (int e0 = blockIdx.x * 16; e0 < n_el; e0 += gridDim.x * 16) {
     const int e = e0 + el;
     float top = 0.f, bot = 0.f;
     if (e < n_el) {
       if (MODE == 0) {
-        for (int p = w; p < nsplit; p += 4) top += part[(size_t)p * IJ + e];
+        for (int p = sg; p < nsplit; p += 16) top += part[(size_t)p * IJ + e];
       } else {  // e = (o, c) over [Co, C]: top = d wcat[o][c], bot = d wcat[Co + o][c]
-        for (int p = w; p < nsplit; p += 4) {
+        for (int p = sg; p < nsplit; p += 16) {
           top += part[(size_t)p * IJ + e];
           bot += part[(size_t)p * IJ + (size_t)Co * C + e];
         }
       }
     }
-    s_sum[0][w][el] = top;
-    s_sum[1][w][el] = bot;
+    s_sum[0][sg][el] = top;
+    s_sum[1][sg][el] = bot;
     __syncthreads();
-    if (w == 0 && e < n_el) {
-      top = ((s_sum[0][0][el] + s_sum[0][1][el]) + s_sum[0][2][el]) + s_sum[0][3][el];
+    if (sg == 0 && e < n_el) {
+      top = s_sum[0][0][el];
+      bot = s_sum[1][0][el];
+#pragma unroll
+      for (int g = 1; g < 16; ++g) {
+        top += s_sum[0][g][el];
+        bot += s_sum[1][g][el];
+      }
       if (MODE == 0) {
         out[e] = top;
       } else {
-        bot = ((s_sum[1][0][el] + s_sum[1][1][el]) + s_sum[1][2][el]) + s_sum[1][3][el];
         const int o = e / C, c = e - o * C;
         const int ld = 3 + 2 * C;
         out[(size_t)o * ld + 3 + c] = bot;            // d W_c
@@ -480,6 +533,14 @@ constexpr int kCUs = 256;
 // rounds = workgroups / CUs.  Fractional rounds below one count as one (the chain is serial per wave); ties go to
 // the larger tile (fewer re-staged operand bytes).
 static void pick_tile(int I, int J, int nsplit, int *wi_out, int *wj_out) {
+  if (const char *force = getenv("CL3D_GEMM_TILE")) {  // tuning override "wi,wj" (scripts/bench_point_gemm.py --tiles)
+    int wi = 0, wj = 0;
+    if (sscanf(force, "%d,%d", &wi, &wj) == 2 && (wi == 1 || wi == 2) && (wj == 1 || wj == 2)) {
+      *wi_out = wi;
+      *wj_out = wj;
+      return;
+    }
+  }
   const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
   double best = 1e300;
   for (int c = 0; c < 4; ++c) {
@@ -506,7 +567,9 @@ static int wgrad_slices(long long K, int kc, int I, int J, int *chunks_per_split
   long long want = kCUs / (tiles > 0 ? tiles : 1);
   if (want < 1) want = 1;
   long long cps = (total + want - 1) / want;
-  if (cps < 8) cps = 8;
+  long long min_cps = 8;
+  if (const char *force = getenv("CL3D_GEMM_MIN_CPS")) min_cps = atoll(force) > 0 ? atoll(force) : 8;  // tuning override
+  if (cps < min_cps) cps = min_cps;
   if (cps > total) cps = total > 0 ? total : 1;
   *chunks_per_split = (int)cps;
   return (int)((total + cps - 1) / cps);
@@ -557,8 +620,8 @@ static int run_wgrad(GemmArgs &a, int precision, int nb, int K, void *ws, size_t
   int rc = run_gemm(a, precision, st, who);
   if (rc != CL3D_OK) return rc;
   const int n_el = MODE == 0 ? I * J : Co * C;
-  int grid = ceil_div(n_el, 64);
-  if (grid > 4096) grid = 4096;
+  int grid = ceil_div(n_el, 16);
+  if (grid > 8192) grid = 8192;
   hipLaunchKernelGGL((gemm_reduce_kernel<MODE>), dim3(grid), dim3(256), 0, st, partial, a.nsplit > 1 ? a.nsplit : 1, I * J,
                      out, dwr, Co, C);
   return check_launch(who);
@@ -627,6 +690,24 @@ extern "C" int cl3d_conv1x1_fwd(const float *x, const float *W, int B, int C, in
   a.D = y; a.d_si = N; a.d_sj = 1; a.d_fold_n = B > 1 ? N : 0; a.d_sb = (long long)Co * N;
   a.K = C;
   return run_gemm(a, precision, (hipStream_t)stream, "cl3d_conv1x1_fwd");
+}
+
+// inference: y = act(scale[o] * (W x)[o] + shift[o] + residual) in the GEMM's epilogue -- the BatchNorm of eval mode
+// folded into a per-channel affine map (scale = gamma / sqrt(var + eps), shift = beta - mean * scale), the shortcut
+// add and the ReLU of backbones/resnet.py:58-66 without a pass of their own
+extern "C" int cl3d_conv1x1_bn_act_fwd(const float *x, const float *W, const float *scale, const float *shift,
+                                       const float *residual, int relu, int B, int C, int N, int Co, int precision,
+                                       float *y, cl3d_stream_t stream) {
+  GEMM_COMMON_CHECKS("conv1x1_bn_act_fwd");
+  CL3D_REQUIRE(W && (B == 0 || (x && y)) && (!scale == !shift), "conv1x1_bn_act_fwd: null pointer");
+  if (B == 0) return CL3D_OK;
+  GemmArgs a{};
+  a.A = plain(W, C, 1, Co, C);
+  a.B = channel_major(x, B, C, N, true);
+  a.D = y; a.d_si = N; a.d_sj = 1; a.d_fold_n = B > 1 ? N : 0; a.d_sb = (long long)Co * N;
+  a.K = C;
+  a.ep_scale = scale; a.ep_shift = shift; a.ep_res = residual; a.ep_relu = relu;
+  return run_gemm(a, precision, (hipStream_t)stream, "cl3d_conv1x1_bn_act_fwd");
 }
 
 extern "C" int cl3d_conv1x1_bwd_data(const float *dy, const float *W, int B, int C, int N, int Co, int precision,

@@ -536,3 +536,160 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
     return _PointwiseMLP.apply(ght.contiguous(), wr, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                query_xyz.contiguous(), support_xyz.contiguous(), idx, radius, use_batch_stats,
                                momentum, bn.eps, _wants_grad(features, conv.weight, bn.weight, bn.bias))
+
+
+# ---------------------------------------------------------------- the 1x1 convolutions and BatchNorm tails of a bottleneck
+class _Conv1x1(Function):
+    """y [B,Co,N] = W [Co,C] x [B,C,N] on the matrix cores (csrc/mfma_gemm.hip), with both gradients; replaces the
+    library's Conv1d forward / backward-data / backward-weight kernels of backbones/resnet.py:32-39,58-66."""
+
+    @staticmethod
+    def forward(ctx, x, W, precision):
+        x = x.contiguous()
+        W = W.contiguous()
+        B, C, N = x.shape
+        Co = W.shape[0]
+        y = torch.empty((B, Co, N), dtype=torch.float32, device=x.device)
+        with _lib.on_device(x.device):
+            _lib.check(_lib.lib().cl3d_conv1x1_fwd(_p(x), _p(W), B, C, N, Co, precision, _p(y), _stream(x)))
+        ctx.save_for_backward(x, W)
+        ctx.precision = precision
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        B, C, N = x.shape
+        Co = W.shape[0]
+        dy = dy.contiguous()
+        lib = _lib.lib()
+        dx = dW = None
+        with _lib.on_device(x.device):
+            st = _stream(x)
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _lib.check(lib.cl3d_conv1x1_bwd_data(_p(dy), _p(W), B, C, N, Co, ctx.precision, _p(dx), st))
+            if ctx.needs_input_grad[1]:
+                dW = torch.empty_like(W)
+                ws_bytes = lib.cl3d_workspace_bytes(15, B, N, Co, 0, C)  # CL3D_OP_CONV1X1
+                ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=x.device)
+                _lib.check(lib.cl3d_conv1x1_bwd_weight(_p(x), _p(dy), B, C, N, Co, ctx.precision, _p(dW), _p(ws), ws_bytes, st))
+        return dx, dW, None
+
+
+def _batch_stats(x, bn, vec):
+    """Training-mode statistics of x for `bn` (scale, shift, mean, invstd into vec [4,C]; running statistics updated
+    with nn.BatchNorm1d's rule)."""
+    B, C, N = x.shape
+    lib = _lib.lib()
+    nparts = lib.cl3d_bn_partials(B, C, N)
+    partial = torch.empty((nparts, C, 2), dtype=torch.float64, device=x.device)
+    _lib.check(lib.cl3d_bn_relu_stats(_p(x), B, C, N, _p(partial), nparts, float(B * N), float(bn.eps),
+                                      float(bn.momentum), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
+                                      _p(bn.running_var), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _stream(x)))
+
+
+class _BnAddRelu(Function):
+    """out = ReLU(BN1(x1) + R), R = 0 | x2 | BN2(x2), training-mode statistics (csrc/bn_relu.hip).  One streaming
+    pass forward, two backward; x1, x2 and the output are what is kept for the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x1, gamma1, beta1, x2, gamma2, beta2, bn1, bn2, relu):
+        x1 = x1.contiguous()
+        B, C, N = x1.shape
+        dev = x1.device
+        out = torch.empty_like(x1)
+        vec1 = torch.empty((4, C), dtype=torch.float32, device=dev)
+        vec2 = None
+        with _lib.on_device(dev):
+            _batch_stats(x1, bn1, vec1)
+            if x2 is not None:
+                x2 = x2.contiguous()
+                if bn2 is not None:
+                    vec2 = torch.empty((4, C), dtype=torch.float32, device=dev)
+                    _batch_stats(x2, bn2, vec2)
+            _lib.check(_lib.lib().cl3d_bn_add_relu_apply(
+                _p(x1), _p(vec1[0]), _p(vec1[1]), _p(x2), _p(vec2[0]) if vec2 is not None else None,
+                _p(vec2[1]) if vec2 is not None else None, int(relu), B, C, N, _p(out), _stream(x1)))
+        ctx.save_for_backward(x1, x2, out, vec1, vec2, gamma1, gamma2)
+        ctx.relu = relu
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x1, x2, out, vec1, vec2, gamma1, gamma2 = ctx.saved_tensors
+        B, C, N = x1.shape
+        dev = x1.device
+        g = g.contiguous()
+        lib = _lib.lib()
+        nparts = lib.cl3d_bn_partials(B, C, N)
+        partial = torch.empty((2, nparts, C, 2), dtype=torch.float64, device=dev)
+        coef1 = torch.empty((5, C), dtype=torch.float32, device=dev)
+        coef2 = torch.empty((5, C), dtype=torch.float32, device=dev) if vec2 is not None else None
+        dx1 = torch.empty_like(x1)
+        dx2 = torch.empty_like(x2) if x2 is not None else None
+        with _lib.on_device(dev):
+            _lib.check(lib.cl3d_bn_add_relu_bwd(
+                _p(g), _p(out), _p(x1), _p(vec1[2]), _p(vec1[3]), _p(gamma1), _p(x2),
+                _p(vec2[2]) if vec2 is not None else None, _p(vec2[3]) if vec2 is not None else None,
+                _p(gamma2) if vec2 is not None else None, int(ctx.relu), B, C, N, float(B * N), _p(partial), nparts,
+                _p(coef1), _p(coef2), _p(dx1), _p(dx2), _stream(g)))
+        return (dx1, coef1[3], coef1[4], dx2, coef2[3] if coef2 is not None else None,
+                coef2[4] if coef2 is not None else None, None, None, None)
+
+
+def _bn_unit_ok(x, bn):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and bn.affine and bn.track_running_stats
+            and bn.momentum is not None)
+
+
+def _folded(bn):
+    invstd = torch.rsqrt(bn.running_var.double() + bn.eps)
+    scale = bn.weight.double() * invstd
+    return scale.float(), (bn.bias.double() - bn.running_mean.double() * scale).float()
+
+
+def conv_bn_act(x, conv, bn, relu=True, residual=None, res_conv=None, res_bn=None, precision='f32'):
+    """act(BN(conv(x)) + R): a bottleneck's conv1 (R = 0) or its tail conv2 + shortcut + add + ReLU
+    (backbones/resnet.py:32-39,58-66), on the engine: MFMA 1x1 convolutions, one statistics pass per BatchNorm and one
+    fused apply / add / ReLU pass.  Inference (no gradient): BatchNorm folded into the convolution's epilogue, one
+    launch per convolution.  Returns None when the modules are outside what the kernels cover."""
+    if conv.bias is not None or conv.kernel_size != (1,) or not _bn_unit_ok(x, bn):
+        return None
+    if res_conv is not None and (res_conv.bias is not None or not _bn_unit_ok(x, res_bn)):
+        return None
+    prec = PRECISIONS[precision]
+    Co, C = conv.weight.shape[0], conv.weight.shape[1]
+    W = conv.weight.view(Co, C)
+    training = bn.training
+    params = [conv.weight, bn.weight, bn.bias] + ([res_conv.weight, res_bn.weight, res_bn.bias] if res_conv is not None else [])
+    if not training:
+        if _wants_grad(x, residual, *params):
+            return None  # backward through frozen statistics: the nn modules do it
+        x = x.contiguous()
+        B, _, N = x.shape
+        lib = _lib.lib()
+        with _lib.on_device(x.device):
+            st = _stream(x)
+            res = residual.contiguous() if residual is not None else None
+            if res_conv is not None:
+                s2, t2 = _folded(res_bn)
+                Cr = res_conv.weight.shape[1]
+                ys = torch.empty((B, Co, N), dtype=torch.float32, device=x.device)
+                _lib.check(lib.cl3d_conv1x1_bn_act_fwd(_p(res), _p(res_conv.weight.view(Co, Cr).contiguous()), _p(s2), _p(t2),
+                                                       None, 0, B, Cr, N, Co, prec, _p(ys), st))
+                res = ys
+            s1, t1 = _folded(bn)
+            y = torch.empty((B, Co, N), dtype=torch.float32, device=x.device)
+            _lib.check(lib.cl3d_conv1x1_bn_act_fwd(_p(x), _p(W.contiguous()), _p(s1), _p(t1), _p(res), int(relu), B, C, N, Co,
+                                                   prec, _p(y), st))
+        return y
+    for b in (bn, res_bn):
+        if b is not None and b.num_batches_tracked is not None:
+            b.num_batches_tracked.add_(1)
+    y1 = _Conv1x1.apply(x, W, prec)
+    x2 = residual
+    if res_conv is not None:
+        x2 = _Conv1x1.apply(residual, res_conv.weight.view(Co, res_conv.weight.shape[1]), prec)
+    return _BnAddRelu.apply(y1, bn.weight, bn.bias, x2, res_bn.weight if res_bn is not None else None,
+                            res_bn.bias if res_bn is not None else None, bn, res_bn, relu)

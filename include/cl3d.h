@@ -148,6 +148,20 @@ int cl3d_bn_relu_bwd(const float *g, const float *x, const float *scale, const f
                      const float *invstd, const float *gamma, int B, int C, int N, double count, double *partial,
                      int n_partials, float *coef, float *dx, cl3d_stream_t stream);
 
+/* The tail of a bottleneck (backbones/resnet.py:58-66): out = ReLU(BN1(x1) + R) with R = 0 (x2 null), x2 (identity
+ * shortcut: scale2 / gamma2 null) or BN2(x2) (shortcut convolution); relu = 0 leaves the sum as it is.  The batch
+ * statistics of each branch come from cl3d_bn_relu_stats; apply is one streaming pass.  bwd: g = d out, `out` the saved
+ * result (its sign is the ReLU mask); one reduction pass yields both BatchNorm backward sums, coef1 / coef2 [5,C]
+ * receive A, Bc, D, d gamma, d beta per branch, dx1 / dx2 the input gradients (dx2 = gated g for the identity);
+ * partial: scratch [2, cl3d_bn_partials(B,C,N), C, 2] doubles. */
+int cl3d_bn_add_relu_apply(const float *x1, const float *scale1, const float *shift1, const float *x2,
+                           const float *scale2, const float *shift2, int relu, int B, int C, int N, float *out,
+                           cl3d_stream_t stream);
+int cl3d_bn_add_relu_bwd(const float *g, const float *out, const float *x1, const float *mean1, const float *invstd1,
+                         const float *gamma1, const float *x2, const float *mean2, const float *invstd2,
+                         const float *gamma2, int relu, int B, int C, int N, double count, double *partial,
+                         int n_partials, float *coef1, float *coef2, float *dx1, float *dx2, cl3d_stream_t stream);
+
 /* [B,R,C] -> [B,C,R] float32: the layout change at the fused operators' boundary (channel-major
  * reference tensors <-> point-major rows). */
 int cl3d_transpose(const float *src, int B, int R, int C, float *dst, cl3d_stream_t stream);
@@ -230,6 +244,12 @@ int cl3d_pwmlp_point_gemm_bwd_weight(const float *features, const float *dght, c
  * (ws: cl3d_workspace_bytes(CL3D_OP_CONV1X1, B, N, Co, 0, C)). */
 int cl3d_conv1x1_fwd(const float *x, const float *W, int B, int C, int N, int Co, int precision, float *y,
                      cl3d_stream_t stream);
+/* inference form: y = act(scale[o] * (W x)[o] + shift[o] + residual) with the eval-mode BatchNorm folded to a
+ * per-channel affine map, the shortcut add (residual [B,Co,N], nullable) and the ReLU (relu != 0) in the epilogue;
+ * scale / shift nullable together (plain convolution). */
+int cl3d_conv1x1_bn_act_fwd(const float *x, const float *W, const float *scale, const float *shift,
+                            const float *residual, int relu, int B, int C, int N, int Co, int precision, float *y,
+                            cl3d_stream_t stream);
 int cl3d_conv1x1_bwd_data(const float *dy, const float *W, int B, int C, int N, int Co, int precision, float *dx,
                           cl3d_stream_t stream);
 int cl3d_conv1x1_bwd_weight(const float *x, const float *dy, int B, int C, int N, int Co, int precision, float *dW,

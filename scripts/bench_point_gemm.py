@@ -93,7 +93,18 @@ if __name__ == "__main__":
     ap.add_argument("--Co", type=int, default=64)
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--sweep", action="store_true", help="also the ModelNet backbone's operator shapes (width 144)")
+    ap.add_argument("--tiles", action="store_true", help="tuning: every workgroup tile (CL3D_GEMM_TILE) per shape, f32 and bf16")
     a = ap.parse_args()
+    if a.tiles:
+        shapes = [(a.C, a.N)] + ([(72, 4096), (144, 1024), (288, 256), (576, 64)] if a.sweep else [])
+        for C, N in shapes:
+            for tile in ("2,2", "2,1", "1,2", "1,1"):
+                os.environ["CL3D_GEMM_TILE"] = tile
+                r = measure(a.B, C, N, C, a.reps, library=False)
+                print(json.dumps({"C": C, "N": N, "tile": tile,
+                                  "f32": [round(r["mfma_f32"][k], 1) for k in ("fwd_us", "bwd_data_us", "bwd_weight_us")],
+                                  "bf16": [round(r["mfma_bf16"][k], 1) for k in ("fwd_us", "bwd_data_us", "bwd_weight_us")]}))
+        sys.exit(0)
     res = [measure(a.B, a.C, a.N, a.Co, a.reps)]
     if a.sweep:
         for C, N in ((72, 4096), (144, 1024), (288, 256), (576, 64)):

@@ -1,0 +1,134 @@
+"""the bottleneck around the operator on the engine (reference backbones/resnet.py:22-68).
+
+`fused.conv_bn_act` = MFMA 1x1 convolution + BatchNorm statistics + one fused BatchNorm / shortcut-add / ReLU pass
+(training), or the convolution with BatchNorm folded into its epilogue (inference), against the nn modules the
+reference composes (Conv1d, BatchNorm1d, ReLU, +): outputs, every gradient, running statistics.  Then whole
+`Bottleneck`s, engine path against module path, same parameters."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from tests.helpers import default_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _unit(cin, cout, relu):
+    layers = [nn.Conv1d(cin, cout, 1, bias=False), nn.BatchNorm1d(cout, momentum=0.1)]
+    if relu:
+        layers.append(nn.ReLU(inplace=True))
+    seq = nn.Sequential(*layers).cuda()
+    with torch.no_grad():
+        seq[1].weight.uniform_(0.5, 1.5)
+        seq[1].weight[0] = -0.8  # a negative gamma
+        seq[1].bias.normal_(0, 0.3)
+        seq[1].running_mean.normal_(0, 0.2)
+        seq[1].running_var.uniform_(0.5, 2.0)
+    return seq
+
+
+def _close(a, b, tol, what):
+    scale = float(b.abs().max()) + 1e-12
+    err = float((a - b).abs().max()) / scale
+    assert err <= tol, f"{what}: {err:.3e} > {tol}"
+
+
+CASES = [  # B, Cin, Cout, N, residual kind
+    (16, 72, 36, 1024, None), (4, 36, 144, 1000, "identity_like"), (2, 144, 288, 250, "conv"), (16, 576, 1152, 16, "conv"),
+    (3, 3, 72, 777, None),
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,N,res", CASES)
+def test_conv_bn_act_training_matches_modules(B, Cin, Cout, N, res):
+    from closerlook3d_amd import fused
+    torch.manual_seed(Cin * 7 + Cout)
+    main = _unit(Cin, Cout, relu=res is None)
+    short = _unit(24, Cout, relu=False) if res == "conv" else None
+    x = torch.randn(B, Cin, N, device="cuda")
+    r = None if res is None else torch.randn(B, 24 if res == "conv" else Cout, N, device="cuda")
+    probe = torch.randn(B, Cout, N, device="cuda")
+    results = []
+    for mine in (True, False):
+        m, s = copy.deepcopy(main).train(True), copy.deepcopy(short).train(True) if short is not None else None
+        xi = x.clone().requires_grad_(True)
+        ri = r.clone().requires_grad_(True) if r is not None else None
+        if mine:
+            out = fused.conv_bn_act(xi, m[0], m[1], relu=True, residual=ri, res_conv=s[0] if s else None,
+                                    res_bn=s[1] if s else None)
+            assert out is not None
+        else:
+            out = m(xi)
+            if ri is not None:
+                out = torch.relu(out + (s(ri) if s is not None else ri))
+        (out * probe).sum().backward()
+        grads = [xi.grad, m[0].weight.grad, m[1].weight.grad, m[1].bias.grad]
+        stats = [m[1].running_mean, m[1].running_var, m[1].num_batches_tracked.float()]
+        if ri is not None:
+            grads.append(ri.grad)
+        if s is not None:
+            grads += [s[0].weight.grad, s[1].weight.grad, s[1].bias.grad]
+            stats += [s[1].running_mean, s[1].running_var]
+        results.append((out.detach(), grads, stats))
+    (o1, g1, s1), (o2, g2, s2) = results
+    _close(o1, o2, 2e-5, "output")
+    for i, (a, b) in enumerate(zip(g1, g2)):
+        _close(a, b, 1e-4, f"gradient {i}")
+    for i, (a, b) in enumerate(zip(s1, s2)):
+        _close(a, b, 1e-5, f"running statistic {i}")
+
+
+@pytest.mark.parametrize("B,Cin,Cout,N,res", CASES)
+def test_conv_bn_act_inference_folds_batchnorm(B, Cin, Cout, N, res):
+    from closerlook3d_amd import fused
+    torch.manual_seed(Cin + Cout)
+    main = _unit(Cin, Cout, relu=res is None).eval()
+    short = _unit(24, Cout, relu=False).eval() if res == "conv" else None
+    x = torch.randn(B, Cin, N, device="cuda")
+    r = None if res is None else torch.randn(B, 24 if res == "conv" else Cout, N, device="cuda")
+    with torch.no_grad():
+        want = main(x)
+        if r is not None:
+            want = torch.relu(want + (short(r) if short is not None else r))
+        got = fused.conv_bn_act(x, main[0], main[1], relu=True, residual=r, res_conv=short[0] if short else None,
+                                res_bn=short[1] if short else None)
+    assert got is not None
+    _close(got, want, 2e-5, "folded inference output")
+
+
+@pytest.mark.parametrize("kind,downsample", [("pospool", False), ("pointwisemlp", False), ("pospool", True)])
+def test_bottleneck_engine_path_matches_module_path(kind, downsample):
+    from closerlook3d_amd.backbones import Bottleneck
+    from oracle import operators as oo
+    rng = np.random.default_rng(4)
+    B, N, K = 4, 1024, 16
+    xyz_np, mask_np = oo.make_cloud(rng, B, N, pad_frac=0.1)
+    xyz, mask = torch.from_numpy(xyz_np).cuda(), torch.from_numpy(mask_np).cuda()
+    cin, cout = (72, 144)
+    f_np = rng.standard_normal((B, cin, N)).astype(np.float32)
+    over = {"pospool__position_embedding": "xyz", "pospool__reduction": "avg"} if kind == "pospool" else \
+        {"pointwisemlp__feature_type": "dp_fi_df"}
+    res = {}
+    state = None
+    for impl in ("auto", "grouped"):
+        torch.manual_seed(1)
+        cfg = default_config(kind, over, cl3d_impl=impl)
+        btn = Bottleneck(cin, cout, 2, 0.15, K, cfg, downsample=downsample, sampleDl=0.08 if downsample else None,
+                         npoint=256 if downsample else None)
+        if state is None:
+            state = copy.deepcopy(btn.state_dict())
+        btn.load_state_dict(state)
+        btn = btn.cuda().train(True)
+        feats = torch.from_numpy(f_np).cuda().requires_grad_(True)
+        qx, qm, out = btn(xyz, mask, feats)
+        probe = torch.from_numpy(np.random.default_rng(5).standard_normal(tuple(out.shape)).astype(np.float32)).cuda()
+        (out * probe).sum().backward()
+        res[impl] = (qx, qm, out.detach(), feats.grad, {k: p.grad for k, p in btn.named_parameters()})
+    assert torch.equal(res["auto"][0], res["grouped"][0]) and torch.equal(res["auto"][1], res["grouped"][1])
+    _close(res["auto"][2], res["grouped"][2], 5e-5, "bottleneck output")
+    _close(res["auto"][3], res["grouped"][3], 5e-4, "bottleneck d features")
+    for k in res["grouped"][4]:
+        _close(res["auto"][4][k], res["grouped"][4][k], 5e-4, f"bottleneck d {k}")
