@@ -43,12 +43,12 @@ SIGNATURES = {
     "cl3d_bn_add_relu_apply": [_P] * 6 + [_I, _I, _I, _I, _P, _P],
     "cl3d_bn_add_relu_bwd": [_P] * 10 + [_I, _I, _I, _I, ctypes.c_double, _P, _I, _P, _P, _P, _P, _P],
     "cl3d_pwmlp_partials": [_I, _I, _I],
-    "cl3d_pwmlp_point_gemm_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P],
-    "cl3d_pwmlp_point_gemm_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "cl3d_pwmlp_point_gemm_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P],
+    "cl3d_pwmlp_point_gemm_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_pwmlp_point_gemm_bwd_weight": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
-    "cl3d_conv1x1_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
-    "cl3d_conv1x1_bn_act_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
-    "cl3d_conv1x1_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "cl3d_conv1x1_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
+    "cl3d_conv1x1_bn_act_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
+    "cl3d_conv1x1_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_conv1x1_bwd_weight": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_pwmlp_split_weight": [_P, _I, _I, _P, _P, _P],
     "cl3d_pwmlp_merge_weight_grad": [_P, _P, _I, _I, _I, _P, _P],

@@ -29,10 +29,10 @@ extern "C" size_t cl3d_workspace_bytes(int op, int B, int N, int M, int K, int C
       return cl3d::inverse_index_workspace(B, N, M * K);
     case CL3D_OP_DATASET_GRID:  // keys and order (x2), heads, ranks, rocPRIM temporary storage; one cloud of N points
       return cl3d::dataset_grid_workspace(N);
-    case CL3D_OP_POINT_GEMM:  // PointWiseMLP per-point contraction: M carries Co; partials of d wcat [2Co, C]
-      return cl3d::gemm_wgrad_workspace(B, N, 2 * M, C);
-    case CL3D_OP_CONV1X1:  // 1x1 Conv1d C -> M over B clouds of N points: partials of d W [M, C]
-      return cl3d::gemm_wgrad_workspace(B, N, M, C);
+    case CL3D_OP_POINT_GEMM:  // PointWiseMLP per-point contraction: M carries Co; K-slice partials of any of its three products
+      return cl3d::gemm_family_workspace(B, N, 2 * M, C, true);
+    case CL3D_OP_CONV1X1:  // 1x1 Conv1d C -> M over B clouds of N points: K-slice partials of any of its three products
+      return cl3d::gemm_family_workspace(B, N, M, C, false);
     default:  // every other op of ABI v1 keeps its scratch in LDS
       return 0;
   }

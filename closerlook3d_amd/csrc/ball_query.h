@@ -22,7 +22,8 @@ size_t grid_subsampling_workspace(int B, int N);
 // csr.hip
 size_t inverse_index_workspace(int B, int N, int MK);
 size_t dataset_grid_workspace(int n);
-// mfma_gemm.hip: scratch of a weight-gradient contraction D[I][J] over nb batches of K points (split-K partials)
-size_t gemm_wgrad_workspace(int nb, int K, int I, int J);
+// mfma_gemm.hip: scratch (K-slice partial tiles) of the three products of a per-point contraction rows_in -> rows_out
+// over nb clouds of n points; merge: the PointWiseMLP form, whose weight gradient always goes through the reduce
+size_t gemm_family_workspace(int nb, int n, int rows_out, int rows_in, bool merge);
 
 }  // namespace cl3d

@@ -54,19 +54,40 @@ struct GemmOperand {
   long long sb;          // cloud stride of a folded axis
 };
 
-struct GemmArgs {
-  GemmOperand A, B;  // D[i][j] = sum_k A(i,k) B(j,k)
+// where a result element (i, j) goes, and what happens to it on the way (inference epilogue)
+struct OutMap {
   float *D;
-  long long d_si, d_sj;
-  int d_fold_n;        // != 0: j = cloud * d_fold_n + point, cloud stride d_sb (channel-major output)
-  long long d_sb;
-  int K;               // contraction extent (clouds folded in for weight gradients)
-  int nsplit, chunks_per_split;  // nsplit > 1: K cut into slices, slice s writes its partial tile to D + s*I*J
-  int tiles_i, tiles_j;
-  // inference epilogue (BatchNorm folded to a per-row affine map, residual, ReLU): D = act(scale[i] * acc + shift[i] + res)
+  long long si, sj;
+  int fold_n;          // != 0: j = cloud * fold_n + point, cloud stride sb (channel-major output)
+  long long sb;
+  // D = act(scale[i] * acc + shift[i] + res): BatchNorm folded to a per-row affine map, residual, ReLU
   const float *ep_scale, *ep_shift, *ep_res;
   int ep_relu;
 };
+
+struct GemmArgs {
+  GemmOperand A, B;  // D[i][j] = sum_k A(i,k) B(j,k)
+  OutMap out;
+  float *partial;      // nsplit > 1: slice s writes its I x J tile (row-major) to partial + s*I*J instead
+  int K;               // contraction extent (clouds folded in for weight gradients)
+  int nsplit, chunks_per_split;
+  int tiles_i, tiles_j;
+};
+
+__device__ __forceinline__ long long out_col(const OutMap &o, int j) {
+  if (o.fold_n) {
+    const int b = j / o.fold_n;
+    return b * o.sb + (long long)(j - b * o.fold_n) * o.sj;
+  }
+  return (long long)j * o.sj;
+}
+__device__ __forceinline__ void out_store(const OutMap &o, int i, long long joff, float v) {
+  const long long at = i * o.si + joff;
+  if (o.ep_scale) v = __builtin_fmaf(v, o.ep_scale[i], o.ep_shift[i]);
+  if (o.ep_res) v += o.ep_res[at];
+  if (o.ep_relu) v = v > 0.f ? v : 0.f;
+  o.D[at] = v;
+}
 
 // element offset of (r, k) of an operand; the pointer base is wave-uniform, the offset a 32-bit lane value
 __device__ __forceinline__ unsigned gemm_off(const GemmOperand &s, int r, int k) {
@@ -256,8 +277,11 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
   using SA = StagePick<PREC, TI>;
   using SB = StagePick<PREC, TJ>;
   constexpr int KC = SA::KC;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[SA::kLdsBytes + SB::kLdsBytes];
-  unsigned char *ldsA = lds, *ldsB = lds + SA::kLdsBytes;
+  // LDS: two copies of the (A, B) chunk pair -- chunk g+1 is written while chunk g is multiplied, one barrier per
+  // chunk -- except for the 128 x 128 tile, whose pair is 33 KB (static LDS ends at 64 KB): one copy, two barriers.
+  constexpr int NBUF = (WI * WJ == 4) ? 1 : 2;
+  constexpr int kPair = SA::kLdsBytes + SB::kLdsBytes;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * kPair];
 
   // tile / K slice of this workgroup
   int bid = blockIdx.x;
@@ -286,10 +310,10 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
 
-  // Two K chunks are kept in flight in registers (sets 0 and 1): a chunk is written to LDS two loop turns after its
-  // loads were issued, so the write never waits on HBM latency even with one wave per SIMD.
-  // (the widest register footprints -- bf16 at 128 x 128, the scalar fallback -- keep a single set)
-  constexpr int DEPTH = ((PREC == PREC_BF16 && WI * WJ == 4) || AM == STAGE_SCALAR) ? 1 : 2;
+  // Up to two K chunks are kept in flight in registers (sets 0 and 1) on top of the one in LDS, so a chunk's loads
+  // have two multiply phases to land even with one wave per SIMD (the widest register footprints -- bf16 above
+  // 128 x 128, the scalar fallback -- keep a single set).
+  constexpr int DEPTH = ((PREC == PREC_BF16 && WI * WJ >= 2) || AM == STAGE_SCALAR) ? 1 : 2;
   typename SA::type sa[DEPTH];
   typename SB::type sb[DEPTH];
   auto issue = [&](int set, int g) {
@@ -301,7 +325,8 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
       sb[DEPTH - 1].template load<BM>(a.B, j0, g * KC, a.K);
     }
   };
-  auto multiply = [&]() {
+  auto multiply = [&](int buf) {
+    const unsigned char *ldsA = lds + (NBUF == 2 ? buf : 0) * kPair, *ldsB = ldsA + SA::kLdsBytes;
     if constexpr (PREC == PREC_F32) {
       const float *TA = reinterpret_cast<const float *>(ldsA), *TB = reinterpret_cast<const float *>(ldsB);
       const int strA = SA::type::stride(a.A), strB = SB::type::stride(a.B);
@@ -336,8 +361,8 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
       }
     }
   };
-  auto to_lds = [&](int set) {
-    __syncthreads();  // the previous chunk has been multiplied out of LDS
+  auto to_lds = [&](int set, int buf) {
+    unsigned char *ldsA = lds + (NBUF == 2 ? buf : 0) * kPair, *ldsB = ldsA + SA::kLdsBytes;
     if constexpr (PREC == PREC_F32) {
       if (set == 0 || DEPTH == 1) {
         sa[0].template store<AM>(a.A, reinterpret_cast<float *>(ldsA));
@@ -355,71 +380,94 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
         sb[DEPTH - 1].template store<BM>(a.B, reinterpret_cast<uint4 *>(ldsB));
       }
     }
-    __syncthreads();
   };
   if (g0 < g1) issue(0, g0);
-  if constexpr (DEPTH == 2) {
+  if constexpr (NBUF == 2) {
+    // chunk g sits in LDS copy (g - g0) & 1; register set s carries the chunk that goes to LDS copy s next
+    if (DEPTH == 2 && g0 + 1 < g1) issue(1, g0 + 1);
+    if (g0 < g1) to_lds(0, 0);
+    __syncthreads();
+    for (int g = g0; g < g1; g += 2) {
+      // --- chunk g out of copy 0
+      if constexpr (DEPTH == 2) {
+        if (g + 2 < g1) issue(0, g + 2);
+      } else {
+        if (g + 1 < g1) issue(0, g + 1);
+      }
+      multiply(0);
+      if (g + 1 < g1) to_lds(DEPTH == 2 ? 1 : 0, 1);
+      __syncthreads();
+      if (g + 1 >= g1) break;
+      // --- chunk g + 1 out of copy 1
+      if constexpr (DEPTH == 2) {
+        if (g + 3 < g1) issue(1, g + 3);
+      } else {
+        if (g + 2 < g1) issue(0, g + 2);
+      }
+      multiply(1);
+      if (g + 2 < g1) to_lds(0, 0);
+      __syncthreads();
+    }
+  } else if constexpr (DEPTH == 2) {
     if (g0 + 1 < g1) issue(1, g0 + 1);
     for (int g = g0; g < g1; g += 2) {
-      to_lds(0);
+      __syncthreads();  // the previous chunk has been multiplied out of LDS
+      to_lds(0, 0);
+      __syncthreads();
       if (g + 2 < g1) issue(0, g + 2);
-      multiply();
+      multiply(0);
       if (g + 1 < g1) {
-        to_lds(1);
+        __syncthreads();
+        to_lds(1, 0);
+        __syncthreads();
         if (g + 3 < g1) issue(1, g + 3);
-        multiply();
+        multiply(0);
       }
     }
   } else {
     for (int g = g0; g < g1; ++g) {
-      to_lds(0);
+      __syncthreads();
+      to_lds(0, 0);
+      __syncthreads();
       if (g + 1 < g1) issue(0, g + 1);
-      multiply();
+      multiply(0);
     }
   }
 
   // D: a lane holds column j = lane & 31 and rows (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) of each 32x32 block
   const int I = a.A.R, J = a.B.R;
   const bool part = a.nsplit > 1;
-  float *D = a.D + (part ? (long long)z * I * J : 0);
-  const long long si = part ? J : a.d_si, sj = part ? 1 : a.d_sj;
+  float *P = part ? a.partial + (long long)z * I * J : nullptr;
 #pragma unroll
   for (int x = 0; x < WI; ++x)
 #pragma unroll
     for (int y = 0; y < WJ; ++y) {
       const int j = j0 + wj0 + 32 * y + lr;
-      long long joff = j * sj;
-      if (!part && a.d_fold_n) {
-        const int b = j / a.d_fold_n;
-        joff = b * a.d_sb + (j - b * a.d_fold_n) * sj;
-      }
+      const long long joff = part ? j : out_col(a.out, j);
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int i = i0 + wi0 + 32 * x + (e & 3) + 8 * (e >> 2) + 4 * lh;
         if (i < I && j < J) {
-          float v = acc[x][y][e];
-          if (a.ep_scale) v = __builtin_fmaf(v, a.ep_scale[i], a.ep_shift[i]);
-          if (a.ep_res) v += a.ep_res[i * si + joff];
-          if (a.ep_relu) v = v > 0.f ? v : 0.f;
-          D[i * si + joff] = v;
+          if (part) P[(long long)i * J + j] = acc[x][y][e];
+          else out_store(a.out, i, joff, acc[x][y][e]);
         }
       }
     }
 }
 
-// ---- slice-ordered sum of the split-K partials.  A workgroup owns 16 consecutive output elements; its 16 thread
-// groups take the slices s = g, g+16, g+32, ... and the 16 sub-sums are added in group order through LDS: the
-// summation order depends on nsplit only (bit-reproducible), and 8 MB of partials are read by a few hundred
-// workgroups instead of a few dozen.  MODE 1 also turns d wcat [2Co, C] (+ d W_r) into d W [Co, 3+2C].
+// ---- slice-ordered sum of the split-K partials.  A workgroup owns 16 consecutive elements of the I x J tile; its 16
+// thread groups take the slices s = g, g+16, g+32, ... and the 16 sub-sums are added in group order through LDS: the
+// summation order depends on nsplit only (bit-reproducible).  MODE 0 sends element (i, j) through the output map
+// (strides, folded clouds, inference epilogue); MODE 1 turns d wcat [2Co, C] (+ d W_r) into d W [Co, 3+2C].
 template <int MODE>
-__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ part, int nsplit, int IJ,
-                                                          float *__restrict__ out, const float *__restrict__ dwr,
-                                                          int Co, int C) {
+__global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ part, int nsplit, int I, int J,
+                                                          OutMap o, const float *__restrict__ dwr, int Co, int C) {
   __shared__ float s_sum[2][16][17];
   const int el = threadIdx.x & 15, sg = threadIdx.x >> 4;
-  const int n_el = MODE == 0 ? IJ : Co * C;
-  for (int e0 = blockIdx.x * 16; e0 < n_el; e0 += gridDim.x * 16) {
-    const int e = e0 + el;
+  const long long IJ = (long long)I * J;
+  const long long n_el = MODE == 0 ? IJ : (long long)Co * C;
+  for (long long e0 = (long long)blockIdx.x * 16; e0 < n_el; e0 += (long long)gridDim.x * 16) {
+    const long long e = e0 + el;
     float top = 0.f, bot = 0.f;
     if (e < n_el) {
       if (MODE == 0) {
@@ -443,13 +491,14 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restric
         bot += s_sum[1][g][el];
       }
       if (MODE == 0) {
-        out[e] = top;
+        const int i = (int)(e / J), j = (int)(e - (long long)i * J);
+        out_store(o, i, out_col(o, j), top);
       } else {
-        const int o = e / C, c = e - o * C;
+        const int oo = (int)(e / C), c = (int)(e - (long long)oo * C);
         const int ld = 3 + 2 * C;
-        out[(size_t)o * ld + 3 + c] = bot;            // d W_c
-        out[(size_t)o * ld + 3 + C + c] = top - bot;  // d W_d
-        if (c < 3) out[(size_t)o * ld + c] = dwr ? dwr[o * 3 + c] : 0.f;
+        o.D[(size_t)oo * ld + 3 + c] = bot;            // d W_c
+        o.D[(size_t)oo * ld + 3 + C + c] = top - bot;  // d W_d
+        if (c < 3) o.D[(size_t)oo * ld + c] = dwr ? dwr[oo * 3 + c] : 0.f;
       }
     }
     __syncthreads();
@@ -528,64 +577,100 @@ static void launch_modes(GemmArgs &a, int wi, int wj, int blocks, hipStream_t st
 
 constexpr int kCUs = 256;
 
-// Workgroup tile for an I x J output (x nsplit K slices).  A workgroup's four waves sit on the four SIMDs of a CU,
-// so a CU works through its workgroups' MFMA chains one after the other: time ~ rounds x (accumulators per wave),
-// rounds = workgroups / CUs.  Fractional rounds below one count as one (the chain is serial per wave); ties go to
-// the larger tile (fewer re-staged operand bytes).
-static void pick_tile(int I, int J, int nsplit, int *wi_out, int *wj_out) {
-  if (const char *force = getenv("CL3D_GEMM_TILE")) {  // tuning override "wi,wj" (scripts/bench_point_gemm.py --tiles)
-    int wi = 0, wj = 0;
-    if (sscanf(force, "%d,%d", &wi, &wj) == 2 && (wi == 1 || wi == 2) && (wj == 1 || wj == 2)) {
-      *wi_out = wi;
-      *wj_out = wj;
-      return;
-    }
-  }
-  const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
-  double best = 1e300;
-  for (int c = 0; c < 4; ++c) {
-    const int wi = cand[c][0], wj = cand[c][1];
-    const long long blocks = (long long)ceil_div(I, 64 * wi) * ceil_div(J, 64 * wj) * (nsplit > 1 ? nsplit : 1);
-    double rounds = (double)blocks / kCUs;
-    if (rounds < 1.0) rounds = 1.0;
-    const double cost = rounds * wi * wj;
-    if (cost < best * 0.97) {
-      best = cost;
-      *wi_out = wi;
-      *wj_out = wj;
-    }
-  }
-}
-
 static int kc_of(int precision) { return precision == PREC_BF16 ? 64 : 32; }
 
-// K slices of a weight-gradient contraction: about one workgroup per CU over all output tiles, at least 8 chunks per
-// slice so that a partial tile is written once per >= 256 points
-static int wgrad_slices(long long K, int kc, int I, int J, int *chunks_per_split) {
-  const long long total = (K + kc - 1) / kc;
-  const int tiles = ceil_div(I, 128) * ceil_div(J, 64);  // the 128 x 64 tile, as run_gemm picks for small outputs
-  long long want = kCUs / (tiles > 0 ? tiles : 1);
-  if (want < 1) want = 1;
-  long long cps = (total + want - 1) / want;
-  long long min_cps = 8;
-  if (const char *force = getenv("CL3D_GEMM_MIN_CPS")) min_cps = atoll(force) > 0 ? atoll(force) : 8;  // tuning override
-  if (cps < min_cps) cps = min_cps;
-  if (cps > total) cps = total > 0 ? total : 1;
-  *chunks_per_split = (int)cps;
-  return (int)((total + cps - 1) / cps);
+// Workgroup tile and K slicing for an I x J output over K.  A workgroup's four waves sit on the four SIMDs of a CU,
+// so a CU works through its workgroups' MFMA chains one after the other: time ~ rounds x (accumulators per wave) x
+// (chunks per slice), rounds = workgroups / CUs, never below one (the chain is serial per wave).  Few tiles and a
+// long K (the deep stages: 256 points x 2304 channels; every weight gradient) are cut along K into slices whose
+// partial tiles are summed in slice order by gemm_reduce_kernel; a slice keeps >= 4 chunks and the partials must
+// fit the caller's scratch.  Ties go to the larger tile (fewer re-staged operand bytes).
+struct Plan {
+  int wi, wj, nsplit, cps;
+};
+
+static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes) {
+  const int kc = kc_of(precision);
+  const long long chunks = (K + kc - 1) / kc;
+  const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  Plan best{2, 2, 1, (int)chunks};
+  double best_cost = 1e300;
+  int force_wi = 0, force_wj = 0;
+  if (const char *force = getenv("CL3D_GEMM_TILE")) {  // tuning override "wi,wj" (scripts/bench_point_gemm.py --tiles)
+    if (sscanf(force, "%d,%d", &force_wi, &force_wj) != 2) force_wi = force_wj = 0;
+  }
+  for (int c = 0; c < 4; ++c) {
+    const int wi = cand[c][0], wj = cand[c][1];
+    if (force_wi && (wi != force_wi || wj != force_wj)) continue;
+    const long long tiles = (long long)ceil_div(I, 64 * wi) * ceil_div(J, 64 * wj);
+    long long split = 1;
+    if (tiles < kCUs && max_split > 1) {
+      split = (kCUs + tiles - 1) / tiles;                       // fill the chip once
+      if (split > chunks / 4) split = chunks / 4;               // >= 4 chunks per slice
+      if (split > max_split) split = max_split;
+      while (split > 1 && (size_t)split * I * J * sizeof(float) > ws_bytes) --split;
+      if (split < 1) split = 1;
+    }
+    const long long cps = (chunks + split - 1) / split;
+    split = (chunks + cps - 1) / cps;
+    double rounds = (double)(tiles * split) / kCUs;
+    if (rounds < 1.0) rounds = 1.0;
+    // multiply time + what a slice costs on top (partial tile out and back in, ~one chunk's worth per slice pair)
+    const double cost = rounds * wi * wj * (double)(cps + (split > 1 ? 2 : 0));
+    if (cost < best_cost * 0.97) {
+      best_cost = cost;
+      best = Plan{wi, wj, (int)split, (int)cps};
+    }
+  }
+  return best;
 }
 
-static int run_gemm(GemmArgs &a, int precision, hipStream_t st, const char *who) {
+// scratch a GEMM of this shape may use for K slices (0 when it never splits)
+static size_t plan_workspace(int I, int J, long long K, int max_split, bool always_reduce) {
+  size_t worst = 0;
+  for (int prec = 0; prec < 2; ++prec) {
+    const Plan p = plan_gemm(I, J, K, prec, max_split, ~(size_t)0);
+    const size_t bytes = (p.nsplit > 1 || always_reduce) ? (size_t)p.nsplit * I * J * sizeof(float) : 0;
+    worst = bytes > worst ? bytes : worst;
+  }
+  return worst;
+}
+
+constexpr int kMaxSplitFwd = 16;    // forward / input-gradient products: K = channels
+constexpr int kMaxSplitWgrad = 512; // weight gradients: K = every point of the batch
+
+// REDUCE_MODE 0: result through the output map; 1: PointWiseMLP weight-gradient merge (always via the reduce kernel)
+template <int REDUCE_MODE>
+static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t ws_bytes, const float *dwr, int Co, int C,
+                    hipStream_t st, const char *who) {
   const int I = a.A.R, J = a.B.R;
-  int wi = 2, wj = 2;
-  pick_tile(I, J, a.nsplit, &wi, &wj);
-  a.tiles_i = ceil_div(I, 64 * wi);
-  a.tiles_j = ceil_div(J, 64 * wj);
-  const long long blocks = (long long)a.tiles_i * a.tiles_j * (a.nsplit > 1 ? a.nsplit : 1);
+  if (I == 0 || J == 0) return CL3D_OK;
+  const bool always_reduce = REDUCE_MODE == 1;
+  if (always_reduce && (!ws || ws_bytes < (size_t)I * J * sizeof(float)))
+    return fail(CL3D_E_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, plan_workspace(I, J, a.K, max_split, true));
+  const Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0);
+  a.tiles_i = ceil_div(I, 64 * p.wi);
+  a.tiles_j = ceil_div(J, 64 * p.wj);
+  a.nsplit = p.nsplit;
+  a.chunks_per_split = p.cps;
+  a.partial = static_cast<float *>(ws);
+  const bool reduce = p.nsplit > 1 || always_reduce;
+  OutMap final_out = a.out;
+  if (reduce && p.nsplit == 1) {  // one slice, but the result still goes through the reduce kernel's mapping
+    a.out = OutMap{};
+    a.out.D = a.partial; a.out.si = J; a.out.sj = 1;
+  }
+  const long long blocks = (long long)a.tiles_i * a.tiles_j * p.nsplit;
   if (blocks > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "%s: grid too large", who);
-  if (blocks == 0) return CL3D_OK;
-  if (precision == PREC_BF16) launch_modes<PREC_BF16>(a, wi, wj, (int)blocks, st);
-  else launch_modes<PREC_F32>(a, wi, wj, (int)blocks, st);
+  if (precision == PREC_BF16) launch_modes<PREC_BF16>(a, p.wi, p.wj, (int)blocks, st);
+  else launch_modes<PREC_F32>(a, p.wi, p.wj, (int)blocks, st);
+  int rc = check_launch(who);
+  if (rc != CL3D_OK || !reduce) return rc;
+  const long long n_el = REDUCE_MODE == 0 ? (long long)I * J : (long long)Co * C;
+  long long grid = (n_el + 15) / 16;
+  if (grid > 16384) grid = 16384;
+  hipLaunchKernelGGL((gemm_reduce_kernel<REDUCE_MODE>), dim3((unsigned)grid), dim3(256), 0, st, a.partial, p.nsplit, I, J,
+                     final_out, dwr, Co, C);
   return check_launch(who);
 }
 
@@ -594,37 +679,17 @@ static int round_up_grid(int n) {
   return g < 1 ? 1 : (g > 2048 ? 2048 : g);
 }
 
-size_t gemm_wgrad_workspace(int nb, int K, int I, int J) {
-  size_t worst = 0;
-  for (int prec = 0; prec < 2; ++prec) {
-    int cps = 0;
-    const int ns = wgrad_slices((long long)nb * K, kc_of(prec), I, J, &cps);
-    const size_t bytes = (size_t)ns * I * J * sizeof(float);
-    worst = bytes > worst ? bytes : worst;
-  }
-  return worst;
-}
-
-// weight gradient D[I][J] = sum over all nb*K points: slices to scratch, then the ordered reduce
-template <int MODE>
-static int run_wgrad(GemmArgs &a, int precision, int nb, int K, void *ws, size_t ws_bytes, float *out, const float *dwr,
-                     int Co, int C, hipStream_t st, const char *who) {
-  const int I = a.A.R, J = a.B.R;
-  const size_t need = gemm_wgrad_workspace(nb, K, I, J);
-  if (!ws || ws_bytes < need) return fail(CL3D_E_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, need);
-  a.K = nb * K;
-  a.nsplit = wgrad_slices((long long)nb * K, kc_of(precision), I, J, &a.chunks_per_split);
-  float *partial = static_cast<float *>(ws);
-  if (a.nsplit == 1) a.nsplit = 0;  // one slice: the "partial" is the result, still through the reduce for MODE 1
-  a.D = partial; a.d_si = J; a.d_sj = 1; a.d_fold_n = 0;
-  int rc = run_gemm(a, precision, st, who);
-  if (rc != CL3D_OK) return rc;
-  const int n_el = MODE == 0 ? I * J : Co * C;
-  int grid = ceil_div(n_el, 16);
-  if (grid > 8192) grid = 8192;
-  hipLaunchKernelGGL((gemm_reduce_kernel<MODE>), dim3(grid), dim3(256), 0, st, partial, a.nsplit > 1 ? a.nsplit : 1, I * J,
-                     out, dwr, Co, C);
-  return check_launch(who);
+// scratch of the three products of a per-point contraction  out[Co'] <- in[C']  over nb clouds of n points
+size_t gemm_family_workspace(int nb, int n, int rows_out, int rows_in, bool merge) {
+  const long long P = (long long)nb * n;
+  if (P > 0x7fffffffLL) return 0;
+  size_t w = plan_workspace(rows_out, rows_in, P, kMaxSplitWgrad, merge);                    // weight gradient
+  const size_t f = plan_workspace((int)P, rows_out, rows_in, kMaxSplitFwd, false);           // forward (either orientation:
+  const size_t f2 = plan_workspace(rows_out, (int)P, rows_in, kMaxSplitFwd, false);          //  points on i or on j)
+  const size_t d = plan_workspace(rows_in, (int)P, rows_out, kMaxSplitFwd, false);           // input gradient
+  w = f > w ? f : w;
+  w = f2 > w ? f2 : w;
+  return d > w ? d : w;
 }
 
 }  // namespace cl3d
@@ -638,7 +703,8 @@ using namespace cl3d;
     return fail(CL3D_E_UNSUPPORTED, who ": tensor too large (32-bit element offsets)");
 
 extern "C" int cl3d_pwmlp_point_gemm_fwd(const float *features, const float *W, int B, int C, int N, int Co,
-                                         int precision, float *ght, float *wr, float *wcat, cl3d_stream_t stream) {
+                                         int precision, float *ght, float *wr, float *wcat, void *ws, size_t ws_bytes,
+                                         cl3d_stream_t stream) {
   GEMM_COMMON_CHECKS("pwmlp_point_gemm_fwd");
   CL3D_REQUIRE(W && wcat && (B == 0 || (features && ght)), "pwmlp_point_gemm_fwd: null pointer");
   hipStream_t st = (hipStream_t)stream;
@@ -648,22 +714,24 @@ extern "C" int cl3d_pwmlp_point_gemm_fwd(const float *features, const float *W, 
   GemmArgs a{};  // D[i = (cloud, point)][j = o] = sum_c F[c][point] wcat[o][c]  ->  ght [B*N, 2Co]
   a.A = channel_major(features, B, C, N, true);
   a.B = plain(wcat, C, 1, 2 * Co, C);
-  a.D = ght; a.d_si = 2 * Co; a.d_sj = 1;
+  a.out.D = ght; a.out.si = 2 * Co; a.out.sj = 1;
   a.K = C;
-  return run_gemm(a, precision, st, "cl3d_pwmlp_point_gemm_fwd");
+  return run_gemm<0>(a, precision, kMaxSplitFwd, ws, ws_bytes, nullptr, 0, 0, st, "cl3d_pwmlp_point_gemm_fwd");
 }
 
 extern "C" int cl3d_pwmlp_point_gemm_bwd_data(const float *dght, const float *wcat, int B, int C, int N, int Co,
-                                              int precision, float *dfeatures, cl3d_stream_t stream) {
+                                              int precision, float *dfeatures, void *ws, size_t ws_bytes,
+                                              cl3d_stream_t stream) {
   GEMM_COMMON_CHECKS("pwmlp_point_gemm_bwd_data");
   CL3D_REQUIRE(wcat && (B == 0 || (dght && dfeatures)), "pwmlp_point_gemm_bwd_data: null pointer");
   if (B == 0) return CL3D_OK;
   GemmArgs a{};  // D[i = c][j = (cloud, point)] = sum_o wcat[o][c] dght[point][o]  ->  d features [B, C, N]
   a.A = plain(wcat, 1, C, C, 2 * Co);
   a.B = plain(dght, 2 * Co, 1, B * N, 2 * Co);
-  a.D = dfeatures; a.d_si = N; a.d_sj = 1; a.d_fold_n = B > 1 ? N : 0; a.d_sb = (long long)C * N;
+  a.out.D = dfeatures; a.out.si = N; a.out.sj = 1; a.out.fold_n = B > 1 ? N : 0; a.out.sb = (long long)C * N;
   a.K = 2 * Co;
-  return run_gemm(a, precision, (hipStream_t)stream, "cl3d_pwmlp_point_gemm_bwd_data");
+  return run_gemm<0>(a, precision, kMaxSplitFwd, ws, ws_bytes, nullptr, 0, 0, (hipStream_t)stream,
+                     "cl3d_pwmlp_point_gemm_bwd_data");
 }
 
 extern "C" int cl3d_pwmlp_point_gemm_bwd_weight(const float *features, const float *dght, const float *dwr, int B,
@@ -674,22 +742,32 @@ extern "C" int cl3d_pwmlp_point_gemm_bwd_weight(const float *features, const flo
   GemmArgs a{};  // D[i = o][j = c] = sum_(cloud, point) dght[point][o] F[c][point]  ->  d wcat [2Co, C] per slice
   a.A = plain(dght, 1, 2 * Co, 2 * Co, B * N);
   a.B = channel_major(features, B, C, N, false);
-  return run_wgrad<1>(a, precision, B, N, ws, ws_bytes, dW, dwr, Co, C, (hipStream_t)stream,
-                      "cl3d_pwmlp_point_gemm_bwd_weight");
+  a.K = B * N;
+  a.out.D = dW;
+  return run_gemm<1>(a, precision, kMaxSplitWgrad, ws, ws_bytes, dwr, Co, C, (hipStream_t)stream,
+                     "cl3d_pwmlp_point_gemm_bwd_weight");
 }
 
 // ---- the 1x1 Conv1d layers around the operator (backbones/resnet.py:32-39,58-66), channel-major in and out ---------
-extern "C" int cl3d_conv1x1_fwd(const float *x, const float *W, int B, int C, int N, int Co, int precision, float *y,
-                                cl3d_stream_t stream) {
-  GEMM_COMMON_CHECKS("conv1x1_fwd");
-  CL3D_REQUIRE(W && (B == 0 || (x && y)), "conv1x1_fwd: null pointer");
-  if (B == 0) return CL3D_OK;
+static int conv_forward(const float *x, const float *W, const float *scale, const float *shift, const float *residual,
+                        int relu, int B, int C, int N, int Co, int precision, float *y, void *ws, size_t ws_bytes,
+                        hipStream_t st, const char *who) {
   GemmArgs a{};  // D[i = o][j = (cloud, point)] = sum_c W[o][c] x[c][point]
   a.A = plain(W, C, 1, Co, C);
   a.B = channel_major(x, B, C, N, true);
-  a.D = y; a.d_si = N; a.d_sj = 1; a.d_fold_n = B > 1 ? N : 0; a.d_sb = (long long)Co * N;
+  a.out.D = y; a.out.si = N; a.out.sj = 1; a.out.fold_n = B > 1 ? N : 0; a.out.sb = (long long)Co * N;
+  a.out.ep_scale = scale; a.out.ep_shift = shift; a.out.ep_res = residual; a.out.ep_relu = relu;
   a.K = C;
-  return run_gemm(a, precision, (hipStream_t)stream, "cl3d_conv1x1_fwd");
+  return run_gemm<0>(a, precision, kMaxSplitFwd, ws, ws_bytes, nullptr, 0, 0, st, who);
+}
+
+extern "C" int cl3d_conv1x1_fwd(const float *x, const float *W, int B, int C, int N, int Co, int precision, float *y,
+                                void *ws, size_t ws_bytes, cl3d_stream_t stream) {
+  GEMM_COMMON_CHECKS("conv1x1_fwd");
+  CL3D_REQUIRE(W && (B == 0 || (x && y)), "conv1x1_fwd: null pointer");
+  if (B == 0) return CL3D_OK;
+  return conv_forward(x, W, nullptr, nullptr, nullptr, 0, B, C, N, Co, precision, y, ws, ws_bytes, (hipStream_t)stream,
+                      "cl3d_conv1x1_fwd");
 }
 
 // inference: y = act(scale[o] * (W x)[o] + shift[o] + residual) in the GEMM's epilogue -- the BatchNorm of eval mode
@@ -697,30 +775,25 @@ extern "C" int cl3d_conv1x1_fwd(const float *x, const float *W, int B, int C, in
 // add and the ReLU of backbones/resnet.py:58-66 without a pass of their own
 extern "C" int cl3d_conv1x1_bn_act_fwd(const float *x, const float *W, const float *scale, const float *shift,
                                        const float *residual, int relu, int B, int C, int N, int Co, int precision,
-                                       float *y, cl3d_stream_t stream) {
+                                       float *y, void *ws, size_t ws_bytes, cl3d_stream_t stream) {
   GEMM_COMMON_CHECKS("conv1x1_bn_act_fwd");
   CL3D_REQUIRE(W && (B == 0 || (x && y)) && (!scale == !shift), "conv1x1_bn_act_fwd: null pointer");
   if (B == 0) return CL3D_OK;
-  GemmArgs a{};
-  a.A = plain(W, C, 1, Co, C);
-  a.B = channel_major(x, B, C, N, true);
-  a.D = y; a.d_si = N; a.d_sj = 1; a.d_fold_n = B > 1 ? N : 0; a.d_sb = (long long)Co * N;
-  a.K = C;
-  a.ep_scale = scale; a.ep_shift = shift; a.ep_res = residual; a.ep_relu = relu;
-  return run_gemm(a, precision, (hipStream_t)stream, "cl3d_conv1x1_bn_act_fwd");
+  return conv_forward(x, W, scale, shift, residual, relu, B, C, N, Co, precision, y, ws, ws_bytes, (hipStream_t)stream,
+                      "cl3d_conv1x1_bn_act_fwd");
 }
 
 extern "C" int cl3d_conv1x1_bwd_data(const float *dy, const float *W, int B, int C, int N, int Co, int precision,
-                                     float *dx, cl3d_stream_t stream) {
+                                     float *dx, void *ws, size_t ws_bytes, cl3d_stream_t stream) {
   GEMM_COMMON_CHECKS("conv1x1_bwd_data");
   CL3D_REQUIRE(W && (B == 0 || (dy && dx)), "conv1x1_bwd_data: null pointer");
   if (B == 0) return CL3D_OK;
   GemmArgs a{};  // D[i = c][j = (cloud, point)] = sum_o W[o][c] dy[o][point]
   a.A = plain(W, 1, C, C, Co);
   a.B = channel_major(dy, B, Co, N, true);
-  a.D = dx; a.d_si = N; a.d_sj = 1; a.d_fold_n = B > 1 ? N : 0; a.d_sb = (long long)C * N;
+  a.out.D = dx; a.out.si = N; a.out.sj = 1; a.out.fold_n = B > 1 ? N : 0; a.out.sb = (long long)C * N;
   a.K = Co;
-  return run_gemm(a, precision, (hipStream_t)stream, "cl3d_conv1x1_bwd_data");
+  return run_gemm<0>(a, precision, kMaxSplitFwd, ws, ws_bytes, nullptr, 0, 0, (hipStream_t)stream, "cl3d_conv1x1_bwd_data");
 }
 
 extern "C" int cl3d_conv1x1_bwd_weight(const float *x, const float *dy, int B, int C, int N, int Co, int precision,
@@ -730,5 +803,8 @@ extern "C" int cl3d_conv1x1_bwd_weight(const float *x, const float *dy, int B, i
   GemmArgs a{};  // D[i = o][j = c] = sum_(cloud, point) dy[o][point] x[c][point]
   a.A = channel_major(dy, B, Co, N, false);
   a.B = channel_major(x, B, C, N, false);
-  return run_wgrad<0>(a, precision, B, N, ws, ws_bytes, dW, nullptr, Co, C, (hipStream_t)stream, "cl3d_conv1x1_bwd_weight");
+  a.K = B * N;
+  a.out.D = dW; a.out.si = C; a.out.sj = 1;
+  return run_gemm<0>(a, precision, kMaxSplitWgrad, ws, ws_bytes, nullptr, 0, 0, (hipStream_t)stream,
+                     "cl3d_conv1x1_bwd_weight");
 }

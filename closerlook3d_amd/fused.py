@@ -68,6 +68,13 @@ def _stream(t):
     return _lib.stream_ptr(t.device)
 
 
+def _gemm_scratch(op, B, N, Co, C, device):
+    """Scratch for the K-slice partials of a per-point contraction (cl3d_workspace_bytes(CL3D_OP_POINT_GEMM = 14 /
+    CL3D_OP_CONV1X1 = 15)): (tensor, bytes); the tensor is kept alive by the caller until its launches are queued."""
+    nbytes = _lib.lib().cl3d_workspace_bytes(op, B, N, Co, 0, C)
+    return torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=device), nbytes
+
+
 def _build_inverse(idx, n_support):
     B = idx.shape[0]
     MK = idx[0].numel()
@@ -443,9 +450,10 @@ class _PointRows(Function):
         wr = torch.empty((Co, 3), dtype=torch.float32, device=dev)
         wcat = torch.empty((2 * Co, C), dtype=torch.float32, device=dev)
         ght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
+        ws, ws_bytes = _gemm_scratch(14, B, N, Co, C, dev)
         with _lib.on_device(dev):
             _lib.check(_lib.lib().cl3d_pwmlp_point_gemm_fwd(_p(features), _p(W), B, C, N, Co, precision, _p(ght), _p(wr),
-                                                            _p(wcat), _stream(features)))
+                                                            _p(wcat), _p(ws), ws_bytes, _stream(features)))
         ctx.save_for_backward(features, wcat)
         ctx.precision = precision
         return ght, wr
@@ -461,15 +469,15 @@ class _PointRows(Function):
         if dght is None:
             dght = torch.zeros((B, N, 2 * Co), dtype=torch.float32, device=dev)
         dght = dght.contiguous()
+        ws, ws_bytes = _gemm_scratch(14, B, N, Co, C, dev)  # stream-ordered: the two products use it one after the other
         with _lib.on_device(dev):
             st = _stream(features)
             if ctx.needs_input_grad[0]:
                 dfeat = torch.empty((B, C, N), dtype=torch.float32, device=dev)
-                _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_data(_p(dght), _p(wcat), B, C, N, Co, ctx.precision, _p(dfeat), st))
+                _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_data(_p(dght), _p(wcat), B, C, N, Co, ctx.precision, _p(dfeat),
+                                                              _p(ws), ws_bytes, st))
             if ctx.needs_input_grad[1]:
                 dW = torch.empty((Co, 3 + 2 * C), dtype=torch.float32, device=dev)
-                ws_bytes = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)  # CL3D_OP_POINT_GEMM
-                ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=dev)
                 dwr = dwr.contiguous() if dwr is not None else None
                 _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_weight(_p(features), _p(dght), _p(dwr), B, C, N, Co,
                                                                 ctx.precision, _p(dW), _p(ws), ws_bytes, st))
@@ -550,8 +558,9 @@ class _Conv1x1(Function):
         B, C, N = x.shape
         Co = W.shape[0]
         y = torch.empty((B, Co, N), dtype=torch.float32, device=x.device)
+        ws, ws_bytes = _gemm_scratch(15, B, N, Co, C, x.device)
         with _lib.on_device(x.device):
-            _lib.check(_lib.lib().cl3d_conv1x1_fwd(_p(x), _p(W), B, C, N, Co, precision, _p(y), _stream(x)))
+            _lib.check(_lib.lib().cl3d_conv1x1_fwd(_p(x), _p(W), B, C, N, Co, precision, _p(y), _p(ws), ws_bytes, _stream(x)))
         ctx.save_for_backward(x, W)
         ctx.precision = precision
         return y
@@ -564,15 +573,14 @@ class _Conv1x1(Function):
         dy = dy.contiguous()
         lib = _lib.lib()
         dx = dW = None
+        ws, ws_bytes = _gemm_scratch(15, B, N, Co, C, x.device)
         with _lib.on_device(x.device):
             st = _stream(x)
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
-                _lib.check(lib.cl3d_conv1x1_bwd_data(_p(dy), _p(W), B, C, N, Co, ctx.precision, _p(dx), st))
+                _lib.check(lib.cl3d_conv1x1_bwd_data(_p(dy), _p(W), B, C, N, Co, ctx.precision, _p(dx), _p(ws), ws_bytes, st))
             if ctx.needs_input_grad[1]:
                 dW = torch.empty_like(W)
-                ws_bytes = lib.cl3d_workspace_bytes(15, B, N, Co, 0, C)  # CL3D_OP_CONV1X1
-                ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=x.device)
                 _lib.check(lib.cl3d_conv1x1_bwd_weight(_p(x), _p(dy), B, C, N, Co, ctx.precision, _p(dW), _p(ws), ws_bytes, st))
         return dx, dW, None
 
@@ -676,13 +684,15 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, res_conv=None, res_bn=Non
                 s2, t2 = _folded(res_bn)
                 Cr = res_conv.weight.shape[1]
                 ys = torch.empty((B, Co, N), dtype=torch.float32, device=x.device)
+                ws, ws_bytes = _gemm_scratch(15, B, N, Co, Cr, x.device)
                 _lib.check(lib.cl3d_conv1x1_bn_act_fwd(_p(res), _p(res_conv.weight.view(Co, Cr).contiguous()), _p(s2), _p(t2),
-                                                       None, 0, B, Cr, N, Co, prec, _p(ys), st))
+                                                       None, 0, B, Cr, N, Co, prec, _p(ys), _p(ws), ws_bytes, st))
                 res = ys
             s1, t1 = _folded(bn)
             y = torch.empty((B, Co, N), dtype=torch.float32, device=x.device)
+            ws, ws_bytes = _gemm_scratch(15, B, N, Co, C, x.device)
             _lib.check(lib.cl3d_conv1x1_bn_act_fwd(_p(x), _p(W.contiguous()), _p(s1), _p(t1), _p(res), int(relu), B, C, N, Co,
-                                                   prec, _p(y), st))
+                                                   prec, _p(y), _p(ws), ws_bytes, st))
         return y
     for b in (bn, res_bn):
         if b is not None and b.num_batches_tracked is not None:

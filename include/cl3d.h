@@ -228,30 +228,32 @@ int cl3d_pwmlp_partials(int B, int M, int Co);
  *   fwd:        ght; also leaves wr [Co,3] = W_r (nullable) and wcat [2Co,C] = [W_d ; W_c - W_d] (one small launch);
  *   bwd_data:   d features [B,C,N] from d ght and the wcat the forward call produced;
  *   bwd_weight: d W [Co, 3+2C] from features, d ght and d wr [Co,3] (nullable: zeros); the sum over all B*N points
- *               is cut into slices summed in a fixed order (bit-reproducible);
- *               ws: cl3d_workspace_bytes(CL3D_OP_POINT_GEMM, B, N, Co, 0, C). */
+ *               is cut into slices summed in a fixed order (bit-reproducible).
+ * ws: cl3d_workspace_bytes(CL3D_OP_POINT_GEMM, B, N, Co, 0, C) covers all three; the forward and data-gradient
+ * products use it to cut a long contraction into K slices when the output has too few tiles to fill the chip (deep
+ * stages) and run unsplit -- same result up to summation order -- when ws is NULL; bwd_weight requires it. */
 #define CL3D_PRECISION_F32 0
 #define CL3D_PRECISION_BF16 1
 int cl3d_pwmlp_point_gemm_fwd(const float *features, const float *W, int B, int C, int N, int Co, int precision,
-                              float *ght, float *wr, float *wcat, cl3d_stream_t stream);
+                              float *ght, float *wr, float *wcat, void *ws, size_t ws_bytes, cl3d_stream_t stream);
 int cl3d_pwmlp_point_gemm_bwd_data(const float *dght, const float *wcat, int B, int C, int N, int Co, int precision,
-                                   float *dfeatures, cl3d_stream_t stream);
+                                   float *dfeatures, void *ws, size_t ws_bytes, cl3d_stream_t stream);
 int cl3d_pwmlp_point_gemm_bwd_weight(const float *features, const float *dght, const float *dwr, int B, int C,
                                      int N, int Co, int precision, float *dW, void *ws, size_t ws_bytes,
                                      cl3d_stream_t stream);
 /* The 1x1 Conv1d layers either side of the operator (backbones/resnet.py:32-39,58-66; bias-free), same kernel:
  * y [B,Co,N] = W [Co,C] x [B,C,N], its input gradient and its weight gradient
- * (ws: cl3d_workspace_bytes(CL3D_OP_CONV1X1, B, N, Co, 0, C)). */
-int cl3d_conv1x1_fwd(const float *x, const float *W, int B, int C, int N, int Co, int precision, float *y,
-                     cl3d_stream_t stream);
+ * (ws: cl3d_workspace_bytes(CL3D_OP_CONV1X1, B, N, Co, 0, C); optional for fwd / bwd_data as above). */
+int cl3d_conv1x1_fwd(const float *x, const float *W, int B, int C, int N, int Co, int precision, float *y, void *ws,
+                     size_t ws_bytes, cl3d_stream_t stream);
 /* inference form: y = act(scale[o] * (W x)[o] + shift[o] + residual) with the eval-mode BatchNorm folded to a
  * per-channel affine map, the shortcut add (residual [B,Co,N], nullable) and the ReLU (relu != 0) in the epilogue;
  * scale / shift nullable together (plain convolution). */
 int cl3d_conv1x1_bn_act_fwd(const float *x, const float *W, const float *scale, const float *shift,
                             const float *residual, int relu, int B, int C, int N, int Co, int precision, float *y,
-                            cl3d_stream_t stream);
+                            void *ws, size_t ws_bytes, cl3d_stream_t stream);
 int cl3d_conv1x1_bwd_data(const float *dy, const float *W, int B, int C, int N, int Co, int precision, float *dx,
-                          cl3d_stream_t stream);
+                          void *ws, size_t ws_bytes, cl3d_stream_t stream);
 int cl3d_conv1x1_bwd_weight(const float *x, const float *dy, int B, int C, int N, int Co, int precision, float *dW,
                             void *ws, size_t ws_bytes, cl3d_stream_t stream);
 /* weight plumbing of the factored contraction: W [Co,3+2C] = [W_r | W_c | W_d] -> wr [Co,3], wcat [2Co,C] =

@@ -54,8 +54,8 @@ def measure(B=16, C=64, N=4096, Co=64, reps=50, library=True):
     io_bytes = 4.0 * (B * C * N + B * N * 2 * Co)  # one operand in, the other out (weights are negligible)
     out = {"shape": {"B": B, "C": C, "N": N, "Co": Co}, "flops_per_gemm": flops, "hbm_bytes_per_gemm": io_bytes}
     for name, prec in (("f32", 0), ("bf16", 1)):
-        t_f = _time(lambda: lib.cl3d_pwmlp_point_gemm_fwd(p(f), p(W), B, C, N, Co, prec, p(ght), p(wr), p(wcat), st), reps)
-        t_d = _time(lambda: lib.cl3d_pwmlp_point_gemm_bwd_data(p(dght), p(wcat), B, C, N, Co, prec, p(dfeat), st), reps)
+        t_f = _time(lambda: lib.cl3d_pwmlp_point_gemm_fwd(p(f), p(W), B, C, N, Co, prec, p(ght), p(wr), p(wcat), p(ws), ws_bytes, st), reps)
+        t_d = _time(lambda: lib.cl3d_pwmlp_point_gemm_bwd_data(p(dght), p(wcat), B, C, N, Co, prec, p(dfeat), p(ws), ws_bytes, st), reps)
         t_w = _time(lambda: lib.cl3d_pwmlp_point_gemm_bwd_weight(p(f), p(dght), p(dwr), B, C, N, Co, prec, p(dW), p(ws),
                                                                   ws_bytes, st), reps)
         tot = t_f + t_d + t_w
@@ -85,6 +85,45 @@ def measure(B=16, C=64, N=4096, Co=64, reps=50, library=True):
     return out
 
 
+def measure_conv(B, C, N, Co, reps=30):
+    """One 1x1 convolution C -> Co over B clouds of N points: the engine's three products against torch's Conv1d
+    (MIOpen / rocBLAS) forward and backward, microseconds."""
+    dev = torch.device("cuda:0")
+    lib = _lib.lib()
+    p = lambda t: t.data_ptr()  # noqa: E731
+    g = torch.Generator(device="cpu").manual_seed(0)
+    x = torch.randn(B, C, N, generator=g).to(dev)
+    W = (torch.randn(Co, C, generator=g) / C ** 0.5).to(dev)
+    dy = torch.randn(B, Co, N, generator=g).to(dev)
+    y, dx, dW = torch.empty(B, Co, N, device=dev), torch.empty(B, C, N, device=dev), torch.empty(Co, C, device=dev)
+    ws_bytes = lib.cl3d_workspace_bytes(15, B, N, Co, 0, C)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
+    st = _lib.stream_ptr(dev)
+    out = {"conv": {"B": B, "C": C, "N": N, "Co": Co}, "gflop": 2.0 * B * N * C * Co / 1e9}
+    for name, prec in (("f32", 0), ("bf16", 1)):
+        out[name] = [round(_time(fn, reps) * 1e6, 1) for fn in (
+            lambda: lib.cl3d_conv1x1_fwd(p(x), p(W), B, C, N, Co, prec, p(y), p(ws), ws_bytes, st),
+            lambda: lib.cl3d_conv1x1_bwd_data(p(dy), p(W), B, C, N, Co, prec, p(dx), p(ws), ws_bytes, st),
+            lambda: lib.cl3d_conv1x1_bwd_weight(p(x), p(dy), B, C, N, Co, prec, p(dW), p(ws), ws_bytes, st))]
+    conv = torch.nn.Conv1d(C, Co, 1, bias=False).to(dev)
+    xr = x.clone().requires_grad_(True)
+    t_f = _time(lambda: conv(xr), reps)
+
+    def fb():
+        conv.weight.grad = None
+        xr.grad = None
+        conv(xr).backward(dy)
+
+    t_fb = _time(fb, reps)
+    out["library_f32"] = [round(t_f * 1e6, 1), round((t_fb - t_f) * 1e6, 1)]  # forward, backward (both gradients)
+    return out
+
+
+CONFIG2_CONVS = [(3, 72, 4096), (72, 72, 4096), (72, 144, 4096), (144, 144, 4096), (144, 288, 1024), (288, 144, 1024),
+                 (288, 288, 1024), (288, 576, 256), (576, 288, 256), (576, 576, 256), (576, 1152, 64), (1152, 576, 64),
+                 (1152, 1152, 64), (1152, 2304, 16), (2304, 1152, 16)]
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--B", type=int, default=16)
@@ -93,8 +132,13 @@ if __name__ == "__main__":
     ap.add_argument("--Co", type=int, default=64)
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--sweep", action="store_true", help="also the ModelNet backbone's operator shapes (width 144)")
+    ap.add_argument("--convs", action="store_true", help="the 1x1 convolutions of the ModelNet backbone (config 2) vs torch Conv1d")
     ap.add_argument("--tiles", action="store_true", help="tuning: every workgroup tile (CL3D_GEMM_TILE) per shape, f32 and bf16")
     a = ap.parse_args()
+    if a.convs:
+        for C, Co, N in CONFIG2_CONVS:
+            print(json.dumps(measure_conv(a.B, C, N, Co, a.reps)))
+        sys.exit(0)
     if a.tiles:
         shapes = [(a.C, a.N)] + ([(72, 4096), (144, 1024), (288, 256), (576, 64)] if a.sweep else [])
         for C, N in shapes:

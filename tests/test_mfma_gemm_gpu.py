@@ -69,16 +69,16 @@ def test_point_gemm_forward_and_gradients(B, C, N, Co, prec):
     wr = torch.empty(Co, 3, device=_dev())
     wcat = torch.empty(2 * Co, C, device=_dev())
     ght = torch.full((B, N, 2 * Co), float("nan"), device=_dev())
-    _lib.check(lib.cl3d_pwmlp_point_gemm_fwd(_p(f), _p(W), B, C, N, Co, prec, _p(ght), _p(wr), _p(wcat), _st()))
+    ws_bytes = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=_dev())
+    _lib.check(lib.cl3d_pwmlp_point_gemm_fwd(_p(f), _p(W), B, C, N, Co, prec, _p(ght), _p(wr), _p(wcat), _p(ws), ws_bytes, _st()))
     wc64 = _wcat64(W, Co, C)
     assert torch.equal(wr, W[:, :3].contiguous())
     assert torch.equal(wcat.double(), torch.cat([W[:, 3 + C:], W[:, 3:3 + C] - W[:, 3 + C:]], 0).double())  # f32 subtraction
     want = torch.einsum("bcn,oc->bno", f.double(), wc64)
     dfeat = torch.full((B, C, N), float("nan"), device=_dev())
-    _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_data(_p(dght), _p(wcat), B, C, N, Co, prec, _p(dfeat), _st()))
+    _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_data(_p(dght), _p(wcat), B, C, N, Co, prec, _p(dfeat), _p(ws), ws_bytes, _st()))
     want_df = torch.einsum("bno,oc->bcn", dght.double(), wc64)
-    ws_bytes = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)
-    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=_dev())
     dW = torch.full((Co, 3 + 2 * C), float("nan"), device=_dev())
     _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_weight(_p(f), _p(dght), _p(dwr), B, C, N, Co, prec, _p(dW), _p(ws), ws_bytes, _st()))
     dwcat = torch.einsum("bno,bcn->oc", dght.double(), f.double())
@@ -106,7 +106,7 @@ def test_point_gemm_forward_and_gradients(B, C, N, Co, prec):
 
 
 @pytest.mark.parametrize("B,C,N,Co", [(2, 72, 4096, 144), (4, 144, 1000, 36), (1, 3, 130, 72), (2, 1152, 64, 576),
-                                      (1, 288, 10000, 288)])
+                                      (1, 288, 10000, 288), (16, 2304, 16, 1152), (16, 1152, 16, 2304)])  # deep: K slices
 @pytest.mark.parametrize("prec", [0, 1])
 def test_conv1x1_matches_conv1d(B, C, N, Co, prec):
     lib = _lib.lib()
@@ -119,8 +119,12 @@ def test_conv1x1_matches_conv1d(B, C, N, Co, prec):
     dW = torch.full((Co, C), float("nan"), device=_dev())
     ws_bytes = lib.cl3d_workspace_bytes(15, B, N, Co, 0, C)
     ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=_dev())
-    _lib.check(lib.cl3d_conv1x1_fwd(_p(x), _p(W), B, C, N, Co, prec, _p(y), _st()))
-    _lib.check(lib.cl3d_conv1x1_bwd_data(_p(dy), _p(W), B, C, N, Co, prec, _p(dx), _st()))
+    _lib.check(lib.cl3d_conv1x1_fwd(_p(x), _p(W), B, C, N, Co, prec, _p(y), _p(ws), ws_bytes, _st()))
+    _lib.check(lib.cl3d_conv1x1_bwd_data(_p(dy), _p(W), B, C, N, Co, prec, _p(dx), _p(ws), ws_bytes, _st()))
+    if prec == 0:  # without scratch the products run unsplit: same values up to the summation order
+        y0 = torch.empty_like(y)
+        _lib.check(lib.cl3d_conv1x1_fwd(_p(x), _p(W), B, C, N, Co, prec, _p(y0), None, 0, _st()))
+        assert _rel(y0, y.double()) <= TOL
     _lib.check(lib.cl3d_conv1x1_bwd_weight(_p(x), _p(dy), B, C, N, Co, prec, _p(dW), _p(ws), ws_bytes, _st()))
     rnd = (lambda t: t.double()) if prec == 0 else _bf16_round
     xr, wr, gr = rnd(x), rnd(W), rnd(dy)
@@ -137,7 +141,7 @@ def test_conv1x1_matches_conv1d(B, C, N, Co, prec):
 
 def test_bad_arguments_are_refused():
     lib = _lib.lib()
-    assert lib.cl3d_pwmlp_point_gemm_fwd(None, None, 1, 8, 16, 4, 0, None, None, None, None) == -1
-    assert lib.cl3d_conv1x1_fwd(None, None, 1, 8, 16, 4, 7, None, None) == -1  # precision 7
+    assert lib.cl3d_pwmlp_point_gemm_fwd(None, None, 1, 8, 16, 4, 0, None, None, None, None, 0, None) == -1
+    assert lib.cl3d_conv1x1_fwd(None, None, 1, 8, 16, 4, 7, None, None, 0, None) == -1  # precision 7
     x = torch.zeros(1, 8, 16, device=_dev())
     assert lib.cl3d_conv1x1_bwd_weight(_p(x), _p(x), 1, 8, 16, 8, 0, _p(x), None, 0, None) == -3  # workspace
