@@ -325,13 +325,13 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
       sb[DEPTH - 1].template load<BM>(a.B, j0, g * KC, a.K);
     }
   };
-  auto multiply = [&](int buf) {
+  auto multiply = [&](int buf, int g) {
     const unsigned char *ldsA = lds + (NBUF == 2 ? buf : 0) * kPair, *ldsB = ldsA + SA::kLdsBytes;
+    const int kleft = a.K - g * KC;  // the last chunk of a K that is not a multiple of KC stops early
     if constexpr (PREC == PREC_F32) {
       const float *TA = reinterpret_cast<const float *>(ldsA), *TB = reinterpret_cast<const float *>(ldsB);
       const int strA = SA::type::stride(a.A), strB = SB::type::stride(a.B);
-#pragma unroll 4
-      for (int kk = 0; kk < KC / 2; ++kk) {
+      auto kstep = [&](int kk) {
         float fa[WI], fb[WJ];
 #pragma unroll
         for (int x = 0; x < WI; ++x) fa[x] = TA[(2 * kk + lh) * strA + wi0 + 32 * x + lr];
@@ -342,11 +342,19 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
 #pragma unroll
           for (int y = 0; y < WJ; ++y)
             acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x], fb[y], acc[x][y], 0, 0, 0);
+      };
+      if (kleft >= KC) {
+#pragma unroll 4
+        for (int kk = 0; kk < KC / 2; ++kk) kstep(kk);
+      } else {
+        const int steps = (kleft + 1) / 2;
+#pragma unroll 1
+        for (int kk = 0; kk < steps; ++kk) kstep(kk);
       }
     } else {
       const uint4 *TA = reinterpret_cast<const uint4 *>(ldsA), *TB = reinterpret_cast<const uint4 *>(ldsB);
-#pragma unroll
-      for (int ks = 0; ks < KC / 16; ++ks) {
+      const int steps = kleft >= KC ? KC / 16 : (kleft + 15) / 16;
+      for (int ks = 0; ks < steps; ++ks) {
         uint4 fa[WI], fb[WJ];
 #pragma unroll
         for (int x = 0; x < WI; ++x) fa[x] = TA[(2 * ks + lh) * (TI + 1) + wi0 + 32 * x + lr];
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
       } else {
         if (g + 1 < g1) issue(0, g + 1);
       }
-      multiply(0);
+      multiply(0, g);
       if (g + 1 < g1) to_lds(DEPTH == 2 ? 1 : 0, 1);
       __syncthreads();
       if (g + 1 >= g1) break;
@@ -404,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
       } else {
         if (g + 2 < g1) issue(0, g + 2);
       }
-      multiply(1);
+      multiply(1, g + 1);
       if (g + 2 < g1) to_lds(0, 0);
       __syncthreads();
     }
@@ -415,13 +423,13 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
       to_lds(0, 0);
       __syncthreads();
       if (g + 2 < g1) issue(0, g + 2);
-      multiply(0);
+      multiply(0, g);
       if (g + 1 < g1) {
         __syncthreads();
         to_lds(1, 0);
         __syncthreads();
         if (g + 3 < g1) issue(1, g + 3);
-        multiply(0);
+        multiply(0, g + 1);
       }
     }
   } else {
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
       to_lds(0, 0);
       __syncthreads();
       if (g + 1 < g1) issue(0, g + 1);
-      multiply(0);
+      multiply(0, g);
     }
   }
 
@@ -579,12 +587,15 @@ constexpr int kCUs = 256;
 
 static int kc_of(int precision) { return precision == PREC_BF16 ? 64 : 32; }
 
-// Workgroup tile and K slicing for an I x J output over K.  A workgroup's four waves sit on the four SIMDs of a CU,
-// so a CU works through its workgroups' MFMA chains one after the other: time ~ rounds x (accumulators per wave) x
-// (chunks per slice), rounds = workgroups / CUs, never below one (the chain is serial per wave).  Few tiles and a
-// long K (the deep stages: 256 points x 2304 channels; every weight gradient) are cut along K into slices whose
-// partial tiles are summed in slice order by gemm_reduce_kernel; a slice keeps >= 4 chunks and the partials must
-// fit the caller's scratch.  Ties go to the larger tile (fewer re-staged operand bytes).
+// Workgroup tile and K slicing for an I x J output over K.  Two regimes decide the time of a product here:
+//   * matrix-core bound: padded flops / 157 TFLOP/s (f32) -- padding matters, these layers have I or J = 72 .. 288;
+//   * latency bound: a workgroup keeps <= 2 chunks (16-32 KB) in flight, and ~100 KB per CU are needed to cover
+//     HBM/L2 latency at the rate the MFMAs consume operands, so a CU wants `resident` workgroups (what registers and
+//     LDS admit) and the grid >= CUs x resident; with fewer the time stretches by that ratio.
+// Outputs with few tiles and a long K (the deep stages: 256 points x 2304 channels; every weight gradient) are
+// therefore cut along K into slices whose partial tiles are summed in slice order by gemm_reduce_kernel; a slice
+// costs its partial tile written and read once (priced at 4 TB/s), keeps >= 4 chunks, and the partials must fit the
+// caller's scratch.  The candidate with the smallest estimate wins; ties go to the larger tile.
 struct Plan {
   int wi, wj, nsplit, cps;
 };
@@ -592,34 +603,34 @@ struct Plan {
 static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes) {
   const int kc = kc_of(precision);
   const long long chunks = (K + kc - 1) / kc;
-  const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  const int cand[4][3] = {{2, 2, 2}, {2, 1, 3}, {1, 2, 3}, {1, 1, 4}};  // wi, wj, resident workgroups per CU
+  const double peak_flops_per_us = precision == PREC_BF16 ? 1.2e9 : 157.3e6;  // bf16: what staging sustains, not 2.5 PF
   Plan best{2, 2, 1, (int)chunks};
   double best_cost = 1e300;
   int force_wi = 0, force_wj = 0;
   if (const char *force = getenv("CL3D_GEMM_TILE")) {  // tuning override "wi,wj" (scripts/bench_point_gemm.py --tiles)
     if (sscanf(force, "%d,%d", &force_wi, &force_wj) != 2) force_wi = force_wj = 0;
   }
+  long long force_split = 0;
+  if (const char *force = getenv("CL3D_GEMM_SPLIT")) force_split = atoll(force);  // tuning override
   for (int c = 0; c < 4; ++c) {
-    const int wi = cand[c][0], wj = cand[c][1];
+    const int wi = cand[c][0], wj = cand[c][1], resident = cand[c][2];
     if (force_wi && (wi != force_wi || wj != force_wj)) continue;
-    const long long tiles = (long long)ceil_div(I, 64 * wi) * ceil_div(J, 64 * wj);
-    long long split = 1;
-    if (tiles < kCUs && max_split > 1) {
-      split = (kCUs + tiles - 1) / tiles;                       // fill the chip once
-      if (split > chunks / 4) split = chunks / 4;               // >= 4 chunks per slice
-      if (split > max_split) split = max_split;
-      while (split > 1 && (size_t)split * I * J * sizeof(float) > ws_bytes) --split;
-      if (split < 1) split = 1;
-    }
-    const long long cps = (chunks + split - 1) / split;
-    split = (chunks + cps - 1) / cps;
-    double rounds = (double)(tiles * split) / kCUs;
-    if (rounds < 1.0) rounds = 1.0;
-    // multiply time + what a slice costs on top (partial tile out and back in, ~one chunk's worth per slice pair)
-    const double cost = rounds * wi * wj * (double)(cps + (split > 1 ? 2 : 0));
-    if (cost < best_cost * 0.97) {
-      best_cost = cost;
-      best = Plan{wi, wj, (int)split, (int)cps};
+    const long long ti = ceil_div(I, 64 * wi), tj = ceil_div(J, 64 * wj), tiles = ti * tj;
+    const double flops = 2.0 * (double)(ti * 64 * wi) * (double)(tj * 64 * wj) * (double)K;
+    for (long long split = 1; split <= max_split && split <= (chunks >= 4 ? chunks / 4 : 1); split += (split < 4 ? 1 : split / 2)) {
+      if (force_split && split != force_split && force_split <= max_split) continue;
+      if (split > 1 && (size_t)split * I * J * sizeof(float) > ws_bytes) break;
+      const long long cps = (chunks + split - 1) / split;
+      const long long real_split = (chunks + cps - 1) / cps;
+      double fill = (double)(tiles * real_split) / (double)(kCUs * resident);
+      if (fill > 1.0) fill = 1.0;
+      const double partial_us = real_split > 1 ? 2.0 * (double)real_split * I * J * 4.0 / 4.0e6 : 0.0;
+      const double cost = flops / peak_flops_per_us / fill + partial_us + 2.0;
+      if (cost < best_cost * 0.97) {
+        best_cost = cost;
+        best = Plan{wi, wj, (int)real_split, (int)cps};
+      }
     }
   }
   return best;

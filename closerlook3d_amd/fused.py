@@ -425,6 +425,9 @@ class _PointwiseMLP(Function):
         return (dght, dwr, dgamma, dbeta) + (None,) * 10
 
 
+import os
+
+CONV_ENGINE = os.environ.get('CL3D_CONV', 'mfma')  # 'mfma': csrc/mfma_gemm.hip; 'library': torch's Conv1d (A/B only)
 PRECISIONS = {'f32': 0, 'bf16': 1}  # CL3D_PRECISION_*: arithmetic of the dense contraction only
 POINT_GEMM = 'mfma'  # 'mfma': csrc/mfma_gemm.hip; 'bmm': the library GEMM (kept for scripts/bench_point_gemm.py's A/B)
 
@@ -697,9 +700,13 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, res_conv=None, res_bn=Non
     for b in (bn, res_bn):
         if b is not None and b.num_batches_tracked is not None:
             b.num_batches_tracked.add_(1)
-    y1 = _Conv1x1.apply(x, W, prec)
-    x2 = residual
-    if res_conv is not None:
-        x2 = _Conv1x1.apply(residual, res_conv.weight.view(Co, res_conv.weight.shape[1]), prec)
+    if CONV_ENGINE == 'library':
+        y1 = torch.nn.functional.conv1d(x, conv.weight)
+        x2 = torch.nn.functional.conv1d(residual, res_conv.weight) if res_conv is not None else residual
+    else:
+        y1 = _Conv1x1.apply(x, W, prec)
+        x2 = residual
+        if res_conv is not None:
+            x2 = _Conv1x1.apply(residual, res_conv.weight.view(Co, res_conv.weight.shape[1]), prec)
     return _BnAddRelu.apply(y1, bn.weight, bn.bias, x2, res_bn.weight if res_bn is not None else None,
                             res_bn.bias if res_bn is not None else None, bn, res_bn, relu)

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--impl", default="auto")
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
+                    help="arithmetic of the dense contractions (PointWiseMLP rows and 1x1 convolutions); BASELINE config 2 is bf16")
     ap.add_argument("--no-cache", action="store_true", help="disable the per-forward ball-query memo")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python")
     args = ap.parse_args()
@@ -45,6 +47,7 @@ def main():
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     cfg = make_config(kind, args.impl)
+    cfg["cl3d_precision"] = args.precision
     if kind == "pospool" and "deep" in args.config:
         cfg.pospool.position_embedding = "sin_cos"
     net = ResNet(cfg, 3, radius, dl, nsamples, npoints, width=width, depth=2, bottleneck_ratio=2).to(dev).train(True)
@@ -91,7 +94,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"config": args.config, "operator": kind, "clouds": B, "points": N, "width": width,
-                      "launch": "hip_graph" if graph is not None else "eager",
+                      "precision": args.precision, "launch": "hip_graph" if graph is not None else "eager",
                       "ms_per_step": round(dt * 1e3, 3), "input_points_per_s": round(B * N / dt, 1),
                       "params_M": round(sum(p.numel() for p in net.parameters()) / 1e6, 2),
                       "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}))

@@ -144,4 +144,7 @@ def test_bad_arguments_are_refused():
     assert lib.cl3d_pwmlp_point_gemm_fwd(None, None, 1, 8, 16, 4, 0, None, None, None, None, 0, None) == -1
     assert lib.cl3d_conv1x1_fwd(None, None, 1, 8, 16, 4, 7, None, None, 0, None) == -1  # precision 7
     x = torch.zeros(1, 8, 16, device=_dev())
-    assert lib.cl3d_conv1x1_bwd_weight(_p(x), _p(x), 1, 8, 16, 8, 0, _p(x), None, 0, None) == -3  # workspace
+    w = torch.zeros(4, 3 + 16, device=_dev())
+    g = torch.zeros(1, 16, 8, device=_dev())
+    # the PointWiseMLP weight gradient always goes through the reduce kernel: scratch is mandatory
+    assert lib.cl3d_pwmlp_point_gemm_bwd_weight(_p(x), _p(g), None, 1, 8, 16, 4, 0, _p(w), None, 0, None) == -3
