@@ -21,13 +21,18 @@ def _conv_bn(cin, cout, momentum, relu):
     return nn.Sequential(*layers)
 
 
+import os
+
+_BLOCK_ENGINE = os.environ.get('CL3D_BLOCK', 'engine')  # 'modules': nn.Conv1d / BatchNorm1d as in round 1 (A/B only)
+
+
 def run_conv_bn(seq, x, impl='auto', precision='f32', residual=None, shortcut=None):
     """A `_conv_bn` unit (Conv1d + BatchNorm1d [+ ReLU]) -- optionally the tail of a bottleneck: + residual (through the
     `shortcut` unit when given), then ReLU -- through the engine's kernels (fused.conv_bn_act: MFMA convolutions, fused
     BatchNorm / add / ReLU passes, BatchNorm folded into the convolution in inference), or module by module as the
     reference runs it when impl == 'grouped' or the configuration is outside what the kernels cover."""
     relu = len(seq) == 3 or residual is not None
-    if impl != 'grouped' and x.is_cuda:
+    if impl != 'grouped' and x.is_cuda and _BLOCK_ENGINE != 'modules':
         from . import fused
         y = fused.conv_bn_act(x, seq[0], seq[1], relu=relu, residual=residual,
                               res_conv=shortcut[0] if shortcut is not None else None,

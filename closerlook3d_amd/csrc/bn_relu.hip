@@ -288,6 +288,127 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(Bn2Args a) {
   }
 }
 
+// ---- few values per channel (the deep stages: 16 clouds x 16 .. 1024 points, hundreds to thousands of channels): ONE
+// workgroup per channel does the statistics pass, the per-channel algebra and the apply pass in a single launch (the
+// second read comes out of L2) instead of three launches whose grids are mostly launch overhead.
+constexpr int kBnSmallMax = 16384;  // B*N up to here: <= 64 elements per thread and pass
+
+struct BnSmallArgs {
+  const float *x1, *x2, *g, *out_ref;
+  const float *gamma1, *beta1, *gamma2, *beta2;
+  float *rm1, *rv1, *rm2, *rv2;
+  float *vec1, *vec2;    // [4,C]: scale, shift, mean, invstd (written by forward, read by backward)
+  float *coef1, *coef2;  // [5,C]: A, Bc, D, d gamma, d beta (backward)
+  float *o1, *o2;
+  int B, C, N;
+  float eps1, mom1, eps2, mom2;
+  int mode2, relu;
+};
+
+__device__ __forceinline__ void channel_stats(const float *x, int c, int B, int C, int N, double *scratch, double &mean,
+                                              double &var) {
+  float s0 = 0.f, s1 = 0.f;
+  const int total = B * N;
+  for (int t = threadIdx.x; t < total; t += 256) {
+    const int b = t / N, n = t - b * N;
+    const float v = x[((size_t)b * C + c) * N + n];
+    s0 += v;
+    s1 = __builtin_fmaf(v, v, s1);
+  }
+  const double t0 = block_sum((double)s0, scratch);
+  const double t1 = block_sum((double)s1, scratch);
+  mean = t0 / total;
+  var = t1 / total - mean * mean;
+  var = var > 0.0 ? var : 0.0;
+}
+
+__global__ __launch_bounds__(256) void bn2_fwd_small_kernel(BnSmallArgs a) {
+  __shared__ double scratch[4];
+  __shared__ float s_par[4];
+  const int c = blockIdx.x, total = a.B * a.N;
+  double mean, var;
+  channel_stats(a.x1, c, a.B, a.C, a.N, scratch, mean, var);
+  if (threadIdx.x == 0) {
+    const double invstd = 1.0 / sqrt(var + (double)a.eps1), scale = (double)a.gamma1[c] * invstd;
+    s_par[0] = (float)scale;
+    s_par[1] = (float)((double)a.beta1[c] - mean * scale);
+    a.vec1[c] = s_par[0]; a.vec1[a.C + c] = s_par[1]; a.vec1[2 * a.C + c] = (float)mean; a.vec1[3 * a.C + c] = (float)invstd;
+    if (a.rm1) {
+      const double unbiased = var * ((double)total / (total > 1 ? total - 1.0 : 1.0));
+      a.rm1[c] = a.rm1[c] * (1.0f - a.mom1) + a.mom1 * (float)mean;
+      a.rv1[c] = a.rv1[c] * (1.0f - a.mom1) + a.mom1 * (float)unbiased;
+    }
+  }
+  if (a.mode2 == 2) {
+    channel_stats(a.x2, c, a.B, a.C, a.N, scratch, mean, var);
+    if (threadIdx.x == 0) {
+      const double invstd = 1.0 / sqrt(var + (double)a.eps2), scale = (double)a.gamma2[c] * invstd;
+      s_par[2] = (float)scale;
+      s_par[3] = (float)((double)a.beta2[c] - mean * scale);
+      a.vec2[c] = s_par[2]; a.vec2[a.C + c] = s_par[3]; a.vec2[2 * a.C + c] = (float)mean; a.vec2[3 * a.C + c] = (float)invstd;
+      if (a.rm2) {
+        const double unbiased = var * ((double)total / (total > 1 ? total - 1.0 : 1.0));
+        a.rm2[c] = a.rm2[c] * (1.0f - a.mom2) + a.mom2 * (float)mean;
+        a.rv2[c] = a.rv2[c] * (1.0f - a.mom2) + a.mom2 * (float)unbiased;
+      }
+    }
+  }
+  __syncthreads();
+  const float s1 = s_par[0], t1 = s_par[1];
+  const float s2 = a.mode2 == 2 ? s_par[2] : 1.f, t2 = a.mode2 == 2 ? s_par[3] : 0.f;
+  for (int t = threadIdx.x; t < total; t += 256) {
+    const int b = t / a.N, n = t - b * a.N;
+    const size_t at = ((size_t)b * a.C + c) * a.N + n;
+    float z = __builtin_fmaf(a.x1[at], s1, t1);
+    if (a.mode2 == 1) z += a.x2[at];
+    else if (a.mode2 == 2) z += __builtin_fmaf(a.x2[at], s2, t2);
+    a.o1[at] = (a.relu && !(z > 0.f)) ? 0.f : z;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn2_bwd_small_kernel(BnSmallArgs a) {
+  __shared__ double scratch[4];
+  __shared__ float s_co[6];
+  const int c = blockIdx.x, total = a.B * a.N;
+  const float mu1 = a.vec1[2 * a.C + c], is1 = a.vec1[3 * a.C + c];
+  const float mu2 = a.mode2 == 2 ? a.vec2[2 * a.C + c] : 0.f, is2 = a.mode2 == 2 ? a.vec2[3 * a.C + c] : 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  for (int t = threadIdx.x; t < total; t += 256) {
+    const int b = t / a.N, n = t - b * a.N;
+    const size_t at = ((size_t)b * a.C + c) * a.N + n;
+    const float dz = (a.relu && !(a.out_ref[at] > 0.f)) ? 0.f : a.g[at];
+    s0 += dz;
+    s1 = __builtin_fmaf(dz, (a.x1[at] - mu1) * is1, s1);
+    if (a.mode2 == 2) s2 = __builtin_fmaf(dz, (a.x2[at] - mu2) * is2, s2);
+  }
+  const double t0 = block_sum((double)s0, scratch);
+  const double t1 = block_sum((double)s1, scratch);
+  const double t2 = block_sum((double)s2, scratch);
+  if (threadIdx.x == 0) {
+    auto coeffs = [&](double gamma, double mean, double invstd, double sxh, float *coef, float *sh) {
+      const double A = gamma * invstd;
+      const double D = -A * invstd * sxh / total;
+      const double Bc = -A * t0 / total - D * mean;
+      coef[c] = (float)A; coef[a.C + c] = (float)Bc; coef[2 * a.C + c] = (float)D;
+      coef[3 * a.C + c] = (float)sxh; coef[4 * a.C + c] = (float)t0;
+      sh[0] = (float)A; sh[1] = (float)Bc; sh[2] = (float)D;
+    };
+    coeffs((double)a.gamma1[c], (double)mu1, (double)is1, t1, a.coef1, s_co);
+    if (a.mode2 == 2) coeffs((double)a.gamma2[c], (double)mu2, (double)is2, t2, a.coef2, s_co + 3);
+  }
+  __syncthreads();
+  const float A1 = s_co[0], B1 = s_co[1], D1 = s_co[2];
+  const float A2 = a.mode2 == 2 ? s_co[3] : 1.f, B2 = a.mode2 == 2 ? s_co[4] : 0.f, D2 = a.mode2 == 2 ? s_co[5] : 0.f;
+  for (int t = threadIdx.x; t < total; t += 256) {
+    const int b = t / a.N, n = t - b * a.N;
+    const size_t at = ((size_t)b * a.C + c) * a.N + n;
+    const float dz = (a.relu && !(a.out_ref[at] > 0.f)) ? 0.f : a.g[at];
+    a.o1[at] = __builtin_fmaf(A1, dz, __builtin_fmaf(D1, a.x1[at], B1));
+    if (a.mode2 == 1) a.o2[at] = dz;
+    else if (a.mode2 == 2) a.o2[at] = __builtin_fmaf(A2, dz, __builtin_fmaf(D2, a.x2[at], B2));
+  }
+}
+
 static void bn_shape(BnArgs &a) {
   a.span = 16384;
   a.chunks = ceil_div(a.N, a.span);
@@ -385,6 +506,16 @@ extern "C" int cl3d_bn_add_relu_bwd(const float *g, const float *out, const floa
   CL3D_REQUIRE(!gamma2 || (x2 && mean2 && invstd2 && coef2), "bn_add_relu_bwd: second BatchNorm incomplete");
   CL3D_REQUIRE(n_partials == cl3d_bn_partials(B, C, N) && n_partials <= 65535, "bn_add_relu_bwd: wrong partial count");
   hipStream_t st = (hipStream_t)stream;
+  if ((long long)B * N <= kBnSmallMax && mean1 + C == invstd1 && (!gamma2 || mean2 + C == invstd2)) {
+    // few values per channel and the statistics in the [4,C] block cl3d_bn_add_relu_train_fwd leaves: one launch
+    BnSmallArgs s{};
+    s.g = g; s.out_ref = out; s.x1 = x1; s.x2 = x2; s.gamma1 = gamma1; s.gamma2 = gamma2;
+    s.vec1 = const_cast<float *>(mean1) - 2 * C; s.vec2 = gamma2 ? const_cast<float *>(mean2) - 2 * C : nullptr;
+    s.coef1 = coef1; s.coef2 = coef2; s.o1 = dx1; s.o2 = dx2; s.B = B; s.C = C; s.N = N;
+    s.mode2 = !x2 ? 0 : (gamma2 ? 2 : 1); s.relu = relu;
+    hipLaunchKernelGGL(bn2_bwd_small_kernel, dim3(C), dim3(256), 0, st, s);
+    return check_launch("cl3d_bn_add_relu_bwd(small)");
+  }
   Bn2Args a{};
   a.g = g; a.out_ref = out; a.x1 = x1; a.mu1 = mean1; a.is1 = invstd1; a.x2 = x2; a.mu2 = mean2; a.is2 = invstd2;
   a.B = B; a.C = C; a.N = N; a.relu = relu; a.mode2 = !x2 ? 0 : (gamma2 ? 2 : 1);
@@ -405,4 +536,40 @@ extern "C" int cl3d_bn_add_relu_bwd(const float *g, const float *out, const floa
   const long long work = (long long)B * C * ceil_div(N, 1024);
   hipLaunchKernelGGL(bn2_bwd_apply_kernel, dim3((unsigned)(work < 65536 ? work : 65536)), dim3(256), 0, st, a);
   return check_launch("cl3d_bn_add_relu_bwd");
+}
+
+// training forward in one call: batch statistics of x1 (and of x2 when it has its own BatchNorm: gamma2 != NULL), running
+// statistics updated with nn.BatchNorm1d's rule, vec1 / vec2 [4,C] = scale, shift, mean, invstd left for the backward
+// pass, out = act(BN1(x1) + R).  One launch when a channel has few values, statistics + apply passes otherwise.
+extern "C" int cl3d_bn_add_relu_train_fwd(const float *x1, const float *gamma1, const float *beta1, float *running_mean1,
+                                          float *running_var1, float eps1, float momentum1, const float *x2,
+                                          const float *gamma2, const float *beta2, float *running_mean2,
+                                          float *running_var2, float eps2, float momentum2, int relu, int B, int C, int N,
+                                          double *partial, int n_partials, float *vec1, float *vec2, float *out,
+                                          cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(B >= 1 && C >= 1 && N >= 1, "bn_add_relu_train_fwd: bad sizes");
+  CL3D_REQUIRE(x1 && gamma1 && beta1 && vec1 && out && (!gamma2 || (x2 && beta2 && vec2)), "bn_add_relu_train_fwd: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int mode2 = !x2 ? 0 : (gamma2 ? 2 : 1);
+  if ((long long)B * N <= kBnSmallMax) {
+    BnSmallArgs s{};
+    s.x1 = x1; s.x2 = x2; s.gamma1 = gamma1; s.beta1 = beta1; s.gamma2 = gamma2; s.beta2 = beta2;
+    s.rm1 = running_mean1; s.rv1 = running_var1; s.rm2 = running_mean2; s.rv2 = running_var2;
+    s.vec1 = vec1; s.vec2 = vec2; s.o1 = out; s.B = B; s.C = C; s.N = N;
+    s.eps1 = eps1; s.mom1 = momentum1; s.eps2 = eps2; s.mom2 = momentum2; s.mode2 = mode2; s.relu = relu;
+    hipLaunchKernelGGL(bn2_fwd_small_kernel, dim3(C), dim3(256), 0, st, s);
+    return check_launch("cl3d_bn_add_relu_train_fwd(small)");
+  }
+  CL3D_REQUIRE(partial && n_partials == cl3d_bn_partials(B, C, N), "bn_add_relu_train_fwd: partial buffer");
+  int rc = cl3d_bn_relu_stats(x1, B, C, N, partial, n_partials, (double)B * N, eps1, momentum1, gamma1, beta1, running_mean1,
+                              running_var1, vec1, vec1 + C, vec1 + 2 * C, vec1 + 3 * C, stream);
+  if (rc != CL3D_OK) return rc;
+  if (mode2 == 2) {
+    rc = cl3d_bn_relu_stats(x2, B, C, N, partial, n_partials, (double)B * N, eps2, momentum2, gamma2, beta2, running_mean2,
+                            running_var2, vec2, vec2 + C, vec2 + 2 * C, vec2 + 3 * C, stream);
+    if (rc != CL3D_OK) return rc;
+  }
+  return cl3d_bn_add_relu_apply(x1, vec1, vec1 + C, x2, mode2 == 2 ? vec2 : nullptr, mode2 == 2 ? vec2 + C : nullptr, relu, B,
+                                C, N, out, stream);
 }

@@ -513,6 +513,37 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restric
   }
 }
 
+// few slices (the forward / input-gradient products: nsplit <= 16): one thread per four consecutive elements of a row,
+// slices added in order p = 0, 1, ...; 16-byte loads and stores, no LDS.  Needs J % 4 == 0 and, for a folded output,
+// fold_n % 4 == 0 (four neighbours never straddle a row or a cloud).
+__global__ __launch_bounds__(256) void gemm_reduce4_kernel(const float *__restrict__ part, int nsplit, int I, int J, OutMap o) {
+  const long long IJ = (long long)I * J, n4 = IJ / 4;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+    const long long e = q * 4;
+    float4 acc = *reinterpret_cast<const float4 *>(part + e);
+    for (int p = 1; p < nsplit; ++p) {
+      const float4 v = *reinterpret_cast<const float4 *>(part + (size_t)p * IJ + e);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const int i = (int)(e / J), j = (int)(e - (long long)i * J);
+    const long long at = i * o.si + out_col(o, j);
+    if (o.ep_scale) {
+      const float sc = o.ep_scale[i], sh = o.ep_shift[i];
+      acc.x = __builtin_fmaf(acc.x, sc, sh); acc.y = __builtin_fmaf(acc.y, sc, sh);
+      acc.z = __builtin_fmaf(acc.z, sc, sh); acc.w = __builtin_fmaf(acc.w, sc, sh);
+    }
+    if (o.ep_res) {
+      const float4 r = *reinterpret_cast<const float4 *>(o.ep_res + at);
+      acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+    }
+    if (o.ep_relu) {
+      acc.x = acc.x > 0.f ? acc.x : 0.f; acc.y = acc.y > 0.f ? acc.y : 0.f;
+      acc.z = acc.z > 0.f ? acc.z : 0.f; acc.w = acc.w > 0.f ? acc.w : 0.f;
+    }
+    *reinterpret_cast<float4 *>(o.D + at) = acc;
+  }
+}
+
 // W [Co, 3+2C] = [W_r | W_c | W_d]  ->  wr [Co,3] and the per-point GEMM weight wcat [2Co, C] = [W_d ; W_c - W_d]
 // (one small launch per forward pass; both gradients read wcat again)
 __global__ __launch_bounds__(256) void pwmlp_weights_kernel(const float *__restrict__ W, int Co, int C,
@@ -625,7 +656,7 @@ static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, s
       const long long real_split = (chunks + cps - 1) / cps;
       double fill = (double)(tiles * real_split) / (double)(kCUs * resident);
       if (fill > 1.0) fill = 1.0;
-      const double partial_us = real_split > 1 ? 2.0 * (double)real_split * I * J * 4.0 / 4.0e6 : 0.0;
+      const double partial_us = real_split > 1 ? 3.0 + 2.0 * (double)real_split * I * J * 4.0 / 2.5e6 : 0.0;
       const double cost = flops / peak_flops_per_us / fill + partial_us + 2.0;
       if (cost < best_cost * 0.97) {
         best_cost = cost;
@@ -677,6 +708,15 @@ static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t 
   else launch_modes<PREC_F32>(a, p.wi, p.wj, (int)blocks, st);
   int rc = check_launch(who);
   if (rc != CL3D_OK || !reduce) return rc;
+  if (REDUCE_MODE == 0 && p.nsplit <= 16 && J % 4 == 0 && final_out.sj == 1 && final_out.si % 4 == 0 &&
+      (final_out.fold_n == 0 || (final_out.fold_n % 4 == 0 && final_out.sb % 4 == 0)) &&
+      (reinterpret_cast<uintptr_t>(final_out.D) & 15u) == 0 &&
+      (!final_out.ep_res || (reinterpret_cast<uintptr_t>(final_out.ep_res) & 15u) == 0)) {
+    long long g4 = ((long long)I * J / 4 + 255) / 256;
+    if (g4 > 8192) g4 = 8192;
+    hipLaunchKernelGGL(gemm_reduce4_kernel, dim3((unsigned)g4), dim3(256), 0, st, a.partial, p.nsplit, I, J, final_out);
+    return check_launch(who);
+  }
   const long long n_el = REDUCE_MODE == 0 ? (long long)I * J : (long long)Co * C;
   long long grid = (n_el + 15) / 16;
   if (grid > 16384) grid = 16384;

@@ -277,7 +277,8 @@ def max_pool(query_xyz, support_xyz, query_mask, support_mask, features, radius,
 
 
 class _BnRelu(Function):
-    """ReLU(BatchNorm1d(x)) on channel-major x [B,C,N]; csrc/bn_relu.hip.  x is the only tensor kept for backward."""
+    """ReLU(BatchNorm1d(x)) on channel-major x [B,C,N]; csrc/bn_relu.hip.  Training: one launch each way when a channel
+    has few values (deep stages), statistics + apply passes otherwise; x and the output are kept for backward."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps):
@@ -292,18 +293,17 @@ class _BnRelu(Function):
                 vec = torch.empty((4, C), dtype=torch.float32, device=dev)
                 nparts = lib.cl3d_bn_partials(B, C, N)
                 partial = torch.empty((nparts, C, 2), dtype=torch.float64, device=dev)
-                _lib.check(lib.cl3d_bn_relu_stats(_p(x), B, C, N, _p(partial), nparts, float(B * N), float(eps),
-                                                  float(momentum), _p(gamma), _p(beta), _p(running_mean),
-                                                  _p(running_var), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), st))
-                scale, shift = vec[0], vec[1]
-                ctx.save_for_backward(x, vec, gamma)
+                _lib.check(lib.cl3d_bn_add_relu_train_fwd(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
+                                                          float(eps), float(momentum), None, None, None, None, None, 0.0,
+                                                          0.0, 1, B, C, N, _p(partial), nparts, _p(vec), None, _p(out), st))
+                ctx.save_for_backward(x, out, vec, gamma)
                 ctx.meta = (B, C, N, nparts)
             else:
                 invstd64 = torch.rsqrt(running_var.double() + eps)
                 scale64 = gamma.double() * invstd64
                 scale = scale64.float()
                 shift = (beta.double() - running_mean.double() * scale64).float()
-            _lib.check(lib.cl3d_bn_relu_apply(_p(x), _p(scale), _p(shift), B, C, N, _p(out), st))
+                _lib.check(lib.cl3d_bn_relu_apply(_p(x), _p(scale), _p(shift), B, C, N, _p(out), st))
         ctx.training = training
         return out
 
@@ -311,17 +311,17 @@ class _BnRelu(Function):
     def backward(ctx, g):
         if not ctx.training:
             raise NotImplementedError("fused BatchNorm+ReLU backward needs training-mode statistics")
-        x, vec, gamma = ctx.saved_tensors
+        x, out, vec, gamma = ctx.saved_tensors
         B, C, N, nparts = ctx.meta
         g = g.contiguous()
         dev = g.device
         dx = torch.empty_like(x)
         coef = torch.empty((5, C), dtype=torch.float32, device=dev)
-        partial = torch.empty((nparts, C, 2), dtype=torch.float64, device=dev)
+        partial = torch.empty((2, nparts, C, 2), dtype=torch.float64, device=dev)
         with _lib.on_device(dev):
-            _lib.check(_lib.lib().cl3d_bn_relu_bwd(_p(g), _p(x), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _p(gamma),
-                                                  B, C, N, float(B * N), _p(partial), nparts, _p(coef), _p(dx),
-                                                  _stream(g)))
+            _lib.check(_lib.lib().cl3d_bn_add_relu_bwd(_p(g), _p(out), _p(x), _p(vec[2]), _p(vec[3]), _p(gamma), None, None,
+                                                      None, None, 1, B, C, N, float(B * N), _p(partial), nparts, _p(coef),
+                                                      None, _p(dx), None, _stream(g)))
         return dx, coef[3], coef[4], None, None, None, None, None
 
 
@@ -588,40 +588,31 @@ class _Conv1x1(Function):
         return dx, dW, None
 
 
-def _batch_stats(x, bn, vec):
-    """Training-mode statistics of x for `bn` (scale, shift, mean, invstd into vec [4,C]; running statistics updated
-    with nn.BatchNorm1d's rule)."""
-    B, C, N = x.shape
-    lib = _lib.lib()
-    nparts = lib.cl3d_bn_partials(B, C, N)
-    partial = torch.empty((nparts, C, 2), dtype=torch.float64, device=x.device)
-    _lib.check(lib.cl3d_bn_relu_stats(_p(x), B, C, N, _p(partial), nparts, float(B * N), float(bn.eps),
-                                      float(bn.momentum), _p(bn.weight), _p(bn.bias), _p(bn.running_mean),
-                                      _p(bn.running_var), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _stream(x)))
-
-
 class _BnAddRelu(Function):
-    """out = ReLU(BN1(x1) + R), R = 0 | x2 | BN2(x2), training-mode statistics (csrc/bn_relu.hip).  One streaming
-    pass forward, two backward; x1, x2 and the output are what is kept for the backward pass."""
+    """out = ReLU(BN1(x1) + R), R = 0 | x2 | BN2(x2), training-mode statistics (csrc/bn_relu.hip).  One launch each way
+    when a channel has few values (deep stages), statistics + apply passes otherwise; x1, x2 and the output are what is
+    kept for the backward pass."""
 
     @staticmethod
     def forward(ctx, x1, gamma1, beta1, x2, gamma2, beta2, bn1, bn2, relu):
         x1 = x1.contiguous()
         B, C, N = x1.shape
         dev = x1.device
+        lib = _lib.lib()
         out = torch.empty_like(x1)
         vec1 = torch.empty((4, C), dtype=torch.float32, device=dev)
-        vec2 = None
+        vec2 = torch.empty((4, C), dtype=torch.float32, device=dev) if bn2 is not None else None
+        if x2 is not None:
+            x2 = x2.contiguous()
+        nparts = lib.cl3d_bn_partials(B, C, N)
+        partial = torch.empty((nparts, C, 2), dtype=torch.float64, device=dev)
         with _lib.on_device(dev):
-            _batch_stats(x1, bn1, vec1)
-            if x2 is not None:
-                x2 = x2.contiguous()
-                if bn2 is not None:
-                    vec2 = torch.empty((4, C), dtype=torch.float32, device=dev)
-                    _batch_stats(x2, bn2, vec2)
-            _lib.check(_lib.lib().cl3d_bn_add_relu_apply(
-                _p(x1), _p(vec1[0]), _p(vec1[1]), _p(x2), _p(vec2[0]) if vec2 is not None else None,
-                _p(vec2[1]) if vec2 is not None else None, int(relu), B, C, N, _p(out), _stream(x1)))
+            _lib.check(lib.cl3d_bn_add_relu_train_fwd(
+                _p(x1), _p(gamma1), _p(beta1), _p(bn1.running_mean), _p(bn1.running_var), float(bn1.eps), float(bn1.momentum),
+                _p(x2), _p(gamma2) if bn2 is not None else None, _p(beta2) if bn2 is not None else None,
+                _p(bn2.running_mean) if bn2 is not None else None, _p(bn2.running_var) if bn2 is not None else None,
+                float(bn2.eps) if bn2 is not None else 0.0, float(bn2.momentum) if bn2 is not None else 0.0, int(relu),
+                B, C, N, _p(partial), nparts, _p(vec1), _p(vec2), _p(out), _stream(x1)))
         ctx.save_for_backward(x1, x2, out, vec1, vec2, gamma1, gamma2)
         ctx.relu = relu
         return out

@@ -157,6 +157,15 @@ int cl3d_bn_relu_bwd(const float *g, const float *x, const float *scale, const f
 int cl3d_bn_add_relu_apply(const float *x1, const float *scale1, const float *shift1, const float *x2,
                            const float *scale2, const float *shift2, int relu, int B, int C, int N, float *out,
                            cl3d_stream_t stream);
+/* training forward of the same in one call (statistics of each BatchNorm, running-statistics update, apply): vec1 / vec2
+ * [4,C] receive scale, shift, mean, invstd -- pass vec + 2C / vec + 3C as mean / invstd to cl3d_bn_add_relu_bwd.  One
+ * launch per direction when a channel has <= 16384 values (the deep stages), statistics + apply passes otherwise;
+ * partial: [cl3d_bn_partials(B,C,N), C, 2] doubles (only touched on the multi-pass route). */
+int cl3d_bn_add_relu_train_fwd(const float *x1, const float *gamma1, const float *beta1, float *running_mean1,
+                               float *running_var1, float eps1, float momentum1, const float *x2, const float *gamma2,
+                               const float *beta2, float *running_mean2, float *running_var2, float eps2,
+                               float momentum2, int relu, int B, int C, int N, double *partial, int n_partials,
+                               float *vec1, float *vec2, float *out, cl3d_stream_t stream);
 int cl3d_bn_add_relu_bwd(const float *g, const float *out, const float *x1, const float *mean1, const float *invstd1,
                          const float *gamma1, const float *x2, const float *mean2, const float *invstd2,
                          const float *gamma2, int relu, int B, int C, int N, double count, double *partial,

@@ -5,7 +5,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 echo "== pytest (gemm, bottleneck)" | tee $OUT/summary.txt
-timeout 1200 python -m pytest tests/test_mfma_gemm_gpu.py tests/test_bottleneck_gpu.py -m gpu -q --timeout=900 -p no:cacheprovider > $OUT/pytest.log 2>&1
+timeout 1200 python -m pytest tests/test_mfma_gemm_gpu.py tests/test_bottleneck_gpu.py tests/test_operators_gpu.py -m gpu -q --timeout=900 -p no:cacheprovider > $OUT/pytest.log 2>&1
 echo "pytest rc=$?" | tee -a $OUT/summary.txt; grep -E "passed|failed|^FAILED|Error:" $OUT/pytest.log | tail -10 | tee -a $OUT/summary.txt
 echo "== raw kernel rate: 4096^3 as a 1x1 convolution (f32 / bf16 [fwd, dx, dW] us; 137.4 GFLOP each)" | tee -a $OUT/summary.txt
 timeout 300 python -c "
@@ -30,7 +30,8 @@ for ln in sys.stdin:
     print('%4d->%4d N=%4d  f32 %s  bf16 %s  lib %s' % (c['C'], c['Co'], c['N'], d['f32'], d['bf16'], d['library_f32']))
 " | tee -a $OUT/summary.txt
 echo "== backbone config 2: engine convs f32 / bf16 / library convs (+ engine BatchNorm passes) / grouped is the reference dataflow" | tee -a $OUT/summary.txt
-timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp 2>$OUT/bb.err | tail -1 | tee -a $OUT/summary.txt
+CL3D_BLOCK=modules timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp 2>$OUT/bb.err | tail -1 | tee -a $OUT/summary.txt
+timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp 2>>$OUT/bb.err | tail -1 | tee -a $OUT/summary.txt
 timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp --precision bf16 2>>$OUT/bb.err | tail -1 | tee -a $OUT/summary.txt
 CL3D_CONV=library timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp 2>>$OUT/bb.err | tail -1 | tee -a $OUT/summary.txt
 echo "== rocprofv3 of the config-2 backbone step (40 replays)" | tee -a $OUT/summary.txt
