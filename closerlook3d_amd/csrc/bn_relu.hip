@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(Bn2Args a) {
 // ---- few values per channel (the deep stages: 16 clouds x 16 .. 1024 points, hundreds to thousands of channels): ONE
 // workgroup per channel does the statistics pass, the per-channel algebra and the apply pass in a single launch (the
 // second read comes out of L2) instead of three launches whose grids are mostly launch overhead.
-constexpr int kBnSmallMax = 16384;  // B*N up to here: <= 64 elements per thread and pass
+constexpr int kBnSmallMax = 16384;  // B*N up to here (16 float4 items per thread and pass)
 
 struct BnSmallArgs {
   const float *x1, *x2, *g, *out_ref;
@@ -305,16 +305,52 @@ struct BnSmallArgs {
   int mode2, relu;
 };
 
+// walk one channel's B*N values, VEC (1 or 4) consecutive points at a time, four items in flight per thread;
+// f(offset of the first value, how many of the VEC are valid) -- items never straddle a cloud (VEC == 4 needs N % 4 == 0)
+template <int VEC, class F>
+__device__ __forceinline__ void for_channel(int c, int B, int C, int N, F &&f) {
+  const int per_row = N / VEC, items = B * per_row;
+#pragma unroll 4
+  for (int t = threadIdx.x; t < items; t += 256) {
+    const int b = t / per_row, n = (t - b * per_row) * VEC;
+    f(((size_t)b * C + c) * N + n);
+  }
+}
+
+template <int VEC>
+struct Pack {
+  float v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ Pack<VEC> ldp(const float *p) {
+  Pack<VEC> r;
+  if constexpr (VEC == 4) {
+    const float4 t = *reinterpret_cast<const float4 *>(p);
+    r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+  } else {
+    r.v[0] = p[0];
+  }
+  return r;
+}
+template <int VEC>
+__device__ __forceinline__ void stp(float *p, const Pack<VEC> &r) {
+  if constexpr (VEC == 4) *reinterpret_cast<float4 *>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+  else p[0] = r.v[0];
+}
+
+template <int VEC>
 __device__ __forceinline__ void channel_stats(const float *x, int c, int B, int C, int N, double *scratch, double &mean,
                                               double &var) {
   float s0 = 0.f, s1 = 0.f;
+  for_channel<VEC>(c, B, C, N, [&](size_t at) {
+    const Pack<VEC> v = ldp<VEC>(x + at);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      s0 += v.v[e];
+      s1 = __builtin_fmaf(v.v[e], v.v[e], s1);
+    }
+  });
   const int total = B * N;
-  for (int t = threadIdx.x; t < total; t += 256) {
-    const int b = t / N, n = t - b * N;
-    const float v = x[((size_t)b * C + c) * N + n];
-    s0 += v;
-    s1 = __builtin_fmaf(v, v, s1);
-  }
   const double t0 = block_sum((double)s0, scratch);
   const double t1 = block_sum((double)s1, scratch);
   mean = t0 / total;
@@ -322,12 +358,13 @@ __device__ __forceinline__ void channel_stats(const float *x, int c, int B, int 
   var = var > 0.0 ? var : 0.0;
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void bn2_fwd_small_kernel(BnSmallArgs a) {
   __shared__ double scratch[4];
   __shared__ float s_par[4];
   const int c = blockIdx.x, total = a.B * a.N;
   double mean, var;
-  channel_stats(a.x1, c, a.B, a.C, a.N, scratch, mean, var);
+  channel_stats<VEC>(a.x1, c, a.B, a.C, a.N, scratch, mean, var);
   if (threadIdx.x == 0) {
     const double invstd = 1.0 / sqrt(var + (double)a.eps1), scale = (double)a.gamma1[c] * invstd;
     s_par[0] = (float)scale;
@@ -340,7 +377,7 @@ __global__ __launch_bounds__(256) void bn2_fwd_small_kernel(BnSmallArgs a) {
     }
   }
   if (a.mode2 == 2) {
-    channel_stats(a.x2, c, a.B, a.C, a.N, scratch, mean, var);
+    channel_stats<VEC>(a.x2, c, a.B, a.C, a.N, scratch, mean, var);
     if (threadIdx.x == 0) {
       const double invstd = 1.0 / sqrt(var + (double)a.eps2), scale = (double)a.gamma2[c] * invstd;
       s_par[2] = (float)scale;
@@ -356,16 +393,22 @@ __global__ __launch_bounds__(256) void bn2_fwd_small_kernel(BnSmallArgs a) {
   __syncthreads();
   const float s1 = s_par[0], t1 = s_par[1];
   const float s2 = a.mode2 == 2 ? s_par[2] : 1.f, t2 = a.mode2 == 2 ? s_par[3] : 0.f;
-  for (int t = threadIdx.x; t < total; t += 256) {
-    const int b = t / a.N, n = t - b * a.N;
-    const size_t at = ((size_t)b * a.C + c) * a.N + n;
-    float z = __builtin_fmaf(a.x1[at], s1, t1);
-    if (a.mode2 == 1) z += a.x2[at];
-    else if (a.mode2 == 2) z += __builtin_fmaf(a.x2[at], s2, t2);
-    a.o1[at] = (a.relu && !(z > 0.f)) ? 0.f : z;
-  }
+  for_channel<VEC>(c, a.B, a.C, a.N, [&](size_t at) {
+    const Pack<VEC> u = ldp<VEC>(a.x1 + at);
+    Pack<VEC> v{}, o;
+    if (a.mode2) v = ldp<VEC>(a.x2 + at);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float z = __builtin_fmaf(u.v[e], s1, t1);
+      if (a.mode2 == 1) z += v.v[e];
+      else if (a.mode2 == 2) z += __builtin_fmaf(v.v[e], s2, t2);
+      o.v[e] = (a.relu && !(z > 0.f)) ? 0.f : z;
+    }
+    stp<VEC>(a.o1 + at, o);
+  });
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void bn2_bwd_small_kernel(BnSmallArgs a) {
   __shared__ double scratch[4];
   __shared__ float s_co[6];
@@ -373,14 +416,19 @@ __global__ __launch_bounds__(256) void bn2_bwd_small_kernel(BnSmallArgs a) {
   const float mu1 = a.vec1[2 * a.C + c], is1 = a.vec1[3 * a.C + c];
   const float mu2 = a.mode2 == 2 ? a.vec2[2 * a.C + c] : 0.f, is2 = a.mode2 == 2 ? a.vec2[3 * a.C + c] : 0.f;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-  for (int t = threadIdx.x; t < total; t += 256) {
-    const int b = t / a.N, n = t - b * a.N;
-    const size_t at = ((size_t)b * a.C + c) * a.N + n;
-    const float dz = (a.relu && !(a.out_ref[at] > 0.f)) ? 0.f : a.g[at];
-    s0 += dz;
-    s1 = __builtin_fmaf(dz, (a.x1[at] - mu1) * is1, s1);
-    if (a.mode2 == 2) s2 = __builtin_fmaf(dz, (a.x2[at] - mu2) * is2, s2);
-  }
+  for_channel<VEC>(c, a.B, a.C, a.N, [&](size_t at) {
+    const Pack<VEC> g = ldp<VEC>(a.g + at), u = ldp<VEC>(a.x1 + at);
+    Pack<VEC> r{}, v{};
+    if (a.relu) r = ldp<VEC>(a.out_ref + at);
+    if (a.mode2 == 2) v = ldp<VEC>(a.x2 + at);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float dz = (a.relu && !(r.v[e] > 0.f)) ? 0.f : g.v[e];
+      s0 += dz;
+      s1 = __builtin_fmaf(dz, (u.v[e] - mu1) * is1, s1);
+      if (a.mode2 == 2) s2 = __builtin_fmaf(dz, (v.v[e] - mu2) * is2, s2);
+    }
+  });
   const double t0 = block_sum((double)s0, scratch);
   const double t1 = block_sum((double)s1, scratch);
   const double t2 = block_sum((double)s2, scratch);
@@ -399,14 +447,20 @@ __global__ __launch_bounds__(256) void bn2_bwd_small_kernel(BnSmallArgs a) {
   __syncthreads();
   const float A1 = s_co[0], B1 = s_co[1], D1 = s_co[2];
   const float A2 = a.mode2 == 2 ? s_co[3] : 1.f, B2 = a.mode2 == 2 ? s_co[4] : 0.f, D2 = a.mode2 == 2 ? s_co[5] : 0.f;
-  for (int t = threadIdx.x; t < total; t += 256) {
-    const int b = t / a.N, n = t - b * a.N;
-    const size_t at = ((size_t)b * a.C + c) * a.N + n;
-    const float dz = (a.relu && !(a.out_ref[at] > 0.f)) ? 0.f : a.g[at];
-    a.o1[at] = __builtin_fmaf(A1, dz, __builtin_fmaf(D1, a.x1[at], B1));
-    if (a.mode2 == 1) a.o2[at] = dz;
-    else if (a.mode2 == 2) a.o2[at] = __builtin_fmaf(A2, dz, __builtin_fmaf(D2, a.x2[at], B2));
-  }
+  for_channel<VEC>(c, a.B, a.C, a.N, [&](size_t at) {
+    const Pack<VEC> g = ldp<VEC>(a.g + at), u = ldp<VEC>(a.x1 + at);
+    Pack<VEC> r{}, v{}, d1, d2;
+    if (a.relu) r = ldp<VEC>(a.out_ref + at);
+    if (a.mode2 == 2) v = ldp<VEC>(a.x2 + at);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float dz = (a.relu && !(r.v[e] > 0.f)) ? 0.f : g.v[e];
+      d1.v[e] = __builtin_fmaf(A1, dz, __builtin_fmaf(D1, u.v[e], B1));
+      d2.v[e] = a.mode2 == 2 ? __builtin_fmaf(A2, dz, __builtin_fmaf(D2, v.v[e], B2)) : dz;
+    }
+    stp<VEC>(a.o1 + at, d1);
+    if (a.mode2) stp<VEC>(a.o2 + at, d2);
+  });
 }
 
 static void bn_shape(BnArgs &a) {
@@ -513,7 +567,8 @@ extern "C" int cl3d_bn_add_relu_bwd(const float *g, const float *out, const floa
     s.vec1 = const_cast<float *>(mean1) - 2 * C; s.vec2 = gamma2 ? const_cast<float *>(mean2) - 2 * C : nullptr;
     s.coef1 = coef1; s.coef2 = coef2; s.o1 = dx1; s.o2 = dx2; s.B = B; s.C = C; s.N = N;
     s.mode2 = !x2 ? 0 : (gamma2 ? 2 : 1); s.relu = relu;
-    hipLaunchKernelGGL(bn2_bwd_small_kernel, dim3(C), dim3(256), 0, st, s);
+    if ((N & 3) == 0) hipLaunchKernelGGL(bn2_bwd_small_kernel<4>, dim3(C), dim3(256), 0, st, s);
+    else hipLaunchKernelGGL(bn2_bwd_small_kernel<1>, dim3(C), dim3(256), 0, st, s);
     return check_launch("cl3d_bn_add_relu_bwd(small)");
   }
   Bn2Args a{};
@@ -558,7 +613,8 @@ extern "C" int cl3d_bn_add_relu_train_fwd(const float *x1, const float *gamma1, 
     s.rm1 = running_mean1; s.rv1 = running_var1; s.rm2 = running_mean2; s.rv2 = running_var2;
     s.vec1 = vec1; s.vec2 = vec2; s.o1 = out; s.B = B; s.C = C; s.N = N;
     s.eps1 = eps1; s.mom1 = momentum1; s.eps2 = eps2; s.mom2 = momentum2; s.mode2 = mode2; s.relu = relu;
-    hipLaunchKernelGGL(bn2_fwd_small_kernel, dim3(C), dim3(256), 0, st, s);
+    if ((N & 3) == 0) hipLaunchKernelGGL(bn2_fwd_small_kernel<4>, dim3(C), dim3(256), 0, st, s);
+    else hipLaunchKernelGGL(bn2_fwd_small_kernel<1>, dim3(C), dim3(256), 0, st, s);
     return check_launch("cl3d_bn_add_relu_train_fwd(small)");
   }
   CL3D_REQUIRE(partial && n_partials == cl3d_bn_partials(B, C, N), "bn_add_relu_train_fwd: partial buffer");
