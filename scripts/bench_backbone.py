@@ -4,7 +4,17 @@
     python scripts/bench_backbone.py --config s3dis_pseudogrid        # config 3: one 40 960-point scene
     python scripts/bench_backbone.py --config partnet_adaptive        # config 4 (per-GPU share: B=4, N=10 000)
     python scripts/bench_backbone.py --config s3dis_pospool_deep      # config 5 (one 81 920-point scene, width x2)
-Synthetic clouds, random-init weights, f32.  Prints one JSON line.
+Synthetic clouds, random-init weights; f32 or, with --precision bf16, bf16 contractions (BASELINE config 2's dtype).
+Prints one JSON line on rank 0.
+
+Data parallel (reference function/train_modelnet_dist.py:117-125,206,280): one process per GPU, every rank
+the per-GPU share above (weak scaling), parameter gradients in one flat buffer averaged by a single RCCL all-reduce per
+step (closerlook3d_amd/dp.py), BatchNorm statistics per rank as in the reference:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \
+        scripts/bench_backbone.py --gpus 8 --config partnet_adaptive
+The compute (zero gradients, forward, backward) is one HIP graph, the all-reduce stays outside it, the optimiser step
+is a second graph; the line reports the step time (max over ranks), the all-reduce time (HIP events) and its bytes.
+CL3D_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 over gloo (exercises the N>1 code path on a 1-GPU box).
 """
 import argparse
 import json
@@ -14,6 +24,7 @@ import time
 
 import numpy as np
 import torch
+import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -32,6 +43,7 @@ CONFIGS = {
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="modelnet_pointwisemlp", choices=sorted(CONFIGS))
+    ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--impl", default="auto")
@@ -41,63 +53,123 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python")
     args = ap.parse_args()
     kind, B, N, radius, dl, nsamples, npoints, width = CONFIGS[args.config]
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
+    one_dev = os.environ.get("CL3D_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if one_dev else "nccl", **({} if one_dev else {"device_id": dev}))
     from closerlook3d_amd.backbones import ResNet
+    from closerlook3d_amd.dp import FlatGradients
     from closerlook3d_amd.pt_utils import ball_query_cache
     import contextlib
-    dev = torch.device("cuda:0")
-    torch.manual_seed(0)
+    torch.manual_seed(0)  # same parameters on every rank
     cfg = make_config(kind, args.impl)
     cfg["cl3d_precision"] = args.precision
     if kind == "pospool" and "deep" in args.config:
         cfg.pospool.position_embedding = "sin_cos"
     net = ResNet(cfg, 3, radius, dl, nsamples, npoints, width=width, depth=2, bottleneck_ratio=2).to(dev).train(True)
-    opt = torch.optim.SGD(net.parameters(), lr=1e-3)
-    xyz, mask, _ = synth_batch(B, N, 3, 7)
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-3)
+    xyz, mask, _ = synth_batch(B, N, 3, 7 + rank)  # every rank its own clouds / scene
     scale = 1.0 if N <= 16384 else 4.0  # scenes: metres; objects: unit cube
     xyz = (xyz * scale).astype(np.float32)
     x = torch.from_numpy(xyz).to(dev)
     m = torch.from_numpy(mask).to(dev)
     feats = x.transpose(1, 2).contiguous()
+    flat = FlatGradients(params) if world > 1 else None
 
-    def step():
-        opt.zero_grad(set_to_none=True)
+    def compute():
+        if flat is not None:
+            flat.zero_()
+        else:
+            opt.zero_grad(set_to_none=True)
         with (contextlib.nullcontext() if args.no_cache else ball_query_cache()):
             ep = net(x, m, feats)
         ep["res5_features"].square().mean().backward()
-        opt.step()
+        if world == 1:
+            opt.step()
+
+    def capture(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
+            fn()
+        return g
 
     # the step is hundreds of short kernels: replayed as one HIP graph unless --no-graph (same kernels, same work)
-    graph = None
+    graph = update_graph = None
     if not args.no_graph:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):
-                    step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                step()
+            graph = capture(compute)
+            if world > 1:
+                update_graph = capture(opt.step)
         except Exception as e:
             print(f"bench_backbone: HIP graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
-            graph = None
+            graph = update_graph = None
             torch.cuda.synchronize()
-    run = graph.replay if graph is not None else step
+    ar_events = []
+
+    def run():
+        if graph is not None:
+            graph.replay()
+        else:
+            compute()
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            flat.allreduce_mean(world)
+            e1.record()
+            ar_events.append((e0, e1))
+            if update_graph is not None:
+                update_graph.replay()
+            else:
+                opt.step()
+
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
+    ar_events.clear()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     dt = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"config": args.config, "operator": kind, "clouds": B, "points": N, "width": width,
-                      "precision": args.precision, "launch": "hip_graph" if graph is not None else "eager",
-                      "ms_per_step": round(dt * 1e3, 3), "input_points_per_s": round(B * N / dt, 1),
-                      "params_M": round(sum(p.numel() for p in net.parameters()) / 1e6, 2),
-                      "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}))
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        line = {"config": args.config, "operator": kind, "n_gpus": world, "clouds_per_gpu": B, "points": N, "width": width,
+                "precision": args.precision, "launch": "hip_graph" if graph is not None else "eager",
+                "ms_per_step": round(dt * 1e3, 3), "input_points_per_s": round(world * B * N / dt, 1), "scaling": "weak",
+                "params_M": round(sum(p.numel() for p in params) / 1e6, 2),
+                "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
+        if world > 1:
+            line["allreduce_ms"] = round(float(np.mean([a.elapsed_time(b) for a, b in ar_events])), 3)
+            line["allreduce_bytes"] = int(flat.buffer.numel() * 4)
+            line["backend"] = dist.get_backend()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

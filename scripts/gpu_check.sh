@@ -1,32 +1,43 @@
 #!/bin/bash
-# One GPU-box session: parity tests, reference pin, native golden vectors, bench (+ rocprof summary of the same
-# command), PMC traffic of the ball_query+group kernels, the other operators and the backbone configs.
+# One GPU-box session: parity tests, reference pin, bench (+ rocprof summary of the same command), PMC counters of the
+# timed step and of the ball_query+group boundary, contraction A/B, the other operators and the backbone configs.
 # Usage (from the repo root on the GPU box): bash scripts/gpu_check.sh [tag]
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 echo "== smoke" | tee $OUT/summary.txt
 timeout 600 python __graft_entry__.py smoke > $OUT/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $OUT/summary.txt
-echo "== pytest -m gpu (engine vs oracle, golden fixtures, reference pin, full-size properties)" | tee -a $OUT/summary.txt
-timeout 1500 python -m pytest tests -m gpu -q --timeout=600 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
-echo "pytest rc=$?" | tee -a $OUT/summary.txt; tail -3 $OUT/pytest_gpu.log | tee -a $OUT/summary.txt
-echo "== native golden from the reference kernels" | tee -a $OUT/summary.txt
-timeout 600 python tests/golden/make_native_golden.py $OUT/native_golden > $OUT/native_golden.log 2>&1; echo "golden rc=$?" | tee -a $OUT/summary.txt
+echo "== pytest -m gpu (engine vs oracle, golden fixtures, reference pin, full-size and scene-size properties, data parallel)" | tee -a $OUT/summary.txt
+timeout 2400 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
+echo "pytest rc=$?" | tee -a $OUT/summary.txt; tail -8 $OUT/pytest_gpu.log | tee -a $OUT/summary.txt
 echo "== bench (the driver's command, default flags)" | tee -a $OUT/summary.txt
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
 cat $OUT/bench.json | tee -a $OUT/summary.txt
+echo "== bench --precision bf16 (config 2's arithmetic)" | tee -a $OUT/summary.txt
+timeout 900 python bench.py --precision bf16 --no-cpu-baseline 2>/dev/null | tee $OUT/bench_bf16.json | cut -c1-300 | tee -a $OUT/summary.txt
 echo "== bench, eager launches" | tee -a $OUT/summary.txt
 timeout 900 python bench.py --no-graph --no-cpu-baseline --no-kernel-roofline 2>/dev/null | tee $OUT/bench_eager.json | cut -c1-260 | tee -a $OUT/summary.txt
 echo "== rocprofv3 kernel trace of the same bench command" | tee -a $OUT/summary.txt
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o bench -- python $R/bench.py --no-cpu-baseline > $R/$OUT/rocprof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
-python scripts/kstats.py $OUT/prof/bench_kernel_stats.csv 36 40 | tee -a $OUT/summary.txt
+python scripts/kstats.py $OUT/prof/bench_kernel_stats.csv 100 40 | tee -a $OUT/summary.txt
+echo "== PMC counters of the timed step (separate passes)" | tee -a $OUT/summary.txt
+n=0
+for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY"; do
+  n=$((n+1))
+  (cd /tmp && timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/$OUT/step_pmc$n -o pmc -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-roofline > $R/$OUT/step_pmc$n.log 2>&1)
+done
+python scripts/step_counters.py $OUT/step_pmc1 $OUT/step_pmc2 $OUT/step_pmc3 $OUT/step_pmc4 > $OUT/step_counters.json 2>> $OUT/summary.txt
+head -c 1200 $OUT/step_counters.json | tee -a $OUT/summary.txt
 echo "== PMC traffic of the ball_query+group kernels (separate passes)" | tee -a $OUT/summary.txt
 (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_fetch -o pmc -- python $R/scripts/pmc_kernels.py > $R/$OUT/pmc_fetch.log 2>&1)
 (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_write -o pmc -- python $R/scripts/pmc_kernels.py > $R/$OUT/pmc_write.log 2>&1)
 python scripts/pmc_kernels.py --parse $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json 2>> $OUT/summary.txt
-head -c 1500 $OUT/pmc_traffic.json | tee -a $OUT/summary.txt
+head -c 1200 $OUT/pmc_traffic.json | tee -a $OUT/summary.txt
+echo "== contraction A/B (engine MFMA f32 / bf16 vs the vendor library)" | tee -a $OUT/summary.txt
+timeout 600 python scripts/bench_point_gemm.py --sweep 2>/dev/null | tee $OUT/point_gemm.jsonl | cut -c1-700 | tee -a $OUT/summary.txt
+timeout 600 python scripts/bench_point_gemm.py --convs --reps 20 2>/dev/null > $OUT/convs.jsonl
 echo "== other operators (bench.py --operator)" | tee -a $OUT/summary.txt
 for op in pospool adaptive_weight pseudo_grid; do
   timeout 600 python bench.py --operator $op --no-cpu-baseline --no-kernel-roofline 2>/dev/null | tee $OUT/bench_$op.json | cut -c1-330 | tee -a $OUT/summary.txt
@@ -35,9 +46,15 @@ echo "== backbone steps (scripts/bench_backbone.py)" | tee -a $OUT/summary.txt
 for c in modelnet_small modelnet_pointwisemlp s3dis_pseudogrid partnet_adaptive s3dis_pospool_deep; do
   timeout 600 python scripts/bench_backbone.py --config $c 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
 done
-echo "== dataset-side grid subsampling (SURVEY 8(f) rank 2): engine vs the reference's C++ on the host" | tee -a $OUT/summary.txt
+timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp --precision bf16 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
+CL3D_BLOCK=modules timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp 2>/dev/null | tail -1 | sed 's/^/round-1 block path (library conv + BatchNorm modules): /' | tee -a $OUT/summary.txt
+echo "== steady-state kernel table of the config-2 backbone step (bf16)" | tee -a $OUT/summary.txt
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bb -o bb -- python $R/scripts/bench_backbone.py --config modelnet_pointwisemlp --precision bf16 --steps 40 > $R/$OUT/rocprof_bb.log 2>&1)
+python scripts/kstats.py $OUT/prof_bb/bb_kernel_stats.csv 47 50 | tee $OUT/backbone_steady_state.txt | head -30 | tee -a $OUT/summary.txt
+echo "== data parallel on one device (2 ranks over gloo): backbone" | tee -a $OUT/summary.txt
+CL3D_BENCH_ONE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 scripts/bench_backbone.py --gpus 2 --config partnet_adaptive 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
+echo "== dataset-side grid subsampling, voting, sphere crops" | tee -a $OUT/summary.txt
 timeout 600 python scripts/bench_dataset_grid.py 2>/dev/null | tee $OUT/bench_dataset_grid.json | tee -a $OUT/summary.txt
-echo "== vote bookkeeping and sphere crops on the device (SURVEY 8(f) ranks 3 and 2)" | tee -a $OUT/summary.txt
 timeout 300 python scripts/bench_voting.py 2>/dev/null | tee $OUT/bench_voting.json | tee -a $OUT/summary.txt
 timeout 300 python scripts/bench_sphere_crop.py 2>/dev/null | tee $OUT/bench_sphere_crop.json | tee -a $OUT/summary.txt
 # keep the merged output small: drop raw traces, keep stats and counter tables

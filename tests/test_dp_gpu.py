@@ -1,0 +1,128 @@
+"""SURVEY 8(e) on the engine itself: two ranks, each running the ENGINE's 5-stage ResNet on
+its own shard of the clouds, gradients exchanged by closerlook3d_amd.dp (bucketed / backward-overlapped, and the flat
+buffer the benches use) -- against the mean of the per-shard gradients computed in one process.  Both ranks sit on
+GPU 0 and talk over gloo (one-GPU box); the RCCL path differs only in the backend string.  BatchNorm statistics are
+per rank, as in the reference (train_modelnet_dist.py:206: broadcast_buffers=False, no SyncBN).
+Also: scripts/bench_backbone.py --gpus 2 runs end to end in that mode (graph capture + all-reduce outside the graph).
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests.helpers import default_config
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B_TOTAL, N, K = 4, 512, 16
+
+
+def _net(kind):
+    from closerlook3d_amd.backbones import ResNet
+    over = {"pospool__position_embedding": "xyz", "pospool__reduction": "avg"} if kind == "pospool" else \
+        {"pointwisemlp__feature_type": "dp_fi_df"}
+    torch.manual_seed(3)
+    cfg = default_config(kind, over)
+    return ResNet(cfg, 3, 0.15, 0.06, [K] * 5, [128, 48, 16, 8], width=24, depth=2, bottleneck_ratio=2).cuda().train(True)
+
+
+def _clouds():
+    from oracle import operators as oo
+    rng = np.random.default_rng(8)
+    xyz, mask = oo.make_cloud(rng, B_TOTAL, N, pad_frac=0.1)
+    return torch.from_numpy(xyz), torch.from_numpy(mask)
+
+
+def _grads(net, xyz, mask):
+    from closerlook3d_amd.pt_utils import ball_query_cache
+    xyz, mask = xyz.cuda(), mask.cuda()
+    with ball_query_cache():
+        ep = net(xyz, mask, xyz.transpose(1, 2).contiguous())
+    ep["res5_features"].square().mean().backward()
+
+
+def _worker(rank, world, port, kind, mode, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from closerlook3d_amd.dp import FlatGradients, GradientSynchronizer, shard_range
+        net = _net(kind)
+        params = list(net.parameters())
+        xyz, mask = _clouds()
+        lo, hi = shard_range(B_TOTAL, rank, world)
+        if mode == "bucketed":
+            sync = GradientSynchronizer(params, world, bucket_bytes=64 << 10)  # many buckets: launches overlap backward
+            _grads(net, xyz[lo:hi], mask[lo:hi])
+            sync.finish()
+        else:
+            flat = FlatGradients(params)
+            flat.zero_()
+            _grads(net, xyz[lo:hi], mask[lo:hi])
+            flat.allreduce_mean(world)
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save([p.grad.detach().cpu().clone() for p in params], out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,mode", [("pospool", "bucketed"), ("pointwisemlp", "flat")])
+def test_engine_backbone_gradient_mean_two_ranks(tmp_path, kind, mode):
+    from closerlook3d_amd.dp import shard_range
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "grads.pt")
+    mp.spawn(_worker, args=(2, port, kind, mode, out), nprocs=2, join=True)
+    got = torch.load(out)
+    xyz, mask = _clouds()
+    want = None
+    for r in range(2):
+        net = _net(kind)
+        lo, hi = shard_range(B_TOTAL, r, 2)
+        _grads(net, xyz[lo:hi], mask[lo:hi])
+        g = [p.grad.detach().cpu() for p in net.parameters()]
+        want = g if want is None else [a + b for a, b in zip(want, g)]
+    worst = 0.0
+    for a, b in zip(got, want):
+        b = b / 2
+        worst = max(worst, float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12))
+    assert worst <= 1e-4, f"data-parallel gradient mean differs from the single-process mean: {worst:.3e}"
+
+
+def test_backbone_bench_runs_data_parallel_on_one_device():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CL3D_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "scripts", "bench_backbone.py"), "--gpus", "2", "--config",
+           "modelnet_small", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["allreduce_bytes"] > 50e6 and line["ms_per_step"] > 0
+
+
+def test_bench_py_runs_data_parallel_on_one_device():
+    """bench.py's N > 1 path (graph for the compute, flat all-reduce outside it, update graph) with both ranks on GPU 0."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CL3D_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+           "--batch", "4", "--no-cpu-baseline", "--no-kernel-roofline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0

@@ -1,0 +1,132 @@
+"""GPU, at the scene configurations' FULL sizes (these ran only in scripts/bench_backbone.py, which checks
+nothing): config 5 = one 81 920-point scene, PosPool sin_cos at width 288 (LA channels 144), K = 26; config 4 = 4 x
+10 000 points, AdaptiveWeight, K = 23.  The CPU oracle's O(M N) scan does not finish in seconds at 81 920 points, so
+these are size-independent properties: radius containment, sorted distances, mask prefix, no
+duplicate neighbours, exact agreement of the cell grid with the exhaustive kernel on a sample of queries,
+gather/scatter adjointness through the large-N code paths (`group_fwd_direct_kernel`, N > 16 384; the rocPRIM CSR
+path, N > 32 768), and fused-vs-grouped operator parity.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_close, default_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(B, N, extent, seed, pad_frac=0.05):
+    """Points on a few random planes + volume noise inside a slab (indoor-scene-like), metres; valid points first."""
+    rng = np.random.default_rng(seed)
+    xyz = np.empty((B, N, 3), np.float32)
+    for b in range(B):
+        n_pl = N * 3 // 4
+        planes = rng.integers(0, 6, n_pl)
+        p = rng.random((n_pl, 3)).astype(np.float32) * extent
+        axis = planes % 3
+        p[np.arange(n_pl), axis] = (planes // 3) * extent * 0.999 + rng.normal(0, 0.01, n_pl).astype(np.float32)
+        vol = rng.random((N - n_pl, 3)).astype(np.float32) * extent
+        xyz[b] = np.concatenate([p, vol])[rng.permutation(N)]
+    mask = np.ones((B, N), np.int32)
+    nv = int(N * (1 - pad_frac))
+    xyz[:, nv:] = xyz[:, np.arange(nv, N) % nv]
+    mask[:, nv:] = 0
+    return torch.from_numpy(xyz).cuda(), torch.from_numpy(mask).cuda()
+
+
+CASES = {  # name: B, N, K, radius, extent, C, kind, overrides
+    "config5_scene": (1, 81920, 26, 0.1, 4.0, 144, "pospool", {"pospool__position_embedding": "sin_cos", "pospool__reduction": "avg"}),
+    "config4_parts": (4, 10000, 23, 0.05, 1.0, 72, "adaptive_weight", {"adaptive_weight__num_mlps": 1, "adaptive_weight__reduction": "avg"}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_ball_query_properties_at_scene_size(name):
+    from closerlook3d_amd import _ext
+    from closerlook3d_amd import _lib
+    B, N, K, radius, extent, _, _, _ = CASES[name]
+    xyz, mask = _scene(B, N, extent, seed=len(name))
+    idx, msk = _ext.masked_ordered_ball_query(xyz, xyz, mask, mask, radius, K)
+    assert int(idx.min()) >= 0 and int(idx.max()) < N
+    nb = torch.gather(xyz, 1, idx.view(B, N * K, 1).long().expand(B, N * K, 3)).view(B, N, K, 3)
+    d2 = ((nb - xyz.unsqueeze(2)) ** 2).sum(-1)
+    m = msk.bool()
+    assert (d2[m] < radius * radius * (1 + 1e-5)).all(), "a reported neighbour lies outside the ball"
+    valid_q = mask.bool()
+    cnt = msk.sum(-1)
+    prefix = torch.arange(K, device="cuda")[None, None, :] < cnt[..., None]
+    assert torch.equal(m & valid_q[..., None], prefix & valid_q[..., None]), "mask must be a prefix of ones"
+    assert not m[~valid_q].any(), "padded queries carry an all-zero mask"
+    both = m[..., 1:] & m[..., :-1]
+    assert (d2[..., 1:] >= d2[..., :-1] - 1e-7)[both].all(), "neighbours must come in non-decreasing distance"
+    srt = torch.sort(torch.where(m, idx, -1 - torch.arange(K, device="cuda", dtype=idx.dtype)[None, None, :]), dim=-1).values
+    assert (srt[..., 1:] != srt[..., :-1]).all(), "a support point appears twice among the valid neighbours"
+    # wrap-around padding rule: slot i >= cnt repeats slot i % cnt
+    ii = torch.arange(K, device="cuda")[None, None, :].expand(B, N, K)
+    src = torch.where(cnt[..., None] > 0, ii % cnt.clamp_min(1)[..., None], torch.zeros_like(ii))
+    assert torch.equal(torch.gather(idx, 2, src)[~m & valid_q[..., None]], idx[~m & valid_q[..., None]])
+    # the cell grid against the exhaustive kernel (same library, other code path) on a sample of queries: bit-equal
+    sel = torch.from_numpy(np.random.default_rng(1).choice(int(N * 0.95), 256, replace=False)).cuda()
+    q = xyz[:, sel].contiguous()
+    qm = mask[:, sel].contiguous()
+    i2 = torch.empty((B, 256, K), dtype=torch.int32, device="cuda")
+    m2 = torch.empty_like(i2)
+    _lib.check(_lib.lib().cl3d_masked_ordered_ball_query(q.data_ptr(), xyz.data_ptr(), qm.data_ptr(), mask.data_ptr(), B, 256, N,
+                                                         radius, K, i2.data_ptr(), m2.data_ptr(), None, 0,
+                                                         _lib.stream_ptr(xyz.device)))  # no workspace -> exhaustive scan
+    assert torch.equal(i2, idx[:, sel]) and torch.equal(m2, msk[:, sel])
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gather_scatter_and_inverse_index_at_scene_size(name):
+    from closerlook3d_amd import _ext, fused
+    B, N, K, radius, extent, _, _, _ = CASES[name]
+    xyz, mask = _scene(B, N, extent, seed=7)
+    idx, _ = _ext.masked_ordered_ball_query(xyz, xyz, mask, mask, radius, K)
+    C = 8
+    f = torch.randn(B, C, N, device="cuda")
+    g = _ext.group_points(f, idx)  # N > 16 384: the direct-gather kernel
+    pick = [torch.randint(0, n, (256,), device="cuda") for n in (B, C, N, K)]
+    assert torch.equal(g[pick[0], pick[1], pick[2], pick[3]], f[pick[0], pick[1], idx[pick[0], pick[2], pick[3]].long()])
+    a = torch.randn(B, C, N, K, device="cuda")
+    back = _ext.group_points_grad(a, idx, N)
+    lhs, rhs = (g.double() * a.double()).sum(), (f.double() * back.double()).sum()
+    assert abs(lhs - rhs) / abs(lhs) < 1e-6, "gather and scatter-add are not adjoint"
+    ones = _ext.group_points_grad(torch.ones(B, 1, N, K, device="cuda"), idx, N)[:, 0]
+    want = torch.stack([torch.bincount(idx[b].flatten().long(), minlength=N) for b in range(B)]).float()
+    assert torch.equal(ones, want)
+    # CSR inverse (N > 32 768: the rocPRIM path): every slot listed exactly once, under its own support point
+    off, slots = fused.inverse_index(idx, N)
+    torch.cuda.synchronize()
+    for b in range(B):
+        o, s = off[b].long(), slots[b].long()
+        assert int(o[0]) == 0 and int(o[-1]) == N * K and (o[1:] >= o[:-1]).all()
+        assert torch.equal(torch.sort(s).values, torch.arange(N * K, device="cuda"))
+        owner = torch.repeat_interleave(torch.arange(N, device="cuda"), o[1:] - o[:-1])
+        assert torch.equal(idx[b].flatten().long()[s], owner)
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_operator_fused_vs_grouped_at_scene_size(name):
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    B, N, K, radius, extent, C, kind, over = CASES[name]
+    xyz, mask = _scene(B, N, extent, seed=11)
+    torch.manual_seed(2)
+    feats = torch.randn(B, C, N, device="cuda")
+    probe = torch.randn(B, C, N, device="cuda")
+    res = {}
+    for impl in ("fused", "grouped"):
+        torch.manual_seed(3)
+        mod = LocalAggregation(C, C, radius, K, default_config(kind, over, cl3d_impl=impl)).cuda().train(True)
+        f = feats.clone().requires_grad_(True)
+        out = mod(xyz, xyz, mask, mask, f)
+        (out * probe).sum().backward()
+        res[impl] = (out.detach(), f.grad)
+        del mod, out
+        torch.cuda.empty_cache()
+    assert_close(res["fused"][0].cpu().numpy(), res["grouped"][0].cpu().numpy(), 2e-5, f"{name} out")
+    gf, gg = res["fused"][1], res["grouped"][1]
+    bad = (gf - gg).abs() > 2e-5 * (1.0 + gg.abs())
+    assert int(bad.sum()) <= 16 * K, f"{name}: {int(bad.sum())} feature-gradient elements disagree"
+    rel = ((gf - gg)[~bad].double().norm() / gg.double().norm()).item()
+    assert rel < 2e-5, f"{name}: relative L2 error of the feature gradient {rel:.2e}"
