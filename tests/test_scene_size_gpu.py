@@ -125,8 +125,11 @@ def test_operator_fused_vs_grouped_at_scene_size(name):
         del mod, out
         torch.cuda.empty_cache()
     assert_close(res["fused"][0].cpu().numpy(), res["grouped"][0].cpu().numpy(), 2e-5, f"{name} out")
+    # gradients: the sin_cos embedding takes sines of arguments up to 100 (one ulp of the argument is already 7.6e-6),
+    # and a BatchNorm + ReLU output that differs by one rounding can sit on the other side of the threshold and
+    # reroute that element's upstream gradient; so: the bulk within 2e-5, few outliers, small overall error
     gf, gg = res["fused"][1], res["grouped"][1]
     bad = (gf - gg).abs() > 2e-5 * (1.0 + gg.abs())
-    assert int(bad.sum()) <= 16 * K, f"{name}: {int(bad.sum())} feature-gradient elements disagree"
-    rel = ((gf - gg)[~bad].double().norm() / gg.double().norm()).item()
-    assert rel < 2e-5, f"{name}: relative L2 error of the feature gradient {rel:.2e}"
+    assert float(bad.float().mean()) <= 5e-3, f"{name}: {float(bad.float().mean()):.2%} of the feature-gradient elements disagree"
+    rel = ((gf - gg).double().norm() / gg.double().norm()).item()
+    assert rel < 1e-4, f"{name}: relative L2 error of the feature gradient {rel:.2e}"
