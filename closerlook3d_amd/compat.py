@@ -12,6 +12,7 @@
     registered for the duration of the load (it only has to unpickle, never to behave).
 """
 import copy
+import pickle
 import sys
 import types
 
@@ -168,10 +169,67 @@ def _strip_module(state):
     return {(k[len('module.'):] if k.startswith('module.') else k): v for k, v in state.items()}
 
 
-def load_reference_checkpoint(model, path, strict=True, map_location='cpu'):
+class _ConfigDict(dict):
+    """Stand-in for easydict.EasyDict when a checkpoint's 'config' entry is unpickled (attribute access, data only)."""
+
+    def __setstate__(self, st):
+        self.update(st or {})
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+_SAFE_GLOBALS = {
+    ('collections', 'OrderedDict'), ('torch._utils', '_rebuild_tensor_v2'), ('torch._utils', '_rebuild_parameter'),
+    ('torch._utils', '_rebuild_tensor'), ('torch', 'Size'), ('torch', 'device'), ('torch', 'dtype'),
+    ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'), ('numpy', 'dtype'),
+    ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'), ('numpy', 'ndarray'),
+    ('builtins', 'set'), ('builtins', 'frozenset'), ('builtins', 'slice'), ('builtins', 'complex'),
+}
+
+
+class _RestrictedUnpickler(pickle.Unpickler):
+    """Unpickler for reference checkpoints: tensors, containers, numpy scalars and the config's EasyDict (mapped to a
+    plain attribute dict) -- nothing that can run code.  torch.load subclasses whatever `pickle_module.Unpickler` it is
+    given and defers unknown globals to it, so this is the gate every GLOBAL opcode of the file goes through."""
+
+    def find_class(self, module, name):
+        if (module, name) == ('easydict', 'EasyDict'):
+            return _ConfigDict
+        if (module, name) == (__name__, 'Config'):
+            return Config
+        if (module, name) in _SAFE_GLOBALS or (module == 'torch' and name.endswith('Storage')):
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"checkpoint references {module}.{name}; pass trusted=True to "
+                                     "load_reference_checkpoint if the file comes from a source you trust")
+
+
+def _restricted_pickle_module():
+    mod = types.ModuleType('cl3d_restricted_pickle')
+    for k in ('load', 'loads', 'dump', 'dumps', 'Pickler', 'PickleError', 'PicklingError', 'UnpicklingError',
+              'HIGHEST_PROTOCOL', 'DEFAULT_PROTOCOL'):
+        setattr(mod, k, getattr(pickle, k))
+    mod.Unpickler = _RestrictedUnpickler
+    return mod
+
+
+def load_reference_checkpoint(model, path, strict=True, map_location='cpu', trusted=False):
     """Load the 'model' entry of a checkpoint written by the reference's `save_checkpoint` (or a bare state dict).
-    Returns the rest of the checkpoint (epoch, best_acc / best_miou, config, optimizer and scheduler state)."""
+    Returns the rest of the checkpoint (epoch, best_acc / best_miou, config, optimizer and scheduler state).
+
+    Only the weights are needed, but the reference pickles its EasyDict config, optimizer and scheduler state into the
+    same file.  The file is therefore read through a restricted unpickler (tensors, containers, numpy scalars, the
+    config as a plain attribute dict): a checkpoint from an untrusted source cannot run code.  A file that holds other
+    pickled objects raises, naming the first one; `trusted=True` then falls back to the unrestricted loader."""
     stub = None
+    if not trusted:
+        ckpt = torch.load(path, map_location=map_location, weights_only=False, pickle_module=_restricted_pickle_module())
+        state = ckpt['model'] if isinstance(ckpt, dict) and 'model' in ckpt else ckpt
+        model.load_state_dict(_strip_module(state), strict=strict)
+        return {k: v for k, v in ckpt.items() if k != 'model'} if isinstance(ckpt, dict) and 'model' in ckpt else {}
     if 'easydict' not in sys.modules:
         try:
             import easydict  # noqa: F401

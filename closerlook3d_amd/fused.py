@@ -104,6 +104,8 @@ def inverse_index(idx, n_support, prefetch=False):
         main, side = torch.cuda.current_stream(idx.device), pt_utils.index_stream(idx.device, 1)
         with torch.cuda.stream(side):
             wait_ready(idx)  # the ball query ran on this stream already; this covers a cached idx too
+            if not torch.cuda.is_current_stream_capturing():
+                idx.record_stream(side)  # read here: the allocator must not recycle it before this stream is done
             off, slots = _build_inverse(idx, n_support)
             ev = torch.cuda.Event()
             ev.record(side)
@@ -185,6 +187,23 @@ class _FusedReduce(Function):
         return (dfeat, g0, g1) + (None,) * 13
 
 
+def _checked(features, query_xyz, support_xyz, query_mask, support_mask):
+    """The fused kernels read raw pointers: apply the reference's CHECK_IS_FLOAT / CHECK_IS_INT / CHECK_CONTIGUOUS rules
+    (utils.h:10-30) here as `_ext` does -- float32 / int32 on the GPU, same device, made contiguous where a copy is
+    legitimate (features, coordinates), refused otherwise -- so half / double features under autocast or a sliced xyz
+    raise instead of reading out of bounds."""
+    from ._ext import _check, _check_dev
+    features, query_xyz, support_xyz = features.contiguous(), query_xyz.contiguous(), support_xyz.contiguous()
+    query_mask, support_mask = query_mask.contiguous(), support_mask.contiguous()
+    _check("support_features", features, torch.float32)
+    _check("query_xyz", query_xyz, torch.float32)
+    _check("support_xyz", support_xyz, torch.float32)
+    _check("query_mask", query_mask, torch.int32)
+    _check("support_mask", support_mask, torch.int32)
+    _check_dev(features, query_xyz=query_xyz, support_xyz=support_xyz, query_mask=query_mask, support_mask=support_mask)
+    return features, query_xyz, support_xyz, query_mask, support_mask
+
+
 def _wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
@@ -200,6 +219,7 @@ def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, ne
 
 
 def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, embedding, reduction):
+    features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, _wants_grad(features))
     C = features.shape[1]
     if embedding == 'xyz':
@@ -218,6 +238,7 @@ def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, 
 
 def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps,
                     shared_channels, reduction):
+    features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     conv = mlps.conv0
     w = conv.weight.view(conv.weight.shape[0], 3)
     idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
@@ -229,6 +250,7 @@ def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, 
 
 def pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, k_points,
                 kernel_weights, extent, influence):
+    features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
                            _wants_grad(features, kernel_weights))
     return _FusedReduce.apply(features, k_points.contiguous(), kernel_weights, OP_PSEUDOGRID, query_xyz,
@@ -272,6 +294,7 @@ class _MaxPool(Function):
 
 def max_pool(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample):
     """MaskedMaxPool's pooling step on the fused path (nsample <= 255)."""
+    features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, _wants_grad(features))
     return _MaxPool.apply(features.contiguous(), idx, _wants_grad(features))
 
@@ -533,6 +556,7 @@ def point_rows(features, W, precision='f32'):
 def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps, reduction,
                   training, precision='f32'):
     assert reduction == 'max'
+    features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     conv, bn = mlps.conv0[0], mlps.conv0[1]
     idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
                     training and _wants_grad(features, conv.weight, bn.weight, bn.bias))

@@ -200,9 +200,11 @@ class PointWiseMLP(nn.Module):
         return _masked_reduce(agg, self.reduction, nmask, query_mask, self.nsample, 'PointWiseMLP')
 
 
-def make_kernel_points(radius, num_points, seed=0, iters=400):
-    """Deterministic kernel-point disposition for PseudoGrid: one point at the centre, the others
-    spread in the ball by repulsion, rescaled so the outermost sits at `radius`.
+def make_kernel_points(radius, num_points, seed=0, iters=400, fixed='center'):
+    """Deterministic kernel-point disposition for PseudoGrid: one point at the centre (`fixed='center'`, what every
+    shipped configuration uses; `'none'` lets it move), the others spread in the ball by repulsion, rescaled as the
+    reference rescales its optimised disposition (models/utlis.py:145-150): the MEAN distance of the non-centre points
+    from the origin equals `radius` (K_radius = 1.5 * extent).
 
     The reference (`models/utlis.py:153-284`) optimises random initial points, so its result differs
     from run to run and from this one; trained models carry their `K_points` in the state dict (it
@@ -212,16 +214,23 @@ def make_kernel_points(radius, num_points, seed=0, iters=400):
     pts = rng.normal(size=(num_points, 3))
     pts /= np.linalg.norm(pts, axis=1, keepdims=True) + 1e-9
     pts *= rng.random((num_points, 1)) ** (1 / 3)
-    pts[0] = 0
+    if fixed not in ('center', 'none'):
+        # 'verticals' pins two more points on the z axis (models/utlis.py:66-75); not generated here
+        raise NotImplementedError(f"fixed_kernel_points='{fixed}': only 'center' and 'none' dispositions are generated; "
+                                  "load K_points from a checkpoint for the others")
+    pinned = fixed == 'center'
+    if pinned:
+        pts[0] = 0
     for it in range(iters):
         diff = pts[:, None, :] - pts[None, :, :]
         d2 = (diff ** 2).sum(-1) + 1e-6
         rep = (diff / (d2[..., None] ** 1.5)).sum(1)
         att = -2.0 * pts  # keeps the cloud bounded
         step = 0.02 * (rep * 0.01 + att * 0.1)
-        step[0] = 0
+        if pinned:
+            step[0] = 0
         pts = pts + step
-    scale = np.linalg.norm(pts, axis=1).max()
+    scale = np.linalg.norm(pts[1:], axis=1).mean()
     return (pts * (radius / scale)).astype(np.float32)
 
 
@@ -236,7 +245,7 @@ class PseudoGrid(_OutputTransform):
         self.convolution_mode = pg.convolution_mode
         self.impl = _cfg(config, 'cl3d_impl', 'auto')
         self.extent = 2 * pg.KP_extent * radius / config.density_parameter
-        k_points = make_kernel_points(1.5 * self.extent, self.num_kernel_points)
+        k_points = make_kernel_points(1.5 * self.extent, self.num_kernel_points, fixed=pg.fixed_kernel_points)
         self.register_buffer('K_points', torch.from_numpy(k_points).type(torch.float32))
         self.grouper = MaskedQueryAndGroup(radius, nsample, use_xyz=False, ret_grouped_xyz=True, normalize_xyz=False)
         # truncated-normal init, std sqrt(2/C), values beyond 2 std zeroed (reference utlis.py:297-303)

@@ -146,21 +146,30 @@ def wait_ready(t):
         torch.cuda.current_stream(t.device).wait_event(ev)
 
 
+_CONSUMER_STREAM = None  # set by prefetch_geometry: the compute stream that will read what is produced ahead of it
+
+
 def _run_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample):
     if not (query_xyz.is_cuda and async_index()):
         return _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
     dev = query_xyz.device
     main, side = torch.cuda.current_stream(dev), index_stream(dev)
-    if main != side:  # (called from prefetch_geometry the caller is already on the index stream)
+    # inside prefetch_geometry the caller already IS on the index stream; the stream that will consume the result is
+    # the one that entered the prefetch
+    consumer = _CONSUMER_STREAM if (main == side and _CONSUMER_STREAM is not None) else main
+    if main != side:
         side.wait_stream(main)  # the coordinates were produced on the caller's stream
     with torch.cuda.stream(side):
         out = _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
         ev = torch.cuda.Event()
         ev.record(side)
     capturing = torch.cuda.is_current_stream_capturing()
+    if not capturing:  # a capture's private pool never hands a block to another stream mid-graph
+        for t in out:
+            t.record_stream(consumer)  # produced on the index stream, read on the consumer's
+        for t in (query_xyz, support_xyz, query_mask, support_mask):
+            t.record_stream(side)      # (possibly temporaries of .contiguous()) read on the index stream
     for t in out:
-        if not capturing:  # a capture's private pool never hands the block to another stream mid-graph
-            t.record_stream(main)
         t._cl3d_ready = ev
     return out
 
@@ -222,6 +231,15 @@ def prefetch_geometry(xyz, mask, radius, sampleDl, nsamples, npoints, self_queri
     side.wait_stream(main)  # the input coordinates were produced on the caller's stream
     capturing = torch.cuda.is_current_stream_capturing()
     xyz, mask = xyz.contiguous(), mask.contiguous()
+    global _CONSUMER_STREAM
+    _CONSUMER_STREAM = main  # the ball queries below run with the index stream current: their outputs are read on `main`
+    try:
+        _prefetch_on(side, main, capturing, xyz, mask, radius, sampleDl, nsamples, npoints, self_queries)
+    finally:
+        _CONSUMER_STREAM = None
+
+
+def _prefetch_on(side, main, capturing, xyz, mask, radius, sampleDl, nsamples, npoints, self_queries):
     with torch.cuda.stream(side):
         def query(q, s, qm, sm, r, k):
             _ball_query(q, s, qm, sm, r, k, defer=True)

@@ -100,3 +100,22 @@ def test_checkpoint_with_pickled_easydict_config_loads_without_easydict(tmp_path
     meta = compat.load_reference_checkpoint(compat.build_model(cfg), path)
     assert meta["epoch"] == 3 and dict(meta["config"]) == {"width": 12}
     assert "easydict" not in sys.modules
+
+
+def test_untrusted_checkpoint_cannot_run_code(tmp_path):
+    """a checkpoint is read through a restricted unpickler; a pickled callable is refused unless the caller
+    says the file is trusted."""
+    import os
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > " + str(tmp_path / "pwned"),))
+
+    cfg = _cfg_from_golden("modelnet/pospool_xyz_avg.yaml")
+    cfg.width, cfg.nsamples, cfg.npoints = 12, [8] * 5, [64, 32, 16, 8]
+    model = compat.build_model(cfg)
+    path = str(tmp_path / "evil.pth")
+    torch.save({"model": model.state_dict(), "scheduler": Evil()}, path)
+    with pytest.raises(Exception, match="trusted=True"):
+        compat.load_reference_checkpoint(model, path)
+    assert not (tmp_path / "pwned").exists()
