@@ -68,6 +68,28 @@ def _stream(t):
     return _lib.stream_ptr(t.device)
 
 
+def _fork_join(device, side_fn, main_fn):
+    """Two independent pieces of a backward pass (the data gradient and the weight gradient of one contraction; the
+    arg-max scatter and the per-channel BatchNorm algebra) side by side: `side_fn` on a side HIP stream, `main_fn` on the
+    caller's, joined before returning.  Each is a short latency-bound launch that leaves most of the chip idle on its
+    own.  Active whenever the index streams are (pt_utils.async_index(): always while a HIP graph is captured, where the
+    fork becomes two parallel branches of the graph); otherwise one after the other on the caller's stream.  Outputs
+    are allocated by the caller BEFORE the fork (on the caller's stream); whatever side_fn allocates is scratch that
+    lives and dies on the side stream."""
+    if not (device.type == 'cuda' and pt_utils.async_index()):
+        side_fn()
+        main_fn()
+        return
+    main, side = torch.cuda.current_stream(device), pt_utils.index_stream(device, 2)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        side_fn()
+        ev = torch.cuda.Event()
+        ev.record(side)
+    main_fn()
+    main.wait_event(ev)
+
+
 def _gemm_scratch(op, B, N, Co, C, device):
     """Scratch for the K-slice partials of a per-point contraction (cl3d_workspace_bytes(CL3D_OP_POINT_GEMM = 14 /
     CL3D_OP_CONV1X1 = 15)): (tensor, bytes); the tensor is kept alive by the caller until its launches are queued."""
@@ -433,14 +455,20 @@ class _PointwiseMLP(Function):
                                                _p(vec[1]), _p(vec[2]), _p(vec[3]), B, M, K, Co, _p(dz_cm), _p(ts_cm),
                                                _p(partial), nparts, st))
             hit = torch.empty((B, Co, N), dtype=torch.float32, device=dev)
-            _lib.check(lib.cl3d_pwmlp_bwd_hits(_p(dz_cm), _p(ts_cm), B, N, M, Co, _p(hit), st))
             # d gamma, d beta, d W_r and the coefficients of  dy = A dz + Bc + D y  (BatchNorm backward is affine in y)
             coef = torch.empty((5, Co), dtype=torch.float32, device=dev)
             cA, cB, cD, dgamma, dbeta = coef[0], coef[1], coef[2], coef[3], coef[4]
             dwr = torch.empty((Co, 3), dtype=torch.float32, device=dev)
-            _lib.check(lib.cl3d_pwmlp_bn_backward_coeffs(_p(partial), nparts, Co, float(n), _p(gamma), _p(vec[2]),
-                                                         _p(vec[3]), _p(sums), _p(cA), _p(cB), _p(cD), _p(dgamma),
-                                                         _p(dbeta), _p(dwr), st))
+
+            def hits():  # the arg-max scatter ...
+                _lib.check(lib.cl3d_pwmlp_bwd_hits(_p(dz_cm), _p(ts_cm), B, N, M, Co, _p(hit), _stream(gout)))
+
+            def coeffs():  # ... beside the per-channel algebra: both only need what bwd_rows left
+                _lib.check(lib.cl3d_pwmlp_bn_backward_coeffs(_p(partial), nparts, Co, float(n), _p(gamma), _p(vec[2]),
+                                                             _p(vec[3]), _p(sums), _p(cA), _p(cB), _p(cD), _p(dgamma),
+                                                             _p(dbeta), _p(dwr), _stream(gout)))
+
+            _fork_join(dev, coeffs, hits)
             off, slots = inverse_index(idx, N)
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
             _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_cm), _p(sy), _p(hq),
@@ -495,18 +523,28 @@ class _PointRows(Function):
         if dght is None:
             dght = torch.zeros((B, N, 2 * Co), dtype=torch.float32, device=dev)
         dght = dght.contiguous()
-        ws, ws_bytes = _gemm_scratch(14, B, N, Co, C, dev)  # stream-ordered: the two products use it one after the other
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        if need_x:
+            dfeat = torch.empty((B, C, N), dtype=torch.float32, device=dev)
+        if need_w:
+            dW = torch.empty((Co, 3 + 2 * C), dtype=torch.float32, device=dev)
+            dwr = dwr.contiguous() if dwr is not None else None
+        prec = ctx.precision
+
+        def data_grad():
+            if need_x:
+                ws, ws_bytes = _gemm_scratch(14, B, N, Co, C, dev)
+                _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_data(_p(dght), _p(wcat), B, C, N, Co, prec, _p(dfeat), _p(ws),
+                                                              ws_bytes, _stream(features)))
+
+        def weight_grad():
+            if need_w:
+                ws, ws_bytes = _gemm_scratch(14, B, N, Co, C, dev)
+                _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_weight(_p(features), _p(dght), _p(dwr), B, C, N, Co, prec, _p(dW),
+                                                                _p(ws), ws_bytes, _stream(features)))
+
         with _lib.on_device(dev):
-            st = _stream(features)
-            if ctx.needs_input_grad[0]:
-                dfeat = torch.empty((B, C, N), dtype=torch.float32, device=dev)
-                _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_data(_p(dght), _p(wcat), B, C, N, Co, ctx.precision, _p(dfeat),
-                                                              _p(ws), ws_bytes, st))
-            if ctx.needs_input_grad[1]:
-                dW = torch.empty((Co, 3 + 2 * C), dtype=torch.float32, device=dev)
-                dwr = dwr.contiguous() if dwr is not None else None
-                _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_weight(_p(features), _p(dght), _p(dwr), B, C, N, Co,
-                                                                ctx.precision, _p(dW), _p(ws), ws_bytes, st))
+            _fork_join(dev, weight_grad, data_grad)
         return dfeat, dW, None
 
 
@@ -599,16 +637,22 @@ class _Conv1x1(Function):
         Co = W.shape[0]
         dy = dy.contiguous()
         lib = _lib.lib()
-        dx = dW = None
-        ws, ws_bytes = _gemm_scratch(15, B, N, Co, C, x.device)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W) if ctx.needs_input_grad[1] else None
+        prec = ctx.precision
+
+        def data_grad():
+            if dx is not None:
+                ws, ws_bytes = _gemm_scratch(15, B, N, Co, C, x.device)
+                _lib.check(lib.cl3d_conv1x1_bwd_data(_p(dy), _p(W), B, C, N, Co, prec, _p(dx), _p(ws), ws_bytes, _stream(x)))
+
+        def weight_grad():
+            if dW is not None:
+                ws, ws_bytes = _gemm_scratch(15, B, N, Co, C, x.device)
+                _lib.check(lib.cl3d_conv1x1_bwd_weight(_p(x), _p(dy), B, C, N, Co, prec, _p(dW), _p(ws), ws_bytes, _stream(x)))
+
         with _lib.on_device(x.device):
-            st = _stream(x)
-            if ctx.needs_input_grad[0]:
-                dx = torch.empty_like(x)
-                _lib.check(lib.cl3d_conv1x1_bwd_data(_p(dy), _p(W), B, C, N, Co, ctx.precision, _p(dx), _p(ws), ws_bytes, st))
-            if ctx.needs_input_grad[1]:
-                dW = torch.empty_like(W)
-                _lib.check(lib.cl3d_conv1x1_bwd_weight(_p(x), _p(dy), B, C, N, Co, ctx.precision, _p(dW), _p(ws), ws_bytes, st))
+            _fork_join(x.device, weight_grad, data_grad)
         return dx, dW, None
 
 
