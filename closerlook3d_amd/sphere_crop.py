@@ -70,6 +70,22 @@ class SceneCropper:
             out["labels"] = self.labels[input_inds].to(torch.int64)
         return out
 
+    def project(self, points, chunk=4096):
+        """Index of the nearest sub-sampled point for every ORIGINAL scene point (`datasets/S3DIS.py:262-270`:
+        `search_tree.query(points, return_distance=False)`, the projection that carries votes from the sub-sampled
+        cloud back to the full one) as int32, computed in float64 like the tree; among exactly equidistant candidates
+        (where the tree's choice is unspecified) the smallest index."""
+        q = torch.as_tensor(points).to(self.device, torch.float64)
+        out = torch.empty(q.shape[0], dtype=torch.int32, device=self.device)
+        p = self.points64
+        for lo in range(0, q.shape[0], chunk):
+            c = q[lo:lo + chunk]
+            dx = c[:, 0][:, None] - p[:, 0][None, :]
+            dy = c[:, 1][:, None] - p[:, 1][None, :]
+            dz = c[:, 2][:, None] - p[:, 2][None, :]
+            out[lo:lo + chunk] = torch.argmin((dx * dx + dy * dy) + dz * dz, dim=1).to(torch.int32)
+        return out
+
     # ---- a whole batch of samples at once: the same results with ~30 device operations per BATCH instead of per
     # sample (a single crop is launch-bound: measured 2.7 ms per sample against 0.6 ms for one KD-tree query on a
     # host core, scene of 800 000 points)
@@ -121,3 +137,68 @@ class SceneCropper:
         if self.labels is not None:
             out["labels"] = self.labels[input_inds].to(torch.int64)
         return out
+
+
+class EpochPlanner:
+    """The pick points of S3DIS epochs, planned on the device (`datasets/S3DIS.py:212-253`).
+
+    The reference plans every (epoch, step) once, on the host: the scene whose smallest potential is smallest, in it
+    the point of smallest potential, a Gaussian offset, the KD-tree's sorted in-radius list cut to `num_points`, a
+    Tukey bump `(1 - d^2 / r^2)^2` added to the potentials of those points -- so the next pick lands elsewhere.  Each
+    step depends on the previous one, so this is a sequential loop of small operations either way; what the device
+    version buys is that the scenes (already resident for `SceneCropper.crop_batch`) never travel, and that the plan
+    can be extended while training runs.
+
+        planner = EpochPlanner([SceneCropper(...), ...], initial_potentials)     # potentials: float64 per scene point
+        cloud_inds, point_inds, picks = planner.plan(noise)                      # noise [steps, 3] float64
+
+    Random draws are the caller's (the reference takes them from numpy's global state: `np.random.rand(n) * 1e-3` for
+    the initial potentials, `np.random.normal(scale=in_radius / 10, size=(1, 3))` per step).
+
+    `promotion`: the Tukey weights are computed from float32 squared distances divided by `np.square(in_radius)`, a
+    float64 SCALAR.  Under the NumPy the reference was written for (< 2.0, value-based casting) the quotient stays
+    float32 ('legacy', the default: plans identical to the reference's own era); under NumPy >= 2 (NEP 50) it is float64
+    ('nep50').  The two give different potentials in the last bits and, after enough steps, different plans.
+    """
+
+    def __init__(self, scenes, potentials, promotion="legacy"):
+        if promotion not in ("legacy", "nep50"):
+            raise ValueError("promotion must be 'legacy' or 'nep50'")
+        self.scenes = list(scenes)
+        self.promotion = promotion
+        self.potentials = [torch.as_tensor(p, dtype=torch.float64).to(s.device).clone() for p, s in zip(potentials, self.scenes)]
+        self.min_potentials = [float(p.min()) for p in self.potentials]
+
+    def step(self, noise):
+        """One pick: (cloud index, point index, pick point [3] float64 tensor); potentials updated."""
+        cloud = min(range(len(self.scenes)), key=lambda i: (self.min_potentials[i], i))  # np.argmin: first minimum
+        scene, pot = self.scenes[cloud], self.potentials[cloud]
+        point = int(torch.argmin(pot))  # first occurrence of the minimum, as np.argmin
+        centre = scene.points64[point]
+        pick = centre + torch.as_tensor(noise, dtype=torch.float64, device=scene.device).reshape(3)
+        inds = scene.query(pick)
+        d = (scene.points64[inds] - pick).to(torch.float32)  # (points[query_inds] - pick_point).astype(np.float32)
+        sq = d * d
+        dists = (sq[:, 0] + sq[:, 1]) + sq[:, 2]             # np.sum(..., axis=1) of three float32 values
+        r2 = scene.in_radius * scene.in_radius
+        if self.promotion == "legacy":
+            t = 1.0 - dists / torch.tensor(r2, dtype=torch.float32, device=scene.device)
+            tukey = t * t
+            tukey = torch.where(dists > torch.tensor(r2, dtype=torch.float32, device=scene.device), torch.zeros_like(tukey), tukey)
+        else:
+            t = 1.0 - dists.to(torch.float64) / r2
+            tukey = t * t
+            tukey = torch.where(dists.to(torch.float64) > r2, torch.zeros_like(tukey), tukey)
+        pot[inds] += tukey.to(torch.float64)                   # query indices are distinct
+        self.min_potentials[cloud] = float(pot.min())
+        return cloud, point, pick
+
+    def plan(self, noise):
+        """noise [steps, 3] -> (cloud_inds [steps], point_inds [steps], picks [steps, 3] float64 on the host)."""
+        clouds, points, picks = [], [], []
+        for row in noise:
+            c, p, pick = self.step(row)
+            clouds.append(c)
+            points.append(p)
+            picks.append(pick.cpu())
+        return clouds, points, torch.stack(picks) if picks else torch.zeros((0, 3), dtype=torch.float64)
