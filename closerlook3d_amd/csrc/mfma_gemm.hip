@@ -258,25 +258,28 @@ struct StageBF16 {
   }
 };
 
-template <int PREC, int TR>
+// K chunk: f32 32 channels (16 MFMA k-steps per barrier round), 48 for the 64 x 64 tile -- the deep, latency-bound
+// layers run on it and want fewer rounds and more bytes in flight per workgroup, and it is the only tile whose two LDS
+// copies of a 48-deep pair stay under the 64 KB a kernel gets without opting in; bf16 64 (four 16-deep steps).
+__host__ __device__ constexpr int gemm_kc(int prec, int wi, int wj) { return prec == PREC_BF16 ? 64 : (wi * wj == 1 ? 48 : 32); }
+
+template <int PREC, int TR, int KC>
 struct StagePick {
-  using type = StageF32<TR, 32>;
-  static constexpr int KC = 32;
-  static constexpr int kLdsBytes = StageF32<TR, 32>::kLdsFloats * 4;
+  using type = StageF32<TR, KC>;
+  static constexpr int kLdsBytes = StageF32<TR, KC>::kLdsFloats * 4;
 };
-template <int TR>
-struct StagePick<PREC_BF16, TR> {
+template <int TR, int KC>
+struct StagePick<PREC_BF16, TR, KC> {
   using type = StageBF16<TR>;
-  static constexpr int KC = 64;
   static constexpr int kLdsBytes = StageBF16<TR>::kLdsPacks * 16;
 };
 
 template <int PREC, int WI, int WJ, int AM, int BM>
 __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
   constexpr int TI = 64 * WI, TJ = 64 * WJ;
-  using SA = StagePick<PREC, TI>;
-  using SB = StagePick<PREC, TJ>;
-  constexpr int KC = SA::KC;
+  constexpr int KC = gemm_kc(PREC, WI, WJ);
+  using SA = StagePick<PREC, TI, KC>;
+  using SB = StagePick<PREC, TJ, KC>;
   // LDS: two copies of the (A, B) chunk pair -- chunk g+1 is written while chunk g is multiplied, one barrier per
   // chunk -- except for the 128 x 128 tile, whose pair is 33 KB (static LDS ends at 64 KB): one copy, two barriers.
   constexpr int NBUF = (WI * WJ == 4) ? 1 : 2;
@@ -616,7 +619,6 @@ static void launch_modes(GemmArgs &a, int wi, int wj, int blocks, hipStream_t st
 
 constexpr int kCUs = 256;
 
-static int kc_of(int precision) { return precision == PREC_BF16 ? 64 : 32; }
 
 // Workgroup tile and K slicing for an I x J output over K.  Two regimes decide the time of a product here:
 //   * matrix-core bound: padded flops / 157 TFLOP/s (f32) -- padding matters, these layers have I or J = 72 .. 288;
@@ -631,12 +633,10 @@ struct Plan {
   int wi, wj, nsplit, cps;
 };
 
-static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes) {
-  const int kc = kc_of(precision);
-  const long long chunks = (K + kc - 1) / kc;
+static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes, bool scalar_staging = false) {
   const int cand[4][3] = {{2, 2, 2}, {2, 1, 3}, {1, 2, 3}, {1, 1, 4}};  // wi, wj, resident workgroups per CU
   const double peak_flops_per_us = precision == PREC_BF16 ? 1.2e9 : 157.3e6;  // bf16: what staging sustains, not 2.5 PF
-  Plan best{2, 2, 1, (int)chunks};
+  Plan best{2, 1, 1, (int)((K + gemm_kc(precision, 2, 1) - 1) / gemm_kc(precision, 2, 1))};
   double best_cost = 1e300;
   int force_wi = 0, force_wj = 0;
   if (const char *force = getenv("CL3D_GEMM_TILE")) {  // tuning override "wi,wj" (scripts/bench_point_gemm.py --tiles)
@@ -647,6 +647,9 @@ static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, s
   for (int c = 0; c < 4; ++c) {
     const int wi = cand[c][0], wj = cand[c][1], resident = cand[c][2];
     if (force_wi && (wi != force_wi || wj != force_wj)) continue;
+    if (scalar_staging && wi * wj == 4) continue;  // the element-wise staging fallback at 128 x 128 runs out of registers
+    const int kc = gemm_kc(precision, wi, wj);
+    const long long chunks = (K + kc - 1) / kc;
     const long long ti = ceil_div(I, 64 * wi), tj = ceil_div(J, 64 * wj), tiles = ti * tj;
     const double flops = 2.0 * (double)(ti * 64 * wi) * (double)(tj * 64 * wj) * (double)K;
     for (long long split = 1; split <= max_split && split <= (chunks >= 4 ? chunks / 4 : 1); split += (split < 4 ? 1 : split / 2)) {
@@ -690,7 +693,10 @@ static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t 
   const bool always_reduce = REDUCE_MODE == 1;
   if (always_reduce && (!ws || ws_bytes < (size_t)I * J * sizeof(float)))
     return fail(CL3D_E_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, plan_workspace(I, J, a.K, max_split, true));
-  const Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0);
+  const int am = stage_mode(a.A), bm = stage_mode(a.B);
+  const bool vec_pair = (am == STAGE_VEC_RC && bm == STAGE_VEC_KC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_RC) ||
+                        (am == STAGE_VEC_RC && bm == STAGE_VEC_RC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_KC);
+  const Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, !vec_pair);
   a.tiles_i = ceil_div(I, 64 * p.wi);
   a.tiles_j = ceil_div(J, 64 * p.wj);
   a.nsplit = p.nsplit;
