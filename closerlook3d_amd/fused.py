@@ -762,18 +762,6 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, res_conv=None, res_bn=Non
     if CONV_ENGINE == 'library':
         y1 = torch.nn.functional.conv1d(x, conv.weight)
         x2 = torch.nn.functional.conv1d(residual, res_conv.weight) if res_conv is not None else residual
-    elif res_conv is not None and x.is_cuda and torch.cuda.is_current_stream_capturing():
-        # the main and the shortcut convolution read different tensors: two parallel branches of the captured graph
-        box = {}
-
-        def shortcut():
-            box['x2'] = _Conv1x1.apply(residual, res_conv.weight.view(Co, res_conv.weight.shape[1]), prec)
-
-        def main_conv():
-            box['y1'] = _Conv1x1.apply(x, W, prec)
-
-        _fork_join(x.device, shortcut, main_conv)
-        y1, x2 = box['y1'], box['x2']
     else:
         y1 = _Conv1x1.apply(x, W, prec)
         x2 = residual

@@ -4,7 +4,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== pytest subset" | tee $OUT/summary.txt
-timeout 1500 python -m pytest tests/test_operators_gpu.py tests/test_bottleneck_gpu.py tests/test_scene_size_gpu.py tests/test_compat.py tests/test_dp_gpu.py -m gpu -q --timeout=900 -p no:cacheprovider > $OUT/pytest.log 2>&1
+timeout 1500 python -m pytest tests/test_mfma_gemm_gpu.py tests/test_bottleneck_gpu.py tests/test_scene_size_gpu.py tests/test_planner.py tests/test_operators_gpu.py -m gpu -q --timeout=900 -p no:cacheprovider > $OUT/pytest.log 2>&1
 echo "pytest rc=$?" | tee -a $OUT/summary.txt; grep -E "passed|failed|^FAILED|Error:" $OUT/pytest.log | tail -8 | tee -a $OUT/summary.txt
 for i in 1 2; do
 echo "== bench f32 / bf16 (run $i)" | tee -a $OUT/summary.txt
