@@ -258,10 +258,10 @@ struct StageBF16 {
   }
 };
 
-// K chunk: f32 32 channels (16 MFMA k-steps per barrier round), 48 for the 64 x 64 tile -- the deep, latency-bound
-// layers run on it and want fewer rounds and more bytes in flight per workgroup, and it is the only tile whose two LDS
-// copies of a 48-deep pair stay under the 64 KB a kernel gets without opting in; bf16 64 (four 16-deep steps).
-__host__ __device__ constexpr int gemm_kc(int prec, int wi, int wj) { return prec == PREC_BF16 ? 64 : (wi * wj == 1 ? 48 : 32); }
+// K chunk: f32 32 channels (16 MFMA k-steps per barrier round), bf16 64 (four 16-deep steps).  (48-deep chunks on the
+// 64 x 64 tile -- fewer rounds, more bytes in flight per workgroup -- were measured on the config-2 backbone: 2 %
+// slower; the larger LDS and register footprint costs a resident workgroup per CU.)
+__host__ __device__ constexpr int gemm_kc(int prec, int wi, int wj) { return prec == PREC_BF16 ? 64 : ((void)wi, (void)wj, 32); }
 
 template <int PREC, int TR, int KC>
 struct StagePick {
