@@ -738,7 +738,8 @@ __global__ __launch_bounds__(256, 1) void mfma_ring_kernel(GemmArgs a) {
       const bool isA = pc < PA;
       const GemmOperand &op = isA ? a.A : a.B;
       int k = k0 + pkoff[u];
-      k = k + 4 <= a.K ? k : a.K - 4;  // K tail: clamp (those k are not multiplied)
+      const int kmax = a.K - ((isA ? A_KC : B_KC) ? 4 : 1);  // K tail: clamp to the last quad / row (not multiplied)
+      k = k <= kmax ? k : kmax;
       const float *src = op.p + (poff[u] + (unsigned)(k * pkmul[u]));
       float *dst = stage + (size_t)pc * 256;  // wave-uniform: the DMA adds lane * 16 bytes itself
       __builtin_amdgcn_global_load_lds((global_void_t *)src, (lds_void_t *)dst, 16, 0, 0);
@@ -901,7 +902,8 @@ struct Plan {
   int wi, wj, nsplit, cps;
 };
 
-static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes, bool scalar_staging = false) {
+static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes, bool scalar_staging = false,
+                      bool ring = false) {
   const int cand[4][3] = {{2, 2, 2}, {2, 1, 3}, {1, 2, 3}, {1, 1, 4}};  // wi, wj, resident workgroups per CU
   const double peak_flops_per_us = precision == PREC_BF16 ? 1.2e9 : 157.3e6;  // bf16: what staging sustains, not 2.5 PF
   Plan best{2, 1, 1, (int)((K + gemm_kc(precision, 2, 1) - 1) / gemm_kc(precision, 2, 1))};
@@ -913,7 +915,8 @@ static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, s
   long long force_split = 0;
   if (const char *force = getenv("CL3D_GEMM_SPLIT")) force_split = atoll(force);  // tuning override
   for (int c = 0; c < 4; ++c) {
-    const int wi = cand[c][0], wj = cand[c][1], resident = cand[c][2];
+    // the LDS-ring kernel hides latency inside one workgroup (3-4 stages in flight): one workgroup per CU fills it
+    const int wi = cand[c][0], wj = cand[c][1], resident = ring ? 1 : cand[c][2];
     if (force_wi && (wi != force_wi || wj != force_wj)) continue;
     if (scalar_staging && wi * wj == 4) continue;  // the element-wise staging fallback at 128 x 128 runs out of registers
     const int kc = gemm_kc(precision, wi, wj);
@@ -964,7 +967,7 @@ static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t 
   const int am = stage_mode(a.A), bm = stage_mode(a.B);
   const bool vec_pair = (am == STAGE_VEC_RC && bm == STAGE_VEC_KC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_RC) ||
                         (am == STAGE_VEC_RC && bm == STAGE_VEC_RC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_KC);
-  const Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, !vec_pair);
+  const Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, !vec_pair, ring_eligible(a, precision));
   a.tiles_i = ceil_div(I, 64 * p.wi);
   a.tiles_j = ceil_div(J, 64 * p.wj);
   a.nsplit = p.nsplit;
