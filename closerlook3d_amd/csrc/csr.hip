@@ -90,18 +90,23 @@ static bool csr_plan(int B, int N, int MK, CsrPlan *p) {
 // COUNT: per-wave histograms of the workgroup's slot ranges, merged (fixed wave order) into table[b][gb][:].
 // FILL:  the same histograms again, turned into per-wave cursors (table[b][gb][i] now holds the first output
 //        position of this workgroup inside row i; wave w starts after waves < w), then the scatter.
+// Workgroups are numbered cloud-fastest (linear id = cloud + B * range-group): consecutive ids go to consecutive XCDs,
+// so with B a multiple of 8 every workgroup of a cloud runs on ONE XCD and the 4-byte scatter stores of the fill pass
+// (64 random rows per wave instruction) merge into whole lines in that XCD's L2 before they leave it -- with the
+// clouds spread over all XCDs the same stores left as partial lines (measured WRITE_SIZE 65 MB for a 4 MB table).
 template <bool FILL>
-__global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restrict__ idx, int N, int MK, int GB, int per,
+__global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restrict__ idx, int B, int N, int MK, int GB, int per,
                                                              int *__restrict__ table, const int *__restrict__ inv_off,
                                                              int *__restrict__ inv_slots) {
   extern __shared__ int lds_cnt[];
   const int lane = lane_id();
   const int wpb = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int g = blockIdx.x * wpb + wave;
-  const int b = blockIdx.y;
+  const int b = (int)(blockIdx.x % (unsigned)B);
+  const int gblk = (int)(blockIdx.x / (unsigned)B);
+  const int g = gblk * wpb + wave;
   int *h = lds_cnt + (size_t)wave * N;
-  int *row = table + ((size_t)b * GB + blockIdx.x) * N;
+  int *row = table + ((size_t)b * GB + gblk) * N;
   for (int i = lane; i < N; i += CL3D_WAVE) h[i] = 0;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -291,13 +296,13 @@ extern "C" int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK
                                 128 * 1024, "build_inverse_index");
     if (rc_lds != CL3D_OK) return rc_lds;
     int *table = static_cast<int *>(ws);
-    const dim3 grid(plan.G / plan.wpb, B), block(64 * plan.wpb);
     const int GB = plan.G / plan.wpb;
-    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<false>), grid, block, plan.lds, st, idx, N, MK, GB, plan.per,
+    const dim3 grid((unsigned)GB * (unsigned)B), block(64 * plan.wpb);
+    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<false>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per,
                        table, (const int *)nullptr, (int *)nullptr);
     hipLaunchKernelGGL(cl3d::csr_rows_kernel, dim3(cl3d::ceil_div(N, 64), B), dim3(256), 0, st, N, GB, table, inv_off);
     hipLaunchKernelGGL(cl3d::csr_scan_kernel, dim3(B), dim3(1024), 0, st, N, inv_off);
-    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true>), grid, block, plan.lds, st, idx, N, MK, GB, plan.per,
+    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per,
                        table, (const int *)inv_off, inv_slots);
     return cl3d::check_launch("cl3d_build_inverse_index");
   }

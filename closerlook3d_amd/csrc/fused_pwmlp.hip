@@ -197,14 +197,22 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
       const size_t orow = ((size_t)b * M + j) * Co + c0;
 
       if constexpr (MODE == PW_TRAIN) {
-        float s1[V], s2[V], sr0[V], sr1[V], sr2[V], best[V], sgn[V];
+        // everything inside the slot loop works on y' = sgn * y (sgn = sign(gamma) = sign(scale): which extreme of
+        // y wins the max).  Negation is exact, so with w' = sgn*w and h' = sgn*h,  y' = fma(g, sgn, w'.rel + h')
+        // is sgn * y bit for bit, sum y'^2 = sum y^2, and sum y / sum y*rel are sgn times the primed sums --
+        // the sign costs nothing per slot.
+        float s1[V], s2[V], sr0[V], sr1[V], sr2[V], best[V], sgn[V], ws[V][3], hs[V];
         int kb[V];
         float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           s1[v] = s2[v] = sr0[v] = sr1[v] = sr2[v] = best[v] = 0.f;
           kb[v] = 0;
-          sgn[v] = c_v0[v] < 0.f ? -1.f : 1.f;  // sign(gamma) = sign(scale): which extreme of y wins the max
+          sgn[v] = c_v0[v] < 0.f ? -1.f : 1.f;
+          ws[v][0] = sgn[v] * w[v][0];
+          ws[v][1] = sgn[v] * w[v][1];
+          ws[v][2] = sgn[v] * w[v][2];
+          hs[v] = sgn[v] * hc.v[v];
         }
         if (q_on) {
         for_each_slot<V, KB>(myslots, K, rows, row, c0, [&](int k, const float4 &sr, const Vec<V> &gr) {
@@ -213,15 +221,17 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
           rs2 += sr.w;
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gr.v[v]);
+            float t = ws[v][0] * sr.y;
+            t = __builtin_fmaf(ws[v][1], sr.z, t);
+            t = __builtin_fmaf(ws[v][2], sr.w, t);
+            const float y = __builtin_fmaf(gr.v[v], sgn[v], t + hs[v]);  // = sgn * pw_preact(w, rel, hc, g)
             s1[v] += y;
             s2[v] = __builtin_fmaf(y, y, s2[v]);
             sr0[v] = __builtin_fmaf(y, sr.y, sr0[v]);
             sr1[v] = __builtin_fmaf(y, sr.z, sr1[v]);
             sr2[v] = __builtin_fmaf(y, sr.w, sr2[v]);
-            const float yy = sgn[v] * y;
-            if (k == 0 || yy > best[v]) {  // first extreme
-              best[v] = yy;
+            if (k == 0 || y > best[v]) {  // first extreme
+              best[v] = y;
               kb[v] = k;
             }
           }
@@ -230,6 +240,10 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           ys.v[v] = sgn[v] * best[v];
+          s1[v] *= sgn[v];
+          sr0[v] *= sgn[v];
+          sr1[v] *= sgn[v];
+          sr2[v] *= sgn[v];
           sy.v[v] = s1[v];
         }
         store_row<V>(a.ystar_t + orow, ys);
@@ -676,30 +690,37 @@ struct FinArgs {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
-  constexpr int NS = MODE == FIN_STATS ? 8 : 5;
-  __shared__ double s_red[NS][256];
+  // thread t sums column k = t & 7 of the partial records g = t >> 3 (mod 32): a wave reads 8 whole 64-byte records
+  // per load, kFinBatch loads are in flight per thread (the sums are a chain of memory round trips otherwise:
+  // measured 16.5 us for 1024 records x 64 channels before), and the 32 partial sums of a column are folded in a
+  // fixed order -- lanes by shuffle, then the four waves.
+  constexpr int kFinBatch = 8;
+  __shared__ double s_red[4][8];
+  __shared__ double s_tot[8];
   const int c = blockIdx.x;
-  double acc[NS];
+  const int k = threadIdx.x & 7, gl = threadIdx.x >> 3;
+  double acc = 0.0;
+  for (int g0 = 0; g0 < a.G; g0 += 32 * kFinBatch) {
+    double v[kFinBatch];
 #pragma unroll
-  for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-  for (int g = threadIdx.x; g < a.G; g += 256) {
-    const double *p = a.partial + ((size_t)g * a.Co + c) * kPartialW;
-#pragma unroll
-    for (int k = 0; k < NS; ++k) acc[k] += p[k];
-  }
-#pragma unroll
-  for (int k = 0; k < NS; ++k) s_red[k][threadIdx.x] = acc[k];
-  __syncthreads();
-  for (int w = 128; w >= 1; w >>= 1) {
-    if ((int)threadIdx.x < w) {
-#pragma unroll
-      for (int k = 0; k < NS; ++k) s_red[k][threadIdx.x] += s_red[k][threadIdx.x + w];
+    for (int u = 0; u < kFinBatch; ++u) {
+      const int g = g0 + u * 32 + gl;
+      v[u] = a.partial[((size_t)(g < a.G ? g : a.G - 1) * a.Co + c) * kPartialW + k];
     }
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kFinBatch; ++u)
+      if (g0 + u * 32 + gl < a.G) acc += v[u];
   }
+  acc += __shfl_xor(acc, 8, CL3D_WAVE);
+  acc += __shfl_xor(acc, 16, CL3D_WAVE);
+  acc += __shfl_xor(acc, 32, CL3D_WAVE);
+  if ((threadIdx.x & 63) < 8) s_red[threadIdx.x >> 6][k] = acc;
+  __syncthreads();
+  if (threadIdx.x < 8) s_tot[k] = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
+  __syncthreads();
   if (threadIdx.x != 0) return;
   if constexpr (MODE == FIN_STATS) {
-    const double s0 = s_red[0][0], s1 = s_red[1][0];
+    const double s0 = s_tot[0], s1 = s_tot[1];
     const double mean = s0 / a.count;
     double var = s1 / a.count - mean * mean;
     var = var > 0.0 ? var : 0.0;
@@ -710,7 +731,7 @@ __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
     a.o2[c] = (float)mean;
     a.o3[c] = (float)invstd;
 #pragma unroll
-    for (int k = 0; k < 6; ++k) a.sums[c * 6 + k] = s_red[2 + k][0];
+    for (int k = 0; k < 6; ++k) a.sums[c * 6 + k] = s_tot[2 + k];
     if (a.running_mean != nullptr) {  // nn.BatchNorm2d: running = (1-m) running + m batch, unbiased variance
       const double unbiased = var * (a.count / (a.count > 1.0 ? a.count - 1.0 : 1.0));
       a.running_mean[c] = a.running_mean[c] * (1.0f - a.momentum) + a.momentum * (float)mean;
@@ -718,7 +739,7 @@ __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
     }
   } else {
     // BatchNorm backward, affine in y:  dy = A dz [k = k*] + Bc + D y   (s0 = sum dz = d beta, s1 = sum dz*xhat = d gamma)
-    const double s0 = s_red[0][0], s1 = s_red[1][0];
+    const double s0 = s_tot[0], s1 = s_tot[1];
     const double invstd = (double)a.invstd_in[c], mean = (double)a.mean_in[c];
     const double A = (double)a.gamma[c] * invstd;
     const double D = -A * invstd * s1 / a.count;
@@ -731,7 +752,7 @@ __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
     // d W_r[c][a] = sum_{slots} dy * rel_a = A T_a + Bc R_a + D S_a
 #pragma unroll
     for (int k = 0; k < 3; ++k)
-      a.o5[c * 3 + k] = (float)(A * s_red[2 + k][0] + Bc * a.sums[c * 6 + 3 + k] + D * a.sums[c * 6 + k]);
+      a.o5[c * 3 + k] = (float)(A * s_tot[2 + k] + Bc * a.sums[c * 6 + 3 + k] + D * a.sums[c * 6 + k]);
   }
 }
 
