@@ -37,11 +37,11 @@ SIGNATURES = {
     "cl3d_dataset_grid_subsampling": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "cl3d_transpose": [_P, _I, _I, _I, _P, _P],
     "cl3d_bn_partials": [_I, _I, _I],
-    "cl3d_bn_relu_stats": [_P, _I, _I, _I, _P, _I, ctypes.c_double, _F, _F] + [_P] * 9,
+    "cl3d_bn_relu_stats": [_P, _I, _I, _I, _P, _I, ctypes.c_double, _F, _F] + [_P] * 10,
     "cl3d_bn_relu_apply": [_P, _P, _P, _I, _I, _I, _P, _P],
     "cl3d_bn_relu_bwd": [_P] * 7 + [_I, _I, _I, ctypes.c_double, _P, _I, _P, _P, _P],
     "cl3d_bn_add_relu_apply": [_P] * 6 + [_I, _I, _I, _I, _P, _P],
-    "cl3d_bn_add_relu_train_fwd": [_P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
+    "cl3d_bn_add_relu_train_fwd": [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
     "cl3d_bn_add_relu_bwd": [_P] * 10 + [_I, _I, _I, _I, ctypes.c_double, _P, _I, _P, _P, _P, _P, _P],
     "cl3d_pwmlp_partials": [_I, _I, _I],
     "cl3d_pwmlp_point_gemm_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P],
@@ -54,7 +54,7 @@ SIGNATURES = {
     "cl3d_pwmlp_split_weight": [_P, _I, _I, _P, _P, _P],
     "cl3d_pwmlp_merge_weight_grad": [_P, _P, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_stats": [_P] * 6 + [_I] * 5 + [_F, _P, _P, _P, _P, _P, _P, _P, _I, _P],
-    "cl3d_pwmlp_finalize_stats": [_P, _I, _I, ctypes.c_double, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "cl3d_pwmlp_finalize_stats": [_P, _I, _I, ctypes.c_double, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "cl3d_pwmlp_apply": [_P, _P, _P, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P],
     "cl3d_pwmlp_bwd_rows": [_P, _I] + [_P] * 8 + [_I] * 4 + [_P, _P, _P, _I, _P],

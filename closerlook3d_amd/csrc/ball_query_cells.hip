@@ -40,9 +40,7 @@ constexpr int kPrepU = 4;    // point sweeps in flight per thread in the prep ke
 struct BqGrid {
   float ox, oy, oz, inv_h;
   int nx, ny, nz, ncells;
-  int ntasks, nv;
-  int ticket;  // tasks handed out beyond the first one of every wave (bq_query_kernel); zeroed by the prep kernel
-  int pad1;
+  int ntasks, nv, pad0, pad1;
 };
 
 // One task = up to kBqQW queries of one cell, together with that cell's candidate window: the <= 9
@@ -371,7 +369,7 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
     BqGrid g;
     g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_h = inv_h;
     g.nx = nx; g.ny = ny; g.nz = nz; g.ncells = ncells;
-    g.ntasks = total[2]; g.nv = nv; g.ticket = 0; g.pad1 = 0;
+    g.ntasks = total[2]; g.nv = nv; g.pad0 = g.pad1 = 0;
     w.grid[b] = g;
   }
 }
@@ -423,13 +421,9 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
   const BqTask *tasks = w.tasks + (size_t)b * w.max_tasks;
   int *oflow = w.overflow + (size_t)b * M;
 
-  // tasks differ in length (candidate window, list sizes) and there are a few thousand of them per cloud: a wave
-  // takes its first task by position and every further one from a per-cloud ticket counter, drawn BEFORE the
-  // current task is processed so the atomic's round trip is hidden behind it
-  int *ticket = &w.grid[b].ticket;
-  for (int t = blockIdx.x * 4 + wave; t < ntasks;) {
-    int drawn = 0;
-    if (lane == 0) drawn = atomicAdd(ticket, 1);
+  // (a per-cloud ticket counter for dynamic balance was tried: ~2300 returning atomics on one address per cloud
+  // serialise at ~60 ns each -- 148 us for the kernel against 53 us with this static walk)
+  for (int t = blockIdx.x * 4 + wave; t < ntasks; t += gridDim.x * 4) {
     const BqTask tk = tasks[t];
     const int n = tk.n;
     int jq[kBqQW];
@@ -592,7 +586,6 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    t = (int)gridDim.x * 4 + __builtin_amdgcn_readfirstlane(drawn);
   }
 }
 
@@ -624,12 +617,11 @@ int ball_query_cells(const float *query_xyz, const float *support_xyz, const int
   hipLaunchKernelGGL(bq_prep_kernel, dim3(parts, B), dim3(1024), 2 * kMaxCells * sizeof(int), st, query_xyz, support_xyz,
                      support_mask, M, N, radius, w);
   const size_t lds = (size_t)4 * bq_lds_ints_per_wave(K) * sizeof(int);
-  // resident capacity of the chip (8 workgroups per CU by LDS and registers) shared by the clouds; the ticket
-  // counter balances the rest
-  int gx = 2048 / (B > 0 ? B : 1);
-  const int most = ceil_div(w.max_tasks, 4);
-  gx = gx < 16 ? 16 : gx;
-  gx = gx > most ? most : gx;
+  // one task per wave: M/QW tasks if every cell held a multiple of QW queries, plus one per cell with a remainder
+  // (the host does not know the cell count: M/8 extra covers the metric shape's ~12 %; waves without a task leave at
+  // once, waves beyond the cap walk the table with the grid's stride)
+  int gx = ceil_div(ceil_div(M, kBqQW) + ceil_div(M, 8), 4);
+  gx = gx > 1024 ? 1024 : gx;
   hipLaunchKernelGGL(bq_query_kernel, dim3(gx, B), dim3(256), lds, st, query_xyz, query_mask, M, N, radius * radius, K, w, idx, idx_mask);
   int rc = check_launch("cl3d_masked_ordered_ball_query(cells)");
   if (rc != CL3D_OK) return rc;

@@ -130,6 +130,7 @@ struct BnFinArgs {
   float eps, momentum;
   const float *gamma, *beta, *mean_in, *invstd_in;
   float *running_mean, *running_var;
+  long long *num_batches_tracked;  // nn.BatchNorm's step counter, bumped by the block of channel 0 (may be null)
   float *o0, *o1, *o2, *o3, *o4;
 };
 
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(64) void bn_finalize_kernel(BnFinArgs a) {
       a.running_mean[c] = a.running_mean[c] * (1.0f - a.momentum) + a.momentum * (float)mean;
       a.running_var[c] = a.running_var[c] * (1.0f - a.momentum) + a.momentum * (float)unbiased;
     }
+    if (c == 0 && a.num_batches_tracked != nullptr) *a.num_batches_tracked += 1;
   } else {  // dx = A dz + Bc + D x   (s0 = sum dz = d beta, s1 = sum dz * xhat = d gamma)
     const double invstd = (double)a.invstd_in[c], mean = (double)a.mean_in[c];
     const double A = (double)a.gamma[c] * invstd;
@@ -297,6 +299,7 @@ struct BnSmallArgs {
   const float *x1, *x2, *g, *out_ref;
   const float *gamma1, *beta1, *gamma2, *beta2;
   float *rm1, *rv1, *rm2, *rv2;
+  long long *nbt1, *nbt2;  // num_batches_tracked of the two BatchNorms (may be null)
   float *vec1, *vec2;    // [4,C]: scale, shift, mean, invstd (written by forward, read by backward)
   float *coef1, *coef2;  // [5,C]: A, Bc, D, d gamma, d beta (backward)
   float *o1, *o2;
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(256) void bn2_fwd_small_kernel(BnSmallArgs a) {
       a.rm1[c] = a.rm1[c] * (1.0f - a.mom1) + a.mom1 * (float)mean;
       a.rv1[c] = a.rv1[c] * (1.0f - a.mom1) + a.mom1 * (float)unbiased;
     }
+    if (c == 0 && a.nbt1) *a.nbt1 += 1;
   }
   if (a.mode2 == 2) {
     channel_stats<VEC>(a.x2, c, a.B, a.C, a.N, scratch, mean, var);
@@ -388,6 +392,7 @@ __global__ __launch_bounds__(256) void bn2_fwd_small_kernel(BnSmallArgs a) {
         a.rm2[c] = a.rm2[c] * (1.0f - a.mom2) + a.mom2 * (float)mean;
         a.rv2[c] = a.rv2[c] * (1.0f - a.mom2) + a.mom2 * (float)unbiased;
       }
+      if (c == 0 && a.nbt2) *a.nbt2 += 1;
     }
   }
   __syncthreads();
@@ -477,8 +482,8 @@ extern "C" int cl3d_bn_partials(int B, int C, int N) {
 
 extern "C" int cl3d_bn_relu_stats(const float *x, int B, int C, int N, double *partial, int n_partials, double count,
                                   float eps, float momentum, const float *gamma, const float *beta,
-                                  float *running_mean, float *running_var, float *scale, float *shift, float *mean,
-                                  float *invstd, cl3d_stream_t stream) {
+                                  float *running_mean, float *running_var, int64_t *num_batches_tracked, float *scale,
+                                  float *shift, float *mean, float *invstd, cl3d_stream_t stream) {
   using namespace cl3d;
   CL3D_REQUIRE(B >= 1 && C >= 1 && N >= 1 && count > 0, "bn_relu_stats: bad sizes");
   CL3D_REQUIRE(x && partial && gamma && beta && scale && shift && mean && invstd, "bn_relu_stats: null pointer");
@@ -490,6 +495,7 @@ extern "C" int cl3d_bn_relu_stats(const float *x, int B, int C, int N, double *p
   BnFinArgs f{};
   f.partial = partial; f.G = n_partials; f.C = C; f.count = count; f.eps = eps; f.momentum = momentum;
   f.gamma = gamma; f.beta = beta; f.running_mean = running_mean; f.running_var = running_var;
+  f.num_batches_tracked = reinterpret_cast<long long *>(num_batches_tracked);
   f.o0 = scale; f.o1 = shift; f.o2 = mean; f.o3 = invstd;
   hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(C), dim3(64), 0, (hipStream_t)stream, f);
   return check_launch("cl3d_bn_relu_stats");
@@ -597,9 +603,10 @@ extern "C" int cl3d_bn_add_relu_bwd(const float *g, const float *out, const floa
 // statistics updated with nn.BatchNorm1d's rule, vec1 / vec2 [4,C] = scale, shift, mean, invstd left for the backward
 // pass, out = act(BN1(x1) + R).  One launch when a channel has few values, statistics + apply passes otherwise.
 extern "C" int cl3d_bn_add_relu_train_fwd(const float *x1, const float *gamma1, const float *beta1, float *running_mean1,
-                                          float *running_var1, float eps1, float momentum1, const float *x2,
-                                          const float *gamma2, const float *beta2, float *running_mean2,
-                                          float *running_var2, float eps2, float momentum2, int relu, int B, int C, int N,
+                                          float *running_var1, int64_t *num_batches_tracked1, float eps1, float momentum1,
+                                          const float *x2, const float *gamma2, const float *beta2, float *running_mean2,
+                                          float *running_var2, int64_t *num_batches_tracked2, float eps2, float momentum2,
+                                          int relu, int B, int C, int N,
                                           double *partial, int n_partials, float *vec1, float *vec2, float *out,
                                           cl3d_stream_t stream) {
   using namespace cl3d;
@@ -611,6 +618,8 @@ extern "C" int cl3d_bn_add_relu_train_fwd(const float *x1, const float *gamma1, 
     BnSmallArgs s{};
     s.x1 = x1; s.x2 = x2; s.gamma1 = gamma1; s.beta1 = beta1; s.gamma2 = gamma2; s.beta2 = beta2;
     s.rm1 = running_mean1; s.rv1 = running_var1; s.rm2 = running_mean2; s.rv2 = running_var2;
+    s.nbt1 = reinterpret_cast<long long *>(num_batches_tracked1);
+    s.nbt2 = reinterpret_cast<long long *>(num_batches_tracked2);
     s.vec1 = vec1; s.vec2 = vec2; s.o1 = out; s.B = B; s.C = C; s.N = N;
     s.eps1 = eps1; s.mom1 = momentum1; s.eps2 = eps2; s.mom2 = momentum2; s.mode2 = mode2; s.relu = relu;
     if ((N & 3) == 0) hipLaunchKernelGGL(bn2_fwd_small_kernel<4>, dim3(C), dim3(256), 0, st, s);
@@ -619,11 +628,11 @@ extern "C" int cl3d_bn_add_relu_train_fwd(const float *x1, const float *gamma1, 
   }
   CL3D_REQUIRE(partial && n_partials == cl3d_bn_partials(B, C, N), "bn_add_relu_train_fwd: partial buffer");
   int rc = cl3d_bn_relu_stats(x1, B, C, N, partial, n_partials, (double)B * N, eps1, momentum1, gamma1, beta1, running_mean1,
-                              running_var1, vec1, vec1 + C, vec1 + 2 * C, vec1 + 3 * C, stream);
+                              running_var1, num_batches_tracked1, vec1, vec1 + C, vec1 + 2 * C, vec1 + 3 * C, stream);
   if (rc != CL3D_OK) return rc;
   if (mode2 == 2) {
     rc = cl3d_bn_relu_stats(x2, B, C, N, partial, n_partials, (double)B * N, eps2, momentum2, gamma2, beta2, running_mean2,
-                            running_var2, vec2, vec2 + C, vec2 + 2 * C, vec2 + 3 * C, stream);
+                            running_var2, num_batches_tracked2, vec2, vec2 + C, vec2 + 2 * C, vec2 + 3 * C, stream);
     if (rc != CL3D_OK) return rc;
   }
   return cl3d_bn_add_relu_apply(x1, vec1, vec1 + C, x2, mode2 == 2 ? vec2 : nullptr, mode2 == 2 ? vec2 + C : nullptr, relu, B,

@@ -684,6 +684,7 @@ struct FinArgs {
   float eps, momentum;
   const float *gamma, *beta, *mean_in, *invstd_in;
   float *running_mean, *running_var;
+  long long *num_batches_tracked;  // nn.BatchNorm's step counter, bumped by the block of channel 0 (may be null)
   double *sums;           // [Co,6]: S_a = sum y*rel_a, R_a = sum rel_a  (STATS writes, COEFFS reads)
   float *o0, *o1, *o2, *o3, *o4, *o5;
 };
@@ -737,6 +738,7 @@ __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
       a.running_mean[c] = a.running_mean[c] * (1.0f - a.momentum) + a.momentum * (float)mean;
       a.running_var[c] = a.running_var[c] * (1.0f - a.momentum) + a.momentum * (float)unbiased;
     }
+    if (c == 0 && a.num_batches_tracked != nullptr) *a.num_batches_tracked += 1;
   } else {
     // BatchNorm backward, affine in y:  dy = A dz [k = k*] + Bc + D y   (s0 = sum dz = d beta, s1 = sum dz*xhat = d gamma)
     const double s0 = s_tot[0], s1 = s_tot[1];
@@ -934,13 +936,15 @@ extern "C" int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz
 
 extern "C" int cl3d_pwmlp_finalize_stats(const double *partial, int n_partials, int Co, double count, float eps,
                                          float momentum, const float *gamma, const float *beta,
-                                         float *running_mean, float *running_var, float *scale, float *shift,
-                                         float *mean, float *invstd, double *sums, cl3d_stream_t stream) {
+                                         float *running_mean, float *running_var, int64_t *num_batches_tracked,
+                                         float *scale, float *shift, float *mean, float *invstd, double *sums,
+                                         cl3d_stream_t stream) {
   CL3D_REQUIRE(partial && gamma && beta && scale && shift && mean && invstd && sums && n_partials > 0 && Co > 0 && count > 0,
                "pwmlp_finalize_stats: bad arguments");
   cl3d::FinArgs a{};
   a.partial = partial; a.G = n_partials; a.Co = Co; a.count = count; a.eps = eps; a.momentum = momentum;
   a.gamma = gamma; a.beta = beta; a.running_mean = running_mean; a.running_var = running_var;
+  a.num_batches_tracked = reinterpret_cast<long long *>(num_batches_tracked);
   a.o0 = scale; a.o1 = shift; a.o2 = mean; a.o3 = invstd; a.sums = sums;
   hipLaunchKernelGGL((cl3d::pwmlp_finalize_kernel<cl3d::FIN_STATS>), dim3(Co), dim3(256), 0, (hipStream_t)stream, a);
   return cl3d::check_launch("cl3d_pwmlp_finalize_stats");

@@ -619,272 +619,12 @@ static void launch_modes(GemmArgs &a, int wi, int wj, int blocks, hipStream_t st
 }
 
 
-// ---- the same product with an LDS ring filled by LDS-DMA (global_load_lds_dwordx4) --------------------------------
-// The register-staged kernel above keeps at most two 16-32 KB chunks in flight per workgroup; with K = 288 .. 2304 and
-// a few hundred workgroups on the chip (the deep stages) every chunk then costs an HBM / L2 round trip.  Here a stage
-// of the ring is written straight from global memory into LDS by DMA, S - 1 stages ahead of the one being multiplied,
-// with a counted `s_waitcnt vmcnt(N)` (never 0 in the steady state) and ONE raw `s_barrier` per chunk:
-//     wait for my pieces of chunk g -> barrier (everybody's pieces landed, everybody left chunk g-1) ->
-//     issue chunk g+S-1 into the buffer chunk g-1 just left -> multiply chunk g.
-// LDS-DMA writes lane-linear images (wave-uniform base + lane * 16 bytes), so layouts are chosen by the SOURCE address:
-//   r-contiguous operand (channel-major x, W^T):  image [KC][TR] floats, a piece = 256 consecutive floats of it;
-//                                                 fragments are ds_read_b32 of 32 consecutive floats: conflict-free;
-//   k-contiguous operand (weight rows, point-major rows): image [TR][KC] floats, rows of 128 bytes, the eight 16-byte
-//                                                 chunks of a row XOR-swizzled with (row & 7) on the source side (a
-//                                                 piece = 8 rows x 128 bytes, full lines from memory); a fragment is
-//                                                 ONE ds_read_b128 = four consecutive k of a row.
-// The contraction index is permuted inside a chunk so that both kinds agree: MFMA step 4q + e of lane half h multiplies
-// k = 8q + 4h + e (the sum over k does not care).  Needs K % 8 == 0, 16-byte alignment and clouds folded on r only;
-// rows / k beyond the operand are clamped to valid addresses -- their products land in accumulator rows / columns that
-// are never stored, and k steps beyond K are not issued.  f32 (v_mfma_f32_32x32x2_f32).
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void global_void_t;
+// (An LDS-ring variant of this kernel -- stages written by global_load_lds_dwordx4 DMA three chunks ahead, counted
+// s_waitcnt vmcnt, one raw s_barrier per chunk, inline-asm fragment reads -- was built and measured in round 2: equal
+// results, 5-10 % faster on the deepest layers (K >= 576, 64 points per cloud), 20-35 % SLOWER on the 4096-point
+// layers and, with ~100 KiB of LDS per workgroup, it starves whatever kernel runs beside it on another stream
+// (the ball query next to the per-point GEMM: 148 us instead of 53).  Removed; see git history and DESIGN.md 3.2.)
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 ds_b128(unsigned addr) {
-  f32x4 v;
-  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-  return v;
-}
-// four rows of an r-contiguous image: addr + BASE + {0, 1, 2, 3} * STRIDE bytes (immediate offsets, one address VGPR)
-template <int BASE, int STRIDE>
-__device__ __forceinline__ f32x4 ds_rows4(unsigned addr) {
-  float v0, v1, v2, v3;
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v0) : "v"(addr), "n"(BASE));
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v1) : "v"(addr), "n"(BASE + STRIDE));
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v2) : "v"(addr), "n"(BASE + 2 * STRIDE));
-  asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v3) : "v"(addr), "n"(BASE + 3 * STRIDE));
-  f32x4 r = {v0, v1, v2, v3};
-  return r;
-}
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-template <int WI, int WJ, bool A_KC, bool B_KC, int S>
-__global__ __launch_bounds__(256, 1) void mfma_ring_kernel(GemmArgs a) {
-  constexpr int TI = 64 * WI, TJ = 64 * WJ, KC = 32;
-  constexpr int kAFloats = KC * TI, kBFloats = KC * TJ, kStageFloats = kAFloats + kBFloats;
-  constexpr int PA = kAFloats / 256, PB = kBFloats / 256, P = PA + PB;  // 1 KB pieces per stage
-  constexpr int PPW = P / 4;                                            // pieces per wave and stage
-  static_assert(P % 4 == 0, "pieces must divide over the four waves");
-  extern __shared__ __attribute__((aligned(16))) float ring[];
-
-  int bid = blockIdx.x;
-  const int tj = bid % a.tiles_j;
-  bid /= a.tiles_j;
-  const int ti = bid % a.tiles_i;
-  const int z = bid / a.tiles_i;
-  const int i0 = ti * TI, j0 = tj * TJ;
-  const int chunks = (a.K + KC - 1) / KC;
-  int g0 = 0, g1 = chunks;
-  if (a.nsplit > 1) {
-    g0 = z * a.chunks_per_split;
-    g1 = g0 + a.chunks_per_split;
-    if (g1 > chunks) g1 = chunks;
-  }
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wi0 = (wave >> 1) * 32 * WI, wj0 = (wave & 1) * 32 * WJ;
-  const int lr = lane & 31, lh = lane >> 5;
-
-  // ---- this wave's pieces: pieces w, w+4, w+8, ... of the stage; per piece a loop-invariant lane offset (elements)
-  // and what one chunk adds to it
-  unsigned poff[PPW];
-  int pstep[PPW];          // elements added per chunk (KC * sk for an r-contiguous operand, KC for a k-contiguous one)
-  int pkoff[PPW];          // k (rc) or first k of the lane's quad (kc) inside a chunk: clamped per chunk at the K tail
-  int pkmul[PPW];          // element stride of k for this piece's operand
-#pragma unroll
-  for (int u = 0; u < PPW; ++u) {
-    const int pc = wave + 4 * u;  // piece index inside the stage, A pieces first
-    const bool isA = pc < PA;
-    const GemmOperand &op = isA ? a.A : a.B;
-    const bool kc_kind = isA ? A_KC : B_KC;
-    const int TR = isA ? TI : TJ;
-    const int pl = isA ? pc : pc - PA;
-    const int t0 = isA ? i0 : j0;
-    int r, k;
-    if (!kc_kind) {  // image [KC][TR]: float offset pl*256 + 4*lane
-      const int off = pl * 256 + 4 * lane;
-      k = off / TR;
-      r = off - k * TR;
-    } else {         // image [TR][KC], 16-byte chunks swizzled: row = 8*pl + lane/8, source chunk = (lane&7) ^ (row&7)
-      r = 8 * pl + (lane >> 3);
-      k = 4 * ((lane & 7) ^ (r & 7));
-    }
-    int rg = t0 + r;
-    rg = rg < op.R ? rg : op.R - (kc_kind ? 1 : 4);  // beyond the operand: any valid address (never stored / multiplied)
-    if (rg < 0) rg = 0;
-    unsigned base;
-    if (op.fold == 1) {
-      const int b = rg / op.fold_n;
-      base = (unsigned)(b * (int)op.sb + (rg - b * op.fold_n) * op.sr);
-    } else {
-      base = (unsigned)(rg * op.sr);
-    }
-    poff[u] = base;
-    pkoff[u] = k;
-    pkmul[u] = op.sk;
-    pstep[u] = KC * op.sk;
-  }
-  auto issue = [&](int g) {
-    float *stage = ring + (size_t)((g - g0) % S) * kStageFloats;
-    const int k0 = g * KC;
-#pragma unroll
-    for (int u = 0; u < PPW; ++u) {
-      const int pc = wave + 4 * u;
-      const bool isA = pc < PA;
-      const GemmOperand &op = isA ? a.A : a.B;
-      int k = k0 + pkoff[u];
-      const int kmax = a.K - ((isA ? A_KC : B_KC) ? 4 : 1);  // K tail: clamp to the last quad / row (not multiplied)
-      k = k <= kmax ? k : kmax;
-      const float *src = op.p + (poff[u] + (unsigned)(k * pkmul[u]));
-      float *dst = stage + (size_t)pc * 256;  // wave-uniform: the DMA adds lane * 16 bytes itself
-      __builtin_amdgcn_global_load_lds((global_void_t *)src, (lds_void_t *)dst, 16, 0, 0);
-    }
-  };
-
-  f32x16 acc[WI][WJ];
-#pragma unroll
-  for (int x = 0; x < WI; ++x)
-#pragma unroll
-    for (int y = 0; y < WJ; ++y)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[x][y][e] = 0.f;
-
-  // Fragment reads are inline asm: to the compiler an LDS-DMA is a store to `ring`, and it would drain the DMA queue
-  // (s_waitcnt vmcnt(0)) ahead of every ordinary LDS load of the loop -- the pipeline this kernel exists for.  The
-  // reads below are invisible to that analysis; their own latency is covered by the lgkmcnt wait that takes the loaded
-  // registers as operands, so no MFMA can be scheduled ahead of it.
-  const unsigned ring_base = (unsigned)(size_t)(lds_void_t *)ring;
-  unsigned addrA[WI], addrB[WJ];  // byte address of this lane's row inside a stage's image (chunk-invariant part)
-  int swzA[WI], swzB[WJ];
-#pragma unroll
-  for (int x = 0; x < WI; ++x) {
-    const int row = wi0 + 32 * x + lr;
-    addrA[x] = A_KC ? (unsigned)(row * KC * 4) : (unsigned)((4 * lh * TI + row) * 4);
-    swzA[x] = row & 7;
-  }
-#pragma unroll
-  for (int y = 0; y < WJ; ++y) {
-    const int row = wj0 + 32 * y + lr;
-    addrB[y] = (unsigned)(kAFloats * 4) + (B_KC ? (unsigned)(row * KC * 4) : (unsigned)((4 * lh * TJ + row) * 4));
-    swzB[y] = row & 7;
-  }
-  auto multiply = [&](int g) {
-    const unsigned stage = ring_base + (unsigned)(((g - g0) % S) * kStageFloats * 4);
-    const int kleft = a.K - g * KC;
-    const int quads = kleft >= KC ? KC / 8 : kleft / 8;  // K % 8 == 0
-    auto quad = [&](auto qc) {
-      constexpr int Q = decltype(qc)::value;
-      if (Q >= quads) return;
-      f32x4 fa[WI], fb[WJ];
-#pragma unroll
-      for (int x = 0; x < WI; ++x) {
-        if (A_KC) fa[x] = ds_b128(stage + addrA[x] + 16u * (unsigned)((2 * Q + lh) ^ swzA[x]));
-        else fa[x] = ds_rows4<Q * 8 * TI * 4, TI * 4>(stage + addrA[x]);
-      }
-#pragma unroll
-      for (int y = 0; y < WJ; ++y) {
-        if (B_KC) fb[y] = ds_b128(stage + addrB[y] + 16u * (unsigned)((2 * Q + lh) ^ swzB[y]));
-        else fb[y] = ds_rows4<Q * 8 * TJ * 4, TJ * 4>(stage + addrB[y]);
-      }
-      if constexpr (WI == 1 && WJ == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fb[0])::"memory");
-      else if constexpr (WI == 2 && WJ == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0])::"memory");
-      else if constexpr (WI == 1 && WJ == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fb[0]), "+v"(fb[1])::"memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0]), "+v"(fa[1]), "+v"(fb[0]), "+v"(fb[1])::"memory");
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int x = 0; x < WI; ++x)
-#pragma unroll
-          for (int y = 0; y < WJ; ++y)
-            acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[x][e], fb[y][e], acc[x][y], 0, 0, 0);
-    };
-    quad(std::integral_constant<int, 0>{});
-    quad(std::integral_constant<int, 1>{});
-    quad(std::integral_constant<int, 2>{});
-    quad(std::integral_constant<int, 3>{});
-  };
-
-  // prologue: S - 1 chunks in flight
-#pragma unroll
-  for (int s = 0; s < S - 1; ++s)
-    if (g0 + s < g1) issue(g0 + s);
-  for (int g = g0; g < g1; ++g) {
-    // my pieces of chunk g have landed once at most PPW * (chunks issued after g) loads are outstanding
-    const int later = g1 - 1 - g < S - 2 ? g1 - 1 - g : S - 2;
-    if (later >= 3) wait_vmcnt<3 * PPW>();
-    else if (later == 2) wait_vmcnt<2 * PPW>();
-    else if (later == 1) wait_vmcnt<PPW>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (g + S - 1 < g1) issue(g + S - 1);  // into the buffer chunk g-1 was multiplied out of
-    multiply(g);
-  }
-
-  const int I = a.A.R, J = a.B.R;
-  const bool part = a.nsplit > 1;
-  float *Pp = part ? a.partial + (long long)z * I * J : nullptr;
-#pragma unroll
-  for (int x = 0; x < WI; ++x)
-#pragma unroll
-    for (int y = 0; y < WJ; ++y) {
-      const int j = j0 + wj0 + 32 * y + lr;
-      const long long joff = part ? j : out_col(a.out, j);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = i0 + wi0 + 32 * x + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (i < I && j < J) {
-          if (part) Pp[(long long)i * J + j] = acc[x][y][e];
-          else out_store(a.out, i, joff, acc[x][y][e]);
-        }
-      }
-    }
-}
-
-template <int WI, int WJ, bool A_KC, bool B_KC>
-static int launch_ring(const GemmArgs &a, int blocks, hipStream_t st) {
-  constexpr int S = (WI * WJ == 4) ? 3 : 4;  // (stages <= 5: the vmcnt ladder above covers S - 2 <= 3)
-  constexpr size_t bytes = (size_t)S * 32 * 64 * (WI + WJ) * sizeof(float);
-  static std::atomic<unsigned long long> granted{0};
-  const void *fn = reinterpret_cast<const void *>(&mfma_ring_kernel<WI, WJ, A_KC, B_KC, S>);
-  int rc = lds_opt_in(granted, fn, bytes, "mfma_ring");
-  if (rc != CL3D_OK) return rc;
-  hipLaunchKernelGGL((mfma_ring_kernel<WI, WJ, A_KC, B_KC, S>), dim3(blocks), dim3(256), bytes, st, a);
-  return CL3D_OK;
-}
-
-// f32 products whose operands the DMA can carry: 16-byte aligned, clouds folded on r only, K a multiple of 8
-static bool ring_eligible(const GemmArgs &a, int precision) {
-  static const int enabled = [] { const char *e = getenv("CL3D_GEMM_RING"); return e ? atoi(e) : 1; }();
-  if (!enabled || precision != PREC_F32 || a.K % 8 != 0 || a.K < 32) return false;
-  const GemmOperand *ops[2] = {&a.A, &a.B};
-  for (const GemmOperand *o : ops) {
-    if (!o->vec || o->fold == 2) return false;
-    if (o->rc ? (o->sk % 4 != 0) : (o->sr % 4 != 0)) return false;
-    if (o->R < 4) return false;
-  }
-  return !(stage_mode(a.A) == STAGE_VEC_KC && stage_mode(a.B) == STAGE_VEC_KC);
-}
-
-template <bool A_KC, bool B_KC>
-static int launch_ring_shape(const GemmArgs &a, int wi, int wj, int blocks, hipStream_t st) {
-  if (wi == 2 && wj == 2) return launch_ring<2, 2, A_KC, B_KC>(a, blocks, st);
-  if (wi == 2) return launch_ring<2, 1, A_KC, B_KC>(a, blocks, st);
-  if (wj == 2) return launch_ring<1, 2, A_KC, B_KC>(a, blocks, st);
-  return launch_ring<1, 1, A_KC, B_KC>(a, blocks, st);
-}
-
-static int launch_ring_modes(const GemmArgs &a, int wi, int wj, int blocks, hipStream_t st) {
-  const bool akc = !a.A.rc, bkc = !a.B.rc;
-  if (akc && !bkc) return launch_ring_shape<true, false>(a, wi, wj, blocks, st);
-  if (!akc && bkc) return launch_ring_shape<false, true>(a, wi, wj, blocks, st);
-  return launch_ring_shape<false, false>(a, wi, wj, blocks, st);
-}
 
 constexpr int kCUs = 256;
 
@@ -902,8 +642,7 @@ struct Plan {
   int wi, wj, nsplit, cps;
 };
 
-static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes, bool scalar_staging = false,
-                      bool ring = false) {
+static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes, bool scalar_staging = false) {
   const int cand[4][3] = {{2, 2, 2}, {2, 1, 3}, {1, 2, 3}, {1, 1, 4}};  // wi, wj, resident workgroups per CU
   const double peak_flops_per_us = precision == PREC_BF16 ? 1.2e9 : 157.3e6;  // bf16: what staging sustains, not 2.5 PF
   Plan best{2, 1, 1, (int)((K + gemm_kc(precision, 2, 1) - 1) / gemm_kc(precision, 2, 1))};
@@ -915,8 +654,7 @@ static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, s
   long long force_split = 0;
   if (const char *force = getenv("CL3D_GEMM_SPLIT")) force_split = atoll(force);  // tuning override
   for (int c = 0; c < 4; ++c) {
-    // the LDS-ring kernel hides latency inside one workgroup (3-4 stages in flight): one workgroup per CU fills it
-    const int wi = cand[c][0], wj = cand[c][1], resident = ring ? 1 : cand[c][2];
+    const int wi = cand[c][0], wj = cand[c][1], resident = cand[c][2];
     if (force_wi && (wi != force_wi || wj != force_wj)) continue;
     if (scalar_staging && wi * wj == 4) continue;  // the element-wise staging fallback at 128 x 128 runs out of registers
     const int kc = gemm_kc(precision, wi, wj);
@@ -967,7 +705,7 @@ static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t 
   const int am = stage_mode(a.A), bm = stage_mode(a.B);
   const bool vec_pair = (am == STAGE_VEC_RC && bm == STAGE_VEC_KC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_RC) ||
                         (am == STAGE_VEC_RC && bm == STAGE_VEC_RC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_KC);
-  const Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, !vec_pair, ring_eligible(a, precision));
+  const Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, !vec_pair);
   a.tiles_i = ceil_div(I, 64 * p.wi);
   a.tiles_j = ceil_div(J, 64 * p.wj);
   a.nsplit = p.nsplit;
@@ -981,10 +719,7 @@ static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t 
   }
   const long long blocks = (long long)a.tiles_i * a.tiles_j * p.nsplit;
   if (blocks > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "%s: grid too large", who);
-  if (ring_eligible(a, precision)) {
-    const int rc_ring = launch_ring_modes(a, p.wi, p.wj, (int)blocks, st);
-    if (rc_ring != CL3D_OK) return rc_ring;
-  } else if (precision == PREC_BF16) {
+  if (precision == PREC_BF16) {
     launch_modes<PREC_BF16>(a, p.wi, p.wj, (int)blocks, st);
   } else {
     launch_modes<PREC_F32>(a, p.wi, p.wj, (int)blocks, st);

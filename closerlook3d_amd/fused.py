@@ -326,7 +326,7 @@ class _BnRelu(Function):
     has few values (deep stages), statistics + apply passes otherwise; x and the output are kept for backward."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, num_batches_tracked=None):
         x = x.contiguous()
         B, C, N = x.shape
         dev = x.device
@@ -339,8 +339,9 @@ class _BnRelu(Function):
                 nparts = lib.cl3d_bn_partials(B, C, N)
                 partial = torch.empty((nparts, C, 2), dtype=torch.float64, device=dev)
                 _lib.check(lib.cl3d_bn_add_relu_train_fwd(_p(x), _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                                          float(eps), float(momentum), None, None, None, None, None, 0.0,
-                                                          0.0, 1, B, C, N, _p(partial), nparts, _p(vec), None, _p(out), st))
+                                                          _p(num_batches_tracked), float(eps), float(momentum), None, None,
+                                                          None, None, None, None, 0.0, 0.0, 1, B, C, N, _p(partial), nparts,
+                                                          _p(vec), None, _p(out), st))
                 ctx.save_for_backward(x, out, vec, gamma)
                 ctx.meta = (B, C, N, nparts)
             else:
@@ -367,7 +368,19 @@ class _BnRelu(Function):
             _lib.check(_lib.lib().cl3d_bn_add_relu_bwd(_p(g), _p(out), _p(x), _p(vec[2]), _p(vec[3]), _p(gamma), None, None,
                                                       None, None, 1, B, C, N, float(B * N), _p(partial), nparts, _p(coef),
                                                       None, _p(dx), None, _stream(g)))
-        return dx, coef[3], coef[4], None, None, None, None, None
+        return dx, coef[3], coef[4], None, None, None, None, None, None
+
+
+def _step_counter(bn):
+    """nn.BatchNorm's num_batches_tracked when the engine can bump it inside the statistics kernel (an int64 scalar on
+    the module's device, as PyTorch registers it); anything else is bumped here and None is returned."""
+    t = getattr(bn, 'num_batches_tracked', None)
+    if t is None:
+        return None
+    if t.dtype == torch.int64 and t.is_cuda and t.numel() == 1:
+        return t
+    t.add_(1)
+    return None
 
 
 def bn_relu(x, bn):
@@ -378,9 +391,9 @@ def bn_relu(x, bn):
             or not bn.track_running_stats or (not training and torch.is_grad_enabled() and
                                               _wants_grad(x, bn.weight, bn.bias))):
         return None
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return _BnRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps)
+    # num_batches_tracked is bumped by the kernel that updates the running statistics (no launch of its own)
+    return _BnRelu.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, bn.momentum, bn.eps,
+                         _step_counter(bn) if training else None)
 
 
 class _PointwiseMLP(Function):
@@ -388,7 +401,7 @@ class _PointwiseMLP(Function):
 
     @staticmethod
     def forward(ctx, ght, wr, gamma, beta, running_mean, running_var, query_xyz, support_xyz, idx, radius,
-                training, momentum, eps, need_grad):
+                training, momentum, eps, need_grad, num_batches_tracked=None):
         B, N, two_co = ght.shape
         Co = two_co // 2
         _, M, K = idx.shape
@@ -419,7 +432,8 @@ class _PointwiseMLP(Function):
                 # batch statistics, scale/shift and the running-statistics update in one small launch
                 _lib.check(lib.cl3d_pwmlp_finalize_stats(_p(partial), nparts, Co, float(n), float(eps), float(momentum),
                                                          _p(gamma), _p(beta), _p(running_mean), _p(running_var),
-                                                         _p(scale), _p(shift), _p(mean), _p(invstd), _p(sums), st))
+                                                         _p(num_batches_tracked), _p(scale), _p(shift), _p(mean),
+                                                         _p(invstd), _p(sums), st))
                 _lib.check(lib.cl3d_pwmlp_apply(_p(ystar), _p(scale), _p(shift), B, M, Co, _p(out), st))
                 if need_grad:
                     ctx.save_for_backward(ght, wr, gamma, vec, ystar, sy, kstar, slotrec, sums, hq, tstar)
@@ -468,12 +482,15 @@ class _PointwiseMLP(Function):
                                                              _p(vec[3]), _p(sums), _p(cA), _p(cB), _p(cD), _p(dgamma),
                                                              _p(dbeta), _p(dwr), _stream(gout)))
 
-            _fork_join(dev, coeffs, hits)
+            # one after the other: a fork/join across HIP streams costs more idle time in a captured graph (measured
+            # ~29 us before the next kernel starts) than these two short launches take together (~15 us)
+            coeffs()
+            hits()
             off, slots = inverse_index(idx, N)
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
             _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_cm), _p(sy), _p(hq),
                                                   _p(slotrec), _p(off), _p(slots), B, N, M, K, Co, _p(dght), st))
-        return (dght, dwr, dgamma, dbeta) + (None,) * 10
+        return (dght, dwr, dgamma, dbeta) + (None,) * 11
 
 
 import os
@@ -603,12 +620,11 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
     W = conv.weight.view(Co, 3 + 2 * C)
     ght, wr = point_rows(features, W, precision)
     use_batch_stats = training or bn.running_mean is None
-    if use_batch_stats and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
     momentum = bn.momentum  # never None here: use_fused() sends that configuration to the grouped path
     return _PointwiseMLP.apply(ght.contiguous(), wr, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                query_xyz.contiguous(), support_xyz.contiguous(), idx, radius, use_batch_stats,
-                               momentum, bn.eps, _wants_grad(features, conv.weight, bn.weight, bn.bias))
+                               momentum, bn.eps, _wants_grad(features, conv.weight, bn.weight, bn.bias),
+                               _step_counter(bn) if use_batch_stats and bn.track_running_stats else None)
 
 
 # ---------------------------------------------------------------- the 1x1 convolutions and BatchNorm tails of a bottleneck
@@ -676,9 +692,11 @@ class _BnAddRelu(Function):
         partial = torch.empty((nparts, C, 2), dtype=torch.float64, device=dev)
         with _lib.on_device(dev):
             _lib.check(lib.cl3d_bn_add_relu_train_fwd(
-                _p(x1), _p(gamma1), _p(beta1), _p(bn1.running_mean), _p(bn1.running_var), float(bn1.eps), float(bn1.momentum),
+                _p(x1), _p(gamma1), _p(beta1), _p(bn1.running_mean), _p(bn1.running_var), _p(_step_counter(bn1)),
+                float(bn1.eps), float(bn1.momentum),
                 _p(x2), _p(gamma2) if bn2 is not None else None, _p(beta2) if bn2 is not None else None,
                 _p(bn2.running_mean) if bn2 is not None else None, _p(bn2.running_var) if bn2 is not None else None,
+                _p(_step_counter(bn2)) if bn2 is not None else None,
                 float(bn2.eps) if bn2 is not None else 0.0, float(bn2.momentum) if bn2 is not None else 0.0, int(relu),
                 B, C, N, _p(partial), nparts, _p(vec1), _p(vec2), _p(out), _stream(x1)))
         ctx.save_for_backward(x1, x2, out, vec1, vec2, gamma1, gamma2)
@@ -756,9 +774,6 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, res_conv=None, res_bn=Non
             _lib.check(lib.cl3d_conv1x1_bn_act_fwd(_p(x), _p(W.contiguous()), _p(s1), _p(t1), _p(res), int(relu), B, C, N, Co,
                                                    prec, _p(y), _p(ws), ws_bytes, st))
         return y
-    for b in (bn, res_bn):
-        if b is not None and b.num_batches_tracked is not None:
-            b.num_batches_tracked.add_(1)
     if CONV_ENGINE == 'library':
         y1 = torch.nn.functional.conv1d(x, conv.weight)
         x2 = torch.nn.functional.conv1d(residual, res_conv.weight) if res_conv is not None else residual

@@ -140,8 +140,8 @@ int cl3d_dataset_grid_subsampling(const float *points, const float *features, co
 int cl3d_bn_partials(int B, int C, int N);
 int cl3d_bn_relu_stats(const float *x, int B, int C, int N, double *partial, int n_partials, double count,
                        float eps, float momentum, const float *gamma, const float *beta, float *running_mean,
-                       float *running_var, float *scale, float *shift, float *mean, float *invstd,
-                       cl3d_stream_t stream);
+                       float *running_var, int64_t *num_batches_tracked, float *scale, float *shift, float *mean,
+                       float *invstd, cl3d_stream_t stream);
 int cl3d_bn_relu_apply(const float *x, const float *scale, const float *shift, int B, int C, int N, float *out,
                        cl3d_stream_t stream);
 int cl3d_bn_relu_bwd(const float *g, const float *x, const float *scale, const float *shift, const float *mean,
@@ -162,10 +162,11 @@ int cl3d_bn_add_relu_apply(const float *x1, const float *scale1, const float *sh
  * launch per direction when a channel has <= 16384 values (the deep stages), statistics + apply passes otherwise;
  * partial: [cl3d_bn_partials(B,C,N), C, 2] doubles (only touched on the multi-pass route). */
 int cl3d_bn_add_relu_train_fwd(const float *x1, const float *gamma1, const float *beta1, float *running_mean1,
-                               float *running_var1, float eps1, float momentum1, const float *x2, const float *gamma2,
-                               const float *beta2, float *running_mean2, float *running_var2, float eps2,
-                               float momentum2, int relu, int B, int C, int N, double *partial, int n_partials,
-                               float *vec1, float *vec2, float *out, cl3d_stream_t stream);
+                               float *running_var1, int64_t *num_batches_tracked1, float eps1, float momentum1,
+                               const float *x2, const float *gamma2, const float *beta2, float *running_mean2,
+                               float *running_var2, int64_t *num_batches_tracked2, float eps2, float momentum2, int relu,
+                               int B, int C, int N, double *partial, int n_partials, float *vec1, float *vec2,
+                               float *out, cl3d_stream_t stream);
 int cl3d_bn_add_relu_bwd(const float *g, const float *out, const float *x1, const float *mean1, const float *invstd1,
                          const float *gamma1, const float *x2, const float *mean2, const float *invstd2,
                          const float *gamma2, int relu, int B, int C, int N, double count, double *partial,
@@ -286,8 +287,8 @@ int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int
  * d gamma, d beta and d W_r [Co,3]. */
 int cl3d_pwmlp_finalize_stats(const double *partial, int n_partials, int Co, double count, float eps,
                               float momentum, const float *gamma, const float *beta, float *running_mean,
-                              float *running_var, float *scale, float *shift, float *mean, float *invstd,
-                              double *sums, cl3d_stream_t stream);
+                              float *running_var, int64_t *num_batches_tracked, float *scale, float *shift,
+                              float *mean, float *invstd, double *sums, cl3d_stream_t stream);
 /* out [B,Co,M] = ReLU(scale * ystar + shift)  (== max_k ReLU(BN(y)): the affine map is monotone) */
 int cl3d_pwmlp_apply(const float *ystar_t, const float *scale, const float *shift, int B, int M, int Co,
                      float *out, cl3d_stream_t stream);
