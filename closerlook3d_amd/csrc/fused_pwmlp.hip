@@ -21,7 +21,7 @@
 //     sum_k dy * rel follow from sum_k y, dz and the per-channel sums S_a = sum y*rel_a, R_a = sum rel_a.
 // Passes:
 //   TRAIN     (gather, query-major) per channel: sum y, sum y^2, S_a, R_a (double partials);
-//             per (query, channel): y*, k*, the support index t* of that slot, sum_k y, the centre's H row;
+//             per (query, channel): y*, k*, sum_k y;
 //             per slot: slotrec {rel, centre index}
 //   APPLY     (element-wise) out = ReLU(scale*y* + shift), transposed to channel-major through LDS
 //   FWD       (gather; inference with running statistics) the same output in one pass
@@ -52,8 +52,6 @@ struct PwArgs {
   float *ystar_t, *sy_t;           // TRAIN: [B,M,Co]
   unsigned char *kstar_out;        // TRAIN / FWD
   float4 *slotrec;                 // TRAIN / FWD write {rel, centre index} (may be null); SUPPORT reads
-  float *hq_t;                     // TRAIN: [B,M,Co] H row of each query's centre (may be null); SUPPORT reads
-  int *tstar_t;                    // TRAIN: [B,M,Co] support index of the arg-max slot (may be null)
   const float *hit_cm;             // SUPPORT: [B,Co,N] sum of arg-max dz per support point (channel-major)
   const float *dz_cm;              // SUPPORT: [B,Co,M] gated upstream gradient (channel-major)
   const float *sy_in;              // SUPPORT: [B,M,Co]
@@ -215,7 +213,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
           hs[v] = sgn[v] * hc.v[v];
         }
         if (q_on) {
-        for_each_slot<V, KB>(myslots, K, rows, row, c0, [&](int k, const float4 &sr, const Vec<V> &gr) {
+        auto slot = [&](int k, const float4 &sr, const Vec<V> &gr) {
           rs0 += sr.y;
           rs1 += sr.z;
           rs2 += sr.w;
@@ -235,7 +233,8 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
               kb[v] = k;
             }
           }
-        });
+        };
+        for_each_slot<V, KB>(myslots, K, rows, row, c0, slot);
         Vec<V> ys, sy;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -253,11 +252,6 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
               (unsigned)kb[0] | ((unsigned)kb[1] << 8) | ((unsigned)kb[2] << 16) | ((unsigned)kb[3] << 24);
         } else {
           a.kstar_out[orow] = (unsigned char)kb[0];
-        }
-        if (a.hq_t != nullptr) store_row<V>(a.hq_t + orow, hc);
-        if (a.tstar_t != nullptr) {
-#pragma unroll
-          for (int v = 0; v < V; ++v) a.tstar_t[orow + v] = __float_as_int(myslots[kb[v]].x);
         }
         }  // q_on
         accr[0] += rs0;
@@ -377,18 +371,18 @@ __global__ __launch_bounds__(1024) void pwmlp_hit_kernel(HitArgs a) {
 // support-major backward pass through the CSR inverse of idx.  For support point i with slot list S_i:
 //   dG_i = sum_{s in S_i} dy_s,  dy_s = D y_s + Bc + A dz [slot s is the arg-max],  y_s = W_r rel_s + H[centre_s] + G_i
 //        = D (W_r . sum rel_s + sum H[centre_s] + |S_i| G_i) + |S_i| Bc + A hit_i
-// so a slot costs its slotrec (rel) and one row of hq_t (= H[centre] per query, left behind by the forward
-// pass); hit_i = the arg-max term from pwmlp_hit_kernel.
+// so a slot costs its slotrec (rel, centre index) and the H half of the centre's row of ght (a row gather, like the
+// forward pass's G half); hit_i = the arg-max term from pwmlp_hit_kernel.
 // dH_i = sum over the queries centred on i (= the slots (j,0) of S_i, reference :290) of
 //        D sum_k y + K Bc + A dz  (sum_k y was left behind by the forward pass).
 // Staged like the forward kernels: the slot lists of a tile's TR consecutive points are ONE contiguous range
 // of inv_slots, so the whole block loads it (and the slotrec of every slot) coalesced / fully parallel into
-// LDS records {rel, query id | centre flag}; the lane groups then walk their rows out of LDS and the only
-// global loads left in the loop are batches of independent hq-row gathers.
+// LDS records {rel, centre index (or query id | centre flag)}; the lane groups then walk their rows out of LDS and
+// the only global loads left in the loop are batches of independent H-row gathers.
 constexpr int kSupCap = 1024;  // slot records staged per round (16 KiB)
 constexpr unsigned kCentreFlag = 0x80000000u;
 
-template <int V, int SB, int WPE>  // SB = hq rows in flight per lane, WPE = waves per SIMD the register budget allows
+template <int V, int SB, int WPE>  // SB = H rows in flight per lane, WPE = waves per SIMD the register budget allows
 __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
   __shared__ float4 srec[kSupCap];
   const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
@@ -414,7 +408,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
       const int *off = a.inv_off + (size_t)b * (N + 1);
       const int *slots = a.inv_slots + (size_t)b * MK;
       const float4 *rec = a.slotrec + (size_t)b * MK;
-      const float *hqrow = a.hq_t + (size_t)b * M * Co + c0;
+      const float *hrows = a.ght + (size_t)b * N * row + Co + c0;  // H halves of the cloud's rows
       const float *syrow = a.sy_in + (size_t)b * M * Co + c0;
       const float *dzcol = a.dz_cm + ((size_t)b * Co + c0) * M;
       const int e_lo = off[i0], e_hi = off[i0 + TR < N ? i0 + TR : N];
@@ -441,8 +435,10 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
           for (int u = 0; u < 4; ++u) {
             const int t = t0 + u * 256 + (int)threadIdx.x;
             if (t < cn) {
+              // tag = the support index of the query's centre (whose H row this slot adds); a slot (j, 0) IS a
+              // centre reference -- its centre is this row's own point -- and carries the query id j instead, flagged
               const int j = sl[u] / K;
-              const unsigned tag = (unsigned)j | (sl[u] - j * K == 0 ? kCentreFlag : 0u);
+              const unsigned tag = sl[u] - j * K == 0 ? ((unsigned)j | kCentreFlag) : __float_as_uint(rr[u].w);
               srec[t] = make_float4(rr[u].x, rr[u].y, rr[u].z, __uint_as_float(tag));
             }
           }
@@ -469,7 +465,8 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
             }
           }
 #pragma unroll
-          for (int u = 0; u < SB; ++u) hc[u] = load_row<V>(hqrow + (size_t)(tags[u] & ~kCentreFlag) * Co);
+          for (int u = 0; u < SB; ++u)
+            hc[u] = load_row<V>(hrows + (size_t)((tags[u] & kCentreFlag) != 0u ? (unsigned)i : tags[u]) * row);
           if (jc >= 0) {  // about one slot per row: its loads ride along with the batch
             const Vec<V> sy = load_row<V>(syrow + (size_t)jc * Co);
             ncen += 1.f;
@@ -531,7 +528,7 @@ constexpr int kRowsBatch = 4;
 struct RowArgs {
   const float *ystar_t;           // [B,M,Co]
   const unsigned char *kstar_t;   // [B,M,Co]
-  const int *tstar_t;             // [B,M,Co]
+  const int *idx;                 // [B,M,K]: the arg-max slot's support index is idx[j, kstar]
   const float4 *slotrec;          // [B,M,K]
   const float *gout;              // [B,Co,M] (channel-major) or [B,M,Co]
   int gout_channel_major;
@@ -601,13 +598,14 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
             const size_t e = ((size_t)b * M + j0 + jq) * Co + c;
             y[u] = a.ystar_t[e];
             ks[u] = a.kstar_t[e];
-            ts[u] = a.tstar_t[e];
             gq[u] = a.gout_channel_major ? tile[cl * 65 + jq] : a.gout[e];
           }
 #pragma unroll
           for (int u = 0; u < kRowsBatch; ++u) {
             const int jq = jb + u * RS < nj ? jb + u * RS : nj - 1;
-            rel[u] = a.slotrec[((size_t)b * M + j0 + jq) * K + ks[u]];
+            const size_t slot = ((size_t)b * M + j0 + jq) * K + ks[u];
+            rel[u] = a.slotrec[slot];
+            ts[u] = a.idx[slot];  // a wave = the channels of one query: one 128-byte row of idx
           }
 #pragma unroll
           for (int u = 0; u < kRowsBatch; ++u) {
@@ -804,6 +802,9 @@ static int launch_query(PwArgs &a, int nacc, int n_partials, hipStream_t st, con
   const int gx = nacc > 0 ? n_partials : round_grid(tiles, 8192);
   // measured at the metric shape (TRAIN): 8 gathers in flight at 3 waves/SIMD 87 us, 6 at 3 89 us, 4 at 4 76 us:
   // occupancy buys more than depth per wave
+  // (software-pipelining the walk -- batch n+1's gathers issued before batch n is consumed, 2 or 3 waves per SIMD --
+  // measured 95-120 us: the loop is bound by its arithmetic (40 us of VALU at the metric shape), not by the gathers
+  // (12 us); the other half of this kernel is its streaming traffic)
   if (V == 4) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4>), dim3(gx, m.chunks), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1, 8, 4>), dim3(gx, m.chunks), dim3(256), lds, st, a);
   return check_launch(who);
@@ -915,14 +916,12 @@ extern "C" int cl3d_pwmlp_partials(int B, int M, int Co) {
 
 extern "C" int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
                                 const float *ght, const float *wr, const float *gamma, int B, int N, int M,
-                                int K, int Co, float radius, float *ystar_t, unsigned char *kstar_t,
-                                int32_t *tstar_t, float *sy_t, float *slotrec, float *hq_t, double *partial,
-                                int n_partials, cl3d_stream_t stream) {
+                                int K, int Co, float radius, float *ystar_t, unsigned char *kstar_t, float *sy_t,
+                                float *slotrec, double *partial, int n_partials, cl3d_stream_t stream) {
   using namespace cl3d;
   PwArgs a{};
   a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr; a.v0 = gamma;
   a.ystar_t = ystar_t; a.kstar_out = kstar_t; a.sy_t = sy_t; a.slotrec = reinterpret_cast<float4 *>(slotrec);
-  a.hq_t = hq_t; a.tstar_t = tstar_t;
   a.partial = partial;
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
   int rc = pw_check(a, "pwmlp_stats");
@@ -997,19 +996,19 @@ extern "C" int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, 
 }
 
 extern "C" int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, const float *ystar_t,
-                                   const unsigned char *kstar_t, const int32_t *tstar_t, const float *slotrec,
+                                   const unsigned char *kstar_t, const int32_t *idx, const float *slotrec,
                                    const float *scale, const float *shift, const float *mean, const float *invstd,
                                    int B, int M, int K, int Co, float *dz_cm, int32_t *ts_cm, double *partial,
                                    int n_partials, cl3d_stream_t stream) {
   using namespace cl3d;
   CL3D_REQUIRE(B >= 0 && M >= 1 && K >= 1 && K <= 255 && Co >= 1, "pwmlp_bwd_rows: bad sizes");
-  CL3D_REQUIRE(gout && ystar_t && kstar_t && tstar_t && slotrec && scale && shift && mean && invstd && dz_cm && ts_cm &&
+  CL3D_REQUIRE(gout && ystar_t && kstar_t && idx && slotrec && scale && shift && mean && invstd && dz_cm && ts_cm &&
                    partial,
                "pwmlp_bwd_rows: null pointer");
   CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_bwd_rows: wrong partial block count");
   if (B == 0) return CL3D_OK;
   RowArgs a{};
-  a.tstar_t = tstar_t; a.dz_cm = dz_cm; a.ts_cm = ts_cm;
+  a.idx = idx; a.dz_cm = dz_cm; a.ts_cm = ts_cm;
   a.gout = gout; a.gout_channel_major = gout_channel_major; a.ystar_t = ystar_t; a.kstar_t = kstar_t;
   a.slotrec = reinterpret_cast<const float4 *>(slotrec); a.scale = scale; a.shift = shift; a.mean = mean;
   a.invstd = invstd; a.partial = partial; a.B = B; a.M = M; a.K = K; a.Co = Co;
@@ -1040,19 +1039,18 @@ extern "C" int cl3d_pwmlp_bwd_hits(const float *dz_cm, const int32_t *ts_cm, int
 
 extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const float *cA, const float *cB,
                                       const float *cD, const float *hit_cm, const float *dz_cm, const float *sy_t,
-                                      const float *hq_t, const float *slotrec, const int32_t *inv_off,
+                                      const float *slotrec, const int32_t *inv_off,
                                       const int32_t *inv_slots, int B, int N, int M, int K, int Co, float *dght,
                                       cl3d_stream_t stream) {
   using namespace cl3d;
   PwArgs a{};
   a.ght = ght; a.wr = wr; a.v0 = cA; a.v1 = cB; a.v2 = cD; a.hit_cm = hit_cm; a.dz_cm = dz_cm; a.sy_in = sy_t;
-  a.hq_t = const_cast<float *>(hq_t);
   a.slotrec = reinterpret_cast<float4 *>(const_cast<float *>(slotrec));
   a.inv_off = inv_off; a.inv_slots = inv_slots; a.dght = dght;
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co;
   int rc = pw_check(a, "pwmlp_bwd_support");
   if (rc != CL3D_OK) return rc;
-  CL3D_REQUIRE(ght && wr && cA && cB && cD && hit_cm && dz_cm && sy_t && hq_t && slotrec && inv_off && inv_slots && dght,
+  CL3D_REQUIRE(ght && wr && cA && cB && cD && hit_cm && dz_cm && sy_t && slotrec && inv_off && inv_slots && dght,
                "pwmlp_bwd_support: null pointer");
   if (B == 0) return CL3D_OK;
   const int V = (Co % 4 == 0) ? 4 : 1;

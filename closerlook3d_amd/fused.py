@@ -422,13 +422,11 @@ class _PointwiseMLP(Function):
                 ystar, sy = rows[0], rows[1]
                 kstar = torch.empty((B, M, Co), dtype=torch.uint8, device=dev)
                 slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev) if need_grad else None
-                hq = torch.empty((B, M, Co), dtype=torch.float32, device=dev) if need_grad else None
-                tstar = torch.empty((B, M, Co), dtype=torch.int32, device=dev) if need_grad else None
                 partial = torch.empty((nparts, Co, 8), dtype=torch.float64, device=dev)
                 sums = torch.empty((Co, 6), dtype=torch.float64, device=dev)
                 _lib.check(lib.cl3d_pwmlp_stats(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(gamma),
-                                                B, N, M, K, Co, float(radius), _p(ystar), _p(kstar), _p(tstar), _p(sy),
-                                                _p(slotrec), _p(hq), _p(partial), nparts, st))
+                                                B, N, M, K, Co, float(radius), _p(ystar), _p(kstar), _p(sy),
+                                                _p(slotrec), _p(partial), nparts, st))
                 # batch statistics, scale/shift and the running-statistics update in one small launch
                 _lib.check(lib.cl3d_pwmlp_finalize_stats(_p(partial), nparts, Co, float(n), float(eps), float(momentum),
                                                          _p(gamma), _p(beta), _p(running_mean), _p(running_var),
@@ -436,7 +434,7 @@ class _PointwiseMLP(Function):
                                                          _p(invstd), _p(sums), st))
                 _lib.check(lib.cl3d_pwmlp_apply(_p(ystar), _p(scale), _p(shift), B, M, Co, _p(out), st))
                 if need_grad:
-                    ctx.save_for_backward(ght, wr, gamma, vec, ystar, sy, kstar, slotrec, sums, hq, tstar)
+                    ctx.save_for_backward(ght, wr, gamma, vec, ystar, sy, kstar, slotrec, sums)
                     ctx.idx = idx
                     ctx.meta = (B, N, M, K, Co, nparts)
             else:
@@ -453,7 +451,7 @@ class _PointwiseMLP(Function):
 
     @staticmethod
     def backward(ctx, gout):
-        ght, wr, gamma, vec, ystar, sy, kstar, slotrec, sums, hq, tstar = ctx.saved_tensors
+        ght, wr, gamma, vec, ystar, sy, kstar, slotrec, sums = ctx.saved_tensors
         B, N, M, K, Co, nparts = ctx.meta
         idx = ctx.idx
         dev = gout.device
@@ -465,7 +463,7 @@ class _PointwiseMLP(Function):
             dz_cm = torch.empty((B, Co, M), dtype=torch.float32, device=dev)
             ts_cm = torch.empty((B, Co, M), dtype=torch.int32, device=dev)
             partial = torch.empty((nparts, Co, 8), dtype=torch.float64, device=dev)
-            _lib.check(lib.cl3d_pwmlp_bwd_rows(_p(gout), 1, _p(ystar), _p(kstar), _p(tstar), _p(slotrec), _p(vec[0]),
+            _lib.check(lib.cl3d_pwmlp_bwd_rows(_p(gout), 1, _p(ystar), _p(kstar), _p(idx), _p(slotrec), _p(vec[0]),
                                                _p(vec[1]), _p(vec[2]), _p(vec[3]), B, M, K, Co, _p(dz_cm), _p(ts_cm),
                                                _p(partial), nparts, st))
             hit = torch.empty((B, Co, N), dtype=torch.float32, device=dev)
@@ -488,7 +486,7 @@ class _PointwiseMLP(Function):
             hits()
             off, slots = inverse_index(idx, N)
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
-            _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_cm), _p(sy), _p(hq),
+            _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_cm), _p(sy),
                                                   _p(slotrec), _p(off), _p(slots), B, N, M, K, Co, _p(dght), st))
         return (dght, dwr, dgamma, dbeta) + (None,) * 11
 
