@@ -150,13 +150,14 @@ ENTRY_KERNELS = {
 }
 
 
-def step_model_bytes(B, N, M, K, C):
+def step_model_bytes(B, N, M, K, C, kind="pointwisemlp"):
     """Per entry point: (algorithmic HBM bytes = every distinct input byte read once + every output byte written
     once, modelled L2 gather bytes = rows fetched through the cache hierarchy by the gather passes, bound)."""
     MK, Co = M * K, C
     f = 4
     xyzm = 12 * (M + N) + 4 * (M + N)
     rows_q = f * M * Co
+    pg = 1 if kind == "pseudo_grid" else 0  # PseudoGrid keeps 32 B of (kernel point, influence) pairs per slot
     t = {
         "cl3d_masked_ordered_ball_query": (B * (xyzm + 8 * MK), 0, "valu+latency"),
         "cl3d_build_inverse_index": (B * (8 * MK + 4 * N), 0, "latency"),
@@ -171,8 +172,8 @@ def step_model_bytes(B, N, M, K, C):
         # support-major pass: one H row per slot through the CSR + per-slot record
         "cl3d_pwmlp_bwd_support": (B * (f * N * 2 * Co * 2 + f * Co * N + 2 * rows_q + 16 * MK + 4 * MK + 4 * N), B * MK * f * Co, "l2-gather+latency"),
         # PosPool / AdaptiveWeight / PseudoGrid: one feature row per slot each way
-        "cl3d_fused_reduce_fwd": (B * (f * C * N + xyzm + 8 * MK + f * C * M + 16 * MK), B * MK * f * C, "l2-gather+latency"),
-        "cl3d_fused_reduce_bwd": (B * (3 * f * C * N + f * C * M + 16 * MK + 8 * MK), B * MK * f * C, "l2-gather+latency"),
+        "cl3d_fused_reduce_fwd": (B * (f * C * N + xyzm + 8 * MK + f * C * M + 16 * MK + pg * 32 * MK), B * MK * f * C, "l2-gather+latency"),
+        "cl3d_fused_reduce_bwd": (B * (3 * f * C * N + f * C * M + 16 * MK + 8 * MK + pg * 64 * MK), B * MK * f * C, "l2-gather+latency"),
         "cl3d_transpose": (2 * B * f * C * N, 0, "hbm"),
         "cl3d_bn_relu_stats": (B * f * C * N, 0, "hbm"),
         "cl3d_bn_relu_apply": (2 * B * f * C * N, 0, "hbm"),
@@ -193,7 +194,7 @@ def step_counters():
         return {}, None
 
 
-def step_table(compute, B, N, M, K, C, reps):
+def step_table(compute, B, N, M, K, C, reps, kind="pointwisemlp"):
     """The timed step's own kernels: GPU microseconds per C-ABI entry point from HIP events on the launch stream, in
     an eager run of the SAME compute() with the index streams folded onto the main stream (so durations are not
     stretched by overlap).  The graph-replayed step overlaps some of these, so the rows sum to more than ms_per_step."""
@@ -209,7 +210,7 @@ def step_table(compute, B, N, M, K, C, reps):
         summary = tr.summary()
     finally:
         pt_utils.ASYNC_INDEX = saved
-    model = step_model_bytes(B, N, M, K, C)
+    model = step_model_bytes(B, N, M, K, C, kind)
     counters, counters_src = step_counters()
     rows = []
     for name, (calls, us) in summary.items():
@@ -534,7 +535,7 @@ def main():
                                                   "frac": round(value / world * 17696.0 / HBM_PEAK, 4),
                                                   "definition": "points_per_s_per_gpu x 17,696 B / 8.0e12 B/s"}}
             if not args.no_step_table:
-                line["roofline"]["step"] = step_table(compute, B, N, N, K, C, reps=10)
+                line["roofline"]["step"] = step_table(compute, B, N, N, K, C, reps=10, kind=kind)
                 line["roofline"]["step"]["graph_step_us"] = round(ms * 1e3, 1)
             if kind == "pointwisemlp":
                 line["roofline"]["contraction"] = contraction_block(B, C, N, C, args.precision)

@@ -29,9 +29,9 @@ SIGNATURES = {
     "cl3d_masked_nearest_query": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "cl3d_group_xyz_features": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P],
     "cl3d_build_inverse_index": [_P, _I, _I, _I, _P, _P, _P, _Z, _P],
-    "cl3d_fused_reduce_fwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _I, _F, _I, _P, _I, _P, _P],
+    "cl3d_fused_reduce_fwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _I, _F, _I, _P, _I, _P, _P, _P],
     "cl3d_fused_param_partials": [_I, _I, _I, _I],
-    "cl3d_fused_reduce_bwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _F, _I, _P, _I, _P, _I, _P],
+    "cl3d_fused_reduce_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _F, _I, _P, _I, _P, _I, _P],
     "cl3d_maxpool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cl3d_maxpool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     "cl3d_dataset_grid_subsampling": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],

@@ -9,6 +9,8 @@ feature rows with hand-written HIP kernels, forward and backward, without that t
 cover (non-shipped variants such as PosPool with max reduction or a two-layer AdaptiveWeight MLP) run the
 'grouped' dataflow instead -- still on the engine's native ops -- and `impl='fused'` raises for them.
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -68,6 +70,9 @@ def _stream(t):
     return _lib.stream_ptr(t.device)
 
 
+FORK_GRADS = os.environ.get('CL3D_FORK_GRADS', '1') != '0'  # A/B knob: 0 = the two gradients one after the other
+
+
 def _fork_join(device, side_fn, main_fn):
     """Two independent pieces of a backward pass (the data gradient and the weight gradient of one contraction; the
     arg-max scatter and the per-channel BatchNorm algebra) side by side: `side_fn` on a side HIP stream, `main_fn` on the
@@ -76,7 +81,7 @@ def _fork_join(device, side_fn, main_fn):
     fork becomes two parallel branches of the graph); otherwise one after the other on the caller's stream.  Outputs
     are allocated by the caller BEFORE the fork (on the caller's stream); whatever side_fn allocates is scratch that
     lives and dies on the side stream."""
-    if not (device.type == 'cuda' and pt_utils.async_index()):
+    if not (FORK_GRADS and device.type == 'cuda' and pt_utils.async_index()):
         side_fn()
         main_fn()
         return
@@ -174,12 +179,15 @@ class _FusedReduce(Function):
         wait_ready(idx)  # ball query ran on the index stream
         out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)  # channel-major, written by the kernel
         slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=features.device) if need_grad else None
+        pairs = None
+        if need_grad and op == OP_PSEUDOGRID and C % 4 == 0 and not constant:  # the slots' non-zero influences, kept for the backward
+            pairs = torch.empty((B, M, K, 8), dtype=torch.float32, device=features.device)
         with _lib.on_device(features.device):
             _lib.check(_lib.lib().cl3d_fused_reduce_fwd(
                 op, _p(query_xyz), _p(support_xyz), _p(query_mask), _p(idx), _p(idx_mask), _p(ft), B, N, M, K, C,
                 float(radius), int(normalize), reduction, _p(p0), _p(p1), pint, float(pfloat), int(constant),
-                _p(out), 1, _p(slotrec), _stream(features)))
-        ctx.save_for_backward(ft, slotrec, p0, p1)
+                _p(out), 1, _p(slotrec), _p(pairs), _stream(features)))
+        ctx.save_for_backward(ft, slotrec, p0, p1, pairs)
         ctx.idx = idx
         ctx.meta = (op, B, N, M, K, C, pint, pfloat, constant)
         _join_inverse(idx)
@@ -187,7 +195,7 @@ class _FusedReduce(Function):
 
     @staticmethod
     def backward(ctx, gout):
-        ft, slotrec, p0, p1 = ctx.saved_tensors
+        ft, slotrec, p0, p1, pairs = ctx.saved_tensors
         op, B, N, M, K, C, pint, pfloat, constant = ctx.meta
         gout_t = _transposed(gout)
         off, slots = inverse_index(ctx.idx, N)
@@ -197,15 +205,17 @@ class _FusedReduce(Function):
         npar = {OP_ADAPTIVE: 4, OP_PSEUDOGRID: 16}.get(op, 0)
         dparam = torch.empty((nparts, C, npar), dtype=torch.float32, device=gout.device) if nparts else None
         with _lib.on_device(gout.device):
-            _lib.check(lib.cl3d_fused_reduce_bwd(op, _p(gout_t), _p(ft), _p(slotrec), _p(ctx.idx), _p(off), _p(slots), B, N, M, K,
+            _lib.check(lib.cl3d_fused_reduce_bwd(op, _p(gout_t), _p(ft), _p(slotrec), _p(pairs), _p(ctx.idx), _p(off), _p(slots), B, N, M, K,
                                                  C, _p(p0), _p(p1), pint, float(pfloat), int(constant), _p(dfeat), 1,
                                                  _p(dparam), nparts, _stream(gout)))
         g0 = g1 = None
+        # the blocks' partial sums are added in double: they are a few hundred terms that cancel heavily (a channel's
+        # gradient is often two orders of magnitude below its partial sums)
         if op == OP_ADAPTIVE:
-            d = dparam.sum(0).view(C // pint, pint, 4).sum(1)  # fixed-order reductions
+            d = dparam.double().sum(0).view(C // pint, pint, 4).sum(1).float()  # fixed-order reductions
             g0, g1 = d[:, :3].contiguous(), d[:, 3].contiguous()
         elif op == OP_PSEUDOGRID:
-            g1 = dparam.sum(0)[:, :pint].t().contiguous()
+            g1 = dparam.double().sum(0)[:, :pint].t().float().contiguous()
         return (dfeat, g0, g1) + (None,) * 13
 
 

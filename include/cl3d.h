@@ -195,20 +195,21 @@ int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK, int32_t *
  * local_aggregation_operators.py:92-103).  Replaces PosPool.forward :65-103, AdaptiveWeight.forward
  * :188-214, PseudoGrid.forward :383-419 up to the output transform.
  * out: [B,M,C], or [B,C,M] (the reference's layout) when out_channel_major != 0.
- * slotrec [B,M,K,4] (nullable) receives what the backward pass needs per slot. */
+ * slotrec [B,M,K,4] (nullable) receives what the backward pass needs per slot; pairs [B,M,K,8] (nullable; PseudoGrid
+ * with C % 4 == 0 only) the slot's non-zero kernel-point influences {h0..h3, p0..p3}, evaluated once here and read by
+ * the backward passes. */
 int cl3d_fused_reduce_fwd(int op, const float *query_xyz, const float *support_xyz,
                           const int32_t *query_mask, const int32_t *idx, const int32_t *idx_mask,
                           const float *ft, int B, int N, int M, int K, int C, float radius,
                           int normalize_xyz, int reduction, const float *p0, const float *p1, int pint,
                           float pfloat, int constant_influence, float *out, int out_channel_major,
-                          float *slotrec, cl3d_stream_t stream);
+                          float *slotrec, float *pairs, cl3d_stream_t stream);
 /* number of partial blocks of the parameter-gradient buffer dparam [n, C, NP] (NP = 4 adaptive:
  * dW[:,0..2], dbias; 16 pseudo grid: d kernel_weights[p]); 0 for operators without parameters. */
 int cl3d_fused_param_partials(int op, int B, int N, int C);
-int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *ft, const float *slotrec,
+int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *ft, const float *slotrec, const float *pairs,
                           const int32_t *idx, const int32_t *inv_off, const int32_t *inv_slots, int B, int N,
-                          int M, int K,
-                          int C, const float *p0, const float *p1, int pint, float pfloat,
+                          int M, int K, int C, const float *p0, const float *p1, int pint, float pfloat,
                           int constant_influence, float *dft, int dft_channel_major, float *dparam,
                           int n_partials, cl3d_stream_t stream);
 
