@@ -321,9 +321,10 @@ extern "C" int cl3d_group_points_grad(const float *grad_out, const int32_t *idx,
     return CL3D_OK;
   }
   CL3D_REQUIRE(grad_out && idx, "group_points_grad: null pointer");
-  // Each block owns one (cloud, channel) row and one tile of T support indices, accumulated in W
-  // private LDS rows (one per wave, combined in a fixed order).  N <= 16384: a single tile; larger
-  // clouds sweep the grad_out row once per tile (still no global atomics, still order-fixed).
+  // Each block owns one (cloud, channel) row (two when they fit) and one tile of T support indices, accumulated in ONE
+  // shared LDS row of doubles with ds_add_f64 (see group_bwd_lds_kernel: the sum is exact in double for the handful of
+  // terms a row element gets, so the float result does not depend on arrival order except on a rounding boundary).
+  // N <= 8192: a single tile; larger clouds sweep the grad_out row once per tile.  No global atomics.
   CL3D_REQUIRE((long long)B * C <= 0x7fffffffLL, "group_points_grad: B*C too large");
   const int kTile = 8192;  // doubles per block: 64 KiB, the no-opt-in dynamic LDS limit
   const int T = N <= kTile ? N : kTile;
