@@ -85,9 +85,15 @@ def test_resnet_and_seg_head_match_reference(kind):
     assert_close(logits.detach().cpu().numpy(), fx["out"], 2e-4, "logits")
     (logits * torch.from_numpy(fx["probe"]).cuda()).sum().backward()
     got, want = feats.grad.cpu().numpy().astype(np.float64), fx["grad_features"].astype(np.float64)
-    # arg-max routing makes the input gradient discontinuous: near-ties can pick another neighbour, so
-    # the deep-network gradient is compared in norm, not element by element
+    # arg-max routing makes the input gradient discontinuous: a near-tie between two neighbours (max-pooling, the
+    # PointWiseMLP max) can resolve the other way after ten layers of float noise and moves a whole gradient entry.
+    # So: (i) almost every element agrees at the single-operator tolerance -- the fraction that does not (the flipped
+    # routes) is stated and bounded; (ii) the flips stay small in norm.
+    flipped = np.abs(got - want) > 2e-4 + 2e-4 * np.abs(want)
+    frac = float(flipped.mean())
     rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    print(f"[{kind}] input-gradient entries outside 2e-4: {int(flipped.sum())} of {flipped.size} ({frac:.2e}); relative L2 {rel:.2e}")
+    assert frac < 2e-2, f"{int(flipped.sum())} of {flipped.size} input-gradient entries differ (arg-max flips): {frac:.3e}"
     assert rel < 2e-2, f"relative L2 error of d logits / d input features: {rel:.3e}"
 
 
