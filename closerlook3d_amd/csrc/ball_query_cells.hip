@@ -622,6 +622,7 @@ int ball_query_cells(const float *query_xyz, const float *support_xyz, const int
   // once, waves beyond the cap walk the table with the grid's stride)
   int gx = ceil_div(ceil_div(M, kBqQW) + ceil_div(M, 8), 4);
   gx = gx > 1024 ? 1024 : gx;
+  // (measured per-cloud grids at the metric shape, B = 16: 128 -> 71.9 us, 256 -> 64.8, 384 -> 63.2, 512 -> 63.0, 640 -> 60.8)
   hipLaunchKernelGGL(bq_query_kernel, dim3(gx, B), dim3(256), lds, st, query_xyz, query_mask, M, N, radius * radius, K, w, idx, idx_mask);
   int rc = check_launch("cl3d_masked_ordered_ball_query(cells)");
   if (rc != CL3D_OK) return rc;
