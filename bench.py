@@ -165,12 +165,12 @@ def step_model_bytes(B, N, M, K, C, kind="pointwisemlp"):
         "cl3d_pwmlp_point_gemm_bwd_data": (B * f * (C * N + N * 2 * Co), 0, "mfma+hbm"),
         "cl3d_pwmlp_point_gemm_bwd_weight": (B * f * (C * N + N * 2 * Co), 0, "mfma+hbm"),
         # TRAIN gather pass: one G row (Co floats) per slot + the centre's H row per query
-        "cl3d_pwmlp_stats": (B * (f * N * 2 * Co + 4 * MK + xyzm + 2 * rows_q + M * Co + 16 * MK), B * MK * f * Co, "l2-gather+latency"),
+        "cl3d_pwmlp_stats": (B * (f * N * 2 * Co + 4 * MK + xyzm + 2 * rows_q + M * Co), B * MK * f * Co, "l2-gather+latency"),
         "cl3d_pwmlp_apply": (B * 2 * rows_q, 0, "hbm"),
-        "cl3d_pwmlp_bwd_rows": (B * (4 * rows_q + M * Co + 16 * MK + 4 * MK), 0, "hbm"),
+        "cl3d_pwmlp_bwd_rows": (B * (4 * rows_q + M * Co + 4 * MK + xyzm), 0, "hbm"),
         "cl3d_pwmlp_bwd_hits": (B * (2 * rows_q + f * Co * N), 0, "lds-atomics"),
         # support-major pass: one H row per slot through the CSR + per-slot record
-        "cl3d_pwmlp_bwd_support": (B * (f * N * 2 * Co * 2 + f * Co * N + 2 * rows_q + 16 * MK + 4 * MK + 4 * N), B * MK * f * Co, "l2-gather+latency"),
+        "cl3d_pwmlp_bwd_support": (B * (f * N * 2 * Co * 2 + f * Co * N + 2 * rows_q + 4 * MK + 4 * MK + 4 * N + xyzm), B * MK * f * Co, "l2-gather+latency"),
         # PosPool / AdaptiveWeight / PseudoGrid: one feature row per slot each way
         "cl3d_fused_reduce_fwd": (B * (f * C * N + xyzm + 8 * MK + f * C * M + 16 * MK + pg * 32 * MK), B * MK * f * C, "l2-gather+latency"),
         "cl3d_fused_reduce_bwd": (B * (3 * f * C * N + f * C * M + 16 * MK + 8 * MK + pg * 64 * MK), B * MK * f * C, "l2-gather+latency"),

@@ -53,14 +53,14 @@ SIGNATURES = {
     "cl3d_conv1x1_bwd_weight": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_pwmlp_split_weight": [_P, _I, _I, _P, _P, _P],
     "cl3d_pwmlp_merge_weight_grad": [_P, _P, _I, _I, _I, _P, _P],
-    "cl3d_pwmlp_stats": [_P] * 6 + [_I] * 5 + [_F, _P, _P, _P, _P, _P, _I, _P],
+    "cl3d_pwmlp_stats": [_P] * 6 + [_I] * 5 + [_F, _P, _P, _P, _P, _I, _P],
     "cl3d_pwmlp_finalize_stats": [_P, _I, _I, ctypes.c_double, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "cl3d_pwmlp_apply": [_P, _P, _P, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P],
-    "cl3d_pwmlp_bwd_rows": [_P, _I] + [_P] * 8 + [_I] * 4 + [_P, _P, _P, _I, _P],
+    "cl3d_pwmlp_bwd_rows": [_P, _I] + [_P] * 5 + [_F] + [_P] * 4 + [_I] * 5 + [_P, _P, _P, _I, _P],
     "cl3d_pwmlp_bwd_hits": [_P, _P, _I, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_bn_backward_coeffs": [_P, _I, _I, ctypes.c_double] + [_P] * 11,
-    "cl3d_pwmlp_bwd_support": [_P] * 11 + [_I] * 5 + [_P, _P],
+    "cl3d_pwmlp_bwd_support": [_P] * 11 + [_F, _P, _P] + [_I] * 5 + [_P, _P],
 }
 
 

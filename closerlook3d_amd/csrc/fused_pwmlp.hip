@@ -22,7 +22,6 @@
 // Passes:
 //   TRAIN     (gather, query-major) per channel: sum y, sum y^2, S_a, R_a (double partials);
 //             per (query, channel): y*, k*, sum_k y;
-//             per slot: slotrec {rel, centre index}
 //   APPLY     (element-wise) out = ReLU(scale*y* + shift), transposed to channel-major through LDS
 //   FWD       (gather; inference with running statistics) the same output in one pass
 //   BWD_ROWS  (element-wise) dz at the arg-max (ReLU gate), d beta = sum dz, d gamma = sum dz*xhat,
@@ -51,7 +50,7 @@ struct PwArgs {
   int out_channel_major;
   float *ystar_t, *sy_t;           // TRAIN: [B,M,Co]
   unsigned char *kstar_out;        // TRAIN / FWD
-  float4 *slotrec;                 // TRAIN / FWD write {rel, centre index} (may be null); SUPPORT reads
+  float4 *slotrec;                 // FWD writes {rel, centre index} per slot when asked to (cl3d_pwmlp_fwd)
   const float *hit_cm;             // SUPPORT: [B,Co,N] sum of arg-max dz per support point (channel-major)
   const float *dz_cm;              // SUPPORT: [B,Co,M] gated upstream gradient (channel-major)
   const float *sy_in;              // SUPPORT: [B,M,Co]
@@ -371,12 +370,12 @@ __global__ __launch_bounds__(1024) void pwmlp_hit_kernel(HitArgs a) {
 // support-major backward pass through the CSR inverse of idx.  For support point i with slot list S_i:
 //   dG_i = sum_{s in S_i} dy_s,  dy_s = D y_s + Bc + A dz [slot s is the arg-max],  y_s = W_r rel_s + H[centre_s] + G_i
 //        = D (W_r . sum rel_s + sum H[centre_s] + |S_i| G_i) + |S_i| Bc + A hit_i
-// so a slot costs its slotrec (rel, centre index) and the H half of the centre's row of ght (a row gather, like the
-// forward pass's G half); hit_i = the arg-max term from pwmlp_hit_kernel.
+// so a slot costs its relative position (rebuilt from the coordinates), its query's centre index and the H half of
+// the centre's row of ght (a row gather, like the forward pass's G half); hit_i = the arg-max term from pwmlp_hit_kernel.
 // dH_i = sum over the queries centred on i (= the slots (j,0) of S_i, reference :290) of
 //        D sum_k y + K Bc + A dz  (sum_k y was left behind by the forward pass).
 // Staged like the forward kernels: the slot lists of a tile's TR consecutive points are ONE contiguous range
-// of inv_slots, so the whole block loads it (and the slotrec of every slot) coalesced / fully parallel into
+// of inv_slots, so the whole block loads it (and builds the record of every slot) coalesced / fully parallel into
 // LDS records {rel, centre index (or query id | centre flag)}; the lane groups then walk their rows out of LDS and
 // the only global loads left in the loop are batches of independent H-row gathers.
 constexpr int kSupCap = 1024;  // slot records staged per round (16 KiB)
@@ -385,6 +384,8 @@ constexpr unsigned kCentreFlag = 0x80000000u;
 template <int V, int SB, int WPE>  // SB = H rows in flight per lane, WPE = waves per SIMD the register budget allows
 __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
   __shared__ float4 srec[kSupCap];
+  __shared__ int s_off[257];     // row starts of the tile (TR = 4 * QW <= 256 rows) and its end
+  __shared__ float4 s_pos[256];  // coordinates of the tile's rows
   const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
   const int row = 2 * Co;
   const int MK = M * K;
@@ -394,6 +395,8 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
   const int g = lane / L, cl = lane - g * L;
   const int tiles_per_cloud = (N + TR - 1) / TR;
   const int ntiles = a.B * tiles_per_cloud;
+  int top = 1;  // first step of the search for a slot's row among the tile's TR rows
+  while (top * 2 < TR) top *= 2;
   for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {  // channel chunks over gridDim.y, see pwmlp_query_kernel
     const int c0 = (ch * L + cl) * V;
     const bool chan_on = g < QW && c0 < Co;
@@ -407,7 +410,9 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
       const bool row_on = chan_on && i < N;
       const int *off = a.inv_off + (size_t)b * (N + 1);
       const int *slots = a.inv_slots + (size_t)b * MK;
-      const float4 *rec = a.slotrec + (size_t)b * MK;
+      const int *cidx = a.idx + (size_t)b * MK;                    // cidx[j * K] = centre of query j
+      const float *qxyz = a.query_xyz + (size_t)b * M * 3;
+      const float *sxyz = a.support_xyz + (size_t)b * N * 3;
       const float *hrows = a.ght + (size_t)b * N * row + Co + c0;  // H halves of the cloud's rows
       const float *syrow = a.sy_in + (size_t)b * M * Co + c0;
       const float *dzcol = a.dz_cm + ((size_t)b * Co + c0) * M;
@@ -418,28 +423,52 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
       float r0 = 0.f, r1 = 0.f, r2 = 0.f, ncen = 0.f;
 #pragma unroll
       for (int v = 0; v < V; ++v) shc[v] = csy[v] = cdz[v] = 0.f;
+      __syncthreads();  // the previous tile's readers are done with the row table
+      for (int t = threadIdx.x; t <= TR; t += 256) {
+        const int ii = i0 + t < N ? i0 + t : N;
+        s_off[t] = off[ii];
+        if (t < TR) {
+          const int ix = ii < N ? ii : N - 1;
+          s_pos[t] = make_float4(sxyz[ix * 3 + 0], sxyz[ix * 3 + 1], sxyz[ix * 3 + 2], 0.f);
+        }
+      }
       for (int cbeg = e_lo; cbeg < e_hi; cbeg += kSupCap) {
         const int cn = e_hi - cbeg < kSupCap ? e_hi - cbeg : kSupCap;
-        __syncthreads();  // the previous round's records have been consumed
+        __syncthreads();  // the previous round's records have been consumed (and the row table is written)
+        // A slot's record {rel, tag} is rebuilt from what is cache-resident anyway -- the query's coordinates, its
+        // centre idx[j, 0], and the coordinates of the row the slot belongs to (found in the tile's 17 row starts) --
+        // with the forward pass's own expression for rel.  (Keeping the forward's records instead cost 33 MB written
+        // there and a 16-byte random gather per slot here.)
         for (int t0 = 0; t0 < cn; t0 += 256 * 4) {
-          int sl[4];
-          float4 rr[4];
+          int sl[4], cen[4];
+          float qv[4][3];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int t = t0 + u * 256 + (int)threadIdx.x;
             sl[u] = slots[cbeg + (t < cn ? t : cn - 1)];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) rr[u] = rec[sl[u]];
+          for (int u = 0; u < 4; ++u) {
+            const int j = sl[u] / K;
+            cen[u] = cidx[(size_t)j * K];
+            qv[u][0] = qxyz[j * 3 + 0];
+            qv[u][1] = qxyz[j * 3 + 1];
+            qv[u][2] = qxyz[j * 3 + 2];
+          }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int t = t0 + u * 256 + (int)threadIdx.x;
             if (t < cn) {
+              int r = 0;  // row of the tile that owns position cbeg + t: last r with s_off[r] <= position
+              for (int step = top; step >= 1; step >>= 1)
+                if (r + step < TR && s_off[r + step] <= cbeg + t) r += step;
+              const float4 sp = s_pos[r];
               // tag = the support index of the query's centre (whose H row this slot adds); a slot (j, 0) IS a
               // centre reference -- its centre is this row's own point -- and carries the query id j instead, flagged
               const int j = sl[u] / K;
-              const unsigned tag = sl[u] - j * K == 0 ? ((unsigned)j | kCentreFlag) : __float_as_uint(rr[u].w);
-              srec[t] = make_float4(rr[u].x, rr[u].y, rr[u].z, __uint_as_float(tag));
+              const unsigned tag = sl[u] - j * K == 0 ? ((unsigned)j | kCentreFlag) : (unsigned)cen[u];
+              srec[t] = make_float4((sp.x - qv[u][0]) * a.inv_radius, (sp.y - qv[u][1]) * a.inv_radius,
+                                    (sp.z - qv[u][2]) * a.inv_radius, __uint_as_float(tag));
             }
           }
         }
@@ -529,7 +558,9 @@ struct RowArgs {
   const float *ystar_t;           // [B,M,Co]
   const unsigned char *kstar_t;   // [B,M,Co]
   const int *idx;                 // [B,M,K]: the arg-max slot's support index is idx[j, kstar]
-  const float4 *slotrec;          // [B,M,K]
+  const float *query_xyz, *support_xyz;  // BWD: rel of the arg-max slot is rebuilt from them
+  float inv_radius;
+  int N;
   const float *gout;              // [B,Co,M] (channel-major) or [B,M,Co]
   int gout_channel_major;
   const float *scale, *shift, *mean, *invstd;
@@ -603,9 +634,15 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
 #pragma unroll
           for (int u = 0; u < kRowsBatch; ++u) {
             const int jq = jb + u * RS < nj ? jb + u * RS : nj - 1;
-            const size_t slot = ((size_t)b * M + j0 + jq) * K + ks[u];
-            rel[u] = a.slotrec[slot];
-            ts[u] = a.idx[slot];  // a wave = the channels of one query: one 128-byte row of idx
+            ts[u] = a.idx[((size_t)b * M + j0 + jq) * K + ks[u]];  // a wave = the channels of one query: one 128-byte row of idx
+          }
+#pragma unroll
+          for (int u = 0; u < kRowsBatch; ++u) {  // rel of that slot, with the forward pass's expression
+            const int jq = jb + u * RS < nj ? jb + u * RS : nj - 1;
+            const float *sp = a.support_xyz + ((size_t)b * a.N + ts[u]) * 3;
+            const float *qp = a.query_xyz + ((size_t)b * M + j0 + jq) * 3;
+            rel[u] = make_float4((sp[0] - qp[0]) * a.inv_radius, (sp[1] - qp[1]) * a.inv_radius,
+                                 (sp[2] - qp[2]) * a.inv_radius, 0.f);
           }
 #pragma unroll
           for (int u = 0; u < kRowsBatch; ++u) {
@@ -917,11 +954,11 @@ extern "C" int cl3d_pwmlp_partials(int B, int M, int Co) {
 extern "C" int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
                                 const float *ght, const float *wr, const float *gamma, int B, int N, int M,
                                 int K, int Co, float radius, float *ystar_t, unsigned char *kstar_t, float *sy_t,
-                                float *slotrec, double *partial, int n_partials, cl3d_stream_t stream) {
+                                double *partial, int n_partials, cl3d_stream_t stream) {
   using namespace cl3d;
   PwArgs a{};
   a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr; a.v0 = gamma;
-  a.ystar_t = ystar_t; a.kstar_out = kstar_t; a.sy_t = sy_t; a.slotrec = reinterpret_cast<float4 *>(slotrec);
+  a.ystar_t = ystar_t; a.kstar_out = kstar_t; a.sy_t = sy_t;
   a.partial = partial;
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
   int rc = pw_check(a, "pwmlp_stats");
@@ -996,13 +1033,13 @@ extern "C" int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, 
 }
 
 extern "C" int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, const float *ystar_t,
-                                   const unsigned char *kstar_t, const int32_t *idx, const float *slotrec,
-                                   const float *scale, const float *shift, const float *mean, const float *invstd,
-                                   int B, int M, int K, int Co, float *dz_cm, int32_t *ts_cm, double *partial,
-                                   int n_partials, cl3d_stream_t stream) {
+                                   const unsigned char *kstar_t, const int32_t *idx, const float *query_xyz,
+                                   const float *support_xyz, float radius, const float *scale, const float *shift,
+                                   const float *mean, const float *invstd, int B, int N, int M, int K, int Co,
+                                   float *dz_cm, int32_t *ts_cm, double *partial, int n_partials, cl3d_stream_t stream) {
   using namespace cl3d;
-  CL3D_REQUIRE(B >= 0 && M >= 1 && K >= 1 && K <= 255 && Co >= 1, "pwmlp_bwd_rows: bad sizes");
-  CL3D_REQUIRE(gout && ystar_t && kstar_t && idx && slotrec && scale && shift && mean && invstd && dz_cm && ts_cm &&
+  CL3D_REQUIRE(B >= 0 && N >= 1 && M >= 1 && K >= 1 && K <= 255 && Co >= 1 && radius > 0.f, "pwmlp_bwd_rows: bad sizes");
+  CL3D_REQUIRE(gout && ystar_t && kstar_t && idx && query_xyz && support_xyz && scale && shift && mean && invstd && dz_cm && ts_cm &&
                    partial,
                "pwmlp_bwd_rows: null pointer");
   CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_bwd_rows: wrong partial block count");
@@ -1010,7 +1047,8 @@ extern "C" int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, co
   RowArgs a{};
   a.idx = idx; a.dz_cm = dz_cm; a.ts_cm = ts_cm;
   a.gout = gout; a.gout_channel_major = gout_channel_major; a.ystar_t = ystar_t; a.kstar_t = kstar_t;
-  a.slotrec = reinterpret_cast<const float4 *>(slotrec); a.scale = scale; a.shift = shift; a.mean = mean;
+  a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.inv_radius = 1.0f / radius; a.N = N;
+  a.scale = scale; a.shift = shift; a.mean = mean;
   a.invstd = invstd; a.partial = partial; a.B = B; a.M = M; a.K = K; a.Co = Co;
   hipLaunchKernelGGL((pwmlp_rows_kernel<ROWS_BWD>), dim3(n_partials, rows_chunks(Co)), dim3(256), 0, (hipStream_t)stream,
                      a);
@@ -1039,18 +1077,18 @@ extern "C" int cl3d_pwmlp_bwd_hits(const float *dz_cm, const int32_t *ts_cm, int
 
 extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const float *cA, const float *cB,
                                       const float *cD, const float *hit_cm, const float *dz_cm, const float *sy_t,
-                                      const float *slotrec, const int32_t *inv_off,
-                                      const int32_t *inv_slots, int B, int N, int M, int K, int Co, float *dght,
-                                      cl3d_stream_t stream) {
+                                      const float *query_xyz, const float *support_xyz, const int32_t *idx,
+                                      float radius, const int32_t *inv_off, const int32_t *inv_slots, int B, int N,
+                                      int M, int K, int Co, float *dght, cl3d_stream_t stream) {
   using namespace cl3d;
   PwArgs a{};
   a.ght = ght; a.wr = wr; a.v0 = cA; a.v1 = cB; a.v2 = cD; a.hit_cm = hit_cm; a.dz_cm = dz_cm; a.sy_in = sy_t;
-  a.slotrec = reinterpret_cast<float4 *>(const_cast<float *>(slotrec));
+  a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.inv_radius = 1.0f / radius;
   a.inv_off = inv_off; a.inv_slots = inv_slots; a.dght = dght;
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co;
   int rc = pw_check(a, "pwmlp_bwd_support");
   if (rc != CL3D_OK) return rc;
-  CL3D_REQUIRE(ght && wr && cA && cB && cD && hit_cm && dz_cm && sy_t && slotrec && inv_off && inv_slots && dght,
+  CL3D_REQUIRE(ght && wr && cA && cB && cD && hit_cm && dz_cm && sy_t && query_xyz && support_xyz && idx && inv_off && inv_slots && dght && radius > 0.f,
                "pwmlp_bwd_support: null pointer");
   if (B == 0) return CL3D_OK;
   const int V = (Co % 4 == 0) ? 4 : 1;

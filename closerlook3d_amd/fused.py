@@ -431,12 +431,11 @@ class _PointwiseMLP(Function):
                 rows = torch.empty((2, B, M, Co), dtype=torch.float32, device=dev)
                 ystar, sy = rows[0], rows[1]
                 kstar = torch.empty((B, M, Co), dtype=torch.uint8, device=dev)
-                slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev) if need_grad else None
                 partial = torch.empty((nparts, Co, 8), dtype=torch.float64, device=dev)
                 sums = torch.empty((Co, 6), dtype=torch.float64, device=dev)
                 _lib.check(lib.cl3d_pwmlp_stats(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(gamma),
                                                 B, N, M, K, Co, float(radius), _p(ystar), _p(kstar), _p(sy),
-                                                _p(slotrec), _p(partial), nparts, st))
+                                                _p(partial), nparts, st))
                 # batch statistics, scale/shift and the running-statistics update in one small launch
                 _lib.check(lib.cl3d_pwmlp_finalize_stats(_p(partial), nparts, Co, float(n), float(eps), float(momentum),
                                                          _p(gamma), _p(beta), _p(running_mean), _p(running_var),
@@ -444,7 +443,8 @@ class _PointwiseMLP(Function):
                                                          _p(invstd), _p(sums), st))
                 _lib.check(lib.cl3d_pwmlp_apply(_p(ystar), _p(scale), _p(shift), B, M, Co, _p(out), st))
                 if need_grad:
-                    ctx.save_for_backward(ght, wr, gamma, vec, ystar, sy, kstar, slotrec, sums)
+                    ctx.save_for_backward(ght, wr, gamma, vec, ystar, sy, kstar, sums, query_xyz, support_xyz)
+                    ctx.radius = float(radius)
                     ctx.idx = idx
                     ctx.meta = (B, N, M, K, Co, nparts)
             else:
@@ -461,7 +461,7 @@ class _PointwiseMLP(Function):
 
     @staticmethod
     def backward(ctx, gout):
-        ght, wr, gamma, vec, ystar, sy, kstar, slotrec, sums = ctx.saved_tensors
+        ght, wr, gamma, vec, ystar, sy, kstar, sums, query_xyz, support_xyz = ctx.saved_tensors
         B, N, M, K, Co, nparts = ctx.meta
         idx = ctx.idx
         dev = gout.device
@@ -473,9 +473,9 @@ class _PointwiseMLP(Function):
             dz_cm = torch.empty((B, Co, M), dtype=torch.float32, device=dev)
             ts_cm = torch.empty((B, Co, M), dtype=torch.int32, device=dev)
             partial = torch.empty((nparts, Co, 8), dtype=torch.float64, device=dev)
-            _lib.check(lib.cl3d_pwmlp_bwd_rows(_p(gout), 1, _p(ystar), _p(kstar), _p(idx), _p(slotrec), _p(vec[0]),
-                                               _p(vec[1]), _p(vec[2]), _p(vec[3]), B, M, K, Co, _p(dz_cm), _p(ts_cm),
-                                               _p(partial), nparts, st))
+            _lib.check(lib.cl3d_pwmlp_bwd_rows(_p(gout), 1, _p(ystar), _p(kstar), _p(idx), _p(query_xyz), _p(support_xyz),
+                                               ctx.radius, _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), B, N, M, K, Co,
+                                               _p(dz_cm), _p(ts_cm), _p(partial), nparts, st))
             hit = torch.empty((B, Co, N), dtype=torch.float32, device=dev)
             # d gamma, d beta, d W_r and the coefficients of  dy = A dz + Bc + D y  (BatchNorm backward is affine in y)
             coef = torch.empty((5, Co), dtype=torch.float32, device=dev)
@@ -497,7 +497,8 @@ class _PointwiseMLP(Function):
             off, slots = inverse_index(idx, N)
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
             _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_cm), _p(sy),
-                                                  _p(slotrec), _p(off), _p(slots), B, N, M, K, Co, _p(dght), st))
+                                                  _p(query_xyz), _p(support_xyz), _p(idx), ctx.radius, _p(off), _p(slots),
+                                                  B, N, M, K, Co, _p(dght), st))
         return (dght, dwr, dgamma, dbeta) + (None,) * 11
 
 

@@ -274,12 +274,12 @@ int cl3d_pwmlp_merge_weight_grad(const float *dwr, const float *dwb, int B, int 
                                  cl3d_stream_t stream);
 /* the training gather pass: per channel sum y, sum y^2, sum y*rel, sum rel (partial); per (query, channel)
  * the extreme pre-activation ystar_t that wins the max (max_k y if gamma >= 0 else min_k y), its slot
- * kstar_t (first one) and sy_t = sum_k y; slotrec [B,M,K,4] = {rel, centre index} per slot (only needed by the
- * backward pass; may be null). */
+ * kstar_t (first one) and sy_t = sum_k y.  Nothing is kept per slot: the backward passes rebuild a slot's relative
+ * position from the coordinates and idx. */
 int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
                      const float *ght, const float *wr, const float *gamma, int B, int N, int M, int K,
-                     int Co, float radius, float *ystar_t, unsigned char *kstar_t, float *sy_t, float *slotrec,
-                     double *partial, int n_partials, cl3d_stream_t stream);
+                     int Co, float radius, float *ystar_t, unsigned char *kstar_t, float *sy_t, double *partial,
+                     int n_partials, cl3d_stream_t stream);
 /* fixed-order reduction of the double partials + per-channel BatchNorm2d algebra (batch mean/variance,
  * scale/shift, running-statistics update with nn.BatchNorm2d's rule; sums [Co,6] doubles kept for the
  * backward pass).  bn_backward_coeffs: coefficients of dy = A dz [k = k*] + Bc + D y together with
@@ -298,10 +298,10 @@ int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, const int32
 /* dz_cm [B,Co,M] = gout gated by the ReLU at the arg-max and ts_cm [B,Co,M] = idx[j, kstar] (the support point
  * the arg-max slot refers to), both channel-major for bwd_hits; partial: sum dz, sum dz*xhat, sum dz*rel(k*). */
 int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, const float *ystar_t,
-                        const unsigned char *kstar_t, const int32_t *idx, const float *slotrec,
-                        const float *scale, const float *shift, const float *mean, const float *invstd, int B,
-                        int M, int K, int Co, float *dz_cm, int32_t *ts_cm, double *partial, int n_partials,
-                        cl3d_stream_t stream);
+                        const unsigned char *kstar_t, const int32_t *idx, const float *query_xyz,
+                        const float *support_xyz, float radius, const float *scale, const float *shift,
+                        const float *mean, const float *invstd, int B, int N, int M, int K, int Co, float *dz_cm,
+                        int32_t *ts_cm, double *partial, int n_partials, cl3d_stream_t stream);
 /* the arg-max term of d G: hit_cm [B,Co,N] = sum of dz over the (query, channel) pairs with ts = point */
 int cl3d_pwmlp_bwd_hits(const float *dz_cm, const int32_t *ts_cm, int B, int N, int M, int Co, float *hit_cm,
                         cl3d_stream_t stream);
@@ -311,8 +311,9 @@ int cl3d_pwmlp_bn_backward_coeffs(const double *partial, int n_partials, int Co,
                                   float *dbeta, float *dwr, cl3d_stream_t stream);
 int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const float *cA, const float *cB,
                            const float *cD, const float *hit_cm, const float *dz_cm, const float *sy_t,
-                           const float *slotrec, const int32_t *inv_off, const int32_t *inv_slots, int B, int N,
-                           int M, int K, int Co, float *dght, cl3d_stream_t stream);
+                           const float *query_xyz, const float *support_xyz, const int32_t *idx, float radius,
+                           const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K, int Co,
+                           float *dght, cl3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -5,7 +5,7 @@ OUT=gpurun_out/$TAG
 R=$(pwd)
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_operators_gpu.py tests/test_native_gpu.py tests/test_abi_host_gpu.py tests/test_fullsize_gpu.py -m gpu -q -x --timeout=300 -p no:cacheprovider > $OUT/pytest.log 2>&1
+timeout 600 python -m pytest tests/test_operators_gpu.py tests/test_native_gpu.py tests/test_abi_host_gpu.py tests/test_fullsize_gpu.py -m gpu -q --timeout=300 -p no:cacheprovider > $OUT/pytest.log 2>&1
 echo "pytest rc=$?" | tee $OUT/summary.txt; grep -E "passed|failed|^FAILED|Error:|assert" $OUT/pytest.log | tail -8 | tee -a $OUT/summary.txt
 for i in 1 2 3; do
 timeout 120 python bench.py --no-cpu-baseline --no-kernel-roofline --no-step-table 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('  ms_per_step', d['ms_per_step'])" | tee -a $OUT/summary.txt
