@@ -57,6 +57,13 @@ echo "== dataset-side grid subsampling, voting, sphere crops" | tee -a $OUT/summ
 timeout 600 python scripts/bench_dataset_grid.py 2>/dev/null | tee $OUT/bench_dataset_grid.json | tee -a $OUT/summary.txt
 timeout 300 python scripts/bench_voting.py 2>/dev/null | tee $OUT/bench_voting.json | tee -a $OUT/summary.txt
 timeout 300 python scripts/bench_sphere_crop.py 2>/dev/null | tee $OUT/bench_sphere_crop.json | tee -a $OUT/summary.txt
+echo "== timeline of one replay of the timed step (critical path, idle time between kernels)" | tee -a $OUT/summary.txt
+(cd /tmp && rm -rf /tmp/tl && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o tl -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-kernel-roofline --no-step-table > /dev/null 2>&1)
+python scripts/step_timeline.py "/tmp/tl/**/tl_kernel_trace.csv" | tee $OUT/step_timeline.txt | tail -3 | tee -a $OUT/summary.txt
+echo "== PseudoGrid operator: per-kernel averages" | tee -a $OUT/summary.txt
+(cd /tmp && rm -rf /tmp/pgp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pgp -o pg -- python $R/bench.py --operator pseudo_grid --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-roofline --no-step-table > /dev/null 2>&1)
+cp $(find /tmp/pgp -name "pg_kernel_stats.csv" | head -1) $OUT/bench_pseudo_grid_kernel_stats.csv 2>/dev/null
+python scripts/kstats.py $OUT/bench_pseudo_grid_kernel_stats.csv 45 12 | tee -a $OUT/summary.txt
 # keep the merged output small: drop raw traces, keep stats and counter tables
 find $OUT -type f -name "*kernel_trace*" -delete 2>/dev/null
 find $OUT -type f -size +3M -delete 2>/dev/null
