@@ -1,0 +1,39 @@
+"""Re-attach the PMC columns of a saved bench line (roofline.step.kernels[*].hbm_bytes_pmc / l2_bytes_pmc) from a
+step_counters.json of the SAME session.  bench.py reads the newest committed profiles/rNN/step_counters.json while it
+runs, i.e. the previous session's counters; after a session's files are copied to profiles/rNN/ this puts the
+session's own counters next to its own timings.
+
+    python scripts/refresh_step_pmc.py profiles/r02/bench_pointwisemlp.json profiles/r02/step_counters.json
+"""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bench import ENTRY_KERNELS  # noqa: E402
+
+
+def main():
+    line_path, counters_path = sys.argv[1], sys.argv[2]
+    line = json.load(open(line_path))
+    counters = json.load(open(counters_path))["kernels"]
+    step = line["roofline"]["step"]
+    for row in step["kernels"]:
+        hb = lb = 0.0
+        found = False
+        for kname, rec in counters.items():
+            if any(kname.replace("cl3d::", "").startswith(pref) for pref in ENTRY_KERNELS.get(row["entry"], [])):
+                hb += rec.get("hbm_bytes", 0.0)
+                lb += rec.get("l2_bytes", 0.0)
+                found = True
+        row.pop("hbm_bytes_pmc", None)
+        row.pop("l2_bytes_pmc", None)
+        if found:
+            row["hbm_bytes_pmc"], row["l2_bytes_pmc"] = int(hb), int(lb)
+    step["pmc_source"] = os.path.relpath(counters_path)
+    json.dump(line, open(line_path, "w"))
+    print("refreshed", line_path, "from", counters_path)
+
+
+if __name__ == "__main__":
+    main()
