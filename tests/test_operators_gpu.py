@@ -164,6 +164,21 @@ FUSED_CASES = [
 @pytest.mark.parametrize("kind,over,C,K,N,mult", FUSED_CASES)
 def test_fused_operator_matches_oracle(kind, over, C, K, N, mult):
     """impl='fused' (must not fall back) against the CPU oracle, forward and all gradients."""
+    _fused_vs_oracle(kind, over, C, K, N, mult)
+
+
+def test_pseudo_grid_with_many_influences_per_slot():
+    """The sparse PseudoGrid form keeps four (kernel point, influence) pairs per slot and sums a slot with more of them
+    densely in place.  At the reference's kernel-point spacing no slot has more than four; kernel points pulled in to
+    0.3 of their radius overlap heavily, so most slots take that path (forward, support-major backward and the
+    d kernel_weights staging)."""
+    def pull_in(mod):
+        with torch.no_grad():
+            mod.local_aggregation_operator.K_points.mul_(0.3)
+    _fused_vs_oracle("pseudo_grid", {"pseudo_grid__KP_influence": "linear"}, 32, 20, 600, 1.5, tweak=pull_in)
+
+
+def _fused_vs_oracle(kind, over, C, K, N, mult, tweak=None):
     from closerlook3d_amd.local_aggregation_operators import LocalAggregation
     from oracle import operators as oo
     from tests.helpers import oracle_operator
@@ -181,6 +196,8 @@ def test_fused_operator_matches_oracle(kind, over, C, K, N, mult):
             if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
                 m.weight.uniform_(0.5, 1.5)
                 m.bias.normal_(0, 0.2)
+    if tweak is not None:
+        tweak(mod)
     state = {"state__" + k: v.detach().clone().numpy() for k, v in mod.state_dict().items()}
     probe = rng.standard_normal((B, C, N)).astype(np.float32)
     fx = dict(state, xyz=xyz, mask=mask, features=feats, radius=np.float32(radius), nsample=np.int32(K),
