@@ -221,8 +221,18 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
       }
     }
   };
-  sweep(s, nv, [&](int, float x, float y, float z) { atomicAdd(&s_sup[cell_of(x, y, z)], 1); });
-  sweep(q, M, [&](int, float x, float y, float z) { atomicAdd(&s_qry[cell_of(x, y, z)], 1); });
+  // queries == support points (every non-strided layer): one sweep feeds both histograms, and both scatters below
+  const bool same = query_xyz == support_xyz && M == N;
+  if (same) {
+    sweep(s, N, [&](int i, float x, float y, float z) {
+      const int cell = cell_of(x, y, z);
+      if (i < nv) atomicAdd(&s_sup[cell], 1);
+      atomicAdd(&s_qry[cell], 1);
+    });
+  } else {
+    sweep(s, nv, [&](int, float x, float y, float z) { atomicAdd(&s_sup[cell_of(x, y, z)], 1); });
+    sweep(q, M, [&](int, float x, float y, float z) { atomicAdd(&s_qry[cell_of(x, y, z)], 1); });
+  }
   __syncthreads();
 
   // ---- (3) three exclusive scans over the cells with shared barriers: support counts, query counts,
@@ -363,8 +373,36 @@ __global__ __launch_bounds__(1024) void bq_prep_kernel(const float *__restrict__
         if (pos[u] >= 0) dst[pos[u]] = make_float4(px[u], py[u], pz[u], __int_as_float(base + u * 1024 + tid));
     }
   };
-  scatter(s, nv, s_sup, sorted, sup_lo, sup_hi);
-  scatter(q, M, s_qry, qsorted, qry_lo, qry_hi);
+  if (same) {  // one load per point, two cursors
+    for (int base = 0; base < N; base += 1024 * kPrepU) {
+      float px[kPrepU], py[kPrepU], pz[kPrepU];
+      int ps[kPrepU], pq[kPrepU];
+#pragma unroll
+      for (int u = 0; u < kPrepU; ++u) {
+        const int i = base + u * 1024 + tid;
+        const int ic = i < N ? i : N - 1;
+        px[u] = s[ic * 3 + 0];
+        py[u] = s[ic * 3 + 1];
+        pz[u] = s[ic * 3 + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < kPrepU; ++u) {
+        const int i = base + u * 1024 + tid;
+        const int cell = cell_of(px[u], py[u], pz[u]);
+        ps[u] = (i < nv && cell >= sup_lo && cell < sup_hi) ? atomicAdd(&s_sup[cell], 1) : -1;
+        pq[u] = (i < N && cell >= qry_lo && cell < qry_hi) ? atomicAdd(&s_qry[cell], 1) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < kPrepU; ++u) {
+        const float4 rec = make_float4(px[u], py[u], pz[u], __int_as_float(base + u * 1024 + tid));
+        if (ps[u] >= 0) sorted[ps[u]] = rec;
+        if (pq[u] >= 0) qsorted[pq[u]] = rec;
+      }
+    }
+  } else {
+    scatter(s, nv, s_sup, sorted, sup_lo, sup_hi);
+    scatter(q, M, s_qry, qsorted, qry_lo, qry_hi);
+  }
   if (tid == 0 && part == 0) {
     BqGrid g;
     g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2]; g.inv_h = inv_h;
