@@ -24,6 +24,7 @@ def _conv_bn(cin, cout, momentum, relu):
 import os
 
 _BLOCK_ENGINE = os.environ.get('CL3D_BLOCK', 'engine')  # 'modules': nn.Conv1d / BatchNorm1d as in round 1 (A/B only)
+_DECODE = os.environ.get('CL3D_DECODE', 'split')  # 'cat': the decoders concatenate as the reference does (A/B only)
 
 
 def run_conv_bn(seq, x, impl='auto', precision='f32', residual=None, shortcut=None):
@@ -144,10 +145,17 @@ class _UpsampleDecoder(nn.Module):
     def _decode(self, end_points):
         feats = end_points['res5_features']
         for lvl, (fine, coarse) in enumerate(((4, 5), (3, 4), (2, 3), (1, 2))):
-            feats = getattr(self, f"up{lvl}")(end_points[f'res{fine}_xyz'], end_points[f'res{coarse}_xyz'],
-                                              end_points[f'res{fine}_mask'], end_points[f'res{coarse}_mask'], feats)
-            feats = torch.cat([feats, end_points[f'res{fine}_features']], 1)
-            feats = run_conv_bn(getattr(self, f"up_conv{lvl}"), feats)
+            up, seq = getattr(self, f"up{lvl}"), getattr(self, f"up_conv{lvl}")
+            geom = (end_points[f'res{fine}_xyz'], end_points[f'res{coarse}_xyz'],
+                    end_points[f'res{fine}_mask'], end_points[f'res{coarse}_mask'])
+            skip = end_points[f'res{fine}_features']
+            out = None
+            if feats.is_cuda and _BLOCK_ENGINE != 'modules' and _DECODE != 'cat' and getattr(self, 'impl', 'auto') != 'grouped':
+                from . import fused  # the level without the concatenated tensor, see fused.decode_level
+                out = fused.decode_level(up, *geom, feats, skip, seq[0], seq[1], getattr(self, 'precision', 'f32'))
+            if out is None:
+                out = run_conv_bn(seq, torch.cat([up(*geom, feats), skip], 1))
+            feats = out
         return feats
 
 

@@ -642,7 +642,8 @@ class _Conv1x1(Function):
     library's Conv1d forward / backward-data / backward-weight kernels of backbones/resnet.py:32-39,58-66."""
 
     @staticmethod
-    def forward(ctx, x, W, precision):
+    def forward(ctx, x, W, precision, residual=None):
+        """residual [B,Co,N] (optional) is added in the product's epilogue: y = W x + residual."""
         x = x.contiguous()
         W = W.contiguous()
         B, C, N = x.shape
@@ -650,9 +651,15 @@ class _Conv1x1(Function):
         y = torch.empty((B, Co, N), dtype=torch.float32, device=x.device)
         ws, ws_bytes = _gemm_scratch(15, B, N, Co, C, x.device)
         with _lib.on_device(x.device):
-            _lib.check(_lib.lib().cl3d_conv1x1_fwd(_p(x), _p(W), B, C, N, Co, precision, _p(y), _p(ws), ws_bytes, _stream(x)))
+            if residual is None:
+                _lib.check(_lib.lib().cl3d_conv1x1_fwd(_p(x), _p(W), B, C, N, Co, precision, _p(y), _p(ws), ws_bytes, _stream(x)))
+            else:
+                residual = residual.contiguous()
+                _lib.check(_lib.lib().cl3d_conv1x1_bn_act_fwd(_p(x), _p(W), None, None, _p(residual), 0, B, C, N, Co, precision,
+                                                              _p(y), _p(ws), ws_bytes, _stream(x)))
         ctx.save_for_backward(x, W)
         ctx.precision = precision
+        ctx.has_residual = residual is not None
         return y
 
     @staticmethod
@@ -678,7 +685,37 @@ class _Conv1x1(Function):
 
         with _lib.on_device(x.device):
             _fork_join(x.device, weight_grad, data_grad)
-        return dx, dW, None
+        return dx, dW, None, (dy if ctx.has_residual and ctx.needs_input_grad[3] else None)
+
+
+def decode_level(up, fine_xyz, coarse_xyz, fine_mask, coarse_mask, coarse_feats, skip_feats, conv, bn, precision='f32'):
+    """One level of the segmentation decoders (heads/segmentation_head.py:55-73): nearest up-sampling of the coarse
+    features, concatenation with the skip features, 1x1 Conv1d + BatchNorm1d + ReLU -- without the concatenated tensor.
+    Nearest up-sampling is a column gather and commutes with a 1x1 convolution, and the convolution splits over the two
+    channel groups:  W [up(f) ; s] = up(W_a f) + W_b s.  So W_a runs at the COARSE resolution (a quarter of the points
+    or fewer), the gather moves C_out channels instead of C_up (four times fewer at the first level), and the sum is the
+    epilogue of the skip branch's product.  Same weight tensor as the reference's (its two column blocks); each output
+    element is the same dot product, added in two parts.  Returns None when the modules are outside what the kernels
+    cover (the caller then concatenates as the reference does)."""
+    if conv.bias is not None or conv.kernel_size != (1,) or not _bn_unit_ok(skip_feats, bn) or not coarse_feats.is_cuda:
+        return None
+    if coarse_feats.dtype != torch.float32 or coarse_feats.dim() != 3:
+        return None
+    training = bn.training
+    if not training and _wants_grad(coarse_feats, skip_feats, conv.weight, bn.weight, bn.bias):
+        return None  # backward through frozen statistics: the nn modules do it
+    prec = PRECISIONS[precision]
+    Cu, Cs = coarse_feats.shape[1], skip_feats.shape[1]
+    Co = conv.weight.shape[0]
+    if conv.weight.shape[1] != Cu + Cs:
+        return None
+    W = conv.weight.view(Co, Cu + Cs)
+    a = _Conv1x1.apply(coarse_feats, W[:, :Cu], prec)
+    g = up(fine_xyz, coarse_xyz, fine_mask, coarse_mask, a)
+    y = _Conv1x1.apply(skip_feats, W[:, Cu:], prec, g)
+    if training:
+        return _BnAddRelu.apply(y, bn.weight, bn.bias, None, None, None, bn, None, True)
+    return bn_relu(y, bn)
 
 
 class _BnAddRelu(Function):

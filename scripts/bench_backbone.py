@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="arithmetic of the dense contractions (PointWiseMLP rows and 1x1 convolutions); BASELINE config 2 is bf16")
     ap.add_argument("--no-cache", action="store_true", help="disable the per-forward ball-query memo")
+    ap.add_argument("--head", action="store_true",
+                    help="backbone + the scene-segmentation head (nearest up-sampling decoder + classifier) in the step")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python")
     args = ap.parse_args()
     kind, B, N, radius, dl, nsamples, npoints, width = CONFIGS[args.config]
@@ -76,7 +78,11 @@ def main():
     if kind == "pospool" and "deep" in args.config:
         cfg.pospool.position_embedding = "sin_cos"
     net = ResNet(cfg, 3, radius, dl, nsamples, npoints, width=width, depth=2, bottleneck_ratio=2).to(dev).train(True)
-    params = [p for p in net.parameters() if p.requires_grad]
+    head = None
+    if args.head:  # the scene-segmentation decoder + classifier of the reference's S3DIS / PartNet models (13 classes)
+        from closerlook3d_amd.backbones import SceneSegHeadResNet
+        head = SceneSegHeadResNet(13, width, radius, nsamples).to(dev).train(True)
+    params = [p for p in net.parameters() if p.requires_grad] + ([p for p in head.parameters()] if head is not None else [])
     opt = torch.optim.SGD(params, lr=1e-3)
     xyz, mask, _ = synth_batch(B, N, 3, 7 + rank)  # every rank its own clouds / scene
     scale = 1.0 if N <= 16384 else 4.0  # scenes: metres; objects: unit cube
@@ -93,7 +99,8 @@ def main():
             opt.zero_grad(set_to_none=True)
         with (contextlib.nullcontext() if args.no_cache else ball_query_cache()):
             ep = net(x, m, feats)
-        ep["res5_features"].square().mean().backward()
+            out = head(ep) if head is not None else ep["res5_features"]
+        out.square().mean().backward()
         if world == 1:
             opt.step()
 
@@ -160,6 +167,7 @@ def main():
         line = {"config": args.config, "operator": kind, "n_gpus": world, "clouds_per_gpu": B, "points": N, "width": width,
                 "precision": args.precision, "launch": "hip_graph" if graph is not None else "eager",
                 "ms_per_step": round(dt * 1e3, 3), "input_points_per_s": round(world * B * N / dt, 1), "scaling": "weak",
+                "head": "scene_seg" if head is not None else None,
                 "params_M": round(sum(p.numel() for p in params) / 1e6, 2),
                 "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
         if world > 1:
