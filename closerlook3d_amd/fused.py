@@ -697,6 +697,8 @@ def decode_level(up, fine_xyz, coarse_xyz, fine_mask, coarse_mask, coarse_feats,
     epilogue of the skip branch's product.  Same weight tensor as the reference's (its two column blocks); each output
     element is the same dot product, added in two parts.  Returns None when the modules are outside what the kernels
     cover (the caller then concatenates as the reference does)."""
+    if getattr(up, 'mode', None) != 'nearest':  # only a plain column gather commutes with the convolution
+        return None
     if conv.bias is not None or conv.kernel_size != (1,) or not _bn_unit_ok(skip_feats, bn) or not coarse_feats.is_cuda:
         return None
     if coarse_feats.dtype != torch.float32 or coarse_feats.dim() != 3:
