@@ -47,6 +47,11 @@ for c in modelnet_small modelnet_pointwisemlp s3dis_pseudogrid partnet_adaptive 
   timeout 600 python scripts/bench_backbone.py --config $c 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
 done
 timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp --precision bf16 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
+echo "== segmentation configs with the scene-segmentation head in the step (decoder without / with the concatenated tensor)" | tee -a $OUT/summary.txt
+for c in s3dis_pseudogrid partnet_adaptive s3dis_pospool_deep; do
+  timeout 600 python scripts/bench_backbone.py --config $c --head 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
+  CL3D_DECODE=cat timeout 600 python scripts/bench_backbone.py --config $c --head 2>/dev/null | tail -1 | sed 's/^/concatenating decoder: /' | tee -a $OUT/summary.txt
+done
 CL3D_BLOCK=modules timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp 2>/dev/null | tail -1 | sed 's/^/round-1 block path (library conv + BatchNorm modules): /' | tee -a $OUT/summary.txt
 echo "== steady-state kernel table of the config-2 backbone step (bf16)" | tee -a $OUT/summary.txt
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bb -o bb -- python $R/scripts/bench_backbone.py --config modelnet_pointwisemlp --precision bf16 --steps 40 > $R/$OUT/rocprof_bb.log 2>&1)
