@@ -631,6 +631,32 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
             ks[u] = a.kstar_t[e];
             gq[u] = a.gout_channel_major ? tile[cl * 65 + jq] : a.gout[e];
           }
+          if (CW == 64 && K <= 64) {
+            // a wave = the 64 channels of ONE query: lane l fetches slot l's neighbour index and coordinates -- loads
+            // that do not wait for the arg-max slots -- and every lane then picks its own slot's by shuffle (two
+            // dependent round trips per batch instead of three)
+            int iv[kRowsBatch];
+            float sx[kRowsBatch], sy[kRowsBatch], sz[kRowsBatch], qx[kRowsBatch], qy[kRowsBatch], qz[kRowsBatch];
+#pragma unroll
+            for (int u = 0; u < kRowsBatch; ++u) {
+              const int jq = jb + u * RS < nj ? jb + u * RS : nj - 1;
+              iv[u] = a.idx[((size_t)b * M + j0 + jq) * K + (cl < K ? cl : K - 1)];
+              const float *qp = a.query_xyz + ((size_t)b * M + j0 + jq) * 3;
+              qx[u] = qp[0]; qy[u] = qp[1]; qz[u] = qp[2];
+            }
+#pragma unroll
+            for (int u = 0; u < kRowsBatch; ++u) {
+              const float *sp = a.support_xyz + ((size_t)b * a.N + iv[u]) * 3;
+              sx[u] = sp[0]; sy[u] = sp[1]; sz[u] = sp[2];
+            }
+#pragma unroll
+            for (int u = 0; u < kRowsBatch; ++u) {
+              ts[u] = __shfl(iv[u], ks[u], CL3D_WAVE);
+              rel[u] = make_float4((__shfl(sx[u], ks[u], CL3D_WAVE) - qx[u]) * a.inv_radius,
+                                   (__shfl(sy[u], ks[u], CL3D_WAVE) - qy[u]) * a.inv_radius,
+                                   (__shfl(sz[u], ks[u], CL3D_WAVE) - qz[u]) * a.inv_radius, 0.f);
+            }
+          } else {
 #pragma unroll
           for (int u = 0; u < kRowsBatch; ++u) {
             const int jq = jb + u * RS < nj ? jb + u * RS : nj - 1;
@@ -643,6 +669,7 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
             const float *qp = a.query_xyz + ((size_t)b * M + j0 + jq) * 3;
             rel[u] = make_float4((sp[0] - qp[0]) * a.inv_radius, (sp[1] - qp[1]) * a.inv_radius,
                                  (sp[2] - qp[2]) * a.inv_radius, 0.f);
+          }
           }
 #pragma unroll
           for (int u = 0; u < kRowsBatch; ++u) {
