@@ -1123,7 +1123,8 @@ extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const f
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
   const int gx = round_grid(tiles, 8192);
-  // measured at the metric shape: 8 rows in flight at 3 waves/SIMD 93 us, 6 at 3 93 us, 5 at 4 87 us, 4 at 4 86 us
+  // measured at the metric shape: 8 rows in flight at 3 waves/SIMD 93 us, 6 at 3 93 us, 5 at 4 87 us, 4 at 4 86 us;
+  // more waves with spills: 3 rows at 5 waves/SIMD 102 us, 4 at 5 110 us, 2 at 6 113 us
   if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4, 4, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((pwmlp_support_kernel<1, 8, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_bwd_support");
