@@ -17,6 +17,12 @@ int ball_query_cells(const float *query_xyz, const float *support_xyz, const int
                      const int *support_mask, int B, int M, int N, float radius, int K, int *idx,
                      int *idx_mask, void *ws, size_t ws_bytes, hipStream_t st);
 
+// single-launch search with the cell-sorted cloud resident in LDS (ball_query_lds.hip): N, M <= 4096, no scratch
+bool ball_query_tile_applicable(int M, int N, int K);
+int ball_query_tile(const float *query_xyz, const float *support_xyz, const int *query_mask,
+                    const int *support_mask, int B, int M, int N, float radius, int K, int *idx, int *idx_mask,
+                    hipStream_t st);
+
 // grid_subsample.hip
 size_t grid_subsampling_workspace(int B, int N);
 // csr.hip

@@ -19,6 +19,8 @@
 // Results are bit-identical to the reference semantics (tests/test_native_gpu.py); the
 // distance uses cl3d::dist2's canonical operation order.
 #include "ball_query.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace cl3d {
 
@@ -260,9 +262,20 @@ extern "C" int cl3d_masked_ordered_ball_query(const float *query_xyz, const floa
   CL3D_REQUIRE(query_xyz && support_xyz && query_mask && support_mask && idx && idx_mask, "ball_query: null pointer");
   CL3D_REQUIRE(B <= 65535, "ball_query: B exceeds grid.y limit");
   hipStream_t st = (hipStream_t)stream;
-  // cell-grid search when scratch is provided and the problem is large enough to pay for the prep pass;
-  // otherwise (and for queries too dense for its LDS lists) the exhaustive scan
-  if (ws != nullptr && cl3d::ball_query_cells_applicable(M, N, nsample))
+  // CL3D_BQ_PATH=tile|cells|exhaustive pins one implementation where it applies (A/B timing, tests of the
+  // less-travelled paths); every path returns the same bits
+  static const int pinned = [] {
+    const char *e = getenv("CL3D_BQ_PATH");
+    if (e == nullptr) return 0;
+    return strcmp(e, "tile") == 0 ? 1 : strcmp(e, "cells") == 0 ? 2 : strcmp(e, "exhaustive") == 0 ? 3 : 0;
+  }();
+  // clouds whose cell-sorted copy fits one CU's LDS: one launch, no scratch, nothing but coordinates and results in HBM
+  if ((pinned == 0 || pinned == 1) && cl3d::ball_query_tile_applicable(M, N, nsample))
+    return cl3d::ball_query_tile(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx,
+                                 idx_mask, st);
+  // larger clouds: cell-grid search through HBM scratch when scratch is provided and the problem is large enough to
+  // pay for the prep pass; otherwise (and for queries too dense for its LDS lists) the exhaustive scan
+  if (pinned != 3 && ws != nullptr && cl3d::ball_query_cells_applicable(M, N, nsample))
     return cl3d::ball_query_cells(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx,
                                   idx_mask, ws, ws_bytes, st);
   return cl3d::ball_query_exhaustive(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx,

@@ -1,0 +1,50 @@
+"""Time masked_ordered_ball_query at the metric shape (or --n/--m/--k) under the current CL3D_BQ_PATH; one JSON line."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from closerlook3d_amd import _ext  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--b", type=int, default=16)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--m", type=int, default=0)
+    ap.add_argument("--k", type=int, default=32)
+    ap.add_argument("--mult", type=float, default=1.5)
+    ap.add_argument("--reps", type=int, default=50)
+    a = ap.parse_args()
+    rng = np.random.default_rng(0)
+    s = torch.from_numpy(rng.random((a.b, a.n, 3), dtype=np.float32)).cuda()
+    sm = torch.ones((a.b, a.n), dtype=torch.int32, device="cuda")
+    if a.m:
+        q = s[:, :a.m].contiguous() + 0.001
+        qm = torch.ones((a.b, a.m), dtype=torch.int32, device="cuda")
+    else:
+        q, qm = s, sm
+    r = float((a.mult * a.k * 3 / (4 * np.pi * a.n)) ** (1 / 3))
+    for _ in range(5):
+        _ext.masked_ordered_ball_query(q, s, qm, sm, r, a.k)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(a.reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _ext.masked_ordered_ball_query(q, s, qm, sm, r, a.k)
+        e1.record()
+        e1.synchronize()
+        ts.append(e0.elapsed_time(e1) * 1e3)
+    ts.sort()
+    print(json.dumps({"op": "masked_ordered_ball_query", "path": os.environ.get("CL3D_BQ_PATH", "auto"), "B": a.b, "N": a.n,
+                      "M": a.m or a.n, "K": a.k, "mult": a.mult, "us_median": round(ts[len(ts) // 2], 2),
+                      "us_min": round(ts[0], 2), "us_max": round(ts[-1], 2)}))
+
+
+if __name__ == "__main__":
+    main()
