@@ -72,26 +72,29 @@ def synth_batch(B, N, C, seed, pad_frac=0.0):
     return xyz, mask, feats
 
 
-def event_time_ms(fn, iters, warmup=3, burst=8):
-    """Average duration of one fn() in ms: HIP events on the current (= launch) stream around bursts of
-    `burst` back-to-back launches, so the device stays busy and host launch latency is not counted."""
+def event_time_stats(fn, bursts=12, warmup=3, burst=8):
+    """Duration of one fn() in ms over `bursts` bursts of `burst` back-to-back launches (HIP events on the current
+    (= launch) stream around each burst, so the device stays busy and host launch latency is not counted):
+    {median, min, max, bursts} of the per-burst averages.  The count does not depend on --steps (two
+    bursts made the line's fraction irreproducible)."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    rounds = max(1, iters // burst)
-    start = [torch.cuda.Event(enable_timing=True) for _ in range(rounds)]
-    stop = [torch.cuda.Event(enable_timing=True) for _ in range(rounds)]
-    for i in range(rounds):
+    start = [torch.cuda.Event(enable_timing=True) for _ in range(bursts)]
+    stop = [torch.cuda.Event(enable_timing=True) for _ in range(bursts)]
+    for i in range(bursts):
         start[i].record()
         for _ in range(burst):
             fn()
         stop[i].record()
     torch.cuda.synchronize()
-    return float(np.mean([s.elapsed_time(e) for s, e in zip(start, stop)])) / burst
+    per = sorted(s.elapsed_time(e) / burst for s, e in zip(start, stop))
+    return {"median": float(np.median(per)), "min": per[0], "max": per[-1], "bursts": bursts, "launches_per_burst": burst}
 
 
-def kernel_rooflines(xyz, mask, feats, radius, K, iters):
-    """Per-kernel achieved bandwidth of the materialising ball_query+group path."""
+def kernel_rooflines(xyz, mask, feats, radius, K, bursts):
+    """Per-kernel achieved bandwidth of the materialising ball_query+group path; every figure is the
+    MEDIAN over `bursts` bursts, with the spread beside it."""
     from closerlook3d_amd import _ext
     B, N, _ = xyz.shape
     C = feats.shape[1]
@@ -101,8 +104,8 @@ def kernel_rooflines(xyz, mask, feats, radius, K, iters):
     MK = M * K
     specs = {
         # name: (callable, algorithmic bytes per launch)
-        "ball_query_kernel": (lambda: _ext.masked_ordered_ball_query(xyz, xyz, mask, mask, radius, K),
-                              B * (12 * M + 12 * N + 4 * M + 4 * N + 8 * MK)),
+        "ball_query": (lambda: _ext.masked_ordered_ball_query(xyz, xyz, mask, mask, radius, K),
+                       B * (12 * M + 12 * N + 4 * M + 4 * N + 8 * MK)),
         "group_fwd_lds_kernel": (lambda: _ext.group_points(feats, idx), B * (4 * C * MK + 4 * C * N + 4 * MK)),
         "group_rel_kernel+group_fwd_lds_kernel": (lambda: _ext.group_xyz_features(xyz, xyz, feats, idx, radius, True),
                                                   B * (12 * M + 12 * N + 4 * C * N + 4 * MK + 12 * MK + 4 * C * MK)),
@@ -110,18 +113,30 @@ def kernel_rooflines(xyz, mask, feats, radius, K, iters):
     }
     out = {}
     for name, (fn, nbytes) in specs.items():
-        ms = event_time_ms(fn, iters)
-        out[name] = {"ms": round(ms, 5), "bytes": int(nbytes), "achieved_GBps": round(nbytes / ms / 1e6, 1),
+        st = event_time_stats(fn, bursts)
+        ms = st["median"]
+        out[name] = {"ms": round(ms, 5), "ms_min": round(st["min"], 5), "ms_max": round(st["max"], 5),
+                     "bursts": st["bursts"], "bytes": int(nbytes), "achieved_GBps": round(nbytes / ms / 1e6, 1),
                      "frac": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4)}
     # the whole reference-visible boundary: fwd (query + group) and bwd (scatter), 17,696 B/point at the metric shape
-    total_ms = out["ball_query_kernel"]["ms"] + out["group_rel_kernel+group_fwd_lds_kernel"]["ms"] + out["group_bwd_lds_kernel"]["ms"]
+    parts = ("ball_query", "group_rel_kernel+group_fwd_lds_kernel", "group_bwd_lds_kernel")
     fwd = 12 * M + 12 * N + 4 * M + 4 * N + 4 * C * N + 4 * MK + 4 * MK + 12 * MK + 4 * C * MK
     bwd = 4 * C * MK + 4 * MK + 4 * C * N
+
+    def frac_at(key):
+        total = sum(out[p][key] for p in parts)
+        return total, B * (fwd + bwd) / (total * 1e-3) / HBM_PEAK
+
+    total_ms, frac = frac_at("ms")
+    _, frac_slowest = frac_at("ms_max")   # every part at its slowest burst: the floor of the fraction
+    _, frac_fastest = frac_at("ms_min")
     boundary = {"ms": round(total_ms, 5), "bytes_per_point": (fwd + bwd) / M,
                 "points_per_s": round(B * M / (total_ms * 1e-3), 1),
                 "achieved_GBps": round(B * (fwd + bwd) / total_ms / 1e6, 1),
-                "frac": round(B * (fwd + bwd) / (total_ms * 1e-3) / HBM_PEAK, 4),
-                "frac_of_measured_copy_peak": round(B * (fwd + bwd) / (total_ms * 1e-3) / HBM_MEASURED, 4)}
+                "frac": round(frac, 4), "frac_min": round(frac_slowest, 4), "frac_max": round(frac_fastest, 4),
+                "frac_of_measured_copy_peak": round(frac * HBM_PEAK / HBM_MEASURED, 4),
+                "definition": "sum of the medians of ball_query + (group_rel + group_fwd) + group_bwd; frac_min takes "
+                              "every part at its slowest burst"}
     return out, boundary
 
 
@@ -129,7 +144,7 @@ L2_PEAK = 34.5e12  # B/s aggregate L2 bandwidth (MI355X_MICROARCH.md, "L2 (per X
 
 # C-ABI entry point -> kernels it launches (names as rocprofv3 prints them), for merging PMC counters
 ENTRY_KERNELS = {
-    "cl3d_masked_ordered_ball_query": ["bq_prep_kernel", "bq_query_kernel", "ball_query_kernel"],
+    "cl3d_masked_ordered_ball_query": ["bq_tile_kernel", "bq_prep_kernel", "bq_query_kernel", "ball_query_kernel"],
     "cl3d_build_inverse_index": ["csr_count_fill_kernel", "csr_rows_kernel", "csr_scan_kernel"],
     "cl3d_pwmlp_point_gemm_fwd": ["pwmlp_weights_kernel", "mfma_gemm_kernel"],
     "cl3d_pwmlp_point_gemm_bwd_data": ["mfma_gemm_kernel"],
@@ -197,7 +212,9 @@ def step_counters():
 def step_table(compute, B, N, M, K, C, reps, kind="pointwisemlp"):
     """The timed step's own kernels: GPU microseconds per C-ABI entry point from HIP events on the launch stream, in
     an eager run of the SAME compute() with the index streams folded onto the main stream (so durations are not
-    stretched by overlap).  The graph-replayed step overlaps some of these, so the rows sum to more than ms_per_step."""
+    stretched by overlap); median / min / max over `reps` runs.  The graph-replayed step overlaps some of these, so
+    the rows sum to more than ms_per_step.  L2 figures come from the committed PMC passes (TCC_HIT + TCC_MISS
+    requests x 128 B), not from a model."""
     from closerlook3d_amd import _lib, pt_utils
     saved = pt_utils.ASYNC_INDEX
     pt_utils.ASYNC_INDEX = False
@@ -207,22 +224,20 @@ def step_table(compute, B, N, M, K, C, reps, kind="pointwisemlp"):
         with _lib.trace() as tr:
             for _ in range(reps):
                 compute()
-        summary = tr.summary()
+        per_run = tr.per_run(reps)
     finally:
         pt_utils.ASYNC_INDEX = saved
     model = step_model_bytes(B, N, M, K, C, kind)
     counters, counters_src = step_counters()
     rows = []
-    for name, (calls, us) in summary.items():
-        us_step = us / reps
+    for name, (calls, runs) in per_run.items():
+        us_step = float(np.median(runs))
         alg, l2, bound = model.get(name, (0, 0, "small"))
-        cps = calls / reps
-        alg, l2 = int(alg * cps), int(l2 * cps)
-        row = {"entry": name, "calls": round(cps, 2), "us": round(us_step, 2), "algorithmic_bytes": alg,
-               "hbm_frac": round(alg / (us_step * 1e-6) / HBM_PEAK, 4) if us_step > 0 else None, "bound": bound}
-        if l2:
-            row["l2_gather_bytes_model"] = l2
-            row["l2_frac"] = round(l2 / (us_step * 1e-6) / L2_PEAK, 4)
+        alg = int(alg * calls)
+        row = {"entry": name, "calls": calls, "us": round(us_step, 2), "us_min": round(min(runs), 2),
+               "us_max": round(max(runs), 2), "algorithmic_bytes": alg,
+               "hbm_frac": round(alg / (us_step * 1e-6) / HBM_PEAK, 4) if us_step > 0 else None, "bound": bound,
+               "kernels": ENTRY_KERNELS.get(name, [])}
         hb = lb = 0.0
         found = False
         for kname, rec in counters.items():
@@ -232,9 +247,11 @@ def step_table(compute, B, N, M, K, C, reps, kind="pointwisemlp"):
                 found = True
         if found:
             row["hbm_bytes_pmc"], row["l2_bytes_pmc"] = int(hb), int(lb)
+            row["l2_frac"] = round(lb / (us_step * 1e-6) / L2_PEAK, 4) if us_step > 0 else None
         rows.append(row)
     rows.sort(key=lambda r: -r["us"])
-    return {"source": "HIP events around every C-ABI call, eager one-stream run of the timed step, mean of %d runs" % reps,
+    return {"source": "HIP events around every C-ABI call on the launch stream, eager one-stream run of the timed step, "
+                      "median of %d runs" % reps,
             "pmc_source": counters_src, "sum_us": round(sum(r["us"] for r in rows), 1),
             "dominant": rows[0]["entry"] if rows else None, "kernels": rows}
 
@@ -269,26 +286,29 @@ def contraction_block(B, C, N, Co, precision, reps=30):
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (scripts/pmc_kernels.py; rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 FETCH_SIZE correction applied), or None."""
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json"))):
+    """HBM bytes per launch of `kernel` from the newest committed PMC passes (scripts/pmc_kernels.py; rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 FETCH_SIZE correction applied), or None.  "ball_query" sums the
+    kernels one call of the op launches."""
+    prefixes = ("bq_", "ball_query_kernel") if kernel == "ball_query" else (kernel,)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_traffic.json")), reverse=True):
         try:
             data = json.load(open(path))["kernels"]
         except Exception:
             continue
-        for name, rec in data.items():
-            if name.replace("cl3d::", "").startswith(kernel):
-                best = rec["hbm_bytes"]
-    return best
+        hits = [rec["hbm_bytes"] for name, rec in data.items() if name.replace("cl3d::", "").startswith(prefixes)]
+        if hits:
+            return float(sum(hits))
+    return None
 
 
-def cpu_baseline(kind, N, K, C, radius, clouds, iters):
-    """The oracle (port of the reference semantics) timed on the host: LA fwd+bwd over `clouds` clouds, once with every
-    core (OpenMP over batch x query in the C restatement of the native ops + torch's intra-op threads) and once on a
-    single thread (the literal one-block-per-cloud structure of the reference kernels), SURVEY 8(d)."""
+def cpu_baseline_child(kind, N, K, C, radius, clouds, iters, threads):
+    """One leg of the CPU baseline in a process of its own (so that its OpenMP binding touches nothing else): the
+    oracle (port of the reference semantics) timed on the host, LA fwd+bwd over `clouds` clouds with `threads`
+    threads -- OpenMP over batch x query in the C restatement of the native ops + torch's intra-op threads."""
     from oracle import native as on  # noqa: F401  (test/bench infrastructure only)
     from oracle import operators as oo
+    torch.set_num_threads(threads)
+    on.set_threads(threads)
     xyz, mask, feats = synth_batch(clouds, N, C, 12345)
     t = [torch.from_numpy(a) for a in (xyz, xyz, mask, mask)]
     f = torch.from_numpy(feats).requires_grad_(True)
@@ -307,41 +327,72 @@ def cpu_baseline(kind, N, K, C, radius, clouds, iters):
         kp = torch.randn(15, 3, generator=g) * 0.05
         kw = (torch.randn(15, C, generator=g) * 0.1).requires_grad_(True)
         fn = lambda: oo.pseudo_grid(*t, f, radius, K, kp, kw, 2 * radius / 5.0, 'linear')  # noqa: E731
+    fn().sum().backward()  # warm-up
+    ts = []
+    for _ in range(iters):
+        f.grad = None
+        t0 = time.perf_counter()
+        fn().sum().backward()
+        ts.append(time.perf_counter() - t0)
+    print(json.dumps({"seconds": float(np.median(ts)), "threads": threads, "clouds": clouds}), flush=True)
 
-    def timed(n_iters):
-        fn().sum().backward()  # warm-up
-        ts = []
-        for _ in range(n_iters):
-            f.grad = None
-            t0 = time.perf_counter()
-            fn().sum().backward()
-            ts.append(time.perf_counter() - t0)
-        return float(np.median(ts))
 
-    torch_threads = int(torch.get_num_threads())
-    omp_threads = on.set_threads(0)
-    med_all = timed(iters)
-    try:  # one thread everywhere
-        torch.set_num_threads(1)
-        on.set_threads(1)
-        med_one = timed(max(1, iters // 2))
-    finally:
-        torch.set_num_threads(torch_threads)
-        on.set_threads(omp_threads)
+def cpu_baseline(kind, N, K, C, radius, clouds, iters, threads_sweep=(8, 16, 32, 64)):
+    """the reference's CPU-side equivalent timed on the host cores of the same box.  Every leg runs in a
+    child process with OMP_PLACES=cores OMP_PROC_BIND=close (threads on physical cores, close together).  all_cores =
+    the best of a small sweep over the thread count -- the operator's tensors stop scaling long before every core is
+    busy (round 2 timed 128 + 128 threads on 4 clouds and got LESS than one thread); one_thread = the literal
+    one-block-per-cloud structure of the reference kernels, on a quarter of the sample."""
+    import subprocess
+
+    def leg(n_clouds, n_iters, threads):
+        env = dict(os.environ, OMP_PLACES="cores", OMP_PROC_BIND="close", OMP_NUM_THREADS=str(threads),
+                   HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child",
+               json.dumps([kind, N, K, C, radius, n_clouds, n_iters, threads])]
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError("cpu baseline leg failed: " + r.stderr[-500:])
+        return json.loads(r.stdout.strip().splitlines()[-1])["seconds"]
+
+    phys = physical_cores()
+    sweep = {nt: leg(clouds, iters, nt) for nt in ([t for t in threads_sweep if t <= phys] or [phys])}
+    best_t = min(sweep, key=sweep.get)
+    med_all = sweep[best_t]
+    quarter = max(1, clouds // 4)
+    med_one = leg(quarter, 1, 1)
     try:
         cpu_model = [ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")][0]
     except Exception:
         cpu_model = "unknown"
-    return {"value": round(clouds * N / med_all, 1), "unit": "points/s", "cores": max(torch_threads, omp_threads),
+    return {"value": round(clouds * N / med_all, 1), "unit": "points/s", "cores": best_t,
             "kind": "port",
             "sample": f"{clouds} clouds x {iters} timed fwd+bwd of the same operator/shape (N={N},K={K},C={C}); "
-                      f"C oracle for the native ops (OpenMP, {omp_threads} threads over batch x query) + torch CPU ops "
-                      f"({torch_threads} threads); median {med_all * 1e3:.1f} ms; host: {cpu_model}, "
-                      f"{os.cpu_count()} logical cores",
+                      f"C oracle for the native ops (OpenMP over batch x query) + torch CPU ops, {best_t} threads each "
+                      f"(best of the sweep), OMP_PLACES=cores OMP_PROC_BIND=close; median {med_all * 1e3:.1f} ms; host: "
+                      f"{cpu_model}, {phys} physical / {os.cpu_count()} logical cores",
             "all_cores": {"value": round(clouds * N / med_all, 1), "ms": round(med_all * 1e3, 1),
-                          "omp_threads": omp_threads, "torch_threads": torch_threads},
-            "one_thread": {"value": round(clouds * N / med_one, 1), "ms": round(med_one * 1e3, 1),
+                          "omp_threads": best_t, "torch_threads": best_t,
+                          "sweep_ms": {str(k): round(v * 1e3, 1) for k, v in sweep.items()}},
+            "one_thread": {"value": round(quarter * N / med_one, 1), "ms": round(med_one * 1e3, 1), "clouds": quarter,
                            "omp_threads": 1, "torch_threads": 1}}
+
+
+def physical_cores():
+    """Physical cores this process may run on (distinct (package, core) pairs of the allowed CPUs)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+    seen = set()
+    for c in allowed:
+        try:
+            pkg = open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id").read().strip()
+            core = open(f"/sys/devices/system/cpu/cpu{c}/topology/core_id").read().strip()
+            seen.add((pkg, core))
+        except OSError:
+            seen.add(("?", c))
+    return max(len(seen), len(allowed) // 2)  # virtual machines report one (package, core) pair for every CPU
 
 
 # ---- cpu_baseline legs of the auxiliary benches (scripts/bench_dataset_grid.py, scripts/bench_voting.py): like
@@ -376,6 +427,8 @@ def cpu_baseline_voting(batches, num_classes, cloud_sizes):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-baseline-child":
+        return cpu_baseline_child(*json.loads(sys.argv[2]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -391,6 +444,7 @@ def main():
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="arithmetic of the PointWiseMLP's dense contraction (bf16 inputs to the MFMA, f32 accumulation)")
     ap.add_argument("--no-step-table", action="store_true")
+    ap.add_argument("--bursts", type=int, default=12, help="bursts of 8 launches per boundary kernel (median / min / max reported)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
     args = ap.parse_args()
 
@@ -517,30 +571,51 @@ def main():
             "config": {"workload": f"ModelNet40-shape {kind} LocalAggregation fwd+bwd", "operator": kind,
                        "impl": args.impl, "clouds_per_gpu": B, "points": N, "nsample": K, "channels": C,
                        "radius": round(radius, 5), "contraction_precision": args.precision, "launch": "hip_graph" if graph is not None else "eager",
-                       "parallelism": f"dp{world} (clouds sharded, RCCL grad all-reduce)"},
+                       "parallelism": f"dp{world} (clouds sharded, RCCL grad all-reduce)",
+                       "world_size": dist.get_world_size() if world > 1 else 1,
+                       "backend": dist.get_backend() if world > 1 else None,
+                       "device": f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"},
         }
         if not args.no_kernel_roofline:
-            with torch.no_grad():
-                per_kernel, boundary = kernel_rooflines(xyz, mask, feats.detach(), radius, K, max(10, args.steps))
-            dom = max((k for k in per_kernel if "+" not in k), key=lambda k: per_kernel[k]["ms"])
-            line["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": per_kernel[dom]["achieved_GBps"],
-                                "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": per_kernel[dom]["frac"],
-                                "traffic": pmc_traffic(dom),
-                                "path": "_ext materialising (MaskedQueryAndGroup + backward as the reference's Python calls "
-                                        "it; measured after the timed region -- the timed step runs the fused path, see "
-                                        "'step')",
-                                "per_kernel": per_kernel, "ball_query_group": boundary,
-                                # the roofline fraction the headline value itself corresponds to
-                                "achieved_step": {"GBps": round(value / world * 17696.0 / 1e9, 1),
-                                                  "frac": round(value / world * 17696.0 / HBM_PEAK, 4),
-                                                  "definition": "points_per_s_per_gpu x 17,696 B / 8.0e12 B/s"}}
+            # top level: the TIMED STEP's dominant kernel (longest C-ABI entry point of the step table): algorithmic
+            # HBM bytes per launch / median launch duration, HIP events on the launch stream; `traffic` = its PMC HBM
+            # bytes from the committed passes.  `boundary` = the reference-visible ball_query + group path that
+            # north_star's >= 50 % target is defined on (labelled; not what the timed step runs).
+            roof = {"bound": "hbm", "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
             if not args.no_step_table:
-                line["roofline"]["step"] = step_table(compute, B, N, N, K, C, reps=10, kind=kind)
-                line["roofline"]["step"]["graph_step_us"] = round(ms * 1e3, 1)
+                st = step_table(compute, B, N, N, K, C, reps=20, kind=kind)
+                st["graph_step_us"] = round(ms * 1e3, 1)
+                d = st["kernels"][0]
+                roof.update({"kernel": (d["kernels"] or [d["entry"]])[0], "entry": d["entry"], "us": d["us"],
+                             "us_min": d["us_min"], "us_max": d["us_max"], "algorithmic_bytes": d["algorithmic_bytes"],
+                             "achieved": round(d["algorithmic_bytes"] / d["us"] / 1e3, 1), "frac": d["hbm_frac"],
+                             "traffic": d.get("hbm_bytes_pmc"), "l2_frac": d.get("l2_frac"),
+                             "what": "dominant kernel of the timed step (fused path); bound by L2 requests + gather "
+                                     "latency, priced against HBM as the contract asks"})
+            with torch.no_grad():
+                per_kernel, boundary = kernel_rooflines(xyz, mask, feats.detach(), radius, K, bursts=args.bursts)
+            for k, v in per_kernel.items():
+                if "+" not in k:
+                    v["traffic"] = pmc_traffic(k)
+            roof["boundary"] = {"path": "_ext materialising (MaskedQueryAndGroup + backward as the reference's Python "
+                                        "calls it; measured after the timed region -- the timed step runs the fused "
+                                        "path, see 'step')",
+                                "per_kernel": per_kernel, "ball_query_group": boundary}
+            # the roofline fraction the headline value itself corresponds to
+            roof["achieved_step"] = {"GBps": round(value / world * 17696.0 / 1e9, 1),
+                                     "frac": round(value / world * 17696.0 / HBM_PEAK, 4),
+                                     "definition": "points_per_s_per_gpu x 17,696 B / 8.0e12 B/s"}
+            if not args.no_step_table:
+                roof["step"] = st
+            else:
+                d = max((k for k in per_kernel if "+" not in k), key=lambda k: per_kernel[k]["ms"])
+                roof.update({"kernel": d, "achieved": per_kernel[d]["achieved_GBps"], "frac": per_kernel[d]["frac"],
+                             "traffic": per_kernel[d]["traffic"], "what": "boundary kernel (no step table requested)"})
+            line["roofline"] = roof
             if kind == "pointwisemlp":
                 line["roofline"]["contraction"] = contraction_block(B, C, N, C, args.precision)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(kind, N, K, C, radius, clouds=4, iters=4)
+            line["cpu_baseline"] = cpu_baseline(kind, N, K, C, radius, clouds=16, iters=2)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -57,10 +57,10 @@ SIGNATURES = {
     "cl3d_pwmlp_finalize_stats": [_P, _I, _I, ctypes.c_double, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "cl3d_pwmlp_apply": [_P, _P, _P, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _I, _P, _P, _P],
-    "cl3d_pwmlp_bwd_rows": [_P, _I] + [_P] * 5 + [_F] + [_P] * 4 + [_I] * 5 + [_P, _P, _P, _I, _P],
+    "cl3d_pwmlp_bwd_rows": [_P, _I] + [_P] * 5 + [_F] + [_P] * 4 + [_I] * 5 + [_P, _P, _P, _P, _P, _I, _P],
     "cl3d_pwmlp_bwd_hits": [_P, _P, _I, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_bn_backward_coeffs": [_P, _I, _I, ctypes.c_double] + [_P] * 11,
-    "cl3d_pwmlp_bwd_support": [_P] * 11 + [_F, _P, _P] + [_I] * 5 + [_P, _P],
+    "cl3d_pwmlp_bwd_support": [_P] * 10 + [_F, _P, _P] + [_I] * 5 + [_P, _P],
 }
 
 
@@ -138,6 +138,31 @@ class trace:
             out[name] = (calls + 1, us + e0.elapsed_time(e1) * 1e3)
         return out
 
+    def per_run(self, runs):
+        """{entry point: (calls per run, [microseconds of run 0, run 1, ...])} when the traced region was `runs`
+        repetitions of the same step (every run makes the same calls in the same order)."""
+        torch.cuda.synchronize()
+        seen = {}
+        for name, e0, e1 in self.log:
+            seen.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)
+        out = {}
+        for name, us in seen.items():
+            per = max(1, len(us) // runs)
+            out[name] = (per, [sum(us[r * per:(r + 1) * per]) for r in range(len(us) // per)])
+        return out
+
+
+def _header_abi_version():
+    """CL3D_ABI_VERSION of include/cl3d.h: the library must have been built from the same header (a stale .so with
+    another argument layout would run with shifted pointers)."""
+    import re
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "cl3d.h")
+    with open(hdr) as f:
+        return int(re.search(r"#define\s+CL3D_ABI_VERSION\s+(\d+)", f.read()).group(1))
+
+
+ABI_VERSION = _header_abi_version()
+
 
 def lib():
     global _lib
@@ -150,7 +175,7 @@ def lib():
                 "(there is no CPU or PyTorch fallback for these ops).")
         handle = ctypes.CDLL(_PATH)
         _declare(handle)
-        if handle.cl3d_abi_version() != 1:
+        if handle.cl3d_abi_version() != ABI_VERSION:
             raise ImportError("libcl3d.so ABI version mismatch")
         if handle.cl3d_d2_form() != _D2_FORM:
             raise ImportError(f"{_PATH} was built with CL3D_D2_FORM={handle.cl3d_d2_form()}, expected {_D2_FORM}")

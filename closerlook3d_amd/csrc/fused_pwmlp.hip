@@ -34,6 +34,8 @@
 //             in global memory.
 //   plus the weight plumbing around the per-point library GEMM (split_weight / merge_weight_grad).
 #include "fused_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace cl3d {
 
@@ -50,9 +52,9 @@ struct PwArgs {
   int out_channel_major;
   float *ystar_t, *sy_t;           // TRAIN: [B,M,Co]
   unsigned char *kstar_out;        // TRAIN / FWD
-  float4 *slotrec;                 // FWD writes {rel, centre index} per slot when asked to (cl3d_pwmlp_fwd)
   const float *hit_cm;             // SUPPORT: [B,Co,N] sum of arg-max dz per support point (channel-major)
-  const float *dz_cm;              // SUPPORT: [B,Co,M] gated upstream gradient (channel-major)
+  const float *dz_t;               // SUPPORT: [B,M,Co] gated upstream gradient (point-major copy left by bwd_rows)
+  const float4 *qtab;              // SUPPORT: [B,M] {query coordinates, centre index idx[j, 0]} left by bwd_rows
   const float *sy_in;              // SUPPORT: [B,M,Co]
   double *partial;                 // [gridDim.x, Co, kPartialW]
   const int *inv_off, *inv_slots;
@@ -60,6 +62,7 @@ struct PwArgs {
   int B, N, M, K, Co;
   int L, QW, chunks;
   float inv_radius;
+  unsigned kmagic;  // ceil(2^32 / K), see div_k
 };
 
 __device__ __forceinline__ float pw_preact(const float w[3], float rx, float ry, float rz, float hc, float g) {
@@ -69,20 +72,41 @@ __device__ __forceinline__ float pw_preact(const float w[3], float rx, float ry,
   return (t + hc) + g;
 }
 
-// query-major gather passes.  Persistent blocks: tile = 4*QW queries of one cloud.
+// t / K for slot counters (t < 2^24, K <= 255) without the ~20-instruction integer division: magic = ceil(2^32 / K)
+__device__ __forceinline__ int div_k(int t, unsigned magic, int K) {
+  return K == 1 ? t : (int)__umulhi((unsigned)t, magic);
+}
+static unsigned div_magic(int K) { return K <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)K - 1) / (unsigned)K); }
+
+// query-major gather passes.  Persistent blocks: tile = 4*QW*QPG queries of one cloud (every lane group walks QPG
+// queries of a tile one after the other).
 // V == 4 is only used when Co % 4 == 0 and V == 1 rows are single elements, so a lane with c0 < Co always
 // owns a full vector: every row access is one global_load_dwordx4 / dword.
-template <int MODE, int V, int KB, int WPE>  // KB = row gathers in flight per lane, WPE = waves per SIMD to fit
+//
+// What the round-3 rewrite changed (the pass was 71-76 us at the metric shape, half of it staging latency):
+//   * a slot record is {byte offset of the neighbour's row in the cloud's ght, rel}: the gather address is one
+//     32-bit add on a uniform base (was a 64-bit multiply-add per slot and lane);
+//   * staging is batched: a thread issues the index loads of all its slots, then all coordinate loads -- two
+//     dependent round trips per tile whatever the tile size (was two per 256 slots), and QPG = 2 halves the tiles
+//     (barriers, round trips) per slot;
+//   * the centre's H row is fetched together with the first batch of G rows (it was a round trip of its own in
+//     front of every query's walk);
+//   * full batches carry no per-slot guard: with the guard the compiler sank one of the four gathers of a batch
+//     behind a branch and waited for it alone (two dependent round trips per batch instead of one).
+template <int MODE, int V, int KB, int WPE, int QPG>  // KB = row gathers in flight per lane, WPE = waves per SIMD to fit
 __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
   extern __shared__ float4 lds4[];
   const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
-  const int TQ = 4 * QW;
+  const int TG = 4 * QW;       // lane groups of the block
+  const int TQ = TG * QPG;     // queries per tile
   const int row = 2 * Co;
+  const unsigned rowb = (unsigned)row * 4u;
   // per-query rows are K+1 records long: the lane groups of a wave read the same slot of different queries at
   // once, and rows of K float4 (512 B at K = 32) would put all of them in the same LDS banks
   const int KS = K + 1;
-  float4 *slot4 = lds4;  // [TQ][KS] {idx, rx, ry, rz}
-  double *red = reinterpret_cast<double *>(slot4 + TQ * KS);  // [4 waves][L*V*NACC]
+  float4 *slot4 = lds4;  // [TQ][KS] {row byte offset, rx, ry, rz}
+  float4 *qtile = slot4 + TQ * KS;  // [TQ] coordinates of the tile's queries
+  double *red = reinterpret_cast<double *>(qtile + TQ);  // [4 waves][L*V*NACC]
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int g = lane / L, cl = lane - g * L;
@@ -90,17 +114,39 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
   const int tiles_per_cloud = (M + TQ - 1) / TQ;
   const int ntiles = a.B * tiles_per_cloud;
   constexpr int NACC = MODE == PW_TRAIN ? 8 : 0;
+  constexpr int kStage = 4;  // slots staged per thread and round
 
   // channel chunks are spread over gridDim.y: the deep layers of a backbone have few queries and many channels
   // (16 clouds x 16 queries x 1152 channels), and a grid over query tiles alone leaves the chip empty there
   for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {
     const int c0 = (ch * L + cl) * V;
     const bool chan_on = lane_on && c0 < Co;
+    const unsigned lane_off = (unsigned)c0 * 4u;
+    // per-channel constants.  TRAIN works on y' = sgn * y (see below) and keeps only the pre-signed weights;
+    // FWD keeps the weights and the folded BatchNorm scale / shift.
+    constexpr int NW = MODE == PW_TRAIN ? 1 : V;
+    float ws[V][3], sgn[V], c_v0[NW], c_v1[NW];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const int c = chan_on ? c0 + v : 0;
+      sgn[v] = 1.f;
+      if constexpr (MODE == PW_TRAIN) sgn[v] = a.v0[c] < 0.f ? -1.f : 1.f;
+      ws[v][0] = sgn[v] * a.wr[c * 3 + 0];
+      ws[v][1] = sgn[v] * a.wr[c * 3 + 1];
+      ws[v][2] = sgn[v] * a.wr[c * 3 + 2];
+      if constexpr (MODE != PW_TRAIN) {
+        c_v0[v] = a.v0 ? a.v0[c] : 0.f;
+        c_v1[v] = a.v1 ? a.v1[c] : 0.f;
+      }
+    }
+    (void)c_v0;
+    (void)c_v1;
+
     // TRAIN: a lane sums its queries' {sum y, sum y^2, S_0..2, R_0..2} in float (a few hundred terms at most
     // between flushes); every kFlushTiles tiles the lane groups of a wave are folded in a fixed order and
     // group 0 adds the result to the wave's double accumulators in LDS, one slot per (wave, channel) -- no
     // atomics, and half the VGPRs of double register accumulators, which the gather loop's occupancy needs
-    constexpr int kFlushTiles = 16;
+    constexpr int kFlushTiles = 8 / QPG;  // <= 8 queries x K slots per running float sum
     constexpr int NF = NACC > 0 ? 5 : 1;
     float accf[NF][V], accr[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -127,7 +173,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
 #pragma unroll
       for (int p = 0; p < NF; ++p)
 #pragma unroll
-        for (int v = 0; v < V; ++v) f[p][v] = fold_groups(accf[p][v]);
+        for (int v = 0; v < V; ++v) f[p][v] = fold_groups(accf[p][v]) * (p >= 2 ? sgn[v] : 1.f);  // S_a held primed
       if (g == 0) {
         double *mine = red + (size_t)wave * LVN + cl * V * NACC;
 #pragma unroll
@@ -146,103 +192,164 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
         for (int v = 0; v < V; ++v) accf[p][v] = 0.f;
       since_flush = 0;
     };
-    float w[V][3], c_v0[V], c_v1[V];
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const int c = chan_on ? c0 + v : 0;
-      w[v][0] = a.wr[c * 3 + 0];
-      w[v][1] = a.wr[c * 3 + 1];
-      w[v][2] = a.wr[c * 3 + 2];
-      c_v0[v] = a.v0 ? a.v0[c] : 0.f;
-      c_v1[v] = a.v1 ? a.v1[c] : 0.f;
-    }
-
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
       int b, tq;
       decode_tile(tile, a.B, tiles_per_cloud, b, tq);
       const int j0 = tq * TQ;
       const float *q = a.query_xyz + (size_t)b * M * 3;
       const float *s = a.support_xyz + (size_t)b * N * 3;
+      const int *idxb = a.idx + (size_t)b * M * K;
       __syncthreads();  // previous tile's readers are done with slot4
-      for (int t = threadIdx.x; t < TQ * K; t += 256) {
-        const int jq = t / K;
-        const int j = j0 + jq;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (j < M) {
-          const size_t e = ((size_t)b * M + j) * K + (t - jq * K);
-          const int i = a.idx[e];
-          r = make_float4(__int_as_float(i), (s[i * 3 + 0] - q[j * 3 + 0]) * a.inv_radius,
-                          (s[i * 3 + 1] - q[j * 3 + 1]) * a.inv_radius, (s[i * 3 + 2] - q[j * 3 + 2]) * a.inv_radius);
-          // slotrec = {rel, centre index of the query}: one dependent load less per slot in the support-major pass
-          if (ch == 0 && a.slotrec != nullptr)
-            a.slotrec[e] = make_float4(r.y, r.z, r.w, __int_as_float(a.idx[((size_t)b * M + j) * K]));
+      float4 qreg = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((int)threadIdx.x < TQ) {  // the tile's query coordinates: requested first, parked in LDS below
+        const int j = j0 + (int)threadIdx.x < M ? j0 + (int)threadIdx.x : M - 1;
+        qreg = make_float4(q[j * 3 + 0], q[j * 3 + 1], q[j * 3 + 2], 0.f);
+      }
+      for (int t0 = 0; t0 < TQ * K; t0 += 256 * kStage) {
+        // round trip 1: the neighbour indices of this thread's slots; round trip 2: the neighbours' coordinates.
+        // Only the indices and 12 coordinates are live across the waits (the gather loop's accumulators stay in
+        // registers around this: occupancy is what the pass lives on).  The slot counter goes through an empty asm
+        // so that the compiler does not hoist every round's index arithmetic out of the tile loop into registers.
+        int iv[kStage];
+        float sx[kStage], sy[kStage], sz[kStage];
+#pragma unroll
+        for (int u = 0; u < kStage; ++u) {
+          int t = t0 + u * 256 + (int)threadIdx.x;
+          asm volatile("" : "+v"(t));
+          const int tc = t < TQ * K ? t : TQ * K - 1;
+          const int jq = div_k(tc, a.kmagic, K);
+          const int j = j0 + jq < M ? j0 + jq : M - 1;
+          iv[u] = idxb[(size_t)j * K + (tc - jq * K)];
         }
-        slot4[jq * KS + (t - jq * K)] = r;
+#pragma unroll
+        for (int u = 0; u < kStage; ++u) {
+          sx[u] = s[iv[u] * 3 + 0];
+          sy[u] = s[iv[u] * 3 + 1];
+          sz[u] = s[iv[u] * 3 + 2];
+        }
+        if (t0 == 0) {
+          if ((int)threadIdx.x < TQ) qtile[threadIdx.x] = qreg;
+          __syncthreads();
+        }
+#pragma unroll
+        for (int u = 0; u < kStage; ++u) {
+          int t = t0 + u * 256 + (int)threadIdx.x;
+          asm volatile("" : "+v"(t));
+          if (t >= TQ * K) continue;
+          const int jq = div_k(t, a.kmagic, K);
+          const int k = t - jq * K;
+          float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (j0 + jq < M) {
+            const float4 qq = qtile[jq];
+            r = make_float4(__uint_as_float((unsigned)iv[u] * rowb), (sx[u] - qq.x) * a.inv_radius,
+                            (sy[u] - qq.y) * a.inv_radius, (sz[u] - qq.z) * a.inv_radius);
+          }
+          slot4[jq * KS + k] = r;
+        }
       }
       __syncthreads();
-      const int jq = wave * QW + g;
+      const char *rows = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
+      auto ldrow = [&](unsigned off) { return load_row<V>(reinterpret_cast<const float *>(rows + off)); };
+#pragma unroll 1
+      for (int qp = 0; qp < QPG; ++qp) {
+      const int jq = qp * TG + wave * QW + g;
       const int j = j0 + jq;
       const bool q_on = chan_on && j < M;
       if (MODE != PW_TRAIN && !q_on) continue;
       const float4 *myslots = slot4 + (q_on ? jq : 0) * KS;
-      const float *rows = a.ght + (size_t)b * N * row;
-      const int ic = __float_as_int(myslots[0].x);  // centre = nearest neighbour (reference :290)
-      Vec<V> hc;
+      const size_t orow = ((size_t)b * M + j) * Co + c0;
+
+      // batch 0 of the walk together with the centre's H row (centre = nearest neighbour = slot 0, reference :290)
+      float4 sr[KB];
+      Vec<V> gr[KB], hc;
 #pragma unroll
       for (int v = 0; v < V; ++v) hc.v[v] = 0.f;
-      if (q_on) hc = load_row<V>(rows + (size_t)ic * row + Co + c0);
-      const size_t orow = ((size_t)b * M + j) * Co + c0;
+#pragma unroll
+      for (int u = 0; u < KB; ++u) sr[u] = myslots[u < K ? u : K - 1];
+      if (q_on) {
+#pragma unroll
+        for (int u = 0; u < KB; ++u) gr[u] = ldrow(__float_as_uint(sr[u].x) + lane_off);
+        hc = ldrow(__float_as_uint(sr[0].x) + (unsigned)Co * 4u + lane_off);
+      }
+      // walk: batch 0 is in flight; full batches carry no guards, the tail (K % KB slots) is guarded
+      auto walk = [&](auto &&slot) {
+        if (K >= KB) {
+#pragma unroll
+          for (int u = 0; u < KB; ++u) {
+            if (u == 0) slot(std::true_type{}, 0, sr[0], gr[0]);
+            else slot(std::false_type{}, u, sr[u], gr[u]);
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < KB; ++u) {
+            if (u == 0) slot(std::true_type{}, 0, sr[0], gr[0]);
+            else if (u < K) slot(std::false_type{}, u, sr[u], gr[u]);
+          }
+        }
+        int k0 = KB;
+        for (; k0 + KB <= K; k0 += KB) {
+#pragma unroll
+          for (int u = 0; u < KB; ++u) sr[u] = myslots[k0 + u];
+#pragma unroll
+          for (int u = 0; u < KB; ++u) gr[u] = ldrow(__float_as_uint(sr[u].x) + lane_off);
+#pragma unroll
+          for (int u = 0; u < KB; ++u) slot(std::false_type{}, k0 + u, sr[u], gr[u]);
+        }
+        if (k0 < K) {
+#pragma unroll
+          for (int u = 0; u < KB; ++u) sr[u] = myslots[k0 + u < K ? k0 + u : K - 1];
+#pragma unroll
+          for (int u = 0; u < KB; ++u) gr[u] = ldrow(__float_as_uint(sr[u].x) + lane_off);
+#pragma unroll
+          for (int u = 0; u < KB; ++u)
+            if (k0 + u < K) slot(std::false_type{}, k0 + u, sr[u], gr[u]);
+        }
+      };
 
       if constexpr (MODE == PW_TRAIN) {
         // everything inside the slot loop works on y' = sgn * y (sgn = sign(gamma) = sign(scale): which extreme of
         // y wins the max).  Negation is exact, so with w' = sgn*w and h' = sgn*h,  y' = fma(g, sgn, w'.rel + h')
         // is sgn * y bit for bit, sum y'^2 = sum y^2, and sum y / sum y*rel are sgn times the primed sums --
-        // the sign costs nothing per slot.
-        float s1[V], s2[V], sr0[V], sr1[V], sr2[V], best[V], sgn[V], ws[V][3], hs[V];
+        // the sign costs nothing per slot.  sum y^2, S_a and R_a go straight into the lane's running float sums
+        // (flushed to double every kFlushTiles tiles); only sum_k y, which is also a per-query output, has its own
+        // registers -- the pass lives on its register budget.
+        float s1[V], best[V], hs[V];
         int kb[V];
-        float rs0 = 0.f, rs1 = 0.f, rs2 = 0.f;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          s1[v] = s2[v] = sr0[v] = sr1[v] = sr2[v] = best[v] = 0.f;
+          s1[v] = best[v] = 0.f;
           kb[v] = 0;
-          sgn[v] = c_v0[v] < 0.f ? -1.f : 1.f;
-          ws[v][0] = sgn[v] * w[v][0];
-          ws[v][1] = sgn[v] * w[v][1];
-          ws[v][2] = sgn[v] * w[v][2];
           hs[v] = sgn[v] * hc.v[v];
         }
         if (q_on) {
-        auto slot = [&](int k, const float4 &sr, const Vec<V> &gr) {
-          rs0 += sr.y;
-          rs1 += sr.z;
-          rs2 += sr.w;
+        walk([&](auto first, int k, const float4 &sr_, const Vec<V> &gr_) {
+          accr[0] += sr_.y;
+          accr[1] += sr_.z;
+          accr[2] += sr_.w;
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            float t = ws[v][0] * sr.y;
-            t = __builtin_fmaf(ws[v][1], sr.z, t);
-            t = __builtin_fmaf(ws[v][2], sr.w, t);
-            const float y = __builtin_fmaf(gr.v[v], sgn[v], t + hs[v]);  // = sgn * pw_preact(w, rel, hc, g)
+            float t = ws[v][0] * sr_.y;
+            t = __builtin_fmaf(ws[v][1], sr_.z, t);
+            t = __builtin_fmaf(ws[v][2], sr_.w, t);
+            const float y = __builtin_fmaf(gr_.v[v], sgn[v], t + hs[v]);  // = sgn * pw_preact(w, rel, hc, g)
             s1[v] += y;
-            s2[v] = __builtin_fmaf(y, y, s2[v]);
-            sr0[v] = __builtin_fmaf(y, sr.y, sr0[v]);
-            sr1[v] = __builtin_fmaf(y, sr.z, sr1[v]);
-            sr2[v] = __builtin_fmaf(y, sr.w, sr2[v]);
-            if (k == 0 || y > best[v]) {  // first extreme
+            accf[1][v] = __builtin_fmaf(y, y, accf[1][v]);
+            accf[2][v] = __builtin_fmaf(y, sr_.y, accf[2][v]);
+            accf[3][v] = __builtin_fmaf(y, sr_.z, accf[3][v]);
+            accf[4][v] = __builtin_fmaf(y, sr_.w, accf[4][v]);
+            if (decltype(first)::value || y > best[v]) {  // first extreme
               best[v] = y;
               kb[v] = k;
             }
           }
-        };
-        for_each_slot<V, KB>(myslots, K, rows, row, c0, slot);
+        });
         Vec<V> ys, sy;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           ys.v[v] = sgn[v] * best[v];
           s1[v] *= sgn[v];
-          sr0[v] *= sgn[v];
-          sr1[v] *= sgn[v];
-          sr2[v] *= sgn[v];
           sy.v[v] = s1[v];
+          accf[0][v] += s1[v];
         }
         store_row<V>(a.ystar_t + orow, ys);
         store_row<V>(a.sy_t + orow, sy);
@@ -253,18 +360,6 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
           a.kstar_out[orow] = (unsigned char)kb[0];
         }
         }  // q_on
-        accr[0] += rs0;
-        accr[1] += rs1;
-        accr[2] += rs2;
-#pragma unroll
-        for (int v = 0; v < V; ++v) {
-          accf[0][v] += s1[v];
-          accf[1][v] += s2[v];
-          accf[2][v] += sr0[v];
-          accf[3][v] += sr1[v];
-          accf[4][v] += sr2[v];
-        }
-        if (++since_flush == kFlushTiles) flush();  // uniform: every thread of the block walks the same tiles
       } else {  // PW_FWD
         float best[V];
         int kb[V];
@@ -273,13 +368,13 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
           best[v] = 0.f;
           kb[v] = 0;
         }
-        for_each_slot<V, KB>(myslots, K, rows, row, c0, [&](int k, const float4 &sr, const Vec<V> &gr) {
+        walk([&](auto first, int k, const float4 &sr_, const Vec<V> &gr_) {
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            const float y = pw_preact(w[v], sr.y, sr.z, sr.w, hc.v[v], gr.v[v]);
+            const float y = pw_preact(ws[v], sr_.y, sr_.z, sr_.w, hc.v[v], gr_.v[v]);  // sgn = 1 here: ws = w
             float z = __builtin_fmaf(y, c_v0[v], c_v1[v]);
             z = z > 0.f ? z : 0.f;
-            if (k == 0 || z > best[v]) {
+            if (decltype(first)::value || z > best[v]) {
               best[v] = z;
               kb[v] = k;
             }
@@ -292,6 +387,10 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
           else a.out_t[orow + v] = best[v];
           if (a.kstar_out) a.kstar_out[orow + v] = (unsigned char)kb[v];
         }
+      }
+      }  // qp
+      if constexpr (MODE == PW_TRAIN) {
+        if (++since_flush == kFlushTiles) flush();  // uniform: every thread of the block walks the same tiles
       }
     }
 
@@ -388,6 +487,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
   __shared__ float4 s_pos[256];  // coordinates of the tile's rows
   const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
   const int row = 2 * Co;
+  const unsigned rowb = (unsigned)row * 4u;
   const int MK = M * K;
   const int TR = 4 * QW;
   const int lane = lane_id();
@@ -400,6 +500,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
   for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {  // channel chunks over gridDim.y, see pwmlp_query_kernel
     const int c0 = (ch * L + cl) * V;
     const bool chan_on = g < QW && c0 < Co;
+    const unsigned lane_off = ((unsigned)Co + (unsigned)c0) * 4u;  // this lane's piece of the H half of a row
     // per-channel constants are (re)loaded where they are used -- the row epilogue and the rare centre
     // term -- instead of being held across the gather loop: the loop's occupancy is what this pass lives on
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -410,12 +511,11 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
       const bool row_on = chan_on && i < N;
       const int *off = a.inv_off + (size_t)b * (N + 1);
       const int *slots = a.inv_slots + (size_t)b * MK;
-      const int *cidx = a.idx + (size_t)b * MK;                    // cidx[j * K] = centre of query j
-      const float *qxyz = a.query_xyz + (size_t)b * M * 3;
+      const float4 *qtab = a.qtab + (size_t)b * M;                 // {query coordinates, centre idx[j, 0]}
       const float *sxyz = a.support_xyz + (size_t)b * N * 3;
-      const float *hrows = a.ght + (size_t)b * N * row + Co + c0;  // H halves of the cloud's rows
+      const char *rows = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
       const float *syrow = a.sy_in + (size_t)b * M * Co + c0;
-      const float *dzcol = a.dz_cm + ((size_t)b * Co + c0) * M;
+      const float *dzrow = a.dz_t + (size_t)b * M * Co + c0;
       const int e_lo = off[i0], e_hi = off[i0 + TR < N ? i0 + TR : N];
       const int ic = i < N ? i : N - 1;
       const int s0 = off[ic], s1 = off[ic + 1];
@@ -435,26 +535,21 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
       for (int cbeg = e_lo; cbeg < e_hi; cbeg += kSupCap) {
         const int cn = e_hi - cbeg < kSupCap ? e_hi - cbeg : kSupCap;
         __syncthreads();  // the previous round's records have been consumed (and the row table is written)
-        // A slot's record {rel, tag} is rebuilt from what is cache-resident anyway -- the query's coordinates, its
-        // centre idx[j, 0], and the coordinates of the row the slot belongs to (found in the tile's 17 row starts) --
-        // with the forward pass's own expression for rel.  (Keeping the forward's records instead cost 33 MB written
-        // there and a 16-byte random gather per slot here.)
+        // A slot's record {rel, tag} is rebuilt from the query table cl3d_pwmlp_bwd_rows leaves behind -- one aligned
+        // 16-byte record {coordinates, centre idx[j, 0]} per query, ONE L2 request per slot (round 2 read the centre
+        // index and the three coordinates separately: two to three requests per slot, 11.7 M per launch at the metric
+        // shape against 4.2 M for the H rows themselves) -- and the coordinates of the row the slot belongs to (found
+        // in the tile's row starts), with the forward pass's own expression for rel.
         for (int t0 = 0; t0 < cn; t0 += 256 * 4) {
-          int sl[4], cen[4];
-          float qv[4][3];
+          int sl[4];
+          float4 qt[4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int t = t0 + u * 256 + (int)threadIdx.x;
             sl[u] = slots[cbeg + (t < cn ? t : cn - 1)];
           }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int j = sl[u] / K;
-            cen[u] = cidx[(size_t)j * K];
-            qv[u][0] = qxyz[j * 3 + 0];
-            qv[u][1] = qxyz[j * 3 + 1];
-            qv[u][2] = qxyz[j * 3 + 2];
-          }
+          for (int u = 0; u < 4; ++u) qt[u] = qtab[div_k(sl[u], a.kmagic, K)];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int t = t0 + u * 256 + (int)threadIdx.x;
@@ -465,10 +560,10 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
               const float4 sp = s_pos[r];
               // tag = the support index of the query's centre (whose H row this slot adds); a slot (j, 0) IS a
               // centre reference -- its centre is this row's own point -- and carries the query id j instead, flagged
-              const int j = sl[u] / K;
-              const unsigned tag = sl[u] - j * K == 0 ? ((unsigned)j | kCentreFlag) : (unsigned)cen[u];
-              srec[t] = make_float4((sp.x - qv[u][0]) * a.inv_radius, (sp.y - qv[u][1]) * a.inv_radius,
-                                    (sp.z - qv[u][2]) * a.inv_radius, __uint_as_float(tag));
+              const int j = div_k(sl[u], a.kmagic, K);
+              const unsigned tag = sl[u] - j * K == 0 ? ((unsigned)j | kCentreFlag) : __float_as_uint(qt[u].w);
+              srec[t] = make_float4((sp.x - qt[u].x) * a.inv_radius, (sp.y - qt[u].y) * a.inv_radius,
+                                    (sp.z - qt[u].z) * a.inv_radius, __uint_as_float(tag));
             }
           }
         }
@@ -494,15 +589,18 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
             }
           }
 #pragma unroll
-          for (int u = 0; u < SB; ++u)
-            hc[u] = load_row<V>(hrows + (size_t)((tags[u] & kCentreFlag) != 0u ? (unsigned)i : tags[u]) * row);
-          if (jc >= 0) {  // about one slot per row: its loads ride along with the batch
+          for (int u = 0; u < SB; ++u) {
+            const unsigned ri = (tags[u] & kCentreFlag) != 0u ? (unsigned)i : tags[u];
+            hc[u] = load_row<V>(reinterpret_cast<const float *>(rows + (__umul24(ri, rowb) + lane_off)));
+          }
+          if (jc >= 0) {  // about one slot per row: its loads ride along with the batch (two point-major rows)
             const Vec<V> sy = load_row<V>(syrow + (size_t)jc * Co);
+            const Vec<V> dz = load_row<V>(dzrow + (size_t)jc * Co);
             ncen += 1.f;
 #pragma unroll
             for (int v = 0; v < V; ++v) {
               csy[v] += sy.v[v];
-              cdz[v] += dzcol[(size_t)v * M + jc];
+              cdz[v] += dz.v[v];
             }
           }
 #pragma unroll
@@ -518,11 +616,12 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
               if ((tag & kCentreFlag) == 0u || seen++ == 0) continue;
               const int j2 = (int)(tag & ~kCentreFlag);
               const Vec<V> sy = load_row<V>(syrow + (size_t)j2 * Co);
+              const Vec<V> dz = load_row<V>(dzrow + (size_t)j2 * Co);
               ncen += 1.f;
 #pragma unroll
               for (int v = 0; v < V; ++v) {
                 csy[v] += sy.v[v];
-                cdz[v] += dzcol[(size_t)v * M + j2];
+                cdz[v] += dz.v[v];
               }
             }
           }
@@ -566,6 +665,8 @@ struct RowArgs {
   const float *scale, *shift, *mean, *invstd;
   float *out;                     // APPLY: [B,Co,M]
   float *dz_cm;                   // BWD: [B,Co,M] gated upstream gradient
+  float *dz_t;                    // BWD: [B,M,Co] the same, point-major
+  float4 *qtab;                   // BWD: [B,M] {query coordinates, idx[j, 0]} for the support-major pass
   int *ts_cm;                     // BWD: [B,Co,M] tstar, transposed for the hit pass
   double *partial;                // BWD: [gridDim.x, Co, kPartialW]
   int B, M, K, Co;
@@ -679,12 +780,20 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
             const float dz = z > 0.f ? gq[u] : 0.f;
             tile[cl * 65 + jq] = dz;  // own element of the tile: overwritten in place, transposed out below
             tile2[cl * 65 + jq] = ts[u];
+            // ... and a point-major copy: the support-major pass reads the rows of the queries centred on a point
+            // (one 16-byte piece per lane; out of the channel-major array that was 64 L2 requests per centred query)
+            a.dz_t[((size_t)b * M + j0 + jq) * Co + c] = dz;
             acc[0] += (double)dz;
             acc[1] += (double)(dz * ((y[u] - mean) * invstd));
             acc[2] += (double)(dz * rel[u].x);
             acc[3] += (double)(dz * rel[u].y);
             acc[4] += (double)(dz * rel[u].z);
           }
+        }
+        if (q == 0 && tid < nj) {  // the query table of the support-major pass: {coordinates, centre idx[j, 0]}
+          const size_t j = (size_t)b * M + j0 + tid;
+          const float *qp = a.query_xyz + j * 3;
+          a.qtab[j] = make_float4(qp[0], qp[1], qp[2], __int_as_float(a.idx[j * K]));
         }
         __syncthreads();
         for (int e = tid; e < CW * 64; e += 256) {  // dz and its target, channel-major, for the hit pass
@@ -820,16 +929,46 @@ __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
   }
 }
 
+// {rel, centre index} per slot for callers of cl3d_pwmlp_fwd that ask for the records (element-wise; the engine's own
+// backward passes rebuild rel from the coordinates and do not use it)
+__global__ __launch_bounds__(256) void pwmlp_slotrec_kernel(const float *__restrict__ query_xyz,
+                                                            const float *__restrict__ support_xyz,
+                                                            const int *__restrict__ idx, int B, int N, int M, int K,
+                                                            float inv_radius, float4 *__restrict__ slotrec) {
+  const long long total = (long long)B * M * K;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const long long bj = e / K;
+    const int b = (int)(bj / M);
+    const int i = idx[e];
+    const float *sp = support_xyz + ((size_t)b * N + i) * 3;
+    const float *qp = query_xyz + (size_t)bj * 3;
+    slotrec[e] = make_float4((sp[0] - qp[0]) * inv_radius, (sp[1] - qp[1]) * inv_radius, (sp[2] - qp[2]) * inv_radius,
+                             __int_as_float(idx[bj * K]));
+  }
+}
+
 static int rows_chunks(int Co) { return (Co >> 6) + __builtin_popcount(Co & 63); }
 
 static int pw_check(const PwArgs &a, const char *who) {
   if (a.B < 0 || a.N < 1 || a.M < 1 || a.K < 1 || a.Co < 1) return fail(CL3D_E_INVALID, "%s: bad sizes", who);
   if (a.K > 255) return fail(CL3D_E_UNSUPPORTED, "%s: nsample=%d > 255 (arg-max is stored in a byte)", who, a.K);
   if ((long long)a.M * a.K > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "%s: M*K too large", who);
+  if ((long long)a.N * a.Co * 8 > 0xffffffffLL)  // row offsets inside a cloud's [N, 2Co] table are 32-bit byte offsets
+    return fail(CL3D_E_UNSUPPORTED, "%s: N*Co too large", who);
   return CL3D_OK;
 }
 
-static LaneMap pw_lane_map(int Co, int K, int V, int nacc, size_t *lds_out) {
+// queries a lane group walks per tile (template parameter QPG of the query kernels).  CL3D_PW_QPG=1|2 pins it for
+// A/B timing; 2 unless the tile's slot records would not fit the LDS budget.
+static int pw_qpg_wanted() {
+  static const int v = [] {
+    const char *e = getenv("CL3D_PW_QPG");
+    return (e != nullptr && e[0] == '1') ? 1 : 2;
+  }();
+  return v;
+}
+
+static LaneMap pw_lane_map(int Co, int K, int V, int nacc, int qpg, size_t *lds_out) {
   LaneMap m = pick_lane_map(Co, V);
   if (m.QW > 16) {
     m.QW = 16;
@@ -837,8 +976,8 @@ static LaneMap pw_lane_map(int Co, int K, int V, int nacc, size_t *lds_out) {
     m.chunks = ((Co + V - 1) / V + m.L - 1) / m.L;
   }
   for (;;) {
-    const size_t tq = 4 * (size_t)m.QW;
-    const size_t lds = tq * (K + 1) * sizeof(float4) + (size_t)4 * m.L * V * nacc * sizeof(double);
+    const size_t tq = 4 * (size_t)m.QW * qpg;
+    const size_t lds = tq * (K + 2) * sizeof(float4) + (size_t)4 * m.L * V * nacc * sizeof(double);
     if (lds <= 60 * 1024 || m.QW == 1) {
       *lds_out = lds;
       return m;
@@ -851,7 +990,7 @@ bool pwmlp_supported(int K, int Co) {
   if (K < 1 || K > 255 || Co < 1) return false;
   const int V = (Co % 4 == 0) ? 4 : 1;
   size_t lds = 0;
-  pw_lane_map(Co, K, V, 8, &lds);  // the training pass carries the most accumulators
+  pw_lane_map(Co, K, V, 8, 1, &lds);  // the training pass carries the most accumulators
   return lds <= 64 * 1024;
 }
 
@@ -859,18 +998,34 @@ template <int MODE>
 static int launch_query(PwArgs &a, int nacc, int n_partials, hipStream_t st, const char *who) {
   const int V = (a.Co % 4 == 0) ? 4 : 1;
   size_t lds = 0;
-  const LaneMap m = pw_lane_map(a.Co, a.K, V, nacc, &lds);
+  int qpg = pw_qpg_wanted();
+  LaneMap m = pw_lane_map(a.Co, a.K, V, nacc, qpg, &lds);
+  {  // two queries per lane group only where that does not narrow the groups (large nsample: LDS) or starve the grid
+    size_t lds1 = 0;
+    const LaneMap m1 = pw_lane_map(a.Co, a.K, V, nacc, 1, &lds1);
+    const long long tiles2 = (long long)a.B * ceil_div(a.M, 4 * m.QW * 2) * m.chunks;
+    if (qpg == 2 && (m.QW != m1.QW || lds > 64 * 1024 || tiles2 < 1024)) {
+      qpg = 1;
+      m = m1;
+      lds = lds1;
+    }
+  }
   if (lds > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "%s: nsample=%d needs %zu B of LDS", who, a.K, lds);
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
-  const long long tiles = (long long)a.B * ceil_div(a.M, 4 * m.QW);
+  a.kmagic = div_magic(a.K);
+  const long long tiles = (long long)a.B * ceil_div(a.M, 4 * m.QW * qpg);
   const int gx = nacc > 0 ? n_partials : round_grid(tiles, 8192);
-  // measured at the metric shape (TRAIN): 8 gathers in flight at 3 waves/SIMD 87 us, 6 at 3 89 us, 4 at 4 76 us:
+  // measured at the metric shape (TRAIN, round 2): 8 gathers in flight at 3 waves/SIMD 87 us, 6 at 3 89 us, 4 at 4 76 us:
   // occupancy buys more than depth per wave
   // (software-pipelining the walk -- batch n+1's gathers issued before batch n is consumed, 2 or 3 waves per SIMD --
-  // measured 95-120 us: the loop is bound by its arithmetic (40 us of VALU at the metric shape), not by the gathers
-  // (12 us); the other half of this kernel is its streaming traffic)
-  if (V == 4) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4>), dim3(gx, m.chunks), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1, 8, 4>), dim3(gx, m.chunks), dim3(256), lds, st, a);
+  // measured 95-120 us)
+  if (V == 4) {
+    if (qpg == 2) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4, 2>), dim3(gx, m.chunks), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4, 1>), dim3(gx, m.chunks), dim3(256), lds, st, a);
+  } else {
+    if (qpg == 2) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1, 8, 4, 2>), dim3(gx, m.chunks), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1, 8, 4, 1>), dim3(gx, m.chunks), dim3(256), lds, st, a);
+  }
   return check_launch(who);
 }
 
@@ -1050,12 +1205,18 @@ extern "C" int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, 
   PwArgs a{};
   a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.ght = ght; a.wr = wr;
   a.v0 = scale; a.v1 = shift; a.out_t = out; a.out_channel_major = out_channel_major; a.kstar_out = kstar_t;
-  a.slotrec = reinterpret_cast<float4 *>(slotrec);
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co; a.inv_radius = 1.0f / radius;
   int rc = pw_check(a, "pwmlp_fwd");
   if (rc != CL3D_OK) return rc;
   CL3D_REQUIRE(query_xyz && support_xyz && idx && ght && wr && scale && shift && out, "pwmlp_fwd: null pointer");
   if (B == 0) return CL3D_OK;
+  if (slotrec != nullptr) {
+    const long long total = (long long)B * M * K;
+    hipLaunchKernelGGL(pwmlp_slotrec_kernel, dim3(round_grid((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       query_xyz, support_xyz, idx, B, N, M, K, a.inv_radius, reinterpret_cast<float4 *>(slotrec));
+    rc = check_launch("cl3d_pwmlp_fwd(slotrec)");
+    if (rc != CL3D_OK) return rc;
+  }
   return launch_query<PW_FWD>(a, 0, 0, (hipStream_t)stream, "cl3d_pwmlp_fwd");
 }
 
@@ -1063,16 +1224,17 @@ extern "C" int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, co
                                    const unsigned char *kstar_t, const int32_t *idx, const float *query_xyz,
                                    const float *support_xyz, float radius, const float *scale, const float *shift,
                                    const float *mean, const float *invstd, int B, int N, int M, int K, int Co,
-                                   float *dz_cm, int32_t *ts_cm, double *partial, int n_partials, cl3d_stream_t stream) {
+                                   float *dz_cm, int32_t *ts_cm, float *dz_t, float *qtab, double *partial,
+                                   int n_partials, cl3d_stream_t stream) {
   using namespace cl3d;
   CL3D_REQUIRE(B >= 0 && N >= 1 && M >= 1 && K >= 1 && K <= 255 && Co >= 1 && radius > 0.f, "pwmlp_bwd_rows: bad sizes");
   CL3D_REQUIRE(gout && ystar_t && kstar_t && idx && query_xyz && support_xyz && scale && shift && mean && invstd && dz_cm && ts_cm &&
-                   partial,
+                   dz_t && qtab && partial,
                "pwmlp_bwd_rows: null pointer");
   CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_bwd_rows: wrong partial block count");
   if (B == 0) return CL3D_OK;
   RowArgs a{};
-  a.idx = idx; a.dz_cm = dz_cm; a.ts_cm = ts_cm;
+  a.idx = idx; a.dz_cm = dz_cm; a.ts_cm = ts_cm; a.dz_t = dz_t; a.qtab = reinterpret_cast<float4 *>(qtab);
   a.gout = gout; a.gout_channel_major = gout_channel_major; a.ystar_t = ystar_t; a.kstar_t = kstar_t;
   a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.inv_radius = 1.0f / radius; a.N = N;
   a.scale = scale; a.shift = shift; a.mean = mean;
@@ -1103,19 +1265,20 @@ extern "C" int cl3d_pwmlp_bwd_hits(const float *dz_cm, const int32_t *ts_cm, int
 }
 
 extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const float *cA, const float *cB,
-                                      const float *cD, const float *hit_cm, const float *dz_cm, const float *sy_t,
-                                      const float *query_xyz, const float *support_xyz, const int32_t *idx,
-                                      float radius, const int32_t *inv_off, const int32_t *inv_slots, int B, int N,
-                                      int M, int K, int Co, float *dght, cl3d_stream_t stream) {
+                                      const float *cD, const float *hit_cm, const float *dz_t, const float *sy_t,
+                                      const float *qtab, const float *support_xyz, float radius,
+                                      const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K,
+                                      int Co, float *dght, cl3d_stream_t stream) {
   using namespace cl3d;
   PwArgs a{};
-  a.ght = ght; a.wr = wr; a.v0 = cA; a.v1 = cB; a.v2 = cD; a.hit_cm = hit_cm; a.dz_cm = dz_cm; a.sy_in = sy_t;
-  a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.idx = idx; a.inv_radius = 1.0f / radius;
+  a.ght = ght; a.wr = wr; a.v0 = cA; a.v1 = cB; a.v2 = cD; a.hit_cm = hit_cm; a.dz_t = dz_t; a.sy_in = sy_t;
+  a.qtab = reinterpret_cast<const float4 *>(qtab); a.support_xyz = support_xyz; a.inv_radius = 1.0f / radius;
   a.inv_off = inv_off; a.inv_slots = inv_slots; a.dght = dght;
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co;
+  a.kmagic = div_magic(K);
   int rc = pw_check(a, "pwmlp_bwd_support");
   if (rc != CL3D_OK) return rc;
-  CL3D_REQUIRE(ght && wr && cA && cB && cD && hit_cm && dz_cm && sy_t && query_xyz && support_xyz && idx && inv_off && inv_slots && dght && radius > 0.f,
+  CL3D_REQUIRE(ght && wr && cA && cB && cD && hit_cm && dz_t && sy_t && qtab && support_xyz && inv_off && inv_slots && dght && radius > 0.f,
                "pwmlp_bwd_support: null pointer");
   if (B == 0) return CL3D_OK;
   const int V = (Co % 4 == 0) ? 4 : 1;
@@ -1125,7 +1288,12 @@ extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const f
   const int gx = round_grid(tiles, 8192);
   // measured at the metric shape: 8 rows in flight at 3 waves/SIMD 93 us, 6 at 3 93 us, 5 at 4 87 us, 4 at 4 86 us;
   // more waves with spills: 3 rows at 5 waves/SIMD 102 us, 4 at 5 110 us, 2 at 6 113 us
-  if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4, 4, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
+  static const int sb6 = [] {  // CL3D_PW_SB=6: six H rows in flight per lane instead of four (A/B timing)
+    const char *e = getenv("CL3D_PW_SB");
+    return (e != nullptr && e[0] == '6') ? 1 : 0;
+  }();
+  if (V == 4 && sb6) hipLaunchKernelGGL((pwmlp_support_kernel<4, 6, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
+  else if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4, 4, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((pwmlp_support_kernel<1, 8, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_bwd_support");
 }

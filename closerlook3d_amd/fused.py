@@ -473,9 +473,13 @@ class _PointwiseMLP(Function):
             dz_cm = torch.empty((B, Co, M), dtype=torch.float32, device=dev)
             ts_cm = torch.empty((B, Co, M), dtype=torch.int32, device=dev)
             partial = torch.empty((nparts, Co, 8), dtype=torch.float64, device=dev)
+            # for the support-major pass: dz again as point-major rows, and one 16-byte record per query
+            # {coordinates, centre idx[j, 0]} (a slot of that pass then costs one L2 request instead of three)
+            dz_t = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
+            qtab = torch.empty((B, M, 4), dtype=torch.float32, device=dev)
             _lib.check(lib.cl3d_pwmlp_bwd_rows(_p(gout), 1, _p(ystar), _p(kstar), _p(idx), _p(query_xyz), _p(support_xyz),
                                                ctx.radius, _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), B, N, M, K, Co,
-                                               _p(dz_cm), _p(ts_cm), _p(partial), nparts, st))
+                                               _p(dz_cm), _p(ts_cm), _p(dz_t), _p(qtab), _p(partial), nparts, st))
             hit = torch.empty((B, Co, N), dtype=torch.float32, device=dev)
             # d gamma, d beta, d W_r and the coefficients of  dy = A dz + Bc + D y  (BatchNorm backward is affine in y)
             coef = torch.empty((5, Co), dtype=torch.float32, device=dev)
@@ -496,8 +500,8 @@ class _PointwiseMLP(Function):
             hits()
             off, slots = inverse_index(idx, N)
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
-            _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_cm), _p(sy),
-                                                  _p(query_xyz), _p(support_xyz), _p(idx), ctx.radius, _p(off), _p(slots),
+            _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t), _p(sy),
+                                                  _p(qtab), _p(support_xyz), ctx.radius, _p(off), _p(slots),
                                                   B, N, M, K, Co, _p(dght), st))
         return (dght, dwr, dgamma, dbeta) + (None,) * 11
 

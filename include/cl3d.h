@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-#define CL3D_ABI_VERSION 1
+/* 2: round 3 -- cl3d_pwmlp_bwd_rows / cl3d_pwmlp_bwd_support changed their argument lists (query table and
+ * point-major dz rows); the round-2 changes to bn_relu_stats / fused_reduce / pwmlp_* had been made under version 1 */
+#define CL3D_ABI_VERSION 2
 
 #define CL3D_OK 0
 #define CL3D_E_INVALID (-1)     /* bad argument (null pointer, negative size, ...) */
@@ -296,12 +298,15 @@ int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, const int32
                    int N, int M, int K, int Co, float radius, float *out, int out_channel_major,
                    unsigned char *kstar_t, float *slotrec, cl3d_stream_t stream);
 /* dz_cm [B,Co,M] = gout gated by the ReLU at the arg-max and ts_cm [B,Co,M] = idx[j, kstar] (the support point
- * the arg-max slot refers to), both channel-major for bwd_hits; partial: sum dz, sum dz*xhat, sum dz*rel(k*). */
+ * the arg-max slot refers to), both channel-major for bwd_hits; dz_t [B,M,Co] = dz again, point-major, and
+ * qtab [B,M,4] = {query coordinates, as_float(idx[j, 0])} for bwd_support (one 16-byte record per query: a slot of
+ * the support-major pass costs one L2 request instead of three); partial: sum dz, sum dz*xhat, sum dz*rel(k*). */
 int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, const float *ystar_t,
                         const unsigned char *kstar_t, const int32_t *idx, const float *query_xyz,
                         const float *support_xyz, float radius, const float *scale, const float *shift,
                         const float *mean, const float *invstd, int B, int N, int M, int K, int Co, float *dz_cm,
-                        int32_t *ts_cm, double *partial, int n_partials, cl3d_stream_t stream);
+                        int32_t *ts_cm, float *dz_t, float *qtab, double *partial, int n_partials,
+                        cl3d_stream_t stream);
 /* the arg-max term of d G: hit_cm [B,Co,N] = sum of dz over the (query, channel) pairs with ts = point */
 int cl3d_pwmlp_bwd_hits(const float *dz_cm, const int32_t *ts_cm, int B, int N, int M, int Co, float *hit_cm,
                         cl3d_stream_t stream);
@@ -309,9 +314,10 @@ int cl3d_pwmlp_bn_backward_coeffs(const double *partial, int n_partials, int Co,
                                   const float *gamma, const float *mean, const float *invstd,
                                   const double *sums, float *cA, float *cB, float *cD, float *dgamma,
                                   float *dbeta, float *dwr, cl3d_stream_t stream);
+/* d ght [B,N,2Co] through the CSR inverse of idx; dz_t, qtab: left by cl3d_pwmlp_bwd_rows of the same step */
 int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const float *cA, const float *cB,
-                           const float *cD, const float *hit_cm, const float *dz_cm, const float *sy_t,
-                           const float *query_xyz, const float *support_xyz, const int32_t *idx, float radius,
+                           const float *cD, const float *hit_cm, const float *dz_t, const float *sy_t,
+                           const float *qtab, const float *support_xyz, float radius,
                            const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K, int Co,
                            float *dght, cl3d_stream_t stream);
 

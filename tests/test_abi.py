@@ -38,7 +38,8 @@ def test_header_symbols_exported(libpath):
 def test_library_loads_and_reports_version(libpath):
     import torch  # noqa: F401  (binds the HIP runtime first, as the product does)
     h = ctypes.CDLL(libpath)
-    assert h.cl3d_abi_version() == 1
+    from closerlook3d_amd import _lib
+    assert h.cl3d_abi_version() == _lib.ABI_VERSION == 2  # bumped with the round-3 argument lists (include/cl3d.h)
     h.cl3d_last_error_string.restype = ctypes.c_char_p
     assert isinstance(h.cl3d_last_error_string(), bytes)
     h.cl3d_workspace_bytes.restype = ctypes.c_size_t
