@@ -57,9 +57,7 @@ def group_points_grad(grad_out, idx, n):
     return out
 
 
-def masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, out=None):
-    """out: optional (idx, idx_mask) int32 [B,M,nsample] buffers to fill (pt_utils issues the query of a batch as two
-    half-batch launches into one pair of tensors); the reference's five-function `_ext` surface never passes it."""
+def masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample):
     _check("query_xyz", query_xyz, torch.float32)
     _check("support_xyz", support_xyz, torch.float32)
     _check("query_mask", query_mask, torch.int32)
@@ -67,14 +65,8 @@ def masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, 
     _check_dev(query_xyz, support_xyz=support_xyz, query_mask=query_mask, support_mask=support_mask)
     B, M, _ = query_xyz.shape
     N = support_xyz.shape[1]
-    if out is None:
-        idx = torch.empty((B, M, int(nsample)), dtype=torch.int32, device=query_xyz.device)
-        idx_mask = torch.empty_like(idx)
-    else:
-        idx, idx_mask = out
-        for t in (idx, idx_mask):
-            if t.dtype != torch.int32 or tuple(t.shape) != (B, M, int(nsample)) or not t.is_contiguous() or t.device != query_xyz.device:
-                raise RuntimeError("masked_ordered_ball_query: out buffers must be contiguous int32 [B,M,nsample] on the inputs' device")
+    idx = torch.empty((B, M, int(nsample)), dtype=torch.int32, device=query_xyz.device)
+    idx_mask = torch.empty_like(idx)
     lib = _lib.lib()
     ws_bytes = lib.cl3d_workspace_bytes(1, B, N, M, int(nsample), 0)  # CL3D_OP_BALL_QUERY
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=query_xyz.device) if ws_bytes else None

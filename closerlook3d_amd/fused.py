@@ -240,11 +240,11 @@ def _wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad=False, split=False):
+def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad=False):
     """Ball query (and, when a backward will follow, the CSR inverse) on the index stream; the fused
     Functions wait_ready() the result right before their first kernel that reads it."""
     idx, idx_mask = _ball_query(query_xyz.contiguous(), support_xyz.contiguous(), query_mask.contiguous(),
-                                support_mask.contiguous(), radius, nsample, defer=True, split=split)
+                                support_mask.contiguous(), radius, nsample, defer=True)
     if need_grad:
         inverse_index(idx, support_xyz.shape[1], prefetch=True)
     return idx, idx_mask
@@ -418,16 +418,8 @@ class _PointwiseMLP(Function):
         dev = ght.device
         lib = _lib.lib()
         n = B * M * K
-        # the ball query may have gone out as two half-batch launches (pt_utils._run_ball_query): the statistics pass
-        # then runs per half, the first one while the second half is still being searched
-        halves = getattr(idx, '_cl3d_halves', None) if training else None
-        if halves is not None:
-            hb = halves[0]
-            nparts_h = lib.cl3d_pwmlp_partials(hb, M, Co)
-            nparts = 2 * nparts_h
-        else:
-            nparts = lib.cl3d_pwmlp_partials(B, M, Co)
-            wait_ready(idx)  # ball query ran on the index stream while the per-point GEMM ran here
+        nparts = lib.cl3d_pwmlp_partials(B, M, Co)
+        wait_ready(idx)  # ball query ran on the index stream while the per-point GEMM ran here
         out = torch.empty((B, Co, M), dtype=torch.float32, device=dev)  # channel-major, written by the kernels
         with _lib.on_device(dev):
             st = _stream(ght)
@@ -441,18 +433,9 @@ class _PointwiseMLP(Function):
                 kstar = torch.empty((B, M, Co), dtype=torch.uint8, device=dev)
                 partial = torch.empty((nparts, Co, 8), dtype=torch.float64, device=dev)
                 sums = torch.empty((Co, 6), dtype=torch.float64, device=dev)
-                if halves is not None:
-                    for lo, ev in ((0, halves[1]), (hb, halves[2])):
-                        torch.cuda.current_stream(dev).wait_event(ev)
-                        s_ = slice(lo, lo + hb)
-                        p_ = slice(0, nparts_h) if lo == 0 else slice(nparts_h, nparts)
-                        _lib.check(lib.cl3d_pwmlp_stats(_p(query_xyz[s_]), _p(support_xyz[s_]), _p(idx[s_]), _p(ght[s_]),
-                                                        _p(wr), _p(gamma), hb, N, M, K, Co, float(radius), _p(ystar[s_]),
-                                                        _p(kstar[s_]), _p(sy[s_]), _p(partial[p_]), nparts_h, st))
-                else:
-                    _lib.check(lib.cl3d_pwmlp_stats(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(gamma),
-                                                    B, N, M, K, Co, float(radius), _p(ystar), _p(kstar), _p(sy),
-                                                    _p(partial), nparts, st))
+                _lib.check(lib.cl3d_pwmlp_stats(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(gamma),
+                                                B, N, M, K, Co, float(radius), _p(ystar), _p(kstar), _p(sy),
+                                                _p(partial), nparts, st))
                 # batch statistics, scale/shift and the running-statistics update in one small launch
                 _lib.check(lib.cl3d_pwmlp_finalize_stats(_p(partial), nparts, Co, float(n), float(eps), float(momentum),
                                                          _p(gamma), _p(beta), _p(running_mean), _p(running_var),
@@ -463,7 +446,7 @@ class _PointwiseMLP(Function):
                     ctx.save_for_backward(ght, wr, gamma, vec, ystar, sy, kstar, sums, query_xyz, support_xyz)
                     ctx.radius = float(radius)
                     ctx.idx = idx
-                    ctx.meta = (B, N, M, K, Co, lib.cl3d_pwmlp_partials(B, M, Co))  # the backward passes run on the whole batch
+                    ctx.meta = (B, N, M, K, Co, nparts)
             else:
                 if need_grad:
                     raise NotImplementedError("fused PointWiseMLP backward needs training-mode BatchNorm")
@@ -644,7 +627,7 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     conv, bn = mlps.conv0[0], mlps.conv0[1]
     idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
-                    training and _wants_grad(features, conv.weight, bn.weight, bn.bias), split=training)
+                    training and _wants_grad(features, conv.weight, bn.weight, bn.bias))
     C = features.shape[1]
     Co = conv.weight.shape[0]
     W = conv.weight.view(Co, 3 + 2 * C)

@@ -122,11 +122,6 @@ def ball_query_cache():
 ASYNC_INDEX = {'1': True, '0': False}.get(os.environ.get('CL3D_ASYNC', ''), 'auto')
 
 
-# With the index streams on, a batch's ball query goes out as two half-batch launches (see _run_ball_query);
-# CL3D_SPLIT=0 keeps it one launch (A/B timing).
-SPLIT_BATCH = os.environ.get('CL3D_SPLIT', '1') != '0'
-
-
 def async_index():
     if ASYNC_INDEX == 'auto':
         return torch.cuda.is_current_stream_capturing()
@@ -154,7 +149,7 @@ def wait_ready(t):
 _CONSUMER_STREAM = None  # set by prefetch_geometry: the compute stream that will read what is produced ahead of it
 
 
-def _run_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, split=False):
+def _run_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample):
     if not (query_xyz.is_cuda and async_index()):
         return _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
     dev = query_xyz.device
@@ -164,29 +159,10 @@ def _run_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, ns
     consumer = _CONSUMER_STREAM if (main == side and _CONSUMER_STREAM is not None) else main
     if main != side:
         side.wait_stream(main)  # the coordinates were produced on the caller's stream
-    B = query_xyz.shape[0]
-    halves = None
     with torch.cuda.stream(side):
-        if split and SPLIT_BATCH and B >= 4 and B % 2 == 0:
-            # two half-batch launches into one pair of tensors, an event after each: a consumer that knows about
-            # the halves (the PointWiseMLP statistics pass) starts on the first half while the second is searched --
-            # the query is VALU / LDS bound, the gather pass latency bound, side by side they fill each other's gaps
-            h = B // 2
-            out = [torch.empty((B, query_xyz.shape[1], int(nsample)), dtype=torch.int32, device=dev) for _ in range(2)]
-            evs = []
-            for lo in (0, h):
-                _ext.masked_ordered_ball_query(query_xyz[lo:lo + h], support_xyz[lo:lo + h], query_mask[lo:lo + h],
-                                               support_mask[lo:lo + h], radius, nsample,
-                                               out=(out[0][lo:lo + h], out[1][lo:lo + h]))
-                e = torch.cuda.Event()
-                e.record(side)
-                evs.append(e)
-            ev = evs[1]
-            halves = (h, evs[0], evs[1])
-        else:
-            out = _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
-            ev = torch.cuda.Event()
-            ev.record(side)
+        out = _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+        ev = torch.cuda.Event()
+        ev.record(side)
     capturing = torch.cuda.is_current_stream_capturing()
     if not capturing:  # a capture's private pool never hands a block to another stream mid-graph
         for t in out:
@@ -195,21 +171,19 @@ def _run_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, ns
             t.record_stream(side)      # (possibly temporaries of .contiguous()) read on the index stream
     for t in out:
         t._cl3d_ready = ev
-        t._cl3d_halves = halves
     return out
 
 
-def _ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, defer=False, split=False):
-    """(idx, idx_mask); with defer=True the caller promises to wait_ready() them before use; split=True: the caller
-    can start on the first half of the batch while the second is searched (see _run_ball_query)."""
+def _ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, defer=False):
+    """(idx, idx_mask); with defer=True the caller promises to wait_ready() them before use."""
     if _BQ_CACHE is None:
-        out = _run_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, split)
+        out = _run_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
     else:
         tensors = (query_xyz, support_xyz, query_mask, support_mask)
         key = tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors) + (float(radius), int(nsample))
         hit = _BQ_CACHE.get(key)
         if hit is None:
-            out = _run_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, split)
+            out = _run_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
             hit = (out, tensors)
             _BQ_CACHE[key] = hit
         out = hit[0]
