@@ -958,12 +958,14 @@ static int pw_check(const PwArgs &a, const char *who) {
   return CL3D_OK;
 }
 
-// queries a lane group walks per tile (template parameter QPG of the query kernels).  CL3D_PW_QPG=1|2 pins it for
-// A/B timing; 2 unless the tile's slot records would not fit the LDS budget.
+// queries a lane group walks per tile (template parameter QPG of the query kernels).  Measured at the metric shape
+// (round 3): alone, 2 is the faster kernel (68.9 vs 71.1 us: half the barriers and staging round trips per slot);
+// inside the replayed step, next to the CSR build on the other queue, 1 is (0.3623-0.3635 vs 0.3791-0.3799 ms per
+// step on two boxes).  1 is the default; CL3D_PW_QPG=2 selects the other for A/B timing.
 static int pw_qpg_wanted() {
   static const int v = [] {
     const char *e = getenv("CL3D_PW_QPG");
-    return (e != nullptr && e[0] == '1') ? 1 : 2;
+    return (e != nullptr && e[0] == '2') ? 2 : 1;
   }();
   return v;
 }

@@ -5,7 +5,7 @@ queue, plus the idle time on the critical path (gaps where no kernel of the step
     python scripts/step_timeline.py out/**/tl_kernel_trace.csv [marker_kernel_substring]
 
 The step is delimited by consecutive launches of the marker kernel (default: the first kernel of the fused step,
-bq_prep_kernel); the last complete replay in the trace is printed.
+bq_tile_kernel or bq_prep_kernel); the last complete replay in the trace is printed.
 """
 import csv
 import glob
@@ -14,12 +14,14 @@ import sys
 
 def main():
     paths = [p for a in sys.argv[1:2] for p in glob.glob(a, recursive=True)]
-    marker = sys.argv[2] if len(sys.argv) > 2 else "bq_prep_kernel"
+    marker = sys.argv[2] if len(sys.argv) > 2 else None
     rows = []
     for p in paths:
         for r in csv.DictReader(open(p)):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?")))
     rows.sort()
+    if marker is None:  # the ball query opens the step: the LDS-resident kernel, or the cell grid's prep kernel
+        marker = "bq_tile_kernel" if any("bq_tile_kernel" in r[2] for r in rows) else "bq_prep_kernel"
     marks = [i for i, r in enumerate(rows) if marker in r[2]]
     if len(marks) < 3:
         print("marker kernel not found often enough")
