@@ -1,0 +1,159 @@
+"""The engine against the float64 anchors (tests/golden/make_fp64_anchor.py: the reference's own modules in double).
+
+BASELINE.md section 2 "features and gradients within 1e-5 (fp32)":
+  * outputs: 1e-5 against the reference's float32 fixtures (tests/test_operators_gpu.py) AND the anchor bound below;
+  * gradients: the engine may be at most twice as far from the float64 anchor as the reference's own float32 run
+    is at its worst element, + 1e-6 (tests/test_fp64_anchor.py: assert_as_close_as_reference);
+  * the deep network: arg-max routing (max over neighbours, max-pool) is discontinuous, so float32 noise moves whole
+    gradient entries -- in the reference's own float32 run too (its input gradient is up to 1.3e-1 away from the
+    anchor on the PointWiseMLP net).  The engine's count of entries away from the anchor is bounded by the
+    reference's own count, instead of a blanket allowance;
+  * every arg-max slot the PointWiseMLP gather pass picks is either the float64 arg-max or within 1e-5 of it
+    (a near-tie), and among duplicated neighbours it is the first.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import default_config, load_fixture, operator_fixtures, state_of
+from tests.test_fp64_anchor import assert_as_close_as_reference, load_anchor
+
+pytestmark = pytest.mark.gpu
+
+
+def _la(fx, impl):
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    C = fx["features"].shape[1]
+    mod = LocalAggregation(C, C, float(fx["radius"]), int(fx["nsample"]), default_config(fx["kind"], fx["over"], cl3d_impl=impl))
+    mod.load_state_dict(state_of(fx), strict=True)
+    return mod.cuda().train(bool(fx["training"]))
+
+
+@pytest.mark.parametrize("impl", ["grouped", "auto"])
+@pytest.mark.parametrize("name", operator_fixtures())
+def test_operator_is_as_close_to_the_anchor_as_the_reference(name, impl):
+    fx, a = load_fixture(name), load_anchor(name)
+    mod = _la(fx, impl)
+    xyz, mask = torch.from_numpy(fx["xyz"]).cuda(), torch.from_numpy(fx["mask"]).cuda()
+    feats = torch.from_numpy(fx["features"]).cuda().requires_grad_(True)
+    out = mod(xyz, xyz, mask, mask, feats)
+    (out * torch.from_numpy(fx["probe"]).cuda()).sum().backward()
+    tag = f"{name}[{impl}]"
+    report = [assert_as_close_as_reference(out.detach().cpu().numpy(), fx["out"], a["out64"], tag + " out"),
+              assert_as_close_as_reference(feats.grad.cpu().numpy(), fx["grad_features"], a["grad_features64"],
+                                           tag + " grad_features")]
+    for k, p in mod.named_parameters():
+        if "grad__" + k in fx and "grad64__" + k in a:
+            assert p.grad is not None, k
+            report.append(assert_as_close_as_reference(p.grad.cpu().numpy(), fx["grad__" + k], a["grad64__" + k],
+                                                       tag + " grad " + k))
+    print(tag, " ".join(f"{e:.1e}/{r:.1e}" for e, r in report), "(engine / reference worst distance to the anchor)")
+
+
+@pytest.mark.parametrize("impl", ["grouped", "auto"])
+def test_strided_bottleneck_is_as_close_to_the_anchor_as_the_reference(impl):
+    from closerlook3d_amd.backbones import Bottleneck
+    name = "operators_strided_bottleneck.npz"
+    fx, a = load_fixture(name), load_anchor(name)
+    cfg = default_config("pospool", {"pospool__position_embedding": "xyz", "pospool__reduction": "avg"}, cl3d_impl=impl)
+    btn = Bottleneck(24, 48, 2, 0.15, 16, cfg, downsample=True, sampleDl=0.12, npoint=64)
+    btn.load_state_dict(state_of(fx), strict=True)
+    btn = btn.cuda().train(True)
+    feats = torch.from_numpy(fx["features"]).cuda().requires_grad_(True)
+    _, _, out = btn(torch.from_numpy(fx["xyz"]).cuda(), torch.from_numpy(fx["mask"]).cuda(), feats)
+    (out * torch.from_numpy(fx["probe"]).cuda()).sum().backward()
+    assert_as_close_as_reference(out.detach().cpu().numpy(), fx["out"], a["out64"], "bottleneck out")
+    # the max-pool shortcut routes by arg-max: a route that flips moves an entry by its full size in either float32 run
+    assert_as_close_as_reference(feats.grad.cpu().numpy(), fx["grad_features"], a["grad_features64"],
+                                 "bottleneck grad_features", factor=3.0)
+
+
+@pytest.mark.parametrize("kind", ["pospool", "pointwisemlp"])
+def test_resnet_input_gradient_is_as_close_to_the_anchor_as_the_reference(kind):
+    """Ten layers of arg-max routing: count the input-gradient entries away from the float64 anchor.  The reference's
+    own float32 run has such entries (re-routed near-ties); the engine may have at most twice as many (+ 16), and may
+    be at most twice as far in norm."""
+    from closerlook3d_amd.backbones import ResNet, SceneSegHeadResNet
+    from closerlook3d_amd.pt_utils import ball_query_cache
+    name = f"operators_resnet_seg_{kind}.npz"
+    fx, a = load_fixture(name), load_anchor(name)
+    K = 16
+    net = ResNet(default_config(kind, fx["over"]), 3, 0.1, 0.05, [K] * 5, [128, 48, 16, 8], width=12, depth=2, bottleneck_ratio=2)
+    head = SceneSegHeadResNet(5, 12, 0.1, [K] * 5)
+    net.load_state_dict(state_of(fx, "backbone."), strict=True)
+    head.load_state_dict(state_of(fx, "head."), strict=True)
+    net, head = net.cuda().train(True), head.cuda().train(True)
+    feats = torch.from_numpy(fx["features"]).cuda().requires_grad_(True)
+    with ball_query_cache():
+        ep = net(torch.from_numpy(fx["xyz"]).cuda(), torch.from_numpy(fx["mask"]).cuda(), feats)
+        logits = head(ep)
+    (logits * torch.from_numpy(fx["probe"]).cuda()).sum().backward()
+    truth = a["grad_features64"]
+    tol = 2e-4 + 2e-4 * np.abs(truth)
+
+    def away(x):
+        d = np.abs(np.asarray(x, np.float64) - truth)
+        return int((d > tol).sum()), float(np.linalg.norm(d) / np.linalg.norm(truth))
+
+    n_eng, l2_eng = away(feats.grad.cpu().numpy())
+    n_ref, l2_ref = away(fx["grad_features"])
+    print(f"[{kind}] input-gradient entries away from the float64 anchor: engine {n_eng}, reference float32 {n_ref} of "
+          f"{truth.size}; relative L2 engine {l2_eng:.2e}, reference {l2_ref:.2e}")
+    assert n_eng <= 2 * n_ref + 16, (n_eng, n_ref)
+    assert l2_eng <= 2 * l2_ref + 1e-4, (l2_eng, l2_ref)
+    # forward: logits and res5 features against the anchor, as close as the reference
+    assert_as_close_as_reference(logits.detach().cpu().numpy(), fx["out"], a["out64"], f"{kind} logits", factor=3.0, slack=1e-5)
+    assert_as_close_as_reference(ep["res5_features"].detach().cpu().numpy(), fx["out2"], a["res5_features64"],
+                                 f"{kind} res5_features", factor=3.0, slack=1e-5)
+
+
+def test_pointwisemlp_argmax_slots_are_the_float64_argmax_or_a_near_tie():
+    """The statistics pass's arg-max slot k* per (query, channel) against a float64 evaluation of all K pre-activations
+    from the same float32 operands: wherever they differ, the two candidates are within 1e-5 (a near-tie that float32
+    rounding resolved the other way); among duplicated neighbours (wrap-around padding of short lists) the first wins."""
+    from closerlook3d_amd import _ext, _lib
+    from oracle import operators as oo
+    rng = np.random.default_rng(77)
+    B, N, K, Co = 2, 1024, 16, 16
+    xyz_np, mask_np = oo.make_cloud(rng, B, N, pad_frac=0.1)
+    radius = 0.09  # short lists: some neighbourhoods have fewer than K points and repeat their entries
+    xyz, mask = torch.from_numpy(xyz_np).cuda(), torch.from_numpy(mask_np).cuda()
+    idx, _ = _ext.masked_ordered_ball_query(xyz, xyz, mask, mask, radius, K)
+    ght = torch.from_numpy(rng.standard_normal((B, N, 2 * Co)).astype(np.float32)).cuda()
+    wr = torch.from_numpy(rng.standard_normal((Co, 3)).astype(np.float32)).cuda()
+    gamma = torch.from_numpy(np.where(np.arange(Co) % 3 == 0, -1.0, 1.0).astype(np.float32)).cuda()  # both extremes
+    lib = _lib.lib()
+    nparts = lib.cl3d_pwmlp_partials(B, N, Co)
+    ystar = torch.empty((B, N, Co), dtype=torch.float32, device="cuda")
+    sy = torch.empty_like(ystar)
+    kstar = torch.empty((B, N, Co), dtype=torch.uint8, device="cuda")
+    partial = torch.empty((nparts, Co, 8), dtype=torch.float64, device="cuda")
+    _lib.check(lib.cl3d_pwmlp_stats(xyz.data_ptr(), xyz.data_ptr(), idx.data_ptr(), ght.data_ptr(), wr.data_ptr(),
+                                    gamma.data_ptr(), B, N, N, K, Co, radius, ystar.data_ptr(), kstar.data_ptr(),
+                                    sy.data_ptr(), partial.data_ptr(), nparts, _lib.stream_ptr(xyz.device)))
+    torch.cuda.synchronize()
+    i = idx.cpu().numpy().astype(np.int64)
+    g64, w64 = ght.cpu().numpy().astype(np.float64), wr.cpu().numpy().astype(np.float64)
+    inv_r = np.float32(1.0) / np.float32(radius)
+    nbr = np.stack([xyz_np[b][i[b]] for b in range(B)])                      # [B,M,K,3]
+    rel = ((nbr - xyz_np[:, :, None, :]).astype(np.float32) * inv_r).astype(np.float64)  # the engine's float32 rel, exactly
+    G = np.stack([g64[b][i[b]][..., :Co] for b in range(B)])                 # [B,M,K,Co]
+    H = np.stack([g64[b][i[b][:, 0]][..., Co:] for b in range(B)])[:, :, None]  # centre = slot 0
+    y = rel @ w64.T + H + G
+    sgn = np.where(gamma.cpu().numpy() < 0, -1.0, 1.0)
+    ys = y * sgn                                                              # the pass maximises sgn * y
+    ks = kstar.cpu().numpy().astype(np.int64)
+    picked = np.take_along_axis(ys, ks[:, :, None, :], axis=2)[:, :, 0]
+    best = ys.max(axis=2)
+    gap = best - picked
+    assert (gap <= 1e-5 * (1.0 + np.abs(best))).all(), f"arg-max slot off by {gap.max():.3e}"
+    n_diff = int((ks != ys.argmax(axis=2)).sum())
+    # first occurrence among duplicated neighbours
+    for b, j in zip(*np.nonzero((np.diff(np.sort(i, axis=2), axis=2) == 0).any(axis=2))):
+        first = {}
+        for k in range(K):
+            first.setdefault(int(i[b, j, k]), k)
+        assert all(first[int(i[b, j, kk])] == kk for kk in ks[b, j]), (b, j)
+    ystar_np = ystar.cpu().numpy().astype(np.float64)
+    assert np.abs(ystar_np - np.take_along_axis(y, ks[:, :, None, :], axis=2)[:, :, 0]).max() < 1e-5
+    print(f"arg-max slots differing from the float64 arg-max (near-ties): {n_diff} of {ks.size}; largest gap {gap.max():.2e}")

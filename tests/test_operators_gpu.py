@@ -83,21 +83,12 @@ def test_resnet_and_seg_head_match_reference(kind):
     # ten BN layers deep: allow float noise to grow a little beyond the single-operator bound
     assert_close(ep["res5_features"].detach().cpu().numpy(), fx["out2"], 2e-4, "res5_features")
     assert_close(logits.detach().cpu().numpy(), fx["out"], 2e-4, "logits")
+    # The input gradient goes through ten layers of arg-max routing (max over neighbours, max-pool): float32 noise
+    # re-routes near-ties and moves whole entries -- in the reference's own float32 run as well.  It is therefore held
+    # against the float64 anchor, entry count against the reference's own count, in
+    # tests/test_fp64_anchor_gpu.py::test_resnet_input_gradient_is_as_close_to_the_anchor_as_the_reference.
     (logits * torch.from_numpy(fx["probe"]).cuda()).sum().backward()
-    got, want = feats.grad.cpu().numpy().astype(np.float64), fx["grad_features"].astype(np.float64)
-    # arg-max routing makes the input gradient discontinuous: a near-tie between two neighbours (max-pooling, the
-    # PointWiseMLP max) can resolve the other way after ten layers of float noise and moves a whole gradient entry.
-    # So: (i) almost every element agrees at the single-operator tolerance -- the fraction that does not (the flipped
-    # routes) is stated and bounded; (ii) the flips stay small in norm.
-    flipped = np.abs(got - want) > 2e-4 + 2e-4 * np.abs(want)
-    frac = float(flipped.mean())
-    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
-    print(f"[{kind}] input-gradient entries outside 2e-4: {int(flipped.sum())} of {flipped.size} ({frac:.2e}); relative L2 {rel:.2e}")
-    # measured on MI355X: pointwisemlp 193 of 3072 entries (6.3e-2; every one of its ten layers takes a max over
-    # neighbours), pospool below 2e-2
-    assert frac < (1.5e-1 if kind == "pointwisemlp" else 2e-2), \
-        f"{int(flipped.sum())} of {flipped.size} input-gradient entries differ (arg-max flips): {frac:.3e}"
-    assert rel < 2e-2, f"relative L2 error of d logits / d input features: {rel:.3e}"
+    assert torch.isfinite(feats.grad).all()
 
 
 @pytest.mark.parametrize("kind", ["pospool", "pointwisemlp"])

@@ -1,6 +1,7 @@
 """GPU, at the scene configurations' FULL sizes (these ran only in scripts/bench_backbone.py, which checks
 nothing): config 5 = one 81 920-point scene, PosPool sin_cos at width 288 (LA channels 144), K = 26; config 4 = 4 x
-10 000 points, AdaptiveWeight, K = 23.  The CPU oracle's O(M N) scan does not finish in seconds at 81 920 points, so
+10 000 points, AdaptiveWeight, K = 23; config 3 = one 40 960-point scene, PseudoGrid linear at width 144 (LA
+channels 72), K = 26 (the operator had never run at that size under a test).  The CPU oracle's O(M N) scan does not finish in seconds at 81 920 points, so
 these are size-independent properties: radius containment, sorted distances, mask prefix, no
 duplicate neighbours, exact agreement of the cell grid with the exhaustive kernel on a sample of queries,
 gather/scatter adjointness through the large-N code paths (`group_fwd_direct_kernel`, N > 16 384; the rocPRIM CSR
@@ -37,6 +38,8 @@ def _scene(B, N, extent, seed, pad_frac=0.05):
 CASES = {  # name: B, N, K, radius, extent, C, kind, overrides
     "config5_scene": (1, 81920, 26, 0.1, 4.0, 144, "pospool", {"pospool__position_embedding": "sin_cos", "pospool__reduction": "avg"}),
     "config4_parts": (4, 10000, 23, 0.05, 1.0, 72, "adaptive_weight", {"adaptive_weight__num_mlps": 1, "adaptive_weight__reduction": "avg"}),
+    # config 3: one 40 960-point S3DIS-sized scene, PseudoGrid linear at width 144 (LA channels 72), K = 26, radius 0.1
+    "config3_scene": (1, 40960, 26, 0.1, 3.0, 72, "pseudo_grid", {"pseudo_grid__KP_influence": "linear"}),
 }
 
 
