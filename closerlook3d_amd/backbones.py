@@ -132,6 +132,12 @@ class _UpsampleDecoder(nn.Module):
     """Nearest-neighbour up-sampling decode shared by the two segmentation heads
     (reference heads/segmentation_head.py:32-48,55-73 and :99-115,125-143)."""
 
+    def _engine_options(self, config):
+        """`config` (optional, beyond the reference's constructor arguments) carries the engine's two switches to the
+        decoder: cl3d_impl ('grouped' = the reference's own dataflow, for validation) and cl3d_precision."""
+        self.impl = getattr(config, 'cl3d_impl', 'auto') if config is not None else 'auto'
+        self.precision = getattr(config, 'cl3d_precision', 'f32') if config is not None else 'f32'
+
     def _make_decoder(self, width, base_radius, nsamples):
         for lvl in range(4):
             setattr(self, f"up{lvl}", MaskedUpsample(radius=(8 >> lvl) * base_radius, nsample=nsamples[3 - lvl],
@@ -150,11 +156,11 @@ class _UpsampleDecoder(nn.Module):
                     end_points[f'res{fine}_mask'], end_points[f'res{coarse}_mask'])
             skip = end_points[f'res{fine}_features']
             out = None
-            if feats.is_cuda and _BLOCK_ENGINE != 'modules' and _DECODE != 'cat' and getattr(self, 'impl', 'auto') != 'grouped':
+            if feats.is_cuda and _BLOCK_ENGINE != 'modules' and _DECODE != 'cat' and self.impl != 'grouped':
                 from . import fused  # the level without the concatenated tensor, see fused.decode_level
-                out = fused.decode_level(up, *geom, feats, skip, seq[0], seq[1], getattr(self, 'precision', 'f32'))
+                out = fused.decode_level(up, *geom, feats, skip, seq[0], seq[1], self.precision)
             if out is None:
-                out = run_conv_bn(seq, torch.cat([up(*geom, feats), skip], 1))
+                out = run_conv_bn(seq, torch.cat([up(*geom, feats), skip], 1), self.impl, self.precision)
             feats = out
         return feats
 
@@ -168,8 +174,9 @@ def _seg_classifier(width, nout):
 class SceneSegHeadResNet(_UpsampleDecoder):
     """logits (B, num_classes, N).  Reference: heads/segmentation_head.py:15-77."""
 
-    def __init__(self, num_classes, width, base_radius, nsamples):
+    def __init__(self, num_classes, width, base_radius, nsamples, config=None):
         super().__init__()
+        self._engine_options(config)
         self.num_classes, self.base_radius, self.nsamples = num_classes, base_radius, nsamples
         self._make_decoder(width, base_radius, nsamples)
         self.head = _seg_classifier(width, num_classes)
@@ -181,8 +188,9 @@ class SceneSegHeadResNet(_UpsampleDecoder):
 class MultiPartSegHeadResNet(_UpsampleDecoder):
     """One part-logit tensor per shape category: [(B, num_parts[i], N)].  Reference: :80-149."""
 
-    def __init__(self, num_classes, width, base_radius, nsamples, num_parts):
+    def __init__(self, num_classes, width, base_radius, nsamples, num_parts, config=None):
         super().__init__()
+        self._engine_options(config)
         self.num_classes, self.base_radius, self.nsamples, self.num_parts = num_classes, base_radius, nsamples, num_parts
         self._make_decoder(width, base_radius, nsamples)
         self.multi_shape_heads = nn.ModuleList(_seg_classifier(width, num_parts[i]) for i in range(num_classes))

@@ -133,7 +133,7 @@ class MultiPartSegmentationModel(_Model):
         if config.head != 'resnet_part_seg':
             raise NotImplementedError(f"Head {config.head} not implemented in Multi-Part Segmentation Model")
         self.segmentation_head = MultiPartSegHeadResNet(config.num_classes, config.width, config.radius,
-                                                        config.nsamples, config.num_parts)
+                                                        config.nsamples, config.num_parts, config=config)
 
     def forward(self, xyz, mask, features):
         return self.segmentation_head(self.backbone(xyz, mask, features))
@@ -147,7 +147,8 @@ class SceneSegmentationModel(_Model):
         self.backbone = self._backbone(config)
         if config.head != 'resnet_scene_seg':
             raise NotImplementedError(f"Head {config.head} not implemented in Scene Segmentation Model")
-        self.segmentation_head = SceneSegHeadResNet(config.num_classes, config.width, config.radius, config.nsamples)
+        self.segmentation_head = SceneSegHeadResNet(config.num_classes, config.width, config.radius, config.nsamples,
+                                                    config=config)
 
     def forward(self, xyz, mask, features):
         return self.segmentation_head(self.backbone(xyz, mask, features))
@@ -188,6 +189,10 @@ _SAFE_GLOBALS = {
     ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'), ('numpy', 'dtype'),
     ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'), ('numpy', 'ndarray'),
     ('builtins', 'set'), ('builtins', 'frozenset'), ('builtins', 'slice'), ('builtins', 'complex'),
+    # scheduler.state_dict() is part of every checkpoint the reference writes (train_modelnet_dist.py:157-164): MultiStepLR
+    # -- its default 'step' schedule, also nested under GradualWarmupScheduler's 'after_scheduler'
+    # (utils/lr_scheduler.py:41-50) -- keeps its milestones in a collections.Counter
+    ('collections', 'Counter'), ('collections', 'defaultdict'),
 }
 
 

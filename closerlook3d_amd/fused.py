@@ -707,6 +707,10 @@ def decode_level(up, fine_xyz, coarse_xyz, fine_mask, coarse_mask, coarse_feats,
         return None
     if coarse_feats.dtype != torch.float32 or coarse_feats.dim() != 3:
         return None
+    if (skip_feats.shape[0] != coarse_feats.shape[0] or skip_feats.shape[2] != fine_xyz.shape[1]
+            or coarse_feats.shape[2] != coarse_xyz.shape[1] or skip_feats.device != coarse_feats.device
+            or conv.weight.shape[1] != coarse_feats.shape[1] + skip_feats.shape[1]):
+        return None  # shapes the raw-pointer kernels would read out of bounds on: the modules raise the proper error
     training = bn.training
     if not training and _wants_grad(coarse_feats, skip_feats, conv.weight, bn.weight, bn.bias):
         return None  # backward through frozen statistics: the nn modules do it
@@ -794,9 +798,21 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, res_conv=None, res_bn=Non
     (backbones/resnet.py:32-39,58-66), on the engine: MFMA 1x1 convolutions, one statistics pass per BatchNorm and one
     fused apply / add / ReLU pass.  Inference (no gradient): BatchNorm folded into the convolution's epilogue, one
     launch per convolution.  Returns None when the modules are outside what the kernels cover."""
-    if conv.bias is not None or conv.kernel_size != (1,) or not _bn_unit_ok(x, bn):
+    if conv.bias is not None or conv.kernel_size != (1,) or not _bn_unit_ok(x, bn) or x.shape[1] != conv.weight.shape[1]:
         return None
-    if res_conv is not None and (res_conv.bias is not None or not _bn_unit_ok(x, res_bn)):
+    if residual is not None:
+        # the kernels take the residual as a raw pointer: its dtype, device, rank and shape are checked here, against
+        # the tensor it is added to ([B,Co,N]) or the shortcut convolution's input ([B,Cr,N]) (ADVICE r2)
+        if res_conv is not None:
+            if (res_conv.bias is not None or res_conv.kernel_size != (1,) or not _bn_unit_ok(residual, res_bn)
+                    or residual.shape[1] != res_conv.weight.shape[1] or res_conv.weight.shape[0] != conv.weight.shape[0]):
+                return None
+        elif not (residual.is_cuda and residual.dtype == torch.float32 and residual.dim() == 3
+                  and residual.shape[1] == conv.weight.shape[0]):
+            return None
+        if residual.device != x.device or residual.shape[0] != x.shape[0] or residual.shape[2] != x.shape[2]:
+            return None
+    elif res_conv is not None:
         return None
     prec = PRECISIONS[precision]
     Co, C = conv.weight.shape[0], conv.weight.shape[1]

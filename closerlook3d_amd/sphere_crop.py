@@ -70,7 +70,7 @@ class SceneCropper:
             out["labels"] = self.labels[input_inds].to(torch.int64)
         return out
 
-    def project(self, points, chunk=4096):
+    def project(self, points, chunk=None, budget_bytes=1 << 30):
         """Index of the nearest sub-sampled point for every ORIGINAL scene point (`datasets/S3DIS.py:262-270`:
         `search_tree.query(points, return_distance=False)`, the projection that carries votes from the sub-sampled
         cloud back to the full one) as int32, computed in float64 like the tree; among exactly equidistant candidates
@@ -78,6 +78,10 @@ class SceneCropper:
         q = torch.as_tensor(points).to(self.device, torch.float64)
         out = torch.empty(q.shape[0], dtype=torch.int32, device=self.device)
         p = self.points64
+        if chunk is None:
+            # six [chunk, P] float64 temporaries are alive at once: bound them by `budget_bytes` (a sub-sampled room of
+            # 800 000 points at the old fixed chunk of 4096 would have asked for 26 GB each -- ADVICE r2)
+            chunk = max(1, min(4096, budget_bytes // max(1, p.shape[0] * 8 * 6)))
         for lo in range(0, q.shape[0], chunk):
             c = q[lo:lo + chunk]
             dx = c[:, 0][:, None] - p[:, 0][None, :]

@@ -81,7 +81,7 @@ def main():
     head = None
     if args.head:  # the scene-segmentation decoder + classifier of the reference's S3DIS / PartNet models (13 classes)
         from closerlook3d_amd.backbones import SceneSegHeadResNet
-        head = SceneSegHeadResNet(13, width, radius, nsamples).to(dev).train(True)
+        head = SceneSegHeadResNet(13, width, radius, nsamples, config=cfg).to(dev).train(True)
     params = [p for p in net.parameters() if p.requires_grad] + ([p for p in head.parameters()] if head is not None else [])
     opt = torch.optim.SGD(params, lr=1e-3)
     xyz, mask, _ = synth_batch(B, N, 3, 7 + rank)  # every rank its own clouds / scene

@@ -119,3 +119,32 @@ def test_untrusted_checkpoint_cannot_run_code(tmp_path):
     with pytest.raises(Exception, match="trusted=True"):
         compat.load_reference_checkpoint(model, path)
     assert not (tmp_path / "pwned").exists()
+
+
+def test_checkpoint_with_real_optimizer_and_step_scheduler_state_loads(tmp_path):
+    """the reference saves optimizer.state_dict() and scheduler.state_dict() into every checkpoint
+    (function/train_modelnet_dist.py:157-164).  Its default schedule is MultiStepLR behind a GradualWarmupScheduler
+    whose state nests the inner scheduler's under 'after_scheduler' (utils/lr_scheduler.py:41-50); MultiStepLR keeps its
+    milestones in a collections.Counter.  Such a file must load through the restricted unpickler."""
+    cfg = _cfg_from_golden("modelnet/pospool_xyz_avg.yaml")
+    cfg.width, cfg.nsamples, cfg.npoints = 12, [8] * 5, [64, 32, 16, 8]
+    torch.manual_seed(0)
+    src = compat.build_model(cfg)
+    opt = torch.optim.SGD(src.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-4)
+    for p in src.parameters():  # one step so that the momentum buffers exist
+        p.grad = torch.zeros_like(p)
+    opt.step()
+    inner = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[30, 60, 60], gamma=0.1)
+    # the warm-up wrapper's state_dict, shaped as the reference builds it: its own fields + the inner scheduler's state
+    sched_state = {"multiplier": 100.0, "warmup_epoch": 5, "base_lrs": [0.01], "last_epoch": 3, "_step_count": 4,
+                   "after_scheduler": inner.state_dict()}
+    assert type(sched_state["after_scheduler"]["milestones"]).__name__ == "Counter"
+    path = str(tmp_path / "current.pth")
+    torch.save({"config": dict(cfg), "model": {"module." + k: v for k, v in src.state_dict().items()},
+                "optimizer": opt.state_dict(), "scheduler": sched_state, "epoch": 4, "best_acc": 0.25}, path)
+    dst = compat.build_model(cfg)
+    meta = compat.load_reference_checkpoint(dst, path)  # trusted=False: the restricted unpickler
+    assert meta["scheduler"]["after_scheduler"]["milestones"] == inner.state_dict()["milestones"]
+    assert meta["epoch"] == 4 and len(meta["optimizer"]["state"]) == len(list(src.parameters()))
+    for (ka, a), (kb, b) in zip(src.state_dict().items(), dst.state_dict().items()):
+        assert ka == kb and torch.equal(a, b)
