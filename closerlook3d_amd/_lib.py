@@ -35,6 +35,8 @@ SIGNATURES = {
     "cl3d_maxpool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cl3d_maxpool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
     "cl3d_dataset_grid_subsampling": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
+    "cl3d_sphere_crop_query": [_P, _I, _P, ctypes.c_double, _P, _P, _P, _Z, _P],
+    "cl3d_sphere_crop_assemble": [_P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P],
     "cl3d_transpose": [_P, _I, _I, _I, _P, _P],
     "cl3d_bn_partials": [_I, _I, _I],
     "cl3d_bn_relu_stats": [_P, _I, _I, _I, _P, _I, ctypes.c_double, _F, _F] + [_P] * 10,
@@ -51,6 +53,11 @@ SIGNATURES = {
     "cl3d_conv1x1_bn_act_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_conv1x1_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_conv1x1_bwd_weight": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
+    "cl3d_pwmlp_point_gemm_fwd_pro": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P],
+    "cl3d_pwmlp_point_gemm_bwd_weight_pro": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
+    "cl3d_conv1x1_rows_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
+    "cl3d_conv1x1_rows_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
+    "cl3d_conv1x1_rows_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_pwmlp_split_weight": [_P, _I, _I, _P, _P, _P],
     "cl3d_pwmlp_merge_weight_grad": [_P, _P, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_stats": [_P] * 6 + [_I] * 5 + [_F, _P, _P, _P, _P, _I, _P],

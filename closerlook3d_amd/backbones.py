@@ -25,6 +25,13 @@ import os
 
 _BLOCK_ENGINE = os.environ.get('CL3D_BLOCK', 'engine')  # 'modules': nn.Conv1d / BatchNorm1d as in round 1 (A/B only)
 _DECODE = os.environ.get('CL3D_DECODE', 'split')  # 'cat': the decoders concatenate as the reference does (A/B only)
+# CL3D_FUSE_BOTTLENECK=0: a PointWiseMLP bottleneck layer by layer, with the activated tensors between its layers
+# materialised as in round 2 (A/B only); default: fused.pointwise_bottleneck
+_FUSE_BOTTLENECK = os.environ.get('CL3D_FUSE_BOTTLENECK', '1') != '0'
+# ... for layers with at least this many values per channel (B * N): below it the BatchNorm tails are single-launch
+# kernels that keep a channel in L2 (csrc/bn_relu.hip, bn2_*_small), and there is no round trip to HBM to save
+_FUSE_MIN_VALUES = int(os.environ.get('CL3D_FUSE_MIN_VALUES', '16384'))
+
 
 
 def run_conv_bn(seq, x, impl='auto', precision='f32', residual=None, shortcut=None):
@@ -77,10 +84,21 @@ class Bottleneck(nn.Module):
             query_xyz, query_mask, identity = xyz, mask, features
         # the whole bottleneck on the engine -- conv1+BN+ReLU, the operator, then conv2 + BN +
         # shortcut (+ its conv and BN) + add + ReLU as MFMA convolutions and fused BatchNorm passes
+        shortcut = self.shortcut if self.in_channels != self.out_channels else None
+        la = getattr(self.local_aggregation, 'local_aggregation_operator', None)
+        if (_FUSE_BOTTLENECK and self.impl != 'grouped' and _BLOCK_ENGINE != 'modules' and features.is_cuda and self.training
+                and type(la).__name__ == 'PointWiseMLP' and la.impl != 'grouped'
+                and features.shape[0] * features.shape[2] >= _FUSE_MIN_VALUES):
+            # ... and, for a PointWiseMLP bottleneck in training, without the [B,C,N] tensors between its layers:
+            # conv1's BatchNorm + ReLU ride in the operator's contraction, the operator's in conv2's (fused.pointwise_bottleneck)
+            from . import fused
+            out = fused.pointwise_bottleneck(self.conv1, la, self.conv2, shortcut, query_xyz, xyz, query_mask, mask,
+                                             features, identity, self.precision)
+            if out is not None:
+                return query_xyz, query_mask, out
         out = run_conv_bn(self.conv1, features, self.impl, self.precision)
         out = self.local_aggregation(query_xyz, xyz, query_mask, mask, out)
-        out = run_conv_bn(self.conv2, out, self.impl, self.precision, residual=identity,
-                          shortcut=self.shortcut if self.in_channels != self.out_channels else None)
+        out = run_conv_bn(self.conv2, out, self.impl, self.precision, residual=identity, shortcut=shortcut)
         return query_xyz, query_mask, out
 
 

@@ -29,6 +29,8 @@ extern "C" size_t cl3d_workspace_bytes(int op, int B, int N, int M, int K, int C
       return cl3d::inverse_index_workspace(B, N, M * K);
     case CL3D_OP_DATASET_GRID:  // keys and order (x2), heads, ranks, rocPRIM temporary storage; one cloud of N points
       return cl3d::dataset_grid_workspace(N);
+    case CL3D_OP_SPHERE_CROP:  // sort keys and order (x2), rocPRIM temporary storage; N scene points or sample slots
+      return cl3d::sphere_crop_workspace(N);
     case CL3D_OP_POINT_GEMM:  // PointWiseMLP per-point contraction: M carries Co; K-slice partials of any of its three products
       return cl3d::gemm_family_workspace(B, N, 2 * M, C, true);
     case CL3D_OP_CONV1X1:  // 1x1 Conv1d C -> M over B clouds of N points: K-slice partials of any of its three products

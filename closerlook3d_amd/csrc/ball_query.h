@@ -28,6 +28,8 @@ size_t grid_subsampling_workspace(int B, int N);
 // csr.hip
 size_t inverse_index_workspace(int B, int N, int MK);
 size_t dataset_grid_workspace(int n);
+// sphere_crop.hip: sort keys / values (x2) and rocPRIM temporary storage for P scene points (or num_points slots)
+size_t sphere_crop_workspace(int P);
 // mfma_gemm.hip: scratch (K-slice partial tiles) of the three products of a per-point contraction rows_in -> rows_out
 // over nb clouds of n points; merge: the PointWiseMLP form, whose weight gradient always goes through the reduce
 size_t gemm_family_workspace(int nb, int n, int rows_out, int rows_in, bool merge);

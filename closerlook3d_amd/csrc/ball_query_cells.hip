@@ -612,14 +612,21 @@ __global__ __launch_bounds__(256) void bq_query_kernel(const float *__restrict__
         __builtin_amdgcn_wave_barrier();
       }
       const int qmk = qm[j];
-      for (int i = lane; i < K; i += CL3D_WAVE) {
-        int v = 0, mk = 0;
-        if (c > 0) {
-          v = so[i < c ? i : i % c];
-          mk = (i < c && qmk != 0) ? 1 : 0;
+      if (c >= K) {  // uniform, the common case: a full list, no wrap-around padding (and no integer modulo)
+        for (int i = lane; i < K; i += CL3D_WAVE) {
+          oi[i] = so[i];
+          om[i] = qmk != 0 ? 1 : 0;
         }
-        oi[i] = v;
-        om[i] = mk;
+      } else {
+        for (int i = lane; i < K; i += CL3D_WAVE) {
+          int v = 0, mk = 0;
+          if (c > 0) {
+            v = so[i < c ? i : i % c];
+            mk = (i < c && qmk != 0) ? 1 : 0;
+          }
+          oi[i] = v;
+          om[i] = mk;
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");

@@ -598,14 +598,21 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
           tl_wave_sync();
         }
         const int qmk = qm[j];
-        for (int i = lane; i < K; i += CL3D_WAVE) {
-          int v = 0, mkv = 0;
-          if (c > 0) {
-            v = so[i < c ? i : i % c];
-            mkv = (i < c && qmk != 0) ? 1 : 0;
+        if (c >= K) {  // uniform, the common case: a full list, no wrap-around padding (and no integer modulo)
+          for (int i = lane; i < K; i += CL3D_WAVE) {
+            oi[i] = so[i];
+            om[i] = qmk != 0 ? 1 : 0;
           }
-          oi[i] = v;
-          om[i] = mkv;
+        } else {
+          for (int i = lane; i < K; i += CL3D_WAVE) {
+            int v = 0, mkv = 0;
+            if (c > 0) {
+              v = so[i < c ? i : i % c];
+              mkv = (i < c && qmk != 0) ? 1 : 0;
+            }
+            oi[i] = v;
+            om[i] = mkv;
+          }
         }
       }
       tl_wave_sync();

@@ -53,6 +53,12 @@ struct GemmOperand {
   int fold;              // 0: none; 1: r = cloud * fold_n + point; 2: k = cloud * fold_n + point  (channel-major tensors)
   int fold_n;            // points per cloud
   long long sb;          // cloud stride of a folded axis
+  // prologue (nullable): element (r, k) enters the product as max(scale[c] * x + shift[c], 0) with c = k (pro_axis 0)
+  // or c = r (pro_axis 1) -- the BatchNorm + ReLU that precedes this contraction in a bottleneck, applied while the
+  // tile is staged instead of in a pass of its own (backbones/resnet.py:32-34,47-56: conv1's BatchNorm + ReLU in
+  // front of the operator, the operator's in front of conv2)
+  const float *pro_scale, *pro_shift;
+  int pro_axis;
 };
 
 // where a result element (i, j) goes, and what happens to it on the way (inference epilogue)
@@ -106,6 +112,31 @@ __device__ __forceinline__ unsigned gemm_off(const GemmOperand &s, int r, int k)
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float &comp(float4 &v, int e) { return reinterpret_cast<float *>(&v)[e]; }
 
+__device__ __forceinline__ float pro1(const GemmOperand &s, float x, int r, int k) {
+  const int c = s.pro_axis ? r : k;
+  const float z = __builtin_fmaf(x, s.pro_scale[c], s.pro_shift[c]);
+  return z > 0.f ? z : 0.f;
+}
+// four elements starting at (r, k), running along r (ALONG_R) or along k; the operand's prologue, if any, applied
+template <bool ALONG_R>
+__device__ __forceinline__ float4 pro4(const GemmOperand &s, float4 v, int r, int k) {
+  if (s.pro_scale == nullptr) return v;  // wave-uniform
+  if ((s.pro_axis != 0) == ALONG_R) {    // the channel index runs along the vector: four channels
+    const int c0 = ALONG_R ? r : k;
+    const float4 sc = ld4(s.pro_scale + c0), sh = ld4(s.pro_shift + c0);  // c0 % 4 == 0 and 16-byte aligned arrays (host check)
+    v.x = __builtin_fmaf(v.x, sc.x, sh.x); v.y = __builtin_fmaf(v.y, sc.y, sh.y);
+    v.z = __builtin_fmaf(v.z, sc.z, sh.z); v.w = __builtin_fmaf(v.w, sc.w, sh.w);
+  } else {                               // one channel for the whole vector
+    const int c = ALONG_R ? k : r;
+    const float sc = s.pro_scale[c], sh = s.pro_shift[c];
+    v.x = __builtin_fmaf(v.x, sc, sh); v.y = __builtin_fmaf(v.y, sc, sh);
+    v.z = __builtin_fmaf(v.z, sc, sh); v.w = __builtin_fmaf(v.w, sc, sh);
+  }
+  v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+  v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+  return v;
+}
+
 // ---- staging, f32: LDS tile T[KC][TR + 4] floats (row stride TR+4 for an r-contiguous source, TR+1 for a
 // k-contiguous one: odd, so the transposing scalar stores are conflict-free) ------------------------------------
 template <int TR, int KC>
@@ -124,13 +155,13 @@ struct StageF32 {
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int idx = q * 256 + t, r = r0 + 4 * (idx % (TR / 4)), k = k0 + idx / (TR / 4);
-        v[q] = (r < s.R && k < K) ? ld4(s.p + gemm_off(s, r, k)) : zero;
+        v[q] = (r < s.R && k < K) ? pro4<true>(s, ld4(s.p + gemm_off(s, r, k)), r, k) : zero;
       }
     } else if (MODE == STAGE_VEC_KC) {
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int idx = q * 256 + t, k = k0 + 4 * (idx % (KC / 4)), r = r0 + idx / (KC / 4);
-        v[q] = (r < s.R && k < K) ? ld4(s.p + gemm_off(s, r, k)) : zero;
+        v[q] = (r < s.R && k < K) ? pro4<false>(s, ld4(s.p + gemm_off(s, r, k)), r, k) : zero;
       }
     } else {
 #pragma unroll
@@ -139,7 +170,9 @@ struct StageF32 {
         for (int e = 0; e < 4; ++e) {
           const int idx = (q * 4 + e) * 256 + t;
           const int r = r0 + (s.rc ? idx % TR : idx / KC), k = k0 + (s.rc ? idx / TR : idx % KC);
-          comp(v[q], e) = (r < s.R && k < K) ? s.p[gemm_off(s, r, k)] : 0.f;
+          float x = (r < s.R && k < K) ? s.p[gemm_off(s, r, k)] : 0.f;
+          if (s.pro_scale != nullptr && r < s.R && k < K) x = pro1(s, x, r, k);
+          comp(v[q], e) = x;
         }
     }
   }
@@ -192,15 +225,15 @@ struct StageBF16 {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = k0 + 8 * g + e;
-        v[e] = (g < G && r < s.R && k < K) ? ld4(s.p + gemm_off(s, r, k)) : zero;
+        v[e] = (g < G && r < s.R && k < K) ? pro4<true>(s, ld4(s.p + gemm_off(s, r, k)), r, k) : zero;
       }
     } else if (MODE == STAGE_VEC_KC) {  // (row, k group) items: 32 contiguous bytes, 8 lanes cover 256 bytes of a row
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int idx = q * 256 + t, g = idx % G, r = r0 + idx / G, k = k0 + 8 * g;
         const bool ok = idx < TR * G && r < s.R;
-        v[2 * q] = (ok && k < K) ? ld4(s.p + gemm_off(s, r, k)) : zero;
-        v[2 * q + 1] = (ok && k + 4 < K) ? ld4(s.p + gemm_off(s, r, k + 4)) : zero;
+        v[2 * q] = (ok && k < K) ? pro4<false>(s, ld4(s.p + gemm_off(s, r, k)), r, k) : zero;
+        v[2 * q + 1] = (ok && k + 4 < K) ? pro4<false>(s, ld4(s.p + gemm_off(s, r, k + 4)), r, k + 4) : zero;
       }
     } else {
 #pragma unroll
@@ -210,7 +243,10 @@ struct StageBF16 {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int k = k0 + 8 * g + e;
-          comp(v[2 * q + e / 4], e % 4) = (idx < TR * G && r < s.R && k < K) ? s.p[gemm_off(s, r, k)] : 0.f;
+          const bool in = idx < TR * G && r < s.R && k < K;
+          float x = in ? s.p[gemm_off(s, r, k)] : 0.f;
+          if (s.pro_scale != nullptr && in) x = pro1(s, x, r, k);
+          comp(v[2 * q + e / 4], e % 4) = x;
         }
       }
     }
@@ -595,6 +631,15 @@ static GemmOperand channel_major(const float *p, int nb, int rows, int n, bool p
 
 static int stage_mode(const GemmOperand &s) { return !s.vec ? STAGE_SCALAR : (s.rc ? STAGE_VEC_RC : STAGE_VEC_KC); }
 
+// BatchNorm + ReLU of the producing layer applied while this operand is staged: channel = k (axis 0) or r (axis 1).
+// The vector staging paths read four consecutive channels' coefficients at once where the channel axis is the
+// contiguous one: without 16-byte aligned coefficient arrays the operand falls back to element-wise staging.
+static void set_prologue(GemmOperand &s, const float *scale, const float *shift, int axis) {
+  s.pro_scale = scale; s.pro_shift = shift; s.pro_axis = axis;
+  const bool channel_contiguous = (axis == 1) == (s.rc != 0);
+  if (scale != nullptr && channel_contiguous && !(aligned16(scale) && aligned16(shift))) s.vec = 0;
+}
+
 template <int PREC, int AM, int BM>
 static void launch_shape(const GemmArgs &a, int wi, int wj, int blocks, hipStream_t st) {
   if (wi == 2 && wj == 2) hipLaunchKernelGGL((mfma_gemm_kernel<PREC, 2, 2, AM, BM>), dim3(blocks), dim3(256), 0, st, a);
@@ -771,21 +816,39 @@ using namespace cl3d;
   if ((long long)B * N * (long long)(2 * Co > C ? 2 * Co : C) > 0x7fffffffLL)                         \
     return fail(CL3D_E_UNSUPPORTED, who ": tensor too large (32-bit element offsets)");
 
+static int point_gemm_fwd(const float *features, const float *pro_scale, const float *pro_shift, const float *W, int B,
+                          int C, int N, int Co, int precision, float *ght, float *wr, float *wcat, void *ws,
+                          size_t ws_bytes, hipStream_t st, const char *who) {
+  hipLaunchKernelGGL(pwmlp_weights_kernel, dim3(round_up_grid(Co * (3 + 2 * C))), dim3(256), 0, st, W, Co, C, wr, wcat);
+  const int rc = check_launch(who);
+  if (rc != CL3D_OK || B == 0) return rc;
+  GemmArgs a{};  // D[i = (cloud, point)][j = o] = sum_c F[c][point] wcat[o][c]  ->  ght [B*N, 2Co]
+  a.A = channel_major(features, B, C, N, true);
+  set_prologue(a.A, pro_scale, pro_shift, 0);
+  a.B = plain(wcat, C, 1, 2 * Co, C);
+  a.out.D = ght; a.out.si = 2 * Co; a.out.sj = 1;
+  a.K = C;
+  return run_gemm<0>(a, precision, kMaxSplitFwd, ws, ws_bytes, nullptr, 0, 0, st, who);
+}
+
 extern "C" int cl3d_pwmlp_point_gemm_fwd(const float *features, const float *W, int B, int C, int N, int Co,
                                          int precision, float *ght, float *wr, float *wcat, void *ws, size_t ws_bytes,
                                          cl3d_stream_t stream) {
   GEMM_COMMON_CHECKS("pwmlp_point_gemm_fwd");
   CL3D_REQUIRE(W && wcat && (B == 0 || (features && ght)), "pwmlp_point_gemm_fwd: null pointer");
-  hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(pwmlp_weights_kernel, dim3(round_up_grid(Co * (3 + 2 * C))), dim3(256), 0, st, W, Co, C, wr, wcat);
-  const int rc = check_launch("cl3d_pwmlp_point_gemm_fwd(weights)");
-  if (rc != CL3D_OK || B == 0) return rc;
-  GemmArgs a{};  // D[i = (cloud, point)][j = o] = sum_c F[c][point] wcat[o][c]  ->  ght [B*N, 2Co]
-  a.A = channel_major(features, B, C, N, true);
-  a.B = plain(wcat, C, 1, 2 * Co, C);
-  a.out.D = ght; a.out.si = 2 * Co; a.out.sj = 1;
-  a.K = C;
-  return run_gemm<0>(a, precision, kMaxSplitFwd, ws, ws_bytes, nullptr, 0, 0, st, "cl3d_pwmlp_point_gemm_fwd");
+  return point_gemm_fwd(features, nullptr, nullptr, W, B, C, N, Co, precision, ght, wr, wcat, ws, ws_bytes,
+                        (hipStream_t)stream, "cl3d_pwmlp_point_gemm_fwd");
+}
+
+// the same product on features = max(scale[c] * x + shift[c], 0): the BatchNorm + ReLU of the bottleneck's conv1
+// (backbones/resnet.py:32-34) applied while the tile is staged, so the activated tensor is never written
+extern "C" int cl3d_pwmlp_point_gemm_fwd_pro(const float *x, const float *scale, const float *shift, const float *W,
+                                             int B, int C, int N, int Co, int precision, float *ght, float *wr,
+                                             float *wcat, void *ws, size_t ws_bytes, cl3d_stream_t stream) {
+  GEMM_COMMON_CHECKS("pwmlp_point_gemm_fwd_pro");
+  CL3D_REQUIRE(W && wcat && scale && shift && (B == 0 || (x && ght)), "pwmlp_point_gemm_fwd_pro: null pointer");
+  return point_gemm_fwd(x, scale, shift, W, B, C, N, Co, precision, ght, wr, wcat, ws, ws_bytes, (hipStream_t)stream,
+                        "cl3d_pwmlp_point_gemm_fwd_pro");
 }
 
 extern "C" int cl3d_pwmlp_point_gemm_bwd_data(const float *dght, const float *wcat, int B, int C, int N, int Co,
@@ -803,18 +866,35 @@ extern "C" int cl3d_pwmlp_point_gemm_bwd_data(const float *dght, const float *wc
                      "cl3d_pwmlp_point_gemm_bwd_data");
 }
 
+static int point_gemm_bwd_weight(const float *features, const float *pro_scale, const float *pro_shift,
+                                 const float *dght, const float *dwr, int B, int C, int N, int Co, int precision,
+                                 float *dW, void *ws, size_t ws_bytes, hipStream_t st, const char *who) {
+  GemmArgs a{};  // D[i = o][j = c] = sum_(cloud, point) dght[point][o] F[c][point]  ->  d wcat [2Co, C] per slice
+  a.A = plain(dght, 1, 2 * Co, 2 * Co, B * N);
+  a.B = channel_major(features, B, C, N, false);
+  set_prologue(a.B, pro_scale, pro_shift, 1);
+  a.K = B * N;
+  a.out.D = dW;
+  return run_gemm<1>(a, precision, kMaxSplitWgrad, ws, ws_bytes, dwr, Co, C, st, who);
+}
+
 extern "C" int cl3d_pwmlp_point_gemm_bwd_weight(const float *features, const float *dght, const float *dwr, int B,
                                                 int C, int N, int Co, int precision, float *dW, void *ws,
                                                 size_t ws_bytes, cl3d_stream_t stream) {
   GEMM_COMMON_CHECKS("pwmlp_point_gemm_bwd_weight");
   CL3D_REQUIRE(B >= 1 && features && dght && dW, "pwmlp_point_gemm_bwd_weight: null pointer");
-  GemmArgs a{};  // D[i = o][j = c] = sum_(cloud, point) dght[point][o] F[c][point]  ->  d wcat [2Co, C] per slice
-  a.A = plain(dght, 1, 2 * Co, 2 * Co, B * N);
-  a.B = channel_major(features, B, C, N, false);
-  a.K = B * N;
-  a.out.D = dW;
-  return run_gemm<1>(a, precision, kMaxSplitWgrad, ws, ws_bytes, dwr, Co, C, (hipStream_t)stream,
-                     "cl3d_pwmlp_point_gemm_bwd_weight");
+  return point_gemm_bwd_weight(features, nullptr, nullptr, dght, dwr, B, C, N, Co, precision, dW, ws, ws_bytes,
+                               (hipStream_t)stream, "cl3d_pwmlp_point_gemm_bwd_weight");
+}
+
+extern "C" int cl3d_pwmlp_point_gemm_bwd_weight_pro(const float *x, const float *scale, const float *shift,
+                                                    const float *dght, const float *dwr, int B, int C, int N, int Co,
+                                                    int precision, float *dW, void *ws, size_t ws_bytes,
+                                                    cl3d_stream_t stream) {
+  GEMM_COMMON_CHECKS("pwmlp_point_gemm_bwd_weight_pro");
+  CL3D_REQUIRE(B >= 1 && x && scale && shift && dght && dW, "pwmlp_point_gemm_bwd_weight_pro: null pointer");
+  return point_gemm_bwd_weight(x, scale, shift, dght, dwr, B, C, N, Co, precision, dW, ws, ws_bytes, (hipStream_t)stream,
+                               "cl3d_pwmlp_point_gemm_bwd_weight_pro");
 }
 
 // ---- the 1x1 Conv1d layers around the operator (backbones/resnet.py:32-39,58-66), channel-major in and out ---------
@@ -876,4 +956,52 @@ extern "C" int cl3d_conv1x1_bwd_weight(const float *x, const float *dy, int B, i
   a.out.D = dW; a.out.si = C; a.out.sj = 1;
   return run_gemm<0>(a, precision, kMaxSplitWgrad, ws, ws_bytes, nullptr, 0, 0, (hipStream_t)stream,
                      "cl3d_conv1x1_bwd_weight");
+}
+
+// ---- the convolution that FOLLOWS the operator (backbones/resnet.py:58: conv2), fed by the operator's point-major
+// rows [B, N, C] (its per-(query, channel) pre-activations) with the operator's BatchNorm + ReLU as the operand
+// prologue: the channel-major activated tensor between the operator and conv2 is never written.  The input gradient
+// comes back as rows too -- the gradient with respect to the ACTIVATED input, which the operator's backward expects.
+extern "C" int cl3d_conv1x1_rows_fwd(const float *x_rows, const float *scale, const float *shift, const float *W, int B,
+                                     int C, int N, int Co, int precision, float *y, void *ws, size_t ws_bytes,
+                                     cl3d_stream_t stream) {
+  GEMM_COMMON_CHECKS("conv1x1_rows_fwd");
+  CL3D_REQUIRE(W && scale && shift && (B == 0 || (x_rows && y)), "conv1x1_rows_fwd: null pointer");
+  if (B == 0) return CL3D_OK;
+  GemmArgs a{};  // D[i = o][j = (cloud, point)] = sum_c W[o][c] act(x[(cloud, point)][c])
+  a.A = plain(W, C, 1, Co, C);
+  a.B = plain(x_rows, C, 1, B * N, C);
+  set_prologue(a.B, scale, shift, 0);
+  a.out.D = y; a.out.si = N; a.out.sj = 1; a.out.fold_n = B > 1 ? N : 0; a.out.sb = (long long)Co * N;
+  a.K = C;
+  return run_gemm<0>(a, precision, kMaxSplitFwd, ws, ws_bytes, nullptr, 0, 0, (hipStream_t)stream, "cl3d_conv1x1_rows_fwd");
+}
+
+extern "C" int cl3d_conv1x1_rows_bwd_data(const float *dy, const float *W, int B, int C, int N, int Co, int precision,
+                                          float *dx_rows, void *ws, size_t ws_bytes, cl3d_stream_t stream) {
+  GEMM_COMMON_CHECKS("conv1x1_rows_bwd_data");
+  CL3D_REQUIRE(W && (B == 0 || (dy && dx_rows)), "conv1x1_rows_bwd_data: null pointer");
+  if (B == 0) return CL3D_OK;
+  GemmArgs a{};  // D[i = (cloud, point)][j = c] = sum_o dy[o][point] W[o][c]  ->  rows [B*N, C]
+  a.A = channel_major(dy, B, Co, N, true);
+  a.B = plain(W, 1, C, C, Co);
+  a.out.D = dx_rows; a.out.si = C; a.out.sj = 1;
+  a.K = Co;
+  return run_gemm<0>(a, precision, kMaxSplitFwd, ws, ws_bytes, nullptr, 0, 0, (hipStream_t)stream,
+                     "cl3d_conv1x1_rows_bwd_data");
+}
+
+extern "C" int cl3d_conv1x1_rows_bwd_weight(const float *x_rows, const float *scale, const float *shift, const float *dy,
+                                            int B, int C, int N, int Co, int precision, float *dW, void *ws,
+                                            size_t ws_bytes, cl3d_stream_t stream) {
+  GEMM_COMMON_CHECKS("conv1x1_rows_bwd_weight");
+  CL3D_REQUIRE(B >= 1 && x_rows && scale && shift && dy && dW, "conv1x1_rows_bwd_weight: null pointer");
+  GemmArgs a{};  // D[i = o][j = c] = sum_(cloud, point) dy[o][point] act(x[(cloud, point)][c])
+  a.A = channel_major(dy, B, Co, N, false);
+  a.B = plain(x_rows, 1, C, C, B * N);
+  set_prologue(a.B, scale, shift, 1);
+  a.K = B * N;
+  a.out.D = dW; a.out.si = C; a.out.sj = 1;
+  return run_gemm<0>(a, precision, kMaxSplitWgrad, ws, ws_bytes, nullptr, 0, 0, (hipStream_t)stream,
+                     "cl3d_conv1x1_rows_bwd_weight");
 }

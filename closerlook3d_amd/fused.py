@@ -411,7 +411,10 @@ class _PointwiseMLP(Function):
 
     @staticmethod
     def forward(ctx, ght, wr, gamma, beta, running_mean, running_var, query_xyz, support_xyz, idx, radius,
-                training, momentum, eps, need_grad, num_batches_tracked=None):
+                training, momentum, eps, need_grad, num_batches_tracked=None, rows_out=False):
+        """rows_out (training only): return (ystar [B,M,Co], scale [Co], shift [Co]) instead of the activated
+        channel-major tensor -- the consumer (conv2 of a bottleneck, _Conv1x1Rows) applies max(scale * y + shift, 0)
+        while it stages its operand, and hands back the gradient with respect to the activated rows."""
         B, N, two_co = ght.shape
         Co = two_co // 2
         _, M, K = idx.shape
@@ -428,8 +431,8 @@ class _PointwiseMLP(Function):
                 # max, its slot and sum_k y -- the rest of forward and most of backward is algebra on those
                 vec = torch.empty((4, Co), dtype=torch.float32, device=dev)
                 scale, shift, mean, invstd = vec[0], vec[1], vec[2], vec[3]
-                rows = torch.empty((2, B, M, Co), dtype=torch.float32, device=dev)
-                ystar, sy = rows[0], rows[1]
+                ystar = torch.empty((B, M, Co), dtype=torch.float32, device=dev)  # (an output when rows_out)
+                sy = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
                 kstar = torch.empty((B, M, Co), dtype=torch.uint8, device=dev)
                 partial = torch.empty((nparts, Co, 8), dtype=torch.float64, device=dev)
                 sums = torch.empty((Co, 6), dtype=torch.float64, device=dev)
@@ -441,12 +444,18 @@ class _PointwiseMLP(Function):
                                                          _p(gamma), _p(beta), _p(running_mean), _p(running_var),
                                                          _p(num_batches_tracked), _p(scale), _p(shift), _p(mean),
                                                          _p(invstd), _p(sums), st))
-                _lib.check(lib.cl3d_pwmlp_apply(_p(ystar), _p(scale), _p(shift), B, M, Co, _p(out), st))
+                if not rows_out:
+                    _lib.check(lib.cl3d_pwmlp_apply(_p(ystar), _p(scale), _p(shift), B, M, Co, _p(out), st))
                 if need_grad:
                     ctx.save_for_backward(ght, wr, gamma, vec, ystar, sy, kstar, sums, query_xyz, support_xyz)
                     ctx.radius = float(radius)
                     ctx.idx = idx
                     ctx.meta = (B, N, M, K, Co, nparts)
+                ctx.rows_out = bool(rows_out)
+                if rows_out:
+                    _join_inverse(idx)
+                    ctx.mark_non_differentiable(scale, shift)
+                    return ystar, scale, shift  # ystar is saved above AND returned: an output may be saved
             else:
                 if need_grad:
                     raise NotImplementedError("fused PointWiseMLP backward needs training-mode BatchNorm")
@@ -460,14 +469,15 @@ class _PointwiseMLP(Function):
         return out
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, gout, *unused):
         ght, wr, gamma, vec, ystar, sy, kstar, sums, query_xyz, support_xyz = ctx.saved_tensors
         B, N, M, K, Co, nparts = ctx.meta
         idx = ctx.idx
         dev = gout.device
         lib = _lib.lib()
         n = B * M * K
-        gout = gout.contiguous()  # channel-major [B,Co,M], read directly by the kernel
+        gout = gout.contiguous()  # channel-major [B,Co,M] (or point-major rows [B,M,Co]), read directly by the kernel
+        gout_cm = 0 if getattr(ctx, 'rows_out', False) else 1
         with _lib.on_device(dev):
             st = _stream(gout)
             dz_cm = torch.empty((B, Co, M), dtype=torch.float32, device=dev)
@@ -477,7 +487,7 @@ class _PointwiseMLP(Function):
             # {coordinates, centre idx[j, 0]} (a slot of that pass then costs one L2 request instead of three)
             dz_t = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
             qtab = torch.empty((B, M, 4), dtype=torch.float32, device=dev)
-            _lib.check(lib.cl3d_pwmlp_bwd_rows(_p(gout), 1, _p(ystar), _p(kstar), _p(idx), _p(query_xyz), _p(support_xyz),
+            _lib.check(lib.cl3d_pwmlp_bwd_rows(_p(gout), gout_cm, _p(ystar), _p(kstar), _p(idx), _p(query_xyz), _p(support_xyz),
                                                ctx.radius, _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), B, N, M, K, Co,
                                                _p(dz_cm), _p(ts_cm), _p(dz_t), _p(qtab), _p(partial), nparts, st))
             hit = torch.empty((B, Co, N), dtype=torch.float32, device=dev)
@@ -503,7 +513,7 @@ class _PointwiseMLP(Function):
             _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t), _p(sy),
                                                   _p(qtab), _p(support_xyz), ctx.radius, _p(off), _p(slots),
                                                   B, N, M, K, Co, _p(dght), st))
-        return (dght, dwr, dgamma, dbeta) + (None,) * 11
+        return (dght, dwr, dgamma, dbeta) + (None,) * 12
 
 
 import os
@@ -611,6 +621,177 @@ class _PointRowsLibrary(Function):
             with _lib.on_device(features.device):
                 _lib.check(_lib.lib().cl3d_pwmlp_merge_weight_grad(_p(dwr), _p(dwb), B, Co, C, _p(dW), _stream(dwb)))
         return dfeat, dW
+
+
+class _BnReluPointRows(Function):
+    """The PointWiseMLP's per-point rows from a bottleneck's RAW conv1 output y1 [B,C,N]: BatchNorm (batch statistics)
+    + ReLU are applied while the contraction stages its operand (cl3d_pwmlp_point_gemm_fwd_pro), so the activated
+    tensor conv1 -> operator (backbones/resnet.py:32-34,54) is never written; backward: d act from the data-gradient
+    product, the weight gradient again on the staged activation, then BatchNorm + ReLU backward on (d act, y1)."""
+
+    @staticmethod
+    def forward(ctx, y1, gamma, beta, bn, W, precision):
+        y1 = y1.contiguous()
+        W = W.contiguous()
+        B, C, N = y1.shape
+        Co = W.shape[0]
+        dev = y1.device
+        lib = _lib.lib()
+        vec = torch.empty((4, C), dtype=torch.float32, device=dev)  # scale, shift, mean, invstd
+        nparts = lib.cl3d_bn_partials(B, C, N)
+        partial = torch.empty((nparts, C, 2), dtype=torch.float64, device=dev)
+        wr = torch.empty((Co, 3), dtype=torch.float32, device=dev)
+        wcat = torch.empty((2 * Co, C), dtype=torch.float32, device=dev)
+        ght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
+        ws, ws_bytes = _gemm_scratch(14, B, N, Co, C, dev)
+        with _lib.on_device(dev):
+            st = _stream(y1)
+            _lib.check(lib.cl3d_bn_relu_stats(_p(y1), B, C, N, _p(partial), nparts, float(B * N), float(bn.eps),
+                                              float(bn.momentum), _p(gamma), _p(beta), _p(bn.running_mean),
+                                              _p(bn.running_var), _p(_step_counter(bn)), _p(vec[0]), _p(vec[1]),
+                                              _p(vec[2]), _p(vec[3]), st))
+            _lib.check(lib.cl3d_pwmlp_point_gemm_fwd_pro(_p(y1), _p(vec[0]), _p(vec[1]), _p(W), B, C, N, Co, precision,
+                                                         _p(ght), _p(wr), _p(wcat), _p(ws), ws_bytes, st))
+        ctx.save_for_backward(y1, vec, gamma, wcat)
+        ctx.precision = precision
+        ctx.nparts = nparts
+        return ght, wr
+
+    @staticmethod
+    def backward(ctx, dght, dwr):
+        y1, vec, gamma, wcat = ctx.saved_tensors
+        B, C, N = y1.shape
+        Co = wcat.shape[0] // 2
+        dev = y1.device
+        lib = _lib.lib()
+        prec = ctx.precision
+        if dght is None:
+            dght = torch.zeros((B, N, 2 * Co), dtype=torch.float32, device=dev)
+        dght = dght.contiguous()
+        dwr = dwr.contiguous() if dwr is not None else None
+        dact = torch.empty((B, C, N), dtype=torch.float32, device=dev)
+        dW = torch.empty((Co, 3 + 2 * C), dtype=torch.float32, device=dev)
+
+        def data_grad():
+            ws, ws_bytes = _gemm_scratch(14, B, N, Co, C, dev)
+            _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_data(_p(dght), _p(wcat), B, C, N, Co, prec, _p(dact), _p(ws),
+                                                          ws_bytes, _stream(y1)))
+
+        def weight_grad():
+            ws, ws_bytes = _gemm_scratch(14, B, N, Co, C, dev)
+            _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_weight_pro(_p(y1), _p(vec[0]), _p(vec[1]), _p(dght), _p(dwr), B, C, N,
+                                                                Co, prec, _p(dW), _p(ws), ws_bytes, _stream(y1)))
+
+        dy1 = torch.empty_like(y1)
+        coef = torch.empty((5, C), dtype=torch.float32, device=dev)
+        partial = torch.empty((ctx.nparts, C, 2), dtype=torch.float64, device=dev)
+        with _lib.on_device(dev):
+            _fork_join(dev, weight_grad, data_grad)
+            _lib.check(lib.cl3d_bn_relu_bwd(_p(dact), _p(y1), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _p(gamma), B, C, N,
+                                            float(B * N), _p(partial), ctx.nparts, _p(coef), _p(dy1), _stream(y1)))
+        return dy1, coef[3], coef[4], None, dW, None
+
+
+class _Conv1x1Rows(Function):
+    """y [B,Co,N] = W max(scale * rows + shift, 0) with rows [B,N,C] the operator's point-major pre-activations and
+    (scale, shift) its folded batch statistics: conv2 of a bottleneck reading the operator's output directly
+    (backbones/resnet.py:56-58).  backward returns the gradient with respect to the ACTIVATED rows (the operator's own
+    backward gates it by the ReLU and takes it through its BatchNorm) and d W."""
+
+    @staticmethod
+    def forward(ctx, rows, scale, shift, W, precision):
+        rows = rows.contiguous()
+        W = W.contiguous()
+        B, N, C = rows.shape
+        Co = W.shape[0]
+        y = torch.empty((B, Co, N), dtype=torch.float32, device=rows.device)
+        ws, ws_bytes = _gemm_scratch(15, B, N, Co, C, rows.device)
+        with _lib.on_device(rows.device):
+            _lib.check(_lib.lib().cl3d_conv1x1_rows_fwd(_p(rows), _p(scale), _p(shift), _p(W), B, C, N, Co, precision, _p(y),
+                                                        _p(ws), ws_bytes, _stream(rows)))
+        ctx.save_for_backward(rows, scale, shift, W)
+        ctx.precision = precision
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, scale, shift, W = ctx.saved_tensors
+        B, N, C = rows.shape
+        Co = W.shape[0]
+        dev = rows.device
+        dy = dy.contiguous()
+        lib = _lib.lib()
+        prec = ctx.precision
+        drows = torch.empty_like(rows) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(W) if ctx.needs_input_grad[3] else None
+
+        def data_grad():
+            if drows is not None:
+                ws, ws_bytes = _gemm_scratch(15, B, N, Co, C, dev)
+                _lib.check(lib.cl3d_conv1x1_rows_bwd_data(_p(dy), _p(W), B, C, N, Co, prec, _p(drows), _p(ws), ws_bytes,
+                                                          _stream(rows)))
+
+        def weight_grad():
+            if dW is not None:
+                ws, ws_bytes = _gemm_scratch(15, B, N, Co, C, dev)
+                _lib.check(lib.cl3d_conv1x1_rows_bwd_weight(_p(rows), _p(scale), _p(shift), _p(dy), B, C, N, Co, prec, _p(dW),
+                                                            _p(ws), ws_bytes, _stream(rows)))
+
+        with _lib.on_device(dev):
+            _fork_join(dev, weight_grad, data_grad)
+        return drows, None, None, dW, None
+
+
+def pointwise_bottleneck(conv1, la, conv2, shortcut, query_xyz, support_xyz, query_mask, support_mask, features,
+                         identity, precision='f32'):
+    """A whole PointWiseMLP bottleneck in training mode without the two [B,C,N] tensors between its layers
+    (backbones/resnet.py:47-66):
+        y1 = conv1(x)                          MFMA convolution, raw output
+        ght = rows(act1(y1))                   BatchNorm + ReLU of conv1 inside the per-point contraction's staging
+        rows, scale, shift = operator(ght)     point-major pre-activations, the operator's BatchNorm left to the consumer
+        y2 = conv2(act(rows))                  conv2 reads the rows, the operator's BatchNorm + ReLU inside ITS staging
+        out = ReLU(BN2(y2) + shortcut)         the fused tail of conv_bn_act
+    conv1 / conv2 / shortcut: the bottleneck's `_conv_bn` units; la: its PointWiseMLP module.  Returns None when the
+    configuration is outside what the kernels cover (the caller then runs layer by layer)."""
+    c1, bn1 = conv1[0], conv1[1]
+    c2, bn2 = conv2[0], conv2[1]
+    mconv, mbn = la.mlps.conv0[0], la.mlps.conv0[1]
+    if (CONV_ENGINE != 'mfma' or POINT_GEMM != 'mfma' or la.reduction != 'max' or la.num_mlps != 1
+            or la.feature_type != 'dp_fi_df' or not (bn1.training and bn2.training and mbn.training)):
+        return None
+    if c1.bias is not None or c1.kernel_size != (1,) or c2.bias is not None or c2.kernel_size != (1,):
+        return None
+    if not (_bn_unit_ok(features, bn1) and mbn.affine and mbn.track_running_stats and mbn.momentum is not None
+            and bn2.affine and bn2.track_running_stats and bn2.momentum is not None):
+        return None
+    C1 = c1.weight.shape[0]
+    Cla = mconv.weight.shape[0]
+    if (features.shape[1] != c1.weight.shape[1] or mconv.weight.shape[1] != 3 + 2 * C1 or c2.weight.shape[1] != Cla
+            or C1 % 4 or Cla % 4):
+        return None
+    if not _lib.lib().cl3d_fused_supported(10, int(la.nsample), int(Cla)):
+        return None
+    if not (features.is_cuda and query_xyz.is_cuda and query_xyz.dim() == 3 and features.shape[2] == support_xyz.shape[1]):
+        return None
+    sc, sbn = (shortcut[0], shortcut[1]) if shortcut is not None else (None, None)
+    if sbn is not None and not sbn.training:
+        return None
+    if not _residual_ok(c2, identity, sc, sbn, features.device, features.shape[0], query_xyz.shape[1]):
+        return None  # (checked before anything runs: a late refusal would have updated running statistics twice)
+    features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
+    prec = PRECISIONS[precision]
+    params = (c1.weight, bn1.weight, bn1.bias, mconv.weight, mbn.weight, mbn.bias, c2.weight, bn2.weight, bn2.bias)
+    need_grad = _wants_grad(features, identity, *params)
+    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, la.radius, la.nsample, need_grad)
+    y1 = _Conv1x1.apply(features, c1.weight.view(C1, -1), prec)
+    ght, wr = _BnReluPointRows.apply(y1, bn1.weight, bn1.bias, bn1, mconv.weight.view(Cla, 3 + 2 * C1), prec)
+    rows, scale, shift = _PointwiseMLP.apply(ght, wr, mbn.weight, mbn.bias, mbn.running_mean, mbn.running_var,
+                                             query_xyz.contiguous(), support_xyz.contiguous(), idx, la.radius, True,
+                                             mbn.momentum, mbn.eps, need_grad, _step_counter(mbn), True)
+    y2 = _Conv1x1Rows.apply(rows, scale, shift, c2.weight.view(c2.weight.shape[0], Cla), prec)
+    return conv_bn_act(None, c2, bn2, relu=True, residual=identity,
+                       res_conv=shortcut[0] if shortcut is not None else None,
+                       res_bn=shortcut[1] if shortcut is not None else None, precision=precision, conv_out=y2)
 
 
 def point_rows(features, W, precision='f32'):
@@ -787,32 +968,41 @@ def _bn_unit_ok(x, bn):
             and bn.momentum is not None)
 
 
+def _residual_ok(conv, residual, res_conv, res_bn, device, B, N):
+    """The kernels take the residual as a raw pointer: its dtype, device, rank and shape are checked here, against the
+    tensor it is added to ([B,Co,N]) or the shortcut convolution's input ([B,Cr,N])."""
+    if residual is None:
+        return res_conv is None
+    if res_conv is not None:
+        if (res_conv.bias is not None or res_conv.kernel_size != (1,) or not _bn_unit_ok(residual, res_bn)
+                or residual.shape[1] != res_conv.weight.shape[1] or res_conv.weight.shape[0] != conv.weight.shape[0]):
+            return False
+    elif not (residual.is_cuda and residual.dtype == torch.float32 and residual.dim() == 3
+              and residual.shape[1] == conv.weight.shape[0]):
+        return False
+    return residual.device == device and residual.shape[0] == B and residual.shape[2] == N
+
+
 def _folded(bn):
     invstd = torch.rsqrt(bn.running_var.double() + bn.eps)
     scale = bn.weight.double() * invstd
     return scale.float(), (bn.bias.double() - bn.running_mean.double() * scale).float()
 
 
-def conv_bn_act(x, conv, bn, relu=True, residual=None, res_conv=None, res_bn=None, precision='f32'):
+def conv_bn_act(x, conv, bn, relu=True, residual=None, res_conv=None, res_bn=None, precision='f32', conv_out=None):
     """act(BN(conv(x)) + R): a bottleneck's conv1 (R = 0) or its tail conv2 + shortcut + add + ReLU
     (backbones/resnet.py:32-39,58-66), on the engine: MFMA 1x1 convolutions, one statistics pass per BatchNorm and one
     fused apply / add / ReLU pass.  Inference (no gradient): BatchNorm folded into the convolution's epilogue, one
     launch per convolution.  Returns None when the modules are outside what the kernels cover."""
-    if conv.bias is not None or conv.kernel_size != (1,) or not _bn_unit_ok(x, bn) or x.shape[1] != conv.weight.shape[1]:
+    if conv_out is not None:
+        # training-mode tail on a convolution the caller has already run (pointwise_bottleneck: conv2 fed by the
+        # operator's rows): x is not needed, everything below the convolution is what this function does anyway
+        if not bn.training or not _bn_unit_ok(conv_out, bn):
+            raise RuntimeError("conv_bn_act(conv_out=...) is the training-mode tail only")
+        x = conv_out
+    elif conv.bias is not None or conv.kernel_size != (1,) or not _bn_unit_ok(x, bn) or x.shape[1] != conv.weight.shape[1]:
         return None
-    if residual is not None:
-        # the kernels take the residual as a raw pointer: its dtype, device, rank and shape are checked here, against
-        # the tensor it is added to ([B,Co,N]) or the shortcut convolution's input ([B,Cr,N]) (ADVICE r2)
-        if res_conv is not None:
-            if (res_conv.bias is not None or res_conv.kernel_size != (1,) or not _bn_unit_ok(residual, res_bn)
-                    or residual.shape[1] != res_conv.weight.shape[1] or res_conv.weight.shape[0] != conv.weight.shape[0]):
-                return None
-        elif not (residual.is_cuda and residual.dtype == torch.float32 and residual.dim() == 3
-                  and residual.shape[1] == conv.weight.shape[0]):
-            return None
-        if residual.device != x.device or residual.shape[0] != x.shape[0] or residual.shape[2] != x.shape[2]:
-            return None
-    elif res_conv is not None:
+    if not _residual_ok(conv, residual, res_conv, res_bn, x.device, x.shape[0], x.shape[2]):
         return None
     prec = PRECISIONS[precision]
     Co, C = conv.weight.shape[0], conv.weight.shape[1]
@@ -842,7 +1032,12 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, res_conv=None, res_bn=Non
             _lib.check(lib.cl3d_conv1x1_bn_act_fwd(_p(x), _p(W.contiguous()), _p(s1), _p(t1), _p(res), int(relu), B, C, N, Co,
                                                    prec, _p(y), _p(ws), ws_bytes, st))
         return y
-    if CONV_ENGINE == 'library':
+    if conv_out is not None:
+        y1 = conv_out
+        x2 = residual
+        if res_conv is not None:
+            x2 = _Conv1x1.apply(residual, res_conv.weight.view(Co, res_conv.weight.shape[1]), prec)
+    elif CONV_ENGINE == 'library':
         y1 = torch.nn.functional.conv1d(x, conv.weight)
         x2 = torch.nn.functional.conv1d(residual, res_conv.weight) if res_conv is not None else residual
     else:

@@ -16,6 +16,8 @@ Equal distances: scikit-learn's sort is not stable, so among points at EXACTLY t
 pick point its order is unspecified; here they come in ascending index order.  The set of returned points and every
 position outside such a tie group are identical (tests/test_sphere_crop.py, against scikit-learn itself).
 """
+import ctypes
+
 import torch
 
 
@@ -32,8 +34,36 @@ class SceneCropper:
     def _pick(self, pick_point):
         return torch.as_tensor(pick_point, dtype=torch.float64, device=self.device).reshape(3)
 
+    # ---- the engine's kernels (csrc/sphere_crop.hip) when the scene lives on a GPU: one streaming pass + one stable
+    # radix sort per query, one gather kernel per sample; the indexed torch operations below remain the CPU path
+    def _native(self):
+        return self.device.type == "cuda"
+
+    def _sorted_scene(self, pick_point):
+        """(sorted_idx [P] int32: every scene index by (inside first, distance, index); count [1] int32 on the device;
+        the pick point as three host doubles).  Nothing is synchronised here."""
+        from . import _lib
+        lib = _lib.lib()
+        pick = [float(v) for v in torch.as_tensor(pick_point, dtype=torch.float64).reshape(3).cpu().tolist()]
+        P = self.points64.shape[0]
+        if getattr(self, "_ws", None) is None:
+            nbytes = max(lib.cl3d_workspace_bytes(16, 1, P, 0, 0, 0), lib.cl3d_workspace_bytes(16, 1, self.num_points, 0, 0, 0))
+            self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
+        sorted_idx = torch.empty((P,), dtype=torch.int32, device=self.device)
+        count = torch.empty((1,), dtype=torch.int32, device=self.device)
+        arr = (ctypes.c_double * 3)(*pick)
+        with _lib.on_device(self.device):
+            _lib.check(lib.cl3d_sphere_crop_query(self.points64.data_ptr(), P, ctypes.cast(arr, ctypes.c_void_p), self.in_radius,
+                                                  sorted_idx.data_ptr(), count.data_ptr(), self._ws.data_ptr(),
+                                                  self._ws.numel(), _lib.stream_ptr(self.device)))
+        return sorted_idx, count, arr
+
     def query(self, pick_point, limit=True):
         """Scene indices inside the sphere, nearest first, at most `num_points` of them (S3DIS.py:300-306)."""
+        if self._native():
+            sorted_idx, count, _ = self._sorted_scene(pick_point)
+            n = int(count)  # the one host round trip: the length of the list the caller receives
+            return sorted_idx[:min(n, self.num_points) if limit else n].long()
         c = self._pick(pick_point)
         d = self.points64 - c
         rdist = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
@@ -47,6 +77,8 @@ class SceneCropper:
         `generator` (a torch.Generator on this device) instead of numpy's global state:
         dict(points [N,3] f32 centred on the pick point, mask [N] i32, input_inds [N] i64, height [N,1] f32,
         colors / labels gathered if the scene has them)."""
+        if self._native():
+            return self._crop_native(pick_point, generator)
         c = self._pick(pick_point)
         query = self.query(c)
         cur, N = int(query.numel()), self.num_points
@@ -68,6 +100,30 @@ class SceneCropper:
             out["colors"] = self.colors[input_inds]
         if self.labels is not None:
             out["labels"] = self.labels[input_inds].to(torch.int64)
+        return out
+
+    def _crop_native(self, pick_point, generator):
+        from . import _lib
+        lib = _lib.lib()
+        N = self.num_points
+        sorted_idx, count, arr = self._sorted_scene(pick_point)
+        u = torch.rand((2, N), device=self.device, generator=generator)  # the sample's draws: shuffle keys, re-draws
+        points = torch.empty((N, 3), dtype=torch.float32, device=self.device)
+        mask = torch.empty((N,), dtype=torch.int32, device=self.device)
+        inds = torch.empty((N,), dtype=torch.int64, device=self.device)
+        height = torch.empty((N, 1), dtype=torch.float32, device=self.device)
+        with _lib.on_device(self.device):
+            _lib.check(lib.cl3d_sphere_crop_assemble(self.points64.data_ptr(), sorted_idx.data_ptr(), count.data_ptr(), N,
+                                                     ctypes.cast(arr, ctypes.c_void_p), u[0].data_ptr(), u[1].data_ptr(),
+                                                     points.data_ptr(), mask.data_ptr(), inds.data_ptr(), height.data_ptr(),
+                                                     self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr(self.device)))
+        out = {"points": points, "mask": mask, "input_inds": inds, "height": height}
+        if self.colors is not None:
+            out["colors"] = self.colors[inds]
+        if self.labels is not None:
+            out["labels"] = self.labels[inds].to(torch.int64)
+        if int(count) == 0:  # checked once everything is queued
+            raise RuntimeError("sphere crop: no scene point within in_radius of the pick point")
         return out
 
     def project(self, points, chunk=None, budget_bytes=1 << 30):

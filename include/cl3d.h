@@ -60,6 +60,7 @@ typedef void *cl3d_stream_t; /* hipStream_t */
 #define CL3D_OP_MAX_POOL 13      /* cl3d_maxpool_fwd/bwd (only meaningful for cl3d_fused_supported) */
 #define CL3D_OP_POINT_GEMM 14    /* cl3d_pwmlp_point_gemm_bwd_weight: (B, N, M = Co, K unused, C) */
 #define CL3D_OP_CONV1X1 15       /* cl3d_conv1x1_bwd_weight: (B, N, M = Cout, K unused, C = Cin) */
+#define CL3D_OP_SPHERE_CROP 16   /* cl3d_sphere_crop_query: N = scene points; _assemble: N = num_points */
 
 int cl3d_abi_version(void);
 const char *cl3d_last_error_string(void);
@@ -132,6 +133,22 @@ int cl3d_dataset_grid_subsampling(const float *points, const float *features, co
                                   int fdim, int ldim, float sampleDl, float *sub_points, float *sub_features,
                                   int32_t *sub_labels, int32_t *count, void *ws, size_t ws_bytes,
                                   cl3d_stream_t stream);
+
+/* S3DIS sphere crop of a scene resident in HBM (datasets/S3DIS.py:296-314: KDTree.query_radius(pick, r,
+ * return_distance=True, sort_results=True), the num_points nearest, shuffled, padded by re-drawn valid points).
+ * query: points [P,3] float64 (the tree's own copies), pick: 3 doubles ON THE HOST; sorted_idx [P] receives every
+ * scene index ordered by (in-sphere first, float64 distance sqrt((dx*dx + dy*dy) + dz*dz), index), *count (device) the
+ * number of points with rdist <= radius^2: the first *count entries are the tree's sorted in-radius list.
+ * assemble: one sample of num_points slots from (sorted_idx, count): m = min(*count, num_points) nearest points in
+ * the order of their draws u_shuffle [num_points] (uniform [0,1), caller's RNG), then slots >= m re-draw one of them
+ * by u_redraw; out_inds int64, out_mask, out_points = float32(point - pick), out_height = float32(z).
+ * ws: cl3d_workspace_bytes(CL3D_OP_SPHERE_CROP, 1, P or num_points, 0, 0, 0). */
+int cl3d_sphere_crop_query(const double *points, int P, const double *pick, double radius, int32_t *sorted_idx,
+                           int32_t *count, void *ws, size_t ws_bytes, cl3d_stream_t stream);
+int cl3d_sphere_crop_assemble(const double *points, const int32_t *sorted_idx, const int32_t *count, int num_points,
+                              const double *pick, const float *u_shuffle, const float *u_redraw, float *out_points,
+                              int32_t *out_mask, int64_t *out_inds, float *out_height, void *ws, size_t ws_bytes,
+                              cl3d_stream_t stream);
 
 /* BatchNorm1d + ReLU on channel-major x [B,C,N]: the output transform of every LocalAggregation operator
  * (local_aggregation_operators.py:40-45) as streaming kernels.  Training forward = stats (batch statistics ->
@@ -269,6 +286,30 @@ int cl3d_conv1x1_bwd_data(const float *dy, const float *W, int B, int C, int N, 
                           void *ws, size_t ws_bytes, cl3d_stream_t stream);
 int cl3d_conv1x1_bwd_weight(const float *x, const float *dy, int B, int C, int N, int Co, int precision, float *dW,
                             void *ws, size_t ws_bytes, cl3d_stream_t stream);
+
+/* A bottleneck without its two [B,C,N] round trips (backbones/resnet.py:32-39,47-66).  The
+ * BatchNorm + ReLU that precedes a contraction is applied while the contraction's operand tile is staged
+ * (act(x) = max(scale[c] * x + shift[c], 0), scale / shift = the producing layer's folded batch statistics, 16-byte
+ * aligned for the vector paths), so the activated tensor between the two layers is never written:
+ *   point_gemm_fwd_pro / _bwd_weight_pro: the PointWiseMLP's per-point contraction and its weight gradient on
+ *       act(x) with x [B,C,N] = conv1's raw output;
+ *   conv1x1_rows_fwd: y [B,Co,N] = W act(x_rows) with x_rows [B,N,C] = the operator's point-major rows (conv2 reading
+ *       the operator's output directly); _rows_bwd_data: d x_rows [B,N,C], the gradient with respect to the
+ *       ACTIVATED input (what cl3d_pwmlp_bwd_rows takes with gout_channel_major = 0); _rows_bwd_weight: d W [Co,C].
+ * ws as for the plain entry points (CL3D_OP_POINT_GEMM / CL3D_OP_CONV1X1). */
+int cl3d_pwmlp_point_gemm_fwd_pro(const float *x, const float *scale, const float *shift, const float *W, int B, int C,
+                                  int N, int Co, int precision, float *ght, float *wr, float *wcat, void *ws,
+                                  size_t ws_bytes, cl3d_stream_t stream);
+int cl3d_pwmlp_point_gemm_bwd_weight_pro(const float *x, const float *scale, const float *shift, const float *dght,
+                                         const float *dwr, int B, int C, int N, int Co, int precision, float *dW,
+                                         void *ws, size_t ws_bytes, cl3d_stream_t stream);
+int cl3d_conv1x1_rows_fwd(const float *x_rows, const float *scale, const float *shift, const float *W, int B, int C,
+                          int N, int Co, int precision, float *y, void *ws, size_t ws_bytes, cl3d_stream_t stream);
+int cl3d_conv1x1_rows_bwd_data(const float *dy, const float *W, int B, int C, int N, int Co, int precision,
+                               float *dx_rows, void *ws, size_t ws_bytes, cl3d_stream_t stream);
+int cl3d_conv1x1_rows_bwd_weight(const float *x_rows, const float *scale, const float *shift, const float *dy, int B,
+                                 int C, int N, int Co, int precision, float *dW, void *ws, size_t ws_bytes,
+                                 cl3d_stream_t stream);
 /* weight plumbing of the factored contraction: W [Co,3+2C] = [W_r | W_c | W_d] -> wr [Co,3], wcat [2Co,C] =
  * [W_d ; W_c - W_d];  d W from d wr (nullable) and the per-cloud products dwb [B,C,2Co] = F_b G_b. */
 int cl3d_pwmlp_split_weight(const float *W, int Co, int C, float *wr, float *wcat, cl3d_stream_t stream);

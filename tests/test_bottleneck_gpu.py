@@ -11,7 +11,7 @@ import pytest
 import torch
 import torch.nn as nn
 
-from tests.helpers import default_config
+from tests.helpers import assert_close, default_config
 
 pytestmark = pytest.mark.gpu
 
@@ -132,3 +132,57 @@ def test_bottleneck_engine_path_matches_module_path(kind, downsample):
     _close(res["auto"][3], res["grouped"][3], 5e-4, "bottleneck d features")
     for k in res["grouped"][4]:
         _close(res["auto"][4][k], res["grouped"][4][k], 5e-4, f"bottleneck d {k}")
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("strided", [False, True])
+def test_pointwisemlp_bottleneck_without_the_tensors_between_its_layers(strided, precision, monkeypatch):
+    """SURVEY 8(f) rank 1, the part that defines the row: a PointWiseMLP bottleneck in training mode with conv1's
+    BatchNorm + ReLU applied inside the operator's per-point contraction and the operator's inside conv2
+    (fused.pointwise_bottleneck; backbones/resnet.py:47-66) against the same module run layer by layer with the
+    activated tensors materialised: same output, same gradients (input, every parameter), same running statistics."""
+    from closerlook3d_amd import backbones
+    from closerlook3d_amd.backbones import Bottleneck
+    from oracle import operators as oo
+    rng = np.random.default_rng(5)
+    B, N, K = 4, 1024, 16
+    cin, cout = (32, 64) if strided else (64, 64)
+    xyz_np, mask_np = oo.make_cloud(rng, B, N, pad_frac=0.1)
+    xyz, mask = torch.from_numpy(xyz_np).cuda(), torch.from_numpy(mask_np).cuda()
+    f_np = rng.standard_normal((B, cin, N)).astype(np.float32)
+    res = {}
+    for fuse in (True, False):
+        monkeypatch.setattr(backbones, "_FUSE_BOTTLENECK", fuse)
+        monkeypatch.setattr(backbones, "_FUSE_MIN_VALUES", 0)
+        torch.manual_seed(3)
+        cfg = default_config("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df"}, cl3d_precision=precision)
+        btn = Bottleneck(cin, cout, 2, 0.12, K, cfg, downsample=strided, sampleDl=0.08, npoint=256).cuda().train(True)
+        with torch.no_grad():
+            for m in btn.modules():
+                if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.normal_(0, 0.2)
+        feats = torch.from_numpy(f_np).cuda().requires_grad_(True)
+        sub_xyz, sub_mask, out = btn(xyz, mask, feats)
+        probe = torch.from_numpy(np.random.default_rng(6).standard_normal(tuple(out.shape)).astype(np.float32)).cuda()
+        (out * probe).sum().backward()
+        res[fuse] = (out.detach().cpu().numpy(), feats.grad.cpu().numpy(),
+                     {k: p.grad.cpu().numpy() for k, p in btn.named_parameters() if p.grad is not None},
+                     {k: v.detach().cpu().numpy() for k, v in btn.named_buffers()})
+    tol = 1e-5 if precision == "f32" else 2e-2
+    a, b = res[True], res[False]
+    assert_close(a[0], b[0], tol, "out")
+    # gradients: sums over B*N*K terms in another order; an arg-max near-tie may re-route a whole entry in bf16
+    if precision == "f32":
+        assert_close(a[1], b[1], 1e-4, "grad input")
+        for k in b[2]:
+            assert_close(a[2][k], b[2][k], 3e-4, f"grad {k}")
+    else:
+        rel = np.linalg.norm(a[1] - b[1]) / np.linalg.norm(b[1])
+        assert rel < 5e-2, rel
+    for k in b[3]:
+        if a[3][k].dtype.kind == "f":
+            assert_close(a[3][k], b[3][k], 1e-5 if precision == "f32" else 1e-3, f"buffer {k}")
+        else:
+            assert np.array_equal(a[3][k], b[3][k]), k
+    assert set(a[2]) == set(b[2])
