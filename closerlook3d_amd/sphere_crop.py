@@ -39,22 +39,26 @@ class SceneCropper:
     def _native(self):
         return self.device.type == "cuda"
 
-    def _sorted_scene(self, pick_point):
-        """(sorted_idx [P] int32: every scene index by (inside first, distance, index); count [1] int32 on the device;
-        the pick point as three host doubles).  Nothing is synchronised here."""
+    def _sorted_scene(self, pick_point, cap=None):
+        """(sorted_idx [cap] int32: the in-sphere scene indices by (distance, index) when there are at most `cap` of
+        them; count [1] int32 on the device; the pick point as three host doubles).  Nothing is synchronised here.
+        cap: host-known size of the sort (default: four samples' worth, at least 65 536, at most the scene); a caller
+        that finds count > cap repeats with cap = P."""
         from . import _lib
         lib = _lib.lib()
         pick = [float(v) for v in torch.as_tensor(pick_point, dtype=torch.float64).reshape(3).cpu().tolist()]
         P = self.points64.shape[0]
+        if cap is None:
+            cap = min(P, max(4 * self.num_points, 65536))
         if getattr(self, "_ws", None) is None:
             nbytes = max(lib.cl3d_workspace_bytes(16, 1, P, 0, 0, 0), lib.cl3d_workspace_bytes(16, 1, self.num_points, 0, 0, 0))
             self._ws = torch.empty((nbytes,), dtype=torch.uint8, device=self.device)
-        sorted_idx = torch.empty((P,), dtype=torch.int32, device=self.device)
+        sorted_idx = torch.empty((cap,), dtype=torch.int32, device=self.device)
         count = torch.empty((1,), dtype=torch.int32, device=self.device)
         arr = (ctypes.c_double * 3)(*pick)
         with _lib.on_device(self.device):
             _lib.check(lib.cl3d_sphere_crop_query(self.points64.data_ptr(), P, ctypes.cast(arr, ctypes.c_void_p), self.in_radius,
-                                                  sorted_idx.data_ptr(), count.data_ptr(), self._ws.data_ptr(),
+                                                  cap, sorted_idx.data_ptr(), count.data_ptr(), self._ws.data_ptr(),
                                                   self._ws.numel(), _lib.stream_ptr(self.device)))
         return sorted_idx, count, arr
 
@@ -63,6 +67,8 @@ class SceneCropper:
         if self._native():
             sorted_idx, count, _ = self._sorted_scene(pick_point)
             n = int(count)  # the one host round trip: the length of the list the caller receives
+            if n > sorted_idx.numel():  # more points in the sphere than the sort was sized for: the whole scene
+                sorted_idx, count, _ = self._sorted_scene(pick_point, cap=self.points64.shape[0])
             return sorted_idx[:min(n, self.num_points) if limit else n].long()
         c = self._pick(pick_point)
         d = self.points64 - c
@@ -102,11 +108,11 @@ class SceneCropper:
             out["labels"] = self.labels[input_inds].to(torch.int64)
         return out
 
-    def _crop_native(self, pick_point, generator):
+    def _crop_native(self, pick_point, generator, cap=None):
         from . import _lib
         lib = _lib.lib()
         N = self.num_points
-        sorted_idx, count, arr = self._sorted_scene(pick_point)
+        sorted_idx, count, arr = self._sorted_scene(pick_point, cap)
         u = torch.rand((2, N), device=self.device, generator=generator)  # the sample's draws: shuffle keys, re-draws
         points = torch.empty((N, 3), dtype=torch.float32, device=self.device)
         mask = torch.empty((N,), dtype=torch.int32, device=self.device)
@@ -122,8 +128,11 @@ class SceneCropper:
             out["colors"] = self.colors[inds]
         if self.labels is not None:
             out["labels"] = self.labels[inds].to(torch.int64)
-        if int(count) == 0:  # checked once everything is queued
+        n = int(count)  # checked once everything is queued
+        if n == 0:
             raise RuntimeError("sphere crop: no scene point within in_radius of the pick point")
+        if n > sorted_idx.numel():  # the sphere held more points than the sort was sized for (the draws are spent)
+            return self._crop_native(pick_point, generator, cap=self.points64.shape[0])
         return out
 
     def project(self, points, chunk=None, budget_bytes=1 << 30):

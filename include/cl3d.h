@@ -136,15 +136,16 @@ int cl3d_dataset_grid_subsampling(const float *points, const float *features, co
 
 /* S3DIS sphere crop of a scene resident in HBM (datasets/S3DIS.py:296-314: KDTree.query_radius(pick, r,
  * return_distance=True, sort_results=True), the num_points nearest, shuffled, padded by re-drawn valid points).
- * query: points [P,3] float64 (the tree's own copies), pick: 3 doubles ON THE HOST; sorted_idx [P] receives every
- * scene index ordered by (in-sphere first, float64 distance sqrt((dx*dx + dy*dy) + dz*dz), index), *count (device) the
- * number of points with rdist <= radius^2: the first *count entries are the tree's sorted in-radius list.
+ * query: points [P,3] float64 (the tree's own copies), pick: 3 doubles ON THE HOST; *count (device) = the number of
+ * points with rdist = (dx*dx + dy*dy) + dz*dz <= radius^2; sorted_idx [cap] receives them ordered by (float64 distance
+ * sqrt(rdist), index) -- the tree's sorted in-radius list -- when *count <= cap (1 <= cap <= P: the host-known size of
+ * the sort; cap = P always suffices, a smaller bound sorts less).  *count > cap: repeat with a larger cap.
  * assemble: one sample of num_points slots from (sorted_idx, count): m = min(*count, num_points) nearest points in
  * the order of their draws u_shuffle [num_points] (uniform [0,1), caller's RNG), then slots >= m re-draw one of them
  * by u_redraw; out_inds int64, out_mask, out_points = float32(point - pick), out_height = float32(z).
- * ws: cl3d_workspace_bytes(CL3D_OP_SPHERE_CROP, 1, P or num_points, 0, 0, 0). */
-int cl3d_sphere_crop_query(const double *points, int P, const double *pick, double radius, int32_t *sorted_idx,
-                           int32_t *count, void *ws, size_t ws_bytes, cl3d_stream_t stream);
+ * ws: cl3d_workspace_bytes(CL3D_OP_SPHERE_CROP, 1, P, 0, 0, 0) (query, any cap; also enough for assemble). */
+int cl3d_sphere_crop_query(const double *points, int P, const double *pick, double radius, int cap,
+                           int32_t *sorted_idx, int32_t *count, void *ws, size_t ws_bytes, cl3d_stream_t stream);
 int cl3d_sphere_crop_assemble(const double *points, const int32_t *sorted_idx, const int32_t *count, int num_points,
                               const double *pick, const float *u_shuffle, const float *u_redraw, float *out_points,
                               int32_t *out_mask, int64_t *out_inds, float *out_height, void *ws, size_t ws_bytes,

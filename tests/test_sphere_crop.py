@@ -102,3 +102,22 @@ def test_batched_crops_equal_single_crops(device, num_points):
         assert np.array_equal(s["points"][b].view(np.uint32), centred.view(np.uint32))
         assert np.array_equal(s["height"][b], pts[inds][:, 2:])
         assert np.array_equal(s["labels"][b], labels[inds].astype(np.int64))
+
+
+@pytest.mark.gpu
+def test_native_query_with_a_sort_smaller_than_the_sphere_falls_back_to_the_whole_scene():
+    """csrc/sphere_crop.hip sorts a host-known number of candidate slots (`cap`); a sphere holding more points than
+    that is reported through *count and the query is repeated over the whole scene: same list either way."""
+    g = np.load(GOLDEN)
+    scene = SceneCropper(g["points"], in_radius=float(g["in_radius"]), num_points=700, device="cuda")
+    pick, want = g["picks"][0], g["inds0"]
+    assert len(want) > 64
+    sorted_idx, count, _ = scene._sorted_scene(pick, cap=64)
+    assert int(count) == len(want) and sorted_idx.numel() == 64          # reported, not truncated silently
+    sorted_idx, count, _ = scene._sorted_scene(pick, cap=len(want))        # exactly enough
+    assert np.array_equal(sorted_idx[:int(count)].cpu().numpy(), want)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4)
+    s = scene._crop_native(pick, gen, cap=64)                              # too small -> repeated with cap = P
+    inds = s["input_inds"].cpu().numpy()
+    assert np.array_equal(np.sort(inds), np.sort(want[:700])) if len(want) >= 700 else np.isin(inds, want).all()
