@@ -53,6 +53,9 @@ def main():
     ap.add_argument("--head", action="store_true",
                     help="backbone + the scene-segmentation head (nearest up-sampling decoder + classifier) in the step")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python")
+    ap.add_argument("--checksums", action="store_true", help="add the L2 norms of the last step's gradients and of the parameters")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: one flat all-reduce after the whole backward instead of the two-graph overlapped exchange")
     args = ap.parse_args()
     kind, B, N, radius, dl, nsamples, npoints, width = CONFIGS[args.config]
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -90,7 +93,33 @@ def main():
     x = torch.from_numpy(xyz).to(dev)
     m = torch.from_numpy(mask).to(dev)
     feats = x.transpose(1, 2).contiguous()
-    flat = FlatGradients(params) if world > 1 else None
+    # N > 1: the step is cut where most parameters sit behind most of the backward TIME.  The two widest stages
+    # (layer3, layer4, the head) hold ~94 % of the parameters, the early stages the points: graph A = zero gradients +
+    # forward + backward down to layer3's input; the late-stage gradients (the head of the flat buffer) are then
+    # all-reduced on RCCL's stream WHILE graph B replays the backward of the early stages; the small remainder follows.
+    # (reference: DistributedDataParallel's bucketed overlap, function/train_modelnet_dist.py:206,280)
+    overlap = world > 1 and not args.no_overlap
+    late = [p for n_, p in net.named_parameters() if p.requires_grad and n_.startswith(("layer3.", "layer4."))]
+    late += [p for p in head.parameters()] if head is not None else []
+    late_ids = {id(p) for p in late}
+    early = [p for p in params if id(p) not in late_ids]
+    flat = FlatGradients(late + early) if world > 1 else None
+    n_late = sum(p.numel() for p in late)
+    cut_keys = ["res3_features"] if head is None else ["res1_features", "res2_features", "res3_features"]
+    held = {}
+
+    def compute_late():  # graph A
+        flat.zero_()
+        with (contextlib.nullcontext() if args.no_cache else ball_query_cache()):
+            ep = net(x, m, feats)
+            out = head(ep) if head is not None else ep["res5_features"]
+        cuts = [ep[k] for k in cut_keys]
+        torch.autograd.backward([out.square().mean()], inputs=cuts + late, retain_graph=True)
+        held["cuts"] = cuts  # (kept alive: graph B reads their .grad and walks the graph below them)
+
+    def compute_early():  # graph B
+        cuts = held["cuts"]
+        torch.autograd.backward(cuts, grad_tensors=[c.grad for c in cuts], inputs=early)
 
     def compute():
         if flat is not None:
@@ -104,43 +133,75 @@ def main():
         if world == 1:
             opt.step()
 
-    def capture(fn):
+    def capture(fn, pool=None):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
+                if fn is compute_early:
+                    compute_late()
                 fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
+        with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local" if world > 1 else "global"):
             fn()
         return g
 
     # the step is hundreds of short kernels: replayed as one HIP graph unless --no-graph (same kernels, same work)
-    graph = update_graph = None
+    graph = update_graph = graph_b = None
     if not args.no_graph:
         try:
-            graph = capture(compute)
+            if overlap:
+                graph = capture(compute_late)
+                graph_b = capture(compute_early, pool=graph.pool())
+            else:
+                graph = capture(compute)
             if world > 1:
                 update_graph = capture(opt.step)
         except Exception as e:
             print(f"bench_backbone: HIP graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
-            graph = update_graph = None
+            graph = update_graph = graph_b = None
             torch.cuda.synchronize()
     ar_events = []
+    comm = torch.cuda.Stream() if overlap else None
+    from closerlook3d_amd.dp import _mean_inplace
 
     def run():
-        if graph is not None:
-            graph.replay()
-        else:
-            compute()
-        if world > 1:
+        if overlap:
+            if graph is not None:
+                graph.replay()
+            else:
+                compute_late()
+            main = torch.cuda.current_stream()
+            comm.wait_stream(main)
+            with torch.cuda.stream(comm):  # the late-stage gradients leave while the early stages are differentiated
+                work, need_div = _mean_inplace(flat.buffer[:n_late], world, None, async_op=True)
+            if graph_b is not None:
+                graph_b.replay()
+            else:
+                compute_early()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            flat.allreduce_mean(world)
+            e0.record()  # from here on the exchange is exposed: what is left of the first bucket + the small second one
+            _mean_inplace(flat.buffer[n_late:], world, None)
+            work.wait()
+            main.wait_stream(comm)
+            if need_div:
+                flat.buffer.div_(world)
             e1.record()
             ar_events.append((e0, e1))
+        else:
+            if graph is not None:
+                graph.replay()
+            else:
+                compute()
+            if world > 1:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                flat.allreduce_mean(world)
+                e1.record()
+                ar_events.append((e0, e1))
+        if world > 1:
             if update_graph is not None:
                 update_graph.replay()
             else:
@@ -171,9 +232,18 @@ def main():
                 "params_M": round(sum(p.numel() for p in params) / 1e6, 2),
                 "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
         if world > 1:
-            line["allreduce_ms"] = round(float(np.mean([a.elapsed_time(b) for a, b in ar_events])), 3)
+            line["allreduce_exposed_ms"] = round(float(np.mean([a.elapsed_time(b) for a, b in ar_events])), 3)
             line["allreduce_bytes"] = int(flat.buffer.numel() * 4)
+            line["exchange"] = ("two graphs: late-stage gradients (%d B) all-reduced while the early stages' backward "
+                                "replays, remainder (%d B) after it" % (n_late * 4, (flat.buffer.numel() - n_late) * 4)
+                                if overlap else "one flat all-reduce after the graph")
             line["backend"] = dist.get_backend()
+            line["world_size"] = dist.get_world_size()
+        line["device"] = f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"
+        if args.checksums:  # same seeds, same steps: the exchange scheme must not change a bit of either
+            grads = torch.cat([p.grad.reshape(-1).double() for p in params if p.grad is not None])
+            line["grad_l2"] = float(grads.norm())
+            line["param_l2"] = float(torch.cat([p.detach().reshape(-1).double() for p in params]).norm())
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -111,6 +111,29 @@ def test_backbone_bench_runs_data_parallel_on_one_device():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["allreduce_bytes"] > 50e6 and line["ms_per_step"] > 0
+    assert line["world_size"] == 2 and line["backend"] == "gloo" and "two graphs" in line["exchange"]
+
+
+def test_overlapped_exchange_gives_the_same_step_as_the_flat_one():
+    """scripts/bench_backbone.py --gpus 2: the step cut into two graphs with the late-stage gradients exchanged while
+    the early stages' backward replays (DistributedDataParallel's overlap, train_modelnet_dist.py:206,280) against one
+    flat all-reduce after the whole backward: same gradients, same parameters after the same steps."""
+    lines = {}
+    for flag in ((), ("--no-overlap",)):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, CL3D_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "scripts", "bench_backbone.py"), "--gpus", "2",
+               "--config", "modelnet_small", "--steps", "3", "--warmup", "1", "--checksums", "--head", *flag]
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        lines[bool(flag)] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    a, b = lines[False], lines[True]
+    assert "two graphs" in a["exchange"] and "one flat" in b["exchange"]
+    assert abs(a["grad_l2"] - b["grad_l2"]) <= 1e-6 * b["grad_l2"], (a["grad_l2"], b["grad_l2"])
+    assert abs(a["param_l2"] - b["param_l2"]) <= 1e-9 * b["param_l2"], (a["param_l2"], b["param_l2"])
 
 
 def test_bench_py_runs_data_parallel_on_one_device():
