@@ -109,6 +109,40 @@ __device__ __forceinline__ unsigned gemm_off(const GemmOperand &s, int r, int k)
   return (unsigned)(r * s.sr + k * s.sk);
 }
 
+// Offsets of one load() call.  A tile starts at (r0, k0) with r0 % TR == 0 and k0 % KC == 0, so when the points per
+// cloud are a multiple of the tile extent along the folded axis the whole tile lies in ONE cloud: the cloud index is
+// one division per call on wave-uniform values instead of one per loaded vector (round 2: ~30 VALU instructions of
+// address arithmetic per 16-byte load -- the f32 kernels issued 5-7 times the vendor kernels' VALU instructions).
+struct TileOff {
+  unsigned base;
+  int rb, kb;
+  bool fast;
+};
+template <int TR, int KC>
+__device__ __forceinline__ TileOff tile_off(const GemmOperand &s, int r0, int k0) {
+  TileOff t{0u, 0, 0, true};
+  if (s.fold == 1) {
+    t.fast = s.fold_n % TR == 0;
+    if (t.fast) {
+      const int b = r0 / s.fold_n;
+      t.base = (unsigned)(b * (int)s.sb);
+      t.rb = b * s.fold_n;
+    }
+  } else if (s.fold == 2) {
+    t.fast = s.fold_n % KC == 0;
+    if (t.fast) {
+      const int b = k0 / s.fold_n;
+      t.base = (unsigned)(b * (int)s.sb);
+      t.kb = b * s.fold_n;
+    }
+  }
+  return t;
+}
+__device__ __forceinline__ unsigned gemm_off(const GemmOperand &s, const TileOff &t, int r, int k) {
+  if (t.fast) return t.base + (unsigned)((r - t.rb) * s.sr + (k - t.kb) * s.sk);
+  return gemm_off(s, r, k);
+}
+
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 __device__ __forceinline__ float &comp(float4 &v, int e) { return reinterpret_cast<float *>(&v)[e]; }
 
@@ -151,17 +185,18 @@ struct StageF32 {
   __device__ __forceinline__ void load(const GemmOperand &s, int r0, int k0, int K) {
     const int t = threadIdx.x;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const TileOff to = tile_off<TR, KC>(s, r0, k0);
     if (MODE == STAGE_VEC_RC) {
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int idx = q * 256 + t, r = r0 + 4 * (idx % (TR / 4)), k = k0 + idx / (TR / 4);
-        v[q] = (r < s.R && k < K) ? pro4<true>(s, ld4(s.p + gemm_off(s, r, k)), r, k) : zero;
+        v[q] = (r < s.R && k < K) ? pro4<true>(s, ld4(s.p + gemm_off(s, to, r, k)), r, k) : zero;
       }
     } else if (MODE == STAGE_VEC_KC) {
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int idx = q * 256 + t, k = k0 + 4 * (idx % (KC / 4)), r = r0 + idx / (KC / 4);
-        v[q] = (r < s.R && k < K) ? pro4<false>(s, ld4(s.p + gemm_off(s, r, k)), r, k) : zero;
+        v[q] = (r < s.R && k < K) ? pro4<false>(s, ld4(s.p + gemm_off(s, to, r, k)), r, k) : zero;
       }
     } else {
 #pragma unroll
@@ -209,6 +244,13 @@ struct StageF32 {
 };
 
 // ---- staging, bf16: LDS tile T[KC/8][TR + 1] packs of 8 bf16 (16 bytes) along k; KC = 64 --------------------
+// Row r of a k group sits at position swz(r) = r ^ ((r >> 4) & 3): the r-contiguous staging path has lane m write rows
+// 4m .. 4m+3 one after the other, i.e. 16 lanes write 16-byte packs 64 bytes apart -- four lanes per bank group
+// (SQ_LDS_BANK_CONFLICT 1.18e6 per launch in round 2's counters); with the swizzle lane m's i-th pack lands in
+// bank group 4 (m % 4) + (i ^ (m >> 2)), all sixteen distinct.  The permutation stays inside blocks of four rows, so the
+// 32 consecutive rows a fragment read covers still tile the banks exactly.
+__device__ __forceinline__ int bf16_swz(int r) { return r ^ ((r >> 4) & 3); }
+
 template <int TR>
 struct StageBF16 {
   static constexpr int KC = 64, G = KC / 8;
@@ -220,20 +262,21 @@ struct StageBF16 {
   __device__ __forceinline__ void load(const GemmOperand &s, int r0, int k0, int K) {
     const int t = threadIdx.x;
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const TileOff to = tile_off<TR, KC>(s, r0, k0);
     if (MODE == STAGE_VEC_RC) {  // one (k group, 4 rows) item per thread: 8 loads, each coalesced over the wave
       const int g = t / (TR / 4), r = r0 + 4 * (t % (TR / 4));
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = k0 + 8 * g + e;
-        v[e] = (g < G && r < s.R && k < K) ? pro4<true>(s, ld4(s.p + gemm_off(s, r, k)), r, k) : zero;
+        v[e] = (g < G && r < s.R && k < K) ? pro4<true>(s, ld4(s.p + gemm_off(s, to, r, k)), r, k) : zero;
       }
     } else if (MODE == STAGE_VEC_KC) {  // (row, k group) items: 32 contiguous bytes, 8 lanes cover 256 bytes of a row
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         const int idx = q * 256 + t, g = idx % G, r = r0 + idx / G, k = k0 + 8 * g;
         const bool ok = idx < TR * G && r < s.R;
-        v[2 * q] = (ok && k < K) ? pro4<false>(s, ld4(s.p + gemm_off(s, r, k)), r, k) : zero;
-        v[2 * q + 1] = (ok && k + 4 < K) ? pro4<false>(s, ld4(s.p + gemm_off(s, r, k + 4)), r, k + 4) : zero;
+        v[2 * q] = (ok && k < K) ? pro4<false>(s, ld4(s.p + gemm_off(s, to, r, k)), r, k) : zero;
+        v[2 * q + 1] = (ok && k + 4 < K) ? pro4<false>(s, ld4(s.p + gemm_off(s, to, r, k + 4)), r, k + 4) : zero;
       }
     } else {
 #pragma unroll
@@ -273,7 +316,7 @@ struct StageBF16 {
             float4 w = v[e];
             x[e] = comp(w, i);
           }
-          T[g * (TR + 1) + r + i] = pack(x);
+          T[g * (TR + 1) + bf16_swz(r + i)] = pack(x);
         }
       }
     } else {
@@ -289,7 +332,7 @@ struct StageBF16 {
           x[e] = comp(lo, e);
           x[4 + e] = comp(hi, e);
         }
-        if (idx < TR * G) T[g * (TR + 1) + r] = pack(x);
+        if (idx < TR * G) T[g * (TR + 1) + bf16_swz(r)] = pack(x);
       }
     }
   }
@@ -397,9 +440,9 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
       for (int ks = 0; ks < steps; ++ks) {
         uint4 fa[WI], fb[WJ];
 #pragma unroll
-        for (int x = 0; x < WI; ++x) fa[x] = TA[(2 * ks + lh) * (TI + 1) + wi0 + 32 * x + lr];
+        for (int x = 0; x < WI; ++x) fa[x] = TA[(2 * ks + lh) * (TI + 1) + bf16_swz(wi0 + 32 * x + lr)];
 #pragma unroll
-        for (int y = 0; y < WJ; ++y) fb[y] = TB[(2 * ks + lh) * (TJ + 1) + wj0 + 32 * y + lr];
+        for (int y = 0; y < WJ; ++y) fb[y] = TB[(2 * ks + lh) * (TJ + 1) + bf16_swz(wj0 + 32 * y + lr)];
 #pragma unroll
         for (int x = 0; x < WI; ++x)
 #pragma unroll
@@ -507,46 +550,62 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
 // thread groups take the slices s = g, g+16, g+32, ... and the 16 sub-sums are added in group order through LDS: the
 // summation order depends on nsplit only (bit-reproducible).  MODE 0 sends element (i, j) through the output map
 // (strides, folded clouds, inference epilogue); MODE 1 turns d wcat [2Co, C] (+ d W_r) into d W [Co, 3+2C].
-template <int MODE>
+template <int MODE, int VEC>
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ part, int nsplit, int I, int J,
                                                           OutMap o, const float *__restrict__ dwr, int Co, int C) {
-  __shared__ float s_sum[2][16][17];
+  // VEC = 4: a thread owns four consecutive elements (16-byte loads of every slice; the caller guarantees that four
+  // neighbours never straddle a row: J % 4 == 0 resp. C % 4 == 0) -- the 512-slice weight-gradient reduce of the
+  // metric shape went 7.5 -> ~4 us
+  __shared__ float s_sum[2][16][16 * VEC + 1];
   const int el = threadIdx.x & 15, sg = threadIdx.x >> 4;
   const long long IJ = (long long)I * J;
   const long long n_el = MODE == 0 ? IJ : (long long)Co * C;
-  for (long long e0 = (long long)blockIdx.x * 16; e0 < n_el; e0 += (long long)gridDim.x * 16) {
-    const long long e = e0 + el;
-    float top = 0.f, bot = 0.f;
+  for (long long e0 = (long long)blockIdx.x * 16 * VEC; e0 < n_el; e0 += (long long)gridDim.x * 16 * VEC) {
+    const long long e = e0 + (long long)el * VEC;
+    float top[VEC], bot[VEC];
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) top[v] = bot[v] = 0.f;
     if (e < n_el) {
-      if (MODE == 0) {
-        for (int p = sg; p < nsplit; p += 16) top += part[(size_t)p * IJ + e];
-      } else {  // e = (o, c) over [Co, C]: top = d wcat[o][c], bot = d wcat[Co + o][c]
-        for (int p = sg; p < nsplit; p += 16) {
-          top += part[(size_t)p * IJ + e];
-          bot += part[(size_t)p * IJ + (size_t)Co * C + e];
+      for (int p = sg; p < nsplit; p += 16) {
+        if constexpr (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4 *>(part + (size_t)p * IJ + e);
+          top[0] += t.x; top[1] += t.y; top[2] += t.z; top[3] += t.w;
+          if (MODE == 1) {
+            const float4 u = *reinterpret_cast<const float4 *>(part + (size_t)p * IJ + (size_t)Co * C + e);
+            bot[0] += u.x; bot[1] += u.y; bot[2] += u.z; bot[3] += u.w;
+          }
+        } else {
+          top[0] += part[(size_t)p * IJ + e];
+          if (MODE == 1) bot[0] += part[(size_t)p * IJ + (size_t)Co * C + e];  // bot = d wcat[Co + o][c]
         }
       }
     }
-    s_sum[0][sg][el] = top;
-    s_sum[1][sg][el] = bot;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      s_sum[0][sg][el * VEC + v] = top[v];
+      s_sum[1][sg][el * VEC + v] = bot[v];
+    }
     __syncthreads();
     if (sg == 0 && e < n_el) {
-      top = s_sum[0][0][el];
-      bot = s_sum[1][0][el];
 #pragma unroll
-      for (int g = 1; g < 16; ++g) {
-        top += s_sum[0][g][el];
-        bot += s_sum[1][g][el];
-      }
-      if (MODE == 0) {
-        const int i = (int)(e / J), j = (int)(e - (long long)i * J);
-        out_store(o, i, out_col(o, j), top);
-      } else {
-        const int oo = (int)(e / C), c = (int)(e - (long long)oo * C);
-        const int ld = 3 + 2 * C;
-        o.D[(size_t)oo * ld + 3 + c] = bot;            // d W_c
-        o.D[(size_t)oo * ld + 3 + C + c] = top - bot;  // d W_d
-        if (c < 3) o.D[(size_t)oo * ld + c] = dwr ? dwr[oo * 3 + c] : 0.f;
+      for (int v = 0; v < VEC; ++v) {
+        float t = s_sum[0][0][el * VEC + v], bt = s_sum[1][0][el * VEC + v];
+#pragma unroll
+        for (int g = 1; g < 16; ++g) {
+          t += s_sum[0][g][el * VEC + v];
+          bt += s_sum[1][g][el * VEC + v];
+        }
+        const long long ev = e + v;
+        if (MODE == 0) {
+          const int i = (int)(ev / J), j = (int)(ev - (long long)i * J);
+          out_store(o, i, out_col(o, j), t);
+        } else {
+          const int oo = (int)(ev / C), c = (int)(ev - (long long)oo * C);
+          const int ld = 3 + 2 * C;
+          o.D[(size_t)oo * ld + 3 + c] = bt;            // d W_c
+          o.D[(size_t)oo * ld + 3 + C + c] = t - bt;    // d W_d
+          if (c < 3) o.D[(size_t)oo * ld + c] = dwr ? dwr[oo * 3 + c] : 0.f;
+        }
       }
     }
     __syncthreads();
@@ -781,10 +840,16 @@ static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t 
     return check_launch(who);
   }
   const long long n_el = REDUCE_MODE == 0 ? (long long)I * J : (long long)Co * C;
-  long long grid = (n_el + 15) / 16;
+  const bool vec4 = (REDUCE_MODE == 0 ? J % 4 == 0 : C % 4 == 0) && ((long long)I * J) % 4 == 0 &&
+                    (reinterpret_cast<uintptr_t>(a.partial) & 15u) == 0;
+  long long grid = (n_el + (vec4 ? 63 : 15)) / (vec4 ? 64 : 16);
   if (grid > 16384) grid = 16384;
-  hipLaunchKernelGGL((gemm_reduce_kernel<REDUCE_MODE>), dim3((unsigned)grid), dim3(256), 0, st, a.partial, p.nsplit, I, J,
-                     final_out, dwr, Co, C);
+  if (vec4)
+    hipLaunchKernelGGL((gemm_reduce_kernel<REDUCE_MODE, 4>), dim3((unsigned)grid), dim3(256), 0, st, a.partial, p.nsplit, I,
+                       J, final_out, dwr, Co, C);
+  else
+    hipLaunchKernelGGL((gemm_reduce_kernel<REDUCE_MODE, 1>), dim3((unsigned)grid), dim3(256), 0, st, a.partial, p.nsplit, I,
+                       J, final_out, dwr, Co, C);
   return check_launch(who);
 }
 
