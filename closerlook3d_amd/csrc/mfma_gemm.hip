@@ -766,7 +766,10 @@ static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, s
     const long long ti = ceil_div(I, 64 * wi), tj = ceil_div(J, 64 * wj), tiles = ti * tj;
     const double flops = 2.0 * (double)(ti * 64 * wi) * (double)(tj * 64 * wj) * (double)K;
     for (long long split = 1; split <= max_split && split <= (chunks >= 4 ? chunks / 4 : 1); split += (split < 4 ? 1 : split / 2)) {
-      if (force_split && split != force_split && force_split <= max_split) continue;
+      if (force_split && force_split <= max_split && force_split <= (chunks >= 4 ? chunks / 4 : 1)) {
+        if (split != 1) break;  // the override replaces the sweep: exactly this many slices
+        split = force_split;
+      }
       if (split > 1 && (size_t)split * I * J * sizeof(float) > ws_bytes) break;
       const long long cps = (chunks + split - 1) / split;
       const long long real_split = (chunks + cps - 1) / cps;

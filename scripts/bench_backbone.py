@@ -133,16 +133,19 @@ def main():
         if world == 1:
             opt.step()
 
-    def capture(fn, pool=None):
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                if fn is compute_early:
-                    compute_late()
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+    def capture(fn, pool=None, warm=None):
+        """warm: what to run eagerly first (default: fn itself).  Graph B is captured right behind graph A with no eager
+        step in between: it must walk the autograd graph -- and read the cut gradients -- that graph A's capture built."""
+        if warm is None:
+            warm = fn
+        if warm:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    warm()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local" if world > 1 else "global"):
             fn()
@@ -153,8 +156,8 @@ def main():
     if not args.no_graph:
         try:
             if overlap:
-                graph = capture(compute_late)
-                graph_b = capture(compute_early, pool=graph.pool())
+                graph = capture(compute_late, warm=lambda: (compute_late(), compute_early()))
+                graph_b = capture(compute_early, pool=graph.pool(), warm=False)
             else:
                 graph = capture(compute)
             if world > 1:
