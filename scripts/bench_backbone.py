@@ -105,21 +105,29 @@ def main():
     early = [p for p in params if id(p) not in late_ids]
     flat = FlatGradients(late + early) if world > 1 else None
     n_late = sum(p.numel() for p in late)
-    cut_keys = ["res3_features"] if head is None else ["res1_features", "res2_features", "res3_features"]
+    # the cut: layer3's input.  The segmentation head also reads res1 .. res3 through its skip connections; it is fed
+    # DETACHED copies of them, so that graph A's backward stops there (a plain `inputs=[res1, res2, res3]` would walk
+    # layer1 and layer2 to form the total derivatives) and graph B starts from [res3, res2, res1] with the skip
+    # gradients as seeds -- autograd adds what flows down the chain.
+    skip_keys = [] if head is None else ["res1_features", "res2_features", "res3_features"]
     held = {}
 
     def compute_late():  # graph A
         flat.zero_()
         with (contextlib.nullcontext() if args.no_cache else ball_query_cache()):
             ep = net(x, m, feats)
-            out = head(ep) if head is not None else ep["res5_features"]
-        cuts = [ep[k] for k in cut_keys]
-        torch.autograd.backward([out.square().mean()], inputs=cuts + late, retain_graph=True)
-        held["cuts"] = cuts  # (kept alive: graph B reads their .grad and walks the graph below them)
+            det = {k: ep[k].detach().requires_grad_(True) for k in skip_keys}
+            out = head({**ep, **det}) if head is not None else ep["res5_features"]
+        main_cut = ep["res3_features"]
+        torch.autograd.backward([out.square().mean()], inputs=[main_cut] + list(det.values()) + late, retain_graph=True)
+        seeds = {"res3_features": main_cut.grad}
+        for k, d in det.items():
+            seeds[k] = d.grad if k not in seeds else seeds[k] + d.grad
+        held["cuts"] = [ep[k] for k in seeds]   # (kept alive: graph B walks the graph below them)
+        held["seeds"] = [seeds[k] for k in seeds]
 
     def compute_early():  # graph B
-        cuts = held["cuts"]
-        torch.autograd.backward(cuts, grad_tensors=[c.grad for c in cuts], inputs=early)
+        torch.autograd.backward(held["cuts"], grad_tensors=held["seeds"], inputs=early)
 
     def compute():
         if flat is not None:
