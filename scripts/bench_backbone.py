@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--head", action="store_true",
                     help="backbone + the scene-segmentation head (nearest up-sampling decoder + classifier) in the step")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python")
+    ap.add_argument("--self-check", action="store_true", help="compare the two-stage backward with the plain one and exit")
     ap.add_argument("--checksums", action="store_true", help="add the L2 norms of the last step's gradients and of the parameters")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one flat all-reduce after the whole backward instead of the two-graph overlapped exchange")
@@ -159,6 +160,28 @@ def main():
             fn()
         return g
 
+    if args.self_check:  # the cut backward against the plain one, parameter by parameter (eager, one process)
+        from closerlook3d_amd.dp import FlatGradients as _FG
+        flat = _FG(late + early)
+        compute_late()
+        compute_early()
+        torch.cuda.synchronize()
+        got = {n_: p.grad.detach().clone() for n_, p in list(net.named_parameters()) + ([("head." + k, v) for k, v in head.named_parameters()] if head is not None else []) if p.grad is not None}
+        flat.zero_()
+        with (contextlib.nullcontext() if args.no_cache else ball_query_cache()):
+            ep = net(x, m, feats)
+            out = head(ep) if head is not None else ep["res5_features"]
+        out.square().mean().backward()
+        torch.cuda.synchronize()
+        worst = []
+        for n_, p in list(net.named_parameters()) + ([("head." + k, v) for k, v in head.named_parameters()] if head is not None else []):
+            if p.grad is None or n_ not in got:
+                continue
+            d = float((got[n_] - p.grad).abs().max()) / (float(p.grad.abs().max()) + 1e-30)
+            worst.append((d, n_))
+        worst.sort(reverse=True)
+        print(json.dumps({"self_check": "cut backward vs plain backward, worst relative differences", "worst": worst[:8]}))
+        return
     # the step is hundreds of short kernels: replayed as one HIP graph unless --no-graph (same kernels, same work)
     graph = update_graph = graph_b = None
     if not args.no_graph:
