@@ -55,8 +55,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python")
     ap.add_argument("--self-check", action="store_true", help="compare the two-stage backward with the plain one and exit")
     ap.add_argument("--checksums", action="store_true", help="add the L2 norms of the last step's gradients and of the parameters")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="N > 1: one flat all-reduce after the whole backward instead of the two-graph overlapped exchange")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N > 1: the step as two graphs with the late-stage gradients exchanged while the early stages' "
+                         "backward replays, instead of one flat all-reduce after the whole backward")
     args = ap.parse_args()
     kind, B, N, radius, dl, nsamples, npoints, width = CONFIGS[args.config]
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,7 +100,15 @@ def main():
     # forward + backward down to layer3's input; the late-stage gradients (the head of the flat buffer) are then
     # all-reduced on RCCL's stream WHILE graph B replays the backward of the early stages; the small remainder follows.
     # (reference: DistributedDataParallel's bucketed overlap, function/train_modelnet_dist.py:206,280)
-    overlap = world > 1 and not args.no_overlap
+    overlap = world > 1 and args.overlap
+    if overlap:
+        # Two captures that both fork work onto the engine's index streams gave WRONG early-stage gradients on this stack
+        # (ROCm 7.2 HIP graphs; measured on one device over gloo, r03: the second graph's early-stage norms drift by
+        # 0.3-4 % and change from replay to replay; with the forks off they equal the single-graph step to 5e-6, and the
+        # eager two-stage backward equals the plain one exactly).  So the overlapped step keeps every kernel on the
+        # capture stream; what it gains over the flat exchange has to pay for the forks it gives up (-6 % per step).
+        from closerlook3d_amd import pt_utils as _pu
+        _pu.ASYNC_INDEX = False
     late = [p for n_, p in net.named_parameters() if p.requires_grad and n_.startswith(("layer3.", "layer4."))]
     late += [p for p in head.parameters()] if head is not None else []
     late_ids = {id(p) for p in late}
@@ -209,8 +218,11 @@ def main():
                 compute_late()
             main = torch.cuda.current_stream()
             comm.wait_stream(main)
-            with torch.cuda.stream(comm):  # the late-stage gradients leave while the early stages are differentiated
-                work, need_div = _mean_inplace(flat.buffer[:n_late], world, None, async_op=True)
+            # the late-stage gradients leave while the early stages are differentiated: the collective is enqueued
+            # behind graph A on `comm` (RCCL: the call returns at once, the stream waits for the result; gloo, the
+            # one-device stand-in, blocks the host here -- correct, just not overlapped)
+            with torch.cuda.stream(comm):
+                _, need_div = _mean_inplace(flat.buffer[:n_late], world, None)
             if graph_b is not None:
                 graph_b.replay()
             else:
@@ -218,7 +230,6 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()  # from here on the exchange is exposed: what is left of the first bucket + the small second one
             _mean_inplace(flat.buffer[n_late:], world, None)
-            work.wait()
             main.wait_stream(comm)
             if need_div:
                 flat.buffer.div_(world)
@@ -243,6 +254,10 @@ def main():
 
     for _ in range(args.warmup):
         run()
+        if os.environ.get("CL3D_DP_DEBUG") == "1" and world > 1 and rank == 0:
+            torch.cuda.synchronize()
+            print("debug step: late %.9g early %.9g params %.12g" % (float(flat.buffer[:n_late].double().norm()), float(flat.buffer[n_late:].double().norm()),
+                  float(torch.cat([p.detach().reshape(-1).double() for p in params]).norm())), file=sys.stderr, flush=True)
     torch.cuda.synchronize()
     ar_events.clear()
     if world > 1:
