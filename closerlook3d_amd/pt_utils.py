@@ -135,7 +135,10 @@ def index_stream(device, which=0):
     """which=0: ball queries (and the prefetched pyramid); which=1: CSR builds (each joined through its own event)."""
     st = _INDEX_STREAMS.get((device, which))
     if st is None:
-        st = _INDEX_STREAMS[(device, which)] = torch.cuda.Stream(device=device)
+        # CL3D_BQ_PRIORITY=1 (experiment): the ball-query stream at high priority -- the query is on the step's critical
+        # path, the per-point GEMM that runs beside it has slack
+        prio = -1 if (which == 0 and os.environ.get('CL3D_BQ_PRIORITY') == '1') else 0
+        st = _INDEX_STREAMS[(device, which)] = torch.cuda.Stream(device=device, priority=prio)
     return st
 
 
@@ -224,7 +227,11 @@ def prefetch_geometry(xyz, mask, radius, sampleDl, nsamples, npoints, self_queri
     No-op without the memo or when the index streams are off (eager mode by default, see ASYNC_INDEX)."""
     if _BQ_CACHE is None or not (xyz.is_cuda and async_index()):
         return
-    if not (PREFETCH_GEOMETRY if PREFETCH_GEOMETRY != 'auto' else xyz.shape[0] < 8):
+    # with 8 or more clouds only the sub-sampling chain goes ahead (round 3): its four launches are one workgroup per
+    # cloud (16 CUs busy, 72 us each at 16 x 4096 points) and sit on the critical path when run in line, while beside
+    # the first stage's feature kernels they cost nothing; the ball queries fill the chip and stay in line there
+    queries = PREFETCH_GEOMETRY if PREFETCH_GEOMETRY != 'auto' else xyz.shape[0] < 8
+    if not queries and PREFETCH_GEOMETRY is False:
         return
     dev = xyz.device
     main, side = torch.cuda.current_stream(dev), index_stream(dev)
@@ -234,15 +241,16 @@ def prefetch_geometry(xyz, mask, radius, sampleDl, nsamples, npoints, self_queri
     global _CONSUMER_STREAM
     _CONSUMER_STREAM = main  # the ball queries below run with the index stream current: their outputs are read on `main`
     try:
-        _prefetch_on(side, main, capturing, xyz, mask, radius, sampleDl, nsamples, npoints, self_queries)
+        _prefetch_on(side, main, capturing, xyz, mask, radius, sampleDl, nsamples, npoints, self_queries, queries)
     finally:
         _CONSUMER_STREAM = None
 
 
-def _prefetch_on(side, main, capturing, xyz, mask, radius, sampleDl, nsamples, npoints, self_queries):
+def _prefetch_on(side, main, capturing, xyz, mask, radius, sampleDl, nsamples, npoints, self_queries, queries=True):
     with torch.cuda.stream(side):
         def query(q, s, qm, sm, r, k):
-            _ball_query(q, s, qm, sm, r, k, defer=True)
+            if queries:
+                _ball_query(q, s, qm, sm, r, k, defer=True)
 
         query(xyz, xyz, mask, mask, radius, nsamples[0])
         for stage in range(4):
