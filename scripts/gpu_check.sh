@@ -2,7 +2,7 @@
 # One GPU-box session: parity tests, reference pin, bench (+ rocprof summary of the same command), PMC counters of the
 # timed step and of the ball_query+group boundary, contraction A/B, the other operators and the backbone configs.
 # Usage (from the repo root on the GPU box): bash scripts/gpu_check.sh [tag]
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -13,12 +13,27 @@ echo "== pytest -m gpu (engine vs oracle, golden fixtures, reference pin, full-s
 timeout 2400 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1
 echo "pytest rc=$?" | tee -a $OUT/summary.txt; tail -8 $OUT/pytest_gpu.log | tee -a $OUT/summary.txt
 echo "== bench (the driver's command, default flags)" | tee -a $OUT/summary.txt
-timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_flags.json 2> $OUT/bench.err; echo "bench (driver's flags) rc=$?" | tee -a $OUT/summary.txt
+timeout 900 python bench.py > $OUT/bench.json 2>> $OUT/bench.err; echo "bench rc=$?" | tee -a $OUT/summary.txt
 cat $OUT/bench.json | tee -a $OUT/summary.txt
+python - <<PY | tee -a $OUT/summary.txt
+import json
+for f in ("bench_driver_flags.json", "bench.json"):
+    d = json.load(open("$OUT/" + f)); r = d["roofline"]
+    print(f, "ms_per_step", d["ms_per_step"], "| top", r["kernel"], r["us"], "us frac", r["frac"], "| boundary", r["boundary"]["ball_query_group"]["frac"], "min", r["boundary"]["ball_query_group"]["frac_min"], "| achieved_step", r["achieved_step"]["frac"], "| cpu", d["cpu_baseline"]["all_cores"]["value"], d["cpu_baseline"]["one_thread"]["value"])
+PY
 echo "== bench --precision bf16 (config 2's arithmetic)" | tee -a $OUT/summary.txt
 timeout 900 python bench.py --precision bf16 --no-cpu-baseline 2>/dev/null | tee $OUT/bench_bf16.json | cut -c1-300 | tee -a $OUT/summary.txt
 echo "== bench, eager launches" | tee -a $OUT/summary.txt
 timeout 900 python bench.py --no-graph --no-cpu-baseline --no-kernel-roofline 2>/dev/null | tee $OUT/bench_eager.json | cut -c1-260 | tee -a $OUT/summary.txt
+echo "== ball query: LDS-resident kernel vs cell grid through HBM (same op, pinned path)" | tee -a $OUT/summary.txt
+for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
+for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --n 1024 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
+for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --mult 4.0 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
+echo "== step variants: cell grid, two queries per lane group, points stored in cell order (experiment)" | tee -a $OUT/summary.txt
+for v in "CL3D_BQ_PATH=cells" "CL3D_PW_QPG=2" "CL3D_BENCH_SORTED=1"; do
+  env $v timeout 300 python bench.py --no-cpu-baseline --no-kernel-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', 'ms_per_step', d['ms_per_step'])" | tee -a $OUT/step_variants.txt | tee -a $OUT/summary.txt
+done
 echo "== rocprofv3 kernel trace of the same bench command" | tee -a $OUT/summary.txt
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o bench -- python $R/bench.py --no-cpu-baseline > $R/$OUT/rocprof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
 python scripts/kstats.py $OUT/prof/bench_kernel_stats.csv 100 40 | tee -a $OUT/summary.txt
@@ -30,6 +45,24 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES
 done
 python scripts/step_counters.py $OUT/step_pmc1 $OUT/step_pmc2 $OUT/step_pmc3 $OUT/step_pmc4 > $OUT/step_counters.json 2>> $OUT/summary.txt
 head -c 1200 $OUT/step_counters.json | tee -a $OUT/summary.txt
+echo "== L2 requests of the gather passes with the points stored in cell order (experiment)" | tee -a $OUT/summary.txt
+(cd /tmp && CL3D_BENCH_SORTED=1 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $R/$OUT/sorted_pmc -o pmc -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-roofline > /dev/null 2>&1)
+python - <<PY | tee $OUT/sorted_points_experiment.txt | tee -a $OUT/summary.txt
+import csv, glob, collections, json
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in glob.glob("$OUT/sorted_pmc/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        k = r["Kernel_Name"].split("(")[0]
+        if "pwmlp_query" in k or "pwmlp_support" in k:
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+base = json.load(open("$OUT/step_counters.json"))["kernels"]
+print("points stored in cell order (CL3D_BENCH_SORTED=1) vs the bench's random order: L2 requests per launch")
+for k, cs in acc.items():
+    hit, miss = (sum(cs[c]) / len(cs[c]) for c in ("TCC_HIT_sum", "TCC_MISS_sum"))
+    b = [v for n, v in base.items() if n.replace("void ", "").split("<")[0] == k.replace("void ", "").split("<")[0]]
+    was = (b[0]["TCC_HIT_sum"] + b[0]["TCC_MISS_sum"]) / 1e6 if b else float("nan")
+    print("  %-40s %.2f M (random order %.2f M), hit rate %.3f" % (k.replace("void cl3d::", "")[:40], (hit + miss) / 1e6, was, hit / (hit + miss)))
+PY
 echo "== PMC traffic of the ball_query+group kernels (separate passes)" | tee -a $OUT/summary.txt
 (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_fetch -o pmc -- python $R/scripts/pmc_kernels.py > $R/$OUT/pmc_fetch.log 2>&1)
 (cd /tmp && timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$OUT/pmc_write -o pmc -- python $R/scripts/pmc_kernels.py > $R/$OUT/pmc_write.log 2>&1)
@@ -56,8 +89,11 @@ CL3D_BLOCK=modules timeout 600 python scripts/bench_backbone.py --config modelne
 echo "== steady-state kernel table of the config-2 backbone step (bf16)" | tee -a $OUT/summary.txt
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bb -o bb -- python $R/scripts/bench_backbone.py --config modelnet_pointwisemlp --precision bf16 --steps 40 > $R/$OUT/rocprof_bb.log 2>&1)
 python scripts/kstats.py $OUT/prof_bb/bb_kernel_stats.csv 47 50 | tee $OUT/backbone_steady_state.txt | head -30 | tee -a $OUT/summary.txt
-echo "== data parallel on one device (2 ranks over gloo): backbone" | tee -a $OUT/summary.txt
+echo "== data parallel on one device (2 ranks over gloo): backbone, flat exchange and two-graph overlapped exchange" | tee -a $OUT/summary.txt
 CL3D_BENCH_ONE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 scripts/bench_backbone.py --gpus 2 --config partnet_adaptive 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
+CL3D_BENCH_ONE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 scripts/bench_backbone.py --gpus 2 --config partnet_adaptive --overlap 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
+echo "== config 2 layer by layer (CL3D_FUSE_BOTTLENECK=0): the activated tensors between a bottleneck's layers materialised" | tee -a $OUT/summary.txt
+for prec in f32 bf16; do CL3D_FUSE_BOTTLENECK=0 timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp --precision $prec 2>/dev/null | tail -1 | tee -a $OUT/summary.txt; done
 echo "== dataset-side grid subsampling, voting, sphere crops" | tee -a $OUT/summary.txt
 timeout 600 python scripts/bench_dataset_grid.py 2>/dev/null | tee $OUT/bench_dataset_grid.json | tee -a $OUT/summary.txt
 timeout 300 python scripts/bench_voting.py 2>/dev/null | tee $OUT/bench_voting.json | tee -a $OUT/summary.txt
