@@ -68,6 +68,8 @@ SIGNATURES = {
     "cl3d_pwmlp_bwd_hits": [_P, _P, _I, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_bn_backward_coeffs": [_P, _I, _I, ctypes.c_double] + [_P] * 11,
     "cl3d_pwmlp_bwd_support": [_P] * 10 + [_F, _P, _P] + [_I] * 5 + [_P, _P],
+    "cl3d_pwmlp_support_summary": [_P] * 5 + [_I] * 4 + [_F, _P, _P, _P],
+    "cl3d_pwmlp_bwd_support_sum": [_P] * 10 + [_I] * 5 + [_P, _P],
 }
 
 

@@ -645,6 +645,218 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
   }
 }
 
+// ---- the support-major pass on a SUMMARY of every support point's slot list -----------------------------------
+// Everything pwmlp_support_kernel reads per slot is a function of the geometry alone: the relative position (summed
+// over the list) and WHICH centre's H row the slot adds.  The centre of query j is idx[j, 0] -- the lowest support
+// index inside j's ball -- so the queries around one support point share a handful of centres: at the metric shape a
+// list of 32 slots names 6.7 distinct rows on average (19 at most), and one query in 32 is centred on the point
+// itself.  pwmlp_summary_kernel boils a list down, once per geometry (it depends on idx and the coordinates only, so
+// every operator of a backbone stage shares it, like the CSR inverse it is built from), to
+//     rec[b, i] = {sum_s rel_s (3 floats), s0 = inv_off[i] | list length, pair count, centred count, -}   (32 bytes)
+//     ent[b, s0 ...]            pairs    centre index | count << 24      (forward from the start of the list's range)
+//     ent[b, ... s0 + len - 1]  centred  query id (slot (j, 0): the query is centred on i; its sum_k y / dz rows feed
+//                                        dH_i)                            (backward from the end of the range)
+// and pwmlp_support_sum_kernel gathers ~8 rows per support point instead of 32 rows + 32 query records.  A list never
+// has more entries than slots, so both runs fit its range of the slot table's shape.
+// Half a wave per support point, 32 slots per round.  The distinct centres of a round are peeled off one per
+// iteration (leader = first unprocessed lane of the half, ballot of the lanes that name the same centre), in
+// first-appearance order, so the table is a pure function of the CSR table.  Pairs are not merged across rounds (a
+// list longer than 32 slots has a few more entries than distinct centres).
+struct SumArgs {
+  const int *idx;
+  const float *query_xyz, *support_xyz;
+  const int *inv_off, *inv_slots;
+  float4 *rec;
+  unsigned *ent;
+  int B, N, M, K;
+  float inv_radius;
+  unsigned kmagic;
+};
+
+__device__ __forceinline__ float half_wave_sum(float v) {  // butterfly over 32 lanes: every lane ends with the same bits
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, CL3D_WAVE);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void pwmlp_summary_kernel(SumArgs a) {
+  const int lane = lane_id();
+  const int half = lane >> 5, hl = lane & 31;
+  const int wave = threadIdx.x >> 6;
+  const int K = a.K, N = a.N, MK = a.M * a.K;
+  const long long rows = (long long)a.B * N;
+  const unsigned long long mine_mask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
+  for (long long r0 = ((long long)blockIdx.x * 4 + wave) * 2; r0 < rows; r0 += (long long)gridDim.x * 8) {
+    const long long r = r0 + half;
+    const bool row_on = r < rows;
+    const long long rc = row_on ? r : rows - 1;
+    const int b = (int)(rc / N), i = (int)(rc - (long long)b * N);
+    const int *off = a.inv_off + (size_t)b * (N + 1);
+    const int s0 = off[i], s1 = row_on ? off[i + 1] : s0;
+    const float *p = a.support_xyz + ((size_t)b * N + i) * 3;
+    const float px = p[0], py = p[1], pz = p[2];
+    const int *slots = a.inv_slots + (size_t)b * MK;
+    const int *idxb = a.idx + (size_t)b * MK;
+    const float *q = a.query_xyz + (size_t)b * a.M * 3;
+    unsigned *ent = a.ent + (size_t)b * MK;
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    int npair = 0, ncen = 0;
+    for (int c0 = s0; __ballot(c0 < s1) != 0ull; c0 += 32) {
+      const int e = c0 + hl;
+      const bool valid = e < s1;
+      const int sl = valid ? slots[e] : 0;
+      const int j = div_k(sl, a.kmagic, K);
+      const int cen = idxb[j * K];
+      const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
+      // the forward pass's own expression for rel (pwmlp_query_kernel's slot record)
+      rx += half_wave_sum(valid ? (px - qx) * a.inv_radius : 0.f);
+      ry += half_wave_sum(valid ? (py - qy) * a.inv_radius : 0.f);
+      rz += half_wave_sum(valid ? (pz - qz) * a.inv_radius : 0.f);
+      const bool centred = valid && sl - j * K == 0;
+      const bool pairable = valid && !centred;
+      unsigned long long rem = __ballot(pairable);
+      unsigned mine = 0u;
+      int np = 0;  // pairs of this round, uniform inside a half
+      while (rem != 0ull) {
+        const unsigned lo = (unsigned)rem, hi = (unsigned)(rem >> 32);
+        const int t_lo = __builtin_amdgcn_readlane(cen, lo != 0u ? __builtin_ctz(lo) : 0);
+        const int t_hi = __builtin_amdgcn_readlane(cen, hi != 0u ? 32 + __builtin_ctz(hi) : 32);
+        const bool busy = (half ? hi : lo) != 0u;  // this half still has a centre to peel
+        const int t = half ? t_hi : t_lo;
+        const unsigned long long same = __ballot(busy && pairable && cen == t && (rem >> lane & 1ull) != 0ull);
+        const int n = __builtin_popcountll(same & mine_mask);
+        if (busy && hl == np) mine = (unsigned)t | ((unsigned)n << 24);
+        np += busy ? 1 : 0;
+        rem &= ~same;
+      }
+      const unsigned long long cm = __ballot(centred) & mine_mask;
+      if (hl < np) ent[s0 + npair + hl] = mine;
+      if (centred) ent[s1 - 1 - ncen - __builtin_popcountll(cm & ((1ull << lane) - 1ull))] = (unsigned)j;
+      npair += np;
+      ncen += __builtin_popcountll(cm);
+    }
+    if (row_on && hl == 0) {
+      a.rec[2 * r] = make_float4(rx, ry, rz, __int_as_float(s0));
+      a.rec[2 * r + 1] = make_float4(__int_as_float(s1 - s0), __int_as_float(npair), __int_as_float(ncen), 0.f);
+    }
+  }
+}
+
+// dG_i, dH_i from the summary.  A lane group (L lanes x V channels) owns one support point.  Three dependent round
+// trips per point whatever its list: the 32-byte record (with the point's own row and its arg-max term, which do not
+// depend on it) -> the entries, one per lane of the group, handed round by shuffles -> the rows, SB at a time: an H
+// half-row of ght per pair, the forward pass's sum_k y row and the dz row per centred query.  No LDS, no barriers.
+template <int V, int SB>
+__global__ __launch_bounds__(256) void pwmlp_support_sum_kernel(PwArgs a, const float4 *__restrict__ rec,
+                                                                const unsigned *__restrict__ ent) {
+  const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
+  const int row = 2 * Co;
+  const unsigned rowb = (unsigned)row * 4u;
+  const int MK = M * K;
+  const int TR = 4 * QW;
+  const int lane = lane_id();
+  const int wave = threadIdx.x >> 6;
+  const int g = lane / L, cl = lane - g * L;
+  const int tiles_per_cloud = (N + TR - 1) / TR;
+  if (g >= QW) return;  // lanes past the last whole group (64 % L) never take part, shuffles included
+  for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {
+    // a lane whose channels lie past Co (last chunk) still carries entries for its group: it reads channel 0's
+    // pieces and stores nothing
+    const bool chan_on = (ch * L + cl) * V < Co;
+    const int c0 = chan_on ? (ch * L + cl) * V : 0;
+    {  // one tile per workgroup (not persistent: nothing for the compiler to hoist out of a tile loop into VGPRs)
+      const int tile = blockIdx.x;
+      int b, tr;
+      decode_tile(tile, a.B, tiles_per_cloud, b, tr);
+      const int i = tr * TR + wave * QW + g;
+      if (i >= N) continue;  // whole groups leave together
+      const size_t r = (size_t)b * N + i;
+      const float4 ra = rec[2 * r], rb = rec[2 * r + 1];
+      const char *own = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
+      const Vec<V> gi = load_row<V>(reinterpret_cast<const float *>(own + ((unsigned)i * rowb + (unsigned)c0 * 4u)));
+      const Vec<V> hi = load_row<V>(reinterpret_cast<const float *>(own + ((unsigned)i * rowb + ((unsigned)Co + (unsigned)c0) * 4u)));
+      float hit[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) hit[v] = a.hit_cm[((size_t)b * Co + c0 + v) * N + i];
+      const int s0 = __float_as_int(ra.w), len = __float_as_int(rb.x);
+      const int npair = __float_as_int(rb.y), ncen = __float_as_int(rb.z);
+      const unsigned *myent = ent + (size_t)b * MK + s0;
+      // uniform bases + 32-bit lane offsets: the gathers are saddr + voffset loads (one VGPR per address)
+      const char *hrows = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
+      const char *syrows = reinterpret_cast<const char *>(a.sy_in + (size_t)b * M * Co);
+      const char *dzrows = reinterpret_cast<const char *>(a.dz_t + (size_t)b * M * Co);
+      const unsigned h_off = ((unsigned)Co + (unsigned)c0) * 4u, q_off = (unsigned)c0 * 4u;
+      // first round of both runs requested together
+      unsigned wp = cl < npair ? myent[cl] : 0u;
+      unsigned wc = cl < ncen ? myent[len - 1 - cl] : 0u;
+      float shc[V], csy[V], cdz[V];
+#pragma unroll
+      for (int v = 0; v < V; ++v) shc[v] = csy[v] = cdz[v] = 0.f;
+      for (int p0 = 0; p0 < npair; p0 += L) {
+        if (p0 > 0) wp = p0 + cl < npair ? myent[p0 + cl] : 0u;
+        const int nr = npair - p0 < L ? npair - p0 : L;
+        for (int u0 = 0; u0 < nr; u0 += SB) {
+          unsigned en[SB];
+          Vec<V> rr[SB];
+#pragma unroll
+          for (int u = 0; u < SB; ++u) en[u] = (unsigned)__shfl((int)wp, g * L + (u0 + u < nr ? u0 + u : nr - 1), CL3D_WAVE);
+#pragma unroll
+          for (int u = 0; u < SB; ++u) rr[u] = load_row<V>(reinterpret_cast<const float *>(hrows + (__umul24(en[u] & 0xffffffu, rowb) + h_off)));
+#pragma unroll
+          for (int u = 0; u < SB; ++u) {
+            const float w = u0 + u < nr ? (float)(en[u] >> 24) : 0.f;
+#pragma unroll
+            for (int v = 0; v < V; ++v) shc[v] = __builtin_fmaf(w, rr[u].v[v], shc[v]);
+          }
+        }
+      }
+      for (int p0 = 0; p0 < ncen; p0 += L) {
+        if (p0 > 0) wc = p0 + cl < ncen ? myent[len - 1 - p0 - cl] : 0u;
+        const int nr = ncen - p0 < L ? ncen - p0 : L;
+        constexpr int SC = SB / 2;
+        for (int u0 = 0; u0 < nr; u0 += SC) {
+          unsigned en[SC];
+          Vec<V> ry[SC], rd[SC];
+#pragma unroll
+          for (int u = 0; u < SC; ++u) en[u] = (unsigned)__shfl((int)wc, g * L + (u0 + u < nr ? u0 + u : nr - 1), CL3D_WAVE);
+#pragma unroll
+          for (int u = 0; u < SC; ++u) {
+            const unsigned o = en[u] * ((unsigned)Co * 4u) + q_off;
+            ry[u] = load_row<V>(reinterpret_cast<const float *>(syrows + o));
+            rd[u] = load_row<V>(reinterpret_cast<const float *>(dzrows + o));
+          }
+#pragma unroll
+          for (int u = 0; u < SC; ++u) {
+            if (u0 + u >= nr) continue;
+#pragma unroll
+            for (int v = 0; v < V; ++v) {
+              csy[v] += ry[u].v[v];
+              cdz[v] += rd[u].v[v];
+            }
+          }
+        }
+      }
+      if (!chan_on) continue;
+      const float cnt = (float)len, fcen = (float)ncen;
+      float *dst = a.dght + r * row + c0;
+      Vec<V> dg, dh;
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        const int c = c0 + v;
+        float t = a.wr[c * 3 + 0] * ra.x;
+        t = __builtin_fmaf(a.wr[c * 3 + 1], ra.y, t);
+        t = __builtin_fmaf(a.wr[c * 3 + 2], ra.z, t);
+        const float hsum = __builtin_fmaf(fcen, hi.v[v], shc[v]);  // the centred queries' centre is this very point
+        const float ysum = (t + hsum) + cnt * gi.v[v];
+        dg.v[v] = __builtin_fmaf(a.v2[c], ysum, __builtin_fmaf(a.v0[c], hit[v], cnt * a.v1[c]));
+        dh.v[v] = __builtin_fmaf(a.v2[c], csy[v], __builtin_fmaf(a.v0[c], cdz[v], fcen * ((float)K * a.v1[c])));
+      }
+      store_row<V>(dst, dg);
+      store_row<V>(dst + Co, dh);
+    }
+  }
+}
+
 // ---- element-wise passes over the per-(query, channel) rows ------------------------------------------
 // Tile = 64 queries x CW channels (CW a power of two <= 64: Co is walked in its binary decomposition, so a
 // thread keeps ONE channel for the whole pass and its partial sums stay in registers).  The channel-major
@@ -1298,4 +1510,56 @@ extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const f
   else if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4, 4, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((pwmlp_support_kernel<1, 8, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_bwd_support");
+}
+
+extern "C" int cl3d_pwmlp_support_summary(const int32_t *idx, const float *query_xyz, const float *support_xyz,
+                                          const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K,
+                                          float radius, float *rec, uint32_t *ent, cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(B >= 0 && N >= 1 && M >= 1 && K >= 1, "pwmlp_support_summary: bad sizes");
+  CL3D_REQUIRE((long long)M * K <= 0x7fffffffLL, "pwmlp_support_summary: M*K too large");
+  if (N > (1 << 24)) return fail(CL3D_E_UNSUPPORTED, "pwmlp_support_summary: N=%d > 2^24 (centre index is stored in 24 bits)", N);
+  CL3D_REQUIRE(idx && query_xyz && support_xyz && inv_off && inv_slots && rec && ent && radius > 0.f,
+               "pwmlp_support_summary: null pointer");
+  if (B == 0) return CL3D_OK;
+  SumArgs a{};
+  a.idx = idx; a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.inv_off = inv_off; a.inv_slots = inv_slots;
+  a.rec = reinterpret_cast<float4 *>(rec); a.ent = ent;
+  a.B = B; a.N = N; a.M = M; a.K = K; a.inv_radius = 1.0f / radius; a.kmagic = div_magic(K);
+  const long long rows = (long long)B * N;
+  const int gx = round_grid((rows + 7) / 8, 16384);
+  hipLaunchKernelGGL(pwmlp_summary_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("cl3d_pwmlp_support_summary");
+}
+
+extern "C" int cl3d_pwmlp_bwd_support_sum(const float *ght, const float *wr, const float *cA, const float *cB,
+                                          const float *cD, const float *hit_cm, const float *dz_t, const float *sy_t,
+                                          const float *rec, const uint32_t *ent, int B, int N, int M, int K, int Co,
+                                          float *dght, cl3d_stream_t stream) {
+  using namespace cl3d;
+  PwArgs a{};
+  a.ght = ght; a.wr = wr; a.v0 = cA; a.v1 = cB; a.v2 = cD; a.hit_cm = hit_cm; a.dz_t = dz_t; a.sy_in = sy_t;
+  a.dght = dght;
+  a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co;
+  int rc = pw_check(a, "pwmlp_bwd_support_sum");
+  if (rc != CL3D_OK) return rc;
+  CL3D_REQUIRE(ght && wr && cA && cB && cD && hit_cm && dz_t && sy_t && rec && ent && dght,
+               "pwmlp_bwd_support_sum: null pointer");
+  if ((long long)M * Co * 4 > 0xffffffffLL) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support_sum: M*Co too large");
+  if (B == 0) return CL3D_OK;
+  const int V = (Co % 4 == 0) ? 4 : 1;
+  const LaneMap m = pick_lane_map(Co, V);
+  a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
+  const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
+  if (tiles > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support_sum: too many tiles");
+  const int gx = (int)tiles;  // one tile per workgroup
+  const float4 *s4 = reinterpret_cast<const float4 *>(rec);
+  static const int sb4 = [] {  // CL3D_PW_SB=4: four rows in flight per lane instead of eight (A/B timing)
+    const char *e = getenv("CL3D_PW_SB");
+    return (e != nullptr && e[0] == '4') ? 1 : 0;
+  }();
+  if (V == 4 && sb4) hipLaunchKernelGGL((pwmlp_support_sum_kernel<4, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a, s4, ent);
+  else if (V == 4) hipLaunchKernelGGL((pwmlp_support_sum_kernel<4, 8>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a, s4, ent);
+  else hipLaunchKernelGGL((pwmlp_support_sum_kernel<1, 8>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a, s4, ent);
+  return check_launch("cl3d_pwmlp_bwd_support_sum");
 }

@@ -159,6 +159,70 @@ def _join_inverse(idx):
         idx._cl3d_inverse = cached[:3] + (None,)
 
 
+# The PointWiseMLP's support-major backward pass either walks every slot of a support point's list (32 row gathers +
+# 32 query records per point at the metric shape) or a summary of the list built once per GEOMETRY (~8 rows per point;
+# support_summary below).  Building the summary costs about as much as one slot walk, so it pays when several operators
+# share the geometry -- the blocks of a backbone stage, which the model runs inside pt_utils.ball_query_cache() -- and
+# not for a lone operator (measured, round 3: 16 x 4096 backbone 8.17 -> 7.98 ms f32, 6.80 -> 6.62 ms bf16 per step;
+# the single-operator bench step 0.359 -> 0.385 ms).  'auto' = summary inside a ball_query_cache() context;
+# CL3D_PW_SUMMARY=1 / 0 force it.
+SUPPORT_SUMMARY = {'1': True, '0': False}.get(os.environ.get('CL3D_PW_SUMMARY', ''), 'auto')
+
+
+def _use_summary():
+    if SUPPORT_SUMMARY == 'auto':
+        return pt_utils._BQ_CACHE is not None
+    return bool(SUPPORT_SUMMARY)
+
+
+def support_summary(idx, n_support, query_xyz, support_xyz, radius, prefetch=False):
+    """What the PointWiseMLP's support-major backward pass needs of every support point's slot list, boiled down
+    once per geometry (csrc/fused_pwmlp.hip, pwmlp_summary_kernel): (rec [B,N,8], ent [B,M*K]); memoised on idx
+    like the CSR inverse it is built from, so every operator of a backbone stage shares one.
+
+    prefetch=True (forward pass, when a backward will follow): queued on the index stream right behind the CSR
+    build; the backward's support pass is the first (and only) consumer and waits for it there -- joining it at the
+    end of the forward pass would put ~30 us of geometry work in front of the first backward kernel."""
+    key = (n_support, float(radius), query_xyz.data_ptr(), support_xyz.data_ptr())
+    cached = getattr(idx, '_cl3d_summary', None)
+    if cached is not None and cached[0] == key:
+        if not prefetch and cached[3] is not None:
+            torch.cuda.current_stream(idx.device).wait_event(cached[3])
+            idx._cl3d_summary = cached[:3] + (None,)
+        return cached[1], cached[2]
+    B, M, K = idx.shape
+    lib = _lib.lib()
+
+    def build(off, slots):
+        rec = torch.empty((B, n_support, 8), dtype=torch.float32, device=idx.device)
+        ent = torch.empty((B, M * K), dtype=torch.int32, device=idx.device)
+        with _lib.on_device(idx.device):
+            _lib.check(lib.cl3d_pwmlp_support_summary(_p(idx), _p(query_xyz), _p(support_xyz), _p(off), _p(slots), B,
+                                                      n_support, M, K, float(radius), _p(rec), _p(ent), _stream(idx)))
+        return rec, ent
+
+    ev = None
+    if prefetch and pt_utils.async_index():
+        main, side = torch.cuda.current_stream(idx.device), pt_utils.index_stream(idx.device, 1)
+        off, slots = inverse_index(idx, n_support, prefetch=True)  # queued on `side` (or already there)
+        with torch.cuda.stream(side):
+            # behind the CSR build on the same stream, which waited for the ball query, which waited for the
+            # coordinates: nothing to wait for (and no wait on the stream's own event: a self-wait inside a capture
+            # crashed hipStreamEndCapture)
+            rec, ent = build(off, slots)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        if not torch.cuda.is_current_stream_capturing():
+            rec.record_stream(main)
+            ent.record_stream(main)
+            query_xyz.record_stream(side)
+            support_xyz.record_stream(side)
+    else:  # (a prefetch without a side stream builds here and now: the backward pass looks for the finished summary)
+        rec, ent = build(*inverse_index(idx, n_support))
+    idx._cl3d_summary = (key, rec, ent, ev)
+    return rec, ent
+
+
 def _transposed(t):
     """[B,R,C] -> contiguous [B,C,R] through the engine's tiled transpose (channel-major <-> point-major rows)."""
     t = t.contiguous()
@@ -512,9 +576,15 @@ class _PointwiseMLP(Function):
             hits()
             off, slots = inverse_index(idx, N)
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
-            _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t), _p(sy),
-                                                  _p(qtab), _p(support_xyz), ctx.radius, _p(off), _p(slots),
-                                                  B, N, M, K, Co, _p(dght), st))
+            # the forward pass decided (and prefetched); a summary left by another operator of the stage is used too
+            if N <= (1 << 24) and (getattr(idx, '_cl3d_summary', None) is not None or SUPPORT_SUMMARY is True):
+                rec, ent = support_summary(idx, N, query_xyz, support_xyz, ctx.radius)
+                _lib.check(lib.cl3d_pwmlp_bwd_support_sum(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t),
+                                                          _p(sy), _p(rec), _p(ent), B, N, M, K, Co, _p(dght), st))
+            else:
+                _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t), _p(sy),
+                                                      _p(qtab), _p(support_xyz), ctx.radius, _p(off), _p(slots),
+                                                      B, N, M, K, Co, _p(dght), st))
         return (dght, dwr, dgamma, dbeta) + (None,) * 12
 
 
@@ -785,6 +855,8 @@ def pointwise_bottleneck(conv1, la, conv2, shortcut, query_xyz, support_xyz, que
     params = (c1.weight, bn1.weight, bn1.bias, mconv.weight, mbn.weight, mbn.bias, c2.weight, bn2.weight, bn2.bias)
     need_grad = _wants_grad(features, identity, *params)
     idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, la.radius, la.nsample, need_grad)
+    if need_grad and _use_summary():
+        support_summary(idx, support_xyz.shape[1], query_xyz, support_xyz, la.radius, prefetch=True)
     y1 = _Conv1x1.apply(features, c1.weight.view(C1, -1), prec)
     ght, wr = _BnReluPointRows.apply(y1, bn1.weight, bn1.bias, bn1, mconv.weight.view(Cla, 3 + 2 * C1), prec)
     rows, scale, shift = _PointwiseMLP.apply(ght, wr, mbn.weight, mbn.bias, mbn.running_mean, mbn.running_var,
@@ -809,8 +881,10 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
     assert reduction == 'max'
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     conv, bn = mlps.conv0[0], mlps.conv0[1]
-    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
-                    training and _wants_grad(features, conv.weight, bn.weight, bn.bias))
+    need_grad = training and _wants_grad(features, conv.weight, bn.weight, bn.bias)
+    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad)
+    if need_grad and _use_summary():
+        support_summary(idx, support_xyz.shape[1], query_xyz, support_xyz, radius, prefetch=True)
     C = features.shape[1]
     Co = conv.weight.shape[0]
     W = conv.weight.view(Co, 3 + 2 * C)

@@ -362,6 +362,23 @@ int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const float *cA, c
                            const float *qtab, const float *support_xyz, float radius,
                            const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K, int Co,
                            float *dght, cl3d_stream_t stream);
+/* The same pass on a summary of every support point's slot list (round 3).  The centre of query j is idx[j, 0], the
+ * lowest support index in j's ball (reference local_aggregation_operators.py:290 takes slot 0 as the centre), so the
+ * ~K slots of a support point name only a handful of distinct centre rows.  cl3d_pwmlp_support_summary boils the CSR
+ * lists down, once per geometry (idx + coordinates + radius; every operator of a backbone stage shares it):
+ *   rec [B,N,8] = {sum of the list's relative positions (p_i - q_j) / radius (3 floats), then as int bits: s0 =
+ *                  inv_off[i], list length, pair count, centred count, 0}
+ *   ent [B,M*K] = per support point: pairs  centre | count << 24  forward from s0; the ids of the queries centred on
+ *                 the point itself (slots (j, 0)) backward from s0 + length - 1
+ * and cl3d_pwmlp_bwd_support_sum gathers one row per entry (~8 at the metric shape) instead of one per slot (32).
+ * Needs N <= 2^24.  Results agree with cl3d_pwmlp_bwd_support to rounding (count * row instead of repeated adds). */
+int cl3d_pwmlp_support_summary(const int32_t *idx, const float *query_xyz, const float *support_xyz,
+                               const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K,
+                               float radius, float *rec, uint32_t *ent, cl3d_stream_t stream);
+int cl3d_pwmlp_bwd_support_sum(const float *ght, const float *wr, const float *cA, const float *cB,
+                               const float *cD, const float *hit_cm, const float *dz_t, const float *sy_t,
+                               const float *rec, const uint32_t *ent, int B, int N, int M, int K, int Co,
+                               float *dght, cl3d_stream_t stream);
 
 #ifdef __cplusplus
 }
