@@ -646,22 +646,20 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
 }
 
 // ---- the support-major pass on a SUMMARY of every support point's slot list -----------------------------------
-// Everything pwmlp_support_kernel reads per slot is a function of the geometry alone: the relative position (summed
-// over the list) and WHICH centre's H row the slot adds.  The centre of query j is idx[j, 0] -- the lowest support
-// index inside j's ball -- so the queries around one support point share a handful of centres: at the metric shape a
-// list of 32 slots names 6.7 distinct rows on average (19 at most), and one query in 32 is centred on the point
-// itself.  pwmlp_summary_kernel boils a list down, once per geometry (it depends on idx and the coordinates only, so
-// every operator of a backbone stage shares it, like the CSR inverse it is built from), to
-//     rec[b, i] = {sum_s rel_s (3 floats), s0 = inv_off[i] | list length, pair count, centred count, -}   (32 bytes)
-//     ent[b, s0 ...]            pairs    centre index | count << 24      (forward from the start of the list's range)
-//     ent[b, ... s0 + len - 1]  centred  query id (slot (j, 0): the query is centred on i; its sum_k y / dz rows feed
-//                                        dH_i)                            (backward from the end of the range)
-// and pwmlp_support_sum_kernel gathers ~8 rows per support point instead of 32 rows + 32 query records.  A list never
-// has more entries than slots, so both runs fit its range of the slot table's shape.
-// Half a wave per support point, 32 slots per round.  The distinct centres of a round are peeled off one per
-// iteration (leader = first unprocessed lane of the half, ballot of the lanes that name the same centre), in
-// first-appearance order, so the table is a pure function of the CSR table.  Pairs are not merged across rounds (a
-// list longer than 32 slots has a few more entries than distinct centres).
+// Everything pwmlp_support_kernel works out per slot before it can gather -- which row of the tile a CSR position
+// belongs to (a search), the slot's query record (a 16-byte gather), the relative position, whose H row the slot
+// adds -- is a function of the geometry alone.  pwmlp_summary_kernel does that once per geometry (it depends on idx
+// and the coordinates only, so every operator of a backbone stage shares it, like the CSR inverse it is built from):
+//     rec[b, i] = {sum_s rel_s (3 floats), s0 = inv_off[i] | list length, centre-row count, centred count, -}  (32 B)
+//     ent[b, s0 ...]            the centre idx[j, 0] of every slot (j, k > 0) of the list, forward from its start
+//     ent[b, ... s0 + len - 1]  the query id j of every slot (j, 0) -- the query is centred on i itself; its
+//                               sum_k y / dz rows feed dH_i -- backward from the end of the list's range
+// and pwmlp_support_sum_kernel is left with the gathers: one H half-row per entry of the first run, two query-major
+// rows per entry of the second.
+// (The centre of a query is its NEAREST support point -- the ball query orders a list by distance -- so the slots of a
+// list name as many distinct centres as it has slots: a first version that merged equal centres of a list into
+// (centre, count) pairs, by a per-wave hash table in LDS, found nothing to merge outside duplicated points and was
+// dropped for this plain form: 35.5 -> see DESIGN.md for the measured times.)
 struct SumArgs {
   const int *idx;
   const float *query_xyz, *support_xyz;
@@ -673,26 +671,50 @@ struct SumArgs {
   unsigned kmagic;
 };
 
-__device__ __forceinline__ float half_wave_sum(float v) {  // butterfly over 32 lanes: every lane ends with the same bits
-#pragma unroll
-  for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, CL3D_WAVE);
-  return v;
+// sum over the wave by DPP (quad swaps, row mirrors, row broadcasts: ~8 cycles a step where a ds_bpermute butterfly
+// pays an LDS round trip per step), fixed order; the total is returned to every lane
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+#define CL3D_DPP_ADD(ctrl, rmask) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
+  CL3D_DPP_ADD(0xB1, 0xf);   // quad_perm [1,0,3,2]
+  CL3D_DPP_ADD(0x4E, 0xf);   // quad_perm [2,3,0,1]
+  CL3D_DPP_ADD(0x141, 0xf);  // row_half_mirror
+  CL3D_DPP_ADD(0x140, 0xf);  // row_mirror: every lane holds its row's 16-lane sum
+  CL3D_DPP_ADD(0x142, 0xa);  // row_bcast15 into rows 1 and 3
+  CL3D_DPP_ADD(0x143, 0xc);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+#undef CL3D_DPP_ADD
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// One wave per support point, 64 slots per round; a wave walks its points with the next point's row bounds and first
+// slots already requested (the chain row bounds -> slots -> centre / coordinates would otherwise be three exposed
+// round trips per point).  Entries keep the CSR order of their slots (ballot + prefix count), so the table is a pure
+// function of the CSR table.
 __global__ __launch_bounds__(256) void pwmlp_summary_kernel(SumArgs a) {
   const int lane = lane_id();
-  const int half = lane >> 5, hl = lane & 31;
   const int wave = threadIdx.x >> 6;
   const int K = a.K, N = a.N, MK = a.M * a.K;
   const long long rows = (long long)a.B * N;
-  const unsigned long long mine_mask = half ? 0xffffffff00000000ull : 0x00000000ffffffffull;
-  for (long long r0 = ((long long)blockIdx.x * 4 + wave) * 2; r0 < rows; r0 += (long long)gridDim.x * 8) {
-    const long long r = r0 + half;
-    const bool row_on = r < rows;
-    const long long rc = row_on ? r : rows - 1;
-    const int b = (int)(rc / N), i = (int)(rc - (long long)b * N);
+  const long long stride = (long long)gridDim.x * 4;
+  long long r = (long long)blockIdx.x * 4 + wave;
+  if (r >= rows) return;
+  auto bounds = [&](long long rr, int &b, int &i, int &s0, int &s1) {  // clamped: past the end = an empty list
+    const long long rc = rr < rows ? rr : rows - 1;
+    b = (int)(rc / N);
+    i = (int)(rc - (long long)b * N);
     const int *off = a.inv_off + (size_t)b * (N + 1);
-    const int s0 = off[i], s1 = row_on ? off[i + 1] : s0;
+    s0 = off[i];
+    s1 = rr < rows ? off[i + 1] : s0;
+  };
+  int b, i, s0, s1, bn, in, s0n, s1n;
+  bounds(r, b, i, s0, s1);
+  bounds(r + stride, bn, in, s0n, s1n);
+  int sl = s0 + lane < s1 ? a.inv_slots[(size_t)b * MK + s0 + lane] : 0;
+  for (; r < rows; r += stride) {
+    // requested now, used in the next iteration
+    const int sl_next = s0n + lane < s1n ? a.inv_slots[(size_t)bn * MK + s0n + lane] : 0;
+    int bnn, inn, s0nn, s1nn;
+    bounds(r + 2 * stride, bnn, inn, s0nn, s1nn);
     const float *p = a.support_xyz + ((size_t)b * N + i) * 3;
     const float px = p[0], py = p[1], pz = p[2];
     const int *slots = a.inv_slots + (size_t)b * MK;
@@ -701,158 +723,227 @@ __global__ __launch_bounds__(256) void pwmlp_summary_kernel(SumArgs a) {
     unsigned *ent = a.ent + (size_t)b * MK;
     float rx = 0.f, ry = 0.f, rz = 0.f;
     int npair = 0, ncen = 0;
-    for (int c0 = s0; __ballot(c0 < s1) != 0ull; c0 += 32) {
-      const int e = c0 + hl;
-      const bool valid = e < s1;
-      const int sl = valid ? slots[e] : 0;
+    for (int c0 = s0; c0 < s1; c0 += CL3D_WAVE) {
+      const bool valid = c0 + lane < s1;
+      if (c0 > s0) sl = valid ? slots[c0 + lane] : 0;  // (lists longer than one round: not prefetched)
       const int j = div_k(sl, a.kmagic, K);
-      const int cen = idxb[j * K];
+      const unsigned cen = (unsigned)idxb[j * K];
       const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
-      // the forward pass's own expression for rel (pwmlp_query_kernel's slot record)
-      rx += half_wave_sum(valid ? (px - qx) * a.inv_radius : 0.f);
-      ry += half_wave_sum(valid ? (py - qy) * a.inv_radius : 0.f);
-      rz += half_wave_sum(valid ? (pz - qz) * a.inv_radius : 0.f);
+      // the forward pass's own expression for rel (pwmlp_query_kernel's slot record), per-lane running sums
+      rx += valid ? (px - qx) * a.inv_radius : 0.f;
+      ry += valid ? (py - qy) * a.inv_radius : 0.f;
+      rz += valid ? (pz - qz) * a.inv_radius : 0.f;
       const bool centred = valid && sl - j * K == 0;
-      const bool pairable = valid && !centred;
-      unsigned long long rem = __ballot(pairable);
-      unsigned mine = 0u;
-      int np = 0;  // pairs of this round, uniform inside a half
-      while (rem != 0ull) {
-        const unsigned lo = (unsigned)rem, hi = (unsigned)(rem >> 32);
-        const int t_lo = __builtin_amdgcn_readlane(cen, lo != 0u ? __builtin_ctz(lo) : 0);
-        const int t_hi = __builtin_amdgcn_readlane(cen, hi != 0u ? 32 + __builtin_ctz(hi) : 32);
-        const bool busy = (half ? hi : lo) != 0u;  // this half still has a centre to peel
-        const int t = half ? t_hi : t_lo;
-        const unsigned long long same = __ballot(busy && pairable && cen == t && (rem >> lane & 1ull) != 0ull);
-        const int n = __builtin_popcountll(same & mine_mask);
-        if (busy && hl == np) mine = (unsigned)t | ((unsigned)n << 24);
-        np += busy ? 1 : 0;
-        rem &= ~same;
-      }
-      const unsigned long long cm = __ballot(centred) & mine_mask;
-      if (hl < np) ent[s0 + npair + hl] = mine;
-      if (centred) ent[s1 - 1 - ncen - __builtin_popcountll(cm & ((1ull << lane) - 1ull))] = (unsigned)j;
-      npair += np;
+      const bool other = valid && !centred;
+      const unsigned long long om = __ballot(other), cm = __ballot(centred);
+      if (other) ent[s0 + npair + prefix_popc(om)] = cen;
+      if (centred) ent[s1 - 1 - ncen - prefix_popc(cm)] = (unsigned)j;
+      npair += __builtin_popcountll(om);
       ncen += __builtin_popcountll(cm);
     }
-    if (row_on && hl == 0) {
+    rx = wave_sum_dpp(rx);
+    ry = wave_sum_dpp(ry);
+    rz = wave_sum_dpp(rz);
+    if (lane == 0) {
       a.rec[2 * r] = make_float4(rx, ry, rz, __int_as_float(s0));
       a.rec[2 * r + 1] = make_float4(__int_as_float(s1 - s0), __int_as_float(npair), __int_as_float(ncen), 0.f);
     }
+    b = bn; i = in; s0 = s0n; s1 = s1n; sl = sl_next;
+    bn = bnn; in = inn; s0n = s0nn; s1n = s1nn;
   }
 }
 
-// dG_i, dH_i from the summary.  A lane group (L lanes x V channels) owns one support point.  Three dependent round
-// trips per point whatever its list: the 32-byte record (with the point's own row and its arg-max term, which do not
-// depend on it) -> the entries, one per lane of the group, handed round by shuffles -> the rows, SB at a time: an H
-// half-row of ght per pair, the forward pass's sum_k y row and the dz row per centred query.  No LDS, no barriers.
+// dG_i, dH_i from the summary.  A lane group (L lanes x V channels) owns one support point of a tile of 4 * QW points;
+// persistent workgroups walk the tiles.  A point costs three dependent round trips -- the 32-byte record -> the
+// entries, one per lane of the group, handed round by shuffles -> the rows (an H half-row of ght per pair, the forward
+// pass's sum_k y row and the dz row per centred query), SB at a time -- and the first two are taken off the path: a
+// group holds the record of its point in the NEXT tile and requests that point's entries, and the record of the tile
+// after, before it gathers the current point's rows.  (Measured, round 3: this prefetching bought nothing -- 45.2 us
+// with, 46.0 without; the pass moves 537 MB of gathered rows and ~120 MB of streams, and 2.1 M random 256-byte row
+// gathers alone take 25 us on this chip, scripts/micro/gather_pitch.hip.)
+// The arg-max term hit_cm is channel-major: the tile's [channels][points] block is fetched in 16-byte pieces along
+// the points by the whole workgroup and turned through LDS (read straight from the lanes it cost one 128-byte line
+// per (channel, lane) -- as many L2 requests as everything else in the pass together); the per-channel constants of
+// the epilogue sit in LDS too.
 template <int V, int SB>
-__global__ __launch_bounds__(256) void pwmlp_support_sum_kernel(PwArgs a, const float4 *__restrict__ rec,
+__global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, const float4 *__restrict__ rec,
                                                                 const unsigned *__restrict__ ent) {
+  __shared__ float s_hit[1280];   // [L * V channels][TR + 1]: L * V * (256 / L + 1) <= 4 * (256 + 64) floats
+  __shared__ float s_con[6][256]; // wr (3), A, Bc, D of the chunk's L * V <= 256 channels
   const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
   const int row = 2 * Co;
   const unsigned rowb = (unsigned)row * 4u;
   const int MK = M * K;
-  const int TR = 4 * QW;
+  const int TR = 4 * QW, LV = L * V;
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int g = lane / L, cl = lane - g * L;
   const int tiles_per_cloud = (N + TR - 1) / TR;
-  if (g >= QW) return;  // lanes past the last whole group (64 % L) never take part, shuffles included
+  const int ntiles = a.B * tiles_per_cloud;
+  const bool grp_on = g < QW;  // lanes past the last whole group (64 % L) only keep the barriers
+  struct Rec {
+    float4 a, b;
+  };
+  // the record of this lane group's point in tile t (zeros = an empty list past the end)
+  auto fetch = [&](int t, int &b, int &i) {
+    Rec r{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+    b = 0;
+    i = N;
+    if (t < ntiles) {
+      int tr;
+      decode_tile(t, a.B, tiles_per_cloud, b, tr);
+      i = tr * TR + wave * QW + g;
+      if (grp_on && i < N) {
+        const size_t p = (size_t)b * N + i;
+        r.a = rec[2 * p];
+        r.b = rec[2 * p + 1];
+      }
+    }
+    return r;
+  };
   for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {
     // a lane whose channels lie past Co (last chunk) still carries entries for its group: it reads channel 0's
     // pieces and stores nothing
     const bool chan_on = (ch * L + cl) * V < Co;
     const int c0 = chan_on ? (ch * L + cl) * V : 0;
-    {  // one tile per workgroup (not persistent: nothing for the compiler to hoist out of a tile loop into VGPRs)
-      const int tile = blockIdx.x;
-      int b, tr;
-      decode_tile(tile, a.B, tiles_per_cloud, b, tr);
-      const int i = tr * TR + wave * QW + g;
-      if (i >= N) continue;  // whole groups leave together
-      const size_t r = (size_t)b * N + i;
-      const float4 ra = rec[2 * r], rb = rec[2 * r + 1];
-      const char *own = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
-      const Vec<V> gi = load_row<V>(reinterpret_cast<const float *>(own + ((unsigned)i * rowb + (unsigned)c0 * 4u)));
-      const Vec<V> hi = load_row<V>(reinterpret_cast<const float *>(own + ((unsigned)i * rowb + ((unsigned)Co + (unsigned)c0) * 4u)));
-      float hit[V];
-#pragma unroll
-      for (int v = 0; v < V; ++v) hit[v] = a.hit_cm[((size_t)b * Co + c0 + v) * N + i];
-      const int s0 = __float_as_int(ra.w), len = __float_as_int(rb.x);
-      const int npair = __float_as_int(rb.y), ncen = __float_as_int(rb.z);
-      const unsigned *myent = ent + (size_t)b * MK + s0;
-      // uniform bases + 32-bit lane offsets: the gathers are saddr + voffset loads (one VGPR per address)
-      const char *hrows = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
-      const char *syrows = reinterpret_cast<const char *>(a.sy_in + (size_t)b * M * Co);
-      const char *dzrows = reinterpret_cast<const char *>(a.dz_t + (size_t)b * M * Co);
-      const unsigned h_off = ((unsigned)Co + (unsigned)c0) * 4u, q_off = (unsigned)c0 * 4u;
-      // first round of both runs requested together
-      unsigned wp = cl < npair ? myent[cl] : 0u;
-      unsigned wc = cl < ncen ? myent[len - 1 - cl] : 0u;
+    const int cbase = ch * LV;
+    __syncthreads();  // the previous chunk's readers are done with the constants
+    for (int t = threadIdx.x; t < LV; t += 256) {
+      const int c = cbase + t < Co ? cbase + t : Co - 1;
+      s_con[0][t] = a.wr[c * 3 + 0]; s_con[1][t] = a.wr[c * 3 + 1]; s_con[2][t] = a.wr[c * 3 + 2];
+      s_con[3][t] = a.v0[c]; s_con[4][t] = a.v1[c]; s_con[5][t] = a.v2[c];
+    }
+    int tile = blockIdx.x;
+    int b, i, bn, in;
+    Rec cur = fetch(tile, b, i);
+    Rec nxt = fetch(tile + gridDim.x, bn, in);
+    unsigned wp = 0u, wc = 0u;
+    {
+      const int s0 = __float_as_int(cur.a.w), len = __float_as_int(cur.b.x);
+      const unsigned *e = ent + (size_t)b * MK + s0;
+      if (cl < __float_as_int(cur.b.y)) wp = e[cl];
+      if (cl < __float_as_int(cur.b.z)) wc = e[len - 1 - cl];
+    }
+    for (; tile < ntiles; tile += gridDim.x) {
+      const bool row_on = grp_on && i < N;
+      int tb, tr;
+      decode_tile(tile, a.B, tiles_per_cloud, tb, tr);  // workgroup-uniform (b, i belong to the lane group)
+      const int i0 = tr * TR;
+      // --- requests for later: the next tile's first entries, the record of the tile after it
+      unsigned wpn = 0u, wcn = 0u;
+      {
+        const int s0 = __float_as_int(nxt.a.w), len = __float_as_int(nxt.b.x);
+        const unsigned *e = ent + (size_t)bn * MK + s0;
+        if (cl < __float_as_int(nxt.b.y)) wpn = e[cl];
+        if (cl < __float_as_int(nxt.b.z)) wcn = e[len - 1 - cl];
+      }
+      int bnn, inn;
+      const Rec nn = fetch(tile + 2 * gridDim.x, bnn, inn);
+      // --- this tile: arg-max terms (to LDS below), the point's own row
+      float4 h4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool hit_vec = (N & 3) == 0 && LV * (TR / 4) <= 256;
+      if (hit_vec) {
+        const int q4 = TR / 4, cc = threadIdx.x / q4, qd = threadIdx.x - cc * q4;
+        if (cc < LV && cbase + cc < Co && i0 + qd * 4 < N)
+          h4 = *reinterpret_cast<const float4 *>(a.hit_cm + ((size_t)tb * Co + cbase + cc) * N + i0 + qd * 4);
+      }
       float shc[V], csy[V], cdz[V];
+      Vec<V> gi, hi;
 #pragma unroll
-      for (int v = 0; v < V; ++v) shc[v] = csy[v] = cdz[v] = 0.f;
-      for (int p0 = 0; p0 < npair; p0 += L) {
-        if (p0 > 0) wp = p0 + cl < npair ? myent[p0 + cl] : 0u;
-        const int nr = npair - p0 < L ? npair - p0 : L;
-        for (int u0 = 0; u0 < nr; u0 += SB) {
-          unsigned en[SB];
-          Vec<V> rr[SB];
+      for (int v = 0; v < V; ++v) shc[v] = csy[v] = cdz[v] = gi.v[v] = hi.v[v] = 0.f;
+      if (row_on) {
+        const char *own = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
+        gi = load_row<V>(reinterpret_cast<const float *>(own + ((unsigned)i * rowb + (unsigned)c0 * 4u)));
+        hi = load_row<V>(reinterpret_cast<const float *>(own + ((unsigned)i * rowb + ((unsigned)Co + (unsigned)c0) * 4u)));
+        const int s0 = __float_as_int(cur.a.w), len = __float_as_int(cur.b.x);
+        const int npair = __float_as_int(cur.b.y), ncen = __float_as_int(cur.b.z);
+        const unsigned *myent = ent + (size_t)b * MK + s0;
+        // uniform bases + 32-bit lane offsets: the gathers are saddr + voffset loads (one VGPR per address)
+        const char *hrows = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
+        const char *syrows = reinterpret_cast<const char *>(a.sy_in + (size_t)b * M * Co);
+        const char *dzrows = reinterpret_cast<const char *>(a.dz_t + (size_t)b * M * Co);
+        const unsigned h_off = ((unsigned)Co + (unsigned)c0) * 4u, q_off = (unsigned)c0 * 4u;
+        for (int p0 = 0; p0 < npair; p0 += L) {
+          if (p0 > 0) wp = p0 + cl < npair ? myent[p0 + cl] : 0u;
+          const int nr = npair - p0 < L ? npair - p0 : L;
+          for (int u0 = 0; u0 < nr; u0 += SB) {
+            unsigned en[SB];
+            Vec<V> rr[SB];
 #pragma unroll
-          for (int u = 0; u < SB; ++u) en[u] = (unsigned)__shfl((int)wp, g * L + (u0 + u < nr ? u0 + u : nr - 1), CL3D_WAVE);
+            for (int u = 0; u < SB; ++u) en[u] = (unsigned)__shfl((int)wp, g * L + (u0 + u < nr ? u0 + u : nr - 1), CL3D_WAVE);
 #pragma unroll
-          for (int u = 0; u < SB; ++u) rr[u] = load_row<V>(reinterpret_cast<const float *>(hrows + (__umul24(en[u] & 0xffffffu, rowb) + h_off)));
+            for (int u = 0; u < SB; ++u) rr[u] = load_row<V>(reinterpret_cast<const float *>(hrows + (en[u] * rowb + h_off)));
 #pragma unroll
-          for (int u = 0; u < SB; ++u) {
-            const float w = u0 + u < nr ? (float)(en[u] >> 24) : 0.f;
+            for (int u = 0; u < SB; ++u) {
+              if (u0 + u >= nr) continue;
 #pragma unroll
-            for (int v = 0; v < V; ++v) shc[v] = __builtin_fmaf(w, rr[u].v[v], shc[v]);
+              for (int v = 0; v < V; ++v) shc[v] += rr[u].v[v];
+            }
           }
         }
-      }
-      for (int p0 = 0; p0 < ncen; p0 += L) {
-        if (p0 > 0) wc = p0 + cl < ncen ? myent[len - 1 - p0 - cl] : 0u;
-        const int nr = ncen - p0 < L ? ncen - p0 : L;
-        constexpr int SC = SB / 2;
-        for (int u0 = 0; u0 < nr; u0 += SC) {
-          unsigned en[SC];
-          Vec<V> ry[SC], rd[SC];
+        for (int p0 = 0; p0 < ncen; p0 += L) {
+          if (p0 > 0) wc = p0 + cl < ncen ? myent[len - 1 - p0 - cl] : 0u;
+          const int nr = ncen - p0 < L ? ncen - p0 : L;
+          constexpr int SC = SB / 2;
+          for (int u0 = 0; u0 < nr; u0 += SC) {
+            unsigned en[SC];
+            Vec<V> ry[SC], rd[SC];
 #pragma unroll
-          for (int u = 0; u < SC; ++u) en[u] = (unsigned)__shfl((int)wc, g * L + (u0 + u < nr ? u0 + u : nr - 1), CL3D_WAVE);
+            for (int u = 0; u < SC; ++u) en[u] = (unsigned)__shfl((int)wc, g * L + (u0 + u < nr ? u0 + u : nr - 1), CL3D_WAVE);
 #pragma unroll
-          for (int u = 0; u < SC; ++u) {
-            const unsigned o = en[u] * ((unsigned)Co * 4u) + q_off;
-            ry[u] = load_row<V>(reinterpret_cast<const float *>(syrows + o));
-            rd[u] = load_row<V>(reinterpret_cast<const float *>(dzrows + o));
-          }
+            for (int u = 0; u < SC; ++u) {
+              const unsigned o = en[u] * ((unsigned)Co * 4u) + q_off;
+              ry[u] = load_row<V>(reinterpret_cast<const float *>(syrows + o));
+              rd[u] = load_row<V>(reinterpret_cast<const float *>(dzrows + o));
+            }
 #pragma unroll
-          for (int u = 0; u < SC; ++u) {
-            if (u0 + u >= nr) continue;
+            for (int u = 0; u < SC; ++u) {
+              if (u0 + u >= nr) continue;
 #pragma unroll
-            for (int v = 0; v < V; ++v) {
-              csy[v] += ry[u].v[v];
-              cdz[v] += rd[u].v[v];
+              for (int v = 0; v < V; ++v) {
+                csy[v] += ry[u].v[v];
+                cdz[v] += rd[u].v[v];
+              }
             }
           }
         }
       }
-      if (!chan_on) continue;
-      const float cnt = (float)len, fcen = (float)ncen;
-      float *dst = a.dght + r * row + c0;
-      Vec<V> dg, dh;
-#pragma unroll
-      for (int v = 0; v < V; ++v) {
-        const int c = c0 + v;
-        float t = a.wr[c * 3 + 0] * ra.x;
-        t = __builtin_fmaf(a.wr[c * 3 + 1], ra.y, t);
-        t = __builtin_fmaf(a.wr[c * 3 + 2], ra.z, t);
-        const float hsum = __builtin_fmaf(fcen, hi.v[v], shc[v]);  // the centred queries' centre is this very point
-        const float ysum = (t + hsum) + cnt * gi.v[v];
-        dg.v[v] = __builtin_fmaf(a.v2[c], ysum, __builtin_fmaf(a.v0[c], hit[v], cnt * a.v1[c]));
-        dh.v[v] = __builtin_fmaf(a.v2[c], csy[v], __builtin_fmaf(a.v0[c], cdz[v], fcen * ((float)K * a.v1[c])));
+      __syncthreads();  // the previous tile's readers are done with s_hit (and the constants are written)
+      if (hit_vec) {
+        const int q4 = TR / 4, cc = threadIdx.x / q4, qd = threadIdx.x - cc * q4;
+        if (cc < LV) {
+          float *d = s_hit + cc * (TR + 1) + qd * 4;
+          d[0] = h4.x; d[1] = h4.y; d[2] = h4.z; d[3] = h4.w;
+        }
+      } else {
+        for (int t = threadIdx.x; t < LV * TR; t += 256) {
+          const int cc = t / TR, ii = t - cc * TR;
+          if (cbase + cc < Co && i0 + ii < N) s_hit[cc * (TR + 1) + ii] = a.hit_cm[((size_t)tb * Co + cbase + cc) * N + i0 + ii];
+        }
       }
-      store_row<V>(dst, dg);
-      store_row<V>(dst + Co, dh);
+      __syncthreads();
+      if (row_on && chan_on) {
+        const float cnt = (float)__float_as_int(cur.b.x), fcen = (float)__float_as_int(cur.b.z);
+        float *dst = a.dght + ((size_t)b * N + i) * row + c0;
+        Vec<V> dg, dh;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+          const int cc = cl * V + v;
+          const float hit = s_hit[cc * (TR + 1) + (i - i0)];
+          float t = s_con[0][cc] * cur.a.x;
+          t = __builtin_fmaf(s_con[1][cc], cur.a.y, t);
+          t = __builtin_fmaf(s_con[2][cc], cur.a.z, t);
+          const float cA = s_con[3][cc], cB = s_con[4][cc], cD = s_con[5][cc];
+          const float hsum = __builtin_fmaf(fcen, hi.v[v], shc[v]);  // the centred queries' centre is this very point
+          const float ysum = (t + hsum) + cnt * gi.v[v];
+          dg.v[v] = __builtin_fmaf(cD, ysum, __builtin_fmaf(cA, hit, cnt * cB));
+          dh.v[v] = __builtin_fmaf(cD, csy[v], __builtin_fmaf(cA, cdz[v], fcen * ((float)K * cB)));
+        }
+        store_row<V>(dst, dg);
+        store_row<V>(dst + Co, dh);
+      }
+      cur = nxt; b = bn; i = in; wp = wpn; wc = wcn;
+      nxt = nn; bn = bnn; in = inn;
     }
   }
 }
@@ -1002,7 +1093,7 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
             acc[4] += (double)(dz * rel[u].z);
           }
         }
-        if (q == 0 && tid < nj) {  // the query table of the support-major pass: {coordinates, centre idx[j, 0]}
+        if (a.qtab != nullptr && q == 0 && tid < nj) {  // the query table of the slot-walking support pass: {coordinates, centre idx[j, 0]}
           const size_t j = (size_t)b * M + j0 + tid;
           const float *qp = a.query_xyz + j * 3;
           a.qtab[j] = make_float4(qp[0], qp[1], qp[2], __int_as_float(a.idx[j * K]));
@@ -1443,8 +1534,8 @@ extern "C" int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, co
   using namespace cl3d;
   CL3D_REQUIRE(B >= 0 && N >= 1 && M >= 1 && K >= 1 && K <= 255 && Co >= 1 && radius > 0.f, "pwmlp_bwd_rows: bad sizes");
   CL3D_REQUIRE(gout && ystar_t && kstar_t && idx && query_xyz && support_xyz && scale && shift && mean && invstd && dz_cm && ts_cm &&
-                   dz_t && qtab && partial,
-               "pwmlp_bwd_rows: null pointer");
+                   dz_t && partial,
+               "pwmlp_bwd_rows: null pointer");  // qtab may be null: only cl3d_pwmlp_bwd_support reads it
   CL3D_REQUIRE(n_partials == cl3d_pwmlp_partials(B, M, Co), "pwmlp_bwd_rows: wrong partial block count");
   if (B == 0) return CL3D_OK;
   RowArgs a{};
@@ -1518,7 +1609,6 @@ extern "C" int cl3d_pwmlp_support_summary(const int32_t *idx, const float *query
   using namespace cl3d;
   CL3D_REQUIRE(B >= 0 && N >= 1 && M >= 1 && K >= 1, "pwmlp_support_summary: bad sizes");
   CL3D_REQUIRE((long long)M * K <= 0x7fffffffLL, "pwmlp_support_summary: M*K too large");
-  if (N > (1 << 24)) return fail(CL3D_E_UNSUPPORTED, "pwmlp_support_summary: N=%d > 2^24 (centre index is stored in 24 bits)", N);
   CL3D_REQUIRE(idx && query_xyz && support_xyz && inv_off && inv_slots && rec && ent && radius > 0.f,
                "pwmlp_support_summary: null pointer");
   if (B == 0) return CL3D_OK;
@@ -1527,7 +1617,7 @@ extern "C" int cl3d_pwmlp_support_summary(const int32_t *idx, const float *query
   a.rec = reinterpret_cast<float4 *>(rec); a.ent = ent;
   a.B = B; a.N = N; a.M = M; a.K = K; a.inv_radius = 1.0f / radius; a.kmagic = div_magic(K);
   const long long rows = (long long)B * N;
-  const int gx = round_grid((rows + 7) / 8, 16384);
+  const int gx = round_grid((rows + 3) / 4, 2048);  // 8 waves per SIMD; a wave pipelines over its points
   hipLaunchKernelGGL(pwmlp_summary_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_support_summary");
 }
@@ -1552,7 +1642,8 @@ extern "C" int cl3d_pwmlp_bwd_support_sum(const float *ght, const float *wr, con
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
   if (tiles > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support_sum: too many tiles");
-  const int gx = (int)tiles;  // one tile per workgroup
+  if (m.L * V > 256) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support_sum: %d channels per chunk", m.L * V);
+  const int gx = round_grid(tiles, 1024);  // persistent: four workgroups per CU, each pipelines over its tiles
   const float4 *s4 = reinterpret_cast<const float4 *>(rec);
   static const int sb4 = [] {  // CL3D_PW_SB=4: four rows in flight per lane instead of eight (A/B timing)
     const char *e = getenv("CL3D_PW_SB");

@@ -159,19 +159,16 @@ def _join_inverse(idx):
         idx._cl3d_inverse = cached[:3] + (None,)
 
 
-# The PointWiseMLP's support-major backward pass either walks every slot of a support point's list (32 row gathers +
-# 32 query records per point at the metric shape) or a summary of the list built once per GEOMETRY (~8 rows per point;
-# support_summary below).  Building the summary costs about as much as one slot walk, so it pays when several operators
-# share the geometry -- the blocks of a backbone stage, which the model runs inside pt_utils.ball_query_cache() -- and
-# not for a lone operator (measured, round 3: 16 x 4096 backbone 8.17 -> 7.98 ms f32, 6.80 -> 6.62 ms bf16 per step;
-# the single-operator bench step 0.359 -> 0.385 ms).  'auto' = summary inside a ball_query_cache() context;
-# CL3D_PW_SUMMARY=1 / 0 force it.
-SUPPORT_SUMMARY = {'1': True, '0': False}.get(os.environ.get('CL3D_PW_SUMMARY', ''), 'auto')
+# The PointWiseMLP's support-major backward pass either works out, per slot of a support point's list, which row of the
+# tile the slot belongs to, its query record and its relative position before it can gather (cl3d_pwmlp_bwd_support), or
+# reads all that from a summary of the lists built once per GEOMETRY (support_summary below; shared by the operators of
+# a backbone stage like the CSR inverse) and only gathers (cl3d_pwmlp_bwd_support_sum).  Measured, round 3, metric
+# shape: slot walk 74 us; summary 35 us on the index stream + 45 us; the replayed step 0.366 -> 0.358-0.361 ms, the
+# 16 x 4096 backbone 8.17 -> 8.03 ms f32, 6.80 -> 6.61 ms bf16.  CL3D_PW_SUMMARY=0 selects the slot walk (A/B timing).
+SUPPORT_SUMMARY = os.environ.get('CL3D_PW_SUMMARY', '1') != '0'
 
 
 def _use_summary():
-    if SUPPORT_SUMMARY == 'auto':
-        return pt_utils._BQ_CACHE is not None
     return bool(SUPPORT_SUMMARY)
 
 
@@ -549,10 +546,10 @@ class _PointwiseMLP(Function):
             dz_cm = torch.empty((B, Co, M), dtype=torch.float32, device=dev)
             ts_cm = torch.empty((B, Co, M), dtype=torch.int32, device=dev)
             partial = torch.empty((nparts, Co, 8), dtype=torch.float64, device=dev)
-            # for the support-major pass: dz again as point-major rows, and one 16-byte record per query
-            # {coordinates, centre idx[j, 0]} (a slot of that pass then costs one L2 request instead of three)
+            # for the support-major pass: dz again as point-major rows, and (slot walk only) one 16-byte record per
+            # query {coordinates, centre idx[j, 0]} (a slot of that pass then costs one L2 request instead of three)
             dz_t = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
-            qtab = torch.empty((B, M, 4), dtype=torch.float32, device=dev)
+            qtab = None if _use_summary() else torch.empty((B, M, 4), dtype=torch.float32, device=dev)
             _lib.check(lib.cl3d_pwmlp_bwd_rows(_p(gout), gout_cm, _p(ystar), _p(kstar), _p(idx), _p(query_xyz), _p(support_xyz),
                                                ctx.radius, _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), B, N, M, K, Co,
                                                _p(dz_cm), _p(ts_cm), _p(dz_t), _p(qtab), _p(partial), nparts, st))
@@ -576,8 +573,7 @@ class _PointwiseMLP(Function):
             hits()
             off, slots = inverse_index(idx, N)
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
-            # the forward pass decided (and prefetched); a summary left by another operator of the stage is used too
-            if N <= (1 << 24) and (getattr(idx, '_cl3d_summary', None) is not None or SUPPORT_SUMMARY is True):
+            if _use_summary():
                 rec, ent = support_summary(idx, N, query_xyz, support_xyz, ctx.radius)
                 _lib.check(lib.cl3d_pwmlp_bwd_support_sum(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t),
                                                           _p(sy), _p(rec), _p(ent), B, N, M, K, Co, _p(dght), st))

@@ -341,8 +341,9 @@ int cl3d_pwmlp_fwd(const float *query_xyz, const float *support_xyz, const int32
                    unsigned char *kstar_t, float *slotrec, cl3d_stream_t stream);
 /* dz_cm [B,Co,M] = gout gated by the ReLU at the arg-max and ts_cm [B,Co,M] = idx[j, kstar] (the support point
  * the arg-max slot refers to), both channel-major for bwd_hits; dz_t [B,M,Co] = dz again, point-major, and
- * qtab [B,M,4] = {query coordinates, as_float(idx[j, 0])} for bwd_support (one 16-byte record per query: a slot of
- * the support-major pass costs one L2 request instead of three); partial: sum dz, sum dz*xhat, sum dz*rel(k*). */
+ * qtab [B,M,4] (nullable: only cl3d_pwmlp_bwd_support reads it) = {query coordinates, as_float(idx[j, 0])} (one
+ * 16-byte record per query: a slot of the slot-walking support pass costs one L2 request instead of three);
+ * partial: sum dz, sum dz*xhat, sum dz*rel(k*). */
 int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, const float *ystar_t,
                         const unsigned char *kstar_t, const int32_t *idx, const float *query_xyz,
                         const float *support_xyz, float radius, const float *scale, const float *shift,
@@ -362,16 +363,17 @@ int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const float *cA, c
                            const float *qtab, const float *support_xyz, float radius,
                            const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K, int Co,
                            float *dght, cl3d_stream_t stream);
-/* The same pass on a summary of every support point's slot list (round 3).  The centre of query j is idx[j, 0], the
- * lowest support index in j's ball (reference local_aggregation_operators.py:290 takes slot 0 as the centre), so the
- * ~K slots of a support point name only a handful of distinct centre rows.  cl3d_pwmlp_support_summary boils the CSR
- * lists down, once per geometry (idx + coordinates + radius; every operator of a backbone stage shares it):
+/* The same pass on a summary of every support point's slot list (round 3).  What cl3d_pwmlp_bwd_support works out per
+ * slot before it can gather (which point a CSR position belongs to, the slot's query record, the relative position,
+ * whose H row the slot adds; reference local_aggregation_operators.py:290 takes slot 0 of a query as its centre) depends
+ * on the geometry only.  cl3d_pwmlp_support_summary does it once per geometry (idx + coordinates + radius; every
+ * operator of a backbone stage shares it):
  *   rec [B,N,8] = {sum of the list's relative positions (p_i - q_j) / radius (3 floats), then as int bits: s0 =
- *                  inv_off[i], list length, pair count, centred count, 0}
- *   ent [B,M*K] = per support point: pairs  centre | count << 24  forward from s0; the ids of the queries centred on
- *                 the point itself (slots (j, 0)) backward from s0 + length - 1
- * and cl3d_pwmlp_bwd_support_sum gathers one row per entry (~8 at the metric shape) instead of one per slot (32).
- * Needs N <= 2^24.  Results agree with cl3d_pwmlp_bwd_support to rounding (count * row instead of repeated adds). */
+ *                  inv_off[i], list length, centre-row count, centred count, 0}
+ *   ent [B,M*K] = per support point: the centre idx[j, 0] of every slot (j, k > 0) forward from s0; the ids of the
+ *                 queries centred on the point itself (slots (j, 0)) backward from s0 + length - 1
+ * and cl3d_pwmlp_bwd_support_sum is left with the row gathers.  Results agree with cl3d_pwmlp_bwd_support to rounding
+ * (the rows of a list are added in a different order). */
 int cl3d_pwmlp_support_summary(const int32_t *idx, const float *query_xyz, const float *support_xyz,
                                const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K,
                                float radius, float *rec, uint32_t *ent, cl3d_stream_t stream);

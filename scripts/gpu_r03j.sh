@@ -5,7 +5,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== summary tests + PointWiseMLP parity" | tee $OUT/summary.txt
-[ -n "$SKIP_TESTS" ] || timeout 1500 python -m pytest tests/test_pwmlp_summary_gpu.py tests/test_operators_gpu.py tests/test_fp64_anchor_gpu.py -m gpu -q -x --timeout=900 -p no:cacheprovider > $OUT/pytest.log 2>&1
+[ -n "$SKIP_TESTS" ] || timeout 1500 python -m pytest tests/test_pwmlp_summary_gpu.py tests/test_operators_gpu.py tests/test_fp64_anchor_gpu.py tests/test_bottleneck_gpu.py tests/test_fullsize_gpu.py tests/test_dp_gpu.py -m gpu -q -x --timeout=900 -p no:cacheprovider > $OUT/pytest.log 2>&1
 echo "pytest rc=$?" | tee -a $OUT/summary.txt; tail -6 $OUT/pytest.log | tee -a $OUT/summary.txt
 for v in "" "CL3D_PW_SUMMARY=0" "CL3D_PW_SB=4" ""; do
   echo "-- $v" | tee -a $OUT/summary.txt
