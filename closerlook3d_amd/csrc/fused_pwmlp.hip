@@ -92,8 +92,13 @@ static unsigned div_magic(int K) { return K <= 1 ? 0u : (unsigned)((0x100000000u
 //   * the centre's H row is fetched together with the first batch of G rows (it was a round trip of its own in
 //     front of every query's walk);
 //   * full batches carry no per-slot guard: with the guard the compiler sank one of the four gathers of a batch
-//     behind a branch and waited for it alone (two dependent round trips per batch instead of one).
-template <int MODE, int V, int KB, int WPE, int QPG>  // KB = row gathers in flight per lane, WPE = waves per SIMD to fit
+//     behind a branch and waited for it alone (two dependent round trips per batch instead of one);
+//   * (PIPE) the walk in two rotating pairs of slots, see the walk below: 69.1 -> 64.5 us.
+// Tried and dropped in round 3: the tile's slot records copied out of a table built once per geometry on the ball
+// query's stream ([B,M,K] x 16 bytes, 19.5 us to build) instead of chasing idx -> coordinates while staging: the pass
+// itself 64.5 -> 68.1 us and the replayed step 0.365-0.372 -> 0.394-0.396 ms -- the 33.5 MB table costs more to
+// stream than the two dependent round trips it replaces (coordinates and indices are L2-resident, the table is not).
+template <int MODE, int V, int KB, int WPE, int QPG, bool PIPE = false>  // KB = row gathers in flight per lane, WPE = waves per SIMD to fit
 __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
   extern __shared__ float4 lds4[];
   const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
@@ -273,6 +278,38 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
       }
       // walk: batch 0 is in flight; full batches carry no guards, the tail (K % KB slots) is guarded
       auto walk = [&](auto &&slot) {
+        if constexpr (PIPE && KB == 4) {
+          // two pairs in rotation: while a pair's two slots are multiplied out, the other pair's rows are in flight
+          // (requested right after that pair was consumed) -- the wave itself overlaps gather latency with arithmetic
+          // instead of leaving that to the other three waves of its SIMD.  ONE branch-free loop body (K % 4 == 0), so
+          // that the waits are exact counts (vmcnt(2)) and not the vmcnt(0) a join of guarded paths forces: the last
+          // round re-requests the list's last rows (L1 hits) instead of branching around the refill.
+          {  // (launched for K % 4 == 0 only)
+#pragma unroll 1
+            for (int k0 = 0; k0 < K; k0 += 4) {
+              // (scheduling fences: left to itself the compiler hoists the refills and runs out of registers)
+              slot(std::false_type{}, k0, sr[0], gr[0]);
+              slot(std::false_type{}, k0 + 1, sr[1], gr[1]);
+              __builtin_amdgcn_sched_barrier(0);
+              const int ka = k0 + 4 < K ? k0 + 4 : K - 2;
+              sr[0] = myslots[ka];
+              sr[1] = myslots[ka + 1];
+              gr[0] = ldrow(__float_as_uint(sr[0].x) + lane_off);
+              gr[1] = ldrow(__float_as_uint(sr[1].x) + lane_off);
+              __builtin_amdgcn_sched_barrier(0);
+              slot(std::false_type{}, k0 + 2, sr[2], gr[2]);
+              slot(std::false_type{}, k0 + 3, sr[3], gr[3]);
+              __builtin_amdgcn_sched_barrier(0);
+              const int kb2 = k0 + 6 < K ? k0 + 6 : K - 2;
+              sr[2] = myslots[kb2];
+              sr[3] = myslots[kb2 + 1];
+              gr[2] = ldrow(__float_as_uint(sr[2].x) + lane_off);
+              gr[3] = ldrow(__float_as_uint(sr[3].x) + lane_off);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+          }
+        }
         if (K >= KB) {
 #pragma unroll
           for (int u = 0; u < KB; ++u) {
@@ -317,7 +354,9 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
         int kb[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          s1[v] = best[v] = 0.f;
+          s1[v] = 0.f;
+          // (the rotating-pair walk treats slot 0 like every other slot: any finite y beats -inf)
+          best[v] = PIPE ? -__builtin_huge_valf() : 0.f;
           kb[v] = 0;
           hs[v] = sgn[v] * hc.v[v];
         }
@@ -365,7 +404,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
         int kb[V];
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-          best[v] = 0.f;
+          best[v] = PIPE ? -__builtin_huge_valf() : 0.f;
           kb[v] = 0;
         }
         walk([&](auto first, int k, const float4 &sr_, const Vec<V> &gr_) {
@@ -1324,6 +1363,16 @@ static int launch_query(PwArgs &a, int nacc, int n_partials, hipStream_t st, con
   // occupancy buys more than depth per wave
   // (software-pipelining the walk -- batch n+1's gathers issued before batch n is consumed, 2 or 3 waves per SIMD --
   // measured 95-120 us)
+  // the slot walk in two rotating pairs (K % 4 == 0): measured at the metric shape, round 3, TRAIN pass alone 69.1 ->
+  // 64.5 us; CL3D_PW_PIPE=0 selects the batch walk (A/B timing)
+  static const int pipe = [] {
+    const char *e = getenv("CL3D_PW_PIPE");
+    return (e != nullptr && e[0] == '0') ? 0 : 1;
+  }();
+  if (V == 4 && pipe && qpg == 1 && (a.K & 3) == 0) {
+    hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4, 1, true>), dim3(gx, m.chunks), dim3(256), lds, st, a);
+    return check_launch(who);
+  }
   if (V == 4) {
     if (qpg == 2) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4, 2>), dim3(gx, m.chunks), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4, 1>), dim3(gx, m.chunks), dim3(256), lds, st, a);
