@@ -11,7 +11,7 @@ cp $S/bench_bf16.json $D/bench_pointwisemlp_bf16.json
 cp $S/bench_eager.json $D/bench_pointwisemlp_eager.json
 cp $S/prof/bench_kernel_stats.csv $D/bench_pointwisemlp_kernel_stats.csv 2>/dev/null || cp $(find $S/prof -name "bench_kernel_stats.csv" | head -1) $D/bench_pointwisemlp_kernel_stats.csv
 for f in step_counters.json step_timeline.txt pmc_traffic.json point_gemm.jsonl convs.jsonl bench_bq.jsonl step_variants.txt \
-         sorted_points_experiment.txt bench_pospool.json bench_adaptive_weight.json bench_pseudo_grid.json \
+         sorted_points_experiment.txt micro_gathers.txt bench_pospool.json bench_adaptive_weight.json bench_pseudo_grid.json \
          bench_pseudo_grid_kernel_stats.csv bench_dataset_grid.json bench_voting.json bench_sphere_crop.json; do
   cp $S/$f $D/$f
 done

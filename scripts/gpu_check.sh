@@ -30,9 +30,14 @@ echo "== ball query: LDS-resident kernel vs cell grid through HBM (same op, pinn
 for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
 for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --n 1024 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
 for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --mult 4.0 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
-echo "== step variants: cell grid, two queries per lane group, points stored in cell order (experiment)" | tee -a $OUT/summary.txt
-for v in "CL3D_BQ_PATH=cells" "CL3D_PW_QPG=2" "CL3D_BENCH_SORTED=1"; do
+echo "== step variants: cell grid, two queries per lane group, slot-walking support pass, batch walk, points stored in cell order (experiment)" | tee -a $OUT/summary.txt
+for v in "CL3D_BQ_PATH=cells" "CL3D_PW_QPG=2" "CL3D_PW_SUMMARY=0" "CL3D_PW_PIPE=0" "CL3D_BENCH_SORTED=1"; do
   env $v timeout 300 python bench.py --no-cpu-baseline --no-kernel-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', 'ms_per_step', d['ms_per_step'])" | tee -a $OUT/step_variants.txt | tee -a $OUT/summary.txt
+done
+echo "== micro-benchmarks: 2.1 M random 256-byte row gathers by row pitch; coordinates as 3 x dword vs 1 x dwordx4" | tee -a $OUT/summary.txt
+for m in gather_pitch gather_xyz; do
+  [ -x scripts/micro/$m ] || (cd scripts/micro && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $m $m.hip > /dev/null 2>&1)
+  timeout 120 scripts/micro/$m | tee -a $OUT/micro_gathers.txt | tee -a $OUT/summary.txt
 done
 echo "== rocprofv3 kernel trace of the same bench command" | tee -a $OUT/summary.txt
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o bench -- python $R/bench.py --no-cpu-baseline > $R/$OUT/rocprof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
