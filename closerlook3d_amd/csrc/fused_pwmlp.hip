@@ -65,11 +65,13 @@ struct PwArgs {
   unsigned kmagic;  // ceil(2^32 / K), see div_k
 };
 
+// y = W_r . rel + H[centre] + G[neighbour], as one chain of fused multiply-adds started on the centre term (one
+// instruction per term; the TRAIN pass evaluates the same chain on pre-signed operands, see there)
 __device__ __forceinline__ float pw_preact(const float w[3], float rx, float ry, float rz, float hc, float g) {
-  float t = w[0] * rx;
+  float t = __builtin_fmaf(w[0], rx, hc);
   t = __builtin_fmaf(w[1], ry, t);
   t = __builtin_fmaf(w[2], rz, t);
-  return (t + hc) + g;
+  return t + g;
 }
 
 // t / K for slot counters (t < 2^24, K <= 255) without the ~20-instruction integer division: magic = ceil(2^32 / K)
@@ -367,10 +369,10 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
           accr[2] += sr_.w;
 #pragma unroll
           for (int v = 0; v < V; ++v) {
-            float t = ws[v][0] * sr_.y;
+            float t = __builtin_fmaf(ws[v][0], sr_.y, hs[v]);
             t = __builtin_fmaf(ws[v][1], sr_.z, t);
             t = __builtin_fmaf(ws[v][2], sr_.w, t);
-            const float y = __builtin_fmaf(gr_.v[v], sgn[v], t + hs[v]);  // = sgn * pw_preact(w, rel, hc, g)
+            const float y = __builtin_fmaf(gr_.v[v], sgn[v], t);  // = sgn * pw_preact(w, rel, hc, g)
             s1[v] += y;
             accf[1][v] = __builtin_fmaf(y, y, accf[1][v]);
             accf[2][v] = __builtin_fmaf(y, sr_.y, accf[2][v]);
