@@ -8,14 +8,16 @@ A step = LocalAggregation fwd + bwd (+ gradient all-reduce over RCCL when N>1 + 
 operator's parameters) over one batch of B=16 synthetic clouds per GPU, N=M=4096 points, K=32
 neighbours, C=64 channels (72 for PosPool, which needs C%3==0).  Clouds are resident in HBM before
 the timed region.  Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline      top level + `per_kernel` + `ball_query_group`: the reference-visible `_ext` MATERIALISING path
-                (`path` says so) -- MaskedQueryAndGroup and its backward as the reference's own Python would call
-                them: algorithmic bytes per launch / average launch duration (HIP events on the launch stream)
-                against the 8 TB/s HBM peak, the whole boundary at SURVEY 8(d)'s 17,696 B/point.  These kernels
-                are NOT the ones the timed step runs (impl=auto takes the fused path);
-                `step`: the timed step's OWN kernels, one row per C-ABI entry point (calls, microseconds from HIP
-                events in a one-stream eager run of the same step, algorithmic HBM bytes, modelled L2 gather bytes,
-                PMC bytes from profiles/rNN/step_counters.json when committed, bound, fraction), dominant one named;
+  roofline      top level: the timed step's longest data-moving kernel (C-ABI entry point of the fused path): algorithmic
+                HBM bytes per launch / median launch duration (HIP events on the launch stream, one-stream eager run of
+                the same step) against the 8 TB/s HBM peak, `traffic` = its PMC HBM bytes (profiles/rNN/
+                step_counters.json), `longest_entry` beside it when a VALU-bound entry (the ball query) is longer;
+                `boundary`: the reference-visible `_ext` MATERIALISING path (`path` says so) -- MaskedQueryAndGroup and
+                its backward as the reference's own Python calls them -- per kernel (median / min / max over >= 12
+                bursts) and as a whole at SURVEY 8(d)'s 17,696 B/point (north_star's >= 50 % target); these kernels are
+                NOT the ones the timed step runs (impl=auto takes the fused path);
+                `step`: the timed step's OWN kernels, one row per C-ABI entry point (calls, microseconds, algorithmic
+                HBM bytes, PMC HBM / L2 bytes when committed, bound, fractions);
                 `achieved_step` = value x 17,696 B / 8 TB/s (BASELINE.md section 2: what the headline corresponds to);
                 `contraction`: the hand-written MFMA per-point GEMMs of the PointWiseMLP (flops, microseconds,
                 fraction of the 157.3 TFLOP/s f32-input / 2.5 PFLOP/s bf16 dense MFMA peaks), with the vendor
@@ -607,13 +609,21 @@ def main():
             if not args.no_step_table:
                 st = step_table(compute, B, N, N, K, C, reps=20, kind=kind)
                 st["graph_step_us"] = round(ms * 1e3, 1)
-                d = st["kernels"][0]
+                # the roofline the contract asks for prices a kernel against HBM (or the matrix cores): taken for the
+                # longest entry that moves data -- a VALU-bound entry (the ball query: 19 MB in ~65 us) can be the
+                # longest of the table by a few microseconds and has no meaningful HBM fraction; it is named beside it
+                movers = [r for r in st["kernels"] if not r["bound"].startswith("valu") and r["algorithmic_bytes"] > 0]
+                d = movers[0] if movers else st["kernels"][0]
+                longest = st["kernels"][0]
+                if longest is not d:
+                    roof["longest_entry"] = {"entry": longest["entry"], "us": longest["us"], "bound": longest["bound"],
+                                             "hbm_frac": longest["hbm_frac"]}
                 roof.update({"kernel": (d["kernels"] or [d["entry"]])[0], "entry": d["entry"], "us": d["us"],
                              "us_min": d["us_min"], "us_max": d["us_max"], "algorithmic_bytes": d["algorithmic_bytes"],
                              "achieved": round(d["algorithmic_bytes"] / d["us"] / 1e3, 1), "frac": d["hbm_frac"],
                              "traffic": d.get("hbm_bytes_pmc"), "l2_frac": d.get("l2_frac"),
-                             "what": f"dominant kernel of the timed step (fused path); bound: {d['bound']}; priced "
-                                     "against HBM as the contract asks"})
+                             "what": f"longest data-moving kernel of the timed step (fused path); bound: {d['bound']}; "
+                                     "priced against HBM as the contract asks"})
             with torch.no_grad():
                 per_kernel, boundary = kernel_rooflines(xyz, mask, feats.detach(), radius, K, bursts=args.bursts)
             for k, v in per_kernel.items():
