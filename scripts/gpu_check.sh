@@ -40,18 +40,18 @@ for m in gather_pitch gather_xyz; do
   timeout 120 scripts/micro/$m | tee -a $OUT/micro_gathers.txt | tee -a $OUT/summary.txt
 done
 echo "== rocprofv3 kernel trace of the same bench command" | tee -a $OUT/summary.txt
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o bench -- python $R/bench.py --no-cpu-baseline > $R/$OUT/rocprof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o bench -- python $R/bench.py --no-cpu-baseline --precondition 0 > $R/$OUT/rocprof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
 python scripts/kstats.py $OUT/prof/bench_kernel_stats.csv 100 40 | tee -a $OUT/summary.txt
 echo "== PMC counters of the timed step (separate passes)" | tee -a $OUT/summary.txt
 n=0
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_ANY"; do
   n=$((n+1))
-  (cd /tmp && timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/$OUT/step_pmc$n -o pmc -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-roofline > $R/$OUT/step_pmc$n.log 2>&1)
+  (cd /tmp && timeout 600 rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/$OUT/step_pmc$n -o pmc -- python $R/bench.py --steps 6 --warmup 2 --precondition 0 --no-cpu-baseline --no-kernel-roofline > $R/$OUT/step_pmc$n.log 2>&1)
 done
 python scripts/step_counters.py $OUT/step_pmc1 $OUT/step_pmc2 $OUT/step_pmc3 $OUT/step_pmc4 > $OUT/step_counters.json 2>> $OUT/summary.txt
 head -c 1200 $OUT/step_counters.json | tee -a $OUT/summary.txt
 echo "== L2 requests of the gather passes with the points stored in cell order (experiment)" | tee -a $OUT/summary.txt
-(cd /tmp && CL3D_BENCH_SORTED=1 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $R/$OUT/sorted_pmc -o pmc -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-kernel-roofline > /dev/null 2>&1)
+(cd /tmp && CL3D_BENCH_SORTED=1 timeout 600 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $R/$OUT/sorted_pmc -o pmc -- python $R/bench.py --steps 6 --warmup 2 --precondition 0 --no-cpu-baseline --no-kernel-roofline > /dev/null 2>&1)
 python - <<PY | tee $OUT/sorted_points_experiment.txt | tee -a $OUT/summary.txt
 import csv, glob, collections, json
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
@@ -104,10 +104,10 @@ timeout 600 python scripts/bench_dataset_grid.py 2>/dev/null | tee $OUT/bench_da
 timeout 300 python scripts/bench_voting.py 2>/dev/null | tee $OUT/bench_voting.json | tee -a $OUT/summary.txt
 timeout 300 python scripts/bench_sphere_crop.py 2>/dev/null | tee $OUT/bench_sphere_crop.json | tee -a $OUT/summary.txt
 echo "== timeline of one replay of the timed step (critical path, idle time between kernels)" | tee -a $OUT/summary.txt
-(cd /tmp && rm -rf /tmp/tl && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o tl -- python $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline --no-kernel-roofline --no-step-table > /dev/null 2>&1)
+(cd /tmp && rm -rf /tmp/tl && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -o tl -- python $R/bench.py --steps 12 --warmup 4 --precondition 0 --no-cpu-baseline --no-kernel-roofline --no-step-table > /dev/null 2>&1)
 python scripts/step_timeline.py "/tmp/tl/**/tl_kernel_trace.csv" | tee $OUT/step_timeline.txt | tail -3 | tee -a $OUT/summary.txt
 echo "== PseudoGrid operator: per-kernel averages" | tee -a $OUT/summary.txt
-(cd /tmp && rm -rf /tmp/pgp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pgp -o pg -- python $R/bench.py --operator pseudo_grid --steps 40 --warmup 5 --no-cpu-baseline --no-kernel-roofline --no-step-table > /dev/null 2>&1)
+(cd /tmp && rm -rf /tmp/pgp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pgp -o pg -- python $R/bench.py --operator pseudo_grid --steps 40 --warmup 5 --precondition 0 --no-cpu-baseline --no-kernel-roofline --no-step-table > /dev/null 2>&1)
 cp $(find /tmp/pgp -name "pg_kernel_stats.csv" | head -1) $OUT/bench_pseudo_grid_kernel_stats.csv 2>/dev/null
 python scripts/kstats.py $OUT/bench_pseudo_grid_kernel_stats.csv 45 12 | tee -a $OUT/summary.txt
 # keep the merged output small: drop raw traces, keep stats and counter tables

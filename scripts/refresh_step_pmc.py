@@ -10,7 +10,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from bench import ENTRY_KERNELS  # noqa: E402
+from bench import ENTRY_KERNELS, L2_PEAK  # noqa: E402
 
 
 def main():
@@ -28,9 +28,15 @@ def main():
                 found = True
         row.pop("hbm_bytes_pmc", None)
         row.pop("l2_bytes_pmc", None)
+        row.pop("l2_frac", None)
         if found:
             row["hbm_bytes_pmc"], row["l2_bytes_pmc"] = int(hb), int(lb)
+            row["l2_frac"] = round(lb / (row["us"] * 1e-6) / L2_PEAK, 4) if row["us"] > 0 else None
     step["pmc_source"] = os.path.relpath(counters_path)
+    top = line["roofline"]
+    for row in step["kernels"]:  # the top-level block repeats one row's counters
+        if row["entry"] == top.get("entry"):
+            top["traffic"], top["l2_frac"] = row.get("hbm_bytes_pmc"), row.get("l2_frac")
     json.dump(line, open(line_path, "w"))
     print("refreshed", line_path, "from", counters_path)
 
