@@ -1668,7 +1668,14 @@ extern "C" int cl3d_pwmlp_support_summary(const int32_t *idx, const float *query
   a.rec = reinterpret_cast<float4 *>(rec); a.ent = ent;
   a.B = B; a.N = N; a.M = M; a.K = K; a.inv_radius = 1.0f / radius; a.kmagic = div_magic(K);
   const long long rows = (long long)B * N;
-  const int gx = round_grid((rows + 3) / 4, 2048);  // 8 waves per SIMD; a wave pipelines over its points
+  // grid: the kernel runs on a side stream beside the critical path's short kernels (per-channel finalize, APPLY): at
+  // 2048 workgroups (every wave slot of the chip) a 64-workgroup kernel launched right behind it waited 23 us for slots
+  static const int cap = [] {
+    const char *e = getenv("CL3D_PW_SUMGRID");  // A/B timing
+    const int v = e ? atoi(e) : 0;
+    return v >= 8 ? v : 1024;
+  }();
+  const int gx = round_grid((rows + 3) / 4, cap);
   hipLaunchKernelGGL(pwmlp_summary_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_support_summary");
 }
