@@ -1018,9 +1018,13 @@ struct RowArgs {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
-  __shared__ float tile[64 * 65];
+  __shared__ __attribute__((aligned(16))) float tile[64 * 65];
   __shared__ int tile2[MODE == ROWS_BWD ? 64 * 65 : 1];
-  __shared__ double red[MODE == ROWS_BWD ? 256 * 5 : 1];
+  // the end-of-kernel reduction reuses the tile (every reader of it has passed the loop's closing barrier): 33 KB per
+  // workgroup instead of 43, four workgroups per CU instead of three -- the BWD pass's 1024 one-tile workgroups are then
+  // all resident at once
+  double *red = reinterpret_cast<double *>(tile);
+  static_assert(sizeof(tile) >= 256 * 5 * sizeof(double), "reduction scratch must fit the tile");
   const int M = a.M, Co = a.Co, K = a.K;
   const int tid = threadIdx.x;
   const int tiles_per_cloud = (M + 63) / 64;
