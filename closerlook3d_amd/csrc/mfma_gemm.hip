@@ -661,6 +661,99 @@ __global__ __launch_bounds__(256) void pwmlp_weights_kernel(const float *__restr
   }
 }
 
+// ---- the PointWiseMLP's forward per-point product WITHOUT LDS and on <= 96 VGPRs ---------------------------------
+// ght[p][j] = sum_c act(F[c][p]) wcat[j][c] for channel-major F and few channels (C <= 72).  In the training step this
+// product runs beside the ball query, whose one workgroup per CU holds ~147 KB of LDS and 4 x 104 VGPRs per SIMD lane:
+// mfma_gemm_kernel (33 KB of LDS per workgroup) cannot be resident next to it and ran in the ball query's tail -- the
+// statistics pass, which needs both, started ~25 us after the ball query had finished.  This form needs no LDS at all
+// and fits the registers the ball query leaves: a wave owns one 32-column tile of the output (its wcat fragments, C / 2
+// VGPRs, loaded once) and walks 32-point blocks; a block's operand fragments come STRAIGHT from global memory (32
+// consecutive points of one channel are 128 contiguous bytes = the lanes of one v_mfma_f32_32x32x2_f32 fragment; the
+// four waves of a workgroup = four column tiles re-read the block out of L1).  Same instruction, same f32 accumulation as
+// the staged kernel; the k order of the sum is the same too (ascending), so are the results.
+template <int CH>  // CH = ceil(C / 2) MFMA steps
+__global__ __launch_bounds__(256, 5) void pwmlp_rows_nolds_kernel(const float *__restrict__ F, const float *__restrict__ pro_scale,
+                                                                  const float *__restrict__ pro_shift,
+                                                                  const float *__restrict__ wcat, float *__restrict__ out,
+                                                                  int C, int N, int J, int nblocks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int j = 32 * (blockIdx.y * 4 + wave) + lr;  // this lane's output column
+  if (32 * (blockIdx.y * 4 + wave) >= J) return;    // (whole waves: no barrier in this kernel)
+  float bw[CH];
+#pragma unroll
+  for (int s = 0; s < CH; ++s) {
+    const int k = 2 * s + lh;
+    bw[s] = (j < J && k < C) ? wcat[(size_t)j * C + k] : 0.f;
+  }
+  const int per_cloud = N / 32;
+  // wave-uniform bases + ONE 32-bit lane offset per side (saddr + voffset accesses): a 64-bit address per fragment load
+  // and per store would alone be more registers than the kernel may have
+  const unsigned a_off = ((unsigned)lh * (unsigned)N + (unsigned)lr) * 4u;
+  const unsigned o_off = ((unsigned)(4 * lh) * (unsigned)J + (unsigned)(j < J ? j : 0)) * 4u;
+  const bool odd_tail = (C & 1) != 0 && lh == 1;  // the last step's second k does not exist
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int b = __builtin_amdgcn_readfirstlane(blk / per_cloud);
+    const int n0 = __builtin_amdgcn_readfirstlane((blk - b * per_cloud) * 32);
+    const char *fb = reinterpret_cast<const char *>(F + (size_t)b * C * N + n0);
+    float a[CH];
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      const char *row = fb + (size_t)(2 * s) * N * 4u;  // uniform
+      a[s] = (s == CH - 1 && odd_tail) ? 0.f : *reinterpret_cast<const float *>(row + a_off);
+    }
+    if (pro_scale != nullptr) {  // the producing layer's BatchNorm + ReLU, applied to the fragment
+#pragma unroll
+      for (int s = 0; s < CH; ++s) {
+        const bool dead = s == CH - 1 && odd_tail;
+        const int k = dead ? 0 : 2 * s + lh;
+        const float z = __builtin_fmaf(a[s], pro_scale[k], pro_shift[k]);
+        a[s] = dead ? 0.f : (z > 0.f ? z : 0.f);
+      }
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < CH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], bw[s], acc, 0, 0, 0);
+    if (j < J) {
+      char *ob = reinterpret_cast<char *>(out + ((size_t)b * N + n0) * J);
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        *reinterpret_cast<float *>(ob + (size_t)((e & 3) + 8 * (e >> 2)) * J * 4u + o_off) = acc[e];
+    }
+  }
+}
+
+static bool nolds_fwd_wanted() {
+  static const int on = [] {  // CL3D_GEMM_NOLDS=0: the staged kernel for every shape (A/B timing)
+    const char *e = getenv("CL3D_GEMM_NOLDS");
+    return (e != nullptr && e[0] == '0') ? 0 : 1;
+  }();
+  return on != 0;
+}
+
+// launches it when the shape qualifies (f32, C in {32, 36, 64, 72}: the layers that run beside a ball query at full
+// resolution, whole 32-point blocks per cloud); false = the caller takes the staged kernel
+static bool launch_rows_nolds(const float *F, const float *pro_scale, const float *pro_shift, const float *wcat, float *ght,
+                              int B, int C, int N, int Co, hipStream_t st) {
+  if (!nolds_fwd_wanted() || (N & 31) != 0 || B < 1) return false;
+  const int J = 2 * Co;
+  const long long nblocks = (long long)B * (N / 32);
+  if (nblocks > 0x7fffffffLL) return false;
+  const dim3 grid((unsigned)(nblocks < 256 ? nblocks : 256), (unsigned)ceil_div(ceil_div(J, 32), 4));  // one workgroup per CU
+#define CL3D_NOLDS(CH_) \
+  hipLaunchKernelGGL((pwmlp_rows_nolds_kernel<CH_>), grid, dim3(256), 0, st, F, pro_scale, pro_shift, wcat, ght, C, N, J, (int)nblocks)
+  switch (C) {
+    case 32: CL3D_NOLDS(16); return true;
+    case 36: CL3D_NOLDS(18); return true;
+    case 64: CL3D_NOLDS(32); return true;
+    case 72: CL3D_NOLDS(36); return true;
+    default: return false;
+  }
+#undef CL3D_NOLDS
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -890,6 +983,7 @@ static int point_gemm_fwd(const float *features, const float *pro_scale, const f
   hipLaunchKernelGGL(pwmlp_weights_kernel, dim3(round_up_grid(Co * (3 + 2 * C))), dim3(256), 0, st, W, Co, C, wr, wcat);
   const int rc = check_launch(who);
   if (rc != CL3D_OK || B == 0) return rc;
+  if (precision == PREC_F32 && launch_rows_nolds(features, pro_scale, pro_shift, wcat, ght, B, C, N, Co, st)) return check_launch(who);
   GemmArgs a{};  // D[i = (cloud, point)][j = o] = sum_c F[c][point] wcat[o][c]  ->  ght [B*N, 2Co]
   a.A = channel_major(features, B, C, N, true);
   set_prologue(a.A, pro_scale, pro_shift, 0);

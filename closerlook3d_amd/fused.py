@@ -159,6 +159,18 @@ def _join_inverse(idx):
         idx._cl3d_inverse = cached[:3] + (None,)
 
 
+def _join_geometry(idx):
+    """End of a PointWiseMLP forward pass.  With a summary queued behind the CSR build (same stream) the caller's stream
+    has nothing to pick up here: the backward's support pass waits for the summary, which covers the build, and no
+    other kernel of the operator reads either.  Joining the build here made the FIRST backward kernel wait across
+    queues for a table it never reads (replayed step, round 3: ~12 us between the forward's last kernel and the
+    backward's first, against ~5 us between kernels of one queue).  Without a pending summary: _join_inverse."""
+    pending = getattr(idx, '_cl3d_summary', None)
+    if pending is not None and pending[3] is not None:
+        return
+    _join_inverse(idx)
+
+
 # The PointWiseMLP's support-major backward pass either works out, per slot of a support point's list, which row of the
 # tile the slot belongs to, its query record and its relative position before it can gather (cl3d_pwmlp_bwd_support), or
 # reads all that from a summary of the lists built once per GEOMETRY (support_summary below; shared by the operators of
@@ -516,7 +528,7 @@ class _PointwiseMLP(Function):
                     ctx.meta = (B, N, M, K, Co, nparts)
                 ctx.rows_out = bool(rows_out)
                 if rows_out:
-                    _join_inverse(idx)
+                    _join_geometry(idx)
                     ctx.mark_non_differentiable(scale, shift)
                     return ystar, scale, shift  # ystar is saved above AND returned: an output may be saved
             else:
@@ -528,7 +540,7 @@ class _PointwiseMLP(Function):
                 shift = (beta.double() - running_mean.double() * scale64).float()
                 _lib.check(lib.cl3d_pwmlp_fwd(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(scale),
                                               _p(shift), B, N, M, K, Co, float(radius), _p(out), 1, None, None, st))
-        _join_inverse(idx)
+        _join_geometry(idx)
         return out
 
     @staticmethod
@@ -571,13 +583,13 @@ class _PointwiseMLP(Function):
             # ~29 us before the next kernel starts) than these two short launches take together (~15 us)
             coeffs()
             hits()
-            off, slots = inverse_index(idx, N)
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
             if _use_summary():
-                rec, ent = support_summary(idx, N, query_xyz, support_xyz, ctx.radius)
+                rec, ent = support_summary(idx, N, query_xyz, support_xyz, ctx.radius)  # (waits for it; covers the CSR build)
                 _lib.check(lib.cl3d_pwmlp_bwd_support_sum(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t),
                                                           _p(sy), _p(rec), _p(ent), B, N, M, K, Co, _p(dght), st))
             else:
+                off, slots = inverse_index(idx, N)
                 _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t), _p(sy),
                                                       _p(qtab), _p(support_xyz), ctx.radius, _p(off), _p(slots),
                                                       B, N, M, K, Co, _p(dght), st))

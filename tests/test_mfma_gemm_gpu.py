@@ -23,6 +23,9 @@ SHAPES = [  # B, C, N, Co
     (1, 36, 250, 20),      # N % 4 != 0: the scalar staging fallback
     (2, 288, 512, 288),    # several output tiles and K chunks
     (1, 8, 64, 4),         # smaller than one tile in every direction
+    (2, 36, 2048, 36),     # forward product: the LDS-free kernel (C in {32, 36, 64, 72}, whole 32-point blocks), 72 outputs = 3 column tiles
+    (1, 72, 1024, 72),     # the same with 144 outputs: five column tiles over two workgroup rows
+    (3, 32, 96, 16),       # one column tile, three blocks per cloud
 ]
 
 
