@@ -3,14 +3,15 @@
 // Tiles of TR x TC elements through LDS (row stride TC + 1: conflict-free both ways).  When both extents are
 // multiples of four (and the pointers 16-byte aligned) every global access is a 16-byte vector -- four consecutive
 // columns of a source row on the way in, four consecutive source rows of one column on the way out -- and the tile
-// extents follow the shape (72 channels are ONE tile of 72 rows, not 64 + 8): round 2's kernel moved 4 bytes per
+// extents follow the shape (72 channels are ONE tile of 72 rows, not 64 + 8; tile_shape): round 2's kernel moved 4 bytes per
 // lane in fixed 64 x 64 tiles and reached 1.1 TB/s on the [16,64,4096] tensors of the operator benches (30 us for
 // 33.5 MB; the 72-channel case ran half its workgroups on 8-row tiles).
 #include "cl3d_common.h"
 
 namespace cl3d {
 
-constexpr int kTrMax = 96;  // largest tile extent (LDS: 96 x 97 floats)
+constexpr int kTrMax = 96;         // largest tile extent
+constexpr int kTrFloats = 3200;    // largest padded tile (12.5 KB of LDS: see tile_shape)
 
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                         int R, int C) {
@@ -39,14 +40,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 // R % 4 == 0, C % 4 == 0, TR % 4 == 0, TC % 4 == 0, TR, TC <= kTrMax
 __global__ __launch_bounds__(256) void transpose4_kernel(const float *__restrict__ src, float *__restrict__ dst, int R,
                                                          int C, int TR, int TC) {
-  __shared__ float tile[kTrMax * (kTrMax + 1)];
+  __shared__ float tile[kTrFloats];
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * TR, c0 = blockIdx.x * TC;
   const float *s = src + (size_t)b * R * C;
   float *d = dst + (size_t)b * R * C;
   const int ld = TC + 1;
   const int cq = TC / 4, rq = TR / 4;
-  constexpr int kMaxV = (kTrMax * kTrMax / 4 + 255) / 256;  // float4 per thread, at most
+  constexpr int kMaxV = (kTrFloats / 4 + 255) / 256;  // float4 per thread, at most
   float4 v[kMaxV];
 #pragma unroll
   for (int u = 0; u < kMaxV; ++u) {  // every load of the thread in flight
@@ -86,6 +87,25 @@ static int tile_extent(int n) {
   return t > kTrMax ? 64 : t;
 }
 
+// Tile of a [R,C] plane.  The padded tile stays under 12.5 KB: the layout changes of an operator's forward pass are
+// queued beside the ball query, whose workgroup leaves ~13 KB of a CU's LDS free (csrc/ball_query_lds.hip) -- a 37 KB
+// tile (96 x 97, rounds 2-3) only got onto a CU when a ball-query workgroup retired (replayed PosPool step: the
+// transpose of the features ended 4 us AFTER the ball query instead of 27 us before its end; the gather pass that
+// waits for both starts one cross-queue hop after the ball query either way, so the step gained nothing measurable
+// there, PseudoGrid 1.2 %).  The long axis gives way first
+// (32 elements = one 128-byte line per row of the tile), then the short one.
+static void tile_shape(int R, int C, int *tr, int *tc) {
+  int TR = tile_extent(R), TC = tile_extent(C);
+  const auto fits = [](int a, int b) { return a * (b + 1) <= kTrFloats; };
+  if (!fits(TR, TC) && C > kTrMax) TC = 32;
+  if (!fits(TR, TC) && R > kTrMax) TR = 32;
+  while (!fits(TR, TC)) {  // both axes short and the plane still too large: halve the longer extent
+    if (TR >= TC) TR = ((TR / 2) + 3) & ~3; else TC = ((TC / 2) + 3) & ~3;
+  }
+  *tr = TR;
+  *tc = TC;
+}
+
 }  // namespace cl3d
 
 extern "C" int cl3d_transpose(const float *src, int B, int R, int C, float *dst, cl3d_stream_t stream) {
@@ -95,7 +115,8 @@ extern "C" int cl3d_transpose(const float *src, int B, int R, int C, float *dst,
   CL3D_REQUIRE(B <= 65535, "transpose: grid limit");
   const bool vec = (R & 3) == 0 && (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
   if (vec) {
-    const int TR = cl3d::tile_extent(R), TC = cl3d::tile_extent(C);
+    int TR, TC;
+    cl3d::tile_shape(R, C, &TR, &TC);
     CL3D_REQUIRE(cl3d::ceil_div(R, TR) <= 65535, "transpose: grid limit");
     hipLaunchKernelGGL(cl3d::transpose4_kernel, dim3(cl3d::ceil_div(C, TC), cl3d::ceil_div(R, TR), B), dim3(256), 0,
                        (hipStream_t)stream, src, dst, R, C, TR, TC);
