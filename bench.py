@@ -155,7 +155,7 @@ L2_PEAK = 34.5e12  # B/s aggregate L2 bandwidth (MI355X_MICROARCH.md, "L2 (per X
 ENTRY_KERNELS = {
     "cl3d_masked_ordered_ball_query": ["bq_tile_kernel", "bq_prep_kernel", "bq_query_kernel", "ball_query_kernel"],
     "cl3d_build_inverse_index": ["csr_count_fill_kernel", "csr_rows_kernel", "csr_scan_kernel"],
-    "cl3d_pwmlp_point_gemm_fwd": ["pwmlp_weights_kernel", "mfma_gemm_kernel"],
+    "cl3d_pwmlp_point_gemm_fwd": ["pwmlp_weights_kernel", "pwmlp_rows_nolds_kernel", "mfma_gemm_kernel"],
     "cl3d_pwmlp_point_gemm_bwd_data": ["mfma_gemm_kernel"],
     "cl3d_pwmlp_point_gemm_bwd_weight": ["mfma_gemm_kernel", "gemm_reduce_kernel"],
     "cl3d_pwmlp_stats": ["pwmlp_query_kernel<0"],
@@ -169,7 +169,7 @@ ENTRY_KERNELS = {
     "cl3d_pwmlp_bwd_support_sum": ["pwmlp_support_sum_kernel"],
     "cl3d_fused_reduce_fwd": ["fused_reduce_fwd_kernel"],
     "cl3d_fused_reduce_bwd": ["fused_reduce_bwd_kernel", "pg_dkw_kernel"],
-    "cl3d_transpose": ["transpose_kernel"],
+    "cl3d_transpose": ["transpose_kernel", "transpose4_kernel"],
     "cl3d_bn_relu_stats": ["bn_stats_kernel", "bn_finalize_kernel"],
     "cl3d_bn_relu_apply": ["bn_apply_kernel"],
     "cl3d_bn_relu_bwd": ["bn_bwd"],
@@ -278,7 +278,8 @@ def contraction_block(B, C, N, Co, precision, reps=30):
     m = bench_point_gemm.measure(B, C, N, Co, reps=reps)
     mine = m["mfma_" + precision]
     us = mine["fwd_us"] + mine["bwd_data_us"] + mine["bwd_weight_us"]
-    out = {"kernel": "cl3d::mfma_gemm_kernel (csrc/mfma_gemm.hip)", "precision": precision,
+    out = {"kernel": "cl3d::mfma_gemm_kernel + cl3d::pwmlp_rows_nolds_kernel (f32 forward) (csrc/mfma_gemm.hip)",
+           "precision": precision,
            "instruction": "v_mfma_f32_32x32x2_f32" if precision == "f32" else "v_mfma_f32_32x32x16_bf16",
            "flops": 3 * m["flops_per_gemm"], "us": round(us, 2),
            "fwd_us": round(mine["fwd_us"], 2), "bwd_data_us": round(mine["bwd_data_us"], 2),

@@ -31,7 +31,7 @@ for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py |
 for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --n 1024 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
 for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --mult 4.0 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
 echo "== step variants: cell grid, two queries per lane group, slot-walking support pass, batch walk, points stored in cell order (experiment)" | tee -a $OUT/summary.txt
-for v in "CL3D_BQ_PATH=cells" "CL3D_PW_QPG=2" "CL3D_PW_SUMMARY=0" "CL3D_PW_PIPE=0" "CL3D_BENCH_SORTED=1"; do
+for v in "CL3D_BQ_PATH=cells" "CL3D_PW_QPG=2" "CL3D_PW_SUMMARY=0" "CL3D_PW_PIPE=0" "CL3D_GEMM_NOLDS=0" "CL3D_BENCH_SORTED=1"; do
   env $v timeout 300 python bench.py --no-cpu-baseline --no-kernel-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', 'ms_per_step', d['ms_per_step'])" | tee -a $OUT/step_variants.txt | tee -a $OUT/summary.txt
 done
 echo "== micro-benchmarks: 2.1 M random 256-byte row gathers by row pitch; coordinates as 3 x dword vs 1 x dwordx4" | tee -a $OUT/summary.txt
