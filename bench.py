@@ -155,7 +155,8 @@ L2_PEAK = 34.5e12  # B/s aggregate L2 bandwidth (MI355X_MICROARCH.md, "L2 (per X
 ENTRY_KERNELS = {
     "cl3d_masked_ordered_ball_query": ["bq_tile_kernel", "bq_prep_kernel", "bq_query_kernel", "ball_query_kernel"],
     "cl3d_build_inverse_index": ["csr_count_fill_kernel", "csr_rows_kernel", "csr_scan_kernel"],
-    "cl3d_pwmlp_point_gemm_fwd": ["pwmlp_weights_kernel", "pwmlp_rows_nolds_kernel", "mfma_gemm_kernel"],
+    # (f32: the LDS-free kernel; bf16 and other shapes: mfma_gemm_kernel, see entry_kernels)
+    "cl3d_pwmlp_point_gemm_fwd": ["pwmlp_weights_kernel", "pwmlp_rows_nolds_kernel"],
     "cl3d_pwmlp_point_gemm_bwd_data": ["mfma_gemm_kernel"],
     "cl3d_pwmlp_point_gemm_bwd_weight": ["mfma_gemm_kernel", "gemm_reduce_kernel"],
     "cl3d_pwmlp_stats": ["pwmlp_query_kernel<0"],
@@ -174,6 +175,14 @@ ENTRY_KERNELS = {
     "cl3d_bn_relu_apply": ["bn_apply_kernel"],
     "cl3d_bn_relu_bwd": ["bn_bwd"],
 }
+
+
+def entry_kernels(entry, counters):
+    """Kernel-name prefixes of one C-ABI entry point, given the kernels a PMC session actually saw."""
+    prefs = list(ENTRY_KERNELS.get(entry, []))
+    if entry == "cl3d_pwmlp_point_gemm_fwd" and not any("pwmlp_rows_nolds_kernel" in k for k in counters):
+        prefs.append("mfma_gemm_kernel")
+    return prefs
 
 
 def step_model_bytes(B, N, M, K, C, kind="pointwisemlp"):
@@ -252,11 +261,11 @@ def step_table(compute, B, N, M, K, C, reps, kind="pointwisemlp"):
         row = {"entry": name, "calls": calls, "us": round(us_step, 2), "us_min": round(min(runs), 2),
                "us_max": round(max(runs), 2), "algorithmic_bytes": alg,
                "hbm_frac": round(alg / (us_step * 1e-6) / HBM_PEAK, 4) if us_step > 0 else None, "bound": bound,
-               "kernels": ENTRY_KERNELS.get(name, [])}
+               "kernels": entry_kernels(name, counters)}
         hb = lb = 0.0
         found = False
         for kname, rec in counters.items():
-            if any(kname.replace("cl3d::", "").startswith(pref) for pref in ENTRY_KERNELS.get(name, [])):
+            if any(kname.replace("cl3d::", "").startswith(pref) for pref in entry_kernels(name, counters)):
                 hb += rec.get("hbm_bytes", 0.0)
                 lb += rec.get("l2_bytes", 0.0)
                 found = True

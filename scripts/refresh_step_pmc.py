@@ -10,7 +10,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from bench import ENTRY_KERNELS, L2_PEAK  # noqa: E402
+from bench import L2_PEAK, entry_kernels  # noqa: E402
 
 
 def main():
@@ -22,10 +22,11 @@ def main():
         hb = lb = 0.0
         found = False
         for kname, rec in counters.items():
-            if any(kname.replace("cl3d::", "").startswith(pref) for pref in ENTRY_KERNELS.get(row["entry"], [])):
+            if any(kname.replace("cl3d::", "").startswith(pref) for pref in entry_kernels(row["entry"], counters)):
                 hb += rec.get("hbm_bytes", 0.0)
                 lb += rec.get("l2_bytes", 0.0)
                 found = True
+        row["kernels"] = entry_kernels(row["entry"], counters)
         row.pop("hbm_bytes_pmc", None)
         row.pop("l2_bytes_pmc", None)
         row.pop("l2_frac", None)
