@@ -21,6 +21,10 @@ struct BnArgs {
   int B, C, N, chunks, span;   // a block reduces `span` points of one (cloud, channel) row
 };
 
+// points of one (cloud, channel) row per workgroup of the statistics passes (2048 -- twice the workgroups, two 16-byte
+// items per thread instead of four -- measured in round 3: no faster, 6.7 / 12.4 against 7.4 / 12.0 us)
+constexpr int kBnSpan = 16384;
+
 __device__ __forceinline__ double block_sum(double v, double *scratch) {
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -193,7 +197,10 @@ struct Bn2Args {
   int B, C, N, chunks, span;
   int mode2;             // 0: no second branch, 1: identity, 2: affine (its own BatchNorm)
   int relu;
+  int vec;               // N % 4 == 0 and every tensor 16-byte aligned: the backward kernels move 16 bytes per lane
 };
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
 
 __global__ __launch_bounds__(256) void bn2_apply_kernel(Bn2Args a) {
   const long long rows = (long long)a.B * a.C;
@@ -238,16 +245,39 @@ __global__ __launch_bounds__(256) void bn2_bwd_stats_kernel(Bn2Args a) {
   const float *ref = a.relu ? a.out_ref + row : nullptr;
   const float mu1 = a.mu1[c], is1 = a.is1[c];
   const float mu2 = a.mode2 == 2 ? a.mu2[c] : 0.f, is2 = a.mode2 == 2 ? a.is2[c] : 0.f;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f;  // <= 64 terms per thread between the double folds
   double d0 = 0.0, d1 = 0.0, d2 = 0.0;
   int it = 0;
-  for (int n = n0 + (int)threadIdx.x; n < n1; n += 256) {
-    const float dz = (a.relu && !(ref[n] > 0.f)) ? 0.f : g[n];
-    s0 += dz;
-    s1 = __builtin_fmaf(dz, (x1[n] - mu1) * is1, s1);
-    if (a.mode2 == 2) s2 = __builtin_fmaf(dz, (x2[n] - mu2) * is2, s2);
-    if (++it == 64) {
-      d0 += (double)s0; d1 += (double)s1; d2 += (double)s2; s0 = s1 = s2 = 0.f; it = 0;
+  if (a.vec) {
+    // 16 bytes per lane and array (round 3; the scalar form below read 57 MB in 15.6 us at the operator benches'
+    // [16,72,4096]: 3.6 TB/s)
+    for (int n = n0 + 4 * (int)threadIdx.x; n < n1; n += 1024) {
+      const float4 gv = ld4(g + n), xv = ld4(x1 + n);
+      float4 rv = make_float4(1.f, 1.f, 1.f, 1.f), yv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (a.relu) rv = ld4(ref + n);
+      if (a.mode2 == 2) yv = ld4(x2 + n);
+      const float gg[4] = {gv.x, gv.y, gv.z, gv.w}, xx[4] = {xv.x, xv.y, xv.z, xv.w};
+      const float rr[4] = {rv.x, rv.y, rv.z, rv.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float dz = (a.relu && !(rr[e] > 0.f)) ? 0.f : gg[e];
+        s0 += dz;
+        s1 = __builtin_fmaf(dz, (xx[e] - mu1) * is1, s1);
+        if (a.mode2 == 2) s2 = __builtin_fmaf(dz, (yy[e] - mu2) * is2, s2);
+      }
+      if (++it == 16) {
+        d0 += (double)s0; d1 += (double)s1; d2 += (double)s2; s0 = s1 = s2 = 0.f; it = 0;
+      }
+    }
+  } else {
+    for (int n = n0 + (int)threadIdx.x; n < n1; n += 256) {
+      const float dz = (a.relu && !(ref[n] > 0.f)) ? 0.f : g[n];
+      s0 += dz;
+      s1 = __builtin_fmaf(dz, (x1[n] - mu1) * is1, s1);
+      if (a.mode2 == 2) s2 = __builtin_fmaf(dz, (x2[n] - mu2) * is2, s2);
+      if (++it == 64) {
+        d0 += (double)s0; d1 += (double)s1; d2 += (double)s2; s0 = s1 = s2 = 0.f; it = 0;
+      }
     }
   }
   d0 += (double)s0; d1 += (double)s1; d2 += (double)s2;
@@ -279,6 +309,30 @@ __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(Bn2Args a) {
       A2 = a.c2[c]; B2 = a.c2[a.C + c]; D2 = a.c2[2 * a.C + c];
     }
     const size_t row = (size_t)r * a.N;
+    if (a.vec) {
+      // every load of the item before its first store (the scalar form's stores, which may alias the inputs as far as
+      // the compiler knows, serialised it: 57 MB in 23.6 us at [16,72,4096])
+      if (n < a.N) {
+        const float4 gv = ld4(a.g + row + n), xv = ld4(a.x1 + row + n);
+        float4 rv = make_float4(1.f, 1.f, 1.f, 1.f), yv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.relu) rv = ld4(a.out_ref + row + n);
+        if (a.mode2 == 2) yv = ld4(a.x2 + row + n);
+        float4 dz;
+        dz.x = (a.relu && !(rv.x > 0.f)) ? 0.f : gv.x;
+        dz.y = (a.relu && !(rv.y > 0.f)) ? 0.f : gv.y;
+        dz.z = (a.relu && !(rv.z > 0.f)) ? 0.f : gv.z;
+        dz.w = (a.relu && !(rv.w > 0.f)) ? 0.f : gv.w;
+        *reinterpret_cast<float4 *>(a.o1 + row + n) =
+            make_float4(__builtin_fmaf(A1, dz.x, __builtin_fmaf(D1, xv.x, B1)), __builtin_fmaf(A1, dz.y, __builtin_fmaf(D1, xv.y, B1)),
+                        __builtin_fmaf(A1, dz.z, __builtin_fmaf(D1, xv.z, B1)), __builtin_fmaf(A1, dz.w, __builtin_fmaf(D1, xv.w, B1)));
+        if (a.mode2 == 1) *reinterpret_cast<float4 *>(a.o2 + row + n) = dz;
+        else if (a.mode2 == 2)
+          *reinterpret_cast<float4 *>(a.o2 + row + n) =
+              make_float4(__builtin_fmaf(A2, dz.x, __builtin_fmaf(D2, yv.x, B2)), __builtin_fmaf(A2, dz.y, __builtin_fmaf(D2, yv.y, B2)),
+                          __builtin_fmaf(A2, dz.z, __builtin_fmaf(D2, yv.z, B2)), __builtin_fmaf(A2, dz.w, __builtin_fmaf(D2, yv.w, B2)));
+      }
+      continue;
+    }
     for (int e = 0; e < 4; ++e) {
       const int m = n + e;
       if (m >= a.N) break;
@@ -469,7 +523,7 @@ __global__ __launch_bounds__(256) void bn2_bwd_small_kernel(BnSmallArgs a) {
 }
 
 static void bn_shape(BnArgs &a) {
-  a.span = 16384;
+  a.span = kBnSpan;
   a.chunks = ceil_div(a.N, a.span);
 }
 
@@ -477,7 +531,7 @@ static void bn_shape(BnArgs &a) {
 
 extern "C" int cl3d_bn_partials(int B, int C, int N) {
   (void)C;
-  return B * cl3d::ceil_div(N > 0 ? N : 1, 16384);
+  return B * cl3d::ceil_div(N > 0 ? N : 1, cl3d::kBnSpan);
 }
 
 extern "C" int cl3d_bn_relu_stats(const float *x, int B, int C, int N, double *partial, int n_partials, double count,
@@ -581,8 +635,10 @@ extern "C" int cl3d_bn_add_relu_bwd(const float *g, const float *out, const floa
   a.g = g; a.out_ref = out; a.x1 = x1; a.mu1 = mean1; a.is1 = invstd1; a.x2 = x2; a.mu2 = mean2; a.is2 = invstd2;
   a.B = B; a.C = C; a.N = N; a.relu = relu; a.mode2 = !x2 ? 0 : (gamma2 ? 2 : 1);
   a.p1 = partial; a.p2 = partial + (size_t)n_partials * C * 2;
-  a.span = 16384;
+  a.span = kBnSpan;
   a.chunks = ceil_div(N, a.span);
+  a.vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(x1) |
+                            reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(dx1) | reinterpret_cast<uintptr_t>(dx2)) & 15u) == 0;
   hipLaunchKernelGGL(bn2_bwd_stats_kernel, dim3(C, n_partials), dim3(256), 0, st, a);
   BnFinArgs f{};
   f.partial = a.p1; f.G = n_partials; f.C = C; f.count = count; f.gamma = gamma1; f.mean_in = mean1; f.invstd_in = invstd1;
