@@ -399,7 +399,7 @@ struct ParamCount {
   static constexpr int value = OP == OP_ADAPTIVE ? 4 : 0;  // PseudoGrid: d kernel_weights comes from pg_dkw_kernel
 };
 
-template <int OP, int V, bool SPARSE = false>
+template <int OP, int V, bool SPARSE = false, int SBX = 4>
 __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
   extern __shared__ float lds[];
   // slot records staged per round; PseudoGrid also stages the kMaxKP kernel-point influences of every slot,
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void fused_reduce_bwd_kernel(ReduceArgs a) {
       float acc[V];
 #pragma unroll
       for (int v = 0; v < V; ++v) acc[v] = 0.f;
-      constexpr int SB = 4;  // gout rows in flight per lane
+      constexpr int SB = SBX;  // gout rows in flight per lane
       for (int cbeg = e_lo; cbeg < e_hi; cbeg += kBwdCap) {
         const int cn = e_hi - cbeg < kBwdCap ? e_hi - cbeg : kBwdCap;
         __syncthreads();  // the previous round's records have been consumed
@@ -823,7 +823,9 @@ static void launch_fwd(int op, const ReduceArgs &a, dim3 grid, size_t lds, hipSt
 template <int V>
 static void launch_bwd(int op, const ReduceArgs &a, dim3 grid, dim3 block, size_t lds, hipStream_t st) {
   switch (op) {
-    case OP_POSPOOL_XYZ: hipLaunchKernelGGL((fused_reduce_bwd_kernel<OP_POSPOOL_XYZ, V>), grid, block, lds, st, a); break;
+    // eight gout rows in flight per lane for the cheapest weight (58 -> ~90 registers, still 5 waves / SIMD): PosPool
+    // step 0.288 -> 0.285 ms; AdaptiveWeight, which carries its parameter partials, loses 4 % that way and keeps four
+    case OP_POSPOOL_XYZ: hipLaunchKernelGGL((fused_reduce_bwd_kernel<OP_POSPOOL_XYZ, V, false, 8>), grid, block, lds, st, a); break;
     case OP_POSPOOL_SINCOS: hipLaunchKernelGGL((fused_reduce_bwd_kernel<OP_POSPOOL_SINCOS, V>), grid, block, lds, st, a); break;
     case OP_ADAPTIVE: hipLaunchKernelGGL((fused_reduce_bwd_kernel<OP_ADAPTIVE, V>), grid, block, lds, st, a); break;
     default:
