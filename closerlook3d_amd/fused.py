@@ -247,7 +247,7 @@ class _FusedReduce(Function):
 
     @staticmethod
     def forward(ctx, features, p0, p1, op, query_xyz, support_xyz, query_mask, idx, idx_mask, radius,
-                normalize, reduction, pint, pfloat, constant, need_grad):
+                normalize, reduction, pint, pfloat, constant, need_grad, defer_join=False):
         B, C, N = features.shape
         _, M, K = idx.shape
         ft = _transposed(features)
@@ -265,7 +265,8 @@ class _FusedReduce(Function):
         ctx.save_for_backward(ft, slotrec, p0, p1, pairs)
         ctx.idx = idx
         ctx.meta = (op, B, N, M, K, C, pint, pfloat, constant)
-        _join_inverse(idx)
+        if not defer_join:
+            _join_inverse(idx)
         return out
 
     @staticmethod
@@ -291,7 +292,7 @@ class _FusedReduce(Function):
             g0, g1 = d[:, :3].contiguous(), d[:, 3].contiguous()
         elif op == OP_PSEUDOGRID:
             g1 = dparam.double().sum(0)[:, :pint].t().float().contiguous()
-        return (dfeat, g0, g1) + (None,) * 13
+        return (dfeat, g0, g1) + (None,) * 14
 
 
 def _checked(features, query_xyz, support_xyz, query_mask, support_mask):
@@ -325,7 +326,25 @@ def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, ne
     return idx, idx_mask
 
 
-def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, embedding, reduction):
+def _deferred(out, idx, defer_join):
+    """defer_join: the operator module runs its BatchNorm + ReLU behind this call and joins the CSR build after those
+    (join_pending) instead of before them -- the build is longer than the gather pass it runs beside (replayed PosPool
+    step: the statistics pass started 19 us after the gather pass ended, waiting for a table only the backward reads)."""
+    if defer_join:
+        out._cl3d_pending = idx
+    return out
+
+
+def join_pending(out):
+    """The caller's stream picks up the CSR build left running by an operator called with defer_join=True."""
+    idx = getattr(out, '_cl3d_pending', None)
+    if idx is not None:
+        _join_inverse(idx)
+        out._cl3d_pending = None
+
+
+def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, embedding, reduction,
+            defer_join=False):
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, _wants_grad(features))
     C = features.shape[1]
@@ -339,31 +358,34 @@ def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, 
         fd = C // 6
         op = OP_POSPOOL_SINCOS
         p0 = torch.pow(1.0 * 1000, (1.0 / fd) * torch.arange(fd, dtype=torch.float32, device=features.device))
-    return _FusedReduce.apply(features, p0, None, op, query_xyz, support_xyz, query_mask, idx, idx_mask, radius,
-                              True, _RED[reduction], 0, 0.0, False, _wants_grad(features))
+    out = _FusedReduce.apply(features, p0, None, op, query_xyz, support_xyz, query_mask, idx, idx_mask, radius,
+                             True, _RED[reduction], 0, 0.0, False, _wants_grad(features), defer_join)
+    return _deferred(out, idx, defer_join)
 
 
 def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps,
-                    shared_channels, reduction):
+                    shared_channels, reduction, defer_join=False):
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     conv = mlps.conv0
     w = conv.weight.view(conv.weight.shape[0], 3)
     idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
                            _wants_grad(features, w, conv.bias))
-    return _FusedReduce.apply(features, w, conv.bias, OP_ADAPTIVE, query_xyz, support_xyz, query_mask, idx,
-                              idx_mask, radius, True, _RED[reduction], int(shared_channels), 0.0, False,
-                              _wants_grad(features, w, conv.bias))
+    out = _FusedReduce.apply(features, w, conv.bias, OP_ADAPTIVE, query_xyz, support_xyz, query_mask, idx,
+                             idx_mask, radius, True, _RED[reduction], int(shared_channels), 0.0, False,
+                             _wants_grad(features, w, conv.bias), defer_join)
+    return _deferred(out, idx, defer_join)
 
 
 def pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, k_points,
-                kernel_weights, extent, influence):
+                kernel_weights, extent, influence, defer_join=False):
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
                            _wants_grad(features, kernel_weights))
-    return _FusedReduce.apply(features, k_points.contiguous(), kernel_weights, OP_PSEUDOGRID, query_xyz,
-                              support_xyz, query_mask, idx, idx_mask, radius, False, _RED['sum'],
-                              int(k_points.shape[0]), 1.0 / float(extent), influence == 'constant',
-                              _wants_grad(features, kernel_weights))
+    out = _FusedReduce.apply(features, k_points.contiguous(), kernel_weights, OP_PSEUDOGRID, query_xyz,
+                             support_xyz, query_mask, idx, idx_mask, radius, False, _RED['sum'],
+                             int(k_points.shape[0]), 1.0 / float(extent), influence == 'constant',
+                             _wants_grad(features, kernel_weights), defer_join)
+    return _deferred(out, idx, defer_join)
 
 
 class _MaxPool(Function):

@@ -68,8 +68,10 @@ class _OutputTransform(nn.Module):
             from . import fused
             seq = self.out_conv if self.output_conv else self.out_transform
             y = fused.bn_relu(seq[0](x) if self.output_conv else x, seq[-2])
-            if y is not None:
-                return y
+            if y is None:
+                y = self.out_conv(x) if self.output_conv else self.out_transform(x)
+            fused.join_pending(x)  # the CSR build of an operator called with defer_join=True: joined behind the BatchNorm
+            return y
         return self.out_conv(x) if self.output_conv else self.out_transform(x)
 
 
@@ -105,7 +107,7 @@ class PosPool(_OutputTransform):
         from . import fused
         if fused.use_fused(self.impl, 'pospool', self):
             out = fused.pospool(query_xyz, support_xyz, query_mask, support_mask, support_features,
-                                self.radius, self.nsample, self.position_embedding, self.reduction)
+                                self.radius, self.nsample, self.position_embedding, self.reduction, defer_join=True)
             return self._output(out)
         feats, rel, nmask = self.grouper(query_xyz, support_xyz, query_mask, support_mask, support_features)
         agg = feats * self._embedding(rel, support_features.shape[1])
@@ -144,7 +146,7 @@ class AdaptiveWeight(_OutputTransform):
         if fused.use_fused(self.impl, 'adaptive_weight', self):
             out = fused.adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, support_features,
                                         self.radius, self.nsample, self.mlps, self.shared_channels,
-                                        self.reduction)
+                                        self.reduction, defer_join=True)
             return self._output(out)
         B, C, M = support_features.shape[0], support_features.shape[1], query_xyz.shape[1]
         feats, rel, nmask = self.grouper(query_xyz, support_xyz, query_mask, support_mask, support_features)
@@ -265,7 +267,7 @@ class PseudoGrid(_OutputTransform):
         if fused.use_fused(self.impl, 'pseudo_grid', self):
             out = fused.pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, support_features,
                                     self.radius, self.nsample, self.K_points, self.kernel_weights,
-                                    self.extent, self.KP_influence)
+                                    self.extent, self.KP_influence, defer_join=True)
             return self._output(out)
         B, C, M = support_features.shape[0], support_features.shape[1], query_xyz.shape[1]
         feats, rel, nmask = self.grouper(query_xyz, support_xyz, query_mask, support_mask, support_features)
