@@ -31,6 +31,7 @@ SIGNATURES = {
     "cl3d_build_inverse_index": [_P, _I, _I, _I, _P, _P, _P, _Z, _P],
     "cl3d_fused_reduce_fwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _I, _F, _I, _P, _I, _P, _P, _P],
     "cl3d_fused_param_partials": [_I, _I, _I, _I],
+    "cl3d_fused_param_reduce": [_I, _P, _I, _I, _I, _P, _P, _P],
     "cl3d_fused_reduce_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _F, _I, _P, _I, _P, _I, _P],
     "cl3d_maxpool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cl3d_maxpool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],

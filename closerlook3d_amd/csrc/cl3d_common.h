@@ -17,6 +17,9 @@ inline char *err_buf() {
   static thread_local char buf[512] = "";
   return buf;
 }
+// (format-checked: a bare '%' in a message is a conversion to vsnprintf -- one such message crashed its own
+// bad-argument test in round 3)
+inline int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
 inline int fail(int code, const char *fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

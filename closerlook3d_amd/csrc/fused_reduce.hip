@@ -888,7 +888,68 @@ bool fused_reduce_supported(int op, int K, int C) {
   return true;
 }
 
+// ---- the blocks' parameter-gradient partials dparam [G, C, NP] summed in double in a fixed order, written in the
+// parameters' own layouts: PseudoGrid d kernel_weights [P, C]; AdaptiveWeight (S consecutive channels share one weight
+// row) d W [C/S, 3] and d bias [C/S].  One workgroup per output row (a channel / a group of S channels); thread =
+// (partial-block lane, column), eight loads in flight.  Replaces five to six library launches per step (cast to double,
+// sum, slice, transpose, cast back: 33 us of the replayed PseudoGrid step) with one.
+template <int NP>
+__global__ __launch_bounds__(256) void param_reduce_kernel(const float *__restrict__ dparam, int G, int C, int S,
+                                                           int pint, int adaptive, float *__restrict__ out0,
+                                                           float *__restrict__ out1) {
+  __shared__ double s_red[256];
+  constexpr int LG = 256 / NP, UB = 8;
+  const int row = blockIdx.x;
+  const int k = threadIdx.x % NP, gl = threadIdx.x / NP;
+  double acc = 0.0;
+  for (int s = 0; s < S; ++s) {
+    const float *col = dparam + (size_t)(row * S + s) * NP + k;
+    for (int g0 = gl; g0 < G; g0 += LG * UB) {
+      float v[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const int g = g0 + u * LG;
+        v[u] = col[(size_t)(g < G ? g : G - 1) * C * NP];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (g0 + u * LG < G) acc += (double)v[u];
+    }
+  }
+  s_red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int stride = LG / 2; stride >= 1; stride >>= 1) {  // the partial-block lanes folded pairwise, always the same pairs
+    if (gl < stride) s_red[threadIdx.x] += s_red[threadIdx.x + stride * NP];
+    __syncthreads();
+  }
+  if (gl != 0) return;
+  const float r = (float)s_red[k];
+  if (adaptive) {
+    if (k < 3) out0[row * 3 + k] = r;
+    else if (k == 3) out1[row] = r;
+  } else if (k < pint) {
+    out1[(size_t)k * C + row] = r;
+  }
+}
+
 }  // namespace cl3d
+
+extern "C" int cl3d_fused_param_reduce(int op, const float *dparam, int n_partials, int C, int pint, float *g0,
+                                       float *g1, cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(op == OP_ADAPTIVE || op == OP_PSEUDOGRID, "fused_param_reduce: operator without parameters");
+  CL3D_REQUIRE(dparam && g1 && n_partials >= 1 && C >= 1 && pint >= 1, "fused_param_reduce: bad arguments");
+  if (op == OP_ADAPTIVE) {
+    CL3D_REQUIRE(g0 && C % pint == 0, "fused_param_reduce: AdaptiveWeight needs d W and C %% shared_channels == 0 (C=%d, shared_channels=%d)", C, pint);
+    hipLaunchKernelGGL(param_reduce_kernel<4>, dim3(C / pint), dim3(256), 0, (hipStream_t)stream, dparam, n_partials, C,
+                       pint, pint, 1, g0, g1);
+  } else {
+    CL3D_REQUIRE(pint <= kMaxKP, "fused_param_reduce: too many kernel points");
+    hipLaunchKernelGGL(param_reduce_kernel<kMaxKP>, dim3(C), dim3(256), 0, (hipStream_t)stream, dparam, n_partials, C,
+                       1, pint, 0, g0, g1);
+  }
+  return check_launch("cl3d_fused_param_reduce");
+}
 
 extern "C" int cl3d_fused_param_partials(int op, int B, int N, int C) {
   (void)C;

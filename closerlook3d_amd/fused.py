@@ -285,13 +285,17 @@ class _FusedReduce(Function):
                                                  C, _p(p0), _p(p1), pint, float(pfloat), int(constant), _p(dfeat), 1,
                                                  _p(dparam), nparts, _stream(gout)))
         g0 = g1 = None
-        # the blocks' partial sums are added in double: they are a few hundred terms that cancel heavily (a channel's
-        # gradient is often two orders of magnitude below its partial sums)
+        # the blocks' partial sums are added in double, in a fixed order: they are a few hundred terms that cancel heavily
+        # (a channel's gradient is often two orders of magnitude below its partial sums); one launch that also writes the
+        # parameters' own layouts (the same through five or six library launches: 33 us of the replayed PseudoGrid step)
         if op == OP_ADAPTIVE:
-            d = dparam.double().sum(0).view(C // pint, pint, 4).sum(1).float()  # fixed-order reductions
-            g0, g1 = d[:, :3].contiguous(), d[:, 3].contiguous()
+            g0 = torch.empty((C // pint, 3), dtype=torch.float32, device=gout.device)
+            g1 = torch.empty((C // pint,), dtype=torch.float32, device=gout.device)
         elif op == OP_PSEUDOGRID:
-            g1 = dparam.double().sum(0)[:, :pint].t().float().contiguous()
+            g1 = torch.empty((pint, C), dtype=torch.float32, device=gout.device)
+        if g1 is not None:
+            with _lib.on_device(gout.device):
+                _lib.check(lib.cl3d_fused_param_reduce(op, _p(dparam), nparts, C, pint, _p(g0), _p(g1), _stream(gout)))
         return (dfeat, g0, g1) + (None,) * 14
 
 

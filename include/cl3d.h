@@ -227,6 +227,13 @@ int cl3d_fused_reduce_fwd(int op, const float *query_xyz, const float *support_x
 /* number of partial blocks of the parameter-gradient buffer dparam [n, C, NP] (NP = 4 adaptive:
  * dW[:,0..2], dbias; 16 pseudo grid: d kernel_weights[p]); 0 for operators without parameters. */
 int cl3d_fused_param_partials(int op, int B, int N, int C);
+/* dparam [n_partials, C, NP] -> the parameters' gradients, summed in double in a fixed order (what the reference's
+ * autograd leaves in conv0.weight.grad / conv0.bias.grad of AdaptiveWeight, local_aggregation_operators.py:188-214,
+ * and in kernel_weights.grad of PseudoGrid, :383-419):
+ *   CL3D_OP_ADAPTIVE   pint = shared_channels: g0 = d W [C/pint, 3], g1 = d bias [C/pint]
+ *   CL3D_OP_PSEUDOGRID pint = kernel points:   g1 = d kernel_weights [pint, C] (g0 unused, may be NULL) */
+int cl3d_fused_param_reduce(int op, const float *dparam, int n_partials, int C, int pint, float *g0, float *g1,
+                            cl3d_stream_t stream);
 int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *ft, const float *slotrec, const float *pairs,
                           const int32_t *idx, const int32_t *inv_off, const int32_t *inv_slots, int B, int N,
                           int M, int K, int C, const float *p0, const float *p1, int pint, float pfloat,
