@@ -493,6 +493,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
+    import closerlook3d_amd
     from closerlook3d_amd.dp import FlatGradients
     from closerlook3d_amd.local_aggregation_operators import LocalAggregation
 
@@ -538,7 +539,10 @@ def main():
         g = torch.cuda.CUDAGraph()
         # N > 1: RCCL's watchdog thread polls events while this thread captures; thread-local capture mode keeps
         # another thread's event query from invalidating the capture (this thread makes no unsafe call itself)
-        with torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
+        # (forward and backward of the step in ONE capture: the operator may leave its forked geometry work to be
+        # joined by its backward, closerlook3d_amd.whole_step_capture)
+        with closerlook3d_amd.whole_step_capture(), \
+                torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
             fn()
         return g
 

@@ -12,3 +12,10 @@ Layout (only what the hot path needs):
   dp.py                         one-process-per-GPU sharding + RCCL gradient all-reduce
 """
 __version__ = "0.1.0"
+
+
+def whole_step_capture(on=True):
+    """Context manager: the HIP graph being captured holds forward AND backward of every operator (see
+    closerlook3d_amd.fused.whole_step_capture)."""
+    from .fused import whole_step_capture as _w
+    return _w(on)

@@ -9,6 +9,7 @@ feature rows with hand-written HIP kernels, forward and backward, without that t
 cover (non-shipped variants such as PosPool with max reduction or a two-layer AdaptiveWeight MLP) run the
 'grouped' dataflow instead -- still on the engine's native ops -- and `impl='fused'` raises for them.
 """
+import contextlib
 import os
 
 import torch
@@ -159,15 +160,39 @@ def _join_inverse(idx):
         idx._cl3d_inverse = cached[:3] + (None,)
 
 
+_WHOLE_STEP = [os.environ.get('CL3D_WHOLE_STEP_CAPTURE', '0') == '1']
+
+
+@contextlib.contextmanager
+def whole_step_capture(on=True):
+    """Declare that the HIP graph being captured holds a whole training step -- every forward pass TOGETHER with its
+    backward pass (bench.py, scripts/bench_backbone.py, a captured training loop).  The PointWiseMLP's forward pass may
+    then leave the geometry work it forked for its backward (CSR build + summary, on the index stream) to be joined by
+    that backward, inside the same capture.  Without the declaration a captured forward pass ends fully joined, as
+    hipStreamEndCapture demands of a capture that stops there (torch.cuda.make_graphed_callables captures forward and
+    backward separately): measured 0.344 against 0.335 ms on the replayed step.  Eager launches never need it."""
+    old = _WHOLE_STEP[0]
+    _WHOLE_STEP[0] = bool(on)
+    try:
+        yield
+    finally:
+        _WHOLE_STEP[0] = old
+
+
 def _join_geometry(idx):
     """End of a PointWiseMLP forward pass.  With a summary queued behind the CSR build (same stream) the caller's stream
     has nothing to pick up here: the backward's support pass waits for the summary, which covers the build, and no
     other kernel of the operator reads either.  Joining the build here made the FIRST backward kernel wait across
     queues for a table it never reads (replayed step, round 3: ~12 us between the forward's last kernel and the
-    backward's first, against ~5 us between kernels of one queue).  Without a pending summary: _join_inverse."""
+    backward's first, against ~5 us between kernels of one queue).  Inside a graph capture that is only allowed when
+    the backward is known to be part of the same capture (whole_step_capture); otherwise -- and without a pending
+    summary -- everything forked is joined here."""
     pending = getattr(idx, '_cl3d_summary', None)
     if pending is not None and pending[3] is not None:
-        return
+        if _WHOLE_STEP[0] or not torch.cuda.is_current_stream_capturing():
+            return
+        torch.cuda.current_stream(idx.device).wait_event(pending[3])  # (behind the CSR build on the same stream)
+        idx._cl3d_summary = pending[:3] + (None,)
     _join_inverse(idx)
 
 

@@ -73,6 +73,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if one_dev else "nccl", **({} if one_dev else {"device_id": dev}))
+    import closerlook3d_amd
     from closerlook3d_amd.backbones import ResNet
     from closerlook3d_amd.dp import FlatGradients
     from closerlook3d_amd.pt_utils import ball_query_cache
@@ -165,7 +166,8 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local" if world > 1 else "global"):
+        with closerlook3d_amd.whole_step_capture(not args.overlap), \
+                torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local" if world > 1 else "global"):
             fn()
         return g
 
