@@ -170,7 +170,8 @@ def whole_step_capture(on=True):
     then leave the geometry work it forked for its backward (CSR build + summary, on the index stream) to be joined by
     that backward, inside the same capture.  Without the declaration a captured forward pass ends fully joined, as
     hipStreamEndCapture demands of a capture that stops there (torch.cuda.make_graphed_callables captures forward and
-    backward separately): measured 0.344 against 0.335 ms on the replayed step.  Eager launches never need it."""
+    backward separately), and the backward walks the CSR slot lists instead of the summary (_use_summary): 0.344-0.346
+    against 0.335 ms on the replayed step.  Eager launches never need it."""
     old = _WHOLE_STEP[0]
     _WHOLE_STEP[0] = bool(on)
     try:
@@ -206,7 +207,11 @@ SUPPORT_SUMMARY = os.environ.get('CL3D_PW_SUMMARY', '1') != '0'
 
 
 def _use_summary():
-    return bool(SUPPORT_SUMMARY)
+    """The summary lives on the index stream until the backward's support pass joins it; a capture that may end with
+    the forward pass (no whole_step_capture declaration) cannot leave it there, and joining it at the end of the
+    forward would put its ~40 us in front of the first backward kernel -- such a capture takes the slot walk instead
+    (measured as CL3D_PW_SUMMARY=0: 0.344-0.346 against 0.335 ms per replayed step)."""
+    return bool(SUPPORT_SUMMARY) and (_WHOLE_STEP[0] or not torch.cuda.is_current_stream_capturing())
 
 
 def support_summary(idx, n_support, query_xyz, support_xyz, radius, prefetch=False):
@@ -612,7 +617,8 @@ class _PointwiseMLP(Function):
             # for the support-major pass: dz again as point-major rows, and (slot walk only) one 16-byte record per
             # query {coordinates, centre idx[j, 0]} (a slot of that pass then costs one L2 request instead of three)
             dz_t = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
-            qtab = None if _use_summary() else torch.empty((B, M, 4), dtype=torch.float32, device=dev)
+            use_summary = _use_summary()
+            qtab = None if use_summary else torch.empty((B, M, 4), dtype=torch.float32, device=dev)
             _lib.check(lib.cl3d_pwmlp_bwd_rows(_p(gout), gout_cm, _p(ystar), _p(kstar), _p(idx), _p(query_xyz), _p(support_xyz),
                                                ctx.radius, _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), B, N, M, K, Co,
                                                _p(dz_cm), _p(ts_cm), _p(dz_t), _p(qtab), _p(partial), nparts, st))
@@ -635,7 +641,7 @@ class _PointwiseMLP(Function):
             coeffs()
             hits()
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
-            if _use_summary():
+            if use_summary:
                 rec, ent = support_summary(idx, N, query_xyz, support_xyz, ctx.radius)  # (waits for it; covers the CSR build)
                 _lib.check(lib.cl3d_pwmlp_bwd_support_sum(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t),
                                                           _p(sy), _p(rec), _p(ent), B, N, M, K, Co, _p(dght), st))
