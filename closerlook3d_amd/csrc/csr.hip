@@ -94,11 +94,16 @@ static bool csr_plan(int B, int N, int MK, CsrPlan *p) {
 // so with B a multiple of 8 every workgroup of a cloud runs on ONE XCD and the 4-byte scatter stores of the fill pass
 // (64 random rows per wave instruction) merge into whole lines in that XCD's L2 before they leave it -- with the
 // clouds spread over all XCDs the same stores left as partial lines (measured WRITE_SIZE 65 MB for a 4 MB table).
-template <bool FILL>
+// SCAN (FILL only, experimental -- CL3D_CSR_SCAN=fused, see cl3d_build_inverse_index): inv_off_in holds the row TOTALS
+// csr_rows_kernel left, every workgroup scans its cloud's totals itself while it turns its histograms into cursors (the
+// loop over i below walks the rows in order, so the exclusive scan is a running carry plus one workgroup-wide scan per
+// sweep), and the cloud's first workgroup writes the offsets to inv_off_out for the consumers: no csr_scan_kernel launch.
+template <bool FILL, bool SCAN = false>
 __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restrict__ idx, int B, int N, int MK, int GB, int per,
                                                              int *__restrict__ table, const int *__restrict__ inv_off,
-                                                             int *__restrict__ inv_slots) {
+                                                             int *__restrict__ inv_slots, int *__restrict__ inv_off_out = nullptr) {
   extern __shared__ int lds_cnt[];
+  __shared__ int s_wtot[4];
   const int lane = lane_id();
   const int wpb = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -135,12 +140,47 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restri
     }
   } else {
     const int *off = inv_off + (size_t)b * (N + 1);
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
-      int run = off[i] + row[i];
-      for (int w = 0; w < wpb; ++w) {
-        const int t = lds_cnt[(size_t)w * N + i];
-        lds_cnt[(size_t)w * N + i] = run;
-        run += t;
+    if constexpr (SCAN) {
+      int *off_out = gblk == 0 ? inv_off_out + (size_t)b * (N + 1) : nullptr;
+      int carry = 0;
+      for (int base = 0; base < N; base += (int)blockDim.x) {  // (uniform trip count: barriers inside)
+        const int i = base + (int)threadIdx.x;
+        const int tot = i < N ? off[i] : 0;
+        int incl = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int t = __shfl_up(incl, o, 64);
+          if (lane >= o) incl += t;
+        }
+        if (lane == 63) s_wtot[wave] = incl;
+        __syncthreads();
+        int woff = 0, total = 0;
+        for (int w = 0; w < wpb; ++w) {
+          if (w < wave) woff += s_wtot[w];
+          total += s_wtot[w];
+        }
+        __syncthreads();  // s_wtot is rewritten by the next sweep
+        const int first = carry + woff + incl - tot;  // exclusive scan = the row's first position
+        carry += total;
+        if (i < N) {
+          if (off_out != nullptr) off_out[i] = first;
+          int run = first + row[i];
+          for (int w = 0; w < wpb; ++w) {
+            const int t = lds_cnt[(size_t)w * N + i];
+            lds_cnt[(size_t)w * N + i] = run;
+            run += t;
+          }
+        }
+      }
+      if (off_out != nullptr && threadIdx.x == 0) off_out[N] = carry;
+    } else {
+      for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        int run = off[i] + row[i];
+        for (int w = 0; w < wpb; ++w) {
+          const int t = lds_cnt[(size_t)w * N + i];
+          lds_cnt[(size_t)w * N + i] = run;
+          run += t;
+        }
       }
     }
     __syncthreads();
@@ -259,11 +299,16 @@ static size_t sort_temp_bytes(int B, int N, int MK) {
   return bytes;
 }
 
+static size_t csr_table_bytes(int B, int N, const CsrPlan &plan) {
+  return (((size_t)B * (plan.G / plan.wpb) * N * sizeof(int)) + 255) & ~(size_t)255;
+}
+
 size_t inverse_index_workspace(int B, int N, int MK) {
   const size_t n = (size_t)B * MK;
   if (n == 0) return 0;
   CsrPlan plan;
-  if (csr_plan(B, N, MK, &plan)) return (((size_t)B * (plan.G / plan.wpb) * N * sizeof(int)) + 255) & ~(size_t)255;
+  if (csr_plan(B, N, MK, &plan))  // the counter table + (fused scan) one row of totals per cloud
+    return csr_table_bytes(B, N, plan) + ((((size_t)B * (N + 1) * sizeof(int)) + 255) & ~(size_t)255);
   return 3 * ((n * 4 + 255) & ~(size_t)255) + sort_temp_bytes(B, N, MK);
 }
 
@@ -300,6 +345,21 @@ extern "C" int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK
     const dim3 grid((unsigned)GB * (unsigned)B), block(64 * plan.wpb);
     hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<false>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per,
                        table, (const int *)nullptr, (int *)nullptr);
+    // CL3D_CSR_SCAN=fused (experimental, written at the end of round 3 after its GPU budget was spent, off by default
+    // until it has run under tests/test_csr*_gpu.py): the scan of the row totals inside the fill pass.  csr_scan_kernel is
+    // ONE 1024-thread workgroup per cloud; beside a gather pass that fills every CU it waits for 16 free wave slots on
+    // one CU (7.8 us alone, 49 us in the replayed PseudoGrid step).
+    static const bool fused_scan = [] {
+      const char *e = getenv("CL3D_CSR_SCAN");
+      return e != nullptr && strcmp(e, "fused") == 0;
+    }();
+    if (fused_scan) {
+      int *totals = reinterpret_cast<int *>(static_cast<char *>(ws) + cl3d::csr_table_bytes(B, N, plan));
+      hipLaunchKernelGGL(cl3d::csr_rows_kernel, dim3(cl3d::ceil_div(N, 64), B), dim3(256), 0, st, N, GB, table, totals);
+      hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true, true>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per,
+                         table, (const int *)totals, inv_slots, inv_off);
+      return cl3d::check_launch("cl3d_build_inverse_index");
+    }
     hipLaunchKernelGGL(cl3d::csr_rows_kernel, dim3(cl3d::ceil_div(N, 64), B), dim3(256), 0, st, N, GB, table, inv_off);
     hipLaunchKernelGGL(cl3d::csr_scan_kernel, dim3(B), dim3(1024), 0, st, N, inv_off);
     hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per,
