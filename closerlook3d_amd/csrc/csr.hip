@@ -103,7 +103,6 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restri
                                                              int *__restrict__ table, const int *__restrict__ inv_off,
                                                              int *__restrict__ inv_slots, int *__restrict__ inv_off_out = nullptr) {
   extern __shared__ int lds_cnt[];
-  __shared__ int s_wtot[4];
   const int lane = lane_id();
   const int wpb = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -141,6 +140,7 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restri
   } else {
     const int *off = inv_off + (size_t)b * (N + 1);
     if constexpr (SCAN) {
+      __shared__ int s_wtot[4];  // (declared here: the other instantiations keep a purely dynamic LDS footprint)
       int *off_out = gblk == 0 ? inv_off_out + (size_t)b * (N + 1) : nullptr;
       int carry = 0;
       for (int base = 0; base < N; base += (int)blockDim.x) {  // (uniform trip count: barriers inside)
@@ -353,7 +353,7 @@ extern "C" int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK
       const char *e = getenv("CL3D_CSR_SCAN");
       return e != nullptr && strcmp(e, "fused") == 0;
     }();
-    if (fused_scan) {
+    if (fused_scan && plan.lds + 64 <= 128 * 1024) {
       int *totals = reinterpret_cast<int *>(static_cast<char *>(ws) + cl3d::csr_table_bytes(B, N, plan));
       hipLaunchKernelGGL(cl3d::csr_rows_kernel, dim3(cl3d::ceil_div(N, 64), B), dim3(256), 0, st, N, GB, table, totals);
       hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true, true>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per,
