@@ -14,21 +14,22 @@
 //           support points into `sorted` (float4 {x,y,z, original index}) -- all P workgroups of a cloud do the same
 //           (same inputs, same arithmetic; the order inside a cell differs and does not matter);
 //   share   workgroup p owns the cells that hold the p-th share of the queries and stages those queries, grouped by
-//           cell, as records + a list of tasks (<= 2 queries of one cell) in LDS;
-//   query   waves draw tasks from an LDS ticket (dynamic balance at LDS-atomic cost), rebuild the task's 9 candidate
-//           runs from the cell ends, stream the window's candidates out of LDS (no global latency anywhere in the
-//           loop), and restate the reference's order-dependent rule order-independently exactly as
-//           ball_query_cells.hip does (see its header): <= 3K in-radius candidates -> all of them; more -> the 3K
-//           smallest original indices with the strict minimum patched into the last slot; result ranked by
-//           (distance, original index).
+//           cell, as records + a list of tasks (<= kTlQT queries of one cell) in LDS;
+//   query   waves draw tasks from an LDS ticket (dynamic balance at LDS-atomic cost).  A task's candidate window -- the
+//           <= 9 runs of `sorted` around its cell -- is read out of LDS ONCE into registers (<= 384 records, 24 VGPRs)
+//           and serves all the task's queries, two at a time: the two distances of a candidate are one chain of packed
+//           FP32 instructions (v_pk_add / v_pk_mul / v_pk_fma: per-lane IEEE, the same bits as the scalar chain of
+//           cl3d::dist2), and every in-radius candidate leaves (d2, original index) in the query's LDS list.  The
+//           reference's order-dependent rule is then restated order-independently exactly as ball_query_cells.hip
+//           does (see its header): <= 3K in-radius candidates -> all of them; more -> the 3K smallest original indices
+//           with the strict minimum patched into the last slot; result ranked by (distance, original index).
 //   dense   a query with more in-radius candidates than its LDS list holds (6K) is finished in place: the 3K-th
 //           smallest original index is found by bisection with counting passes over the window, then one pass
 //           collects those 3K candidates and the strict minimum.  Slow (a dozen window passes) and rare; no flag
 //           array, no second launch.
 //
-// Candidate list entries are 32 bits: (original index << 16) | position in `sorted` (both < 4096), so the rank by
-// original index compares whole entries and the distance is recomputed from the record when an entry is selected
-// (dist2 is a pure function: same operands, same bits).
+// Round 4 (this form): window in registers across the queries of a cell, packed distance arithmetic, distances stored
+// by the candidate pass instead of being recomputed at selection -- 375 -> ~215 vector instructions per query.
 #include "ball_query.h"
 
 namespace cl3d {
@@ -39,21 +40,24 @@ constexpr int kTlPT = 4;                          // points per thread
 constexpr int kTlMaxPts = kTlThreads * kTlPT;     // 4096
 constexpr int kTlMaxCells = 2048;
 constexpr int kTlQChunk = 512;                    // query records staged per round
-constexpr int kTlQW = 2;                          // queries per task
+constexpr int kTlQT = 4;                          // queries per task (of one cell): they share one window read
+constexpr int kTlQW = 2;                          // queries tested per candidate pass (one packed-FP32 chain)
 constexpr int kTlCapMul = 6;                      // candidate list holds kTlCapMul*K entries per query
-constexpr int kTlBatch = 3;                       // candidate records in flight per lane
+constexpr int kTlWin = 6;                         // window batches (of 64 records) a wave holds in registers
+constexpr int kTlIdxRounds = 4;                   // rank-by-index rounds held in registers: kTlCapMul*K <= 256
+
+typedef float tl_v2f __attribute__((ext_vector_type(2)));
 
 __host__ __device__ inline int tl_pad4(int x) { return (x + 3) & ~3; }
 
 // dynamic LDS layout (in ints)
 struct TlLayout {
   int sorted, s_end, q_end, qrec, qcell, tasks, wave0, per_wave, total;
-  int candS, cap3S, outS;
+  int capS, outS;
 };
 __host__ __device__ inline TlLayout tl_layout(int N, int K) {
   TlLayout l;
-  l.candS = tl_pad4(kTlCapMul * K);
-  l.cap3S = tl_pad4(3 * K);
+  l.capS = tl_pad4(kTlCapMul * K) + 4;  // + the four sentinel keys the rank loop's 16-byte reads run into
   l.outS = tl_pad4(K + 1);
   int o = 0;
   l.sorted = o; o += 4 * tl_pad4(N);
@@ -63,7 +67,7 @@ __host__ __device__ inline TlLayout tl_layout(int N, int K) {
   l.qcell = o; o += 2 * kTlQChunk;
   l.tasks = o; o += kTlQChunk;
   l.wave0 = o;
-  l.per_wave = kTlQW * (l.candS + 2 * l.cap3S + l.outS);
+  l.per_wave = kTlQW * (2 * l.capS + l.outS);
   o += kTlWaves * l.per_wave;
   l.total = o;
   return l;
@@ -79,6 +83,26 @@ __device__ __forceinline__ void tl_wave_sync() {
 
 __device__ __forceinline__ float tl_uniform(float v) {
   return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// cl3d::dist2 for two queries against one candidate, as packed FP32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 are
+// IEEE per element: each half is bit for bit the scalar chain of dist2; the library is built with -ffp-contract=off,
+// so nothing is fused or split behind this).  Same CL3D_D2_FORM switch as cl3d_common.h.
+__device__ __forceinline__ tl_v2f tl_dist2_pair(tl_v2f qx, tl_v2f qy, tl_v2f qz, float x, float y, float z) {
+  const tl_v2f dx = qx - x, dy = qy - y, dz = qz - z;
+#if CL3D_D2_FORM == 0
+  const tl_v2f xx = dx * dx;
+  const tl_v2f zz = dz * dz;
+  return __builtin_elementwise_fma(dy, dy, xx) + zz;
+#elif CL3D_D2_FORM == 1
+  const tl_v2f xx = dx * dx;
+  const tl_v2f yy = dy * dy;
+  const tl_v2f zz = dz * dz;
+  return (xx + yy) + zz;
+#else
+  const tl_v2f xx = dx * dx;
+  return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, xx));
+#endif
 }
 
 // The candidate window of a task: <= 9 contiguous runs of `sorted`, laid end to end; w_pe<r> = exclusive prefix of
@@ -183,7 +207,7 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
   __syncthreads();  // s_nv, the cell arrays and s_red are written
   if (first0 < N) atomicMin(&s_nv, first0);
   __syncthreads();
-  const int nv = s_nv;
+  const int nv = __builtin_amdgcn_readfirstlane(s_nv);
 #pragma unroll
   for (int a = 0; a < 3; ++a) {
     mn[a] = s_red[a][0];
@@ -192,6 +216,8 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
       mn[a] = s_red[a][ww] < mn[a] ? s_red[a][ww] : mn[a];
       mx[a] = s_red[3 + a][ww] > mx[a] ? s_red[3 + a][ww] : mx[a];
     }
+    mn[a] = tl_uniform(mn[a]);  // (the same value in every lane: keep it on the scalar side)
+    mx[a] = tl_uniform(mx[a]);
   }
   // cell size: >= radius with slack, grown until the grid fits (every thread computes the same)
   float h = radius * 1.0002f;
@@ -306,9 +332,12 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
     s_share[2 + tid] = c < ncells ? q_end[c] : M;
   }
   __syncthreads();
-  const int c_lo = s_share[0], c_hi = s_share[1], q_lo = s_share[2], q_hi = s_share[3];
+  const int c_lo = __builtin_amdgcn_readfirstlane(s_share[0]), c_hi = __builtin_amdgcn_readfirstlane(s_share[1]);
+  const int q_lo = __builtin_amdgcn_readfirstlane(s_share[2]), q_hi = __builtin_amdgcn_readfirstlane(s_share[3]);
 
-  // ---- (5) scatters: every support point into `sorted`, this share's queries into positions of the share
+  // ---- (5) scatters: every support point into `sorted`, this share's queries into positions of the share; the
+  // share's first kTlQChunk query records are staged straight from the registers (later rounds -- more than 512
+  // queries per workgroup, B > 32 -- read the coordinates again: the registers go to the window below)
   int qpos[kTlPT];
 #pragma unroll
   for (int u = 0; u < kTlPT; ++u) {
@@ -318,45 +347,56 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
       sorted[pos] = make_float4(px[u], py[u], pz[u], __int_as_float(i));
     }
     qpos[u] = -1;
-    if (i < M && cq[u] >= c_lo && cq[u] < c_hi) qpos[u] = atomicAdd(&q_end[cq[u]], 1) - q_lo;
+    if (i < M && cq[u] >= c_lo && cq[u] < c_hi) {
+      qpos[u] = atomicAdd(&q_end[cq[u]], 1) - q_lo;
+      if (qpos[u] < kTlQChunk) {
+        qrec[qpos[u]] = make_float4(qx_[u], qy_[u], qz_[u], __int_as_float(i));
+        qcell[qpos[u]] = make_int2(cq[u] | (cqz[u] << 16), cqxy[u]);
+      }
+    }
   }
   // from here on: s_end[c] = end of cell c in `sorted` (start of cell c+1); q_end[c] = end of cell c in query
   // order for the cells of this share
 
-  // per-wave lists
+  // per-wave lists: for each of the kTlQW queries of a pass, distances [capS], original indices [capS], output [outS]
   int *wbase = tl_lds + L.wave0 + wave * L.per_wave;
-  unsigned *cand = reinterpret_cast<unsigned *>(wbase);                       // [QW][candS]
-  float *sel_d = reinterpret_cast<float *>(wbase + kTlQW * L.candS);           // [QW][cap3S]
-  int *sel_i = wbase + kTlQW * L.candS + kTlQW * L.cap3S;                      // [QW][cap3S]
-  int *out_i = wbase + kTlQW * L.candS + 2 * kTlQW * L.cap3S;                  // [QW][outS]
   const int cap = kTlCapMul * K, cap3 = 3 * K;
   const int lane_ry = lane % 3, lane_rz = (lane / 3) % 3;  // run r = lane < 9: row (y0 + r % 3, z0 + r / 3)
 
   const int nshare = q_hi - q_lo;
   for (int chunk0 = 0; chunk0 < nshare; chunk0 += kTlQChunk) {
     const int cn = nshare - chunk0 < kTlQChunk ? nshare - chunk0 : kTlQChunk;
-    __syncthreads();  // the scatter is complete / the previous round's records have been consumed
+    if (chunk0 > 0) {
+      __syncthreads();  // the previous round's records have been consumed
 #pragma unroll
-    for (int u = 0; u < kTlPT; ++u) {
-      const int r = qpos[u] - chunk0;
-      if (qpos[u] >= 0 && r >= 0 && r < kTlQChunk) {
-        qrec[r] = make_float4(qx_[u], qy_[u], qz_[u], __int_as_float(u * kTlThreads + tid));
-        qcell[r] = make_int2(cq[u] | (cqz[u] << 16), cqxy[u]);
+      for (int u = 0; u < kTlPT; ++u) {
+        const int r = qpos[u] - chunk0;
+        if (qpos[u] >= 0 && r >= 0 && r < kTlQChunk) {
+          const int i = u * kTlThreads + tid;
+          const float x = q[i * 3 + 0], y = q[i * 3 + 1], z = q[i * 3 + 2];
+          int cxy, cz;
+          const int c = cell_of(x, y, z, cxy, cz);
+          qrec[r] = make_float4(x, y, z, __int_as_float(i));
+          qcell[r] = make_int2(c | (cz << 16), cxy);
+        }
       }
     }
     if (tid == 0) s_ticket = 0;
-    __syncthreads();
-    // tasks: pairs of queries of one cell, aligned to even offsets inside the cell
+    __syncthreads();  // the scatter is complete, this round's records are staged
+    // tasks: runs of <= kTlQT queries of one cell, aligned to multiples of kTlQT inside the cell
     bool start = false;
     int tk = 0;
     if (tid < cn) {
       const int c = qcell[tid].x & 0xffff;
+      const int g = q_lo + chunk0 + tid;              // position in the cloud's cell-ordered query sequence
       const int st = c == c_lo ? q_lo : q_end[c - 1];
-      const int o = (q_lo + chunk0 + tid) - st;
-      const bool even = (o & 1) == 0;
-      start = even || tid == 0;
-      const bool two = even && tid + 1 < cn && (qcell[tid + 1].x & 0xffff) == c;
-      tk = tid | ((two ? 2 : 1) << 16);
+      const int o = (g - st) % kTlQT;
+      start = o == 0 || tid == 0;
+      int nn = kTlQT - o;
+      const int left = q_end[c] - g;                  // queries of this cell from here on
+      nn = nn < left ? nn : left;
+      nn = nn < cn - tid ? nn : cn - tid;
+      tk = tid | (nn << 16);
     }
     const unsigned long long sm_ = __ballot(start);
     if (lane == 0) s_wave[0][wave] = (int)__popcll(sm_);
@@ -367,6 +407,7 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
       if (ww < wave) woff += v;
       ntasks += v;
     }
+    ntasks = __builtin_amdgcn_readfirstlane(ntasks);
     if (start) tasks[woff + prefix_popc(sm_)] = tk;
     __syncthreads();
 
@@ -377,19 +418,6 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
       if (t >= ntasks) break;
       const int tkv = __builtin_amdgcn_readfirstlane(tasks[t]);
       const int r0 = tkv & 0xffff, n = tkv >> 16;
-      int jq[kTlQW];
-      float qx[kTlQW], qy[kTlQW], qz[kTlQW];
-      int cnt[kTlQW];
-#pragma unroll
-      for (int u = 0; u < kTlQW; ++u) {
-        const float4 qq = qrec[r0 + (u < n ? u : 0)];
-        jq[u] = __builtin_amdgcn_readfirstlane(__float_as_int(qq.w));
-        // an unused query slot of the task gets a NaN coordinate: its distances are NaN and never "in radius"
-        qx[u] = u < n ? tl_uniform(qq.x) : __builtin_nanf("");
-        qy[u] = tl_uniform(qq.y);
-        qz[u] = tl_uniform(qq.z);
-        cnt[u] = 0;
-      }
       // the cell's candidate window: 3x3 (y,z) rows of <= 3 x-adjacent cells, each one contiguous run of `sorted`
       int w_pe1, w_pe2, w_pe3, w_pe4, w_pe5, w_pe6, w_pe7, w_pe8, w_d0, w_d1, w_d2, w_d3, w_d4, w_d5, w_d6, w_d7, w_d8, T;
       {
@@ -425,203 +453,232 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
         w_d8 = __builtin_amdgcn_readlane(dl, 8);
         T = __builtin_amdgcn_readlane(inc, 8);
       }
-      // ---- candidates: every in-radius candidate of the window goes to the LDS list (unordered: the selection
-      // below restates the reference's order-dependent rule), one ballot + prefix count per query and 64 candidates
-      for (int p0 = 0; p0 < T; p0 += CL3D_WAVE * kTlBatch) {
-        float4 sp[kTlBatch];
-        int sp_pos[kTlBatch];
+      // A window of <= 64 * kTlWin records (the rule at the metric shape: ~320) stays in registers for every query of
+      // the task; a larger one is streamed again for each pair of queries.  A position past the window's end holds a
+      // NaN coordinate: its distances are NaN and never "in radius" -- no per-candidate guard below.
+      const bool resident = T <= CL3D_WAVE * kTlWin;
+      float4 sp[kTlWin];
+      auto load_window = [&](int p0) {
 #pragma unroll
-        for (int v = 0; v < kTlBatch; ++v) {
-          int p = p0 + v * CL3D_WAVE + lane;
-          p = p < T ? p : T - 1;
-          sp_pos[v] = TL_WINDOW_POS(p);
-          sp[v] = sorted[sp_pos[v]];
+        for (int v = 0; v < kTlWin; ++v) {
+          const int p = p0 + v * CL3D_WAVE + lane;
+          const int pc = p < T ? p : T - 1;
+          sp[v] = sorted[TL_WINDOW_POS(pc)];
+          if (p >= T) sp[v].x = __builtin_nanf("");
         }
+      };
+      if (resident && T > 0) load_window(0);
+
+      for (int u0 = 0; u0 < n; u0 += kTlQW) {
+        const int nq = n - u0 < kTlQW ? n - u0 : kTlQW;  // uniform
+        int jq[kTlQW];
+        float qxs[kTlQW], qys[kTlQW], qzs[kTlQW];
+        int cnt[kTlQW];
 #pragma unroll
-        for (int v = 0; v < kTlBatch; ++v) {
-          if (p0 + v * CL3D_WAVE >= T) break;  // uniform
-          const bool live = p0 + v * CL3D_WAVE + lane < T;
-          const unsigned entry = ((unsigned)__float_as_int(sp[v].w) << 16) | (unsigned)sp_pos[v];
+        for (int u = 0; u < kTlQW; ++u) {
+          const float4 qq = qrec[r0 + u0 + (u < nq ? u : 0)];
+          jq[u] = __builtin_amdgcn_readfirstlane(__float_as_int(qq.w));
+          // an unused query slot of the pass gets a NaN coordinate: its distances are NaN and never "in radius"
+          qxs[u] = u < nq ? tl_uniform(qq.x) : __builtin_nanf("");
+          qys[u] = tl_uniform(qq.y);
+          qzs[u] = tl_uniform(qq.z);
+          cnt[u] = 0;
+        }
+        const tl_v2f qx2 = {qxs[0], qxs[1]}, qy2 = {qys[0], qys[1]}, qz2 = {qzs[0], qzs[1]};
+        // ---- candidates: every in-radius candidate of the window leaves (distance, original index) in the query's LDS
+        // list (unordered: the selection below restates the reference's order-dependent rule), one ballot + prefix
+        // count per query and 64 candidates
+        for (int p0 = 0; p0 < T; p0 += CL3D_WAVE * kTlWin) {
+          if (!resident) load_window(p0);
 #pragma unroll
-          for (int u = 0; u < kTlQW; ++u) {
-            const float d2 = dist2(qx[u], qy[u], qz[u], sp[v].x, sp[v].y, sp[v].z);
-            const bool hit = live && (d2 < radius2);
-            const unsigned long long m = __ballot(hit);
-            const int c0 = cnt[u];
-            const int c1 = c0 + (int)__popcll(m);  // wave-uniform
-            if (c1 <= cap && hit) cand[u * L.candS + c0 + prefix_popc(m)] = entry;  // an overflowing list is abandoned
-            cnt[u] = c1;
+          for (int v = 0; v < kTlWin; ++v) {
+            if (p0 + v * CL3D_WAVE >= T) break;  // uniform
+            const tl_v2f d2 = tl_dist2_pair(qx2, qy2, qz2, sp[v].x, sp[v].y, sp[v].z);
+#pragma unroll
+            for (int u = 0; u < kTlQW; ++u) {
+              const float d = u == 0 ? d2.x : d2.y;
+              const bool hit = d < radius2;
+              const unsigned long long m = __ballot(hit);
+              const int c0 = cnt[u];
+              const int c1 = c0 + (int)__popcll(m);  // wave-uniform
+              if (c1 <= cap && hit) {                // an overflowing list is abandoned
+                int *dst = wbase + u * (2 * L.capS + L.outS) + c0 + prefix_popc(m);
+                dst[0] = __float_as_int(d);
+                dst[L.capS] = __float_as_int(sp[v].w);
+              }
+              cnt[u] = c1;
+            }
           }
         }
-      }
-      tl_wave_sync();
+        tl_wave_sync();
 
 #pragma unroll
-      for (int u = 0; u < kTlQW; ++u) {
-        if (u >= n) continue;
-        const int j = jq[u];
-        const int S = __builtin_amdgcn_readfirstlane(cnt[u]);
-        int *oi = idx + ((size_t)b * M + j) * K;
-        int *om = idx_mask + ((size_t)b * M + j) * K;
-        unsigned *lc = cand + u * L.candS;
-        float *ld = sel_d + u * L.cap3S;
-        int *li = sel_i + u * L.cap3S;
-        int c = S;
-        if (S <= cap3) {
-          for (int e = lane; e < S; e += CL3D_WAVE) {
-            const unsigned en = lc[e];
-            const float4 rec = sorted[en & 0xffffu];
-            ld[e] = dist2(qx[u], qy[u], qz[u], rec.x, rec.y, rec.z);
-            li[e] = (int)(en >> 16);
-          }
-        } else {
-          // first-occurrence strict minimum == smallest (d2, original index) of all S in-radius candidates
-          unsigned long long key = ~0ull;
-          int nlist = S;
-          if (S > cap) {
-            // dense: the list was abandoned.  Bisection for T* = (3K-th smallest original index of S) + 1:
-            // count(orig < lo) < 3K <= count(orig < hi)
-            int lo = 0, hi = N;
-            while (hi - lo > 1) {
-              const int mid = (lo + hi) >> 1;
-              int below = 0;
+        for (int u = 0; u < kTlQW; ++u) {
+          if (u >= nq) continue;
+          const int j = jq[u];
+          const float qxu = qxs[u], qyu = qys[u], qzu = qzs[u];
+          const int S = __builtin_amdgcn_readfirstlane(cnt[u]);
+          int *oi = idx + ((size_t)b * M + j) * K;
+          int *om = idx_mask + ((size_t)b * M + j) * K;
+          int *lbase = wbase + u * (2 * L.capS + L.outS);
+          float *ld = reinterpret_cast<float *>(lbase);
+          int *li = lbase + L.capS;
+          int *so = lbase + 2 * L.capS;
+          int c = S;
+          if (S > cap3) {
+            // first-occurrence strict minimum == smallest (d2, original index) of all S in-radius candidates
+            unsigned long long key = ~0ull;
+            int nlist = S;
+            if (S > cap) {
+              // dense: the list was abandoned.  Bisection for T* = (3K-th smallest original index of S) + 1:
+              // count(orig < lo) < 3K <= count(orig < hi)
+              int lo = 0, hi = N;
+              while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                int below = 0;
+                for (int p0 = 0; p0 < T; p0 += CL3D_WAVE) {
+                  const int p = p0 + lane;
+                  const float4 rec = sorted[TL_WINDOW_POS(p < T ? p : T - 1)];
+                  const float d2 = dist2(qxu, qyu, qzu, rec.x, rec.y, rec.z);
+                  const bool hit = p < T && d2 < radius2 && __float_as_int(rec.w) < mid;
+                  below += (int)__popcll(__ballot(hit));
+                }
+                if (below >= cap3) hi = mid;
+                else lo = mid;
+              }
+              int fill = 0;
               for (int p0 = 0; p0 < T; p0 += CL3D_WAVE) {
                 const int p = p0 + lane;
                 const float4 rec = sorted[TL_WINDOW_POS(p < T ? p : T - 1)];
-                const float d2 = dist2(qx[u], qy[u], qz[u], rec.x, rec.y, rec.z);
-                const bool hit = p < T && d2 < radius2 && __float_as_int(rec.w) < mid;
-                below += (int)__popcll(__ballot(hit));
+                const float d2 = dist2(qxu, qyu, qzu, rec.x, rec.y, rec.z);
+                const bool hit = p < T && d2 < radius2;
+                const int orig = __float_as_int(rec.w);
+                if (hit) {
+                  const unsigned long long ke = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)orig;
+                  key = ke < key ? ke : key;
+                }
+                const bool take = hit && orig < hi;
+                const unsigned long long m = __ballot(take);
+                if (take) {
+                  const int e = fill + prefix_popc(m);
+                  ld[e] = d2;
+                  li[e] = orig;
+                }
+                fill += (int)__popcll(m);
               }
-              if (below >= cap3) hi = mid;
-              else lo = mid;
-            }
-            int fill = 0;
-            for (int p0 = 0; p0 < T; p0 += CL3D_WAVE) {
-              const int p = p0 + lane;
-              const int pos = TL_WINDOW_POS(p < T ? p : T - 1);
-              const float4 rec = sorted[pos];
-              const float d2 = dist2(qx[u], qy[u], qz[u], rec.x, rec.y, rec.z);
-              const bool hit = p < T && d2 < radius2;
-              const int orig = __float_as_int(rec.w);
-              if (hit) {
-                const unsigned long long ke = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)orig;
+              nlist = cap3;  // == fill: original indices are distinct
+              tl_wave_sync();
+            } else {
+              for (int e = lane; e < S; e += CL3D_WAVE) {
+                const unsigned long long ke = ((unsigned long long)__float_as_uint(ld[e]) << 32) | (unsigned)li[e];
                 key = ke < key ? ke : key;
               }
-              const bool take = hit && orig < hi;
-              const unsigned long long m = __ballot(take);
-              if (take) lc[fill + prefix_popc(m)] = ((unsigned)orig << 16) | (unsigned)pos;
-              fill += (int)__popcll(m);
             }
-            nlist = cap3;  // == fill: original indices are distinct
+            key = wave_min_u64(key);
+            const int gidx = (int)(unsigned)(key & 0xffffffffull);
+            // the 3K smallest original indices, moved to the front of the list in index order: every lane takes its
+            // entries into registers and ranks them by original index against the whole list, then -- all reads done --
+            // the entries with rank < 3K are written back at their rank
+            float my_d[kTlIdxRounds];
+            int my_i[kTlIdxRounds], my_r[kTlIdxRounds];
+#pragma unroll
+            for (int t2 = 0; t2 < kTlIdxRounds; ++t2) {
+              const int e = t2 * CL3D_WAVE + lane;
+              const bool on = e < nlist;
+              my_d[t2] = on ? ld[e] : 0.f;
+              my_i[t2] = on ? li[e] : 0x7fffffff;
+              my_r[t2] = 0;
+            }
+            for (int f = 0; f < nlist; ++f) {
+              const int kf = li[f];
+#pragma unroll
+              for (int t2 = 0; t2 < kTlIdxRounds; ++t2) my_r[t2] += kf < my_i[t2] ? 1 : 0;
+            }
             tl_wave_sync();
-          } else {
-            for (int e = lane; e < S; e += CL3D_WAVE) {
-              const unsigned en = lc[e];
-              const float4 rec = sorted[en & 0xffffu];
-              const float d2 = dist2(qx[u], qy[u], qz[u], rec.x, rec.y, rec.z);
-              const unsigned long long ke = ((unsigned long long)__float_as_uint(d2) << 32) | (en >> 16);
-              key = ke < key ? ke : key;
+#pragma unroll
+            for (int t2 = 0; t2 < kTlIdxRounds; ++t2) {
+              if (t2 * CL3D_WAVE + lane < nlist && my_r[t2] < cap3) {
+                ld[my_r[t2]] = my_d[t2];
+                li[my_r[t2]] = my_i[t2];
+              }
             }
+            tl_wave_sync();
+            if (gidx > li[cap3 - 1]) {  // uniform: the minimum was cut off -> it takes the last slot
+              if (lane == 0) {
+                li[cap3 - 1] = gidx;
+                ld[cap3 - 1] = __uint_as_float((unsigned)(key >> 32));
+              }
+            }
+            c = cap3;
           }
-          key = wave_min_u64(key);
-          const int gidx = (int)(unsigned)(key & 0xffffffffull);
-          // the 3K smallest original indices, written in index order (an entry orders like its original index)
-          const int n4 = nlist & ~3;
-          for (int e0 = 0; e0 < nlist; e0 += CL3D_WAVE) {
+          // ---- rank by (distance, original index) == stable sort by distance of the index-ordered list.
+          // Fast path: rank by the distance alone (d2 >= 0, so its bit pattern orders like the value), keys broadcast
+          // four at a time from LDS (the list ends in four all-ones sentinels: no tail loop).  Equal distances give
+          // equal ranks and leave a hole in ranks [0, min(c, K+1)); a hole is detected below and the exact ranking
+          // redoes the (rare) list.
+          unsigned *lb = reinterpret_cast<unsigned *>(ld);
+          const int need = c < K + 1 ? c : K + 1;
+          if (lane < 4) lb[c + lane] = 0xffffffffu;
+          for (int i = lane; i < need; i += CL3D_WAVE) so[i] = -1;
+          tl_wave_sync();
+          for (int e0 = 0; e0 < c; e0 += CL3D_WAVE) {
             const int e = e0 + lane;
-            const bool on = e < nlist;
-            const unsigned my = on ? lc[e] : 0u;
-            int r = 0;
-            for (int f = 0; f < n4; f += 4) {
-              const uint4 k4 = *reinterpret_cast<const uint4 *>(lc + f);
-              r += k4.x < my ? 1 : 0;
-              r += k4.y < my ? 1 : 0;
-              r += k4.z < my ? 1 : 0;
-              r += k4.w < my ? 1 : 0;
-            }
-            for (int f = n4; f < nlist; ++f) r += lc[f] < my ? 1 : 0;
-            if (on && r < cap3) {
-              const float4 rec = sorted[my & 0xffffu];
-              ld[r] = dist2(qx[u], qy[u], qz[u], rec.x, rec.y, rec.z);
-              li[r] = (int)(my >> 16);
-            }
-          }
-          tl_wave_sync();
-          if (gidx > li[cap3 - 1]) {  // uniform: the minimum was cut off -> it takes the last slot
-            if (lane == 0) {
-              li[cap3 - 1] = gidx;
-              ld[cap3 - 1] = __uint_as_float((unsigned)(key >> 32));
-            }
-          }
-          c = cap3;
-        }
-        // ---- rank by (distance, original index) == stable sort by distance of the index-ordered list.
-        // Fast path: rank by the distance alone (d2 >= 0, so its bit pattern orders like the value), keys broadcast
-        // four at a time from LDS.  Equal distances give equal ranks and leave a hole in ranks [0, min(c, K+1));
-        // a hole is detected below and the exact ranking redoes the (rare) list.
-        int *so = out_i + u * L.outS;
-        const int need = c < K + 1 ? c : K + 1;
-        for (int i = lane; i < need; i += CL3D_WAVE) so[i] = -1;
-        tl_wave_sync();
-        const unsigned *lb = reinterpret_cast<const unsigned *>(ld);
-        const int c4 = c & ~3;
-        for (int e0 = 0; e0 < c; e0 += CL3D_WAVE) {
-          const int e = e0 + lane;
-          const bool on = e < c;
-          const unsigned my = on ? lb[e] : 0u;
-          int rank = 0;
-          for (int f = 0; f < c4; f += 4) {
-            const uint4 k4 = *reinterpret_cast<const uint4 *>(lb + f);
-            rank += k4.x < my ? 1 : 0;
-            rank += k4.y < my ? 1 : 0;
-            rank += k4.z < my ? 1 : 0;
-            rank += k4.w < my ? 1 : 0;
-          }
-          for (int f = c4; f < c; ++f) rank += lb[f] < my ? 1 : 0;
-          if (on && rank <= K) so[rank] = li[e];
-        }
-        tl_wave_sync();
-        bool hole = false;
-        for (int i = lane; i < need; i += CL3D_WAVE) hole = hole || so[i] < 0;
-        if (__ballot(hole) != 0ull) {  // uniform: ties in distance -> exact (distance, original index) ranking
-          for (int e = lane; e < c; e += CL3D_WAVE) {
-            const float de = ld[e];
-            const int ie = li[e];
+            const bool on = e < c;
+            const unsigned my = on ? lb[e] : 0u;
             int rank = 0;
-#pragma unroll 8
-            for (int f = 0; f < c; ++f) {
-              const float df = ld[f];
-              rank += (df < de || (df == de && li[f] < ie)) ? 1 : 0;
+            for (int f = 0; f < c; f += 4) {
+              const uint4 k4 = *reinterpret_cast<const uint4 *>(lb + f);
+              rank += k4.x < my ? 1 : 0;
+              rank += k4.y < my ? 1 : 0;
+              rank += k4.z < my ? 1 : 0;
+              rank += k4.w < my ? 1 : 0;
             }
-            if (rank <= K) so[rank] = ie;
+            if (on && rank <= K) so[rank] = li[e];
           }
           tl_wave_sync();
-        }
-        const int qmk = qm[j];
-        if (c >= K) {  // uniform, the common case: a full list, no wrap-around padding (and no integer modulo)
-          for (int i = lane; i < K; i += CL3D_WAVE) {
-            oi[i] = so[i];
-            om[i] = qmk != 0 ? 1 : 0;
-          }
-        } else {
-          for (int i = lane; i < K; i += CL3D_WAVE) {
-            int v = 0, mkv = 0;
-            if (c > 0) {
-              v = so[i < c ? i : i % c];
-              mkv = (i < c && qmk != 0) ? 1 : 0;
+          bool hole = false;
+          for (int i = lane; i < need; i += CL3D_WAVE) hole = hole || so[i] < 0;
+          if (__ballot(hole) != 0ull) {  // uniform: ties in distance -> exact (distance, original index) ranking
+            for (int e = lane; e < c; e += CL3D_WAVE) {
+              const float de = ld[e];
+              const int ie = li[e];
+              int rank = 0;
+#pragma unroll 8
+              for (int f = 0; f < c; ++f) {
+                const float df = ld[f];
+                rank += (df < de || (df == de && li[f] < ie)) ? 1 : 0;
+              }
+              if (rank <= K) so[rank] = ie;
             }
-            oi[i] = v;
-            om[i] = mkv;
+            tl_wave_sync();
+          }
+          const int qmk = qm[j];
+          if (c >= K) {  // uniform, the common case: a full list, no wrap-around padding (and no integer modulo)
+            for (int i = lane; i < K; i += CL3D_WAVE) {
+              oi[i] = so[i];
+              om[i] = qmk != 0 ? 1 : 0;
+            }
+          } else {
+            for (int i = lane; i < K; i += CL3D_WAVE) {
+              int v = 0, mkv = 0;
+              if (c > 0) {
+                v = so[i < c ? i : i % c];
+                mkv = (i < c && qmk != 0) ? 1 : 0;
+              }
+              oi[i] = v;
+              om[i] = mkv;
+            }
           }
         }
+        tl_wave_sync();
       }
-      tl_wave_sync();
     }
   }
 }
 
 bool ball_query_tile_applicable(int M, int N, int K) {
   if (N < 512 || M < 64 || N > kTlMaxPts || M > kTlMaxPts || K < 1) return false;
+  if (kTlCapMul * K > kTlIdxRounds * CL3D_WAVE) return false;
   return (size_t)tl_layout(N, K).total * sizeof(int) <= 158 * 1024;
 }
 

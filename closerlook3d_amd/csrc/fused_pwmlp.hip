@@ -735,59 +735,71 @@ __global__ __launch_bounds__(256) void pwmlp_summary_kernel(SumArgs a) {
   const int lane = lane_id();
   const int wave = threadIdx.x >> 6;
   const int K = a.K, N = a.N, MK = a.M * a.K;
-  const long long rows = (long long)a.B * N;
-  const long long stride = (long long)gridDim.x * 4;
-  long long r = (long long)blockIdx.x * 4 + wave;
-  if (r >= rows) return;
-  auto bounds = [&](long long rr, int &b, int &i, int &s0, int &s1) {  // clamped: past the end = an empty list
-    const long long rc = rr < rows ? rr : rows - 1;
-    b = (int)(rc / N);
-    i = (int)(rc - (long long)b * N);
+  // Tiles of four support points (one per wave), walked in the XCD-aware order of the gather passes: with B a multiple
+  // of 8, XCD x works through clouds x, x + 8, ... one after the other, so a cloud's idx / slot / entry arrays (1.5 MB)
+  // are pulled into ONE L2.  (Round 3 walked the rows cloud by cloud with all eight XCDs on the same cloud: every L2
+  // fetched the whole of every cloud's idx for its eighth of the random centre look-ups -- 95.6 MB of HBM traffic per
+  // launch for 12.1 MB of algorithmic bytes.)
+  const int tiles_per_cloud = (N + 3) / 4;
+  const int ntiles = a.B * tiles_per_cloud;
+  const int stride = (int)gridDim.x;
+  int v = (int)blockIdx.x;
+  if (v >= ntiles) return;
+  auto bounds = [&](int vv, int &b, int &i, int &s0, int &s1) {  // clamped: past the end = an empty list
+    int tile;
+    decode_tile(vv < ntiles ? vv : ntiles - 1, a.B, tiles_per_cloud, b, tile);
+    i = tile * 4 + wave;
+    const bool on = vv < ntiles && i < N;
+    i = i < N ? i : N - 1;
     const int *off = a.inv_off + (size_t)b * (N + 1);
     s0 = off[i];
-    s1 = rr < rows ? off[i + 1] : s0;
+    s1 = on ? off[i + 1] : s0;
+    if (!on) i = -1;
   };
   int b, i, s0, s1, bn, in, s0n, s1n;
-  bounds(r, b, i, s0, s1);
-  bounds(r + stride, bn, in, s0n, s1n);
+  bounds(v, b, i, s0, s1);
+  bounds(v + stride, bn, in, s0n, s1n);
   int sl = s0 + lane < s1 ? a.inv_slots[(size_t)b * MK + s0 + lane] : 0;
-  for (; r < rows; r += stride) {
+  for (; v < ntiles; v += stride) {
     // requested now, used in the next iteration
     const int sl_next = s0n + lane < s1n ? a.inv_slots[(size_t)bn * MK + s0n + lane] : 0;
     int bnn, inn, s0nn, s1nn;
-    bounds(r + 2 * stride, bnn, inn, s0nn, s1nn);
-    const float *p = a.support_xyz + ((size_t)b * N + i) * 3;
-    const float px = p[0], py = p[1], pz = p[2];
-    const int *slots = a.inv_slots + (size_t)b * MK;
-    const int *idxb = a.idx + (size_t)b * MK;
-    const float *q = a.query_xyz + (size_t)b * a.M * 3;
-    unsigned *ent = a.ent + (size_t)b * MK;
-    float rx = 0.f, ry = 0.f, rz = 0.f;
-    int npair = 0, ncen = 0;
-    for (int c0 = s0; c0 < s1; c0 += CL3D_WAVE) {
-      const bool valid = c0 + lane < s1;
-      if (c0 > s0) sl = valid ? slots[c0 + lane] : 0;  // (lists longer than one round: not prefetched)
-      const int j = div_k(sl, a.kmagic, K);
-      const unsigned cen = (unsigned)idxb[j * K];
-      const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
-      // the forward pass's own expression for rel (pwmlp_query_kernel's slot record), per-lane running sums
-      rx += valid ? (px - qx) * a.inv_radius : 0.f;
-      ry += valid ? (py - qy) * a.inv_radius : 0.f;
-      rz += valid ? (pz - qz) * a.inv_radius : 0.f;
-      const bool centred = valid && sl - j * K == 0;
-      const bool other = valid && !centred;
-      const unsigned long long om = __ballot(other), cm = __ballot(centred);
-      if (other) ent[s0 + npair + prefix_popc(om)] = cen;
-      if (centred) ent[s1 - 1 - ncen - prefix_popc(cm)] = (unsigned)j;
-      npair += __builtin_popcountll(om);
-      ncen += __builtin_popcountll(cm);
-    }
-    rx = wave_sum_dpp(rx);
-    ry = wave_sum_dpp(ry);
-    rz = wave_sum_dpp(rz);
-    if (lane == 0) {
-      a.rec[2 * r] = make_float4(rx, ry, rz, __int_as_float(s0));
-      a.rec[2 * r + 1] = make_float4(__int_as_float(s1 - s0), __int_as_float(npair), __int_as_float(ncen), 0.f);
+    bounds(v + 2 * stride, bnn, inn, s0nn, s1nn);
+    if (i >= 0) {  // (wave-uniform; a tile's waves past N only keep the prefetch chain going)
+      const float *p = a.support_xyz + ((size_t)b * N + i) * 3;
+      const float px = p[0], py = p[1], pz = p[2];
+      const int *slots = a.inv_slots + (size_t)b * MK;
+      const int *idxb = a.idx + (size_t)b * MK;
+      const float *q = a.query_xyz + (size_t)b * a.M * 3;
+      unsigned *ent = a.ent + (size_t)b * MK;
+      float rx = 0.f, ry = 0.f, rz = 0.f;
+      int npair = 0, ncen = 0;
+      for (int c0 = s0; c0 < s1; c0 += CL3D_WAVE) {
+        const bool valid = c0 + lane < s1;
+        if (c0 > s0) sl = valid ? slots[c0 + lane] : 0;  // (lists longer than one round: not prefetched)
+        const int j = div_k(sl, a.kmagic, K);
+        const unsigned cen = (unsigned)idxb[j * K];
+        const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
+        // the forward pass's own expression for rel (pwmlp_query_kernel's slot record), per-lane running sums
+        rx += valid ? (px - qx) * a.inv_radius : 0.f;
+        ry += valid ? (py - qy) * a.inv_radius : 0.f;
+        rz += valid ? (pz - qz) * a.inv_radius : 0.f;
+        const bool centred = valid && sl - j * K == 0;
+        const bool other = valid && !centred;
+        const unsigned long long om = __ballot(other), cm = __ballot(centred);
+        if (other) ent[s0 + npair + prefix_popc(om)] = cen;
+        if (centred) ent[s1 - 1 - ncen - prefix_popc(cm)] = (unsigned)j;
+        npair += __builtin_popcountll(om);
+        ncen += __builtin_popcountll(cm);
+      }
+      rx = wave_sum_dpp(rx);
+      ry = wave_sum_dpp(ry);
+      rz = wave_sum_dpp(rz);
+      if (lane == 0) {
+        const size_t r = (size_t)b * N + i;
+        a.rec[2 * r] = make_float4(rx, ry, rz, __int_as_float(s0));
+        a.rec[2 * r + 1] = make_float4(__int_as_float(s1 - s0), __int_as_float(npair), __int_as_float(ncen), 0.f);
+      }
     }
     b = bn; i = in; s0 = s0n; s1 = s1n; sl = sl_next;
     bn = bnn; in = inn; s0n = s0nn; s1n = s1nn;
@@ -1671,15 +1683,11 @@ extern "C" int cl3d_pwmlp_support_summary(const int32_t *idx, const float *query
   a.idx = idx; a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.inv_off = inv_off; a.inv_slots = inv_slots;
   a.rec = reinterpret_cast<float4 *>(rec); a.ent = ent;
   a.B = B; a.N = N; a.M = M; a.K = K; a.inv_radius = 1.0f / radius; a.kmagic = div_magic(K);
-  const long long rows = (long long)B * N;
+  CL3D_REQUIRE((long long)B * ((N + 3) / 4) <= 0x7fffffffLL, "pwmlp_support_summary: B*N too large");
   // grid: the kernel runs on a side stream beside the critical path's short kernels (per-channel finalize, APPLY): at
   // 2048 workgroups (every wave slot of the chip) a 64-workgroup kernel launched right behind it waited 23 us for slots
-  static const int cap = [] {
-    const char *e = getenv("CL3D_PW_SUMGRID");  // A/B timing
-    const int v = e ? atoi(e) : 0;
-    return v >= 8 ? v : 1024;
-  }();
-  const int gx = round_grid((rows + 3) / 4, cap);
+  // (round 3: 1024 measured best of 512 / 1024 / 2048).  A multiple of 8, so a workgroup stays on its XCD as it strides.
+  const int gx = round_grid((long long)B * ((N + 3) / 4), 1024);
   hipLaunchKernelGGL(pwmlp_summary_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_support_summary");
 }
