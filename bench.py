@@ -478,8 +478,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed into a bare shell: become the N-rank launch of this very command (one process per GPU over RCCL; on a
+        # box with fewer devices every rank shares device 0 over gloo and the line says so)
+        from closerlook3d_amd.dp import self_launch
+        self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU (python bench.py --gpus N "
+                         f"does it itself when WORLD_SIZE is unset)")
     # CL3D_BENCH_ONE_DEVICE=1: every rank on GPU 0 over gloo -- only to exercise the N>1 code path on a 1-GPU box
     one_dev = os.environ.get("CL3D_BENCH_ONE_DEVICE") == "1"
     if one_dev:
@@ -614,6 +620,8 @@ def main():
                        "backend": dist.get_backend() if world > 1 else None,
                        "device": f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"},
         }
+        if one_dev and world > 1:  # every rank shared device 0 over gloo: the N > 1 code path, not a scaling number
+            line["config"]["one_device_standin"] = True
         if not args.no_kernel_roofline:
             # top level: the TIMED STEP's dominant kernel (longest C-ABI entry point of the step table): algorithmic
             # HBM bytes per launch / median launch duration, HIP events on the launch stream; `traffic` = its PMC HBM

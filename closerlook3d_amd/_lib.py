@@ -10,7 +10,8 @@ import torch  # noqa: F401  -- imported first so libcl3d binds to the HIP runtim
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _D2_FORM = int(os.environ.get("CL3D_D2_FORM", "0") or 0)  # build-time distance canon, see closerlook3d_amd/build.py
-_PATH = os.path.join(_HERE, "libcl3d.so" if _D2_FORM == 0 else f"libcl3d_d2form{_D2_FORM}.so")
+# CL3D_LIB: another build of the same library (scripts/micro/bq_variants.py times kernel variants through the whole engine)
+_PATH = os.environ.get("CL3D_LIB") or os.path.join(_HERE, "libcl3d.so" if _D2_FORM == 0 else f"libcl3d_d2form{_D2_FORM}.so")
 _lib = None
 
 _P = ctypes.c_void_p  # device pointers travel as void*
@@ -29,6 +30,8 @@ SIGNATURES = {
     "cl3d_masked_nearest_query": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "cl3d_group_xyz_features": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P],
     "cl3d_build_inverse_index": [_P, _I, _I, _I, _P, _P, _P, _Z, _P],
+    "cl3d_build_inverse_index_entries": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P],
+    "cl3d_inverse_index_entries": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "cl3d_fused_reduce_fwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _I, _F, _I, _P, _I, _P, _P, _P],
     "cl3d_fused_param_partials": [_I, _I, _I, _I],
     "cl3d_fused_param_reduce": [_I, _P, _I, _I, _I, _P, _P, _P],
@@ -69,7 +72,7 @@ SIGNATURES = {
     "cl3d_pwmlp_bwd_hits": [_P, _P, _I, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_bn_backward_coeffs": [_P, _I, _I, ctypes.c_double] + [_P] * 11,
     "cl3d_pwmlp_bwd_support": [_P] * 10 + [_F, _P, _P] + [_I] * 5 + [_P, _P],
-    "cl3d_pwmlp_support_summary": [_P] * 5 + [_I] * 4 + [_F, _P, _P, _P],
+    "cl3d_pwmlp_support_summary": [_P] * 5 + [_I] * 4 + [_F, _P, _P, _I, _P],
     "cl3d_pwmlp_bwd_support_sum": [_P] * 10 + [_I] * 5 + [_P, _P],
 }
 
@@ -162,16 +165,21 @@ class trace:
         return out
 
 
-def _header_abi_version():
-    """CL3D_ABI_VERSION of include/cl3d.h: the library must have been built from the same header (a stale .so with
-    another argument layout would run with shifted pointers)."""
+# CL3D_ABI_VERSION of include/cl3d.h: the library must have been built from the same header (a stale .so with another
+# argument layout would run with shifted pointers).  A constant, so that a copy of the package without the repository's
+# include/ directory still imports; tests/test_abi.py holds it to the header.
+ABI_VERSION = 3
+
+
+def header_abi_version():
+    """CL3D_ABI_VERSION as include/cl3d.h states it, or None where the header does not travel with the package."""
     import re
     hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "cl3d.h")
+    if not os.path.exists(hdr):
+        return None
     with open(hdr) as f:
-        return int(re.search(r"#define\s+CL3D_ABI_VERSION\s+(\d+)", f.read()).group(1))
-
-
-ABI_VERSION = _header_abi_version()
+        m = re.search(r"#define\s+CL3D_ABI_VERSION\s+(\d+)", f.read())
+    return int(m.group(1)) if m else None
 
 
 def lib():

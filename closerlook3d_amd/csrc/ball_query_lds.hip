@@ -40,11 +40,29 @@ constexpr int kTlPT = 4;                          // points per thread
 constexpr int kTlMaxPts = kTlThreads * kTlPT;     // 4096
 constexpr int kTlMaxCells = 2048;
 constexpr int kTlQChunk = 512;                    // query records staged per round
-constexpr int kTlQT = 4;                          // queries per task (of one cell): they share one window read
+// Tunables: the defaults are what ships; scripts/micro/bq_variants.py builds this file with other values
+// (-DCL3D_BQ_MICRO adds a C entry point) and times them against each other on the GPU box.
+#ifndef CL3D_TL_QT
+#define CL3D_TL_QT 4
+#endif
+#ifndef CL3D_TL_PHASE
+#define CL3D_TL_PHASE 0   // timing experiments only: 1 = stop after the prep, 2 = after the candidate pass, 3 = before the stores
+#endif
+#ifndef CL3D_TL_RANK
+#define CL3D_TL_RANK 1    // 1 = both queries of a pass ranked in lock step; 0 = one after the other (ties by write collisions either way)
+#endif
+#ifndef CL3D_TL_MINWAVES
+#define CL3D_TL_MINWAVES 4  // waves per SIMD the register budget is set for (5 -> 96 VGPRs: room for a second kernel's waves)
+#endif
+constexpr int kTlQT = CL3D_TL_QT;                 // queries per task (of one cell): they share one window read
 constexpr int kTlQW = 2;                          // queries tested per candidate pass (one packed-FP32 chain)
 constexpr int kTlCapMul = 6;                      // candidate list holds kTlCapMul*K entries per query
-constexpr int kTlWin = 6;                         // window batches (of 64 records) a wave holds in registers
+#ifndef CL3D_TL_FLAT
+#define CL3D_TL_FLAT 6
+#endif
+constexpr int kTlFlat = CL3D_TL_FLAT;             // window batches (of 64) whose positions a wave keeps in registers
 constexpr int kTlIdxRounds = 4;                   // rank-by-index rounds held in registers: kTlCapMul*K <= 256
+constexpr int kTlRankRounds = 2;                  // rank-by-distance rounds held in registers: 3*K <= 128
 
 typedef float tl_v2f __attribute__((ext_vector_type(2)));
 
@@ -105,15 +123,8 @@ __device__ __forceinline__ tl_v2f tl_dist2_pair(tl_v2f qx, tl_v2f qy, tl_v2f qz,
 #endif
 }
 
-// The candidate window of a task: <= 9 contiguous runs of `sorted`, laid end to end; w_pe<r> = exclusive prefix of
-// run r in the window's index space, w_d<r> = start(run r) - w_pe<r>.  Plain local scalars and a macro on purpose:
-// held in a struct or an array, the compiler turns the select chain into "select an offset, load the delta from
-// scratch memory" before it promotes the aggregate to registers.
-#define TL_WINDOW_POS(p)                                                                                      \
-  ((p) + ((p) >= w_pe8 ? w_d8 : (p) >= w_pe7 ? w_d7 : (p) >= w_pe6 ? w_d6 : (p) >= w_pe5 ? w_d5 : (p) >= w_pe4 ? w_d4 \
-          : (p) >= w_pe3 ? w_d3 : (p) >= w_pe2 ? w_d2 : (p) >= w_pe1 ? w_d1 : w_d0))
-
-__global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__restrict__ query_xyz,
+template <bool SAME>  // SAME: the queries ARE the support points (every non-strided layer): one set of registers for both roles
+__global__ __launch_bounds__(kTlThreads, CL3D_TL_MINWAVES) void bq_tile_kernel(const float *__restrict__ query_xyz,
                                                             const float *__restrict__ support_xyz,
                                                             const int *__restrict__ query_mask,
                                                             const int *__restrict__ support_mask, int M, int N,
@@ -141,7 +152,6 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
   const float *q = query_xyz + (size_t)b * M * 3;
   const int *sm = support_mask + (size_t)b * N;
   const int *qm = query_mask + (size_t)b * M;
-  const bool same = query_xyz == support_xyz && M == N;
 
   // ---- (1) this thread's points (kept in registers to the end of the prep), valid prefix, bounding box
   float px[kTlPT], py[kTlPT], pz[kTlPT], qx_[kTlPT], qy_[kTlPT], qz_[kTlPT];
@@ -155,21 +165,18 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
     py[u] = s[ic * 3 + 1];
     pz[u] = s[ic * 3 + 2];
   }
-  if (!same) {
 #pragma unroll
-    for (int u = 0; u < kTlPT; ++u) {
+  for (int u = 0; u < kTlPT; ++u) {
+    if constexpr (SAME) {
+      qx_[u] = px[u];
+      qy_[u] = py[u];
+      qz_[u] = pz[u];
+    } else {
       const int i = u * kTlThreads + tid;
       const int ic = i < M ? i : M - 1;
       qx_[u] = q[ic * 3 + 0];
       qy_[u] = q[ic * 3 + 1];
       qz_[u] = q[ic * 3 + 2];
-    }
-  } else {
-#pragma unroll
-    for (int u = 0; u < kTlPT; ++u) {
-      qx_[u] = px[u];
-      qy_[u] = py[u];
-      qz_[u] = pz[u];
     }
   }
   if (tid == 0) s_nv = N;
@@ -257,9 +264,13 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
 #pragma unroll
   for (int u = 0; u < kTlPT; ++u) {
     const int i = u * kTlThreads + tid;
-    int dxy, dz;
-    cs[u] = cell_of(px[u], py[u], pz[u], dxy, dz);
-    cq[u] = cell_of(qx_[u], qy_[u], qz_[u], cqxy[u], cqz[u]);
+    if constexpr (SAME) {
+      cs[u] = cq[u] = cell_of(px[u], py[u], pz[u], cqxy[u], cqz[u]);
+    } else {
+      int dxy, dz;
+      cs[u] = cell_of(px[u], py[u], pz[u], dxy, dz);
+      cq[u] = cell_of(qx_[u], qy_[u], qz_[u], cqxy[u], cqz[u]);
+    }
     if (i < nv) atomicAdd(&s_end[cs[u]], 1);
     if (i < M) atomicAdd(&q_end[cq[u]], 1);
   }
@@ -357,6 +368,9 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
   }
   // from here on: s_end[c] = end of cell c in `sorted` (start of cell c+1); q_end[c] = end of cell c in query
   // order for the cells of this share
+#if CL3D_TL_PHASE == 1
+  return;
+#endif
 
   // per-wave lists: for each of the kTlQW queries of a pass, distances [capS], original indices [capS], output [outS]
   int *wbase = tl_lds + L.wave0 + wave * L.per_wave;
@@ -418,8 +432,12 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
       if (t >= ntasks) break;
       const int tkv = __builtin_amdgcn_readfirstlane(tasks[t]);
       const int r0 = tkv & 0xffff, n = tkv >> 16;
-      // the cell's candidate window: 3x3 (y,z) rows of <= 3 x-adjacent cells, each one contiguous run of `sorted`
-      int w_pe1, w_pe2, w_pe3, w_pe4, w_pe5, w_pe6, w_pe7, w_pe8, w_d0, w_d1, w_d2, w_d3, w_d4, w_d5, w_d6, w_d7, w_d8, T;
+      // the cell's candidate window: 3x3 (y,z) rows of <= 3 x-adjacent cells, each one contiguous run of `sorted`.
+      // Lane r < 9 holds run r's start and length; the passes below walk the runs one after the other, 64 records at a
+      // time (position = start + lane: no search for the run a window position falls into -- round 3 spent a third of
+      // the candidate pass's vector instructions and most of its branches on that -- at the price of a run's last
+      // batch being partly empty).
+      int run_a = 0, run_n = 0;
       {
         const int2 cc = qcell[r0];
         const int cz = __builtin_amdgcn_readfirstlane(cc.x >> 16);
@@ -428,46 +446,77 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
         const int y0 = cy > 0 ? cy - 1 : 0, y1 = cy + 1 < ny ? cy + 1 : ny - 1;
         const int z0 = cz > 0 ? cz - 1 : 0, z1 = cz + 1 < nz ? cz + 1 : nz - 1;
         const int yy = y0 + lane_ry, zz = z0 + lane_rz;
-        int ra = 0, len = 0;
         if (lane < 9 && yy <= y1 && zz <= z1) {
           const int row = nx * (yy + ny * zz);
           const int ca = row + x0, cb = row + x1 + 1;  // cells [ca, cb): starts are the previous cell's end
-          ra = ca > 0 ? s_end[ca - 1] : 0;
-          len = s_end[cb - 1] - ra;
+          run_a = ca > 0 ? s_end[ca - 1] : 0;
+          run_n = s_end[cb - 1] - run_a;
         }
-        int inc = len;
+      }
+      // The window laid end to end is T records; when they fit kTlFlat batches (the rule: ~320 at the metric shape) every
+      // lane works out, once per task, where its kTlFlat window positions lie in `sorted` -- which run a position falls
+      // into is a count of run starts at or below it (eight compares against broadcast prefixes, no branches), the
+      // run's offset a cross-lane read -- and the candidate passes of the task's queries read whole batches of 64
+      // records from those positions.  Larger windows are walked run by run (for_window).
+      int win_pos[kTlFlat];
+      int T;
+      {
+        int inc = run_n;
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) {
           const int v = __shfl_up(inc, o, 64);
           if (lane >= o) inc += v;
         }
-        const int pe = inc - len, dl = ra - pe;
-        w_pe1 = __builtin_amdgcn_readlane(pe, 1); w_pe2 = __builtin_amdgcn_readlane(pe, 2);
-        w_pe3 = __builtin_amdgcn_readlane(pe, 3); w_pe4 = __builtin_amdgcn_readlane(pe, 4);
-        w_pe5 = __builtin_amdgcn_readlane(pe, 5); w_pe6 = __builtin_amdgcn_readlane(pe, 6);
-        w_pe7 = __builtin_amdgcn_readlane(pe, 7); w_pe8 = __builtin_amdgcn_readlane(pe, 8);
-        w_d0 = __builtin_amdgcn_readlane(dl, 0); w_d1 = __builtin_amdgcn_readlane(dl, 1);
-        w_d2 = __builtin_amdgcn_readlane(dl, 2); w_d3 = __builtin_amdgcn_readlane(dl, 3);
-        w_d4 = __builtin_amdgcn_readlane(dl, 4); w_d5 = __builtin_amdgcn_readlane(dl, 5);
-        w_d6 = __builtin_amdgcn_readlane(dl, 6); w_d7 = __builtin_amdgcn_readlane(dl, 7);
-        w_d8 = __builtin_amdgcn_readlane(dl, 8);
         T = __builtin_amdgcn_readlane(inc, 8);
-      }
-      // A window of <= 64 * kTlWin records (the rule at the metric shape: ~320) stays in registers for every query of
-      // the task; a larger one is streamed again for each pair of queries.  A position past the window's end holds a
-      // NaN coordinate: its distances are NaN and never "in radius" -- no per-candidate guard below.
-      const bool resident = T <= CL3D_WAVE * kTlWin;
-      float4 sp[kTlWin];
-      auto load_window = [&](int p0) {
+        const int pe = inc - run_n;   // lane r < 9: exclusive prefix of run r in the window's index space
+        const int dl = run_a - pe;    //             start(run r) - prefix
+        int rr[kTlFlat];
 #pragma unroll
-        for (int v = 0; v < kTlWin; ++v) {
-          const int p = p0 + v * CL3D_WAVE + lane;
-          const int pc = p < T ? p : T - 1;
-          sp[v] = sorted[TL_WINDOW_POS(pc)];
-          if (p >= T) sp[v].x = __builtin_nanf("");
+        for (int v = 0; v < kTlFlat; ++v) rr[v] = 0;
+        if (T <= CL3D_WAVE * kTlFlat) {
+#pragma unroll
+          for (int r = 1; r < 9; ++r) {
+            const int per = __builtin_amdgcn_readlane(pe, r);
+#pragma unroll
+            for (int v = 0; v < kTlFlat; ++v) rr[v] += (v * CL3D_WAVE + lane >= per) ? 1 : 0;
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < kTlFlat; ++v) {
+          const int pw = v * CL3D_WAVE + lane;
+          win_pos[v] = (pw < T ? pw : (T > 0 ? T - 1 : 0)) + __shfl(dl, rr[v], CL3D_WAVE);
+        }
+      }
+      const bool flat = T <= CL3D_WAVE * kTlFlat;
+      // f(record, live) for every record of the window, 64 at a time; a lane past a run's end sees live == false.
+      // Three runs' first batches are requested together (one LDS round trip for ~100 records); what a run holds
+      // beyond 64 records (dense clouds) follows one batch at a time.
+      auto for_window = [&](auto &&f) {
+#pragma unroll 1
+        for (int g = 0; g < 9; g += 3) {
+          int ra[3], rn[3];
+          float4 rec[3];
+#pragma unroll
+          for (int t3 = 0; t3 < 3; ++t3) {
+            ra[t3] = __builtin_amdgcn_readlane(run_a, g + t3);
+            rn[t3] = __builtin_amdgcn_readlane(run_n, g + t3);
+          }
+#pragma unroll
+          for (int t3 = 0; t3 < 3; ++t3)  // (an absent run has start 0, length 0: record 0 is read and ignored)
+            rec[t3] = sorted[ra[t3] + (lane < rn[t3] ? lane : (rn[t3] > 0 ? rn[t3] - 1 : 0))];
+#pragma unroll
+          for (int t3 = 0; t3 < 3; ++t3)
+            if (rn[t3] > 0) f(rec[t3], lane < rn[t3]);
+#pragma unroll 1
+          for (int t3 = 0; t3 < 3; ++t3) {
+            const int ra2 = __builtin_amdgcn_readlane(run_a, g + t3), rn2 = __builtin_amdgcn_readlane(run_n, g + t3);
+            for (int o = CL3D_WAVE; o < rn2; o += CL3D_WAVE) {
+              const int pp = o + lane;
+              f(sorted[ra2 + (pp < rn2 ? pp : rn2 - 1)], pp < rn2);
+            }
+          }
         }
       };
-      if (resident && T > 0) load_window(0);
 
       for (int u0 = 0; u0 < n; u0 += kTlQW) {
         const int nq = n - u0 < kTlQW ? n - u0 : kTlQW;  // uniform
@@ -488,175 +537,167 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
         // ---- candidates: every in-radius candidate of the window leaves (distance, original index) in the query's LDS
         // list (unordered: the selection below restates the reference's order-dependent rule), one ballot + prefix
         // count per query and 64 candidates
-        for (int p0 = 0; p0 < T; p0 += CL3D_WAVE * kTlWin) {
-          if (!resident) load_window(p0);
+        auto test = [&](float4 rec, bool live) {
+          // (a lane past the end gets a NaN coordinate: its distances are NaN and never "in radius")
+          const tl_v2f d2 = tl_dist2_pair(qx2, qy2, qz2, live ? rec.x : __builtin_nanf(""), rec.y, rec.z);
 #pragma unroll
-          for (int v = 0; v < kTlWin; ++v) {
-            if (p0 + v * CL3D_WAVE >= T) break;  // uniform
-            const tl_v2f d2 = tl_dist2_pair(qx2, qy2, qz2, sp[v].x, sp[v].y, sp[v].z);
-#pragma unroll
-            for (int u = 0; u < kTlQW; ++u) {
-              const float d = u == 0 ? d2.x : d2.y;
-              const bool hit = d < radius2;
-              const unsigned long long m = __ballot(hit);
-              const int c0 = cnt[u];
-              const int c1 = c0 + (int)__popcll(m);  // wave-uniform
-              if (c1 <= cap && hit) {                // an overflowing list is abandoned
-                int *dst = wbase + u * (2 * L.capS + L.outS) + c0 + prefix_popc(m);
-                dst[0] = __float_as_int(d);
-                dst[L.capS] = __float_as_int(sp[v].w);
-              }
-              cnt[u] = c1;
+          for (int u = 0; u < kTlQW; ++u) {
+            const float d = u == 0 ? d2.x : d2.y;
+            const bool hit = d < radius2;
+            const unsigned long long m = __ballot(hit);
+            const int c0 = cnt[u];
+            const int c1 = c0 + (int)__popcll(m);  // wave-uniform
+            if (c1 <= cap && hit) {                // an overflowing list is abandoned
+              int *dst = wbase + u * (2 * L.capS + L.outS) + c0 + prefix_popc(m);
+              dst[0] = __float_as_int(d);
+              dst[L.capS] = __float_as_int(rec.w);
             }
+            cnt[u] = c1;
           }
+        };
+        if (flat) {
+#pragma unroll
+          for (int v0 = 0; v0 < kTlFlat; v0 += 3) {  // three batches in flight per LDS round trip
+            if (v0 * CL3D_WAVE >= T) break;           // uniform
+            float4 rec[3];
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3) rec[t3] = sorted[win_pos[v0 + t3]];
+#pragma unroll
+            for (int t3 = 0; t3 < 3; ++t3)
+              if ((v0 + t3) * CL3D_WAVE < T) test(rec[t3], (v0 + t3) * CL3D_WAVE + lane < T);
+          }
+        } else {
+          for_window(test);
         }
         tl_wave_sync();
 
-#pragma unroll
-        for (int u = 0; u < kTlQW; ++u) {
-          if (u >= nq) continue;
-          const int j = jq[u];
+#if CL3D_TL_PHASE == 2
+        continue;
+#endif
+        // ---- selection (rare): more than 3K in-radius candidates -> the 3K smallest original indices, the strict
+        // minimum patched into the last slot; returns the length of the list the ranking works on
+        auto select = [&](int u) -> int {
           const float qxu = qxs[u], qyu = qys[u], qzu = qzs[u];
           const int S = __builtin_amdgcn_readfirstlane(cnt[u]);
-          int *oi = idx + ((size_t)b * M + j) * K;
-          int *om = idx_mask + ((size_t)b * M + j) * K;
           int *lbase = wbase + u * (2 * L.capS + L.outS);
           float *ld = reinterpret_cast<float *>(lbase);
           int *li = lbase + L.capS;
-          int *so = lbase + 2 * L.capS;
-          int c = S;
-          if (S > cap3) {
-            // first-occurrence strict minimum == smallest (d2, original index) of all S in-radius candidates
-            unsigned long long key = ~0ull;
-            int nlist = S;
-            if (S > cap) {
-              // dense: the list was abandoned.  Bisection for T* = (3K-th smallest original index of S) + 1:
-              // count(orig < lo) < 3K <= count(orig < hi)
-              int lo = 0, hi = N;
-              while (hi - lo > 1) {
-                const int mid = (lo + hi) >> 1;
-                int below = 0;
-                for (int p0 = 0; p0 < T; p0 += CL3D_WAVE) {
-                  const int p = p0 + lane;
-                  const float4 rec = sorted[TL_WINDOW_POS(p < T ? p : T - 1)];
-                  const float d2 = dist2(qxu, qyu, qzu, rec.x, rec.y, rec.z);
-                  const bool hit = p < T && d2 < radius2 && __float_as_int(rec.w) < mid;
-                  below += (int)__popcll(__ballot(hit));
-                }
-                if (below >= cap3) hi = mid;
-                else lo = mid;
-              }
-              int fill = 0;
-              for (int p0 = 0; p0 < T; p0 += CL3D_WAVE) {
-                const int p = p0 + lane;
-                const float4 rec = sorted[TL_WINDOW_POS(p < T ? p : T - 1)];
+          if (S <= cap3) return S;
+          // first-occurrence strict minimum == smallest (d2, original index) of all S in-radius candidates
+          unsigned long long key = ~0ull;
+          int nlist = S;
+          if (S > cap) {
+            // dense: the list was abandoned.  Bisection for T* = (3K-th smallest original index of S) + 1:
+            // count(orig < lo) < 3K <= count(orig < hi)
+            int lo = 0, hi = N;
+            while (hi - lo > 1) {
+              const int mid = (lo + hi) >> 1;
+              int below = 0;
+              for_window([&](float4 rec, bool live) {
                 const float d2 = dist2(qxu, qyu, qzu, rec.x, rec.y, rec.z);
-                const bool hit = p < T && d2 < radius2;
-                const int orig = __float_as_int(rec.w);
-                if (hit) {
-                  const unsigned long long ke = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)orig;
-                  key = ke < key ? ke : key;
-                }
-                const bool take = hit && orig < hi;
-                const unsigned long long m = __ballot(take);
-                if (take) {
-                  const int e = fill + prefix_popc(m);
-                  ld[e] = d2;
-                  li[e] = orig;
-                }
-                fill += (int)__popcll(m);
-              }
-              nlist = cap3;  // == fill: original indices are distinct
-              tl_wave_sync();
-            } else {
-              for (int e = lane; e < S; e += CL3D_WAVE) {
-                const unsigned long long ke = ((unsigned long long)__float_as_uint(ld[e]) << 32) | (unsigned)li[e];
+                const bool hit = live && d2 < radius2 && __float_as_int(rec.w) < mid;
+                below += (int)__popcll(__ballot(hit));
+              });
+              if (below >= cap3) hi = mid;
+              else lo = mid;
+            }
+            int fill = 0;
+            for_window([&](float4 rec, bool live) {
+              const float d2 = dist2(qxu, qyu, qzu, rec.x, rec.y, rec.z);
+              const bool hit = live && d2 < radius2;
+              const int orig = __float_as_int(rec.w);
+              if (hit) {
+                const unsigned long long ke = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)orig;
                 key = ke < key ? ke : key;
               }
-            }
-            key = wave_min_u64(key);
-            const int gidx = (int)(unsigned)(key & 0xffffffffull);
-            // the 3K smallest original indices, moved to the front of the list in index order: every lane takes its
-            // entries into registers and ranks them by original index against the whole list, then -- all reads done --
-            // the entries with rank < 3K are written back at their rank
-            float my_d[kTlIdxRounds];
-            int my_i[kTlIdxRounds], my_r[kTlIdxRounds];
-#pragma unroll
-            for (int t2 = 0; t2 < kTlIdxRounds; ++t2) {
-              const int e = t2 * CL3D_WAVE + lane;
-              const bool on = e < nlist;
-              my_d[t2] = on ? ld[e] : 0.f;
-              my_i[t2] = on ? li[e] : 0x7fffffff;
-              my_r[t2] = 0;
-            }
-            for (int f = 0; f < nlist; ++f) {
-              const int kf = li[f];
-#pragma unroll
-              for (int t2 = 0; t2 < kTlIdxRounds; ++t2) my_r[t2] += kf < my_i[t2] ? 1 : 0;
-            }
-            tl_wave_sync();
-#pragma unroll
-            for (int t2 = 0; t2 < kTlIdxRounds; ++t2) {
-              if (t2 * CL3D_WAVE + lane < nlist && my_r[t2] < cap3) {
-                ld[my_r[t2]] = my_d[t2];
-                li[my_r[t2]] = my_i[t2];
+              const bool take = hit && orig < hi;
+              const unsigned long long m = __ballot(take);
+              if (take) {
+                const int e = fill + prefix_popc(m);
+                ld[e] = d2;
+                li[e] = orig;
               }
-            }
+              fill += (int)__popcll(m);
+            });
+            nlist = cap3;  // == fill: original indices are distinct
             tl_wave_sync();
-            if (gidx > li[cap3 - 1]) {  // uniform: the minimum was cut off -> it takes the last slot
-              if (lane == 0) {
-                li[cap3 - 1] = gidx;
-                ld[cap3 - 1] = __uint_as_float((unsigned)(key >> 32));
-              }
+          } else {
+            for (int e = lane; e < S; e += CL3D_WAVE) {
+              const unsigned long long ke = ((unsigned long long)__float_as_uint(ld[e]) << 32) | (unsigned)li[e];
+              key = ke < key ? ke : key;
             }
-            c = cap3;
           }
-          // ---- rank by (distance, original index) == stable sort by distance of the index-ordered list.
-          // Fast path: rank by the distance alone (d2 >= 0, so its bit pattern orders like the value), keys broadcast
-          // four at a time from LDS (the list ends in four all-ones sentinels: no tail loop).  Equal distances give
-          // equal ranks and leave a hole in ranks [0, min(c, K+1)); a hole is detected below and the exact ranking
-          // redoes the (rare) list.
-          unsigned *lb = reinterpret_cast<unsigned *>(ld);
-          const int need = c < K + 1 ? c : K + 1;
-          if (lane < 4) lb[c + lane] = 0xffffffffu;
-          for (int i = lane; i < need; i += CL3D_WAVE) so[i] = -1;
+          key = wave_min_u64(key);
+          const int gidx = (int)(unsigned)(key & 0xffffffffull);
+          // the 3K smallest original indices, moved to the front of the list in index order: every lane takes its
+          // entries into registers and ranks them by original index against the whole list, then -- all reads done --
+          // the entries with rank < 3K are written back at their rank
+          float my_d[kTlIdxRounds];
+          int my_i[kTlIdxRounds], my_r[kTlIdxRounds];
+#pragma unroll
+          for (int t2 = 0; t2 < kTlIdxRounds; ++t2) {
+            const int e = t2 * CL3D_WAVE + lane;
+            const bool on = e < nlist;
+            my_d[t2] = on ? ld[e] : 0.f;
+            my_i[t2] = on ? li[e] : 0x7fffffff;
+            my_r[t2] = 0;
+          }
+          for (int f = 0; f < nlist; ++f) {
+            const int kf = li[f];
+#pragma unroll
+            for (int t2 = 0; t2 < kTlIdxRounds; ++t2) my_r[t2] += kf < my_i[t2] ? 1 : 0;
+          }
           tl_wave_sync();
-          for (int e0 = 0; e0 < c; e0 += CL3D_WAVE) {
-            const int e = e0 + lane;
-            const bool on = e < c;
-            const unsigned my = on ? lb[e] : 0u;
+#pragma unroll
+          for (int t2 = 0; t2 < kTlIdxRounds; ++t2) {
+            if (t2 * CL3D_WAVE + lane < nlist && my_r[t2] < cap3) {
+              ld[my_r[t2]] = my_d[t2];
+              li[my_r[t2]] = my_i[t2];
+            }
+          }
+          tl_wave_sync();
+          if (gidx > li[cap3 - 1]) {  // uniform: the minimum was cut off -> it takes the last slot
+            if (lane == 0) {
+              li[cap3 - 1] = gidx;
+              ld[cap3 - 1] = __uint_as_float((unsigned)(key >> 32));
+            }
+          }
+          return cap3;
+        };
+        // exact ranking by (distance, original index) of a list whose distances tie: ranks < K go to `so`
+        auto rank_exact = [&](int u, int c) {
+          int *lbase = wbase + u * (2 * L.capS + L.outS);
+          const float *ld = reinterpret_cast<const float *>(lbase);
+          const int *li = lbase + L.capS;
+          int *so = lbase + 2 * L.capS;
+          for (int e = lane; e < c; e += CL3D_WAVE) {
+            const float de = ld[e];
+            const int ie = li[e];
             int rank = 0;
-            for (int f = 0; f < c; f += 4) {
-              const uint4 k4 = *reinterpret_cast<const uint4 *>(lb + f);
-              rank += k4.x < my ? 1 : 0;
-              rank += k4.y < my ? 1 : 0;
-              rank += k4.z < my ? 1 : 0;
-              rank += k4.w < my ? 1 : 0;
+#pragma unroll 8
+            for (int f = 0; f < c; ++f) {
+              const float df = ld[f];
+              rank += (df < de || (df == de && li[f] < ie)) ? 1 : 0;
             }
-            if (on && rank <= K) so[rank] = li[e];
+            if (rank <= K) so[rank] = ie;
           }
           tl_wave_sync();
-          bool hole = false;
-          for (int i = lane; i < need; i += CL3D_WAVE) hole = hole || so[i] < 0;
-          if (__ballot(hole) != 0ull) {  // uniform: ties in distance -> exact (distance, original index) ranking
-            for (int e = lane; e < c; e += CL3D_WAVE) {
-              const float de = ld[e];
-              const int ie = li[e];
-              int rank = 0;
-#pragma unroll 8
-              for (int f = 0; f < c; ++f) {
-                const float df = ld[f];
-                rank += (df < de || (df == de && li[f] < ie)) ? 1 : 0;
-              }
-              if (rank <= K) so[rank] = ie;
-            }
-            tl_wave_sync();
-          }
+        };
+        // first K of the ranked list to the caller's arrays; wrap-around padding for a short list
+        auto store = [&](int u, int c, int first) {  // first = so[lane] (lane < K), read by the caller
+          const int j = jq[u];
+          int *oi = idx + ((size_t)b * M + j) * K;
+          int *om = idx_mask + ((size_t)b * M + j) * K;
+          const int *so = wbase + u * (2 * L.capS + L.outS) + 2 * L.capS;
           const int qmk = qm[j];
+#if CL3D_TL_PHASE == 3
+          if (qmk == 0x7fffffff) oi[lane] = first + c;  // (timing experiment: everything but the stores)
+          return;
+#endif
           if (c >= K) {  // uniform, the common case: a full list, no wrap-around padding (and no integer modulo)
-            for (int i = lane; i < K; i += CL3D_WAVE) {
-              oi[i] = so[i];
-              om[i] = qmk != 0 ? 1 : 0;
+            if (lane < K) {
+              oi[lane] = first;
+              om[lane] = qmk != 0 ? 1 : 0;
             }
           } else {
             for (int i = lane; i < K; i += CL3D_WAVE) {
@@ -669,7 +710,145 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
               om[i] = mkv;
             }
           }
+        };
+        // ---- rank by (distance, original index) == stable sort by distance of the index-ordered list.
+        // Fast path: rank by the distance alone (d2 >= 0, so its bit pattern orders like the value), keys broadcast
+        // four at a time from LDS (the list ends in four all-ones sentinels: no tail loop).
+#if CL3D_TL_RANK == 1
+        // Both queries of the pass in lock step (one LDS round trip serves two independent chains).  A tie in distance
+        // gives two entries the same rank: both write the same slot of `so`, one of them reads back another entry's
+        // index -- the collision sends the (rare) list to the exact ranking.  Only ranks < K matter: a tie further out
+        // cannot change the first K.
+        int cq2[kTlQW];
+#pragma unroll
+        for (int u = 0; u < kTlQW; ++u) cq2[u] = u < nq ? select(u) : 0;
+        unsigned *lb0 = reinterpret_cast<unsigned *>(wbase);
+        unsigned *lb1 = reinterpret_cast<unsigned *>(wbase + (2 * L.capS + L.outS));
+        if (lane < 4) {
+          lb0[cq2[0] + lane] = 0xffffffffu;
+          lb1[cq2[1] + lane] = 0xffffffffu;
         }
+        tl_wave_sync();
+        int rk[kTlQW][kTlRankRounds], mi[kTlQW][kTlRankRounds];
+        {
+          // round 0 of both lists: one merged loop over the common length, then the longer list's tail
+          const int c0 = cq2[0], c1 = cq2[1];
+          const unsigned my0 = lane < c0 ? lb0[lane] : 0u, my1 = lane < c1 ? lb1[lane] : 0u;
+          mi[0][0] = lane < c0 ? reinterpret_cast<const int *>(lb0)[L.capS + lane] : -1;
+          mi[1][0] = lane < c1 ? reinterpret_cast<const int *>(lb1)[L.capS + lane] : -1;
+          int r0 = 0, r1 = 0;
+          const int cm = c0 < c1 ? c0 : c1;
+          int f = 0;
+          for (; f < cm; f += 4) {
+            const uint4 a4 = *reinterpret_cast<const uint4 *>(lb0 + f);
+            const uint4 b4 = *reinterpret_cast<const uint4 *>(lb1 + f);
+            r0 += a4.x < my0 ? 1 : 0; r0 += a4.y < my0 ? 1 : 0; r0 += a4.z < my0 ? 1 : 0; r0 += a4.w < my0 ? 1 : 0;
+            r1 += b4.x < my1 ? 1 : 0; r1 += b4.y < my1 ? 1 : 0; r1 += b4.z < my1 ? 1 : 0; r1 += b4.w < my1 ? 1 : 0;
+          }
+          for (int g = f; g < c0; g += 4) {
+            const uint4 a4 = *reinterpret_cast<const uint4 *>(lb0 + g);
+            r0 += a4.x < my0 ? 1 : 0; r0 += a4.y < my0 ? 1 : 0; r0 += a4.z < my0 ? 1 : 0; r0 += a4.w < my0 ? 1 : 0;
+          }
+          for (int g = f; g < c1; g += 4) {
+            const uint4 b4 = *reinterpret_cast<const uint4 *>(lb1 + g);
+            r1 += b4.x < my1 ? 1 : 0; r1 += b4.y < my1 ? 1 : 0; r1 += b4.z < my1 ? 1 : 0; r1 += b4.w < my1 ? 1 : 0;
+          }
+          rk[0][0] = lane < c0 ? r0 : K;
+          rk[1][0] = lane < c1 ? r1 : K;
+        }
+#pragma unroll
+        for (int u = 0; u < kTlQW; ++u) {  // entries 64 .. 3K - 1 of a long list (uniform, uncommon)
+          rk[u][1] = K;
+          mi[u][1] = -1;
+          const int c = cq2[u];
+          if (c > CL3D_WAVE) {
+            const unsigned *lb = u == 0 ? lb0 : lb1;
+            const int e = CL3D_WAVE + lane;
+            const bool on = e < c;
+            const unsigned my = on ? lb[e] : 0u;
+            mi[u][1] = on ? reinterpret_cast<const int *>(lb)[L.capS + e] : -1;
+            int r = 0;
+            for (int g = 0; g < c; g += 4) {
+              const uint4 k4 = *reinterpret_cast<const uint4 *>(lb + g);
+              r += k4.x < my ? 1 : 0; r += k4.y < my ? 1 : 0; r += k4.z < my ? 1 : 0; r += k4.w < my ? 1 : 0;
+            }
+            rk[u][1] = on ? r : K;
+          }
+        }
+        int *so0 = wbase + 2 * L.capS, *so1 = wbase + (2 * L.capS + L.outS) + 2 * L.capS;
+#pragma unroll
+        for (int t2 = 0; t2 < kTlRankRounds; ++t2) {
+          if (rk[0][t2] < K) so0[rk[0][t2]] = mi[0][t2];
+          if (rk[1][t2] < K) so1[rk[1][t2]] = mi[1][t2];
+        }
+        tl_wave_sync();
+        bool bad0 = false, bad1 = false;
+#pragma unroll
+        for (int t2 = 0; t2 < kTlRankRounds; ++t2) {
+          if (rk[0][t2] < K) bad0 = bad0 || so0[rk[0][t2]] != mi[0][t2];
+          if (rk[1][t2] < K) bad1 = bad1 || so1[rk[1][t2]] != mi[1][t2];
+        }
+        int first0 = lane < K ? so0[lane] : 0, first1 = lane < K ? so1[lane] : 0;
+        if (__ballot(bad0) != 0ull) {  // uniform: ties in distance -> exact (distance, original index) ranking
+          rank_exact(0, cq2[0]);
+          first0 = lane < K ? so0[lane] : 0;
+        }
+        if (__ballot(bad1) != 0ull) {
+          rank_exact(1, cq2[1]);
+          first1 = lane < K ? so1[lane] : 0;
+        }
+        store(0, cq2[0], first0);
+        if (nq > 1) store(1, cq2[1], first1);
+#else
+        // One query at a time, same collision rule.
+#pragma unroll
+        for (int u = 0; u < kTlQW; ++u) {
+          if (u >= nq) continue;
+          const int c = select(u);
+          int *lbase = wbase + u * (2 * L.capS + L.outS);
+          const int *li = lbase + L.capS;
+          int *so = lbase + 2 * L.capS;
+          unsigned *lb = reinterpret_cast<unsigned *>(lbase);
+          if (lane < 4) lb[c + lane] = 0xffffffffu;
+          tl_wave_sync();
+          int rk[kTlRankRounds], mi[kTlRankRounds];
+#pragma unroll
+          for (int t2 = 0; t2 < kTlRankRounds; ++t2) {
+            rk[t2] = K;
+            mi[t2] = -1;
+            if (t2 * CL3D_WAVE < c) {  // uniform; the second round only for a list of more than 64
+              const int e = t2 * CL3D_WAVE + lane;
+              const bool on = e < c;
+              const unsigned my = on ? lb[e] : 0u;
+              mi[t2] = on ? li[e] : -1;
+              int rank = 0;
+#pragma unroll 2
+              for (int f = 0; f < c; f += 4) {
+                const uint4 k4 = *reinterpret_cast<const uint4 *>(lb + f);
+                rank += k4.x < my ? 1 : 0;
+                rank += k4.y < my ? 1 : 0;
+                rank += k4.z < my ? 1 : 0;
+                rank += k4.w < my ? 1 : 0;
+              }
+              rk[t2] = on ? rank : K;
+            }
+          }
+#pragma unroll
+          for (int t2 = 0; t2 < kTlRankRounds; ++t2)
+            if (rk[t2] < K) so[rk[t2]] = mi[t2];
+          tl_wave_sync();
+          bool bad = false;
+#pragma unroll
+          for (int t2 = 0; t2 < kTlRankRounds; ++t2)
+            if (rk[t2] < K) bad = bad || so[rk[t2]] != mi[t2];
+          int first = lane < K ? so[lane] : 0;
+          if (__ballot(bad) != 0ull) {  // uniform: ties in distance -> exact (distance, original index) ranking
+            rank_exact(u, c);
+            first = lane < K ? so[lane] : 0;
+          }
+          store(u, c, first);
+        }
+#endif
         tl_wave_sync();
       }
     }
@@ -678,7 +857,7 @@ __global__ __launch_bounds__(kTlThreads) void bq_tile_kernel(const float *__rest
 
 bool ball_query_tile_applicable(int M, int N, int K) {
   if (N < 512 || M < 64 || N > kTlMaxPts || M > kTlMaxPts || K < 1) return false;
-  if (kTlCapMul * K > kTlIdxRounds * CL3D_WAVE) return false;
+  if (kTlCapMul * K > kTlIdxRounds * CL3D_WAVE || 3 * K > kTlRankRounds * CL3D_WAVE || K > CL3D_WAVE) return false;
   return (size_t)tl_layout(N, K).total * sizeof(int) <= 158 * 1024;
 }
 
@@ -687,17 +866,32 @@ int ball_query_tile(const float *query_xyz, const float *support_xyz, const int 
                     hipStream_t st) {
   if (B > 65535) return fail(CL3D_E_UNSUPPORTED, "ball_query: B exceeds grid.y limit");
   const size_t lds = (size_t)tl_layout(N, K).total * sizeof(int);
-  static std::atomic<unsigned long long> granted{0};
-  int rc = lds_opt_in(granted, reinterpret_cast<const void *>(bq_tile_kernel), 158 * 1024, "ball_query");
+  static std::atomic<unsigned long long> granted{0}, granted2{0};
+  const bool same = query_xyz == support_xyz && M == N;
+  int rc = lds_opt_in(granted, reinterpret_cast<const void *>(bq_tile_kernel<true>), 158 * 1024, "ball_query");
+  if (rc == CL3D_OK) rc = lds_opt_in(granted2, reinterpret_cast<const void *>(bq_tile_kernel<false>), 158 * 1024, "ball_query");
   if (rc != CL3D_OK) return rc;
   // workgroups per cloud: one per CU over the whole batch, each with at least 64 queries
   int parts = 256 / (B > 0 ? B : 1);
   const int most = M / 64;
   parts = parts > most ? most : parts;
   parts = parts < 1 ? 1 : (parts > 64 ? 64 : parts);
-  hipLaunchKernelGGL(bq_tile_kernel, dim3(parts, B), dim3(kTlThreads), lds, st, query_xyz, support_xyz, query_mask,
-                     support_mask, M, N, radius, radius * radius, K, idx, idx_mask);
+  if (same)
+    hipLaunchKernelGGL(bq_tile_kernel<true>, dim3(parts, B), dim3(kTlThreads), lds, st, query_xyz, support_xyz, query_mask,
+                       support_mask, M, N, radius, radius * radius, K, idx, idx_mask);
+  else
+    hipLaunchKernelGGL(bq_tile_kernel<false>, dim3(parts, B), dim3(kTlThreads), lds, st, query_xyz, support_xyz, query_mask,
+                       support_mask, M, N, radius, radius * radius, K, idx, idx_mask);
   return check_launch("cl3d_masked_ordered_ball_query(tile)");
 }
 
 }  // namespace cl3d
+
+#ifdef CL3D_BQ_MICRO
+// scripts/micro/bq_variants.py: this file alone as a shared library, one variant of the tunables per build
+extern "C" int cl3d_bq_micro(const float *q, const float *s, const int *qm, const int *sm, int B, int M, int N, float radius,
+                             int K, int *idx, int *idx_mask, void *stream) {
+  if (!cl3d::ball_query_tile_applicable(M, N, K)) return -1;
+  return cl3d::ball_query_tile(q, s, qm, sm, B, M, N, radius, K, idx, idx_mask, (hipStream_t)stream);
+}
+#endif

@@ -80,6 +80,16 @@ __device__ __forceinline__ float dist2(float qx, float qy, float qz, float x, fl
 #endif
 }
 
+// t / K for slot ids (t < 2^24, K <= 255) without the ~20-instruction integer division: magic = ceil(2^32 / K);
+// magic == 0 selects the plain division (anything larger)
+__device__ __forceinline__ int div_k(int t, unsigned magic, int K) {
+  return K == 1 ? t : (magic != 0u ? (int)__umulhi((unsigned)t, magic) : t / K);
+}
+inline unsigned div_magic(int K, long long max_t = 0) {
+  if (K <= 1 || K > 255 || max_t >= (1ll << 24)) return 0u;
+  return (unsigned)((0x100000000ull + (unsigned)K - 1) / (unsigned)K);
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 // number of set bits of m strictly below this lane

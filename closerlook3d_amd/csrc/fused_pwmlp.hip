@@ -74,11 +74,7 @@ __device__ __forceinline__ float pw_preact(const float w[3], float rx, float ry,
   return t + g;
 }
 
-// t / K for slot counters (t < 2^24, K <= 255) without the ~20-instruction integer division: magic = ceil(2^32 / K)
-__device__ __forceinline__ int div_k(int t, unsigned magic, int K) {
-  return K == 1 ? t : (int)__umulhi((unsigned)t, magic);
-}
-static unsigned div_magic(int K) { return K <= 1 ? 0u : (unsigned)((0x100000000ull + (unsigned)K - 1) / (unsigned)K); }
+// (div_k / div_magic: cl3d_common.h)
 
 // query-major gather passes.  Persistent blocks: tile = 4*QW*QPG queries of one cloud (every lane group walks QPG
 // queries of a tile one after the other).
@@ -689,27 +685,29 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
 // ---- the support-major pass on a SUMMARY of every support point's slot list -----------------------------------
 // Everything pwmlp_support_kernel works out per slot before it can gather -- which row of the tile a CSR position
 // belongs to (a search), the slot's query record (a 16-byte gather), the relative position, whose H row the slot
-// adds -- is a function of the geometry alone.  pwmlp_summary_kernel does that once per geometry (it depends on idx
-// and the coordinates only, so every operator of a backbone stage shares it, like the CSR inverse it is built from):
-//     rec[b, i] = {sum_s rel_s (3 floats), s0 = inv_off[i] | list length, centre-row count, centred count, -}  (32 B)
-//     ent[b, s0 ...]            the centre idx[j, 0] of every slot (j, k > 0) of the list, forward from its start
-//     ent[b, ... s0 + len - 1]  the query id j of every slot (j, 0) -- the query is centred on i itself; its
-//                               sum_k y / dz rows feed dH_i -- backward from the end of the list's range
-// and pwmlp_support_sum_kernel is left with the gathers: one H half-row per entry of the first run, two query-major
-// rows per entry of the second.
+// adds -- is a function of the geometry alone, worked out once per geometry (idx and the coordinates only, so every
+// operator of a backbone stage shares it, like the CSR inverse it is built from):
+//     ent[b, s]  per CSR position: the centre idx[j, 0] of a slot (j, k > 0) -- whose H row the slot adds -- or, for a
+//                slot (j, 0), the query id j with bit 31 set (the query is centred on the point itself; its
+//                sum_k y / dz rows feed dH_i).  Written by the CSR build's fill pass (csr.hip, round 4) or, for a table
+//                built without it, by pwmlp_summary_kernel;
+//     rec[b, i]  {sum_s rel_s (3 floats), s0 = inv_off[i] | list length, -, -, -}  (32 B)   pwmlp_summary_kernel
+// and pwmlp_support_sum_kernel is left with the gathers: one H half-row per entry, two query-major rows per flagged one.
+// (Round 3 kept the two kinds of entries apart -- centres forward from the list's start, centred queries backward from
+// its end -- which cost the summary a compaction per list; the flag bit costs the consumer one select per entry.)
 // (The centre of a query is its NEAREST support point -- the ball query orders a list by distance -- so the slots of a
 // list name as many distinct centres as it has slots: a first version that merged equal centres of a list into
-// (centre, count) pairs, by a per-wave hash table in LDS, found nothing to merge outside duplicated points and was
-// dropped for this plain form: 35.5 -> see DESIGN.md for the measured times.)
+// (centre, count) pairs, by a per-wave hash table in LDS, found nothing to merge outside duplicated points.)
 struct SumArgs {
   const int *idx;
   const float *query_xyz, *support_xyz;
   const int *inv_off, *inv_slots;
   float4 *rec;
-  unsigned *ent;
+  unsigned *ent;   // written only when write_ent (the CSR build did not leave the entries)
   int B, N, M, K;
   float inv_radius;
   unsigned kmagic;
+  int write_ent;
 };
 
 // sum over the wave by DPP (quad swaps, row mirrors, row broadcasts: ~8 cycles a step where a ds_bpermute butterfly
@@ -773,24 +771,17 @@ __global__ __launch_bounds__(256) void pwmlp_summary_kernel(SumArgs a) {
       const float *q = a.query_xyz + (size_t)b * a.M * 3;
       unsigned *ent = a.ent + (size_t)b * MK;
       float rx = 0.f, ry = 0.f, rz = 0.f;
-      int npair = 0, ncen = 0;
       for (int c0 = s0; c0 < s1; c0 += CL3D_WAVE) {
         const bool valid = c0 + lane < s1;
         if (c0 > s0) sl = valid ? slots[c0 + lane] : 0;  // (lists longer than one round: not prefetched)
         const int j = div_k(sl, a.kmagic, K);
-        const unsigned cen = (unsigned)idxb[j * K];
         const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
         // the forward pass's own expression for rel (pwmlp_query_kernel's slot record), per-lane running sums
         rx += valid ? (px - qx) * a.inv_radius : 0.f;
         ry += valid ? (py - qy) * a.inv_radius : 0.f;
         rz += valid ? (pz - qz) * a.inv_radius : 0.f;
-        const bool centred = valid && sl - j * K == 0;
-        const bool other = valid && !centred;
-        const unsigned long long om = __ballot(other), cm = __ballot(centred);
-        if (other) ent[s0 + npair + prefix_popc(om)] = cen;
-        if (centred) ent[s1 - 1 - ncen - prefix_popc(cm)] = (unsigned)j;
-        npair += __builtin_popcountll(om);
-        ncen += __builtin_popcountll(cm);
+        if (a.write_ent && valid)  // (uniform flag)
+          ent[c0 + lane] = sl - j * K == 0 ? (0x80000000u | (unsigned)j) : (unsigned)idxb[j * K];
       }
       rx = wave_sum_dpp(rx);
       ry = wave_sum_dpp(ry);
@@ -798,7 +789,7 @@ __global__ __launch_bounds__(256) void pwmlp_summary_kernel(SumArgs a) {
       if (lane == 0) {
         const size_t r = (size_t)b * N + i;
         a.rec[2 * r] = make_float4(rx, ry, rz, __int_as_float(s0));
-        a.rec[2 * r + 1] = make_float4(__int_as_float(s1 - s0), __int_as_float(npair), __int_as_float(ncen), 0.f);
+        a.rec[2 * r + 1] = make_float4(__int_as_float(s1 - s0), 0.f, 0.f, 0.f);
       }
     }
     b = bn; i = in; s0 = s0n; s1 = s1n; sl = sl_next;
@@ -808,8 +799,9 @@ __global__ __launch_bounds__(256) void pwmlp_summary_kernel(SumArgs a) {
 
 // dG_i, dH_i from the summary.  A lane group (L lanes x V channels) owns one support point of a tile of 4 * QW points;
 // persistent workgroups walk the tiles.  A point costs three dependent round trips -- the 32-byte record -> the
-// entries, one per lane of the group, handed round by shuffles -> the rows (an H half-row of ght per pair, the forward
-// pass's sum_k y row and the dz row per centred query), SB at a time -- and the first two are taken off the path: a
+// entries, one per lane of the group, handed round by shuffles -> the rows (an H half-row of ght per entry -- the
+// point's own for a flagged one, so the loop has no branch --, SB at a time; the forward pass's sum_k y row and the dz
+// row per flagged entry, the first of a round requested ahead of the round's H rows) -- and the first two are taken off the path: a
 // group holds the record of its point in the NEXT tile and requests that point's entries, and the record of the tile
 // after, before it gathers the current point's rows.  (Measured, round 3: this prefetching bought nothing -- 45.2 us
 // with, 46.0 without; the pass moves 537 MB of gathered rows and ~120 MB of streams, and 2.1 M random 256-byte row
@@ -870,12 +862,10 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
     int b, i, bn, in;
     Rec cur = fetch(tile, b, i);
     Rec nxt = fetch(tile + gridDim.x, bn, in);
-    unsigned wp = 0u, wc = 0u;
+    unsigned wp = 0u;
     {
       const int s0 = __float_as_int(cur.a.w), len = __float_as_int(cur.b.x);
-      const unsigned *e = ent + (size_t)b * MK + s0;
-      if (cl < __float_as_int(cur.b.y)) wp = e[cl];
-      if (cl < __float_as_int(cur.b.z)) wc = e[len - 1 - cl];
+      if (cl < len) wp = ent[(size_t)b * MK + s0 + cl];
     }
     for (; tile < ntiles; tile += gridDim.x) {
       const bool row_on = grp_on && i < N;
@@ -883,12 +873,10 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
       decode_tile(tile, a.B, tiles_per_cloud, tb, tr);  // workgroup-uniform (b, i belong to the lane group)
       const int i0 = tr * TR;
       // --- requests for later: the next tile's first entries, the record of the tile after it
-      unsigned wpn = 0u, wcn = 0u;
+      unsigned wpn = 0u;
       {
         const int s0 = __float_as_int(nxt.a.w), len = __float_as_int(nxt.b.x);
-        const unsigned *e = ent + (size_t)bn * MK + s0;
-        if (cl < __float_as_int(nxt.b.y)) wpn = e[cl];
-        if (cl < __float_as_int(nxt.b.z)) wcn = e[len - 1 - cl];
+        if (cl < len) wpn = ent[(size_t)bn * MK + s0 + cl];
       }
       int bnn, inn;
       const Rec nn = fetch(tile + 2 * gridDim.x, bnn, inn);
@@ -901,31 +889,49 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
           h4 = *reinterpret_cast<const float4 *>(a.hit_cm + ((size_t)tb * Co + cbase + cc) * N + i0 + qd * 4);
       }
       float shc[V], csy[V], cdz[V];
-      Vec<V> gi, hi;
+      int ncen = 0;  // queries centred on this point (flagged entries)
+      Vec<V> gi;
 #pragma unroll
-      for (int v = 0; v < V; ++v) shc[v] = csy[v] = cdz[v] = gi.v[v] = hi.v[v] = 0.f;
+      for (int v = 0; v < V; ++v) shc[v] = csy[v] = cdz[v] = gi.v[v] = 0.f;
       if (row_on) {
         const char *own = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
         gi = load_row<V>(reinterpret_cast<const float *>(own + ((unsigned)i * rowb + (unsigned)c0 * 4u)));
-        hi = load_row<V>(reinterpret_cast<const float *>(own + ((unsigned)i * rowb + ((unsigned)Co + (unsigned)c0) * 4u)));
         const int s0 = __float_as_int(cur.a.w), len = __float_as_int(cur.b.x);
-        const int npair = __float_as_int(cur.b.y), ncen = __float_as_int(cur.b.z);
         const unsigned *myent = ent + (size_t)b * MK + s0;
         // uniform bases + 32-bit lane offsets: the gathers are saddr + voffset loads (one VGPR per address)
         const char *hrows = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
         const char *syrows = reinterpret_cast<const char *>(a.sy_in + (size_t)b * M * Co);
         const char *dzrows = reinterpret_cast<const char *>(a.dz_t + (size_t)b * M * Co);
         const unsigned h_off = ((unsigned)Co + (unsigned)c0) * 4u, q_off = (unsigned)c0 * 4u;
-        for (int p0 = 0; p0 < npair; p0 += L) {
-          if (p0 > 0) wp = p0 + cl < npair ? myent[p0 + cl] : 0u;
-          const int nr = npair - p0 < L ? npair - p0 : L;
+        const unsigned own_row = (unsigned)i;
+        const unsigned long long gmask = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
+        for (int p0 = 0; p0 < len; p0 += L) {
+          if (p0 > 0) wp = p0 + cl < len ? myent[p0 + cl] : 0u;
+          const int nr = len - p0 < L ? len - p0 : L;
+          // the round's flagged entries (queries centred on this point), as a bit mask over the group's lanes; the
+          // first one's two query-major rows are requested now, ahead of the round's H rows
+          unsigned long long fm = (__ballot(p0 + cl < len && (wp >> 31) != 0u) >> (g * L)) & gmask;
+          ncen += (int)__popcll(fm);
+          Vec<V> ry0, rd0;
+#pragma unroll
+          for (int v = 0; v < V; ++v) ry0.v[v] = rd0.v[v] = 0.f;
+          if (fm != 0ull) {  // (uniform within the lane group)
+            const int l = __ffsll((long long)fm) - 1;
+            fm &= fm - 1ull;
+            const unsigned o = ((unsigned)__shfl((int)wp, g * L + l, CL3D_WAVE) & 0x7fffffffu) * ((unsigned)Co * 4u) + q_off;
+            ry0 = load_row<V>(reinterpret_cast<const float *>(syrows + o));
+            rd0 = load_row<V>(reinterpret_cast<const float *>(dzrows + o));
+          }
           for (int u0 = 0; u0 < nr; u0 += SB) {
             unsigned en[SB];
             Vec<V> rr[SB];
 #pragma unroll
             for (int u = 0; u < SB; ++u) en[u] = (unsigned)__shfl((int)wp, g * L + (u0 + u < nr ? u0 + u : nr - 1), CL3D_WAVE);
 #pragma unroll
-            for (int u = 0; u < SB; ++u) rr[u] = load_row<V>(reinterpret_cast<const float *>(hrows + (en[u] * rowb + h_off)));
+            for (int u = 0; u < SB; ++u) {
+              const unsigned r_ = (en[u] >> 31) != 0u ? own_row : en[u];  // a centred query's centre is this very point
+              rr[u] = load_row<V>(reinterpret_cast<const float *>(hrows + (r_ * rowb + h_off)));
+            }
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
               if (u0 + u >= nr) continue;
@@ -933,30 +939,21 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
               for (int v = 0; v < V; ++v) shc[v] += rr[u].v[v];
             }
           }
-        }
-        for (int p0 = 0; p0 < ncen; p0 += L) {
-          if (p0 > 0) wc = p0 + cl < ncen ? myent[len - 1 - p0 - cl] : 0u;
-          const int nr = ncen - p0 < L ? ncen - p0 : L;
-          constexpr int SC = SB / 2;
-          for (int u0 = 0; u0 < nr; u0 += SC) {
-            unsigned en[SC];
-            Vec<V> ry[SC], rd[SC];
 #pragma unroll
-            for (int u = 0; u < SC; ++u) en[u] = (unsigned)__shfl((int)wc, g * L + (u0 + u < nr ? u0 + u : nr - 1), CL3D_WAVE);
+          for (int v = 0; v < V; ++v) {
+            csy[v] += ry0.v[v];
+            cdz[v] += rd0.v[v];
+          }
+          while (fm != 0ull) {  // further centred queries of the round (duplicated points): one at a time
+            const int l = __ffsll((long long)fm) - 1;
+            fm &= fm - 1ull;
+            const unsigned o = ((unsigned)__shfl((int)wp, g * L + l, CL3D_WAVE) & 0x7fffffffu) * ((unsigned)Co * 4u) + q_off;
+            const Vec<V> ry = load_row<V>(reinterpret_cast<const float *>(syrows + o));
+            const Vec<V> rd = load_row<V>(reinterpret_cast<const float *>(dzrows + o));
 #pragma unroll
-            for (int u = 0; u < SC; ++u) {
-              const unsigned o = en[u] * ((unsigned)Co * 4u) + q_off;
-              ry[u] = load_row<V>(reinterpret_cast<const float *>(syrows + o));
-              rd[u] = load_row<V>(reinterpret_cast<const float *>(dzrows + o));
-            }
-#pragma unroll
-            for (int u = 0; u < SC; ++u) {
-              if (u0 + u >= nr) continue;
-#pragma unroll
-              for (int v = 0; v < V; ++v) {
-                csy[v] += ry[u].v[v];
-                cdz[v] += rd[u].v[v];
-              }
+            for (int v = 0; v < V; ++v) {
+              csy[v] += ry.v[v];
+              cdz[v] += rd.v[v];
             }
           }
         }
@@ -976,7 +973,7 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
       }
       __syncthreads();
       if (row_on && chan_on) {
-        const float cnt = (float)__float_as_int(cur.b.x), fcen = (float)__float_as_int(cur.b.z);
+        const float cnt = (float)__float_as_int(cur.b.x), fcen = (float)ncen;
         float *dst = a.dght + ((size_t)b * N + i) * row + c0;
         Vec<V> dg, dh;
 #pragma unroll
@@ -987,15 +984,14 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
           t = __builtin_fmaf(s_con[1][cc], cur.a.y, t);
           t = __builtin_fmaf(s_con[2][cc], cur.a.z, t);
           const float cA = s_con[3][cc], cB = s_con[4][cc], cD = s_con[5][cc];
-          const float hsum = __builtin_fmaf(fcen, hi.v[v], shc[v]);  // the centred queries' centre is this very point
-          const float ysum = (t + hsum) + cnt * gi.v[v];
+          const float ysum = (t + shc[v]) + cnt * gi.v[v];  // (shc holds this point's own H row once per centred query)
           dg.v[v] = __builtin_fmaf(cD, ysum, __builtin_fmaf(cA, hit, cnt * cB));
           dh.v[v] = __builtin_fmaf(cD, csy[v], __builtin_fmaf(cA, cdz[v], fcen * ((float)K * cB)));
         }
         store_row<V>(dst, dg);
         store_row<V>(dst + Co, dh);
       }
-      cur = nxt; b = bn; i = in; wp = wpn; wc = wcn;
+      cur = nxt; b = bn; i = in; wp = wpn;
       nxt = nn; bn = bnn; in = inn;
     }
   }
@@ -1672,7 +1668,8 @@ extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const f
 
 extern "C" int cl3d_pwmlp_support_summary(const int32_t *idx, const float *query_xyz, const float *support_xyz,
                                           const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K,
-                                          float radius, float *rec, uint32_t *ent, cl3d_stream_t stream) {
+                                          float radius, float *rec, uint32_t *ent, int entries_ready,
+                                          cl3d_stream_t stream) {
   using namespace cl3d;
   CL3D_REQUIRE(B >= 0 && N >= 1 && M >= 1 && K >= 1, "pwmlp_support_summary: bad sizes");
   CL3D_REQUIRE((long long)M * K <= 0x7fffffffLL, "pwmlp_support_summary: M*K too large");
@@ -1682,7 +1679,8 @@ extern "C" int cl3d_pwmlp_support_summary(const int32_t *idx, const float *query
   SumArgs a{};
   a.idx = idx; a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.inv_off = inv_off; a.inv_slots = inv_slots;
   a.rec = reinterpret_cast<float4 *>(rec); a.ent = ent;
-  a.B = B; a.N = N; a.M = M; a.K = K; a.inv_radius = 1.0f / radius; a.kmagic = div_magic(K);
+  a.B = B; a.N = N; a.M = M; a.K = K; a.inv_radius = 1.0f / radius; a.kmagic = div_magic(K, (long long)M * K);
+  a.write_ent = entries_ready ? 0 : 1;
   CL3D_REQUIRE((long long)B * ((N + 3) / 4) <= 0x7fffffffLL, "pwmlp_support_summary: B*N too large");
   // grid: the kernel runs on a side stream beside the critical path's short kernels (per-channel finalize, APPLY): at
   // 2048 workgroups (every wave slot of the chip) a 64-workgroup kernel launched right behind it waited 23 us for slots

@@ -16,8 +16,43 @@ independent units and the only exchange is the parameter-gradient mean.  Here:
   * `allreduce_gradients`          one-shot flat all-reduce for small parameter sets.
 BatchNorm statistics stay per-rank, as in the reference.
 """
+import os
+import socket
+import sys
+
 import torch
 import torch.distributed as dist
+
+
+def torchrun_command(script, argv, nproc, port=None, python=None):
+    """The command line that runs `script argv...` as `nproc` ranks of ONE node, one process per GPU -- the launch the
+    reference documents for its trainers (`python -m torch.distributed.launch --nproc_per_node N`,
+    pytorch/README.md:70-76, function/train_modelnet_dist.py:117-125) in its present-day spelling, and exactly what
+    scripts/scale.sh and the round driver type by hand.  127.0.0.1 on purpose: a container's hostname may not resolve."""
+    if port is None:
+        with socket.socket() as s:  # a free port now; torchrun binds it a moment later (single node: good enough)
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), script] + list(argv)
+
+
+def self_launch(script, argv, nproc, visible_devices=None):
+    """`python bench.py --gpus N` typed into a bare shell (no WORLD_SIZE in the environment): replace this process by
+    the N-rank launch of the same command.  With fewer than N devices visible (a 1-GPU box) every rank is put on
+    device 0 over gloo -- CL3D_BENCH_ONE_DEVICE=1, a stand-in that exercises the N > 1 code path and says so in its
+    JSON line (`backend`, `device`, `one_device_standin`); it is not a scaling measurement.  Never returns."""
+    if visible_devices is None:
+        visible_devices = torch.cuda.device_count()
+    env = dict(os.environ)
+    if visible_devices < nproc:
+        env["CL3D_BENCH_ONE_DEVICE"] = "1"
+        print(f"{os.path.basename(script)}: {nproc} ranks asked for, {visible_devices} device(s) visible -- all ranks on "
+              f"device 0 over gloo (stand-in for the code path, not a scaling run)", file=sys.stderr, flush=True)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    cmd = torchrun_command(script, argv, nproc)
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
 
 
 def shard_range(n, rank, world):

@@ -103,25 +103,33 @@ def _gemm_scratch(op, B, N, Co, C, device):
     return torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=device), nbytes
 
 
-def _build_inverse(idx, n_support):
+def _build_inverse(idx, n_support, entries=False):
     B = idx.shape[0]
     MK = idx[0].numel()
     off = torch.empty((B, n_support + 1), dtype=torch.int32, device=idx.device)
     slots = torch.empty((B, MK), dtype=torch.int32, device=idx.device)
+    ent = torch.empty((B, MK), dtype=torch.int32, device=idx.device) if entries else None
     lib = _lib.lib()
     ws_bytes = lib.cl3d_workspace_bytes(11, B, n_support, MK, 1, 0)  # CL3D_OP_INVERSE_INDEX
     ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=idx.device)
     with _lib.on_device(idx.device):
-        _lib.check(lib.cl3d_build_inverse_index(_p(idx), B, n_support, MK, _p(off), _p(slots), _p(ws), ws_bytes,
-                                                _stream(idx)))
-    return off, slots
+        if entries:
+            _, M, K = idx.shape
+            _lib.check(lib.cl3d_build_inverse_index_entries(_p(idx), B, n_support, M, K, _p(off), _p(slots), _p(ent), _p(ws),
+                                                            ws_bytes, _stream(idx)))
+        else:
+            _lib.check(lib.cl3d_build_inverse_index(_p(idx), B, n_support, MK, _p(off), _p(slots), _p(ws), ws_bytes,
+                                                    _stream(idx)))
+    return off, slots, ent
 
 
-def inverse_index(idx, n_support, prefetch=False):
+def inverse_index(idx, n_support, prefetch=False, entries=False):
     """CSR inverse of idx [B,M,K] (or [B,M]) -> (off [B,N+1], slots [B,MK]); memoised on the tensor.
 
     prefetch=True (forward pass, when a backward will follow): start the build on the index stream right
-    behind the ball query and return nothing; the later call waits for it."""
+    behind the ball query and return nothing; the later call waits for it.
+    entries=True (the PointWiseMLP, idx [B,M,K]): the build's fill pass also leaves the per-position entries of the
+    support-major backward (csrc/csr.hip); `inverse_entries(idx)` returns them."""
     cached = getattr(idx, '_cl3d_inverse', None)
     if cached is not None and cached[0] == n_support:
         if not prefetch and cached[3] is not None:
@@ -134,19 +142,27 @@ def inverse_index(idx, n_support, prefetch=False):
             wait_ready(idx)  # the ball query ran on this stream already; this covers a cached idx too
             if not torch.cuda.is_current_stream_capturing():
                 idx.record_stream(side)  # read here: the allocator must not recycle it before this stream is done
-            off, slots = _build_inverse(idx, n_support)
+            off, slots, ent = _build_inverse(idx, n_support, entries)
             ev = torch.cuda.Event()
             ev.record(side)
         if not torch.cuda.is_current_stream_capturing():
             off.record_stream(main)
             slots.record_stream(main)
+            if ent is not None:
+                ent.record_stream(main)
     elif prefetch:
         return None
     else:
         wait_ready(idx)
-        off, slots = _build_inverse(idx, n_support)
-    idx._cl3d_inverse = (n_support, off, slots, ev)
+        off, slots, ent = _build_inverse(idx, n_support, entries)
+    idx._cl3d_inverse = (n_support, off, slots, ev, ent)
     return off, slots
+
+
+def inverse_entries(idx):
+    """The entries the CSR build left beside the slot table (None: built without them)."""
+    cached = getattr(idx, '_cl3d_inverse', None)
+    return cached[4] if cached is not None else None
 
 
 def _join_inverse(idx):
@@ -157,10 +173,11 @@ def _join_inverse(idx):
     cached = getattr(idx, '_cl3d_inverse', None)
     if cached is not None and cached[3] is not None:
         torch.cuda.current_stream(idx.device).wait_event(cached[3])
-        idx._cl3d_inverse = cached[:3] + (None,)
+        idx._cl3d_inverse = cached[:3] + (None,) + cached[4:]
 
 
-_WHOLE_STEP = [os.environ.get('CL3D_WHOLE_STEP_CAPTURE', '0') == '1']
+_WHOLE_STEP = [False]
+_PENDING = []  # idx tensors whose summary a captured forward left on the index stream for its backward to join
 
 
 @contextlib.contextmanager
@@ -170,14 +187,29 @@ def whole_step_capture(on=True):
     then leave the geometry work it forked for its backward (CSR build + summary, on the index stream) to be joined by
     that backward, inside the same capture.  Without the declaration a captured forward pass ends fully joined, as
     hipStreamEndCapture demands of a capture that stops there (torch.cuda.make_graphed_callables captures forward and
-    backward separately), and the backward walks the CSR slot lists instead of the summary (_use_summary): 0.344-0.346
-    against 0.335 ms on the replayed step.  Eager launches never need it."""
+    backward separately), and the backward walks the CSR slot lists instead of the summary (the choice is made once, in
+    the forward pass, and travels on the autograd node): 0.344-0.346 against 0.335 ms on the replayed step.  Eager
+    launches never need it.  A declared capture whose backward did NOT run inside it is reported here by name instead
+    of as a bare hipErrorStreamCaptureUnjoined."""
     old = _WHOLE_STEP[0]
     _WHOLE_STEP[0] = bool(on)
+    del _PENDING[:]
     try:
         yield
+    except Exception as e:
+        if _PENDING:
+            raise RuntimeError(
+                f"whole_step_capture(): {len(_PENDING)} PointWiseMLP forward pass(es) left their support summary on the "
+                "index stream, but no backward pass joined it inside the capture -- capture forward AND backward "
+                "together, or drop the declaration") from e
+        raise
     finally:
         _WHOLE_STEP[0] = old
+        left = len(_PENDING)
+        del _PENDING[:]
+    if left:
+        raise RuntimeError(f"whole_step_capture(): {left} PointWiseMLP forward pass(es) were captured without their "
+                           "backward pass; the captured graph ends with unjoined work")
 
 
 def _join_geometry(idx):
@@ -190,7 +222,10 @@ def _join_geometry(idx):
     summary -- everything forked is joined here."""
     pending = getattr(idx, '_cl3d_summary', None)
     if pending is not None and pending[3] is not None:
-        if _WHOLE_STEP[0] or not torch.cuda.is_current_stream_capturing():
+        capturing = torch.cuda.is_current_stream_capturing()
+        if _WHOLE_STEP[0] or not capturing:
+            if capturing and not any(t is idx for t in _PENDING):
+                _PENDING.append(idx)
             return
         torch.cuda.current_stream(idx.device).wait_event(pending[3])  # (behind the CSR build on the same stream)
         idx._cl3d_summary = pending[:3] + (None,)
@@ -228,22 +263,27 @@ def support_summary(idx, n_support, query_xyz, support_xyz, radius, prefetch=Fal
         if not prefetch and cached[3] is not None:
             torch.cuda.current_stream(idx.device).wait_event(cached[3])
             idx._cl3d_summary = cached[:3] + (None,)
+            _PENDING[:] = [t for t in _PENDING if t is not idx]
         return cached[1], cached[2]
     B, M, K = idx.shape
     lib = _lib.lib()
 
     def build(off, slots):
         rec = torch.empty((B, n_support, 8), dtype=torch.float32, device=idx.device)
-        ent = torch.empty((B, M * K), dtype=torch.int32, device=idx.device)
+        ent = inverse_entries(idx)  # left by the CSR build's fill pass; a table built without them: written here
+        ready = ent is not None
+        if not ready:
+            ent = torch.empty((B, M * K), dtype=torch.int32, device=idx.device)
         with _lib.on_device(idx.device):
             _lib.check(lib.cl3d_pwmlp_support_summary(_p(idx), _p(query_xyz), _p(support_xyz), _p(off), _p(slots), B,
-                                                      n_support, M, K, float(radius), _p(rec), _p(ent), _stream(idx)))
+                                                      n_support, M, K, float(radius), _p(rec), _p(ent), int(ready),
+                                                      _stream(idx)))
         return rec, ent
 
     ev = None
     if prefetch and pt_utils.async_index():
         main, side = torch.cuda.current_stream(idx.device), pt_utils.index_stream(idx.device, 1)
-        off, slots = inverse_index(idx, n_support, prefetch=True)  # queued on `side` (or already there)
+        off, slots = inverse_index(idx, n_support, prefetch=True, entries=True)  # queued on `side` (or already there)
         with torch.cuda.stream(side):
             # behind the CSR build on the same stream, which waited for the ball query, which waited for the
             # coordinates: nothing to wait for (and no wait on the stream's own event: a self-wait inside a capture
@@ -257,7 +297,7 @@ def support_summary(idx, n_support, query_xyz, support_xyz, radius, prefetch=Fal
             query_xyz.record_stream(side)
             support_xyz.record_stream(side)
     else:  # (a prefetch without a side stream builds here and now: the backward pass looks for the finished summary)
-        rec, ent = build(*inverse_index(idx, n_support))
+        rec, ent = build(*inverse_index(idx, n_support, entries=True))
     idx._cl3d_summary = (key, rec, ent, ev)
     return rec, ent
 
@@ -350,13 +390,14 @@ def _wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad=False):
+def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad=False, entries=False):
     """Ball query (and, when a backward will follow, the CSR inverse) on the index stream; the fused
-    Functions wait_ready() the result right before their first kernel that reads it."""
+    Functions wait_ready() the result right before their first kernel that reads it.  entries: the PointWiseMLP's
+    backward will read the table through its summary (inverse_index)."""
     idx, idx_mask = _ball_query(query_xyz.contiguous(), support_xyz.contiguous(), query_mask.contiguous(),
                                 support_mask.contiguous(), radius, nsample, defer=True)
     if need_grad:
-        inverse_index(idx, support_xyz.shape[1], prefetch=True)
+        inverse_index(idx, support_xyz.shape[1], prefetch=True, entries=entries)
     return idx, idx_mask
 
 
@@ -582,6 +623,9 @@ class _PointwiseMLP(Function):
                     ctx.radius = float(radius)
                     ctx.idx = idx
                     ctx.meta = (B, N, M, K, Co, nparts)
+                    # decided once, here: a summary was queued for this geometry (pointwise_mlp / pointwise_bottleneck
+                    # under _use_summary()) -> the backward reads it; otherwise it walks the CSR slot lists
+                    ctx.use_summary = getattr(idx, '_cl3d_summary', None) is not None
                 ctx.rows_out = bool(rows_out)
                 if rows_out:
                     _join_geometry(idx)
@@ -617,7 +661,7 @@ class _PointwiseMLP(Function):
             # for the support-major pass: dz again as point-major rows, and (slot walk only) one 16-byte record per
             # query {coordinates, centre idx[j, 0]} (a slot of that pass then costs one L2 request instead of three)
             dz_t = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
-            use_summary = _use_summary()
+            use_summary = ctx.use_summary
             qtab = None if use_summary else torch.empty((B, M, 4), dtype=torch.float32, device=dev)
             _lib.check(lib.cl3d_pwmlp_bwd_rows(_p(gout), gout_cm, _p(ystar), _p(kstar), _p(idx), _p(query_xyz), _p(support_xyz),
                                                ctx.radius, _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), B, N, M, K, Co,
@@ -919,7 +963,7 @@ def pointwise_bottleneck(conv1, la, conv2, shortcut, query_xyz, support_xyz, que
     prec = PRECISIONS[precision]
     params = (c1.weight, bn1.weight, bn1.bias, mconv.weight, mbn.weight, mbn.bias, c2.weight, bn2.weight, bn2.bias)
     need_grad = _wants_grad(features, identity, *params)
-    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, la.radius, la.nsample, need_grad)
+    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, la.radius, la.nsample, need_grad, _use_summary())
     if need_grad and _use_summary():
         support_summary(idx, support_xyz.shape[1], query_xyz, support_xyz, la.radius, prefetch=True)
     y1 = _Conv1x1.apply(features, c1.weight.view(C1, -1), prec)
@@ -947,7 +991,7 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     conv, bn = mlps.conv0[0], mlps.conv0[1]
     need_grad = training and _wants_grad(features, conv.weight, bn.weight, bn.bias)
-    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad)
+    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad, _use_summary())
     if need_grad and _use_summary():
         support_summary(idx, support_xyz.shape[1], query_xyz, support_xyz, radius, prefetch=True)
     C = features.shape[1]

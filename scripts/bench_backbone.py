@@ -63,8 +63,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus N>1 must be launched through torch.distributed.run (one process per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # bare shell: become the N-rank launch of this command
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from closerlook3d_amd.dp import self_launch
+        self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU")
     one_dev = os.environ.get("CL3D_BENCH_ONE_DEVICE") == "1"
     if one_dev:
         local_rank = 0
@@ -291,6 +295,8 @@ def main():
             line["backend"] = dist.get_backend()
             line["world_size"] = dist.get_world_size()
         line["device"] = f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"
+        if one_dev and world > 1:
+            line["one_device_standin"] = True
         if args.checksums:  # same seeds, same steps: the exchange scheme must not change a bit of either
             grads = torch.cat([p.grad.reshape(-1).double() for p in params if p.grad is not None])
             line["grad_l2"] = float(grads.norm())

@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--k", type=int, default=32)
     ap.add_argument("--mult", type=float, default=1.5)
     ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--dump", default="", help="write idx of the first call to this .npy (bit-exactness of kernel variants)")
     a = ap.parse_args()
     rng = np.random.default_rng(0)
     s = torch.from_numpy(rng.random((a.b, a.n, 3), dtype=np.float32)).cuda()
@@ -30,8 +31,10 @@ def main():
         q, qm = s, sm
     r = float((a.mult * a.k * 3 / (4 * np.pi * a.n)) ** (1 / 3))
     for _ in range(5):
-        _ext.masked_ordered_ball_query(q, s, qm, sm, r, a.k)
+        out = _ext.masked_ordered_ball_query(q, s, qm, sm, r, a.k)
     torch.cuda.synchronize()
+    if a.dump:
+        np.save(a.dump, torch.stack(out).cpu().numpy())
     ts = []
     for _ in range(a.reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

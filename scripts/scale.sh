@@ -4,7 +4,6 @@
 #   bash scripts/scale.sh [outdir]
 OUT=${1:-gpurun_out/scale}
 mkdir -p $OUT
-PORT=29600
 for n in 1 2 4 8; do
   if [ $n -eq 1 ]; then
     python bench.py --gpus 1 --no-cpu-baseline --no-kernel-roofline | tee $OUT/la_n$n.json
@@ -12,13 +11,11 @@ for n in 1 2 4 8; do
       python scripts/bench_backbone.py --config $c | tail -1 | tee $OUT/${c}_n$n.json
     done
   else
-    PORT=$((PORT + 1))
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $PORT \
-      bench.py --gpus $n --no-cpu-baseline --no-kernel-roofline | grep '^{' | tee $OUT/la_n$n.json
+    # (both scripts re-launch themselves as N ranks when WORLD_SIZE is unset: closerlook3d_amd.dp.torchrun_command,
+    #  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P <script> ...`)
+    python bench.py --gpus $n --no-cpu-baseline --no-kernel-roofline | grep '^{' | tee $OUT/la_n$n.json
     for c in partnet_adaptive s3dis_pospool_deep modelnet_pointwisemlp; do
-      PORT=$((PORT + 1))
-      python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $PORT \
-        scripts/bench_backbone.py --gpus $n --config $c | grep '^{' | tee $OUT/${c}_n$n.json
+      python scripts/bench_backbone.py --gpus $n --config $c | grep '^{' | tee $OUT/${c}_n$n.json
     done
   fi
 done

@@ -140,3 +140,53 @@ def test_gradient_mean_when_a_rank_skips_a_head(tmp_path, mode):
     for a, b, w in zip(got[0], got[1], want):
         assert torch.equal(a, b)
         assert torch.allclose(a, w / 2, atol=1e-6, rtol=1e-5)
+
+
+# ---- `python bench.py --gpus N` from a bare shell re-launches itself as N ranks
+def test_torchrun_command_is_the_documented_launch():
+    from closerlook3d_amd.dp import torchrun_command
+    cmd = torchrun_command("/x/bench.py", ["--gpus", "8", "--steps", "20"], 8, port=29500, python="python")
+    assert cmd == ["python", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+                   "127.0.0.1", "--master-port", "29500", "/x/bench.py", "--gpus", "8", "--steps", "20"]
+    # the driver's own spelling of the same launch (prompt contract) differs only in the port it picks
+    auto = torchrun_command("/x/bench.py", [], 2)
+    assert auto[:8] == [auto[0], "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1"] and 1024 <= int(auto[9]) <= 65535
+
+
+def test_self_launch_runs_the_script_as_n_ranks(tmp_path):
+    """self_launch() replaces the process by the N-rank launch: a stub script stands in for bench.py (same control
+    flow: WORLD_SIZE unset + --gpus 2 -> exec torchrun -> two ranks over gloo, each prints its rank)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = tmp_path / "stub_bench.py"
+    stub.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "if 'WORLD_SIZE' not in os.environ:\n"
+        "    from closerlook3d_amd.dp import self_launch\n"
+        "    self_launch(os.path.abspath(__file__), sys.argv[1:], 2, visible_devices=0)\n"
+        "import torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "print('rank', dist.get_rank(), 'of', dist.get_world_size(), 'one_dev', os.environ.get('CL3D_BENCH_ONE_DEVICE'),"
+        " 'args', sys.argv[1:], flush=True)\n"
+        "dist.barrier(); dist.destroy_process_group()\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(stub), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = sorted(line for line in r.stdout.splitlines() if line.startswith("rank"))
+    assert lines == ["rank 0 of 2 one_dev 1 args ['--gpus', '2']", "rank 1 of 2 one_dev 1 args ['--gpus', '2']"], r.stdout
+    assert "stand-in" in r.stderr
+
+
+def test_benches_relaunch_instead_of_exiting():
+    """bench.py and scripts/bench_backbone.py take the self-launch branch when WORLD_SIZE is unset (source check: the
+    GPU-side run of the same path is tests/test_dp_gpu.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rel in ("bench.py", os.path.join("scripts", "bench_backbone.py")):
+        src = open(os.path.join(root, rel)).read()
+        assert "self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus)" in src, rel
+        assert "must be launched through torch.distributed.run" not in src, rel
+    assert "torch.distributed.run" not in open(os.path.join(root, "scripts", "scale.sh")).read().replace(
+        "`python -m torch.distributed.run", "")

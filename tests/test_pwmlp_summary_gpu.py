@@ -2,8 +2,9 @@
 pwmlp_summary_kernel / pwmlp_support_sum_kernel; semantics: reference local_aggregation_operators.py:288-301 through
 autograd -- slot 0 of a query's neighbour list is its centre, :290).
 
-1. the summary itself against a plain numpy reading of idx: per support point the summed relative positions, the
-   centres of its k != 0 slots in CSR order and the set of queries centred on it (k == 0 slots);
+1. the summary itself against a plain numpy reading of idx: per support point the summed relative positions and, per CSR
+   position, the entry the pass reads -- the centre of a k != 0 slot's query, the flagged query id of a k == 0 slot --
+   whether the CSR build's fill pass left the entries (round 4) or the summary kernel wrote them;
 2. d ght from the summary pass against the slot-by-slot pass (cl3d_pwmlp_bwd_support) on the same inputs, through the
    C ABI -- including duplicated points (several queries centred on one point), lists longer than one 64-slot round,
    M != N, nsample not a multiple of four and a channel count that is not a multiple of four;
@@ -31,7 +32,7 @@ def _cloud(B, N, M, seed, dup=False, spread=1.0):
     return q, s.contiguous()
 
 
-def _geometry(q, s, radius, K):
+def _geometry(q, s, radius, K, entries_from_build=True):
     from closerlook3d_amd import _lib, fused
     from closerlook3d_amd import _ext
     B, M, _ = q.shape
@@ -39,7 +40,8 @@ def _geometry(q, s, radius, K):
     qm = torch.ones(B, M, dtype=torch.int32, device="cuda")
     sm = torch.ones(B, N, dtype=torch.int32, device="cuda")
     idx, _ = _ext.masked_ordered_ball_query(q, s, qm, sm, radius, K)
-    off, slots = fused.inverse_index(idx, N)
+    off, slots = fused.inverse_index(idx, N, entries=entries_from_build)
+    assert (fused.inverse_entries(idx) is not None) == entries_from_build
     rec, ent = fused.support_summary(idx, N, q, s, radius)
     torch.cuda.synchronize()
     return idx, off, slots, rec, ent
@@ -54,10 +56,11 @@ CASES = [  # B, N, M, K, radius, dup
 ]
 
 
+@pytest.mark.parametrize("from_build", [True, False])
 @pytest.mark.parametrize("B,N,M,K,radius,dup", CASES)
-def test_summary_matches_a_plain_reading_of_idx(B, N, M, K, radius, dup):
+def test_summary_matches_a_plain_reading_of_idx(B, N, M, K, radius, dup, from_build):
     q, s = _cloud(B, N, M, seed=N + K, dup=dup)
-    idx, off, slots, rec, ent = _geometry(q, s, radius, K)
+    idx, off, slots, rec, ent = _geometry(q, s, radius, K, from_build)
     idx_h, off_h = idx.cpu().numpy(), off.cpu().numpy()
     rec_h, ent_h = rec.cpu().numpy(), ent.cpu().numpy().view(np.uint32)
     rec_i = rec_h.view(np.int32)
@@ -70,14 +73,13 @@ def test_summary_matches_a_plain_reading_of_idx(B, N, M, K, radius, dup):
         for i in range(N):
             n = off_h[b, i + 1] - off_h[b, i]
             assert n == len(lists[i])
-            s0, length, npair, ncen = (int(x) for x in rec_i[b, i, 3:7])
-            assert s0 == off_h[b, i] and length == n and 0 <= npair and 0 <= ncen and npair + ncen <= n
+            s0, length = (int(x) for x in rec_i[b, i, 3:5])
+            assert s0 == off_h[b, i] and length == n
             rel = sum((s_h[b, i] - q_h[b, j]) / radius for j, _ in lists[i]) if n else np.zeros(3)
             np.testing.assert_allclose(rec_h[b, i, :3], rel, rtol=0, atol=2e-5 * max(1, n))
-            want_rows = [int(idx_h[b, j, 0]) for j, k in lists[i] if k != 0]  # CSR order = slot order = (j, k) order
-            want_cen = [j for j, k in lists[i] if k == 0]
-            assert [int(e) for e in ent_h[b, s0: s0 + npair]] == want_rows, (b, i)
-            assert [int(e) for e in ent_h[b, s0 + n - ncen: s0 + n]][::-1] == want_cen, (b, i)
+            # CSR order = slot order = (j, k) order: the centre of a k != 0 slot's query, the flagged id of a k == 0 slot
+            want = [(0x80000000 | j) if k == 0 else int(idx_h[b, j, 0]) for j, k in lists[i]]
+            assert [int(e) for e in ent_h[b, s0: s0 + n]] == want, (b, i)
 
 
 @pytest.mark.parametrize("Co", [64, 36, 10, 72, 144, 256])
