@@ -166,8 +166,6 @@ ENTRY_KERNELS = {
     "cl3d_pwmlp_bwd_hits": ["pwmlp_hit_kernel"],
     "cl3d_pwmlp_bn_backward_coeffs": ["pwmlp_finalize_kernel<1"],
     "cl3d_pwmlp_bwd_support": ["pwmlp_support_kernel"],
-    "cl3d_pwmlp_support_summary": ["pwmlp_summary_kernel"],
-    "cl3d_pwmlp_bwd_support_sum": ["pwmlp_support_sum_kernel"],
     "cl3d_fused_reduce_fwd": ["fused_reduce_fwd_kernel"],
     "cl3d_fused_reduce_bwd": ["fused_reduce_bwd_kernel", "pg_dkw_kernel"],
     "cl3d_transpose": ["transpose_kernel", "transpose4_kernel"],
@@ -204,12 +202,8 @@ def step_model_bytes(B, N, M, K, C, kind="pointwisemlp"):
         "cl3d_pwmlp_apply": (B * 2 * rows_q, 0, "hbm"),
         "cl3d_pwmlp_bwd_rows": (B * (4 * rows_q + M * Co + 4 * MK + xyzm), 0, "hbm"),
         "cl3d_pwmlp_bwd_hits": (B * (2 * rows_q + f * Co * N), 0, "lds-atomics"),
-        # support-major pass: one H row per slot through the CSR + per-slot record
-        "cl3d_pwmlp_bwd_support": (B * (f * N * 2 * Co * 2 + f * Co * N + 2 * rows_q + 4 * MK + 4 * MK + 4 * N + xyzm), B * MK * f * Co, "l2-gather+latency"),
-        # the geometry summary of the CSR lists (once per geometry) and the support-major pass on it: one row per ENTRY
-        # (distinct centre of a list, ~K/4 at the metric shape); the data-dependent entry words are left out of both
-        "cl3d_pwmlp_support_summary": (B * (4 * MK + 4 * N + 4 * M + xyzm + 16 * N), 0, "latency"),
-        "cl3d_pwmlp_bwd_support_sum": (B * (f * N * 2 * Co * 2 + f * Co * N + 2 * rows_q + 4 * N + 16 * N), 0, "hbm+latency"),
+        # support-major pass: one H row per slot through the CSR (slot ids, row bounds, the per-query table of bwd_rows)
+        "cl3d_pwmlp_bwd_support": (B * (f * N * 2 * Co * 2 + f * Co * N + 2 * rows_q + 4 * MK + 4 * N + 16 * M + 12 * N), B * MK * f * Co, "l2-gather+latency"),
         # PosPool / AdaptiveWeight / PseudoGrid: one feature row per slot each way
         "cl3d_fused_reduce_fwd": (B * (f * C * N + xyzm + 8 * MK + f * C * M + 16 * MK + pg * 32 * MK), B * MK * f * C, "l2-gather+latency"),
         "cl3d_fused_reduce_bwd": (B * (3 * f * C * N + f * C * M + 16 * MK + 8 * MK + pg * 64 * MK), B * MK * f * C, "l2-gather+latency"),

@@ -30,8 +30,6 @@ SIGNATURES = {
     "cl3d_masked_nearest_query": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "cl3d_group_xyz_features": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P],
     "cl3d_build_inverse_index": [_P, _I, _I, _I, _P, _P, _P, _Z, _P],
-    "cl3d_build_inverse_index_entries": [_P, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P],
-    "cl3d_inverse_index_entries": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "cl3d_fused_reduce_fwd": [_I, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P, _P, _I, _F, _I, _P, _I, _P, _P, _P],
     "cl3d_fused_param_partials": [_I, _I, _I, _I],
     "cl3d_fused_param_reduce": [_I, _P, _I, _I, _I, _P, _P, _P],
@@ -72,8 +70,6 @@ SIGNATURES = {
     "cl3d_pwmlp_bwd_hits": [_P, _P, _I, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_bn_backward_coeffs": [_P, _I, _I, ctypes.c_double] + [_P] * 11,
     "cl3d_pwmlp_bwd_support": [_P] * 10 + [_F, _P, _P] + [_I] * 5 + [_P, _P],
-    "cl3d_pwmlp_support_summary": [_P] * 5 + [_I] * 4 + [_F, _P, _P, _I, _P],
-    "cl3d_pwmlp_bwd_support_sum": [_P] * 10 + [_I] * 5 + [_P, _P],
 }
 
 

@@ -25,8 +25,6 @@
 // slot) pairs (rocPRIM, a generic primitive like the library GEMM) + a binary search per row.
 // History (metric shape, 2.1 M slots, per build): global integer atomics + per-segment rank sort 270 us;
 // row-ownership scans 230-350 us; radix sort 113 us; wave-private counting sort: see DESIGN.md.
-#include <cstring>
-
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "cl3d_common.h"
@@ -62,21 +60,6 @@ __global__ __launch_bounds__(256) void csr_offsets_kernel(const unsigned *__rest
   }
 }
 
-// entries (see csr_count_fill_kernel) from a finished slot table: the large-N path, and callers that ask for the entries
-// of a table built without them
-__global__ __launch_bounds__(256) void csr_entries_kernel(const int *__restrict__ idx, const int *__restrict__ inv_off,
-                                                          const int *__restrict__ inv_slots, int N, int MK, int K,
-                                                          unsigned kmagic, long long total, unsigned *__restrict__ ent) {
-  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
-    const int b = (int)(t / MK);
-    const int e = (int)(t - (long long)b * MK);
-    if (e >= inv_off[(size_t)b * (N + 1) + N]) continue;  // past the cloud's valid slots
-    const int p = inv_slots[t];
-    const int j = div_k(p, kmagic, K);
-    ent[t] = p - j * K == 0 ? (0x80000000u | (unsigned)j) : (unsigned)idx[(size_t)b * MK + (size_t)j * K];
-  }
-}
-
 // ---- counting sort with wave-private LDS counters -------------------------------------------------
 constexpr int kCsrBatch = 8;  // slot loads in flight per lane
 
@@ -109,17 +92,10 @@ static bool csr_plan(int B, int N, int MK, CsrPlan *p) {
 // so with B a multiple of 8 every workgroup of a cloud runs on ONE XCD and the 4-byte scatter stores of the fill pass
 // (64 random rows per wave instruction) merge into whole lines in that XCD's L2 before they leave it -- with the
 // clouds spread over all XCDs the same stores left as partial lines (measured WRITE_SIZE 65 MB for a 4 MB table).
-// ENT (FILL only): next to every slot id the fill pass also leaves the ENTRY the PointWiseMLP's support-major backward
-// reads instead (cl3d_pwmlp_bwd_support_sum): for a slot (j, k > 0) the centre idx[j, 0] of its query -- whose H row the
-// slot adds --, for a slot (j, 0) the query id j with bit 31 set (the query is centred on this very point; its per-query
-// rows feed d H).  A wave walks its slots in order, so j and k are p / K and p % K and the centre is a load from the
-// lines the batch has just pulled in; round 3 derived the same table in a pass of its own with 2.1 M random look-ups
-// into idx (pwmlp_summary_kernel: 42 us beside the step's critical path).
-template <bool FILL, bool ENT = false>
+template <bool FILL>
 __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restrict__ idx, int B, int N, int MK, int GB, int per,
                                                              int *__restrict__ table, const int *__restrict__ inv_off,
-                                                             int *__restrict__ inv_slots, int K = 1, unsigned kmagic = 0u,
-                                                             unsigned *__restrict__ ent_out = nullptr) {
+                                                             int *__restrict__ inv_slots) {
   extern __shared__ int lds_cnt[];
   const int lane = lane_id();
   const int wpb = blockDim.x >> 6;
@@ -167,28 +143,17 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restri
     }
     __syncthreads();
     int *dst = inv_slots + (size_t)b * MK;
-    unsigned *ent = ENT ? ent_out + (size_t)b * MK : nullptr;
     for (int s = s0; s < s1; s += CL3D_WAVE * kCsrBatch) {
       int key[kCsrBatch];
-      unsigned en[kCsrBatch];
 #pragma unroll
       for (int u = 0; u < kCsrBatch; ++u) {
         const int p = s + u * CL3D_WAVE + lane;
-        const int pc = p < s1 ? p : s1 - 1;
-        key[u] = src[pc];
-        if constexpr (ENT) {
-          const int j = div_k(pc, kmagic, K);
-          en[u] = pc - j * K == 0 ? (0x80000000u | (unsigned)j) : (unsigned)src[j * K];
-        }
+        key[u] = src[p < s1 ? p : s1 - 1];
       }
 #pragma unroll
       for (int u = 0; u < kCsrBatch; ++u) {  // batches in slot order, lanes in slot order inside a batch
         const int p = s + u * CL3D_WAVE + lane;
-        if (p < s1 && (unsigned)key[u] < (unsigned)N) {
-          const int pos = atomicAdd(&h[key[u]], 1);
-          dst[pos] = p;
-          if constexpr (ENT) ent[pos] = en[u];
-        }
+        if (p < s1 && (unsigned)key[u] < (unsigned)N) dst[atomicAdd(&h[key[u]], 1)] = p;
       }
     }
   }
@@ -306,13 +271,13 @@ size_t inverse_index_workspace(int B, int N, int MK) {
 
 }  // namespace cl3d
 
-static int build_inverse(const int32_t *idx, int B, int N, int MK, int K, int32_t *inv_off, int32_t *inv_slots,
-                         uint32_t *ent, void *ws, size_t ws_bytes, cl3d_stream_t stream) {
+extern "C" int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK, int32_t *inv_off,
+                                        int32_t *inv_slots, void *ws, size_t ws_bytes,
+                                        cl3d_stream_t stream) {
   CL3D_REQUIRE(B >= 0 && N >= 1 && MK >= 0, "build_inverse_index: bad sizes");
   if (B == 0) return CL3D_OK;
   CL3D_REQUIRE(idx || MK == 0, "build_inverse_index: null idx");
   CL3D_REQUIRE(inv_off && (inv_slots || MK == 0), "build_inverse_index: null output");
-  CL3D_REQUIRE(ent == nullptr || (K >= 1 && MK % K == 0), "build_inverse_index: entries need nsample (M*K slots)");
   CL3D_REQUIRE((unsigned long long)B * (unsigned long long)(N + 1) <= 0xffffffffull && (size_t)B * MK <= 0x7fffffffu,
                "build_inverse_index: problem too large for 32-bit keys");
   hipStream_t st = (hipStream_t)stream;
@@ -322,18 +287,14 @@ static int build_inverse(const int32_t *idx, int B, int N, int MK, int K, int32_
   }
   const size_t need = cl3d::inverse_index_workspace(B, N, MK);
   if (ws_bytes < need || !ws) return cl3d::fail(CL3D_E_WORKSPACE, "build_inverse_index: workspace %zu < %zu", ws_bytes, need);
-  const unsigned kmagic = cl3d::div_magic(K, MK);
   cl3d::CsrPlan plan;
   if (cl3d::csr_plan(B, N, MK, &plan)) {
     // N > 16384: one wave's counters exceed the 64 KiB a kernel gets by default
-    static std::atomic<unsigned long long> count_granted{0}, fill_granted{0}, ent_granted{0};
+    static std::atomic<unsigned long long> count_granted{0}, fill_granted{0};
     int rc_lds = cl3d::lds_opt_in(count_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<false>),
                                   128 * 1024, "build_inverse_index");
     if (rc_lds == CL3D_OK)
       rc_lds = cl3d::lds_opt_in(fill_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<true>),
-                                128 * 1024, "build_inverse_index");
-    if (rc_lds == CL3D_OK)
-      rc_lds = cl3d::lds_opt_in(ent_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<true, true>),
                                 128 * 1024, "build_inverse_index");
     if (rc_lds != CL3D_OK) return rc_lds;
     int *table = static_cast<int *>(ws);
@@ -343,12 +304,8 @@ static int build_inverse(const int32_t *idx, int B, int N, int MK, int K, int32_
                        table, (const int *)nullptr, (int *)nullptr);
     hipLaunchKernelGGL(cl3d::csr_rows_kernel, dim3(cl3d::ceil_div(N, 64), B), dim3(256), 0, st, N, GB, table, inv_off);
     hipLaunchKernelGGL(cl3d::csr_scan_kernel, dim3(B), dim3(1024), 0, st, N, inv_off);
-    if (ent != nullptr)
-      hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true, true>), grid, block, plan.lds, st, idx, B, N, MK, GB,
-                         plan.per, table, (const int *)inv_off, inv_slots, K, kmagic, ent);
-    else
-      hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per,
-                         table, (const int *)inv_off, inv_slots);
+    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per,
+                       table, (const int *)inv_off, inv_slots);
     return cl3d::check_launch("cl3d_build_inverse_index");
   }
   const size_t n = (size_t)B * MK;
@@ -369,37 +326,5 @@ static int build_inverse(const int32_t *idx, int B, int N, int MK, int K, int32_
   int gr = (int)((rows + 255) / 256);
   gr = gr > 4096 ? 4096 : gr;
   hipLaunchKernelGGL(cl3d::csr_offsets_kernel, dim3(gr), dim3(256), 0, st, keys_out, B, N, MK, inv_off);
-  if (ent != nullptr)
-    hipLaunchKernelGGL(cl3d::csr_entries_kernel, dim3(gx), dim3(256), 0, st, idx, inv_off, inv_slots, N, MK, K, kmagic,
-                       (long long)n, ent);
   return cl3d::check_launch("cl3d_build_inverse_index");
-}
-
-extern "C" int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK, int32_t *inv_off,
-                                        int32_t *inv_slots, void *ws, size_t ws_bytes,
-                                        cl3d_stream_t stream) {
-  return build_inverse(idx, B, N, MK, 1, inv_off, inv_slots, nullptr, ws, ws_bytes, stream);
-}
-
-extern "C" int cl3d_build_inverse_index_entries(const int32_t *idx, int B, int N, int M, int K, int32_t *inv_off,
-                                                int32_t *inv_slots, uint32_t *entries, void *ws, size_t ws_bytes,
-                                                cl3d_stream_t stream) {
-  CL3D_REQUIRE(M >= 0 && K >= 1 && (long long)M * K <= 0x7fffffffLL, "build_inverse_index_entries: bad sizes");
-  CL3D_REQUIRE(entries != nullptr || M == 0, "build_inverse_index_entries: null entries");
-  return build_inverse(idx, B, N, M * K, K, inv_off, inv_slots, entries, ws, ws_bytes, stream);
-}
-
-extern "C" int cl3d_inverse_index_entries(const int32_t *idx, const int32_t *inv_off, const int32_t *inv_slots, int B, int N,
-                                          int M, int K, uint32_t *entries, cl3d_stream_t stream) {
-  CL3D_REQUIRE(B >= 0 && N >= 1 && M >= 0 && K >= 1 && (long long)M * K <= 0x7fffffffLL && (size_t)B * M * K <= 0x7fffffffu,
-               "inverse_index_entries: bad sizes");
-  if (B == 0 || M == 0) return CL3D_OK;
-  CL3D_REQUIRE(idx && inv_off && inv_slots && entries, "inverse_index_entries: null pointer");
-  const int MK = M * K;
-  const long long n = (long long)B * MK;
-  int gx = (int)((n + 256 * 8 - 1) / (256 * 8));
-  gx = gx > 4096 ? 4096 : (gx < 1 ? 1 : gx);
-  hipLaunchKernelGGL(cl3d::csr_entries_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, idx, inv_off, inv_slots, N, MK, K,
-                     cl3d::div_magic(K, MK), n, entries);
-  return cl3d::check_launch("cl3d_inverse_index_entries");
 }

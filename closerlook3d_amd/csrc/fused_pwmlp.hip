@@ -510,311 +510,51 @@ __global__ __launch_bounds__(1024) void pwmlp_hit_kernel(HitArgs a) {
 // the centre's row of ght (a row gather, like the forward pass's G half); hit_i = the arg-max term from pwmlp_hit_kernel.
 // dH_i = sum over the queries centred on i (= the slots (j,0) of S_i, reference :290) of
 //        D sum_k y + K Bc + A dz  (sum_k y was left behind by the forward pass).
-// Staged like the forward kernels: the slot lists of a tile's TR consecutive points are ONE contiguous range
-// of inv_slots, so the whole block loads it (and builds the record of every slot) coalesced / fully parallel into
-// LDS records {rel, centre index (or query id | centre flag)}; the lane groups then walk their rows out of LDS and
-// the only global loads left in the loop are batches of independent H-row gathers.
-constexpr int kSupCap = 1024;  // slot records staged per round (16 KiB)
+//
+// Round 4 form (one kernel; rounds 2 / 3 had a slot-staging kernel, 74-88 us, then a per-geometry summary kernel on
+// the index stream, 42 us, in front of a gather-only pass, 48 us).  A lane group (L lanes x V channels) owns one
+// support point of a tile of 4 * QW points; persistent workgroups walk the tiles.  Per ENTRY of the point's list the
+// work is done by ONE lane of the group -- lane cl takes entries cl, cl + L, ...: the slot id from inv_slots, its query
+// j = slot / K, that query's 16-byte record {coordinates, centre idx[j, 0]} out of the table cl3d_pwmlp_bwd_rows leaves
+// (one L1-friendly gather), the relative position with the forward pass's own expression -- and only the row gathers
+// are per (entry, lane): the centre is handed round the group by shuffle and every lane reads its 16 bytes of the
+// centre's H half-row, SB rows in flight.  A slot (j, 0) -- the query is centred on this very point -- gathers the
+// point's own row (no branch in the loop) and adds the query's sum_k y / dz rows to dH_i.  The chain row bounds ->
+// slot ids -> query records is three dependent round trips; it runs one, two and three tiles AHEAD of the rows being
+// gathered (a workgroup has only a handful of tiles: unpipelined the chain was a quarter of the pass).
 constexpr unsigned kCentreFlag = 0x80000000u;
+constexpr int kSupRounds = 2;  // entries per lane whose records are fetched ahead (lists up to 2 L; the rest inline)
 
-template <int V, int SB, int WPE>  // SB = H rows in flight per lane, WPE = waves per SIMD the register budget allows
-__global__ __launch_bounds__(256, WPE) void pwmlp_support_kernel(PwArgs a) {
-  __shared__ float4 srec[kSupCap];
-  __shared__ int s_off[257];     // row starts of the tile (TR = 4 * QW <= 256 rows) and its end
-  __shared__ float4 s_pos[256];  // coordinates of the tile's rows
-  const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
-  const int row = 2 * Co;
-  const unsigned rowb = (unsigned)row * 4u;
-  const int MK = M * K;
-  const int TR = 4 * QW;
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  const int g = lane / L, cl = lane - g * L;
-  const int tiles_per_cloud = (N + TR - 1) / TR;
-  const int ntiles = a.B * tiles_per_cloud;
-  int top = 1;  // first step of the search for a slot's row among the tile's TR rows
-  while (top * 2 < TR) top *= 2;
-  for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {  // channel chunks over gridDim.y, see pwmlp_query_kernel
-    const int c0 = (ch * L + cl) * V;
-    const bool chan_on = g < QW && c0 < Co;
-    const unsigned lane_off = ((unsigned)Co + (unsigned)c0) * 4u;  // this lane's piece of the H half of a row
-    // per-channel constants are (re)loaded where they are used -- the row epilogue and the rare centre
-    // term -- instead of being held across the gather loop: the loop's occupancy is what this pass lives on
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-      int b, tr;
-      decode_tile(tile, a.B, tiles_per_cloud, b, tr);
-      const int i0 = tr * TR;
-      const int i = i0 + wave * QW + g;
-      const bool row_on = chan_on && i < N;
-      const int *off = a.inv_off + (size_t)b * (N + 1);
-      const int *slots = a.inv_slots + (size_t)b * MK;
-      const float4 *qtab = a.qtab + (size_t)b * M;                 // {query coordinates, centre idx[j, 0]}
-      const float *sxyz = a.support_xyz + (size_t)b * N * 3;
-      const char *rows = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
-      const float *syrow = a.sy_in + (size_t)b * M * Co + c0;
-      const float *dzrow = a.dz_t + (size_t)b * M * Co + c0;
-      const int e_lo = off[i0], e_hi = off[i0 + TR < N ? i0 + TR : N];
-      const int ic = i < N ? i : N - 1;
-      const int s0 = off[ic], s1 = off[ic + 1];
-      float shc[V], csy[V], cdz[V];  // sum of H rows; sum_k y and dz summed over the queries centred here
-      float r0 = 0.f, r1 = 0.f, r2 = 0.f, ncen = 0.f;
-#pragma unroll
-      for (int v = 0; v < V; ++v) shc[v] = csy[v] = cdz[v] = 0.f;
-      __syncthreads();  // the previous tile's readers are done with the row table
-      for (int t = threadIdx.x; t <= TR; t += 256) {
-        const int ii = i0 + t < N ? i0 + t : N;
-        s_off[t] = off[ii];
-        if (t < TR) {
-          const int ix = ii < N ? ii : N - 1;
-          s_pos[t] = make_float4(sxyz[ix * 3 + 0], sxyz[ix * 3 + 1], sxyz[ix * 3 + 2], 0.f);
-        }
-      }
-      for (int cbeg = e_lo; cbeg < e_hi; cbeg += kSupCap) {
-        const int cn = e_hi - cbeg < kSupCap ? e_hi - cbeg : kSupCap;
-        __syncthreads();  // the previous round's records have been consumed (and the row table is written)
-        // A slot's record {rel, tag} is rebuilt from the query table cl3d_pwmlp_bwd_rows leaves behind -- one aligned
-        // 16-byte record {coordinates, centre idx[j, 0]} per query, ONE L2 request per slot (round 2 read the centre
-        // index and the three coordinates separately: two to three requests per slot, 11.7 M per launch at the metric
-        // shape against 4.2 M for the H rows themselves) -- and the coordinates of the row the slot belongs to (found
-        // in the tile's row starts), with the forward pass's own expression for rel.
-        for (int t0 = 0; t0 < cn; t0 += 256 * 4) {
-          int sl[4];
-          float4 qt[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int t = t0 + u * 256 + (int)threadIdx.x;
-            sl[u] = slots[cbeg + (t < cn ? t : cn - 1)];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) qt[u] = qtab[div_k(sl[u], a.kmagic, K)];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int t = t0 + u * 256 + (int)threadIdx.x;
-            if (t < cn) {
-              int r = 0;  // row of the tile that owns position cbeg + t: last r with s_off[r] <= position
-              for (int step = top; step >= 1; step >>= 1)
-                if (r + step < TR && s_off[r + step] <= cbeg + t) r += step;
-              const float4 sp = s_pos[r];
-              // tag = the support index of the query's centre (whose H row this slot adds); a slot (j, 0) IS a
-              // centre reference -- its centre is this row's own point -- and carries the query id j instead, flagged
-              const int j = div_k(sl[u], a.kmagic, K);
-              const unsigned tag = sl[u] - j * K == 0 ? ((unsigned)j | kCentreFlag) : __float_as_uint(qt[u].w);
-              srec[t] = make_float4((sp.x - qt[u].x) * a.inv_radius, (sp.y - qt[u].y) * a.inv_radius,
-                                    (sp.z - qt[u].z) * a.inv_radius, __uint_as_float(tag));
-            }
-          }
-        }
-        __syncthreads();
-        if (!row_on) continue;
-        const int lo = s0 > cbeg ? s0 : cbeg;
-        const int hi = s1 < cbeg + cn ? s1 : cbeg + cn;
-        for (int e = lo; e < hi; e += SB) {
-          unsigned tags[SB];
-          Vec<V> hc[SB];
-          int jc = -1, ncb = 0;
-#pragma unroll
-          for (int u = 0; u < SB; ++u) {  // rel is summed straight out of LDS; only the query ids stay in registers
-            const float4 rr = srec[(e + u < hi ? e + u : hi - 1) - cbeg];
-            const bool live = e + u < hi;
-            r0 += live ? rr.x : 0.f;
-            r1 += live ? rr.y : 0.f;
-            r2 += live ? rr.z : 0.f;
-            tags[u] = __float_as_uint(rr.w);
-            if ((tags[u] & kCentreFlag) != 0u && live) {
-              if (jc < 0) jc = (int)(tags[u] & ~kCentreFlag);  // first centred query of the batch
-              ++ncb;
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < SB; ++u) {
-            const unsigned ri = (tags[u] & kCentreFlag) != 0u ? (unsigned)i : tags[u];
-            hc[u] = load_row<V>(reinterpret_cast<const float *>(rows + (__umul24(ri, rowb) + lane_off)));
-          }
-          if (jc >= 0) {  // about one slot per row: its loads ride along with the batch (two point-major rows)
-            const Vec<V> sy = load_row<V>(syrow + (size_t)jc * Co);
-            const Vec<V> dz = load_row<V>(dzrow + (size_t)jc * Co);
-            ncen += 1.f;
-#pragma unroll
-            for (int v = 0; v < V; ++v) {
-              csy[v] += sy.v[v];
-              cdz[v] += dz.v[v];
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < SB; ++u) {
-            if (e + u >= hi) continue;
-#pragma unroll
-            for (int v = 0; v < V; ++v) shc[v] += hc[u].v[v];
-          }
-          if (ncb > 1) {  // several queries centred on this point inside one batch (duplicate points): rare, slow path
-            int seen = 0;
-            for (int u = 0; u < SB && e + u < hi; ++u) {
-              const unsigned tag = __float_as_uint(srec[e + u - cbeg].w);
-              if ((tag & kCentreFlag) == 0u || seen++ == 0) continue;
-              const int j2 = (int)(tag & ~kCentreFlag);
-              const Vec<V> sy = load_row<V>(syrow + (size_t)j2 * Co);
-              const Vec<V> dz = load_row<V>(dzrow + (size_t)j2 * Co);
-              ncen += 1.f;
-#pragma unroll
-              for (int v = 0; v < V; ++v) {
-                csy[v] += sy.v[v];
-                cdz[v] += dz.v[v];
-              }
-            }
-          }
-        }
-      }
-      if (!row_on) continue;
-      const float cnt = (float)(s1 - s0);
-      const Vec<V> gi = load_row<V>(a.ght + ((size_t)b * N + i) * row + c0);
-      float *dst = a.dght + ((size_t)b * N + i) * row + c0;
-      _Pragma("unroll") for (int v = 0; v < V; ++v) {
-        const int c = c0 + v;
-        const float hit = a.hit_cm[((size_t)b * Co + c) * N + i];
-        float t = a.wr[c * 3 + 0] * r0;
-        t = __builtin_fmaf(a.wr[c * 3 + 1], r1, t);
-        t = __builtin_fmaf(a.wr[c * 3 + 2], r2, t);
-        const float ysum = (t + shc[v]) + cnt * gi.v[v];
-        dst[v] = __builtin_fmaf(a.v2[c], ysum, __builtin_fmaf(a.v0[c], hit, cnt * a.v1[c]));
-        dst[Co + v] = __builtin_fmaf(a.v2[c], csy[v], __builtin_fmaf(a.v0[c], cdz[v], ncen * ((float)K * a.v1[c])));
-      }
-    }
-  }
-}
-
-// ---- the support-major pass on a SUMMARY of every support point's slot list -----------------------------------
-// Everything pwmlp_support_kernel works out per slot before it can gather -- which row of the tile a CSR position
-// belongs to (a search), the slot's query record (a 16-byte gather), the relative position, whose H row the slot
-// adds -- is a function of the geometry alone, worked out once per geometry (idx and the coordinates only, so every
-// operator of a backbone stage shares it, like the CSR inverse it is built from):
-//     ent[b, s]  per CSR position: the centre idx[j, 0] of a slot (j, k > 0) -- whose H row the slot adds -- or, for a
-//                slot (j, 0), the query id j with bit 31 set (the query is centred on the point itself; its
-//                sum_k y / dz rows feed dH_i).  Written by the CSR build's fill pass (csr.hip, round 4) or, for a table
-//                built without it, by pwmlp_summary_kernel;
-//     rec[b, i]  {sum_s rel_s (3 floats), s0 = inv_off[i] | list length, -, -, -}  (32 B)   pwmlp_summary_kernel
-// and pwmlp_support_sum_kernel is left with the gathers: one H half-row per entry, two query-major rows per flagged one.
-// (Round 3 kept the two kinds of entries apart -- centres forward from the list's start, centred queries backward from
-// its end -- which cost the summary a compaction per list; the flag bit costs the consumer one select per entry.)
-// (The centre of a query is its NEAREST support point -- the ball query orders a list by distance -- so the slots of a
-// list name as many distinct centres as it has slots: a first version that merged equal centres of a list into
-// (centre, count) pairs, by a per-wave hash table in LDS, found nothing to merge outside duplicated points.)
-struct SumArgs {
-  const int *idx;
-  const float *query_xyz, *support_xyz;
-  const int *inv_off, *inv_slots;
-  float4 *rec;
-  unsigned *ent;   // written only when write_ent (the CSR build did not leave the entries)
-  int B, N, M, K;
-  float inv_radius;
-  unsigned kmagic;
-  int write_ent;
-};
-
-// sum over the wave by DPP (quad swaps, row mirrors, row broadcasts: ~8 cycles a step where a ds_bpermute butterfly
-// pays an LDS round trip per step), fixed order; the total is returned to every lane
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-#define CL3D_DPP_ADD(ctrl, rmask) \
-  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, false))
-  CL3D_DPP_ADD(0xB1, 0xf);   // quad_perm [1,0,3,2]
-  CL3D_DPP_ADD(0x4E, 0xf);   // quad_perm [2,3,0,1]
-  CL3D_DPP_ADD(0x141, 0xf);  // row_half_mirror
-  CL3D_DPP_ADD(0x140, 0xf);  // row_mirror: every lane holds its row's 16-lane sum
-  CL3D_DPP_ADD(0x142, 0xa);  // row_bcast15 into rows 1 and 3
-  CL3D_DPP_ADD(0x143, 0xc);  // row_bcast31 into rows 2 and 3: lane 63 holds the total
+// sum over the L lanes of a lane group, returned to every lane of the group.  L == 16: the groups are the DPP rows
+// (quad swaps, row mirrors: no LDS).  Other widths go through a per-wave LDS scratch.
+__device__ __forceinline__ float group_sum(float v, int L, int lane, int first /* first lane of the group, -1: none */,
+                                           float *scratch /* [64] of this wave */) {
+  if (L == 16) {
+#define CL3D_DPP_ADD(ctrl) \
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xf, 0xf, false))
+    CL3D_DPP_ADD(0xB1);   // quad_perm [1,0,3,2]
+    CL3D_DPP_ADD(0x4E);   // quad_perm [2,3,0,1]
+    CL3D_DPP_ADD(0x141);  // row_half_mirror
+    CL3D_DPP_ADD(0x140);  // row_mirror: every lane holds its row's 16-lane sum
 #undef CL3D_DPP_ADD
-  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-
-// One wave per support point, 64 slots per round; a wave walks its points with the next point's row bounds and first
-// slots already requested (the chain row bounds -> slots -> centre / coordinates would otherwise be three exposed
-// round trips per point).  Entries keep the CSR order of their slots (ballot + prefix count), so the table is a pure
-// function of the CSR table.
-__global__ __launch_bounds__(256) void pwmlp_summary_kernel(SumArgs a) {
-  const int lane = lane_id();
-  const int wave = threadIdx.x >> 6;
-  const int K = a.K, N = a.N, MK = a.M * a.K;
-  // Tiles of four support points (one per wave), walked in the XCD-aware order of the gather passes: with B a multiple
-  // of 8, XCD x works through clouds x, x + 8, ... one after the other, so a cloud's idx / slot / entry arrays (1.5 MB)
-  // are pulled into ONE L2.  (Round 3 walked the rows cloud by cloud with all eight XCDs on the same cloud: every L2
-  // fetched the whole of every cloud's idx for its eighth of the random centre look-ups -- 95.6 MB of HBM traffic per
-  // launch for 12.1 MB of algorithmic bytes.)
-  const int tiles_per_cloud = (N + 3) / 4;
-  const int ntiles = a.B * tiles_per_cloud;
-  const int stride = (int)gridDim.x;
-  int v = (int)blockIdx.x;
-  if (v >= ntiles) return;
-  auto bounds = [&](int vv, int &b, int &i, int &s0, int &s1) {  // clamped: past the end = an empty list
-    int tile;
-    decode_tile(vv < ntiles ? vv : ntiles - 1, a.B, tiles_per_cloud, b, tile);
-    i = tile * 4 + wave;
-    const bool on = vv < ntiles && i < N;
-    i = i < N ? i : N - 1;
-    const int *off = a.inv_off + (size_t)b * (N + 1);
-    s0 = off[i];
-    s1 = on ? off[i + 1] : s0;
-    if (!on) i = -1;
-  };
-  int b, i, s0, s1, bn, in, s0n, s1n;
-  bounds(v, b, i, s0, s1);
-  bounds(v + stride, bn, in, s0n, s1n);
-  int sl = s0 + lane < s1 ? a.inv_slots[(size_t)b * MK + s0 + lane] : 0;
-  for (; v < ntiles; v += stride) {
-    // requested now, used in the next iteration
-    const int sl_next = s0n + lane < s1n ? a.inv_slots[(size_t)bn * MK + s0n + lane] : 0;
-    int bnn, inn, s0nn, s1nn;
-    bounds(v + 2 * stride, bnn, inn, s0nn, s1nn);
-    if (i >= 0) {  // (wave-uniform; a tile's waves past N only keep the prefetch chain going)
-      const float *p = a.support_xyz + ((size_t)b * N + i) * 3;
-      const float px = p[0], py = p[1], pz = p[2];
-      const int *slots = a.inv_slots + (size_t)b * MK;
-      const int *idxb = a.idx + (size_t)b * MK;
-      const float *q = a.query_xyz + (size_t)b * a.M * 3;
-      unsigned *ent = a.ent + (size_t)b * MK;
-      float rx = 0.f, ry = 0.f, rz = 0.f;
-      for (int c0 = s0; c0 < s1; c0 += CL3D_WAVE) {
-        const bool valid = c0 + lane < s1;
-        if (c0 > s0) sl = valid ? slots[c0 + lane] : 0;  // (lists longer than one round: not prefetched)
-        const int j = div_k(sl, a.kmagic, K);
-        const float qx = q[j * 3 + 0], qy = q[j * 3 + 1], qz = q[j * 3 + 2];
-        // the forward pass's own expression for rel (pwmlp_query_kernel's slot record), per-lane running sums
-        rx += valid ? (px - qx) * a.inv_radius : 0.f;
-        ry += valid ? (py - qy) * a.inv_radius : 0.f;
-        rz += valid ? (pz - qz) * a.inv_radius : 0.f;
-        if (a.write_ent && valid)  // (uniform flag)
-          ent[c0 + lane] = sl - j * K == 0 ? (0x80000000u | (unsigned)j) : (unsigned)idxb[j * K];
-      }
-      rx = wave_sum_dpp(rx);
-      ry = wave_sum_dpp(ry);
-      rz = wave_sum_dpp(rz);
-      if (lane == 0) {
-        const size_t r = (size_t)b * N + i;
-        a.rec[2 * r] = make_float4(rx, ry, rz, __int_as_float(s0));
-        a.rec[2 * r + 1] = make_float4(__int_as_float(s1 - s0), 0.f, 0.f, 0.f);
-      }
-    }
-    b = bn; i = in; s0 = s0n; s1 = s1n; sl = sl_next;
-    bn = bnn; in = inn; s0n = s0nn; s1n = s1nn;
+    return v;
   }
+  scratch[lane] = v;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  float t = 0.f;
+  if (first >= 0)
+    for (int l = 0; l < L; ++l) t += scratch[first + l];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  return t;
 }
 
-// dG_i, dH_i from the summary.  A lane group (L lanes x V channels) owns one support point of a tile of 4 * QW points;
-// persistent workgroups walk the tiles.  A point costs three dependent round trips -- the 32-byte record -> the
-// entries, one per lane of the group, handed round by shuffles -> the rows (an H half-row of ght per entry -- the
-// point's own for a flagged one, so the loop has no branch --, SB at a time; the forward pass's sum_k y row and the dz
-// row per flagged entry, the first of a round requested ahead of the round's H rows) -- and the first two are taken off the path: a
-// group holds the record of its point in the NEXT tile and requests that point's entries, and the record of the tile
-// after, before it gathers the current point's rows.  (Measured, round 3: this prefetching bought nothing -- 45.2 us
-// with, 46.0 without; the pass moves 537 MB of gathered rows and ~120 MB of streams, and 2.1 M random 256-byte row
-// gathers alone take 25 us on this chip, scripts/micro/gather_pitch.hip.)
-// The arg-max term hit_cm is channel-major: the tile's [channels][points] block is fetched in 16-byte pieces along
-// the points by the whole workgroup and turned through LDS (read straight from the lanes it cost one 128-byte line
-// per (channel, lane) -- as many L2 requests as everything else in the pass together); the per-channel constants of
-// the epilogue sit in LDS too.
 template <int V, int SB>
-__global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, const float4 *__restrict__ rec,
-                                                                const unsigned *__restrict__ ent) {
+__global__ __launch_bounds__(256, 4) void pwmlp_support_kernel(PwArgs a) {
   __shared__ float s_hit[1280];   // [L * V channels][TR + 1]: L * V * (256 / L + 1) <= 4 * (256 + 64) floats
   __shared__ float s_con[6][256]; // wr (3), A, Bc, D of the chunk's L * V <= 256 channels
+  __shared__ float s_grp[4][64];  // group_sum scratch (lane groups that are not DPP rows)
   const int K = a.K, Co = a.Co, M = a.M, N = a.N, L = a.L, QW = a.QW;
   const int row = 2 * Co;
   const unsigned rowb = (unsigned)row * 4u;
@@ -826,25 +566,46 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
   const int tiles_per_cloud = (N + TR - 1) / TR;
   const int ntiles = a.B * tiles_per_cloud;
   const bool grp_on = g < QW;  // lanes past the last whole group (64 % L) only keep the barriers
-  struct Rec {
-    float4 a, b;
+  struct Pt {  // this lane group's point of a tile: cloud, row, list start and length (i == N: none)
+    int b, i, s0, len;
   };
-  // the record of this lane group's point in tile t (zeros = an empty list past the end)
-  auto fetch = [&](int t, int &b, int &i) {
-    Rec r{make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
-    b = 0;
-    i = N;
+  struct En {  // this lane's entry of a round: centre (or kCentreFlag | query id), relative position (zeros: none)
+    unsigned cen;
+    float rx, ry, rz;
+  };
+  auto fetch_point = [&](int t) {
+    Pt p{0, N, 0, 0};
     if (t < ntiles) {
       int tr;
-      decode_tile(t, a.B, tiles_per_cloud, b, tr);
-      i = tr * TR + wave * QW + g;
-      if (grp_on && i < N) {
-        const size_t p = (size_t)b * N + i;
-        r.a = rec[2 * p];
-        r.b = rec[2 * p + 1];
+      decode_tile(t, a.B, tiles_per_cloud, p.b, tr);
+      p.i = tr * TR + wave * QW + g;
+      if (grp_on && p.i < N) {
+        const int *off = a.inv_off + (size_t)p.b * (N + 1) + p.i;
+        p.s0 = off[0];
+        p.len = off[1] - p.s0;
+      } else {
+        p.i = N;
       }
     }
-    return r;
+    return p;
+  };
+  auto fetch_slot_at = [&](const Pt &p, int e) {  // slot id of the list's entry e, -1 past its end
+    return e < p.len ? a.inv_slots[(size_t)p.b * MK + p.s0 + e] : -1;
+  };
+  auto fetch_slot = [&](const Pt &p, int r) { return fetch_slot_at(p, r * L + cl); };  // this lane's entry of round r
+  auto fetch_entry = [&](const Pt &p, int slot) {
+    En e{0u, 0.f, 0.f, 0.f};
+    if (slot >= 0) {
+      const int j = div_k(slot, a.kmagic, K);
+      const float4 qt = a.qtab[(size_t)p.b * M + j];  // {query coordinates, centre idx[j, 0]}
+      const float *pp = a.support_xyz + ((size_t)p.b * N + p.i) * 3;
+      // the forward pass's own expression for rel (pwmlp_query_kernel's slot record)
+      e.rx = (pp[0] - qt.x) * a.inv_radius;
+      e.ry = (pp[1] - qt.y) * a.inv_radius;
+      e.rz = (pp[2] - qt.z) * a.inv_radius;
+      e.cen = slot - j * K == 0 ? (kCentreFlag | (unsigned)j) : (unsigned)__float_as_int(qt.w);
+    }
+    return e;
   };
   for (int ch = blockIdx.y; ch < a.chunks; ch += gridDim.y) {
     // a lane whose channels lie past Co (last chunk) still carries entries for its group: it reads channel 0's
@@ -858,28 +619,29 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
       s_con[0][t] = a.wr[c * 3 + 0]; s_con[1][t] = a.wr[c * 3 + 1]; s_con[2][t] = a.wr[c * 3 + 2];
       s_con[3][t] = a.v0[c]; s_con[4][t] = a.v1[c]; s_con[5][t] = a.v2[c];
     }
+    // ---- the look-ahead chain: point (tile + 3 G) -> slots (tile + 2 G) -> entries (tile + G) -> rows (tile)
     int tile = blockIdx.x;
-    int b, i, bn, in;
-    Rec cur = fetch(tile, b, i);
-    Rec nxt = fetch(tile + gridDim.x, bn, in);
-    unsigned wp = 0u;
-    {
-      const int s0 = __float_as_int(cur.a.w), len = __float_as_int(cur.b.x);
-      if (cl < len) wp = ent[(size_t)b * MK + s0 + cl];
-    }
-    for (; tile < ntiles; tile += gridDim.x) {
-      const bool row_on = grp_on && i < N;
+    const int G = (int)gridDim.x;
+    Pt p0 = fetch_point(tile), p1 = fetch_point(tile + G), p2 = fetch_point(tile + 2 * G);
+    int sl1[kSupRounds];
+    En e0[kSupRounds];
+#pragma unroll
+    for (int r = 0; r < kSupRounds; ++r) e0[r] = fetch_entry(p0, fetch_slot(p0, r));
+#pragma unroll
+    for (int r = 0; r < kSupRounds; ++r) sl1[r] = fetch_slot(p1, r);
+    for (; tile < ntiles; tile += G) {
+      const bool row_on = p0.i < N;
       int tb, tr;
-      decode_tile(tile, a.B, tiles_per_cloud, tb, tr);  // workgroup-uniform (b, i belong to the lane group)
+      decode_tile(tile, a.B, tiles_per_cloud, tb, tr);  // workgroup-uniform (p0 belongs to the lane group)
       const int i0 = tr * TR;
-      // --- requests for later: the next tile's first entries, the record of the tile after it
-      unsigned wpn = 0u;
-      {
-        const int s0 = __float_as_int(nxt.a.w), len = __float_as_int(nxt.b.x);
-        if (cl < len) wpn = ent[(size_t)bn * MK + s0 + cl];
-      }
-      int bnn, inn;
-      const Rec nn = fetch(tile + 2 * gridDim.x, bnn, inn);
+      // --- requests for later tiles
+      En e1[kSupRounds];
+      int sl2[kSupRounds];
+#pragma unroll
+      for (int r = 0; r < kSupRounds; ++r) e1[r] = fetch_entry(p1, sl1[r]);
+#pragma unroll
+      for (int r = 0; r < kSupRounds; ++r) sl2[r] = fetch_slot(p2, r);
+      const Pt p3 = fetch_point(tile + 3 * G);
       // --- this tile: arg-max terms (to LDS below), the point's own row
       float4 h4 = make_float4(0.f, 0.f, 0.f, 0.f);
       const bool hit_vec = (N & 3) == 0 && LV * (TR / 4) <= 256;
@@ -889,28 +651,28 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
           h4 = *reinterpret_cast<const float4 *>(a.hit_cm + ((size_t)tb * Co + cbase + cc) * N + i0 + qd * 4);
       }
       float shc[V], csy[V], cdz[V];
-      int ncen = 0;  // queries centred on this point (flagged entries)
+      float rsx = 0.f, rsy = 0.f, rsz = 0.f;  // this lane's share of sum rel
+      int ncen = 0;                            // queries centred on this point (flagged entries)
       Vec<V> gi;
 #pragma unroll
       for (int v = 0; v < V; ++v) shc[v] = csy[v] = cdz[v] = gi.v[v] = 0.f;
       if (row_on) {
-        const char *own = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
-        gi = load_row<V>(reinterpret_cast<const float *>(own + ((unsigned)i * rowb + (unsigned)c0 * 4u)));
-        const int s0 = __float_as_int(cur.a.w), len = __float_as_int(cur.b.x);
-        const unsigned *myent = ent + (size_t)b * MK + s0;
-        // uniform bases + 32-bit lane offsets: the gathers are saddr + voffset loads (one VGPR per address)
+        const int b = p0.b, i = p0.i, len = p0.len;
         const char *hrows = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
+        gi = load_row<V>(reinterpret_cast<const float *>(hrows + ((unsigned)i * rowb + (unsigned)c0 * 4u)));
+        // uniform bases + 32-bit lane offsets: the gathers are saddr + voffset loads (one VGPR per address)
         const char *syrows = reinterpret_cast<const char *>(a.sy_in + (size_t)b * M * Co);
         const char *dzrows = reinterpret_cast<const char *>(a.dz_t + (size_t)b * M * Co);
         const unsigned h_off = ((unsigned)Co + (unsigned)c0) * 4u, q_off = (unsigned)c0 * 4u;
         const unsigned own_row = (unsigned)i;
         const unsigned long long gmask = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
-        for (int p0 = 0; p0 < len; p0 += L) {
-          if (p0 > 0) wp = p0 + cl < len ? myent[p0 + cl] : 0u;
-          const int nr = len - p0 < L ? len - p0 : L;
+        auto round_of = [&](const En &en, int p) {  // entries p .. p + L - 1 of the list, one per lane of the group
+          rsx += en.rx; rsy += en.ry; rsz += en.rz;
+          const unsigned wp = en.cen;
+          const int nr = len - p < L ? len - p : L;
           // the round's flagged entries (queries centred on this point), as a bit mask over the group's lanes; the
           // first one's two query-major rows are requested now, ahead of the round's H rows
-          unsigned long long fm = (__ballot(p0 + cl < len && (wp >> 31) != 0u) >> (g * L)) & gmask;
+          unsigned long long fm = (__ballot(p + cl < len && (wp >> 31) != 0u) >> (g * L)) & gmask;
           ncen += (int)__popcll(fm);
           Vec<V> ry0, rd0;
 #pragma unroll
@@ -923,13 +685,13 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
             rd0 = load_row<V>(reinterpret_cast<const float *>(dzrows + o));
           }
           for (int u0 = 0; u0 < nr; u0 += SB) {
-            unsigned en[SB];
+            unsigned ce[SB];
             Vec<V> rr[SB];
 #pragma unroll
-            for (int u = 0; u < SB; ++u) en[u] = (unsigned)__shfl((int)wp, g * L + (u0 + u < nr ? u0 + u : nr - 1), CL3D_WAVE);
+            for (int u = 0; u < SB; ++u) ce[u] = (unsigned)__shfl((int)wp, g * L + (u0 + u < nr ? u0 + u : nr - 1), CL3D_WAVE);
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
-              const unsigned r_ = (en[u] >> 31) != 0u ? own_row : en[u];  // a centred query's centre is this very point
+              const unsigned r_ = (ce[u] >> 31) != 0u ? own_row : ce[u];  // a centred query's centre is this very point
               rr[u] = load_row<V>(reinterpret_cast<const float *>(hrows + (r_ * rowb + h_off)));
             }
 #pragma unroll
@@ -956,8 +718,21 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
               cdz[v] += rd.v[v];
             }
           }
+        };
+        int p = 0;
+#pragma unroll
+        for (int r = 0; r < kSupRounds; ++r) {  // the rounds whose records came with the look-ahead
+          if (p < len) {
+            round_of(e0[r], p);
+            p += L;
+          }
         }
+        for (; p < len; p += L) round_of(fetch_entry(p0, fetch_slot_at(p0, p + cl)), p);  // long lists: fetched in line
       }
+      // sum rel over the group's lanes (every lane of the wave takes part; lanes without a row carry zeros)
+      rsx = group_sum(rsx, L, lane, grp_on ? g * L : -1, s_grp[wave]);
+      rsy = group_sum(rsy, L, lane, grp_on ? g * L : -1, s_grp[wave]);
+      rsz = group_sum(rsz, L, lane, grp_on ? g * L : -1, s_grp[wave]);
       __syncthreads();  // the previous tile's readers are done with s_hit (and the constants are written)
       if (hit_vec) {
         const int q4 = TR / 4, cc = threadIdx.x / q4, qd = threadIdx.x - cc * q4;
@@ -973,16 +748,16 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
       }
       __syncthreads();
       if (row_on && chan_on) {
-        const float cnt = (float)__float_as_int(cur.b.x), fcen = (float)ncen;
-        float *dst = a.dght + ((size_t)b * N + i) * row + c0;
+        const float cnt = (float)p0.len, fcen = (float)ncen;
+        float *dst = a.dght + ((size_t)p0.b * N + p0.i) * row + c0;
         Vec<V> dg, dh;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
           const int cc = cl * V + v;
-          const float hit = s_hit[cc * (TR + 1) + (i - i0)];
-          float t = s_con[0][cc] * cur.a.x;
-          t = __builtin_fmaf(s_con[1][cc], cur.a.y, t);
-          t = __builtin_fmaf(s_con[2][cc], cur.a.z, t);
+          const float hit = s_hit[cc * (TR + 1) + (p0.i - i0)];
+          float t = s_con[0][cc] * rsx;
+          t = __builtin_fmaf(s_con[1][cc], rsy, t);
+          t = __builtin_fmaf(s_con[2][cc], rsz, t);
           const float cA = s_con[3][cc], cB = s_con[4][cc], cD = s_con[5][cc];
           const float ysum = (t + shc[v]) + cnt * gi.v[v];  // (shc holds this point's own H row once per centred query)
           dg.v[v] = __builtin_fmaf(cD, ysum, __builtin_fmaf(cA, hit, cnt * cB));
@@ -991,8 +766,12 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_sum_kernel(PwArgs a, con
         store_row<V>(dst, dg);
         store_row<V>(dst + Co, dh);
       }
-      cur = nxt; b = bn; i = in; wp = wpn;
-      nxt = nn; bn = bnn; in = inn;
+      p0 = p1; p1 = p2; p2 = p3;
+#pragma unroll
+      for (int r = 0; r < kSupRounds; ++r) {
+        e0[r] = e1[r];
+        sl1[r] = sl2[r];
+      }
     }
   }
 }
@@ -1643,82 +1422,21 @@ extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const f
   a.qtab = reinterpret_cast<const float4 *>(qtab); a.support_xyz = support_xyz; a.inv_radius = 1.0f / radius;
   a.inv_off = inv_off; a.inv_slots = inv_slots; a.dght = dght;
   a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co;
-  a.kmagic = div_magic(K);
+  a.kmagic = div_magic(K, (long long)M * K);
   int rc = pw_check(a, "pwmlp_bwd_support");
   if (rc != CL3D_OK) return rc;
   CL3D_REQUIRE(ght && wr && cA && cB && cD && hit_cm && dz_t && sy_t && qtab && support_xyz && inv_off && inv_slots && dght && radius > 0.f,
                "pwmlp_bwd_support: null pointer");
+  if ((long long)M * Co * 4 > 0xffffffffLL) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support: M*Co too large");
   if (B == 0) return CL3D_OK;
   const int V = (Co % 4 == 0) ? 4 : 1;
   const LaneMap m = pick_lane_map(Co, V);
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
-  const int gx = round_grid(tiles, 8192);
-  // measured at the metric shape: 8 rows in flight at 3 waves/SIMD 93 us, 6 at 3 93 us, 5 at 4 87 us, 4 at 4 86 us;
-  // more waves with spills: 3 rows at 5 waves/SIMD 102 us, 4 at 5 110 us, 2 at 6 113 us
-  static const int sb6 = [] {  // CL3D_PW_SB=6: six H rows in flight per lane instead of four (A/B timing)
-    const char *e = getenv("CL3D_PW_SB");
-    return (e != nullptr && e[0] == '6') ? 1 : 0;
-  }();
-  if (V == 4 && sb6) hipLaunchKernelGGL((pwmlp_support_kernel<4, 6, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
-  else if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4, 4, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((pwmlp_support_kernel<1, 8, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
-  return check_launch("cl3d_pwmlp_bwd_support");
-}
-
-extern "C" int cl3d_pwmlp_support_summary(const int32_t *idx, const float *query_xyz, const float *support_xyz,
-                                          const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K,
-                                          float radius, float *rec, uint32_t *ent, int entries_ready,
-                                          cl3d_stream_t stream) {
-  using namespace cl3d;
-  CL3D_REQUIRE(B >= 0 && N >= 1 && M >= 1 && K >= 1, "pwmlp_support_summary: bad sizes");
-  CL3D_REQUIRE((long long)M * K <= 0x7fffffffLL, "pwmlp_support_summary: M*K too large");
-  CL3D_REQUIRE(idx && query_xyz && support_xyz && inv_off && inv_slots && rec && ent && radius > 0.f,
-               "pwmlp_support_summary: null pointer");
-  if (B == 0) return CL3D_OK;
-  SumArgs a{};
-  a.idx = idx; a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.inv_off = inv_off; a.inv_slots = inv_slots;
-  a.rec = reinterpret_cast<float4 *>(rec); a.ent = ent;
-  a.B = B; a.N = N; a.M = M; a.K = K; a.inv_radius = 1.0f / radius; a.kmagic = div_magic(K, (long long)M * K);
-  a.write_ent = entries_ready ? 0 : 1;
-  CL3D_REQUIRE((long long)B * ((N + 3) / 4) <= 0x7fffffffLL, "pwmlp_support_summary: B*N too large");
-  // grid: the kernel runs on a side stream beside the critical path's short kernels (per-channel finalize, APPLY): at
-  // 2048 workgroups (every wave slot of the chip) a 64-workgroup kernel launched right behind it waited 23 us for slots
-  // (round 3: 1024 measured best of 512 / 1024 / 2048).  A multiple of 8, so a workgroup stays on its XCD as it strides.
-  const int gx = round_grid((long long)B * ((N + 3) / 4), 1024);
-  hipLaunchKernelGGL(pwmlp_summary_kernel, dim3(gx), dim3(256), 0, (hipStream_t)stream, a);
-  return check_launch("cl3d_pwmlp_support_summary");
-}
-
-extern "C" int cl3d_pwmlp_bwd_support_sum(const float *ght, const float *wr, const float *cA, const float *cB,
-                                          const float *cD, const float *hit_cm, const float *dz_t, const float *sy_t,
-                                          const float *rec, const uint32_t *ent, int B, int N, int M, int K, int Co,
-                                          float *dght, cl3d_stream_t stream) {
-  using namespace cl3d;
-  PwArgs a{};
-  a.ght = ght; a.wr = wr; a.v0 = cA; a.v1 = cB; a.v2 = cD; a.hit_cm = hit_cm; a.dz_t = dz_t; a.sy_in = sy_t;
-  a.dght = dght;
-  a.B = B; a.N = N; a.M = M; a.K = K; a.Co = Co;
-  int rc = pw_check(a, "pwmlp_bwd_support_sum");
-  if (rc != CL3D_OK) return rc;
-  CL3D_REQUIRE(ght && wr && cA && cB && cD && hit_cm && dz_t && sy_t && rec && ent && dght,
-               "pwmlp_bwd_support_sum: null pointer");
-  if ((long long)M * Co * 4 > 0xffffffffLL) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support_sum: M*Co too large");
-  if (B == 0) return CL3D_OK;
-  const int V = (Co % 4 == 0) ? 4 : 1;
-  const LaneMap m = pick_lane_map(Co, V);
-  a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
-  const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
-  if (tiles > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support_sum: too many tiles");
-  if (m.L * V > 256) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support_sum: %d channels per chunk", m.L * V);
+  if (tiles > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support: too many tiles");
+  if (m.L * V > 256) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support: %d channels per chunk", m.L * V);
   const int gx = round_grid(tiles, 1024);  // persistent: four workgroups per CU, each pipelines over its tiles
-  const float4 *s4 = reinterpret_cast<const float4 *>(rec);
-  static const int sb4 = [] {  // CL3D_PW_SB=4: four rows in flight per lane instead of eight (A/B timing)
-    const char *e = getenv("CL3D_PW_SB");
-    return (e != nullptr && e[0] == '4') ? 1 : 0;
-  }();
-  if (V == 4 && sb4) hipLaunchKernelGGL((pwmlp_support_sum_kernel<4, 4>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a, s4, ent);
-  else if (V == 4) hipLaunchKernelGGL((pwmlp_support_sum_kernel<4, 8>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a, s4, ent);
-  else hipLaunchKernelGGL((pwmlp_support_sum_kernel<1, 8>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a, s4, ent);
-  return check_launch("cl3d_pwmlp_bwd_support_sum");
+  if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4, 8>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((pwmlp_support_kernel<1, 8>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("cl3d_pwmlp_bwd_support");
 }

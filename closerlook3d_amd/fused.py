@@ -103,37 +103,31 @@ def _gemm_scratch(op, B, N, Co, C, device):
     return torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=device), nbytes
 
 
-def _build_inverse(idx, n_support, entries=False):
+def _build_inverse(idx, n_support):
     B = idx.shape[0]
     MK = idx[0].numel()
     off = torch.empty((B, n_support + 1), dtype=torch.int32, device=idx.device)
     slots = torch.empty((B, MK), dtype=torch.int32, device=idx.device)
-    ent = torch.empty((B, MK), dtype=torch.int32, device=idx.device) if entries else None
     lib = _lib.lib()
     ws_bytes = lib.cl3d_workspace_bytes(11, B, n_support, MK, 1, 0)  # CL3D_OP_INVERSE_INDEX
     ws = torch.empty((max(ws_bytes, 1),), dtype=torch.uint8, device=idx.device)
     with _lib.on_device(idx.device):
-        if entries:
-            _, M, K = idx.shape
-            _lib.check(lib.cl3d_build_inverse_index_entries(_p(idx), B, n_support, M, K, _p(off), _p(slots), _p(ent), _p(ws),
-                                                            ws_bytes, _stream(idx)))
-        else:
-            _lib.check(lib.cl3d_build_inverse_index(_p(idx), B, n_support, MK, _p(off), _p(slots), _p(ws), ws_bytes,
-                                                    _stream(idx)))
-    return off, slots, ent
+        _lib.check(lib.cl3d_build_inverse_index(_p(idx), B, n_support, MK, _p(off), _p(slots), _p(ws), ws_bytes,
+                                                _stream(idx)))
+    return off, slots
 
 
-def inverse_index(idx, n_support, prefetch=False, entries=False):
+def inverse_index(idx, n_support, prefetch=False):
     """CSR inverse of idx [B,M,K] (or [B,M]) -> (off [B,N+1], slots [B,MK]); memoised on the tensor.
 
     prefetch=True (forward pass, when a backward will follow): start the build on the index stream right
-    behind the ball query and return nothing; the later call waits for it.
-    entries=True (the PointWiseMLP, idx [B,M,K]): the build's fill pass also leaves the per-position entries of the
-    support-major backward (csrc/csr.hip); `inverse_entries(idx)` returns them."""
+    behind the ball query and return nothing; the later call waits for it."""
     cached = getattr(idx, '_cl3d_inverse', None)
     if cached is not None and cached[0] == n_support:
         if not prefetch and cached[3] is not None:
             torch.cuda.current_stream(idx.device).wait_event(cached[3])
+            idx._cl3d_inverse = cached[:3] + (None,)
+            _PENDING[:] = [t for t in _PENDING if t is not idx]
         return cached[1], cached[2]
     ev = None
     if prefetch and pt_utils.async_index():
@@ -142,27 +136,19 @@ def inverse_index(idx, n_support, prefetch=False, entries=False):
             wait_ready(idx)  # the ball query ran on this stream already; this covers a cached idx too
             if not torch.cuda.is_current_stream_capturing():
                 idx.record_stream(side)  # read here: the allocator must not recycle it before this stream is done
-            off, slots, ent = _build_inverse(idx, n_support, entries)
+            off, slots = _build_inverse(idx, n_support)
             ev = torch.cuda.Event()
             ev.record(side)
         if not torch.cuda.is_current_stream_capturing():
             off.record_stream(main)
             slots.record_stream(main)
-            if ent is not None:
-                ent.record_stream(main)
     elif prefetch:
         return None
     else:
         wait_ready(idx)
-        off, slots, ent = _build_inverse(idx, n_support, entries)
-    idx._cl3d_inverse = (n_support, off, slots, ev, ent)
+        off, slots = _build_inverse(idx, n_support)
+    idx._cl3d_inverse = (n_support, off, slots, ev)
     return off, slots
-
-
-def inverse_entries(idx):
-    """The entries the CSR build left beside the slot table (None: built without them)."""
-    cached = getattr(idx, '_cl3d_inverse', None)
-    return cached[4] if cached is not None else None
 
 
 def _join_inverse(idx):
@@ -173,24 +159,26 @@ def _join_inverse(idx):
     cached = getattr(idx, '_cl3d_inverse', None)
     if cached is not None and cached[3] is not None:
         torch.cuda.current_stream(idx.device).wait_event(cached[3])
-        idx._cl3d_inverse = cached[:3] + (None,) + cached[4:]
+        idx._cl3d_inverse = cached[:3] + (None,)
+        _PENDING[:] = [t for t in _PENDING if t is not idx]
 
 
 _WHOLE_STEP = [False]
-_PENDING = []  # idx tensors whose summary a captured forward left on the index stream for its backward to join
+_PENDING = []  # idx tensors whose CSR build a captured forward left on the index stream for its backward to join
 
 
 @contextlib.contextmanager
 def whole_step_capture(on=True):
     """Declare that the HIP graph being captured holds a whole training step -- every forward pass TOGETHER with its
     backward pass (bench.py, scripts/bench_backbone.py, a captured training loop).  The PointWiseMLP's forward pass may
-    then leave the geometry work it forked for its backward (CSR build + summary, on the index stream) to be joined by
-    that backward, inside the same capture.  Without the declaration a captured forward pass ends fully joined, as
-    hipStreamEndCapture demands of a capture that stops there (torch.cuda.make_graphed_callables captures forward and
-    backward separately), and the backward walks the CSR slot lists instead of the summary (the choice is made once, in
-    the forward pass, and travels on the autograd node): 0.344-0.346 against 0.335 ms on the replayed step.  Eager
-    launches never need it.  A declared capture whose backward did NOT run inside it is reported here by name instead
-    of as a bare hipErrorStreamCaptureUnjoined."""
+    then leave the CSR build it forked for its backward (on the index stream) to be joined by that backward's
+    support-major pass, inside the same capture: joined at the end of the forward, the FIRST backward kernel inherits
+    a cross-queue wait for a table only a later kernel reads (replayed step, round 3: ~12 us between the forward's
+    last kernel and the backward's first, against ~5 us between kernels of one queue).  Without the declaration a
+    captured forward pass ends fully joined, as hipStreamEndCapture demands of a capture that stops there
+    (torch.cuda.make_graphed_callables captures forward and backward separately); the backward is the same kernels
+    either way.  Eager launches never need it.  A declared capture whose backward did NOT run inside it is reported
+    here by name instead of as a bare hipErrorStreamCaptureUnjoined."""
     old = _WHOLE_STEP[0]
     _WHOLE_STEP[0] = bool(on)
     del _PENDING[:]
@@ -199,9 +187,9 @@ def whole_step_capture(on=True):
     except Exception as e:
         if _PENDING:
             raise RuntimeError(
-                f"whole_step_capture(): {len(_PENDING)} PointWiseMLP forward pass(es) left their support summary on the "
-                "index stream, but no backward pass joined it inside the capture -- capture forward AND backward "
-                "together, or drop the declaration") from e
+                f"whole_step_capture(): {len(_PENDING)} PointWiseMLP forward pass(es) left their CSR build on the index "
+                "stream, but no backward pass joined it inside the capture -- capture forward AND backward together, "
+                "or drop the declaration") from e
         raise
     finally:
         _WHOLE_STEP[0] = old
@@ -213,93 +201,16 @@ def whole_step_capture(on=True):
 
 
 def _join_geometry(idx):
-    """End of a PointWiseMLP forward pass.  With a summary queued behind the CSR build (same stream) the caller's stream
-    has nothing to pick up here: the backward's support pass waits for the summary, which covers the build, and no
-    other kernel of the operator reads either.  Joining the build here made the FIRST backward kernel wait across
-    queues for a table it never reads (replayed step, round 3: ~12 us between the forward's last kernel and the
-    backward's first, against ~5 us between kernels of one queue).  Inside a graph capture that is only allowed when
-    the backward is known to be part of the same capture (whole_step_capture); otherwise -- and without a pending
-    summary -- everything forked is joined here."""
-    pending = getattr(idx, '_cl3d_summary', None)
-    if pending is not None and pending[3] is not None:
-        capturing = torch.cuda.is_current_stream_capturing()
-        if _WHOLE_STEP[0] or not capturing:
-            if capturing and not any(t is idx for t in _PENDING):
-                _PENDING.append(idx)
-            return
-        torch.cuda.current_stream(idx.device).wait_event(pending[3])  # (behind the CSR build on the same stream)
-        idx._cl3d_summary = pending[:3] + (None,)
+    """End of a PointWiseMLP forward pass: the caller's stream picks up the CSR build that ran beside it -- except in a
+    declared whole-step capture, where the backward's support-major pass (the table's only reader in this operator)
+    joins it right before it runs (whole_step_capture).  In eager mode the join is always taken: it costs nothing
+    there, and the backward then finds a finished table whatever mode IT runs in."""
+    cached = getattr(idx, '_cl3d_inverse', None)
+    if cached is not None and cached[3] is not None and _WHOLE_STEP[0] and torch.cuda.is_current_stream_capturing():
+        if not any(t is idx for t in _PENDING):
+            _PENDING.append(idx)
+        return
     _join_inverse(idx)
-
-
-# The PointWiseMLP's support-major backward pass either works out, per slot of a support point's list, which row of the
-# tile the slot belongs to, its query record and its relative position before it can gather (cl3d_pwmlp_bwd_support), or
-# reads all that from a summary of the lists built once per GEOMETRY (support_summary below; shared by the operators of
-# a backbone stage like the CSR inverse) and only gathers (cl3d_pwmlp_bwd_support_sum).  Measured, round 3, metric
-# shape: slot walk 74 us; summary 35 us on the index stream + 45 us; the replayed step 0.366 -> 0.358-0.361 ms, the
-# 16 x 4096 backbone 8.17 -> 8.03 ms f32, 6.80 -> 6.61 ms bf16.  CL3D_PW_SUMMARY=0 selects the slot walk (A/B timing).
-SUPPORT_SUMMARY = os.environ.get('CL3D_PW_SUMMARY', '1') != '0'
-
-
-def _use_summary():
-    """The summary lives on the index stream until the backward's support pass joins it; a capture that may end with
-    the forward pass (no whole_step_capture declaration) cannot leave it there, and joining it at the end of the
-    forward would put its ~40 us in front of the first backward kernel -- such a capture takes the slot walk instead
-    (measured as CL3D_PW_SUMMARY=0: 0.344-0.346 against 0.335 ms per replayed step)."""
-    return bool(SUPPORT_SUMMARY) and (_WHOLE_STEP[0] or not torch.cuda.is_current_stream_capturing())
-
-
-def support_summary(idx, n_support, query_xyz, support_xyz, radius, prefetch=False):
-    """What the PointWiseMLP's support-major backward pass needs of every support point's slot list, boiled down
-    once per geometry (csrc/fused_pwmlp.hip, pwmlp_summary_kernel): (rec [B,N,8], ent [B,M*K]); memoised on idx
-    like the CSR inverse it is built from, so every operator of a backbone stage shares one.
-
-    prefetch=True (forward pass, when a backward will follow): queued on the index stream right behind the CSR
-    build; the backward's support pass is the first (and only) consumer and waits for it there -- joining it at the
-    end of the forward pass would put ~30 us of geometry work in front of the first backward kernel."""
-    key = (n_support, float(radius), query_xyz.data_ptr(), support_xyz.data_ptr())
-    cached = getattr(idx, '_cl3d_summary', None)
-    if cached is not None and cached[0] == key:
-        if not prefetch and cached[3] is not None:
-            torch.cuda.current_stream(idx.device).wait_event(cached[3])
-            idx._cl3d_summary = cached[:3] + (None,)
-            _PENDING[:] = [t for t in _PENDING if t is not idx]
-        return cached[1], cached[2]
-    B, M, K = idx.shape
-    lib = _lib.lib()
-
-    def build(off, slots):
-        rec = torch.empty((B, n_support, 8), dtype=torch.float32, device=idx.device)
-        ent = inverse_entries(idx)  # left by the CSR build's fill pass; a table built without them: written here
-        ready = ent is not None
-        if not ready:
-            ent = torch.empty((B, M * K), dtype=torch.int32, device=idx.device)
-        with _lib.on_device(idx.device):
-            _lib.check(lib.cl3d_pwmlp_support_summary(_p(idx), _p(query_xyz), _p(support_xyz), _p(off), _p(slots), B,
-                                                      n_support, M, K, float(radius), _p(rec), _p(ent), int(ready),
-                                                      _stream(idx)))
-        return rec, ent
-
-    ev = None
-    if prefetch and pt_utils.async_index():
-        main, side = torch.cuda.current_stream(idx.device), pt_utils.index_stream(idx.device, 1)
-        off, slots = inverse_index(idx, n_support, prefetch=True, entries=True)  # queued on `side` (or already there)
-        with torch.cuda.stream(side):
-            # behind the CSR build on the same stream, which waited for the ball query, which waited for the
-            # coordinates: nothing to wait for (and no wait on the stream's own event: a self-wait inside a capture
-            # crashed hipStreamEndCapture)
-            rec, ent = build(off, slots)
-            ev = torch.cuda.Event()
-            ev.record(side)
-        if not torch.cuda.is_current_stream_capturing():
-            rec.record_stream(main)
-            ent.record_stream(main)
-            query_xyz.record_stream(side)
-            support_xyz.record_stream(side)
-    else:  # (a prefetch without a side stream builds here and now: the backward pass looks for the finished summary)
-        rec, ent = build(*inverse_index(idx, n_support, entries=True))
-    idx._cl3d_summary = (key, rec, ent, ev)
-    return rec, ent
 
 
 def _transposed(t):
@@ -390,14 +301,13 @@ def _wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad=False, entries=False):
+def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad=False):
     """Ball query (and, when a backward will follow, the CSR inverse) on the index stream; the fused
-    Functions wait_ready() the result right before their first kernel that reads it.  entries: the PointWiseMLP's
-    backward will read the table through its summary (inverse_index)."""
+    Functions wait_ready() the result right before their first kernel that reads it."""
     idx, idx_mask = _ball_query(query_xyz.contiguous(), support_xyz.contiguous(), query_mask.contiguous(),
                                 support_mask.contiguous(), radius, nsample, defer=True)
     if need_grad:
-        inverse_index(idx, support_xyz.shape[1], prefetch=True, entries=entries)
+        inverse_index(idx, support_xyz.shape[1], prefetch=True)
     return idx, idx_mask
 
 
@@ -623,9 +533,6 @@ class _PointwiseMLP(Function):
                     ctx.radius = float(radius)
                     ctx.idx = idx
                     ctx.meta = (B, N, M, K, Co, nparts)
-                    # decided once, here: a summary was queued for this geometry (pointwise_mlp / pointwise_bottleneck
-                    # under _use_summary()) -> the backward reads it; otherwise it walks the CSR slot lists
-                    ctx.use_summary = getattr(idx, '_cl3d_summary', None) is not None
                 ctx.rows_out = bool(rows_out)
                 if rows_out:
                     _join_geometry(idx)
@@ -658,11 +565,10 @@ class _PointwiseMLP(Function):
             dz_cm = torch.empty((B, Co, M), dtype=torch.float32, device=dev)
             ts_cm = torch.empty((B, Co, M), dtype=torch.int32, device=dev)
             partial = torch.empty((nparts, Co, 8), dtype=torch.float64, device=dev)
-            # for the support-major pass: dz again as point-major rows, and (slot walk only) one 16-byte record per
-            # query {coordinates, centre idx[j, 0]} (a slot of that pass then costs one L2 request instead of three)
+            # for the support-major pass: dz again as point-major rows, and one 16-byte record per query
+            # {coordinates, centre idx[j, 0]} (an entry of that pass then costs one L2 request instead of three)
             dz_t = torch.empty((B, M, Co), dtype=torch.float32, device=dev)
-            use_summary = ctx.use_summary
-            qtab = None if use_summary else torch.empty((B, M, 4), dtype=torch.float32, device=dev)
+            qtab = torch.empty((B, M, 4), dtype=torch.float32, device=dev)
             _lib.check(lib.cl3d_pwmlp_bwd_rows(_p(gout), gout_cm, _p(ystar), _p(kstar), _p(idx), _p(query_xyz), _p(support_xyz),
                                                ctx.radius, _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), B, N, M, K, Co,
                                                _p(dz_cm), _p(ts_cm), _p(dz_t), _p(qtab), _p(partial), nparts, st))
@@ -685,15 +591,10 @@ class _PointwiseMLP(Function):
             coeffs()
             hits()
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
-            if use_summary:
-                rec, ent = support_summary(idx, N, query_xyz, support_xyz, ctx.radius)  # (waits for it; covers the CSR build)
-                _lib.check(lib.cl3d_pwmlp_bwd_support_sum(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t),
-                                                          _p(sy), _p(rec), _p(ent), B, N, M, K, Co, _p(dght), st))
-            else:
-                off, slots = inverse_index(idx, N)
-                _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t), _p(sy),
-                                                      _p(qtab), _p(support_xyz), ctx.radius, _p(off), _p(slots),
-                                                      B, N, M, K, Co, _p(dght), st))
+            off, slots = inverse_index(idx, N)  # (waits for the build the forward pass forked, if it is still pending)
+            _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t), _p(sy),
+                                                  _p(qtab), _p(support_xyz), ctx.radius, _p(off), _p(slots),
+                                                  B, N, M, K, Co, _p(dght), st))
         return (dght, dwr, dgamma, dbeta) + (None,) * 12
 
 
@@ -963,9 +864,7 @@ def pointwise_bottleneck(conv1, la, conv2, shortcut, query_xyz, support_xyz, que
     prec = PRECISIONS[precision]
     params = (c1.weight, bn1.weight, bn1.bias, mconv.weight, mbn.weight, mbn.bias, c2.weight, bn2.weight, bn2.bias)
     need_grad = _wants_grad(features, identity, *params)
-    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, la.radius, la.nsample, need_grad, _use_summary())
-    if need_grad and _use_summary():
-        support_summary(idx, support_xyz.shape[1], query_xyz, support_xyz, la.radius, prefetch=True)
+    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, la.radius, la.nsample, need_grad)
     y1 = _Conv1x1.apply(features, c1.weight.view(C1, -1), prec)
     ght, wr = _BnReluPointRows.apply(y1, bn1.weight, bn1.bias, bn1, mconv.weight.view(Cla, 3 + 2 * C1), prec)
     rows, scale, shift = _PointwiseMLP.apply(ght, wr, mbn.weight, mbn.bias, mbn.running_mean, mbn.running_var,
@@ -991,9 +890,7 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     conv, bn = mlps.conv0[0], mlps.conv0[1]
     need_grad = training and _wants_grad(features, conv.weight, bn.weight, bn.bias)
-    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad, _use_summary())
-    if need_grad and _use_summary():
-        support_summary(idx, support_xyz.shape[1], query_xyz, support_xyz, radius, prefetch=True)
+    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad)
     C = features.shape[1]
     Co = conv.weight.shape[0]
     W = conv.weight.view(Co, 3 + 2 * C)

@@ -33,7 +33,9 @@ extern "C" {
 #endif
 
 /* 2: round 3 -- cl3d_pwmlp_bwd_rows / cl3d_pwmlp_bwd_support changed their argument lists (query table and
- * point-major dz rows); the round-2 changes to bn_relu_stats / fused_reduce / pwmlp_* had been made under version 1 */
+ * point-major dz rows); the round-2 changes to bn_relu_stats / fused_reduce / pwmlp_* had been made under version 1
+ * 3: round 4 -- cl3d_pwmlp_support_summary / cl3d_pwmlp_bwd_support_sum are gone (cl3d_pwmlp_bwd_support is the one
+ * support-major pass again, same argument list as in version 2) */
 #define CL3D_ABI_VERSION 3
 
 #define CL3D_OK 0
@@ -208,15 +210,6 @@ int cl3d_transpose(const float *src, int B, int R, int C, float *dst, cl3d_strea
  * atomicAdd scatter (group_points_gpu.cu:65), so gradients are bit-reproducible run to run. */
 int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK, int32_t *inv_off,
                              int32_t *inv_slots, void *ws, size_t ws_bytes, cl3d_stream_t stream);
-/* The same build for idx [B,M,K] that also leaves, per CSR position, the ENTRY the PointWiseMLP's support-major backward
- * reads (cl3d_pwmlp_bwd_support_sum): entries [B,M*K] = the centre idx[j, 0] of a slot (j, k > 0) -- the reference takes
- * slot 0 of a query's list as its centre, local_aggregation_operators.py:290 -- or, for a slot (j, 0), 0x80000000 | j.
- * Same workspace.  cl3d_inverse_index_entries derives the entries of a table built without them. */
-int cl3d_build_inverse_index_entries(const int32_t *idx, int B, int N, int M, int K, int32_t *inv_off,
-                                     int32_t *inv_slots, uint32_t *entries, void *ws, size_t ws_bytes,
-                                     cl3d_stream_t stream);
-int cl3d_inverse_index_entries(const int32_t *idx, const int32_t *inv_off, const int32_t *inv_slots, int B, int N,
-                               int M, int K, uint32_t *entries, cl3d_stream_t stream);
 
 /* op: 0 PosPool xyz, 1 PosPool sin_cos (p0 = dim table [C/6]), 2 AdaptiveWeight 'dp' with one conv
  * (p0 = W [C/S,3], p1 = bias [C/S], pint = S), 3 PseudoGrid (p0 = K_points [P,3], p1 = kernel_weights
@@ -373,30 +366,15 @@ int cl3d_pwmlp_bn_backward_coeffs(const double *partial, int n_partials, int Co,
                                   const float *gamma, const float *mean, const float *invstd,
                                   const double *sums, float *cA, float *cB, float *cD, float *dgamma,
                                   float *dbeta, float *dwr, cl3d_stream_t stream);
-/* d ght [B,N,2Co] through the CSR inverse of idx; dz_t, qtab: left by cl3d_pwmlp_bwd_rows of the same step */
+/* d ght [B,N,2Co] through the CSR inverse of idx (cl3d_build_inverse_index); dz_t, qtab: left by cl3d_pwmlp_bwd_rows of
+ * the same step.  Per entry of a support point's slot list one lane looks up the slot's query record in qtab (its
+ * coordinates -> the relative position; its centre idx[j, 0], reference local_aggregation_operators.py:290 -> whose H row
+ * the slot adds); the row gathers are the only per-(entry, channel) work. */
 int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const float *cA, const float *cB,
                            const float *cD, const float *hit_cm, const float *dz_t, const float *sy_t,
                            const float *qtab, const float *support_xyz, float radius,
                            const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K, int Co,
                            float *dght, cl3d_stream_t stream);
-/* The same pass on a summary of every support point's slot list.  What cl3d_pwmlp_bwd_support works out per slot
- * before it can gather (which point a CSR position belongs to, the slot's query record, the relative position, whose H
- * row the slot adds; reference local_aggregation_operators.py:290 takes slot 0 of a query as its centre) depends on the
- * geometry only and is worked out once per geometry (idx + coordinates + radius; every operator of a backbone stage
- * shares it):
- *   ent [B,M*K] = the entries of cl3d_build_inverse_index_entries (entries_ready != 0: already there, only read;
- *                 entries_ready == 0: written here from idx and inv_slots)
- *   rec [B,N,8] = {sum of the list's relative positions (p_i - q_j) / radius (3 floats), then as int bits: s0 =
- *                  inv_off[i], list length, 0, 0, 0}                         (cl3d_pwmlp_support_summary)
- * and cl3d_pwmlp_bwd_support_sum is left with the row gathers.  Results agree with cl3d_pwmlp_bwd_support to rounding
- * (the rows of a list are added in a different order). */
-int cl3d_pwmlp_support_summary(const int32_t *idx, const float *query_xyz, const float *support_xyz,
-                               const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K,
-                               float radius, float *rec, uint32_t *ent, int entries_ready, cl3d_stream_t stream);
-int cl3d_pwmlp_bwd_support_sum(const float *ght, const float *wr, const float *cA, const float *cB,
-                               const float *cD, const float *hit_cm, const float *dz_t, const float *sy_t,
-                               const float *rec, const uint32_t *ent, int B, int N, int M, int K, int Co,
-                               float *dght, cl3d_stream_t stream);
 
 #ifdef __cplusplus
 }

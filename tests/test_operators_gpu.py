@@ -509,3 +509,44 @@ def test_resnet_pointwisemlp_bf16_against_f32_engine():
 
 
 BF16_NET_REL_L2 = 5e-2  # one stage (two bottlenecks: six convolutions, two operators, max-pool) on identical inputs
+
+
+def test_resnet_with_every_bottleneck_fused_matches_the_grouped_network(monkeypatch):
+    """at the fixtures' size (B*N < 16 384) backbones._FUSE_MIN_VALUES routes every bottleneck layer by layer,
+    so fused.pointwise_bottleneck only ever ran as a single bottleneck.  Here the threshold is 0: the whole ResNet +
+    segmentation head with every PointWiseMLP bottleneck fused, under ball_query_cache() -- the blocks of a stage share
+    one idx, one CSR table and one support summary -- against the same network on the grouped dataflow (the reference's
+    tensor algebra on the engine's native ops) and against the reference's own fixture."""
+    from closerlook3d_amd import backbones
+    from closerlook3d_amd.backbones import ResNet, SceneSegHeadResNet
+    from closerlook3d_amd.pt_utils import ball_query_cache
+    fx = load_fixture("operators_resnet_seg_pointwisemlp.npz")
+    K = 16
+    res = {}
+    for impl in ("auto", "grouped"):
+        monkeypatch.setattr(backbones, "_FUSE_MIN_VALUES", 0 if impl == "auto" else 1 << 30)
+        cfg = default_config("pointwisemlp", fx["over"], cl3d_impl=impl)
+        net = ResNet(cfg, 3, 0.1, 0.05, [K] * 5, [128, 48, 16, 8], width=12, depth=2, bottleneck_ratio=2)
+        head = SceneSegHeadResNet(5, 12, 0.1, [K] * 5)
+        net.load_state_dict(state_of(fx, "backbone."), strict=True)
+        head.load_state_dict(state_of(fx, "head."), strict=True)
+        net, head = net.cuda().train(True), head.cuda().train(True)
+        feats = torch.from_numpy(fx["features"]).cuda().requires_grad_(True)
+        with ball_query_cache():
+            ep = net(torch.from_numpy(fx["xyz"]).cuda(), torch.from_numpy(fx["mask"]).cuda(), feats)
+            logits = head(ep)
+        (logits * torch.from_numpy(fx["probe"]).cuda()).sum().backward()
+        res[impl] = (logits.detach().cpu().numpy(), ep["res5_features"].detach().cpu().numpy(), feats.grad.cpu().numpy(),
+                     {k: p.grad.cpu().numpy() for k, p in net.named_parameters() if p.grad is not None})
+    a, b = res["auto"], res["grouped"]
+    assert_close(a[0], fx["out"], 2e-4, "logits vs the reference fixture")
+    assert_close(a[0], b[0], 2e-4, "logits fused vs grouped")
+    assert_close(a[1], b[1], 2e-4, "res5 fused vs grouped")
+    # gradients go through ten layers of arg-max routing: a near-tie resolved the other way moves a whole entry, so the
+    # bulk is held tightly and the norm of the difference loosely (as tests/test_fp64_anchor_gpu.py does for the input)
+    for name, x, y in [("input", a[2], b[2])] + [(k, a[3][k], b[3][k]) for k in sorted(b[3])]:
+        scale = float(np.abs(y).max()) + 1e-12
+        moved = float((np.abs(x - y) > 2e-4 * scale + 2e-4 * np.abs(y)).mean())
+        assert moved <= 0.08, f"{name}: {moved:.1%} of the gradient entries moved"
+        assert np.linalg.norm(x - y) <= 5e-2 * np.linalg.norm(y) + 1e-9, name
+    assert set(a[3]) == set(b[3])
