@@ -23,14 +23,14 @@ def _conv_bn(cin, cout, momentum, relu):
 
 import os
 
-_BLOCK_ENGINE = os.environ.get('CL3D_BLOCK', 'engine')  # 'modules': nn.Conv1d / BatchNorm1d as in round 1 (A/B only)
-_DECODE = os.environ.get('CL3D_DECODE', 'split')  # 'cat': the decoders concatenate as the reference does (A/B only)
-# CL3D_FUSE_BOTTLENECK=0: a PointWiseMLP bottleneck layer by layer, with the activated tensors between its layers
-# materialised as in round 2 (A/B only); default: fused.pointwise_bottleneck
-_FUSE_BOTTLENECK = os.environ.get('CL3D_FUSE_BOTTLENECK', '1') != '0'
+_BLOCK_ENGINE = 'engine'  # 'modules' (set by scripts/bench_backbone.py --block modules): nn.Conv1d / BatchNorm1d as in round 1
+_DECODE = 'split'  # 'cat' (scripts/bench_backbone.py --decode cat): the decoders concatenate as the reference does
+# False (scripts/bench_backbone.py --layerwise): a PointWiseMLP bottleneck layer by layer, with the activated tensors
+# between its layers materialised as in round 2; default: fused.pointwise_bottleneck
+_FUSE_BOTTLENECK = True
 # ... for layers with at least this many values per channel (B * N): below it the BatchNorm tails are single-launch
 # kernels that keep a channel in L2 (csrc/bn_relu.hip, bn2_*_small), and there is no round trip to HBM to save
-_FUSE_MIN_VALUES = int(os.environ.get('CL3D_FUSE_MIN_VALUES', '16384'))
+_FUSE_MIN_VALUES = 16384
 
 
 

@@ -1097,14 +1097,6 @@ static int pw_check(const PwArgs &a, const char *who) {
 // (round 3): alone, 2 is the faster kernel (68.9 vs 71.1 us: half the barriers and staging round trips per slot);
 // inside the replayed step, next to the CSR build on the other queue, 1 is (0.3623-0.3635 vs 0.3791-0.3799 ms per
 // step on two boxes).  1 is the default; CL3D_PW_QPG=2 selects the other for A/B timing.
-static int pw_qpg_wanted() {
-  static const int v = [] {
-    const char *e = getenv("CL3D_PW_QPG");
-    return (e != nullptr && e[0] == '2') ? 2 : 1;
-  }();
-  return v;
-}
-
 static LaneMap pw_lane_map(int Co, int K, int V, int nacc, int qpg, size_t *lds_out) {
   LaneMap m = pick_lane_map(Co, V);
   if (m.QW > 16) {
@@ -1135,44 +1127,23 @@ template <int MODE>
 static int launch_query(PwArgs &a, int nacc, int n_partials, hipStream_t st, const char *who) {
   const int V = (a.Co % 4 == 0) ? 4 : 1;
   size_t lds = 0;
-  int qpg = pw_qpg_wanted();
-  LaneMap m = pw_lane_map(a.Co, a.K, V, nacc, qpg, &lds);
-  {  // two queries per lane group only where that does not narrow the groups (large nsample: LDS) or starve the grid
-    size_t lds1 = 0;
-    const LaneMap m1 = pw_lane_map(a.Co, a.K, V, nacc, 1, &lds1);
-    const long long tiles2 = (long long)a.B * ceil_div(a.M, 4 * m.QW * 2) * m.chunks;
-    if (qpg == 2 && (m.QW != m1.QW || lds > 64 * 1024 || tiles2 < 1024)) {
-      qpg = 1;
-      m = m1;
-      lds = lds1;
-    }
-  }
+  const LaneMap m = pw_lane_map(a.Co, a.K, V, nacc, 1, &lds);
   if (lds > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "%s: nsample=%d needs %zu B of LDS", who, a.K, lds);
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   a.kmagic = div_magic(a.K);
-  const long long tiles = (long long)a.B * ceil_div(a.M, 4 * m.QW * qpg);
+  const long long tiles = (long long)a.B * ceil_div(a.M, 4 * m.QW);
   const int gx = nacc > 0 ? n_partials : round_grid(tiles, 8192);
   // measured at the metric shape (TRAIN, round 2): 8 gathers in flight at 3 waves/SIMD 87 us, 6 at 3 89 us, 4 at 4 76 us:
-  // occupancy buys more than depth per wave
-  // (software-pipelining the walk -- batch n+1's gathers issued before batch n is consumed, 2 or 3 waves per SIMD --
-  // measured 95-120 us)
-  // the slot walk in two rotating pairs (K % 4 == 0): measured at the metric shape, round 3, TRAIN pass alone 69.1 ->
-  // 64.5 us; CL3D_PW_PIPE=0 selects the batch walk (A/B timing)
-  static const int pipe = [] {
-    const char *e = getenv("CL3D_PW_PIPE");
-    return (e != nullptr && e[0] == '0') ? 0 : 1;
-  }();
-  if (V == 4 && pipe && qpg == 1 && (a.K & 3) == 0) {
+  // occupancy buys more than depth per wave (software-pipelining the walk -- batch n+1's gathers issued before batch n
+  // is consumed, 2 or 3 waves per SIMD -- measured 95-120 us).  K % 4 == 0: the slot walk in two rotating pairs (round
+  // 3: 69.1 -> 64.5 us against the batch walk, which the other shapes keep).  Two queries per lane group (round 3's
+  // QPG = 2) measured slower on the replayed step (0.355 against 0.335 ms) and is gone.
+  if (V == 4 && (a.K & 3) == 0)
     hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4, 1, true>), dim3(gx, m.chunks), dim3(256), lds, st, a);
-    return check_launch(who);
-  }
-  if (V == 4) {
-    if (qpg == 2) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4, 2>), dim3(gx, m.chunks), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4, 1>), dim3(gx, m.chunks), dim3(256), lds, st, a);
-  } else {
-    if (qpg == 2) hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1, 8, 4, 2>), dim3(gx, m.chunks), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1, 8, 4, 1>), dim3(gx, m.chunks), dim3(256), lds, st, a);
-  }
+  else if (V == 4)
+    hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 4, 4, 4, 1>), dim3(gx, m.chunks), dim3(256), lds, st, a);
+  else
+    hipLaunchKernelGGL((pwmlp_query_kernel<MODE, 1, 8, 4, 1>), dim3(gx, m.chunks), dim3(256), lds, st, a);
   return check_launch(who);
 }
 

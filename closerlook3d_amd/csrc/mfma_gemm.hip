@@ -725,19 +725,11 @@ __global__ __launch_bounds__(256, 5) void pwmlp_rows_nolds_kernel(const float *_
   }
 }
 
-static bool nolds_fwd_wanted() {
-  static const int on = [] {  // CL3D_GEMM_NOLDS=0: the staged kernel for every shape (A/B timing)
-    const char *e = getenv("CL3D_GEMM_NOLDS");
-    return (e != nullptr && e[0] == '0') ? 0 : 1;
-  }();
-  return on != 0;
-}
-
 // launches it when the shape qualifies (f32, C in {32, 36, 64, 72}: the layers that run beside a ball query at full
 // resolution, whole 32-point blocks per cloud); false = the caller takes the staged kernel
 static bool launch_rows_nolds(const float *F, const float *pro_scale, const float *pro_shift, const float *wcat, float *ght,
                               int B, int C, int N, int Co, hipStream_t st) {
-  if (!nolds_fwd_wanted() || (N & 31) != 0 || B < 1) return false;
+  if ((N & 31) != 0 || B < 1) return false;
   const int J = 2 * Co;
   const long long nblocks = (long long)B * (N / 32);
   if (nblocks > 0x7fffffffLL) return false;
@@ -844,25 +836,14 @@ static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, s
   const double peak_flops_per_us = precision == PREC_BF16 ? 1.2e9 : 157.3e6;  // bf16: what staging sustains, not 2.5 PF
   Plan best{2, 1, 1, (int)((K + gemm_kc(precision, 2, 1) - 1) / gemm_kc(precision, 2, 1))};
   double best_cost = 1e300;
-  int force_wi = 0, force_wj = 0;
-  if (const char *force = getenv("CL3D_GEMM_TILE")) {  // tuning override "wi,wj" (scripts/bench_point_gemm.py --tiles)
-    if (sscanf(force, "%d,%d", &force_wi, &force_wj) != 2) force_wi = force_wj = 0;
-  }
-  long long force_split = 0;
-  if (const char *force = getenv("CL3D_GEMM_SPLIT")) force_split = atoll(force);  // tuning override
   for (int c = 0; c < 4; ++c) {
     const int wi = cand[c][0], wj = cand[c][1], resident = cand[c][2];
-    if (force_wi && (wi != force_wi || wj != force_wj)) continue;
     if (scalar_staging && wi * wj == 4) continue;  // the element-wise staging fallback at 128 x 128 runs out of registers
     const int kc = gemm_kc(precision, wi, wj);
     const long long chunks = (K + kc - 1) / kc;
     const long long ti = ceil_div(I, 64 * wi), tj = ceil_div(J, 64 * wj), tiles = ti * tj;
     const double flops = 2.0 * (double)(ti * 64 * wi) * (double)(tj * 64 * wj) * (double)K;
     for (long long split = 1; split <= max_split && split <= (chunks >= 4 ? chunks / 4 : 1); split += (split < 4 ? 1 : split / 2)) {
-      if (force_split && force_split <= max_split && force_split <= (chunks >= 4 ? chunks / 4 : 1)) {
-        if (split != 1) break;  // the override replaces the sweep: exactly this many slices
-        split = force_split;
-      }
       if (split > 1 && (size_t)split * I * J * sizeof(float) > ws_bytes) break;
       const long long cps = (chunks + split - 1) / split;
       const long long real_split = (chunks + cps - 1) / cps;

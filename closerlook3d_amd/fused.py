@@ -71,7 +71,7 @@ def _stream(t):
     return _lib.stream_ptr(t.device)
 
 
-FORK_GRADS = os.environ.get('CL3D_FORK_GRADS', '1') != '0'  # A/B knob: 0 = the two gradients one after the other
+FORK_GRADS = True  # False: the two gradient products of a contraction one after the other (scripts' A/B)
 
 
 def _fork_join(device, side_fn, main_fn):
@@ -600,7 +600,7 @@ class _PointwiseMLP(Function):
 
 import os
 
-CONV_ENGINE = os.environ.get('CL3D_CONV', 'mfma')  # 'mfma': csrc/mfma_gemm.hip; 'library': torch's Conv1d (A/B only)
+CONV_ENGINE = 'mfma'  # 'mfma': csrc/mfma_gemm.hip; 'library' (scripts' A/B): torch's Conv1d
 PRECISIONS = {'f32': 0, 'bf16': 1}  # CL3D_PRECISION_*: arithmetic of the dense contraction only
 POINT_GEMM = 'mfma'  # 'mfma': csrc/mfma_gemm.hip; 'bmm': the library GEMM (kept for scripts/bench_point_gemm.py's A/B)
 

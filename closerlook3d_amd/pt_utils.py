@@ -194,12 +194,12 @@ def _ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsampl
     return out
 
 
-# 'auto': prefetch when there are fewer than 8 clouds per GPU (see prefetch_geometry); CL3D_PREFETCH=1 / 0 force it.
+# 'auto': prefetch when there are fewer than 8 clouds per GPU (see prefetch_geometry).
 # Same-box A/B of whole backbone steps, off -> on: one 40 960-point scene 7.64 -> 7.34 ms, 4 x 10 000 points
 # 7.19 -> 6.97 ms, one 81 920-point scene (width 288) 20.36 -> 20.06 ms; 16 x 4096 points 8.31 -> 8.52 ms (with 16
 # clouds the one-workgroup-per-cloud kernels already fill 16 CUs and the early, heaviest layers lose more to the
 # contention than the late ones gain).
-PREFETCH_GEOMETRY = {'1': True, '0': False}.get(os.environ.get('CL3D_PREFETCH', ''), 'auto')
+PREFETCH_GEOMETRY = 'auto'  # True / False force it (tests, scripts)
 
 
 def _subsample(xyz, mask, npoint, sampleDl):

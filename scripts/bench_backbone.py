@@ -58,6 +58,12 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1: the step as two graphs with the late-stage gradients exchanged while the early stages' "
                          "backward replays, instead of one flat all-reduce after the whole backward")
+    ap.add_argument("--block", default="engine", choices=["engine", "modules"],
+                    help="A/B: 'modules' runs the bottlenecks' convolutions / BatchNorms as nn modules (the round-1 path)")
+    ap.add_argument("--decode", default="split", choices=["split", "cat"],
+                    help="A/B: 'cat' lets the decoders concatenate as the reference does")
+    ap.add_argument("--layerwise", action="store_true",
+                    help="A/B: PointWiseMLP bottlenecks layer by layer (the activated tensors between their layers materialised)")
     args = ap.parse_args()
     kind, B, N, radius, dl, nsamples, npoints, width = CONFIGS[args.config]
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,6 +84,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if one_dev else "nccl", **({} if one_dev else {"device_id": dev}))
     import closerlook3d_amd
+    from closerlook3d_amd import backbones as _bb
+    _bb._BLOCK_ENGINE, _bb._DECODE, _bb._FUSE_BOTTLENECK = args.block, args.decode, not args.layerwise
     from closerlook3d_amd.backbones import ResNet
     from closerlook3d_amd.dp import FlatGradients
     from closerlook3d_amd.pt_utils import ball_query_cache

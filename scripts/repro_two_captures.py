@@ -27,6 +27,9 @@ VARIANTS = ["baseline", "no_async", "no_fork_grads", "separate_pools", "sync_bet
 
 
 def run(config, variant, replays):
+    import faulthandler
+    faulthandler.enable()
+    note = lambda *a: print("[repro]", *a, file=sys.stderr, flush=True)
     import closerlook3d_amd
     from closerlook3d_amd import fused, pt_utils
     from closerlook3d_amd.backbones import ResNet
@@ -73,10 +76,14 @@ def run(config, variant, replays):
 
     # reference: the same two-stage backward, eager, index streams off
     pt_utils.ASYNC_INDEX = False
+    note("eager reference")
     for _ in range(2):
         compute_late()
+        note("late done")
         compute_early()
+        note("early done")
     ref_e, ref_l = grads()
+    note("reference gradients", float(ref_e.norm()), float(ref_l.norm()))
     # BatchNorm running statistics move with every forward; they do not enter training-mode outputs or gradients
 
     def set_async(on):
@@ -102,13 +109,16 @@ def run(config, variant, replays):
         compute_early()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    note("capture A")
     ga = capture(compute_late, None, a_on)
+    note("capture B")
     if variant == "fresh_streams_b":
         pt_utils._INDEX_STREAMS.clear()
     gb = capture(compute_early, None if variant == "separate_pools" else ga.pool(), b_on)
     fused.FORK_GRADS = fused_fork
     worst_e = worst_l = 0.0
     seen = []
+    note("replays")
     for _ in range(replays):
         ga.replay()
         if variant == "sync_between":
@@ -137,4 +147,4 @@ if __name__ == "__main__":
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", a.config, "--one", v, "--replays",
                                 str(a.replays)], capture_output=True, text=True, timeout=900)
             lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-            print(lines[-1] if lines else json.dumps({"variant": v, "rc": r.returncode, "err": r.stderr[-400:]}), flush=True)
+            print(lines[-1] if lines else json.dumps({"variant": v, "rc": r.returncode, "err": r.stderr[-1500:]}), flush=True)

@@ -156,7 +156,7 @@ def test_torchrun_command_is_the_documented_launch():
 
 def test_self_launch_runs_the_script_as_n_ranks(tmp_path):
     """self_launch() replaces the process by the N-rank launch: a stub script stands in for bench.py (same control
-    flow: WORLD_SIZE unset + --gpus 2 -> exec torchrun -> two ranks over gloo, each prints its rank)."""
+    flow: WORLD_SIZE unset + --gpus 2 -> exec torchrun -> two ranks over gloo, each leaves a file with what it saw)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -169,14 +169,18 @@ def test_self_launch_runs_the_script_as_n_ranks(tmp_path):
         "    self_launch(os.path.abspath(__file__), sys.argv[1:], 2, visible_devices=0)\n"
         "import torch.distributed as dist\n"
         "dist.init_process_group('gloo')\n"
-        "print('rank', dist.get_rank(), 'of', dist.get_world_size(), 'one_dev', os.environ.get('CL3D_BENCH_ONE_DEVICE'),"
-        " 'args', sys.argv[1:], flush=True)\n"
+        "out = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'rank_%d.txt' % dist.get_rank())\n"
+        "open(out, 'w').write('%d of %d one_dev %s args %s' % (dist.get_rank(), dist.get_world_size(),"
+        " os.environ.get('CL3D_BENCH_ONE_DEVICE'), sys.argv[1:]))\n"
         "dist.barrier(); dist.destroy_process_group()\n")
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, str(stub), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    for attempt in range(3):  # (the free port self_launch picks can be taken before torchrun binds it: try again)
+        r = subprocess.run([sys.executable, str(stub), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env)
+        if r.returncode == 0:
+            break
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = sorted(line for line in r.stdout.splitlines() if line.startswith("rank"))
-    assert lines == ["rank 0 of 2 one_dev 1 args ['--gpus', '2']", "rank 1 of 2 one_dev 1 args ['--gpus', '2']"], r.stdout
+    got = [(tmp_path / f"rank_{k}.txt").read_text() for k in range(2)]
+    assert got == ["0 of 2 one_dev 1 args ['--gpus', '2']", "1 of 2 one_dev 1 args ['--gpus', '2']"], got
     assert "stand-in" in r.stderr
 
 
