@@ -550,8 +550,14 @@ __device__ __forceinline__ float group_sum(float v, int L, int lane, int first /
   return t;
 }
 
+#ifndef CL3D_SUP_SB
+#define CL3D_SUP_SB 8      // H rows in flight per lane   } tunables of the support-major pass: the defaults ship,
+#endif                     //                             } scripts/micro/kernel_variants.py times the others
+#ifndef CL3D_SUP_WAVES
+#define CL3D_SUP_WAVES 4   // waves per SIMD the register budget is set for
+#endif
 template <int V, int SB>
-__global__ __launch_bounds__(256, 4) void pwmlp_support_kernel(PwArgs a) {
+__global__ __launch_bounds__(256, CL3D_SUP_WAVES) void pwmlp_support_kernel(PwArgs a) {
   __shared__ float s_hit[1280];   // [L * V channels][TR + 1]: L * V * (256 / L + 1) <= 4 * (256 + 64) floats
   __shared__ float s_con[6][256]; // wr (3), A, Bc, D of the chunk's L * V <= 256 channels
   __shared__ float s_grp[4][64];  // group_sum scratch (lane groups that are not DPP rows)
@@ -566,44 +572,50 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_kernel(PwArgs a) {
   const int tiles_per_cloud = (N + TR - 1) / TR;
   const int ntiles = a.B * tiles_per_cloud;
   const bool grp_on = g < QW;  // lanes past the last whole group (64 % L) only keep the barriers
-  struct Pt {  // this lane group's point of a tile: cloud, row, list start and length (i == N: none)
-    int b, i, s0, len;
+  // A tile is TR consecutive points of ONE cloud: the cloud is workgroup-uniform (kept on the scalar side), the point
+  // belongs to the lane group.
+  struct Pt {  // this lane group's point of a tile: row (N: none), list start and length
+    int i, s0, len;
   };
-  struct En {  // this lane's entry of a round: centre (or kCentreFlag | query id), relative position (zeros: none)
-    unsigned cen;
-    float rx, ry, rz;
+  struct En {  // this lane's entry of a round: byte offset of the row the entry adds in the cloud's ght (bit 31: the
+    unsigned off, j;  // entry is a slot (j, 0) -- the row is this point's own, j the query whose rows feed d H)
   };
-  auto fetch_point = [&](int t) {
-    Pt p{0, N, 0, 0};
+  auto tile_cloud = [&](int t, int &tr) {
+    int b = 0;
+    tr = 0;
+    if (t < ntiles) decode_tile(t, a.B, tiles_per_cloud, b, tr);
+    return __builtin_amdgcn_readfirstlane(b);
+  };
+  auto fetch_point = [&](int t, int b, int tr) {
+    Pt p{N, 0, 0};
     if (t < ntiles) {
-      int tr;
-      decode_tile(t, a.B, tiles_per_cloud, p.b, tr);
-      p.i = tr * TR + wave * QW + g;
-      if (grp_on && p.i < N) {
-        const int *off = a.inv_off + (size_t)p.b * (N + 1) + p.i;
+      const int i = tr * TR + wave * QW + g;
+      if (grp_on && i < N) {
+        const int *off = a.inv_off + (size_t)b * (N + 1) + i;
+        p.i = i;
         p.s0 = off[0];
         p.len = off[1] - p.s0;
-      } else {
-        p.i = N;
       }
     }
     return p;
   };
-  auto fetch_slot_at = [&](const Pt &p, int e) {  // slot id of the list's entry e, -1 past its end
-    return e < p.len ? a.inv_slots[(size_t)p.b * MK + p.s0 + e] : -1;
+  auto fetch_slot_at = [&](const Pt &p, int b, int e) {  // slot id of the list's entry e, -1 past its end
+    return e < p.len ? a.inv_slots[(size_t)b * MK + p.s0 + e] : -1;
   };
-  auto fetch_slot = [&](const Pt &p, int r) { return fetch_slot_at(p, r * L + cl); };  // this lane's entry of round r
-  auto fetch_entry = [&](const Pt &p, int slot) {
-    En e{0u, 0.f, 0.f, 0.f};
+  // the entry of a slot, and its relative position added to (rx, ry, rz) -- the forward pass's own expression for rel
+  // (pwmlp_query_kernel's slot record)
+  auto fetch_entry = [&](const Pt &p, int b, int slot, float &rx, float &ry, float &rz) {
+    En e{0u, 0u};
     if (slot >= 0) {
       const int j = div_k(slot, a.kmagic, K);
-      const float4 qt = a.qtab[(size_t)p.b * M + j];  // {query coordinates, centre idx[j, 0]}
-      const float *pp = a.support_xyz + ((size_t)p.b * N + p.i) * 3;
-      // the forward pass's own expression for rel (pwmlp_query_kernel's slot record)
-      e.rx = (pp[0] - qt.x) * a.inv_radius;
-      e.ry = (pp[1] - qt.y) * a.inv_radius;
-      e.rz = (pp[2] - qt.z) * a.inv_radius;
-      e.cen = slot - j * K == 0 ? (kCentreFlag | (unsigned)j) : (unsigned)__float_as_int(qt.w);
+      const float4 qt = a.qtab[(size_t)b * M + j];  // {query coordinates, centre idx[j, 0]}
+      const float *pp = a.support_xyz + ((size_t)b * N + p.i) * 3;
+      rx += (pp[0] - qt.x) * a.inv_radius;
+      ry += (pp[1] - qt.y) * a.inv_radius;
+      rz += (pp[2] - qt.z) * a.inv_radius;
+      const bool centred = slot - j * K == 0;
+      e.off = (centred ? (unsigned)p.i : (unsigned)__float_as_int(qt.w)) * rowb | (centred ? kCentreFlag : 0u);
+      e.j = (unsigned)j;
     }
     return e;
   };
@@ -622,57 +634,56 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_kernel(PwArgs a) {
     // ---- the look-ahead chain: point (tile + 3 G) -> slots (tile + 2 G) -> entries (tile + G) -> rows (tile)
     int tile = blockIdx.x;
     const int G = (int)gridDim.x;
-    Pt p0 = fetch_point(tile), p1 = fetch_point(tile + G), p2 = fetch_point(tile + 2 * G);
+    int tr0, tr1, tr2;
+    int b0 = tile_cloud(tile, tr0), b1 = tile_cloud(tile + G, tr1), b2 = tile_cloud(tile + 2 * G, tr2);
+    Pt p0 = fetch_point(tile, b0, tr0), p1 = fetch_point(tile + G, b1, tr1), p2 = fetch_point(tile + 2 * G, b2, tr2);
     int sl1[kSupRounds];
     En e0[kSupRounds];
+    float rs0[3] = {0.f, 0.f, 0.f};  // this lane's share of the current point's sum rel
 #pragma unroll
-    for (int r = 0; r < kSupRounds; ++r) e0[r] = fetch_entry(p0, fetch_slot(p0, r));
+    for (int r = 0; r < kSupRounds; ++r) e0[r] = fetch_entry(p0, b0, fetch_slot_at(p0, b0, r * L + cl), rs0[0], rs0[1], rs0[2]);
 #pragma unroll
-    for (int r = 0; r < kSupRounds; ++r) sl1[r] = fetch_slot(p1, r);
+    for (int r = 0; r < kSupRounds; ++r) sl1[r] = fetch_slot_at(p1, b1, r * L + cl);
     for (; tile < ntiles; tile += G) {
       const bool row_on = p0.i < N;
-      int tb, tr;
-      decode_tile(tile, a.B, tiles_per_cloud, tb, tr);  // workgroup-uniform (p0 belongs to the lane group)
-      const int i0 = tr * TR;
+      const int i0 = tr0 * TR;
       // --- requests for later tiles
       En e1[kSupRounds];
+      float rs1[3] = {0.f, 0.f, 0.f};
       int sl2[kSupRounds];
 #pragma unroll
-      for (int r = 0; r < kSupRounds; ++r) e1[r] = fetch_entry(p1, sl1[r]);
+      for (int r = 0; r < kSupRounds; ++r) e1[r] = fetch_entry(p1, b1, sl1[r], rs1[0], rs1[1], rs1[2]);
 #pragma unroll
-      for (int r = 0; r < kSupRounds; ++r) sl2[r] = fetch_slot(p2, r);
-      const Pt p3 = fetch_point(tile + 3 * G);
+      for (int r = 0; r < kSupRounds; ++r) sl2[r] = fetch_slot_at(p2, b2, r * L + cl);
+      int tr3;
+      const int b3 = tile_cloud(tile + 3 * G, tr3);
+      const Pt p3 = fetch_point(tile + 3 * G, b3, tr3);
       // --- this tile: arg-max terms (to LDS below), the point's own row
       float4 h4 = make_float4(0.f, 0.f, 0.f, 0.f);
       const bool hit_vec = (N & 3) == 0 && LV * (TR / 4) <= 256;
       if (hit_vec) {
         const int q4 = TR / 4, cc = threadIdx.x / q4, qd = threadIdx.x - cc * q4;
         if (cc < LV && cbase + cc < Co && i0 + qd * 4 < N)
-          h4 = *reinterpret_cast<const float4 *>(a.hit_cm + ((size_t)tb * Co + cbase + cc) * N + i0 + qd * 4);
+          h4 = *reinterpret_cast<const float4 *>(a.hit_cm + ((size_t)b0 * Co + cbase + cc) * N + i0 + qd * 4);
       }
       float shc[V], csy[V], cdz[V];
-      float rsx = 0.f, rsy = 0.f, rsz = 0.f;  // this lane's share of sum rel
-      int ncen = 0;                            // queries centred on this point (flagged entries)
+      int ncen = 0;  // queries centred on this point (flagged entries)
       Vec<V> gi;
 #pragma unroll
       for (int v = 0; v < V; ++v) shc[v] = csy[v] = cdz[v] = gi.v[v] = 0.f;
       if (row_on) {
-        const int b = p0.b, i = p0.i, len = p0.len;
-        const char *hrows = reinterpret_cast<const char *>(a.ght + (size_t)b * N * row);
-        gi = load_row<V>(reinterpret_cast<const float *>(hrows + ((unsigned)i * rowb + (unsigned)c0 * 4u)));
+        const int len = p0.len;
         // uniform bases + 32-bit lane offsets: the gathers are saddr + voffset loads (one VGPR per address)
-        const char *syrows = reinterpret_cast<const char *>(a.sy_in + (size_t)b * M * Co);
-        const char *dzrows = reinterpret_cast<const char *>(a.dz_t + (size_t)b * M * Co);
-        const unsigned h_off = ((unsigned)Co + (unsigned)c0) * 4u, q_off = (unsigned)c0 * 4u;
-        const unsigned own_row = (unsigned)i;
+        const char *hrows = reinterpret_cast<const char *>(a.ght + (size_t)b0 * N * row) + ((size_t)Co + (size_t)c0) * 4u;
+        const char *syrows = reinterpret_cast<const char *>(a.sy_in + (size_t)b0 * M * Co) + (size_t)c0 * 4u;
+        const char *dzrows = reinterpret_cast<const char *>(a.dz_t + (size_t)b0 * M * Co) + (size_t)c0 * 4u;
+        gi = load_row<V>(reinterpret_cast<const float *>(hrows + (size_t)p0.i * rowb) - Co);
         const unsigned long long gmask = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
         auto round_of = [&](const En &en, int p) {  // entries p .. p + L - 1 of the list, one per lane of the group
-          rsx += en.rx; rsy += en.ry; rsz += en.rz;
-          const unsigned wp = en.cen;
           const int nr = len - p < L ? len - p : L;
           // the round's flagged entries (queries centred on this point), as a bit mask over the group's lanes; the
           // first one's two query-major rows are requested now, ahead of the round's H rows
-          unsigned long long fm = (__ballot(p + cl < len && (wp >> 31) != 0u) >> (g * L)) & gmask;
+          unsigned long long fm = (__ballot(p + cl < len && (en.off >> 31) != 0u) >> (g * L)) & gmask;
           ncen += (int)__popcll(fm);
           Vec<V> ry0, rd0;
 #pragma unroll
@@ -680,19 +691,29 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_kernel(PwArgs a) {
           if (fm != 0ull) {  // (uniform within the lane group)
             const int l = __ffsll((long long)fm) - 1;
             fm &= fm - 1ull;
-            const unsigned o = ((unsigned)__shfl((int)wp, g * L + l, CL3D_WAVE) & 0x7fffffffu) * ((unsigned)Co * 4u) + q_off;
+            const unsigned o = (unsigned)__shfl((int)en.j, g * L + l, CL3D_WAVE) * ((unsigned)Co * 4u);
             ry0 = load_row<V>(reinterpret_cast<const float *>(syrows + o));
             rd0 = load_row<V>(reinterpret_cast<const float *>(dzrows + o));
           }
-          for (int u0 = 0; u0 < nr; u0 += SB) {
-            unsigned ce[SB];
+          int u0 = 0;
+          for (; u0 + SB <= nr; u0 += SB) {  // full batches: no per-entry guard
             Vec<V> rr[SB];
 #pragma unroll
-            for (int u = 0; u < SB; ++u) ce[u] = (unsigned)__shfl((int)wp, g * L + (u0 + u < nr ? u0 + u : nr - 1), CL3D_WAVE);
+            for (int u = 0; u < SB; ++u) {
+              const unsigned o = (unsigned)__shfl((int)en.off, g * L + u0 + u, CL3D_WAVE) & 0x7fffffffu;
+              rr[u] = load_row<V>(reinterpret_cast<const float *>(hrows + o));
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u)
+#pragma unroll
+              for (int v = 0; v < V; ++v) shc[v] += rr[u].v[v];
+          }
+          if (u0 < nr) {  // the list's last, partial batch
+            Vec<V> rr[SB];
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
-              const unsigned r_ = (ce[u] >> 31) != 0u ? own_row : ce[u];  // a centred query's centre is this very point
-              rr[u] = load_row<V>(reinterpret_cast<const float *>(hrows + (r_ * rowb + h_off)));
+              const unsigned o = (unsigned)__shfl((int)en.off, g * L + (u0 + u < nr ? u0 + u : nr - 1), CL3D_WAVE) & 0x7fffffffu;
+              rr[u] = load_row<V>(reinterpret_cast<const float *>(hrows + o));
             }
 #pragma unroll
             for (int u = 0; u < SB; ++u) {
@@ -709,7 +730,7 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_kernel(PwArgs a) {
           while (fm != 0ull) {  // further centred queries of the round (duplicated points): one at a time
             const int l = __ffsll((long long)fm) - 1;
             fm &= fm - 1ull;
-            const unsigned o = ((unsigned)__shfl((int)wp, g * L + l, CL3D_WAVE) & 0x7fffffffu) * ((unsigned)Co * 4u) + q_off;
+            const unsigned o = (unsigned)__shfl((int)en.j, g * L + l, CL3D_WAVE) * ((unsigned)Co * 4u);
             const Vec<V> ry = load_row<V>(reinterpret_cast<const float *>(syrows + o));
             const Vec<V> rd = load_row<V>(reinterpret_cast<const float *>(dzrows + o));
 #pragma unroll
@@ -727,12 +748,13 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_kernel(PwArgs a) {
             p += L;
           }
         }
-        for (; p < len; p += L) round_of(fetch_entry(p0, fetch_slot_at(p0, p + cl)), p);  // long lists: fetched in line
+        for (; p < len; p += L)  // long lists: fetched in line
+          round_of(fetch_entry(p0, b0, fetch_slot_at(p0, b0, p + cl), rs0[0], rs0[1], rs0[2]), p);
       }
       // sum rel over the group's lanes (every lane of the wave takes part; lanes without a row carry zeros)
-      rsx = group_sum(rsx, L, lane, grp_on ? g * L : -1, s_grp[wave]);
-      rsy = group_sum(rsy, L, lane, grp_on ? g * L : -1, s_grp[wave]);
-      rsz = group_sum(rsz, L, lane, grp_on ? g * L : -1, s_grp[wave]);
+      const float rsx = group_sum(rs0[0], L, lane, grp_on ? g * L : -1, s_grp[wave]);
+      const float rsy = group_sum(rs0[1], L, lane, grp_on ? g * L : -1, s_grp[wave]);
+      const float rsz = group_sum(rs0[2], L, lane, grp_on ? g * L : -1, s_grp[wave]);
       __syncthreads();  // the previous tile's readers are done with s_hit (and the constants are written)
       if (hit_vec) {
         const int q4 = TR / 4, cc = threadIdx.x / q4, qd = threadIdx.x - cc * q4;
@@ -743,13 +765,13 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_kernel(PwArgs a) {
       } else {
         for (int t = threadIdx.x; t < LV * TR; t += 256) {
           const int cc = t / TR, ii = t - cc * TR;
-          if (cbase + cc < Co && i0 + ii < N) s_hit[cc * (TR + 1) + ii] = a.hit_cm[((size_t)tb * Co + cbase + cc) * N + i0 + ii];
+          if (cbase + cc < Co && i0 + ii < N) s_hit[cc * (TR + 1) + ii] = a.hit_cm[((size_t)b0 * Co + cbase + cc) * N + i0 + ii];
         }
       }
       __syncthreads();
       if (row_on && chan_on) {
         const float cnt = (float)p0.len, fcen = (float)ncen;
-        float *dst = a.dght + ((size_t)p0.b * N + p0.i) * row + c0;
+        float *dst = a.dght + ((size_t)b0 * N + p0.i) * row + c0;
         Vec<V> dg, dh;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
@@ -767,11 +789,15 @@ __global__ __launch_bounds__(256, 4) void pwmlp_support_kernel(PwArgs a) {
         store_row<V>(dst + Co, dh);
       }
       p0 = p1; p1 = p2; p2 = p3;
+      b0 = b1; b1 = b2; b2 = b3;
+      tr0 = tr1; tr1 = tr2; tr2 = tr3;
 #pragma unroll
       for (int r = 0; r < kSupRounds; ++r) {
         e0[r] = e1[r];
         sl1[r] = sl2[r];
       }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) rs0[c] = rs1[c];
     }
   }
 }
@@ -1406,8 +1432,8 @@ extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const f
   const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
   if (tiles > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support: too many tiles");
   if (m.L * V > 256) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support: %d channels per chunk", m.L * V);
-  const int gx = round_grid(tiles, 1024);  // persistent: four workgroups per CU, each pipelines over its tiles
-  if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4, 8>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
+  const int gx = round_grid(tiles, 256 * CL3D_SUP_WAVES);  // persistent: as many workgroups per CU as fit, each pipelines over its tiles
+  if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4, CL3D_SUP_SB>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((pwmlp_support_kernel<1, 8>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_bwd_support");
 }

@@ -58,6 +58,9 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1: the step as two graphs with the late-stage gradients exchanged while the early stages' "
                          "backward replays, instead of one flat all-reduce after the whole backward")
+    ap.add_argument("--overlap-forks", action="store_true",
+                    help="--overlap with the index-stream forks left ON inside both captures (the configuration that gave "
+                         "wrong early-stage gradients in round 3; kept to reproduce / re-test it)")
     ap.add_argument("--block", default="engine", choices=["engine", "modules"],
                     help="A/B: 'modules' runs the bottlenecks' convolutions / BatchNorms as nn modules (the round-1 path)")
     ap.add_argument("--decode", default="split", choices=["split", "cat"],
@@ -121,7 +124,8 @@ def main():
         # eager two-stage backward equals the plain one exactly).  So the overlapped step keeps every kernel on the
         # capture stream; what it gains over the flat exchange has to pay for the forks it gives up (-6 % per step).
         from closerlook3d_amd import pt_utils as _pu
-        _pu.ASYNC_INDEX = False
+        if not args.overlap_forks:
+            _pu.ASYNC_INDEX = False
     late = [p for n_, p in net.named_parameters() if p.requires_grad and n_.startswith(("layer3.", "layer4."))]
     late += [p for p in head.parameters()] if head is not None else []
     late_ids = {id(p) for p in late}

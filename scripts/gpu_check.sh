@@ -2,7 +2,7 @@
 # One GPU-box session: parity tests, reference pin, bench (+ rocprof summary of the same command), PMC counters of the
 # timed step and of the ball_query+group boundary, contraction A/B, the other operators and the backbone configs.
 # Usage (from the repo root on the GPU box): bash scripts/gpu_check.sh [tag]
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -27,11 +27,11 @@ timeout 900 python bench.py --precision bf16 --no-cpu-baseline 2>/dev/null | tee
 echo "== bench, eager launches" | tee -a $OUT/summary.txt
 timeout 900 python bench.py --no-graph --no-cpu-baseline --no-kernel-roofline 2>/dev/null | tee $OUT/bench_eager.json | cut -c1-260 | tee -a $OUT/summary.txt
 echo "== ball query: LDS-resident kernel vs cell grid through HBM (same op, pinned path)" | tee -a $OUT/summary.txt
-for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
-for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --n 1024 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
-for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --mult 4.0 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
-echo "== step variants: cell grid, two queries per lane group, slot-walking support pass, batch walk, points stored in cell order (experiment)" | tee -a $OUT/summary.txt
-for v in "CL3D_BQ_PATH=cells" "CL3D_PW_QPG=2" "CL3D_PW_SUMMARY=0" "CL3D_PW_PIPE=0" "CL3D_GEMM_NOLDS=0" "CL3D_BENCH_SORTED=1"; do
+for p in tile tile1 cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
+for p in tile tile1 cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --n 1024 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
+for p in tile tile1 cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --mult 4.0 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
+echo "== step variants: the cell-grid ball query through HBM scratch, points stored in cell order (experiment)" | tee -a $OUT/summary.txt
+for v in "CL3D_BQ_PATH=cells" "CL3D_BENCH_SORTED=1"; do
   env $v timeout 300 python bench.py --no-cpu-baseline --no-kernel-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', 'ms_per_step', d['ms_per_step'])" | tee -a $OUT/step_variants.txt | tee -a $OUT/summary.txt
 done
 echo "== micro-benchmarks: 2.1 M random 256-byte row gathers by row pitch; coordinates as 3 x dword vs 1 x dwordx4" | tee -a $OUT/summary.txt
@@ -88,17 +88,19 @@ timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp --pr
 echo "== segmentation configs with the scene-segmentation head in the step (decoder without / with the concatenated tensor)" | tee -a $OUT/summary.txt
 for c in s3dis_pseudogrid partnet_adaptive s3dis_pospool_deep; do
   timeout 600 python scripts/bench_backbone.py --config $c --head 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
-  CL3D_DECODE=cat timeout 600 python scripts/bench_backbone.py --config $c --head 2>/dev/null | tail -1 | sed 's/^/concatenating decoder: /' | tee -a $OUT/summary.txt
+  timeout 600 python scripts/bench_backbone.py --config $c --head --decode cat 2>/dev/null | tail -1 | sed 's/^/concatenating decoder: /' | tee -a $OUT/summary.txt
 done
-CL3D_BLOCK=modules timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp 2>/dev/null | tail -1 | sed 's/^/round-1 block path (library conv + BatchNorm modules): /' | tee -a $OUT/summary.txt
+timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp --block modules 2>/dev/null | tail -1 | sed 's/^/round-1 block path (library conv + BatchNorm modules): /' | tee -a $OUT/summary.txt
 echo "== steady-state kernel table of the config-2 backbone step (bf16)" | tee -a $OUT/summary.txt
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof_bb -o bb -- python $R/scripts/bench_backbone.py --config modelnet_pointwisemlp --precision bf16 --steps 40 > $R/$OUT/rocprof_bb.log 2>&1)
 python scripts/kstats.py $OUT/prof_bb/bb_kernel_stats.csv 47 50 | tee $OUT/backbone_steady_state.txt | head -30 | tee -a $OUT/summary.txt
 echo "== data parallel on one device (2 ranks over gloo): backbone, flat exchange and two-graph overlapped exchange" | tee -a $OUT/summary.txt
-CL3D_BENCH_ONE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 scripts/bench_backbone.py --gpus 2 --config partnet_adaptive 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
-CL3D_BENCH_ONE_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 scripts/bench_backbone.py --gpus 2 --config partnet_adaptive --overlap 2>/dev/null | tail -1 | tee -a $OUT/summary.txt
-echo "== config 2 layer by layer (CL3D_FUSE_BOTTLENECK=0): the activated tensors between a bottleneck's layers materialised" | tee -a $OUT/summary.txt
-for prec in f32 bf16; do CL3D_FUSE_BOTTLENECK=0 timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp --precision $prec 2>/dev/null | tail -1 | tee -a $OUT/summary.txt; done
+# (a bare `--gpus 2`: the scripts re-launch themselves as two ranks; one device visible -> both ranks on it over gloo)
+timeout 600 python scripts/bench_backbone.py --gpus 2 --config partnet_adaptive 2>/dev/null | grep '^{' | tail -1 | tee -a $OUT/summary.txt
+timeout 600 python scripts/bench_backbone.py --gpus 2 --config partnet_adaptive --overlap 2>/dev/null | grep '^{' | tail -1 | tee -a $OUT/summary.txt
+timeout 600 python bench.py --gpus 2 --no-cpu-baseline --no-kernel-roofline 2>/dev/null | grep '^{' | tail -1 | cut -c1-400 | tee -a $OUT/summary.txt
+echo "== config 2 layer by layer (--layerwise): the activated tensors between a bottleneck's layers materialised" | tee -a $OUT/summary.txt
+for prec in f32 bf16; do timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp --precision $prec --layerwise 2>/dev/null | tail -1 | tee -a $OUT/summary.txt; done
 echo "== dataset-side grid subsampling, voting, sphere crops" | tee -a $OUT/summary.txt
 timeout 600 python scripts/bench_dataset_grid.py 2>/dev/null | tee $OUT/bench_dataset_grid.json | tee -a $OUT/summary.txt
 timeout 300 python scripts/bench_voting.py 2>/dev/null | tee $OUT/bench_voting.json | tee -a $OUT/summary.txt

@@ -1,9 +1,10 @@
-"""Build variants of the LDS-resident ball query (csrc/ball_query_lds.hip, its CL3D_TL_* tunables) as whole libraries and
-time them: the kernel alone (scripts/bench_bq.py), its bit-exactness against the shipped library, and the replayed
-step (bench.py) -- the kernel shares the chip with the per-point GEMM there, which decides more than its own time.
+"""Build variants of one kernel file (its compile-time tunables: CL3D_TL_* of csrc/ball_query_lds.hip, CL3D_SUP_* of the
+support-major pass in csrc/fused_pwmlp.hip) as whole libraries and time them: the ball query alone
+(scripts/bench_bq.py) with its bit-exactness against the shipped library, and the replayed step with its per-entry table
+(bench.py) -- a kernel shares the chip with its neighbours there, which decides more than its own time.
 
-  python scripts/micro/bq_variants.py --build            (build container: hipcc cross-compiles; the .so files travel)
-  python scripts/micro/bq_variants.py --run [--step]     (GPU box)
+  python scripts/micro/kernel_variants.py --build            (build container: hipcc cross-compiles; the .so files travel)
+  python scripts/micro/kernel_variants.py --run [--step]     (GPU box)
 """
 import argparse
 import glob
@@ -19,34 +20,33 @@ HIPCC = "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
          "-DCL3D_D2_FORM=0"]
 
-VARIANTS = {
-    "rank1_qt4": [],
-    "rank0_qt4": ["-DCL3D_TL_RANK=0"],
-    "rank1_qt2": ["-DCL3D_TL_QT=2"],
-    "rank0_qt2": ["-DCL3D_TL_RANK=0", "-DCL3D_TL_QT=2"],
-    "rank1_qt4_flat3": ["-DCL3D_TL_FLAT=3"],
-    "rank1_qt8": ["-DCL3D_TL_QT=8"],
-    # timing experiments (results are wrong on purpose: a phase is cut)
-    "rank1_qt4_phase1": ["-DCL3D_TL_PHASE=1"],
-    "rank1_qt4_phase2": ["-DCL3D_TL_PHASE=2"],
+VARIANTS = {  # tag: (source file, extra defines)
+    "sup_sb8_w4": ("fused_pwmlp.hip", []),
+    "sup_sb4_w4": ("fused_pwmlp.hip", ["-DCL3D_SUP_SB=4"]),
+    "sup_sb6_w4": ("fused_pwmlp.hip", ["-DCL3D_SUP_SB=6"]),
+    "sup_sb8_w3": ("fused_pwmlp.hip", ["-DCL3D_SUP_WAVES=3"]),
+    "sup_sb12_w3": ("fused_pwmlp.hip", ["-DCL3D_SUP_SB=12", "-DCL3D_SUP_WAVES=3"]),
+    "sup_sb4_w5": ("fused_pwmlp.hip", ["-DCL3D_SUP_SB=4", "-DCL3D_SUP_WAVES=5"]),
+    "bq_rank0": ("ball_query_lds.hip", ["-DCL3D_TL_RANK=0"]),
+    "bq_qt2": ("ball_query_lds.hip", ["-DCL3D_TL_QT=2"]),
 }
 
 
 def build(only=None):
     os.makedirs(VAR, exist_ok=True)
-    others = [o for o in sorted(glob.glob(os.path.join(CSRC, "*.o"))) if ".d2form" not in o
-              and os.path.basename(o) != "ball_query_lds.o"]
+    objs = [o for o in sorted(glob.glob(os.path.join(CSRC, "*.o"))) if ".d2form" not in o]
     procs = []
-    for tag, defs in VARIANTS.items():
+    for tag, (src, defs) in VARIANTS.items():
         if only and tag not in only:
             continue
-        obj = os.path.join(VAR, f"bq_{tag}.o")
-        procs.append((tag, obj, subprocess.Popen([HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, "ball_query_lds.hip"),
-                                                                          "-o", obj], stderr=subprocess.DEVNULL)))
-    for tag, obj, p in procs:
+        obj = os.path.join(VAR, f"var_{tag}.o")
+        procs.append((tag, src, obj, subprocess.Popen([HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj],
+                                                      stderr=subprocess.DEVNULL)))
+    for tag, src, obj, p in procs:
         if p.wait() != 0:
             raise SystemExit(f"hipcc failed on variant {tag}")
         lib = os.path.join(VAR, f"libcl3d_{tag}.so")
+        others = [o for o in objs if os.path.basename(o) != src[:-4] + ".o"]
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + others + [obj])
         os.remove(obj)
         print("built", lib)
@@ -79,10 +79,14 @@ def run(step, only=None):
             ref = got
         row["bit_exact"] = bool(np.array_equal(ref, got))
         if step and "phase" not in tag:
-            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-kernel-roofline"],
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline"],
                                env=env, capture_output=True, text=True, timeout=600)
             if r.returncode == 0:
-                row["step_ms"] = json.loads(r.stdout.strip().splitlines()[-1])["ms_per_step"]
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                row["step_ms"] = d["ms_per_step"]
+                for k in d["roofline"]["step"]["kernels"]:
+                    if k["entry"] in ("cl3d_pwmlp_bwd_support", "cl3d_masked_ordered_ball_query", "cl3d_pwmlp_stats"):
+                        row[k["entry"].replace("cl3d_", "") + "_us"] = k["us"]
             else:
                 row["step_error"] = r.stderr[-300:]
         rows.append(row)
