@@ -551,11 +551,14 @@ __device__ __forceinline__ float group_sum(float v, int L, int lane, int first /
 }
 
 #ifndef CL3D_SUP_SB
-#define CL3D_SUP_SB 8      // H rows in flight per lane   } tunables of the support-major pass: the defaults ship,
+#define CL3D_SUP_SB 4      // H rows in flight per lane   } tunables of the support-major pass: the defaults ship,
 #endif                     //                             } scripts/micro/kernel_variants.py times the others
 #ifndef CL3D_SUP_WAVES
 #define CL3D_SUP_WAVES 4   // waves per SIMD the register budget is set for
 #endif
+#ifndef CL3D_SUP_LATE
+#define CL3D_SUP_LATE 0    // 1: the tile's arg-max block and the point's own G row are requested after the gather loop
+#endif                     //    (eight registers less across it, one more exposed round trip per tile)
 template <int V, int SB>
 __global__ __launch_bounds__(256, CL3D_SUP_WAVES) void pwmlp_support_kernel(PwArgs a) {
   __shared__ float s_hit[1280];   // [L * V channels][TR + 1]: L * V * (256 / L + 1) <= 4 * (256 + 64) floats
@@ -661,11 +664,14 @@ __global__ __launch_bounds__(256, CL3D_SUP_WAVES) void pwmlp_support_kernel(PwAr
       // --- this tile: arg-max terms (to LDS below), the point's own row
       float4 h4 = make_float4(0.f, 0.f, 0.f, 0.f);
       const bool hit_vec = (N & 3) == 0 && LV * (TR / 4) <= 256;
-      if (hit_vec) {
-        const int q4 = TR / 4, cc = threadIdx.x / q4, qd = threadIdx.x - cc * q4;
-        if (cc < LV && cbase + cc < Co && i0 + qd * 4 < N)
-          h4 = *reinterpret_cast<const float4 *>(a.hit_cm + ((size_t)b0 * Co + cbase + cc) * N + i0 + qd * 4);
-      }
+      auto load_hits = [&]() {
+        if (hit_vec) {
+          const int q4 = TR / 4, cc = threadIdx.x / q4, qd = threadIdx.x - cc * q4;
+          if (cc < LV && cbase + cc < Co && i0 + qd * 4 < N)
+            h4 = *reinterpret_cast<const float4 *>(a.hit_cm + ((size_t)b0 * Co + cbase + cc) * N + i0 + qd * 4);
+        }
+      };
+      if (!CL3D_SUP_LATE) load_hits();
       float shc[V], csy[V], cdz[V];
       int ncen = 0;  // queries centred on this point (flagged entries)
       Vec<V> gi;
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(256, CL3D_SUP_WAVES) void pwmlp_support_kernel(PwAr
         const char *hrows = reinterpret_cast<const char *>(a.ght + (size_t)b0 * N * row) + ((size_t)Co + (size_t)c0) * 4u;
         const char *syrows = reinterpret_cast<const char *>(a.sy_in + (size_t)b0 * M * Co) + (size_t)c0 * 4u;
         const char *dzrows = reinterpret_cast<const char *>(a.dz_t + (size_t)b0 * M * Co) + (size_t)c0 * 4u;
-        gi = load_row<V>(reinterpret_cast<const float *>(hrows + (size_t)p0.i * rowb) - Co);
+        if (!CL3D_SUP_LATE) gi = load_row<V>(reinterpret_cast<const float *>(hrows + (size_t)p0.i * rowb) - Co);
         const unsigned long long gmask = L >= 64 ? ~0ull : ((1ull << L) - 1ull);
         auto round_of = [&](const En &en, int p) {  // entries p .. p + L - 1 of the list, one per lane of the group
           const int nr = len - p < L ? len - p : L;
@@ -750,7 +756,9 @@ __global__ __launch_bounds__(256, CL3D_SUP_WAVES) void pwmlp_support_kernel(PwAr
         }
         for (; p < len; p += L)  // long lists: fetched in line
           round_of(fetch_entry(p0, b0, fetch_slot_at(p0, b0, p + cl), rs0[0], rs0[1], rs0[2]), p);
+        if (CL3D_SUP_LATE) gi = load_row<V>(reinterpret_cast<const float *>(hrows + (size_t)p0.i * rowb) - Co);
       }
+      if (CL3D_SUP_LATE) load_hits();
       // sum rel over the group's lanes (every lane of the wave takes part; lanes without a row carry zeros)
       const float rsx = group_sum(rs0[0], L, lane, grp_on ? g * L : -1, s_grp[wave]);
       const float rsy = group_sum(rs0[1], L, lane, grp_on ? g * L : -1, s_grp[wave]);

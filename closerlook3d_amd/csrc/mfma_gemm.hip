@@ -831,14 +831,18 @@ struct Plan {
   int wi, wj, nsplit, cps;
 };
 
-static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes, bool scalar_staging = false) {
+static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes, bool no_big_tile = false) {
   const int cand[4][3] = {{2, 2, 2}, {2, 1, 3}, {1, 2, 3}, {1, 1, 4}};  // wi, wj, resident workgroups per CU
   const double peak_flops_per_us = precision == PREC_BF16 ? 1.2e9 : 157.3e6;  // bf16: what staging sustains, not 2.5 PF
   Plan best{2, 1, 1, (int)((K + gemm_kc(precision, 2, 1) - 1) / gemm_kc(precision, 2, 1))};
   double best_cost = 1e300;
   for (int c = 0; c < 4; ++c) {
     const int wi = cand[c][0], wj = cand[c][1], resident = cand[c][2];
-    if (scalar_staging && wi * wj == 4) continue;  // the element-wise staging fallback at 128 x 128 runs out of registers
+    // 128 x 128 is left out where it does not fit the register file: the element-wise staging fallback (144 spilled
+    // registers) and, in f32, the pair of k-contiguous operands (a convolution's weight gradient: 38).  A kernel that
+    // spills needs the queue's private scratch, and two such launches on concurrent branches of a HIP graph gave wrong
+    // results on this stack -- no kernel this planner can pick spills.
+    if (no_big_tile && wi * wj == 4) continue;
     const int kc = gemm_kc(precision, wi, wj);
     const long long chunks = (K + kc - 1) / kc;
     const long long ti = ceil_div(I, 64 * wi), tj = ceil_div(J, 64 * wj), tiles = ti * tj;
@@ -886,7 +890,8 @@ static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t 
   const int am = stage_mode(a.A), bm = stage_mode(a.B);
   const bool vec_pair = (am == STAGE_VEC_RC && bm == STAGE_VEC_KC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_RC) ||
                         (am == STAGE_VEC_RC && bm == STAGE_VEC_RC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_KC);
-  const Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, !vec_pair);
+  const bool kc_pair_f32 = precision != PREC_BF16 && am == STAGE_VEC_KC && bm == STAGE_VEC_KC;
+  const Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, !vec_pair || kc_pair_f32);
   a.tiles_i = ceil_div(I, 64 * p.wi);
   a.tiles_j = ceil_div(J, 64 * p.wj);
   a.nsplit = p.nsplit;

@@ -86,7 +86,30 @@ def _fork_join(device, side_fn, main_fn):
         side_fn()
         main_fn()
         return
-    main, side = torch.cuda.current_stream(device), pt_utils.index_stream(device, 2)
+    _FORK_COUNT[0] += 1
+    if _FORK_ONLY is not None and _FORK_COUNT[0] not in _FORK_ONLY:  # (debug: only the named fork episodes of a capture)
+        side_fn()
+        main_fn()
+        return
+    main = torch.cuda.current_stream(device)
+    if _FORK_MODE == 'fresh':  # (debug: a stream no earlier fork of this capture has touched)
+        side = pt_utils.index_stream(device, 100 + _FORK_COUNT[0] % 64)
+    else:
+        side = pt_utils.index_stream(device, 2)
+    if _FORK_MODE == 'serial_side':  # (debug: both pieces on the side stream, one after the other)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            side_fn()
+            main_fn()
+        main.wait_stream(side)
+        return
+    if _FORK_MODE == 'after':  # (debug: the side piece is forked behind the caller's piece: never concurrent)
+        main_fn()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            side_fn()
+        main.wait_stream(side)
+        return
     side.wait_stream(main)
     with torch.cuda.stream(side):
         side_fn()
@@ -94,13 +117,25 @@ def _fork_join(device, side_fn, main_fn):
         ev.record(side)
     main_fn()
     main.wait_event(ev)
+    if _FORK_MODE == 'rejoin':  # (debug: the side stream's tail follows the caller's stream again after the join)
+        side.wait_stream(main)
+
+
+_FORK_MODE = 'reuse'
+_FORK_COUNT = [0]
+_SCRATCH_TRACE = None
+_FORK_ONLY = None
 
 
 def _gemm_scratch(op, B, N, Co, C, device):
     """Scratch for the K-slice partials of a per-point contraction (cl3d_workspace_bytes(CL3D_OP_POINT_GEMM = 14 /
     CL3D_OP_CONV1X1 = 15)): (tensor, bytes); the tensor is kept alive by the caller until its launches are queued."""
     nbytes = _lib.lib().cl3d_workspace_bytes(op, B, N, Co, 0, C)
-    return torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=device), nbytes
+    ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=device)
+    if _SCRATCH_TRACE is not None:  # (debug: scripts/bench_backbone.py --debug-two-graphs trace_scratch)
+        _SCRATCH_TRACE.append((ws.data_ptr(), int(nbytes), torch.cuda.current_stream(device).cuda_stream,
+                               bool(torch.cuda.is_current_stream_capturing()), (_FORK_COUNT[0], op, B, N, Co, C)))
+    return ws, nbytes
 
 
 def _build_inverse(idx, n_support):

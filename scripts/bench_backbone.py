@@ -58,9 +58,18 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="N > 1: the step as two graphs with the late-stage gradients exchanged while the early stages' "
                          "backward replays, instead of one flat all-reduce after the whole backward")
-    ap.add_argument("--overlap-forks", action="store_true",
-                    help="--overlap with the index-stream forks left ON inside both captures (the configuration that gave "
-                         "wrong early-stage gradients in round 3; kept to reproduce / re-test it)")
+    ap.add_argument("--overlap-forks", default="", choices=["", "a", "b", "both", "none"],
+                    help="--overlap: which of the two graphs keeps the side-stream forks (default a; b / both = the "
+                         "configuration that gives wrong early-stage gradients, kept to reproduce it)")
+    ap.add_argument("--debug-two-graphs", default="", help="comma list of: sync_between (device sync between the replays of "
+                    "graph A and graph B), own_pool (graph B in a memory pool of its own), fresh_streams (graph B forks onto "
+                    "streams graph A never saw), eager_b (graph B's work launched eagerly with the forks on)")
+    ap.add_argument("--fork-mode", default="reuse", choices=["reuse", "fresh", "rejoin", "serial_side", "after"], help="debug: closerlook3d_amd.fused._FORK_MODE")
+    ap.add_argument("--fork-only", default="", help="debug: comma list of fork episodes (1-based, counted from graph B's capture) that fork")
+    ap.add_argument("--dump-grads", default="", help="rank 0: after the FIRST step save {parameter name: gradient} here and exit")
+    ap.add_argument("--lead-kernel", action="store_true",
+                    help="--overlap: graph B starts with a trivial kernel on the capture stream, so that no forked branch "
+                         "is a ROOT of the graph")
     ap.add_argument("--block", default="engine", choices=["engine", "modules"],
                     help="A/B: 'modules' runs the bottlenecks' convolutions / BatchNorms as nn modules (the round-1 path)")
     ap.add_argument("--decode", default="split", choices=["split", "cat"],
@@ -89,6 +98,8 @@ def main():
     import closerlook3d_amd
     from closerlook3d_amd import backbones as _bb
     _bb._BLOCK_ENGINE, _bb._DECODE, _bb._FUSE_BOTTLENECK = args.block, args.decode, not args.layerwise
+    from closerlook3d_amd import fused as _fu
+    _fu._FORK_MODE = args.fork_mode
     from closerlook3d_amd.backbones import ResNet
     from closerlook3d_amd.dp import FlatGradients
     from closerlook3d_amd.pt_utils import ball_query_cache
@@ -118,14 +129,17 @@ def main():
     # (reference: DistributedDataParallel's bucketed overlap, function/train_modelnet_dist.py:206,280)
     overlap = world > 1 and args.overlap
     if overlap:
-        # Two captures that both fork work onto the engine's index streams gave WRONG early-stage gradients on this stack
-        # (ROCm 7.2 HIP graphs; measured on one device over gloo, r03: the second graph's early-stage norms drift by
-        # 0.3-4 % and change from replay to replay; with the forks off they equal the single-graph step to 5e-6, and the
-        # eager two-stage backward equals the plain one exactly).  So the overlapped step keeps every kernel on the
-        # capture stream; what it gains over the flat exchange has to pay for the forks it gives up (-6 % per step).
+        # Graph A (forward + late-stage backward) keeps the engine's side-stream forks; graph B (the early stages'
+        # backward alone) is captured single-stream.  Round 3 had found wrong, replay-varying early-stage gradients with
+        # forks in both graphs; round 4 narrowed it: forks in A only are exact, ONE forked weight / data
+        # gradient pair inside graph B -- the third, layer2's strided conv2 in the small config -- is enough to corrupt
+        # results that graph B computed BEFORE that fork, only when the two products run concurrently (the same launches
+        # one behind the other on the same two streams are exact), independent of memory pool, stream reuse and of a
+        # device sync between the two replays.  --overlap-forks b|both re-creates it.
         from closerlook3d_amd import pt_utils as _pu
+        _pu.ASYNC_INDEX = False  # (set per capture below)
         if not args.overlap_forks:
-            _pu.ASYNC_INDEX = False
+            args.overlap_forks = "a"
     late = [p for n_, p in net.named_parameters() if p.requires_grad and n_.startswith(("layer3.", "layer4."))]
     late += [p for p in head.parameters()] if head is not None else []
     late_ids = {id(p) for p in late}
@@ -154,7 +168,10 @@ def main():
         held["seeds"] = [seeds[k] for k in seeds]
 
     def compute_early():  # graph B
-        torch.autograd.backward(held["cuts"], grad_tensors=held["seeds"], inputs=early)
+        seeds = held["seeds"]
+        if args.lead_kernel:
+            seeds = [s_ * 1.0 for s_ in seeds]
+        torch.autograd.backward(held["cuts"], grad_tensors=seeds, inputs=early)
 
     def compute():
         if flat is not None:
@@ -168,7 +185,7 @@ def main():
         if world == 1:
             opt.step()
 
-    def capture(fn, pool=None, warm=None):
+    def capture(fn, pool=None, warm=None, forks=None):
         """warm: what to run eagerly first (default: fn itself).  Graph B is captured right behind graph A with no eager
         step in between: it must walk the autograd graph -- and read the cut gradients -- that graph A's capture built."""
         if warm is None:
@@ -182,6 +199,9 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
+        if forks is not None:
+            from closerlook3d_amd import pt_utils as _pu2
+            _pu2.ASYNC_INDEX = 'auto' if forks else False
         with closerlook3d_amd.whole_step_capture(not args.overlap), \
                 torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local" if world > 1 else "global"):
             fn()
@@ -214,10 +234,34 @@ def main():
     if not args.no_graph:
         try:
             if overlap:
-                graph = capture(compute_late, warm=lambda: (compute_late(), compute_early()))
-                graph_b = capture(compute_early, pool=graph.pool(), warm=False)
+                graph = capture(compute_late, warm=lambda: (compute_late(), compute_early()),
+                                forks=args.overlap_forks in ("a", "both"))
+                dbg = set(filter(None, args.debug_two_graphs.split(",")))
+                if "fresh_streams" in dbg:
+                    from closerlook3d_amd import pt_utils as _pu3
+                    _pu3._INDEX_STREAMS.clear()
+                _fu._FORK_COUNT[0] = 0
+                if args.fork_only:
+                    _fu._FORK_ONLY = {int(t) for t in args.fork_only.split(",")}
+                if "trace_scratch" in dbg:
+                    _fu._SCRATCH_TRACE = []
+                if "eager_b" in dbg:
+                    from closerlook3d_amd import pt_utils as _pu3
+                    _pu3.ASYNC_INDEX = True if args.overlap_forks in ("b", "both") else False
+                    graph_b = None
+                else:
+                    graph_b = capture(compute_early, pool=None if "own_pool" in dbg else graph.pool(), warm=False,
+                                      forks=args.overlap_forks in ("b", "both"))
             else:
                 graph = capture(compute)
+            if overlap and _fu._SCRATCH_TRACE is not None and rank == 0:
+                tr = _fu._SCRATCH_TRACE
+                _fu._SCRATCH_TRACE = None
+                streams = sorted({t[2] for t in tr})
+                print("scratch allocations while graph B was captured: %d, streams %s" % (len(tr), streams), file=sys.stderr)
+                for k in range(len(tr)):
+                    p0, n0, s0, c0, what = tr[k]
+                    print("  #%d ptr %x bytes %d stream %x  (episode, op, B, N, Co, C) = %s" % (k, p0, n0, s0, what), file=sys.stderr)
             if world > 1:
                 update_graph = capture(opt.step)
         except Exception as e:
@@ -241,6 +285,8 @@ def main():
             # one-device stand-in, blocks the host here -- correct, just not overlapped)
             with torch.cuda.stream(comm):
                 _, need_div = _mean_inplace(flat.buffer[:n_late], world, None)
+            if "sync_between" in set(args.debug_two_graphs.split(",")):
+                torch.cuda.synchronize()
             if graph_b is not None:
                 graph_b.replay()
             else:
@@ -270,8 +316,17 @@ def main():
             else:
                 opt.step()
 
-    for _ in range(args.warmup):
+    for it in range(args.warmup):
         run()
+        if args.dump_grads and it == 0:
+            torch.cuda.synchronize()
+            if rank == 0:
+                named = list(net.named_parameters()) + ([("head." + k, v) for k, v in head.named_parameters()] if head is not None else [])
+                torch.save({k: v.grad.detach().cpu().clone() for k, v in named if v.grad is not None}, args.dump_grads)
+            if world > 1:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
         if os.environ.get("CL3D_DP_DEBUG") == "1" and world > 1 and rank == 0:
             torch.cuda.synchronize()
             print("debug step: late %.9g early %.9g params %.12g" % (float(flat.buffer[:n_late].double().norm()), float(flat.buffer[n_late:].double().norm()),

@@ -21,14 +21,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-DCL3D_D2_FORM=0"]
 
 VARIANTS = {  # tag: (source file, extra defines)
-    "sup_sb8_w4": ("fused_pwmlp.hip", []),
-    "sup_sb4_w4": ("fused_pwmlp.hip", ["-DCL3D_SUP_SB=4"]),
-    "sup_sb6_w4": ("fused_pwmlp.hip", ["-DCL3D_SUP_SB=6"]),
-    "sup_sb8_w3": ("fused_pwmlp.hip", ["-DCL3D_SUP_WAVES=3"]),
-    "sup_sb12_w3": ("fused_pwmlp.hip", ["-DCL3D_SUP_SB=12", "-DCL3D_SUP_WAVES=3"]),
-    "sup_sb4_w5": ("fused_pwmlp.hip", ["-DCL3D_SUP_SB=4", "-DCL3D_SUP_WAVES=5"]),
-    "bq_rank0": ("ball_query_lds.hip", ["-DCL3D_TL_RANK=0"]),
-    "bq_qt2": ("ball_query_lds.hip", ["-DCL3D_TL_QT=2"]),
+    "sup_sb4": ("fused_pwmlp.hip", []),
+    "sup_sb4_late": ("fused_pwmlp.hip", ["-DCL3D_SUP_LATE=1"]),
+    "sup_sb6_late": ("fused_pwmlp.hip", ["-DCL3D_SUP_LATE=1", "-DCL3D_SUP_SB=6"]),
+    "sup_sb3_late": ("fused_pwmlp.hip", ["-DCL3D_SUP_LATE=1", "-DCL3D_SUP_SB=3"]),
+    "sup_sb2_late_w5": ("fused_pwmlp.hip", ["-DCL3D_SUP_LATE=1", "-DCL3D_SUP_SB=2", "-DCL3D_SUP_WAVES=5"]),
 }
 
 

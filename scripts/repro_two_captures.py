@@ -22,8 +22,7 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 from bench import make_config, synth_batch  # noqa: E402
 from bench_backbone import CONFIGS  # noqa: E402
 
-VARIANTS = ["baseline", "no_async", "no_fork_grads", "separate_pools", "sync_between", "async_a_only", "async_b_only",
-            "fresh_streams_b", "no_bq_cache"]
+VARIANTS = ["no_async", "async_a_only", "async_b_only", "baseline"]
 
 
 def run(config, variant, replays):
@@ -74,6 +73,10 @@ def run(config, variant, replays):
         return (torch.cat([p.grad.reshape(-1).double() for p in early]).clone(),
                 torch.cat([p.grad.reshape(-1).double() for p in late]).clone())
 
+    def per_param():
+        torch.cuda.synchronize()
+        return {n_: p.grad.detach().double().clone() for n_, p in params if id(p) not in late_ids}
+
     # reference: the same two-stage backward, eager, index streams off
     pt_utils.ASYNC_INDEX = False
     note("eager reference")
@@ -83,6 +86,7 @@ def run(config, variant, replays):
         compute_early()
         note("early done")
     ref_e, ref_l = grads()
+    ref_pp = per_param()
     note("reference gradients", float(ref_e.norm()), float(ref_l.norm()))
     # BatchNorm running statistics move with every forward; they do not enter training-mode outputs or gradients
 
@@ -96,7 +100,7 @@ def run(config, variant, replays):
     def capture(fn, pool, on):
         set_async(on)
         g = torch.cuda.CUDAGraph()
-        with closerlook3d_amd.whole_step_capture(False), torch.cuda.graph(g, pool=pool):
+        with closerlook3d_amd.whole_step_capture(False), torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
             fn()
         return g
 
@@ -128,8 +132,13 @@ def run(config, variant, replays):
         worst_e = max(worst_e, float((e - ref_e).abs().max() / ref_e.abs().max()))
         worst_l = max(worst_l, float((l_ - ref_l).abs().max() / ref_l.abs().max()))
         seen.append(float(e.norm()))
+    got_pp = per_param()
+    bad = sorted(((float((got_pp[k] - ref_pp[k]).abs().max() / (ref_pp[k].abs().max() + 1e-30)), k) for k in ref_pp),
+                 reverse=True)
     print(json.dumps({"config": config, "variant": variant, "early_worst_rel": worst_e, "late_worst_rel": worst_l,
-                      "early_norms_distinct": len(set(seen)), "replays": replays}), flush=True)
+                      "early_norms_distinct": len(set(seen)), "replays": replays,
+                      "worst_params": [(round(e, 6), k) for e, k in bad[:6]],
+                      "exact_params": sum(1 for e, _ in bad if e == 0.0), "n_params": len(bad)}), flush=True)
 
 
 if __name__ == "__main__":
