@@ -77,6 +77,19 @@ class Cl3dError(RuntimeError):
     pass
 
 
+class PwmlpPass(ctypes.Structure):
+    """cl3d_pwmlp_pass of include/cl3d.h (one C-ABI call per pass, csrc/pass.hip): field for field."""
+    _fields_ = (
+        [(n, _I) for n in ("B", "N", "M", "K", "C", "Co", "precision", "idx_ready", "csr_ready", "n_partials")]
+        + [(n, _F) for n in ("radius", "eps", "momentum")]
+        + [(n, _P) for n in ("query_xyz", "support_xyz", "query_mask", "support_mask", "idx", "idx_mask", "inv_off",
+                             "inv_slots", "bq_ws", "csr_ws", "gemm_ws", "gemm_ws_d", "gemm_ws_w")]
+        + [(n, _Z) for n in ("bq_ws_bytes", "csr_ws_bytes", "gemm_ws_bytes", "gemm_ws_bytes_b")]
+        + [(n, _P) for n in ("features", "W", "gamma", "beta", "running_mean", "running_var", "num_batches_tracked",
+                             "ght", "wr", "wcat", "ystar", "sy", "vec", "out", "kstar", "partial", "sums", "partial_b",
+                             "gout", "dz_cm", "dz_t", "qtab", "hit", "coef", "dwr", "dght", "dfeat", "dW", "ts_cm")])
+
+
 def _declare(handle):
     handle.cl3d_abi_version.restype = _I
     handle.cl3d_abi_version.argtypes = []
@@ -89,6 +102,10 @@ def _declare(handle):
     for name, argtypes in SIGNATURES.items():
         fn = getattr(handle, name)
         fn.argtypes = argtypes
+        fn.restype = _I
+    for name in ("cl3d_pwmlp_train_forward", "cl3d_pwmlp_train_backward"):
+        fn = getattr(handle, name)
+        fn.argtypes = [ctypes.POINTER(PwmlpPass), _P]
         fn.restype = _I
 
 

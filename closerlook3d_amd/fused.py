@@ -10,6 +10,7 @@ cover (non-shipped variants such as PosPool with max reduction or a two-layer Ad
 'grouped' dataflow instead -- still on the engine's native ops -- and `impl='fused'` raises for them.
 """
 import contextlib
+import ctypes
 import os
 
 import torch
@@ -86,30 +87,7 @@ def _fork_join(device, side_fn, main_fn):
         side_fn()
         main_fn()
         return
-    _FORK_COUNT[0] += 1
-    if _FORK_ONLY is not None and _FORK_COUNT[0] not in _FORK_ONLY:  # (debug: only the named fork episodes of a capture)
-        side_fn()
-        main_fn()
-        return
-    main = torch.cuda.current_stream(device)
-    if _FORK_MODE == 'fresh':  # (debug: a stream no earlier fork of this capture has touched)
-        side = pt_utils.index_stream(device, 100 + _FORK_COUNT[0] % 64)
-    else:
-        side = pt_utils.index_stream(device, 2)
-    if _FORK_MODE == 'serial_side':  # (debug: both pieces on the side stream, one after the other)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            side_fn()
-            main_fn()
-        main.wait_stream(side)
-        return
-    if _FORK_MODE == 'after':  # (debug: the side piece is forked behind the caller's piece: never concurrent)
-        main_fn()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            side_fn()
-        main.wait_stream(side)
-        return
+    main, side = torch.cuda.current_stream(device), pt_utils.index_stream(device, 2)
     side.wait_stream(main)
     with torch.cuda.stream(side):
         side_fn()
@@ -117,25 +95,13 @@ def _fork_join(device, side_fn, main_fn):
         ev.record(side)
     main_fn()
     main.wait_event(ev)
-    if _FORK_MODE == 'rejoin':  # (debug: the side stream's tail follows the caller's stream again after the join)
-        side.wait_stream(main)
-
-
-_FORK_MODE = 'reuse'
-_FORK_COUNT = [0]
-_SCRATCH_TRACE = None
-_FORK_ONLY = None
 
 
 def _gemm_scratch(op, B, N, Co, C, device):
     """Scratch for the K-slice partials of a per-point contraction (cl3d_workspace_bytes(CL3D_OP_POINT_GEMM = 14 /
     CL3D_OP_CONV1X1 = 15)): (tensor, bytes); the tensor is kept alive by the caller until its launches are queued."""
     nbytes = _lib.lib().cl3d_workspace_bytes(op, B, N, Co, 0, C)
-    ws = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=device)
-    if _SCRATCH_TRACE is not None:  # (debug: scripts/bench_backbone.py --debug-two-graphs trace_scratch)
-        _SCRATCH_TRACE.append((ws.data_ptr(), int(nbytes), torch.cuda.current_stream(device).cuda_stream,
-                               bool(torch.cuda.is_current_stream_capturing()), (_FORK_COUNT[0], op, B, N, Co, C)))
-    return ws, nbytes
+    return torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=device), nbytes
 
 
 def _build_inverse(idx, n_support):
@@ -919,16 +885,138 @@ def point_rows(features, W, precision='f32'):
     return _PointRows.apply(features, W, PRECISIONS[precision])
 
 
+class _PointwiseMLPPass(Function):
+    """The whole PointWiseMLP operator in training mode -- ball query, CSR inverse, per-point product, statistics pass,
+    BatchNorm, activation; and its whole backward -- as ONE C-ABI call per direction (csrc/pass.hip,
+    cl3d_pwmlp_train_forward / _backward): the library enqueues every kernel itself, the geometry work and the weight
+    gradient on its own side streams.  This is the eager caller's path (the reference's unchanged training loop makes one
+    `_ext` call per autograd node, pt_utils.py:16-61): launched kernel by kernel from Python the host sets the pace
+    (0.41 ms per step at the metric shape, 0.59 ms with the forks made from Python), a captured step keeps the
+    Python-side schedule (`pointwise_mlp` below).  Same kernels, same arithmetic, same bits as that path."""
+
+    @staticmethod
+    def forward(ctx, features, W, gamma, beta, running_mean, running_var, num_batches_tracked, query_xyz, support_xyz,
+                query_mask, support_mask, radius, nsample, momentum, eps, precision, need_grad):
+        B, C, N = features.shape
+        M, K, Co = query_xyz.shape[1], int(nsample), W.shape[0]
+        dev = features.device
+        lib = _lib.lib()
+        f32 = dict(dtype=torch.float32, device=dev)
+        p = _lib.PwmlpPass()
+        keep = {}  # every buffer the argument block points at stays alive on the autograd node
+
+        def buf(name, shape, dtype=torch.float32):
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            keep[name] = t
+            setattr(p, name, t.data_ptr())
+            return t
+
+        def ref(name, t):
+            keep[name] = t
+            setattr(p, name, t.data_ptr() if t is not None else None)
+
+        p.B, p.N, p.M, p.K, p.C, p.Co, p.precision = B, N, M, K, C, Co, precision
+        p.radius, p.eps, p.momentum = float(radius), float(eps), float(momentum)
+        for name, t in (("query_xyz", query_xyz), ("support_xyz", support_xyz), ("query_mask", query_mask),
+                        ("support_mask", support_mask), ("features", features), ("W", W), ("gamma", gamma), ("beta", beta),
+                        ("running_mean", running_mean), ("running_var", running_var),
+                        ("num_batches_tracked", num_batches_tracked)):
+            ref(name, t)
+        idx = buf("idx", (B, M, K), torch.int32)
+        buf("idx_mask", (B, M, K), torch.int32)
+        p.idx_ready = p.csr_ready = 0
+        p.bq_ws_bytes = lib.cl3d_workspace_bytes(1, B, N, M, K, 0)  # CL3D_OP_BALL_QUERY
+        if p.bq_ws_bytes:
+            buf("bq_ws", (p.bq_ws_bytes,), torch.uint8)
+        if need_grad:
+            buf("inv_off", (B, N + 1), torch.int32)
+            buf("inv_slots", (B, M * K), torch.int32)
+            p.csr_ws_bytes = lib.cl3d_workspace_bytes(11, B, N, M * K, 1, 0)  # CL3D_OP_INVERSE_INDEX
+            buf("csr_ws", (max(p.csr_ws_bytes, 1),), torch.uint8)
+        p.gemm_ws_bytes = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)
+        buf("gemm_ws", (max(p.gemm_ws_bytes, 1),), torch.uint8)
+        buf("ght", (B, N, 2 * Co))
+        buf("wr", (Co, 3))
+        buf("wcat", (2 * Co, C))
+        buf("ystar", (B, M, Co))
+        buf("sy", (B, M, Co))
+        buf("kstar", (B, M, Co), torch.uint8)
+        p.n_partials = lib.cl3d_pwmlp_partials(B, M, Co)
+        buf("partial", (p.n_partials, Co, 8), torch.float64)
+        buf("vec", (4, Co))
+        buf("sums", (Co, 6), torch.float64)
+        out = buf("out", (B, Co, M))
+        with _lib.on_device(dev):
+            _lib.check(lib.cl3d_pwmlp_train_forward(ctypes.byref(p), _stream(features)))
+        ctx.block, ctx.keep, ctx.need = p, keep, need_grad
+        del f32
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        p, keep = ctx.block, ctx.keep
+        B, N, M, K, C, Co = p.B, p.N, p.M, p.K, p.C, p.Co
+        dev = gout.device
+        lib = _lib.lib()
+
+        def buf(name, shape, dtype=torch.float32):
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            keep[name] = t
+            setattr(p, name, t.data_ptr())
+            return t
+
+        gout = gout.contiguous()
+        keep["gout"] = gout
+        p.gout = gout.data_ptr()
+        buf("dz_cm", (B, Co, M))
+        buf("ts_cm", (B, Co, M), torch.int32)
+        buf("dz_t", (B, M, Co))
+        buf("qtab", (B, M, 4))
+        buf("partial_b", (p.n_partials, Co, 8), torch.float64)
+        buf("hit", (B, Co, N))
+        coef = buf("coef", (5, Co))
+        buf("dwr", (Co, 3))
+        buf("dght", (B, N, 2 * Co))
+        p.gemm_ws_bytes_b = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)
+        buf("gemm_ws_d", (max(p.gemm_ws_bytes_b, 1),), torch.uint8)
+        buf("gemm_ws_w", (max(p.gemm_ws_bytes_b, 1),), torch.uint8)
+        dfeat = buf("dfeat", (B, C, N)) if ctx.needs_input_grad[0] else None
+        dW = buf("dW", (Co, 3 + 2 * C)) if ctx.needs_input_grad[1] else None
+        if dfeat is None:
+            p.dfeat = None
+        if dW is None:
+            p.dW = None
+        with _lib.on_device(dev):
+            _lib.check(lib.cl3d_pwmlp_train_backward(ctypes.byref(p), _stream(gout)))
+        ctx.keep = None  # (the buffers die with this frame: everything that used them is queued in front of what reuses them)
+        return (dfeat, dW, coef[3], coef[4]) + (None,) * 13
+
+
+# the one-call-per-pass path is taken outside HIP-graph capture, for a stand-alone operator (no per-forward ball-query
+# memo: a backbone that shares geometry between its blocks keeps the kernel-by-kernel path, which shares it)
+PASS_CALLS = True
+
+
+def _use_pass_calls(training, need_grad, bn):
+    return (PASS_CALLS and training and need_grad and pt_utils._BQ_CACHE is None and pt_utils.ASYNC_INDEX == 'auto'
+            and not torch.cuda.is_current_stream_capturing() and bn.running_mean is not None and bn.track_running_stats
+            and POINT_GEMM == 'mfma')
+
+
 def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps, reduction,
                   training, precision='f32'):
     assert reduction == 'max'
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     conv, bn = mlps.conv0[0], mlps.conv0[1]
     need_grad = training and _wants_grad(features, conv.weight, bn.weight, bn.bias)
-    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad)
     C = features.shape[1]
     Co = conv.weight.shape[0]
     W = conv.weight.view(Co, 3 + 2 * C)
+    if _use_pass_calls(training, need_grad, bn):
+        return _PointwiseMLPPass.apply(features, W.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                       _step_counter(bn), query_xyz, support_xyz, query_mask, support_mask, radius,
+                                       nsample, bn.momentum, bn.eps, PRECISIONS[precision], True)
+    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad)
     ght, wr = point_rows(features, W, precision)
     use_batch_stats = training or bn.running_mean is None
     momentum = bn.momentum  # never None here: use_fused() sends that configuration to the grouped path

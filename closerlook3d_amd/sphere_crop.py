@@ -108,12 +108,15 @@ class SceneCropper:
             out["labels"] = self.labels[input_inds].to(torch.int64)
         return out
 
-    def _crop_native(self, pick_point, generator, cap=None):
+    def _crop_native(self, pick_point, generator, cap=None, u=None):
+        """One `self._ws` scratch serves query() and crop(): a cropper is used from ONE stream / thread at a time (as a
+        dataset worker does); two concurrent users need two croppers."""
         from . import _lib
         lib = _lib.lib()
         N = self.num_points
         sorted_idx, count, arr = self._sorted_scene(pick_point, cap)
-        u = torch.rand((2, N), device=self.device, generator=generator)  # the sample's draws: shuffle keys, re-draws
+        if u is None:  # the sample's draws: shuffle keys, re-draws -- made ONCE per sample: a retry with a larger sort
+            u = torch.rand((2, N), device=self.device, generator=generator)  # capacity reuses them (ADVICE r3)
         points = torch.empty((N, 3), dtype=torch.float32, device=self.device)
         mask = torch.empty((N,), dtype=torch.int32, device=self.device)
         inds = torch.empty((N,), dtype=torch.int64, device=self.device)
@@ -131,9 +134,9 @@ class SceneCropper:
         n = int(count)  # checked once everything is queued
         if n == 0:
             raise RuntimeError("sphere crop: no scene point within in_radius of the pick point")
-        if n > sorted_idx.numel():  # the sphere held more points than the sort was sized for (the draws are spent)
-            return self._crop_native(pick_point, generator, cap=self.points64.shape[0])
-        return out
+        if n > sorted_idx.numel():  # the sphere held more points than the sort was sized for: again, same draws --
+            return self._crop_native(pick_point, generator, cap=self.points64.shape[0], u=u)  # the generator's stream
+        return out                                                                          # does not depend on `cap`
 
     def project(self, points, chunk=None, budget_bytes=1 << 30):
         """Index of the nearest sub-sampled point for every ORIGINAL scene point (`datasets/S3DIS.py:262-270`:

@@ -35,7 +35,7 @@ extern "C" {
 /* 2: round 3 -- cl3d_pwmlp_bwd_rows / cl3d_pwmlp_bwd_support changed their argument lists (query table and
  * point-major dz rows); the round-2 changes to bn_relu_stats / fused_reduce / pwmlp_* had been made under version 1
  * 3: round 4 -- cl3d_pwmlp_support_summary / cl3d_pwmlp_bwd_support_sum are gone (cl3d_pwmlp_bwd_support is the one
- * support-major pass again, same argument list as in version 2) */
+ * support-major pass again, same argument list as in version 2); cl3d_pwmlp_train_forward / _backward added */
 #define CL3D_ABI_VERSION 3
 
 #define CL3D_OK 0
@@ -375,6 +375,38 @@ int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const float *cA, c
                            const float *qtab, const float *support_xyz, float radius,
                            const int32_t *inv_off, const int32_t *inv_slots, int B, int N, int M, int K, int Co,
                            float *dght, cl3d_stream_t stream);
+
+/* ---- one call per PASS (round 4; csrc/pass.hip).  A PointWiseMLP LocalAggregation in training mode -- ball query, CSR
+ * inverse, per-point product, statistics pass, BatchNorm, activation; backward: rows pass, BatchNorm backward, arg-max
+ * scatter, support-major pass, both gradient products -- enqueued by ONE call per direction, the geometry work and the
+ * weight gradient forked onto streams the library owns and joined by stream-side event waits (the host never waits).
+ * What the reference's eager training loop sees is then what it sees of its own extension: one `_ext`-sized call per
+ * autograd node (pt_utils.py:16-61).  Every buffer is the caller's; shapes as in the per-kernel entry points above:
+ *   idx, idx_mask [B,M,K] (idx_ready != 0: already computed, only read); inv_off [B,N+1] / inv_slots [B,M*K] (NULL: no
+ *   backward will follow; csr_ready != 0: already built); bq_ws / csr_ws / gemm_ws*: cl3d_workspace_bytes of
+ *   CL3D_OP_BALL_QUERY / _INVERSE_INDEX / _POINT_GEMM; vec [4,Co] = scale, shift, mean, invstd; coef [5,Co] = A, Bc, D,
+ *   d gamma, d beta; n_partials = cl3d_pwmlp_partials(B, M, Co) for both partial buffers ([n_partials, Co, 8] doubles).
+ * Every fork is joined (stream-side) before the call that made it returns: buffers may be released in stream order. */
+typedef struct cl3d_pwmlp_pass {
+  int B, N, M, K, C, Co, precision, idx_ready, csr_ready, n_partials;
+  float radius, eps, momentum;
+  const float *query_xyz, *support_xyz;
+  const int32_t *query_mask, *support_mask;
+  int32_t *idx, *idx_mask, *inv_off, *inv_slots;
+  void *bq_ws, *csr_ws, *gemm_ws, *gemm_ws_d, *gemm_ws_w;
+  size_t bq_ws_bytes, csr_ws_bytes, gemm_ws_bytes, gemm_ws_bytes_b;
+  const float *features, *W, *gamma, *beta;
+  float *running_mean, *running_var;
+  int64_t *num_batches_tracked;
+  float *ght, *wr, *wcat, *ystar, *sy, *vec, *out;
+  unsigned char *kstar;
+  double *partial, *sums, *partial_b;
+  const float *gout;
+  float *dz_cm, *dz_t, *qtab, *hit, *coef, *dwr, *dght, *dfeat, *dW;
+  int32_t *ts_cm;
+} cl3d_pwmlp_pass;
+int cl3d_pwmlp_train_forward(const cl3d_pwmlp_pass *p, cl3d_stream_t stream);
+int cl3d_pwmlp_train_backward(const cl3d_pwmlp_pass *p, cl3d_stream_t stream);
 
 #ifdef __cplusplus
 }

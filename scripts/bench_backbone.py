@@ -61,10 +61,11 @@ def main():
     ap.add_argument("--overlap-forks", default="", choices=["", "a", "b", "both", "none"],
                     help="--overlap: which of the two graphs keeps the side-stream forks (default a; b / both = the "
                          "configuration that gives wrong early-stage gradients, kept to reproduce it)")
-    ap.add_argument("--debug-two-graphs", default="", help="comma list of: sync_between (device sync between the replays of "
-                    "graph A and graph B), own_pool (graph B in a memory pool of its own), fresh_streams (graph B forks onto "
-                    "streams graph A never saw), eager_b (graph B's work launched eagerly with the forks on)")
-    ap.add_argument("--fork-mode", default="reuse", choices=["reuse", "fresh", "rejoin", "serial_side", "after"], help="debug: closerlook3d_amd.fused._FORK_MODE")
+    ap.add_argument("--debug-two-graphs", default="", help="two-graph reproducer, comma list of: sync_between (device sync between the replays "
+                    "of graph A and graph B), own_pool (graph B in a memory pool of its own), fresh_streams (graph B forks "
+                    "onto streams graph A never saw)")
+    ap.add_argument("--fork-mode", default="reuse", choices=["reuse", "serial_side", "after"],
+                    help="two-graph reproducer: how a forked pair of gradient products is laid out (reuse = shipped)")
     ap.add_argument("--fork-only", default="", help="debug: comma list of fork episodes (1-based, counted from graph B's capture) that fork")
     ap.add_argument("--dump-grads", default="", help="rank 0: after the FIRST step save {parameter name: gradient} here and exit")
     ap.add_argument("--lead-kernel", action="store_true",
@@ -99,7 +100,38 @@ def main():
     from closerlook3d_amd import backbones as _bb
     _bb._BLOCK_ENGINE, _bb._DECODE, _bb._FUSE_BOTTLENECK = args.block, args.decode, not args.layerwise
     from closerlook3d_amd import fused as _fu
-    _fu._FORK_MODE = args.fork_mode
+    from closerlook3d_amd import pt_utils as _put
+    _fork_shipped, _fork_count = _fu._fork_join, [0]
+
+    def _fork_debug(device, side_fn, main_fn):
+        """The engine's fork / join of two gradient products with the reproducer's switches: only some
+        episodes of a capture fork; the two pieces one behind the other on the same two streams instead of side by side."""
+        if not (_fu.FORK_GRADS and device.type == 'cuda' and _put.async_index()):
+            return _fork_shipped(device, side_fn, main_fn)
+        _fork_count[0] += 1
+        if fork_only is not None and _fork_count[0] not in fork_only:
+            side_fn()
+            main_fn()
+            return
+        main, side = torch.cuda.current_stream(device), _put.index_stream(device, 2)
+        if args.fork_mode == "serial_side":  # both pieces on the side stream, one after the other
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                side_fn()
+                main_fn()
+            main.wait_stream(side)
+        elif args.fork_mode == "after":  # the side piece forked behind the caller's piece: never concurrent
+            main_fn()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                side_fn()
+            main.wait_stream(side)
+        else:
+            _fork_shipped(device, side_fn, main_fn)
+
+    fork_only = {int(t) for t in args.fork_only.split(",")} if args.fork_only else None
+    if fork_only is not None or args.fork_mode != "reuse":
+        _fu._fork_join = _fork_debug
     from closerlook3d_amd.backbones import ResNet
     from closerlook3d_amd.dp import FlatGradients
     from closerlook3d_amd.pt_utils import ball_query_cache
@@ -238,30 +270,13 @@ def main():
                                 forks=args.overlap_forks in ("a", "both"))
                 dbg = set(filter(None, args.debug_two_graphs.split(",")))
                 if "fresh_streams" in dbg:
-                    from closerlook3d_amd import pt_utils as _pu3
-                    _pu3._INDEX_STREAMS.clear()
-                _fu._FORK_COUNT[0] = 0
-                if args.fork_only:
-                    _fu._FORK_ONLY = {int(t) for t in args.fork_only.split(",")}
-                if "trace_scratch" in dbg:
-                    _fu._SCRATCH_TRACE = []
-                if "eager_b" in dbg:
-                    from closerlook3d_amd import pt_utils as _pu3
-                    _pu3.ASYNC_INDEX = True if args.overlap_forks in ("b", "both") else False
-                    graph_b = None
-                else:
+                    _put._INDEX_STREAMS.clear()
+                _fork_count[0] = 0
+                if True:
                     graph_b = capture(compute_early, pool=None if "own_pool" in dbg else graph.pool(), warm=False,
                                       forks=args.overlap_forks in ("b", "both"))
             else:
                 graph = capture(compute)
-            if overlap and _fu._SCRATCH_TRACE is not None and rank == 0:
-                tr = _fu._SCRATCH_TRACE
-                _fu._SCRATCH_TRACE = None
-                streams = sorted({t[2] for t in tr})
-                print("scratch allocations while graph B was captured: %d, streams %s" % (len(tr), streams), file=sys.stderr)
-                for k in range(len(tr)):
-                    p0, n0, s0, c0, what = tr[k]
-                    print("  #%d ptr %x bytes %d stream %x  (episode, op, B, N, Co, C) = %s" % (k, p0, n0, s0, what), file=sys.stderr)
             if world > 1:
                 update_graph = capture(opt.step)
         except Exception as e:

@@ -77,8 +77,10 @@ def test_invalid_arguments_return_codes_not_exit(libpath):
 
 def test_python_binding_table_covers_header():
     from closerlook3d_amd import _lib
-    names = set(_declared()) - {"cl3d_abi_version", "cl3d_last_error_string", "cl3d_workspace_bytes", "cl3d_d2_form"}
-    assert names == set(_lib.SIGNATURES), (names ^ set(_lib.SIGNATURES))
+    names = set(_declared()) - {"cl3d_abi_version", "cl3d_last_error_string", "cl3d_workspace_bytes", "cl3d_d2_form",
+                                "cl3d_pwmlp_pass"}
+    by_pointer = {"cl3d_pwmlp_train_forward", "cl3d_pwmlp_train_backward"}  # (argument block by pointer: _lib._declare)
+    assert names == set(_lib.SIGNATURES) | by_pointer, (names ^ (set(_lib.SIGNATURES) | by_pointer))
 
 
 def test_product_never_imports_oracle():
@@ -122,3 +124,19 @@ def test_cpu_tensors_rejected_like_the_reference():
         _ext.masked_ordered_ball_query(x, x, m, m, 0.1, 4)
     with pytest.raises(RuntimeError, match="CPU not supported"):
         _ext.group_points(torch.rand(1, 2, 8), torch.zeros(1, 2, 2, dtype=torch.int32))
+
+
+def test_pass_argument_block_matches_the_header(tmp_path):
+    """cl3d_pwmlp_pass (include/cl3d.h) against its ctypes mirror (_lib.PwmlpPass): size and the offset of every field, as the
+    C compiler lays the header's struct out."""
+    from closerlook3d_amd import _lib
+    fields = [n for n, _ in _lib.PwmlpPass._fields_]
+    src = tmp_path / "offsets.c"
+    src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "cl3d.h"\nint main(void) {\n'
+                   + '  printf("%zu\\n", sizeof(cl3d_pwmlp_pass));\n'
+                   + "".join(f'  printf("%zu\\n", offsetof(cl3d_pwmlp_pass, {n}));\n' for n in fields) + "  return 0;\n}\n")
+    exe = tmp_path / "offsets"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    assert got[0] == ctypes.sizeof(_lib.PwmlpPass)
+    assert got[1:] == [getattr(_lib.PwmlpPass, n).offset for n in fields]

@@ -1,0 +1,83 @@
+"""One C-ABI call per pass (csrc/pass.hip, fused._PointwiseMLPPass -- the eager caller's path; reference: one `_ext` call per
+autograd node, pt_utils.py:16-61) against the kernel-by-kernel path: the same kernels on the same inputs, so outputs, every
+gradient and the BatchNorm buffers must be BIT-equal -- over two training steps, for M == N, a strided layer (M != N),
+padded clouds and a channel count whose lane groups are not 16 wide; and the eager step through it must be repeatable."""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import default_config
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # B, N, M, K, C, radius, pad
+    (4, 1024, 1024, 16, 36, 0.15, 0.0),
+    (2, 2048, 512, 32, 64, 0.12, 0.1),
+    (3, 600, 600, 24, 72, 0.2, 0.1),
+]
+
+
+def _cloud(B, N, M, pad, seed):
+    from oracle import operators as oo
+    xyz, mask = oo.make_cloud(np.random.default_rng(seed), B, N, pad_frac=pad)
+    s, sm = torch.from_numpy(xyz).cuda(), torch.from_numpy(mask).cuda()
+    return s[:, :M].contiguous(), s, sm[:, :M].contiguous(), sm
+
+
+@pytest.mark.parametrize("B,N,M,K,C,radius,pad", CASES)
+def test_pass_calls_equal_the_kernel_by_kernel_path(B, N, M, K, C, radius, pad, monkeypatch):
+    from closerlook3d_amd import fused
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    q, s, qm, sm = _cloud(B, N, M, pad, seed=N + K)
+    torch.manual_seed(1)
+    feats = torch.randn(B, C, N, device="cuda")
+    probe = torch.randn(B, C, M, device="cuda")
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(fused, "PASS_CALLS", on)
+        torch.manual_seed(2)
+        cfg = default_config("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df"}, cl3d_impl="fused")
+        la = LocalAggregation(C, C, radius, K, cfg).cuda().train()
+        steps = []
+        for step in range(2):
+            la.zero_grad(set_to_none=True)
+            f = feats.clone().requires_grad_(True)
+            out = la(q, s, qm, sm, f)
+            took_pass = type(out.grad_fn).__name__.startswith("_PointwiseMLPPass")
+            assert took_pass == on
+            (out * probe).sum().backward()
+            steps.append([out.detach().clone(), f.grad.clone()] + [p.grad.clone() for p in la.parameters()]
+                         + [b.clone() for b in la.buffers()])
+        torch.cuda.synchronize()
+        res[on] = steps
+    for a_step, b_step in zip(res[True], res[False]):
+        assert len(a_step) == len(b_step)
+        for a, b in zip(a_step, b_step):
+            assert torch.equal(a, b), "the pass calls run the kernel-by-kernel path's kernels: the bits must agree"
+
+
+def test_pass_calls_are_repeatable_and_leave_nothing_in_flight():
+    """Twenty eager steps through the pass calls with the buffers of every step dropped at once (the allocator hands their
+    memory to the next step): every step's gradients equal the first step's, bit for bit -- a fork still writing into a
+    released buffer would show up here."""
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    B, N, K, C = 8, 2048, 32, 64
+    q, s, qm, sm = _cloud(B, N, N, 0.05, seed=3)
+    torch.manual_seed(4)
+    feats = torch.randn(B, C, N, device="cuda")
+    probe = torch.randn(B, C, N, device="cuda")
+    cfg = default_config("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df"}, cl3d_impl="fused")
+    la = LocalAggregation(C, C, 0.1, K, cfg).cuda().train()
+    first = None
+    for step in range(20):
+        la.zero_grad(set_to_none=True)
+        f = feats.clone().requires_grad_(True)
+        out = la(q, s, qm, sm, f)
+        (out * probe).sum().backward()
+        got = [f.grad.clone()] + [p.grad.clone() for p in la.parameters()]
+        del out, f
+        if first is None:
+            first = got
+        else:
+            for a, b in zip(got, first):
+                assert torch.equal(a, b), f"step {step} differs from step 0"

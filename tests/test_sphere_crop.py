@@ -121,3 +121,12 @@ def test_native_query_with_a_sort_smaller_than_the_sphere_falls_back_to_the_whol
     s = scene._crop_native(pick, gen, cap=64)                              # too small -> repeated with cap = P
     inds = s["input_inds"].cpu().numpy()
     assert np.array_equal(np.sort(inds), np.sort(want[:700])) if len(want) >= 700 else np.isin(inds, want).all()
+    #  the sample's random draws are made once: a retry with a larger sort capacity reuses them, so the
+    # sample -- and the generator's state after it -- does not depend on the capacity the first attempt happened to have
+    gen.manual_seed(4)
+    direct = scene._crop_native(pick, gen, cap=scene.points64.shape[0])
+    state_direct = gen.get_state().clone()
+    gen.manual_seed(4)
+    retried = scene._crop_native(pick, gen, cap=64)
+    assert torch.equal(gen.get_state(), state_direct)
+    assert torch.equal(retried["input_inds"], direct["input_inds"]) and torch.equal(retried["points"], direct["points"])
