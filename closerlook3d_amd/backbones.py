@@ -189,6 +189,14 @@ def _seg_classifier(width, nout):
                          nn.Conv1d(width // 2, nout, kernel_size=1, bias=True))
 
 
+def _classify(head, feats, impl, precision):
+    """A `_seg_classifier`: its Conv1d + BatchNorm1d + ReLU unit through the engine's kernels like every other such unit
+    (run_conv_bn) -- besides the fused BatchNorm passes this keeps the step reproducible: the library convolution's weight
+    gradient was the one result of a whole captured step that changed from replay to replay (profiles/r04) --
+    then the class-logit convolution (13 / <= 6 output channels, with a bias) as the module it is."""
+    return head[3](run_conv_bn(head[:3], feats, impl, precision))
+
+
 class SceneSegHeadResNet(_UpsampleDecoder):
     """logits (B, num_classes, N).  Reference: heads/segmentation_head.py:15-77."""
 
@@ -200,7 +208,7 @@ class SceneSegHeadResNet(_UpsampleDecoder):
         self.head = _seg_classifier(width, num_classes)
 
     def forward(self, end_points):
-        return self.head(self._decode(end_points))
+        return _classify(self.head, self._decode(end_points), self.impl, self.precision)
 
 
 class MultiPartSegHeadResNet(_UpsampleDecoder):
@@ -215,7 +223,7 @@ class MultiPartSegHeadResNet(_UpsampleDecoder):
 
     def forward(self, end_points):
         feats = self._decode(end_points)
-        return [head(feats) for head in self.multi_shape_heads]
+        return [_classify(head, feats, self.impl, self.precision) for head in self.multi_shape_heads]
 
 
 class MaskedGlobalAvgPool1d(nn.Module):

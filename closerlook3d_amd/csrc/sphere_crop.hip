@@ -138,12 +138,14 @@ __global__ __launch_bounds__(256) void crop_slot_keys_kernel(const float *__rest
 }
 
 __global__ __launch_bounds__(256) void crop_gather_kernel(const double *__restrict__ pts, const int *__restrict__ sorted_idx,
-                                                          const int *__restrict__ count, int N, double cx, double cy,
-                                                          double cz, const int *__restrict__ perm,
+                                                          const int *__restrict__ count, int cap, int N, double cx,
+                                                          double cy, double cz, const int *__restrict__ perm,
                                                           const float *__restrict__ u_redraw, float *__restrict__ out_points,
                                                           int *__restrict__ out_mask, long long *__restrict__ out_inds,
                                                           float *__restrict__ out_height) {
-  const int m = *count < N ? *count : N;
+  // *count > cap: the list was not written (the sort was sized for fewer points) -- nothing of it is read: every slot
+  // gets point 0 with mask 0 and the caller, who sees *count too, repeats the query with a larger cap
+  const int m = *count > cap ? 0 : (*count < N ? *count : N);
   for (int t = blockIdx.x * 256 + threadIdx.x; t < N; t += gridDim.x * 256) {
     int src = 0, mk = 0;
     if (m > 0) {
@@ -219,14 +221,14 @@ extern "C" int cl3d_sphere_crop_query(const double *points, int P, const double 
   return CL3D_OK;
 }
 
-extern "C" int cl3d_sphere_crop_assemble(const double *points, const int32_t *sorted_idx, const int32_t *count,
+extern "C" int cl3d_sphere_crop_assemble(const double *points, const int32_t *sorted_idx, const int32_t *count, int cap,
                                          int num_points, const double *pick, const float *u_shuffle,
                                          const float *u_redraw, float *out_points, int32_t *out_mask,
                                          int64_t *out_inds, float *out_height, void *ws, size_t ws_bytes,
                                          cl3d_stream_t stream) {
   using namespace cl3d;
   const int N = num_points;
-  CL3D_REQUIRE(N >= 1 && points && sorted_idx && count && pick && u_shuffle && u_redraw && out_points && out_mask &&
+  CL3D_REQUIRE(N >= 1 && cap >= 1 && points && sorted_idx && count && pick && u_shuffle && u_redraw && out_points && out_mask &&
                    out_inds && out_height,
                "sphere_crop_assemble: bad arguments");
   const size_t need = sphere_crop_workspace(N);
@@ -247,7 +249,7 @@ extern "C" int cl3d_sphere_crop_assemble(const double *points, const int32_t *so
   hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned *)keys_in, keys_out, (const int *)vals_in, perm,
                                            (unsigned)N, 0, 32, st);
   if (e != hipSuccess) return fail(CL3D_E_LAUNCH, "sphere_crop_assemble: radix sort: %s", hipGetErrorString(e));
-  hipLaunchKernelGGL(crop_gather_kernel, dim3(gx), dim3(256), 0, st, points, sorted_idx, count, N, pick[0], pick[1], pick[2],
+  hipLaunchKernelGGL(crop_gather_kernel, dim3(gx), dim3(256), 0, st, points, sorted_idx, count, cap, N, pick[0], pick[1], pick[2],
                      perm, u_redraw, out_points, out_mask, reinterpret_cast<long long *>(out_inds), out_height);
   return check_launch("cl3d_sphere_crop_assemble");
 }

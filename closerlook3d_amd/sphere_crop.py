@@ -122,8 +122,8 @@ class SceneCropper:
         inds = torch.empty((N,), dtype=torch.int64, device=self.device)
         height = torch.empty((N, 1), dtype=torch.float32, device=self.device)
         with _lib.on_device(self.device):
-            _lib.check(lib.cl3d_sphere_crop_assemble(self.points64.data_ptr(), sorted_idx.data_ptr(), count.data_ptr(), N,
-                                                     ctypes.cast(arr, ctypes.c_void_p), u[0].data_ptr(), u[1].data_ptr(),
+            _lib.check(lib.cl3d_sphere_crop_assemble(self.points64.data_ptr(), sorted_idx.data_ptr(), count.data_ptr(),
+                                                     sorted_idx.numel(), N, ctypes.cast(arr, ctypes.c_void_p), u[0].data_ptr(), u[1].data_ptr(),
                                                      points.data_ptr(), mask.data_ptr(), inds.data_ptr(), height.data_ptr(),
                                                      self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr(self.device)))
         out = {"points": points, "mask": mask, "input_inds": inds, "height": height}

@@ -142,14 +142,16 @@ int cl3d_dataset_grid_subsampling(const float *points, const float *features, co
  * points with rdist = (dx*dx + dy*dy) + dz*dz <= radius^2; sorted_idx [cap] receives them ordered by (float64 distance
  * sqrt(rdist), index) -- the tree's sorted in-radius list -- when *count <= cap (1 <= cap <= P: the host-known size of
  * the sort; cap = P always suffices, a smaller bound sorts less).  *count > cap: repeat with a larger cap.
- * assemble: one sample of num_points slots from (sorted_idx, count): m = min(*count, num_points) nearest points in
+ * assemble: one sample of num_points slots from (sorted_idx [cap], count) -- *count > cap (the list was not written):
+ * nothing of it is read, every slot gets point 0 with mask 0, the caller repeats the query -- otherwise
+ * m = min(*count, num_points) nearest points in
  * the order of their draws u_shuffle [num_points] (uniform [0,1), caller's RNG), then slots >= m re-draw one of them
  * by u_redraw; out_inds int64, out_mask, out_points = float32(point - pick), out_height = float32(z).
  * ws: cl3d_workspace_bytes(CL3D_OP_SPHERE_CROP, 1, P, 0, 0, 0) (query, any cap; also enough for assemble). */
 int cl3d_sphere_crop_query(const double *points, int P, const double *pick, double radius, int cap,
                            int32_t *sorted_idx, int32_t *count, void *ws, size_t ws_bytes, cl3d_stream_t stream);
-int cl3d_sphere_crop_assemble(const double *points, const int32_t *sorted_idx, const int32_t *count, int num_points,
-                              const double *pick, const float *u_shuffle, const float *u_redraw, float *out_points,
+int cl3d_sphere_crop_assemble(const double *points, const int32_t *sorted_idx, const int32_t *count, int cap,
+                              int num_points, const double *pick, const float *u_shuffle, const float *u_redraw, float *out_points,
                               int32_t *out_mask, int64_t *out_inds, float *out_height, void *ws, size_t ws_bytes,
                               cl3d_stream_t stream);
 

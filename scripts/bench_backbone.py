@@ -64,10 +64,17 @@ def main():
     ap.add_argument("--debug-two-graphs", default="", help="two-graph reproducer, comma list of: sync_between (device sync between the replays "
                     "of graph A and graph B), own_pool (graph B in a memory pool of its own), fresh_streams (graph B forks "
                     "onto streams graph A never saw)")
-    ap.add_argument("--fork-mode", default="reuse", choices=["reuse", "serial_side", "after"],
+    ap.add_argument("--fork-mode", default="reuse", choices=["reuse", "serial_side", "after", "probe"],
                     help="two-graph reproducer: how a forked pair of gradient products is laid out (reuse = shipped)")
     ap.add_argument("--fork-only", default="", help="debug: comma list of fork episodes (1-based, counted from graph B's capture) that fork")
     ap.add_argument("--dump-grads", default="", help="rank 0: after the FIRST step save {parameter name: gradient} here and exit")
+    ap.add_argument("--repeat-check", type=int, default=0, help="N > 1 ranks: replay the step this many times WITHOUT the "
+                    "parameter update (same parameters, same clouds: the same gradients every time) and count the distinct "
+                    "bit patterns of the exchanged gradient buffer, late and early part apart")
+    ap.add_argument("--comm-on-main", action="store_true", help="--overlap reproducer: the first bucket's exchange on the "
+                    "step's own stream (graph B starts behind it: no overlap)")
+    ap.add_argument("--dump-forward", default="", help="rank 0, with --no-graph: bit checksums of every module's output in the "
+                    "first step, in call order, as JSON (run-to-run determinism probe)")
     ap.add_argument("--lead-kernel", action="store_true",
                     help="--overlap: graph B starts with a trivial kernel on the capture stream, so that no forked branch "
                          "is a ROOT of the graph")
@@ -126,9 +133,31 @@ def main():
             with torch.cuda.stream(side):
                 side_fn()
             main.wait_stream(side)
+        elif args.fork_mode == "probe":
+            # ordering probe: the caller's stream counts the episode before the fork, the side stream counts it after its
+            # piece and compares -- equal whenever the fork edge (side after the caller's count) and the join edge (the
+            # caller's next count after the side's check) hold; the same again from the caller's side after the join
+            pr = _probe
+            if "c_main" not in pr:
+                raise RuntimeError("probe buffers must exist before the capture")
+            pr["c_main"].add_(1)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                pr["early"].add_((pr["c_side"] + 1 != pr["c_main"]).long())  # side started before the caller's count?
+                side_fn()
+                pr["c_side"].add_(1)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            main_fn()
+            main.wait_event(ev)
+            pr["late"].add_((pr["c_side"] != pr["c_main"]).long())  # the caller went on before the side's piece ended?
         else:
             _fork_shipped(device, side_fn, main_fn)
 
+    _probe = {}
+    if args.fork_mode == "probe":
+        for k_ in ("c_main", "c_side", "early", "late"):
+            _probe[k_] = torch.zeros(1, dtype=torch.int64, device=dev)
     fork_only = {int(t) for t in args.fork_only.split(",")} if args.fork_only else None
     if fork_only is not None or args.fork_mode != "reuse":
         _fu._fork_join = _fork_debug
@@ -284,7 +313,7 @@ def main():
             graph = update_graph = graph_b = None
             torch.cuda.synchronize()
     ar_events = []
-    comm = torch.cuda.Stream() if overlap else None
+    comm_stream = torch.cuda.Stream() if overlap else None
     from closerlook3d_amd.dp import _mean_inplace
 
     def run():
@@ -294,6 +323,7 @@ def main():
             else:
                 compute_late()
             main = torch.cuda.current_stream()
+            comm = main if args.comm_on_main else comm_stream
             comm.wait_stream(main)
             # the late-stage gradients leave while the early stages are differentiated: the collective is enqueued
             # behind graph A on `comm` (RCCL: the call returns at once, the stream waits for the result; gloo, the
@@ -325,14 +355,53 @@ def main():
                 flat.allreduce_mean(world)
                 e1.record()
                 ar_events.append((e0, e1))
-        if world > 1:
+        if world > 1 and not args.repeat_check:
             if update_graph is not None:
                 update_graph.replay()
             else:
                 opt.step()
 
+    if args.repeat_check and world > 1:
+        seen_late, seen_early, order, per_seen = {}, {}, [], {}
+        per_param = [(n_, p_) for n_, p_ in list(net.named_parameters()) + ([("head." + k, v) for k, v in head.named_parameters()] if head is not None else []) if p_.requires_grad]
+        for it in range(args.repeat_check):
+            run()
+            torch.cuda.synchronize()
+            bits = flat.buffer.view(torch.int32).long()
+            kl, ke = int(bits[:n_late].sum()), int(bits[n_late:].sum())
+            seen_late[kl] = seen_late.get(kl, 0) + 1
+            seen_early[ke] = seen_early.get(ke, 0) + 1
+            order.append((len(seen_late), len(seen_early)))
+            for n_, p_ in per_param:
+                per_seen.setdefault(n_, set()).add(int(p_.grad.view(torch.int32).long().sum()))
+        if rank == 0:
+            print(json.dumps({"repeat_check": args.repeat_check, "overlap": bool(overlap), "forks": args.overlap_forks,
+                              "debug": args.debug_two_graphs, "comm_on_main": args.comm_on_main, "graph": graph is not None,
+                              "pattern_late": max(seen_late, key=seen_late.get), "pattern_early": max(seen_early, key=seen_early.get),
+                              "distinct_late": sorted(seen_late.values(), reverse=True),
+                              "distinct_early": sorted(seen_early.values(), reverse=True),
+                              "varying_parameters": {k: len(v) for k, v in per_seen.items() if len(v) > 1},
+                              "probe": {k: int(v) for k, v in _probe.items()}}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    fwd_trace = []
+    if args.dump_forward and rank == 0:
+        def _bits(o):
+            if torch.is_tensor(o):
+                return [int(o.detach().contiguous().view(torch.int32).long().sum())] if o.dtype == torch.float32 else [int(o.long().sum())]
+            if isinstance(o, dict):
+                return [b for k in sorted(o) for b in _bits(o[k])]
+            if isinstance(o, (tuple, list)):
+                return [b for t in o for b in _bits(t)]
+            return []
+        for name_, mod_ in list(net.named_modules()) + ([("head." + k, v) for k, v in head.named_modules()] if head is not None else []):
+            mod_.register_forward_hook(lambda m_, i_, o_, name_=name_: fwd_trace.append((name_, _bits(o_))))
     for it in range(args.warmup):
         run()
+        if args.dump_forward and it == 0 and rank == 0:
+            with open(args.dump_forward, "w") as fh:
+                json.dump(fwd_trace, fh)
         if args.dump_grads and it == 0:
             torch.cuda.synchronize()
             if rank == 0:

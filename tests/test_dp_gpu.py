@@ -156,21 +156,34 @@ def test_bench_py_runs_data_parallel_on_one_device():
 def test_overlapped_step_with_its_forks_equals_the_single_stream_two_graph_step(tmp_path):
     """VERDICT r3 item 3b.  The overlapped exchange cuts the step into graph A (forward + late-stage backward) and graph B
     (early-stage backward).  Shipped mode: graph A keeps the engine's side-stream forks, graph B is single-stream
-    (scripts/bench_backbone.py, DESIGN 6: a forked pair of gradient products inside graph B corrupts results computed
-    before the fork).  Held here: every parameter gradient of the first step -- same parameters, same clouds -- is
-    bit-equal to the step whose two graphs have no fork at all, and `python scripts/bench_backbone.py --gpus 2` typed
-    as a plain command (no launcher: the script re-launches itself as two ranks) is what runs it."""
+    (scripts/bench_backbone.py, DESIGN 6: a forked pair of gradient products inside graph B gives replay-varying
+    early-stage gradients -- `--overlap-forks b --repeat-check 200` shows it within seconds).  Held here, with
+    `python scripts/bench_backbone.py --gpus 2` typed as a plain command (the script re-launches itself as two ranks):
+    sixty replays of the same step (same parameters, same clouds, no update in between) leave ONE bit pattern in the
+    exchanged gradient buffer, in its late and in its early part, for the shipped mode as for the step whose two graphs
+    have no fork at all -- and it is the same pattern in both, and every parameter gradient of a first step is bit-equal
+    between the two."""
     import torch
-    dumps = {}
+    dumps, lines = {}, {}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    base = [sys.executable, os.path.join(ROOT, "scripts", "bench_backbone.py"), "--gpus", "2", "--config", "modelnet_small",
+            "--warmup", "1", "--head", "--overlap"]
     for mode in ("none", "a"):
+        r = subprocess.run(base + ["--overlap-forks", mode, "--repeat-check", "60"], cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+        lines[mode] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert lines[mode]["graph"] is True, "the step was not captured"
+        assert lines[mode]["distinct_late"] == [60] and lines[mode]["distinct_early"] == [60], \
+            f"forks={mode}: gradients change from replay to replay: {lines[mode]['varying_parameters']}"
         out = tmp_path / f"grads_{mode}.pt"
-        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
-        env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-        cmd = [sys.executable, os.path.join(ROOT, "scripts", "bench_backbone.py"), "--gpus", "2", "--config", "modelnet_small",
-               "--warmup", "1", "--head", "--overlap", "--overlap-forks", mode, "--dump-grads", str(out)]
-        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        r = subprocess.run(base + ["--overlap-forks", mode, "--dump-grads", str(out)], cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=900)
         assert r.returncode == 0 and out.exists(), r.stdout[-1500:] + r.stderr[-3000:]
         dumps[mode] = torch.load(out)
+    assert lines["a"]["pattern_late"] == lines["none"]["pattern_late"]
+    assert lines["a"]["pattern_early"] == lines["none"]["pattern_early"]
     assert set(dumps["a"]) == set(dumps["none"]) and len(dumps["a"]) > 100
     for k, g in dumps["none"].items():
         assert torch.equal(dumps["a"][k], g), f"{k}: the forked graph A changes the gradient"
