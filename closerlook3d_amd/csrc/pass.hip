@@ -7,11 +7,12 @@
 // still (0.59 ms: stream guards, event objects and allocator bookkeeping cost more than the overlap returns).
 // cl3d_pwmlp_train_forward / _backward enqueue EVERY kernel of a pass from here, forks included:
 //
-//   forward    side 0: ball query                                caller's stream: weights + per-point product
-//              side 1: (behind the query) CSR inverse            ... joins the query: statistics pass, BatchNorm
-//                                                                     algebra, activation + transposition; joins the CSR
-//   backward   caller's stream: rows pass, BatchNorm backward algebra, arg-max scatter, support-major pass, data
-//              gradient of the per-point product   |   side 0: its weight gradient (joined)
+//   forward    caller's stream: ball query ... joins the product: statistics pass, BatchNorm algebra, activation +
+//              transposition; joins the CSR           |   side 0: weights + per-point product
+//                                                     |   side 1: (behind the query) CSR inverse
+//   backward   caller's stream: rows pass, BatchNorm backward algebra, arg-max scatter, support-major pass, weight
+//              gradient of the per-point product      |   side 0: its data gradient (joined)
+// (the longest chain never leaves the caller's stream: a forked piece starts one cross-queue hand-over late)
 //
 // The side streams and events belong to the library (one set per device, created on first use, non-blocking); a
 // stream waits for an event, never the host.  Every buffer -- outputs, intermediates kept for the backward pass,
@@ -74,25 +75,27 @@ extern "C" int cl3d_pwmlp_train_forward(const cl3d_pwmlp_pass *p, cl3d_stream_t 
   if (rt == nullptr) return fail(CL3D_E_LAUNCH, "pwmlp_train_forward: side streams could not be created");
   hipStream_t st = (hipStream_t)stream;
   const bool want_csr = p->inv_off != nullptr && !p->csr_ready;
-  // ---- forks: the geometry depends on the coordinates only
-  if (!p->idx_ready || want_csr) CL3D_TRY(hip_ok(hipEventRecord(rt->ev_in, st), "pwmlp_train_forward: event"));
-  if (!p->idx_ready) {
-    CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[0], rt->ev_in, 0), "pwmlp_train_forward: fork"));
+  // ---- the LONGEST chain stays on the caller's stream: ball query -> statistics pass -> BatchNorm -> activation.  A piece
+  // handed to a side stream starts one cross-queue hand-over (~10 us) late and its join is free once it has finished: so
+  // the per-point product (26 us, needs nothing of the geometry) is what forks, and it is done long before the query
+  // (55-62 us) is; the CSR build forks behind the query and is joined at the very end
+  CL3D_TRY(hip_ok(hipEventRecord(rt->ev_in, st), "pwmlp_train_forward: event"));
+  CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[0], rt->ev_in, 0), "pwmlp_train_forward: fork"));
+  CL3D_TRY(cl3d_pwmlp_point_gemm_fwd(p->features, p->W, p->B, p->C, p->N, p->Co, p->precision, p->ght, p->wr, p->wcat,
+                                     p->gemm_ws, p->gemm_ws_bytes, rt->side[0]));
+  CL3D_TRY(hip_ok(hipEventRecord(rt->ev_fork, rt->side[0]), "pwmlp_train_forward: event"));
+  if (!p->idx_ready)
     CL3D_TRY(cl3d_masked_ordered_ball_query(p->query_xyz, p->support_xyz, p->query_mask, p->support_mask, p->B, p->M, p->N,
-                                            p->radius, p->K, p->idx, p->idx_mask, p->bq_ws, p->bq_ws_bytes, rt->side[0]));
-    CL3D_TRY(hip_ok(hipEventRecord(rt->ev_bq, rt->side[0]), "pwmlp_train_forward: event"));
-  }
+                                            p->radius, p->K, p->idx, p->idx_mask, p->bq_ws, p->bq_ws_bytes, st));
   if (want_csr) {
     CL3D_REQUIRE(p->inv_slots != nullptr, "pwmlp_train_forward: null inv_slots");
-    CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[1], p->idx_ready ? rt->ev_in : rt->ev_bq, 0), "pwmlp_train_forward: fork"));
+    CL3D_TRY(hip_ok(hipEventRecord(rt->ev_bq, st), "pwmlp_train_forward: event"));
+    CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[1], rt->ev_bq, 0), "pwmlp_train_forward: fork"));
     CL3D_TRY(cl3d_build_inverse_index(p->idx, p->B, p->N, p->M * p->K, p->inv_off, p->inv_slots, p->csr_ws, p->csr_ws_bytes,
                                       rt->side[1]));
     CL3D_TRY(hip_ok(hipEventRecord(rt->ev_csr, rt->side[1]), "pwmlp_train_forward: event"));
   }
-  // ---- the per-point product beside the query, then the operator
-  CL3D_TRY(cl3d_pwmlp_point_gemm_fwd(p->features, p->W, p->B, p->C, p->N, p->Co, p->precision, p->ght, p->wr, p->wcat,
-                                     p->gemm_ws, p->gemm_ws_bytes, st));
-  if (!p->idx_ready) CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_bq, 0), "pwmlp_train_forward: join"));
+  CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_fork, 0), "pwmlp_train_forward: join"));
   CL3D_TRY(cl3d_pwmlp_stats(p->query_xyz, p->support_xyz, p->idx, p->ght, p->wr, p->gamma, p->B, p->N, p->M, p->K, p->Co,
                             p->radius, p->ystar, p->kstar, p->sy, p->partial, p->n_partials, st));
   float *scale = p->vec, *shift = p->vec + p->Co, *mean = p->vec + 2 * p->Co, *invstd = p->vec + 3 * p->Co;
@@ -100,9 +103,9 @@ extern "C" int cl3d_pwmlp_train_forward(const cl3d_pwmlp_pass *p, cl3d_stream_t 
                                      p->gamma, p->beta, p->running_mean, p->running_var, p->num_batches_tracked, scale, shift,
                                      mean, invstd, p->sums, st));
   CL3D_TRY(cl3d_pwmlp_apply(p->ystar, scale, shift, p->B, p->M, p->Co, p->out, st));
-  // the CSR build is joined HERE, behind ~100 us of operator kernels it finished beside (a stream-side wait on a completed
-  // event costs nothing outside a graph): nothing of this pass is still in flight on a side stream once the caller's
-  // stream has passed this point, so the caller may drop the buffers of a forward pass whose backward never runs
+  // the CSR build is joined HERE, behind ~100 us of operator kernels it finished beside: nothing of this pass is still in
+  // flight on a side stream once the caller's stream has passed this point, so the caller may drop the buffers of a
+  // forward pass whose backward never runs
   if (want_csr) CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_csr, 0), "pwmlp_train_forward: join"));
   return CL3D_OK;
 }
@@ -129,21 +132,22 @@ extern "C" int cl3d_pwmlp_train_backward(const cl3d_pwmlp_pass *p, cl3d_stream_t
   CL3D_TRY(cl3d_pwmlp_bwd_hits(p->dz_cm, p->ts_cm, p->B, p->N, p->M, Co, p->hit, st));
   CL3D_TRY(cl3d_pwmlp_bwd_support(p->ght, p->wr, cA, cB, cD, p->hit, p->dz_t, p->sy, p->qtab, p->support_xyz, p->radius,
                                   p->inv_off, p->inv_slots, p->B, p->N, p->M, p->K, Co, p->dght, st));
-  // ---- the two gradient products side by side
+  // ---- the two gradient products side by side: the longer one (weights: product + slice reduce, ~45 us) on the caller's
+  // stream, the data gradient (~25 us) on the side stream -- hand-over included it ends first, the join is free
   const bool fork = p->dW != nullptr && p->dfeat != nullptr;
-  hipStream_t wst = st;
+  hipStream_t dst = st;
   if (fork) {
     CL3D_TRY(hip_ok(hipEventRecord(rt->ev_fork, st), "pwmlp_train_backward: event"));
     CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[0], rt->ev_fork, 0), "pwmlp_train_backward: fork"));
-    wst = rt->side[0];
+    dst = rt->side[0];
   }
-  if (p->dW != nullptr)
-    CL3D_TRY(cl3d_pwmlp_point_gemm_bwd_weight(p->features, p->dght, p->dwr, p->B, p->C, p->N, Co, p->precision, p->dW,
-                                              p->gemm_ws_w, p->gemm_ws_bytes_b, wst));
-  if (fork) CL3D_TRY(hip_ok(hipEventRecord(rt->ev_w, wst), "pwmlp_train_backward: event"));
   if (p->dfeat != nullptr)
     CL3D_TRY(cl3d_pwmlp_point_gemm_bwd_data(p->dght, p->wcat, p->B, p->C, p->N, Co, p->precision, p->dfeat, p->gemm_ws_d,
-                                            p->gemm_ws_bytes_b, st));
+                                            p->gemm_ws_bytes_b, dst));
+  if (fork) CL3D_TRY(hip_ok(hipEventRecord(rt->ev_w, dst), "pwmlp_train_backward: event"));
+  if (p->dW != nullptr)
+    CL3D_TRY(cl3d_pwmlp_point_gemm_bwd_weight(p->features, p->dght, p->dwr, p->B, p->C, p->N, Co, p->precision, p->dW,
+                                              p->gemm_ws_w, p->gemm_ws_bytes_b, st));
   if (fork) CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_w, 0), "pwmlp_train_backward: join"));
   return CL3D_OK;
 }

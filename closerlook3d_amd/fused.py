@@ -133,8 +133,10 @@ def inverse_index(idx, n_support, prefetch=False):
     ev = None
     if prefetch and pt_utils.async_index():
         main, side = torch.cuda.current_stream(idx.device), pt_utils.index_stream(idx.device, 1)
+        if getattr(idx, '_cl3d_ready', None) is None:
+            side.wait_stream(main)  # an idx produced in line on the caller's stream: the build follows it
         with torch.cuda.stream(side):
-            wait_ready(idx)  # the ball query ran on this stream already; this covers a cached idx too
+            wait_ready(idx)  # the ball query ran on the index stream; this covers a cached idx too
             if not torch.cuda.is_current_stream_capturing():
                 idx.record_stream(side)  # read here: the allocator must not recycle it before this stream is done
             off, slots = _build_inverse(idx, n_support)
