@@ -75,6 +75,7 @@ __device__ __forceinline__ float pw_preact(const float w[3], float rx, float ry,
 }
 
 // (div_k / div_magic: cl3d_common.h)
+typedef float pw_f2 __attribute__((ext_vector_type(2)));
 
 // query-major gather passes.  Persistent blocks: tile = 4*QW*QPG queries of one cloud (every lane group walks QPG
 // queries of a tile one after the other).
@@ -151,11 +152,24 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
     // atomics, and half the VGPRs of double register accumulators, which the gather loop's occupancy needs
     constexpr int kFlushTiles = 8 / QPG;  // <= 8 queries x K slots per running float sum
     constexpr int NF = NACC > 0 ? 5 : 1;
-    float accf[NF][V], accr[3] = {0.f, 0.f, 0.f};
+    // (V == 4: the running sums live as two packed pairs per quantity -- the TRAIN walk below is v_pk_fma_f32 / v_pk_add_f32
+    // on channel pairs: per-element IEEE, the same bits as the scalar chain, two channels per VALU slot)
+    constexpr bool PK = V == 4 && MODE == PW_TRAIN;
+    constexpr int VA = PK ? 2 : V;
+    using acc_t = typename std::conditional<PK, pw_f2, float>::type;
+    acc_t accf[NF][VA];
+    float accr[3] = {0.f, 0.f, 0.f};
+    auto acc_get = [&](int p, int v) -> float {
+      if constexpr (PK) return accf[p][v >> 1][v & 1];
+      else return accf[p][v];
+    };
+    auto acc_zero = [&]() {
 #pragma unroll
-    for (int p = 0; p < NF; ++p)
+      for (int p = 0; p < NF; ++p)
 #pragma unroll
-      for (int v = 0; v < V; ++v) accf[p][v] = 0.f;
+        for (int v = 0; v < VA; ++v) accf[p][v] = acc_t(0.f);
+    };
+    acc_zero();
     int since_flush = 0;
     const int LVN = L * V * NACC;
     if constexpr (NACC > 0) {
@@ -176,7 +190,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
 #pragma unroll
       for (int p = 0; p < NF; ++p)
 #pragma unroll
-        for (int v = 0; v < V; ++v) f[p][v] = fold_groups(accf[p][v]) * (p >= 2 ? sgn[v] : 1.f);  // S_a held primed
+        for (int v = 0; v < V; ++v) f[p][v] = fold_groups(acc_get(p, v)) * (p >= 2 ? sgn[v] : 1.f);  // S_a held primed
       if (g == 0) {
         double *mine = red + (size_t)wave * LVN + cl * V * NACC;
 #pragma unroll
@@ -189,10 +203,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
       }
 #pragma unroll
       for (int p = 0; p < 3; ++p) accr[p] = 0.f;
-#pragma unroll
-      for (int p = 0; p < NF; ++p)
-#pragma unroll
-        for (int v = 0; v < V; ++v) accf[p][v] = 0.f;
+      acc_zero();
       since_flush = 0;
     };
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -358,6 +369,60 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
           kb[v] = 0;
           hs[v] = sgn[v] * hc.v[v];
         }
+        if constexpr (PK) {
+        if (q_on) {
+          pw_f2 w0[2], w1[2], w2[2], sg[2], h2[2], s2[2];
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            w0[h] = (pw_f2){ws[2 * h][0], ws[2 * h + 1][0]};
+            w1[h] = (pw_f2){ws[2 * h][1], ws[2 * h + 1][1]};
+            w2[h] = (pw_f2){ws[2 * h][2], ws[2 * h + 1][2]};
+            sg[h] = (pw_f2){sgn[2 * h], sgn[2 * h + 1]};
+            h2[h] = (pw_f2){hs[2 * h], hs[2 * h + 1]};
+            s2[h] = (pw_f2)(0.f);
+          }
+          walk([&](auto first, int k, const float4 &sr_, const Vec<V> &gr_) {
+            accr[0] += sr_.y;
+            accr[1] += sr_.z;
+            accr[2] += sr_.w;
+            const pw_f2 rx = (pw_f2)(sr_.y), ry = (pw_f2)(sr_.z), rz = (pw_f2)(sr_.w);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              pw_f2 t = __builtin_elementwise_fma(w0[h], rx, h2[h]);
+              t = __builtin_elementwise_fma(w1[h], ry, t);
+              t = __builtin_elementwise_fma(w2[h], rz, t);
+              const pw_f2 y = __builtin_elementwise_fma((pw_f2){gr_.v[2 * h], gr_.v[2 * h + 1]}, sg[h], t);
+              s2[h] += y;
+              accf[1][h] = __builtin_elementwise_fma(y, y, accf[1][h]);
+              accf[2][h] = __builtin_elementwise_fma(y, rx, accf[2][h]);
+              accf[3][h] = __builtin_elementwise_fma(y, ry, accf[3][h]);
+              accf[4][h] = __builtin_elementwise_fma(y, rz, accf[4][h]);
+#pragma unroll
+              for (int e = 0; e < 2; ++e) {
+                if (decltype(first)::value || y[e] > best[2 * h + e]) {  // first extreme
+                  best[2 * h + e] = y[e];
+                  kb[2 * h + e] = k;
+                }
+              }
+            }
+          });
+          Vec<V> ys, sy;
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            s2[h] *= sg[h];
+            accf[0][h] += s2[h];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              ys.v[2 * h + e] = sgn[2 * h + e] * best[2 * h + e];
+              sy.v[2 * h + e] = s2[h][e];
+            }
+          }
+          store_row<V>(a.ystar_t + orow, ys);
+          store_row<V>(a.sy_t + orow, sy);
+          *reinterpret_cast<unsigned *>(a.kstar_out + orow) =
+              (unsigned)kb[0] | ((unsigned)kb[1] << 8) | ((unsigned)kb[2] << 16) | ((unsigned)kb[3] << 24);
+        }
+        } else {
         if (q_on) {
         walk([&](auto first, int k, const float4 &sr_, const Vec<V> &gr_) {
           accr[0] += sr_.y;
@@ -397,6 +462,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
           a.kstar_out[orow] = (unsigned char)kb[0];
         }
         }  // q_on
+        }  // scalar walk
       } else {  // PW_FWD
         float best[V];
         int kb[V];
