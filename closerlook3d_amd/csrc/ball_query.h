@@ -23,11 +23,6 @@ int ball_query_tile(const float *query_xyz, const float *support_xyz, const int 
                     const int *support_mask, int B, int M, int N, float radius, int K, int *idx, int *idx_mask,
                     hipStream_t st);
 
-bool ball_query_tile1_applicable(int M, int N, int K);  // (ball_query_lds_v1.hip: the round-3 kernel, A/B timing)
-int ball_query_tile1(const float *query_xyz, const float *support_xyz, const int *query_mask,
-                     const int *support_mask, int B, int M, int N, float radius, int K, int *idx, int *idx_mask,
-                     hipStream_t st);
-
 // grid_subsample.hip
 size_t grid_subsampling_workspace(int B, int N);
 // csr.hip

@@ -267,11 +267,8 @@ extern "C" int cl3d_masked_ordered_ball_query(const float *query_xyz, const floa
   static const int pinned = [] {
     const char *e = getenv("CL3D_BQ_PATH");
     if (e == nullptr) return 0;
-    return strcmp(e, "tile") == 0 ? 1 : strcmp(e, "cells") == 0 ? 2 : strcmp(e, "exhaustive") == 0 ? 3 : strcmp(e, "tile1") == 0 ? 4 : 0;
+    return strcmp(e, "tile") == 0 ? 1 : strcmp(e, "cells") == 0 ? 2 : strcmp(e, "exhaustive") == 0 ? 3 : 0;
   }();
-  if (pinned == 4 && cl3d::ball_query_tile1_applicable(M, N, nsample))  // (round-3 form of the LDS-resident kernel: A/B timing only)
-    return cl3d::ball_query_tile1(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx,
-                                  idx_mask, st);
   // clouds whose cell-sorted copy fits one CU's LDS: one launch, no scratch, nothing but coordinates and results in HBM
   if ((pinned == 0 || pinned == 1) && cl3d::ball_query_tile_applicable(M, N, nsample))
     return cl3d::ball_query_tile(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx,

@@ -35,7 +35,8 @@ extern "C" {
 /* 2: round 3 -- cl3d_pwmlp_bwd_rows / cl3d_pwmlp_bwd_support changed their argument lists (query table and
  * point-major dz rows); the round-2 changes to bn_relu_stats / fused_reduce / pwmlp_* had been made under version 1
  * 3: round 4 -- cl3d_pwmlp_support_summary / cl3d_pwmlp_bwd_support_sum are gone (cl3d_pwmlp_bwd_support is the one
- * support-major pass again, same argument list as in version 2); cl3d_pwmlp_train_forward / _backward added */
+ * support-major pass again, same argument list as in version 2); cl3d_pwmlp_train_forward / _backward added (one call
+ * per pass, csrc/pass.hip); cl3d_sphere_crop_assemble takes the capacity of the index list it is handed */
 #define CL3D_ABI_VERSION 3
 
 #define CL3D_OK 0

@@ -27,9 +27,9 @@ timeout 900 python bench.py --precision bf16 --no-cpu-baseline 2>/dev/null | tee
 echo "== bench, eager launches" | tee -a $OUT/summary.txt
 timeout 900 python bench.py --no-graph --no-cpu-baseline --no-kernel-roofline 2>/dev/null | tee $OUT/bench_eager.json | cut -c1-260 | tee -a $OUT/summary.txt
 echo "== ball query: LDS-resident kernel vs cell grid through HBM (same op, pinned path)" | tee -a $OUT/summary.txt
-for p in tile tile1 cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
-for p in tile tile1 cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --n 1024 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
-for p in tile tile1 cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --mult 4.0 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
+for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
+for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --n 1024 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
+for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --mult 4.0 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
 echo "== step variants: the cell-grid ball query through HBM scratch, points stored in cell order (experiment)" | tee -a $OUT/summary.txt
 for v in "CL3D_BQ_PATH=cells" "CL3D_BENCH_SORTED=1"; do
   env $v timeout 300 python bench.py --no-cpu-baseline --no-kernel-roofline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('$v', 'ms_per_step', d['ms_per_step'])" | tee -a $OUT/step_variants.txt | tee -a $OUT/summary.txt
@@ -39,6 +39,12 @@ for m in gather_pitch gather_xyz; do
   [ -x scripts/micro/$m ] || (cd scripts/micro && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o $m $m.hip > /dev/null 2>&1)
   timeout 120 scripts/micro/$m | tee -a $OUT/micro_gathers.txt | tee -a $OUT/summary.txt
 done
+echo "== micro-benchmark: issue rate of packed FP32 against scalar FMA" | tee -a $OUT/summary.txt
+mkdir -p scripts/micro/var
+[ -x scripts/micro/var/pk_rate ] || (cd scripts/micro && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -o var/pk_rate pk_rate.hip > /dev/null 2>&1)
+timeout 120 scripts/micro/var/pk_rate | tee $OUT/micro_pk_rate.txt | tee -a $OUT/summary.txt
+echo "== eager step: host enqueue time against drained time (one C-ABI call per pass)" | tee -a $OUT/summary.txt
+timeout 300 python scripts/micro/eager_host.py 2>/dev/null | head -12 | tee $OUT/eager_host.txt | head -3 | tee -a $OUT/summary.txt
 echo "== rocprofv3 kernel trace of the same bench command" | tee -a $OUT/summary.txt
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o bench -- python $R/bench.py --no-cpu-baseline --precondition 0 > $R/$OUT/rocprof.log 2>&1); echo "rocprof rc=$?" | tee -a $OUT/summary.txt
 python scripts/kstats.py $OUT/prof/bench_kernel_stats.csv 100 40 | tee -a $OUT/summary.txt
@@ -99,6 +105,13 @@ echo "== data parallel on one device (2 ranks over gloo): backbone, flat exchang
 timeout 600 python scripts/bench_backbone.py --gpus 2 --config partnet_adaptive 2>/dev/null | grep '^{' | tail -1 | tee -a $OUT/summary.txt
 timeout 600 python scripts/bench_backbone.py --gpus 2 --config partnet_adaptive --overlap 2>/dev/null | grep '^{' | tail -1 | tee -a $OUT/summary.txt
 timeout 600 python bench.py --gpus 2 --no-cpu-baseline --no-kernel-roofline 2>/dev/null | grep '^{' | tail -1 | cut -c1-400 | tee -a $OUT/summary.txt
+echo "== two-graph step, 200 replays without the update: distinct bit patterns of the exchanged gradients (DESIGN 6)" | tee -a $OUT/summary.txt
+for cfg in "" "--overlap --overlap-forks none" "--overlap --overlap-forks a" "--overlap --overlap-forks b" "--overlap --overlap-forks b --fork-mode probe"; do
+  timeout 300 python scripts/bench_backbone.py --gpus 2 --config modelnet_small --warmup 1 --head $cfg --repeat-check 200 2>/dev/null | grep repeat_check | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); v=d['varying_parameters']
+print('[$cfg]', 'late', d['distinct_late'][:4], 'early', d['distinct_early'][:4], 'varying parameters', len(v), 'probe', d['probe'])" | tee -a $OUT/two_graph_repeat_check.txt | tee -a $OUT/summary.txt
+done
 echo "== config 2 layer by layer (--layerwise): the activated tensors between a bottleneck's layers materialised" | tee -a $OUT/summary.txt
 for prec in f32 bf16; do timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp --precision $prec --layerwise 2>/dev/null | tail -1 | tee -a $OUT/summary.txt; done
 echo "== dataset-side grid subsampling, voting, sphere crops" | tee -a $OUT/summary.txt
