@@ -48,6 +48,8 @@ SIGNATURES = {
     "cl3d_bn_add_relu_train_fwd": [_P, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P],
     "cl3d_bn_add_relu_bwd": [_P] * 10 + [_I, _I, _I, _I, ctypes.c_double, _P, _I, _P, _P, _P, _P, _P],
     "cl3d_pwmlp_partials": [_I, _I, _I],
+    "cl3d_pwmlp_pass_graphs": [_I],
+    "cl3d_pwmlp_pass_graph_stats": [_P, _P],
     "cl3d_pwmlp_point_gemm_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P],
     "cl3d_pwmlp_point_gemm_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_pwmlp_point_gemm_bwd_weight": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],

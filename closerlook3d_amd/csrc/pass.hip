@@ -18,7 +18,11 @@
 // stream waits for an event, never the host.  Every buffer -- outputs, intermediates kept for the backward pass,
 // scratch -- is the caller's (cl3d_pwmlp_pass): nothing is allocated here, and every fork is joined before the call
 // that made it returns (joined = the caller's stream waits; the host never does).
-// Inside a stream capture the same calls record the same forks as branches of the graph.
+// Inside a stream capture the same calls record the same forks as branches of the caller's graph; outside one, a pass
+// called twice in a row with a bit-identical argument block is captured into a launch graph of its own and replayed
+// from then on (run_pass below).
+#include <atomic>
+#include <cstring>
 #include <mutex>
 
 #include "cl3d_common.h"
@@ -27,6 +31,7 @@ namespace cl3d {
 
 struct PassRuntime {
   hipStream_t side[2] = {nullptr, nullptr};
+  hipStream_t cap = nullptr;  // launch graphs are captured here, never on the caller's stream (which may be the legacy one)
   hipEvent_t ev_in = nullptr, ev_bq = nullptr, ev_csr = nullptr, ev_fork = nullptr, ev_w = nullptr;
   bool ok = false;
 };
@@ -41,6 +46,7 @@ static PassRuntime *pass_runtime() {
   if (!r.ok) {
     bool good = true;
     for (int k = 0; k < 2; ++k) good = good && hipStreamCreateWithFlags(&r.side[k], hipStreamNonBlocking) == hipSuccess;
+    good = good && hipStreamCreateWithFlags(&r.cap, hipStreamNonBlocking) == hipSuccess;
     hipEvent_t *evs[5] = {&r.ev_in, &r.ev_bq, &r.ev_csr, &r.ev_fork, &r.ev_w};
     for (hipEvent_t *e : evs) good = good && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!good) return nullptr;
@@ -53,6 +59,79 @@ static int hip_ok(hipError_t e, const char *what) {
   return e == hipSuccess ? CL3D_OK : fail(CL3D_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
 }
 
+// ---- launch graphs.  An eager training loop calls a pass with the SAME argument block step after step (the caller's
+// caching allocator hands the same addresses to the same requests), and the host -- a dozen kernel launches and half a
+// dozen event calls per pass -- is what paces it.  The second time in a row a pass is called with a bit-identical block
+// its launches are captured (on the library's own stream) into a HIP graph, and every later call with that block is ONE
+// hipGraphLaunch on the caller's stream.  A kernel's behaviour depends on nothing but its arguments, all of which are in
+// the block (sizes, scalars, every pointer), so a replay IS the call it was captured from; a block seen once (varying
+// batch shapes, a caller that never repeats addresses) is enqueued directly as before.  A few graphs per direction and
+// device are kept, least recently used first out.
+constexpr int kGraphSlots = 8;
+struct PassGraphs {
+  std::mutex mu;
+  cl3d_pwmlp_pass key[kGraphSlots];
+  hipGraphExec_t exec[kGraphSlots] = {};
+  unsigned long long used[kGraphSlots] = {};
+  cl3d_pwmlp_pass last;
+  bool have_last = false;
+  unsigned long long tick = 0;
+};
+static PassGraphs g_graphs[2][64];
+static std::atomic<int> g_graphs_on{1};
+static std::atomic<long long> g_captures{0}, g_replays{0};
+
+template <class Enqueue>
+static int run_pass(int dir, const cl3d_pwmlp_pass *p, hipStream_t st, PassRuntime *rt, Enqueue &&enqueue) {
+  int dev = 0;
+  if (!g_graphs_on.load() || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return enqueue(st);
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return enqueue(st);  // inside the caller's own capture: the launches become nodes of ITS graph
+  }
+  PassGraphs &g = g_graphs[dir][dev];
+  std::lock_guard<std::mutex> lock(g.mu);
+  ++g.tick;
+  for (int k = 0; k < kGraphSlots; ++k)
+    if (g.exec[k] != nullptr && memcmp(&g.key[k], p, sizeof(*p)) == 0) {
+      g.used[k] = g.tick;
+      g_replays.fetch_add(1);
+      return hip_ok(hipGraphLaunch(g.exec[k], st), "pwmlp pass: graph launch");
+    }
+  if (!(g.have_last && memcmp(&g.last, p, sizeof(*p)) == 0)) {  // first sighting: launch directly, remember
+    g.last = *p;
+    g.have_last = true;
+    return enqueue(st);
+  }
+  // second sighting in a row: capture (nothing runs), instantiate, launch
+  int rc = hip_ok(hipStreamBeginCapture(rt->cap, hipStreamCaptureModeRelaxed), "pwmlp pass: begin capture");
+  if (rc != CL3D_OK) return rc;
+  rc = enqueue(rt->cap);
+  hipGraph_t graph = nullptr;
+  const hipError_t ee = hipStreamEndCapture(rt->cap, &graph);
+  if (rc == CL3D_OK) rc = hip_ok(ee, "pwmlp pass: end capture");
+  hipGraphExec_t exec = nullptr;
+  if (rc == CL3D_OK) rc = hip_ok(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), "pwmlp pass: instantiate");
+  if (graph != nullptr) (void)hipGraphDestroy(graph);
+  if (rc != CL3D_OK) {
+    (void)hipGetLastError();
+    g.have_last = false;
+    return rc;
+  }
+  int slot = 0;  // an empty slot, else the least recently used
+  for (int k = 0; k < kGraphSlots; ++k) {
+    if (g.exec[k] == nullptr) { slot = k; break; }
+    if (g.used[k] < g.used[slot]) slot = k;
+  }
+  if (g.exec[slot] != nullptr) (void)hipGraphExecDestroy(g.exec[slot]);
+  g.key[slot] = *p;
+  g.exec[slot] = exec;
+  g.used[slot] = g.tick;
+  g_captures.fetch_add(1);
+  return hip_ok(hipGraphLaunch(exec, st), "pwmlp pass: graph launch");
+}
+
 }  // namespace cl3d
 
 #define CL3D_TRY(call)             \
@@ -60,6 +139,17 @@ static int hip_ok(hipError_t e, const char *what) {
     const int rc_ = (call);        \
     if (rc_ != CL3D_OK) return rc_; \
   } while (0)
+
+static int enqueue_forward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::PassRuntime *rt);
+static int enqueue_backward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::PassRuntime *rt);
+
+extern "C" int cl3d_pwmlp_pass_graphs(int enable) { return cl3d::g_graphs_on.exchange(enable != 0 ? 1 : 0); }
+
+extern "C" int cl3d_pwmlp_pass_graph_stats(long long *captures, long long *replays) {
+  if (captures != nullptr) *captures = cl3d::g_captures.load();
+  if (replays != nullptr) *replays = cl3d::g_replays.load();
+  return CL3D_OK;
+}
 
 extern "C" int cl3d_pwmlp_train_forward(const cl3d_pwmlp_pass *p, cl3d_stream_t stream) {
   using namespace cl3d;
@@ -73,7 +163,11 @@ extern "C" int cl3d_pwmlp_train_forward(const cl3d_pwmlp_pass *p, cl3d_stream_t 
   if (p->B == 0) return CL3D_OK;
   PassRuntime *rt = pass_runtime();
   if (rt == nullptr) return fail(CL3D_E_LAUNCH, "pwmlp_train_forward: side streams could not be created");
-  hipStream_t st = (hipStream_t)stream;
+  return run_pass(0, p, (hipStream_t)stream, rt, [&](hipStream_t s) { return enqueue_forward(p, s, rt); });
+}
+
+static int enqueue_forward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::PassRuntime *rt) {
+  using namespace cl3d;
   const bool want_csr = p->inv_off != nullptr && !p->csr_ready;
   // ---- the LONGEST chain stays on the caller's stream: ball query -> statistics pass -> BatchNorm -> activation.  A piece
   // handed to a side stream starts one cross-queue hand-over (~10 us) late and its join is free once it has finished: so
@@ -120,7 +214,11 @@ extern "C" int cl3d_pwmlp_train_backward(const cl3d_pwmlp_pass *p, cl3d_stream_t
   if (p->B == 0) return CL3D_OK;
   PassRuntime *rt = pass_runtime();
   if (rt == nullptr) return fail(CL3D_E_LAUNCH, "pwmlp_train_backward: side streams could not be created");
-  hipStream_t st = (hipStream_t)stream;
+  return run_pass(1, p, (hipStream_t)stream, rt, [&](hipStream_t s) { return enqueue_backward(p, s, rt); });
+}
+
+static int enqueue_backward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::PassRuntime *rt) {
+  using namespace cl3d;
   const int Co = p->Co;
   const float *scale = p->vec, *shift = p->vec + Co, *mean = p->vec + 2 * Co, *invstd = p->vec + 3 * Co;
   float *cA = p->coef, *cB = p->coef + Co, *cD = p->coef + 2 * Co, *dgamma = p->coef + 3 * Co, *dbeta = p->coef + 4 * Co;

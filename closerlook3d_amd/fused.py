@@ -903,95 +903,98 @@ class _PointwiseMLPPass(Function):
         M, K, Co = query_xyz.shape[1], int(nsample), W.shape[0]
         dev = features.device
         lib = _lib.lib()
-        f32 = dict(dtype=torch.float32, device=dev)
         p = _lib.PwmlpPass()
-        keep = {}  # every buffer the argument block points at stays alive on the autograd node
-
-        def buf(name, shape, dtype=torch.float32):
-            t = torch.empty(shape, dtype=dtype, device=dev)
-            keep[name] = t
-            setattr(p, name, t.data_ptr())
-            return t
-
-        def ref(name, t):
-            keep[name] = t
-            setattr(p, name, t.data_ptr() if t is not None else None)
-
         p.B, p.N, p.M, p.K, p.C, p.Co, p.precision = B, N, M, K, C, Co, precision
         p.radius, p.eps, p.momentum = float(radius), float(eps), float(momentum)
-        for name, t in (("query_xyz", query_xyz), ("support_xyz", support_xyz), ("query_mask", query_mask),
-                        ("support_mask", support_mask), ("features", features), ("W", W), ("gamma", gamma), ("beta", beta),
-                        ("running_mean", running_mean), ("running_var", running_var),
-                        ("num_batches_tracked", num_batches_tracked)):
-            ref(name, t)
-        idx = buf("idx", (B, M, K), torch.int32)
-        buf("idx_mask", (B, M, K), torch.int32)
         p.idx_ready = p.csr_ready = 0
+        inputs = (features, W, gamma, beta, running_mean, running_var, num_batches_tracked, query_xyz, support_xyz,
+                  query_mask, support_mask)  # kept alive on the node: the argument block points into them
+        for name, t in zip(("features", "W", "gamma", "beta", "running_mean", "running_var", "num_batches_tracked",
+                            "query_xyz", "support_xyz", "query_mask", "support_mask"), inputs):
+            setattr(p, name, t.data_ptr())
         p.bq_ws_bytes = lib.cl3d_workspace_bytes(1, B, N, M, K, 0)  # CL3D_OP_BALL_QUERY
-        if p.bq_ws_bytes:
-            buf("bq_ws", (p.bq_ws_bytes,), torch.uint8)
-        if need_grad:
-            buf("inv_off", (B, N + 1), torch.int32)
-            buf("inv_slots", (B, M * K), torch.int32)
-            p.csr_ws_bytes = lib.cl3d_workspace_bytes(11, B, N, M * K, 1, 0)  # CL3D_OP_INVERSE_INDEX
-            buf("csr_ws", (max(p.csr_ws_bytes, 1),), torch.uint8)
-        p.gemm_ws_bytes = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)
-        buf("gemm_ws", (max(p.gemm_ws_bytes, 1),), torch.uint8)
-        buf("ght", (B, N, 2 * Co))
-        buf("wr", (Co, 3))
-        buf("wcat", (2 * Co, C))
-        buf("ystar", (B, M, Co))
-        buf("sy", (B, M, Co))
-        buf("kstar", (B, M, Co), torch.uint8)
+        p.csr_ws_bytes = lib.cl3d_workspace_bytes(11, B, N, M * K, 1, 0) if need_grad else 0  # CL3D_OP_INVERSE_INDEX
+        p.gemm_ws_bytes = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)  # CL3D_OP_POINT_GEMM
         p.n_partials = lib.cl3d_pwmlp_partials(B, M, Co)
-        buf("partial", (p.n_partials, Co, 8), torch.float64)
-        buf("vec", (4, Co))
-        buf("sums", (Co, 6), torch.float64)
-        out = buf("out", (B, Co, M))
+        # everything the pass leaves behind for its backward, and its scratch, is ONE allocation (the host sets the pace
+        # of an eager step: two dozen torch.empty calls cost ~40 us of it); `out` is a tensor of its own
+        arena = _Arena(p)
+        arena.add("idx", 4 * B * M * K)
+        arena.add("idx_mask", 4 * B * M * K)
+        arena.add("bq_ws", p.bq_ws_bytes)
+        if need_grad:
+            arena.add("inv_off", 4 * B * (N + 1))
+            arena.add("inv_slots", 4 * B * M * K)
+            arena.add("csr_ws", p.csr_ws_bytes)
+        arena.add("gemm_ws", p.gemm_ws_bytes)
+        arena.add("ght", 4 * B * N * 2 * Co)
+        arena.add("wr", 4 * Co * 3)
+        arena.add("wcat", 4 * 2 * Co * C)
+        arena.add("ystar", 4 * B * M * Co)
+        arena.add("sy", 4 * B * M * Co)
+        arena.add("kstar", B * M * Co)
+        arena.add("partial", 8 * p.n_partials * Co * 8)
+        arena.add("vec", 4 * 4 * Co)
+        arena.add("sums", 8 * Co * 6)
+        kept = arena.allocate(dev)
+        out = torch.empty((B, Co, M), dtype=torch.float32, device=dev)
+        p.out = out.data_ptr()
         with _lib.on_device(dev):
             _lib.check(lib.cl3d_pwmlp_train_forward(ctypes.byref(p), _stream(features)))
-        ctx.block, ctx.keep, ctx.need = p, keep, need_grad
-        del f32
+        ctx.block, ctx.keep, ctx.need = p, [inputs, kept, out], need_grad
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        p, keep = ctx.block, ctx.keep
-        B, N, M, K, C, Co = p.B, p.N, p.M, p.K, p.C, p.Co
+        p = ctx.block
+        B, N, M, C, Co = p.B, p.N, p.M, p.C, p.Co
         dev = gout.device
         lib = _lib.lib()
-
-        def buf(name, shape, dtype=torch.float32):
-            t = torch.empty(shape, dtype=dtype, device=dev)
-            keep[name] = t
-            setattr(p, name, t.data_ptr())
-            return t
-
         gout = gout.contiguous()
-        keep["gout"] = gout
         p.gout = gout.data_ptr()
-        buf("dz_cm", (B, Co, M))
-        buf("ts_cm", (B, Co, M), torch.int32)
-        buf("dz_t", (B, M, Co))
-        buf("qtab", (B, M, 4))
-        buf("partial_b", (p.n_partials, Co, 8), torch.float64)
-        buf("hit", (B, Co, N))
-        coef = buf("coef", (5, Co))
-        buf("dwr", (Co, 3))
-        buf("dght", (B, N, 2 * Co))
         p.gemm_ws_bytes_b = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)
-        buf("gemm_ws_d", (max(p.gemm_ws_bytes_b, 1),), torch.uint8)
-        buf("gemm_ws_w", (max(p.gemm_ws_bytes_b, 1),), torch.uint8)
-        dfeat = buf("dfeat", (B, C, N)) if ctx.needs_input_grad[0] else None
-        dW = buf("dW", (Co, 3 + 2 * C)) if ctx.needs_input_grad[1] else None
-        if dfeat is None:
-            p.dfeat = None
-        if dW is None:
-            p.dW = None
+        arena = _Arena(p)
+        arena.add("dz_cm", 4 * B * Co * M)
+        arena.add("ts_cm", 4 * B * Co * M)
+        arena.add("dz_t", 4 * B * M * Co)
+        arena.add("qtab", 16 * B * M)
+        arena.add("partial_b", 8 * p.n_partials * Co * 8)
+        arena.add("hit", 4 * B * Co * N)
+        arena.add("dwr", 4 * Co * 3)
+        arena.add("dght", 4 * B * N * 2 * Co)
+        arena.add("gemm_ws_d", p.gemm_ws_bytes_b)
+        arena.add("gemm_ws_w", p.gemm_ws_bytes_b)
+        scratch = arena.allocate(dev)
+        coef = torch.empty((5, Co), dtype=torch.float32, device=dev)
+        p.coef = coef.data_ptr()
+        dfeat = torch.empty((B, C, N), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dW = torch.empty((Co, 3 + 2 * C), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        p.dfeat = dfeat.data_ptr() if dfeat is not None else None
+        p.dW = dW.data_ptr() if dW is not None else None
         with _lib.on_device(dev):
             _lib.check(lib.cl3d_pwmlp_train_backward(ctypes.byref(p), _stream(gout)))
-        ctx.keep = None  # (the buffers die with this frame: everything that used them is queued in front of what reuses them)
+        del scratch  # (everything that used it is queued on -- or joined into -- the stream whose allocations reuse it)
+        ctx.keep = None
         return (dfeat, dW, coef[3], coef[4]) + (None,) * 13
+
+
+class _Arena:
+    """Named sub-buffers of ONE uint8 allocation, 256-byte aligned, their addresses written into the fields of an
+    argument block (a zero-size buffer keeps a valid, unused address)."""
+
+    def __init__(self, block):
+        self.block, self.items, self.size = block, [], 0
+
+    def add(self, name, nbytes):
+        self.items.append((name, self.size))
+        self.size += (max(int(nbytes), 1) + 255) & ~255
+
+    def allocate(self, device):
+        buf = torch.empty((self.size,), dtype=torch.uint8, device=device)
+        base = buf.data_ptr()
+        for name, off in self.items:
+            setattr(self.block, name, base + off)
+        return buf
 
 
 # the one-call-per-pass path is taken outside HIP-graph capture, for a stand-alone operator (no per-forward ball-query

@@ -410,6 +410,13 @@ typedef struct cl3d_pwmlp_pass {
 } cl3d_pwmlp_pass;
 int cl3d_pwmlp_train_forward(const cl3d_pwmlp_pass *p, cl3d_stream_t stream);
 int cl3d_pwmlp_train_backward(const cl3d_pwmlp_pass *p, cl3d_stream_t stream);
+/* Launch graphs of the two pass calls (csrc/pass.hip): outside a stream capture, a pass called twice in a row with a
+ * bit-identical argument block (an eager training loop in its steady state) is captured into a HIP graph on a stream
+ * of the library's and replayed by every later call with that block -- one hipGraphLaunch on the caller's stream instead
+ * of a dozen launches; a block seen once is enqueued directly.  _graphs(0) turns this off (returns the previous
+ * setting; default on); _graph_stats reports how many passes were captured / replayed since load (nullable). */
+int cl3d_pwmlp_pass_graphs(int enable);
+int cl3d_pwmlp_pass_graph_stats(long long *captures, long long *replays);
 
 #ifdef __cplusplus
 }

@@ -140,3 +140,21 @@ def test_pass_argument_block_matches_the_header(tmp_path):
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     assert got[0] == ctypes.sizeof(_lib.PwmlpPass)
     assert got[1:] == [getattr(_lib.PwmlpPass, n).offset for n in fields]
+
+
+def test_pass_calls_validate_their_argument_block_before_any_launch():
+    """cl3d_pwmlp_train_forward / _backward (csrc/pass.hip): a null block, bad sizes and a block with null buffers are
+    CL3D_E_INVALID with a message, not a fault -- checked without a GPU (nothing is launched before the checks pass)."""
+    from closerlook3d_amd import _lib
+    lib = _lib.lib()
+    assert lib.cl3d_pwmlp_train_forward(None, None) == -1
+    assert b"null argument block" in lib.cl3d_last_error_string()
+    assert lib.cl3d_pwmlp_train_backward(None, None) == -1
+    p = _lib.PwmlpPass()
+    assert lib.cl3d_pwmlp_train_forward(ctypes.byref(p), None) == -1  # all sizes zero
+    assert b"bad sizes" in lib.cl3d_last_error_string()
+    p.B, p.N, p.M, p.K, p.C, p.Co, p.radius = 2, 64, 64, 8, 16, 16, 0.1
+    assert lib.cl3d_pwmlp_train_forward(ctypes.byref(p), None) == -1  # every buffer null
+    assert b"null pointer" in lib.cl3d_last_error_string()
+    assert lib.cl3d_pwmlp_train_backward(ctypes.byref(p), None) == -1
+    assert b"null pointer" in lib.cl3d_last_error_string()

@@ -1,7 +1,11 @@
 """One C-ABI call per pass (csrc/pass.hip, fused._PointwiseMLPPass -- the eager caller's path; reference: one `_ext` call per
 autograd node, pt_utils.py:16-61) against the kernel-by-kernel path: the same kernels on the same inputs, so outputs, every
-gradient and the BatchNorm buffers must be BIT-equal -- over two training steps, for M == N, a strided layer (M != N),
-padded clouds and a channel count whose lane groups are not 16 wide; and the eager step through it must be repeatable."""
+gradient and the BatchNorm buffers must be BIT-equal -- over four training steps (the library captures a pass it sees twice
+in a row with an identical argument block into a launch graph and replays it from then on: direct, captured and replayed
+calls are all in the comparison), for M == N, a strided layer (M != N), padded clouds and a channel count whose lane groups
+are not 16 wide; and the eager step through it must be repeatable, with and without the launch graphs."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -39,7 +43,7 @@ def test_pass_calls_equal_the_kernel_by_kernel_path(B, N, M, K, C, radius, pad, 
         cfg = default_config("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df"}, cl3d_impl="fused")
         la = LocalAggregation(C, C, radius, K, cfg).cuda().train()
         steps = []
-        for step in range(2):
+        for step in range(4):
             la.zero_grad(set_to_none=True)
             f = feats.clone().requires_grad_(True)
             out = la(q, s, qm, sm, f)
@@ -56,7 +60,15 @@ def test_pass_calls_equal_the_kernel_by_kernel_path(B, N, M, K, C, radius, pad, 
             assert torch.equal(a, b), "the pass calls run the kernel-by-kernel path's kernels: the bits must agree"
 
 
-def test_pass_calls_are_repeatable_and_leave_nothing_in_flight():
+def _graph_stats():
+    from closerlook3d_amd import _lib
+    c, r = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    _lib.check(_lib.lib().cl3d_pwmlp_pass_graph_stats(ctypes.byref(c), ctypes.byref(r)))
+    return c.value, r.value
+
+
+@pytest.mark.parametrize("graphs", [1, 0])
+def test_pass_calls_are_repeatable_and_leave_nothing_in_flight(graphs):
     """Twenty eager steps through the pass calls with the buffers of every step dropped at once (the allocator hands their
     memory to the next step): every step's gradients equal the first step's, bit for bit -- a fork still writing into a
     released buffer would show up here."""
@@ -68,16 +80,25 @@ def test_pass_calls_are_repeatable_and_leave_nothing_in_flight():
     probe = torch.randn(B, C, N, device="cuda")
     cfg = default_config("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df"}, cl3d_impl="fused")
     la = LocalAggregation(C, C, 0.1, K, cfg).cuda().train()
+    from closerlook3d_amd import _lib
+    was = _lib.lib().cl3d_pwmlp_pass_graphs(graphs)
+    before = _graph_stats()
     first = None
     for step in range(20):
         la.zero_grad(set_to_none=True)
         f = feats.clone().requires_grad_(True)
         out = la(q, s, qm, sm, f)
         (out * probe).sum().backward()
-        got = [f.grad.clone()] + [p.grad.clone() for p in la.parameters()]
+        # bit checksums, nothing kept on the device between steps: the loop settles into the allocator's steady state
+        got = [int(t.view(torch.int32).long().sum()) for t in [f.grad] + [p.grad for p in la.parameters()]]
         del out, f
         if first is None:
             first = got
-        else:
-            for a, b in zip(got, first):
-                assert torch.equal(a, b), f"step {step} differs from step 0"
+        assert got == first, f"step {step} differs from step 0"
+    torch.cuda.synchronize()
+    after = _graph_stats()
+    _lib.lib().cl3d_pwmlp_pass_graphs(was)
+    if graphs:  # the steady state of an eager loop: the allocator repeats its addresses, the passes are replayed
+        assert after[0] - before[0] >= 2 and after[1] - before[1] >= 10, (before, after)
+    else:
+        assert after == before
