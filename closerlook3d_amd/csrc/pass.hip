@@ -32,6 +32,8 @@ namespace cl3d {
 struct PassRuntime {
   hipStream_t side[2] = {nullptr, nullptr};
   hipStream_t cap = nullptr;  // launch graphs are captured here, never on the caller's stream (which may be the legacy one)
+  std::mutex use;             // one pass at a time per device: the side streams and events are shared by the calls
+  int dev = 0;
   hipEvent_t ev_in = nullptr, ev_bq = nullptr, ev_csr = nullptr, ev_fork = nullptr, ev_w = nullptr;
   bool ok = false;
 };
@@ -50,6 +52,7 @@ static PassRuntime *pass_runtime() {
     hipEvent_t *evs[5] = {&r.ev_in, &r.ev_bq, &r.ev_csr, &r.ev_fork, &r.ev_w};
     for (hipEvent_t *e : evs) good = good && hipEventCreateWithFlags(e, hipEventDisableTiming) == hipSuccess;
     if (!good) return nullptr;
+    r.dev = dev;
     r.ok = true;
   }
   return &r;
@@ -61,50 +64,75 @@ static int hip_ok(hipError_t e, const char *what) {
 
 // ---- launch graphs.  An eager training loop calls a pass with the SAME argument block step after step (the caller's
 // caching allocator hands the same addresses to the same requests), and the host -- a dozen kernel launches and half a
-// dozen event calls per pass -- is what paces it.  The second time in a row a pass is called with a bit-identical block
-// its launches are captured (on the library's own stream) into a HIP graph, and every later call with that block is ONE
-// hipGraphLaunch on the caller's stream.  A kernel's behaviour depends on nothing but its arguments, all of which are in
-// the block (sizes, scalars, every pointer), so a replay IS the call it was captured from; a block seen once (varying
-// batch shapes, a caller that never repeats addresses) is enqueued directly as before.  A few graphs per direction and
-// device are kept, least recently used first out.
-constexpr int kGraphSlots = 8;
+// dozen event calls per pass -- is what paces it.  The second time a pass is called with a bit-identical block (within
+// the last kSeen calls of its direction) its launches are captured, on the library's own stream, into a HIP graph, and
+// every later call with that block is ONE hipGraphLaunch on the caller's stream.  A kernel's behaviour depends on
+// nothing but its arguments, all of which are in the block (sizes, scalars, every pointer), so a replay IS the call it
+// was captured from; a block seen once (varying batch shapes, a caller that never repeats addresses) is enqueued directly
+// as before.  kGraphSlots graphs per direction and device; a graph is only evicted when it has not been launched for
+// kIdleCalls calls (a loop over more distinct blocks than slots falls back to direct launches instead of re-capturing
+// every call), and an evicted graph is destroyed kIdleCalls calls later still (its last launch has long drained).
+constexpr int kGraphSlots = 8, kSeen = 32, kIdleCalls = 64;
 struct PassGraphs {
-  std::mutex mu;
   cl3d_pwmlp_pass key[kGraphSlots];
   hipGraphExec_t exec[kGraphSlots] = {};
   unsigned long long used[kGraphSlots] = {};
-  cl3d_pwmlp_pass last;
-  bool have_last = false;
+  unsigned long long seen[kSeen] = {};  // hashes of the last blocks that were launched directly
+  int seen_at = 0;
+  hipGraphExec_t retired[kGraphSlots] = {};
+  unsigned long long retired_at[kGraphSlots] = {};
   unsigned long long tick = 0;
 };
 static PassGraphs g_graphs[2][64];
 static std::atomic<int> g_graphs_on{1};
 static std::atomic<long long> g_captures{0}, g_replays{0};
 
+static unsigned long long block_hash(const cl3d_pwmlp_pass *p) {  // FNV-1a over the block's bytes (never 0)
+  const unsigned char *b = reinterpret_cast<const unsigned char *>(p);
+  unsigned long long h = 1469598103934665603ull;
+  for (size_t k = 0; k < sizeof(*p); ++k) h = (h ^ b[k]) * 1099511628211ull;
+  return h != 0 ? h : 1;
+}
+
+// (called with the device's PassRuntime::use lock held: one pass at a time per device uses the side streams and events)
 template <class Enqueue>
-static int run_pass(int dir, const cl3d_pwmlp_pass *p, hipStream_t st, PassRuntime *rt, Enqueue &&enqueue) {
-  int dev = 0;
-  if (!g_graphs_on.load() || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return enqueue(st);
+static int run_pass(int dir, const cl3d_pwmlp_pass *p, hipStream_t st, PassRuntime *rt, int dev, Enqueue &&enqueue) {
+  if (!g_graphs_on.load()) return enqueue(st);
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
     (void)hipGetLastError();
     return enqueue(st);  // inside the caller's own capture: the launches become nodes of ITS graph
   }
   PassGraphs &g = g_graphs[dir][dev];
-  std::lock_guard<std::mutex> lock(g.mu);
   ++g.tick;
+  for (int k = 0; k < kGraphSlots; ++k)
+    if (g.retired[k] != nullptr && g.retired_at[k] + kIdleCalls < g.tick) {
+      (void)hipGraphExecDestroy(g.retired[k]);
+      g.retired[k] = nullptr;
+    }
   for (int k = 0; k < kGraphSlots; ++k)
     if (g.exec[k] != nullptr && memcmp(&g.key[k], p, sizeof(*p)) == 0) {
       g.used[k] = g.tick;
       g_replays.fetch_add(1);
       return hip_ok(hipGraphLaunch(g.exec[k], st), "pwmlp pass: graph launch");
     }
-  if (!(g.have_last && memcmp(&g.last, p, sizeof(*p)) == 0)) {  // first sighting: launch directly, remember
-    g.last = *p;
-    g.have_last = true;
+  const unsigned long long h = block_hash(p);
+  bool seen = false;
+  for (int k = 0; k < kSeen; ++k) seen = seen || g.seen[k] == h;
+  int slot = -1;  // an empty slot, else one idle for kIdleCalls calls whose predecessor in the retired list is gone
+  for (int k = 0; k < kGraphSlots && slot < 0; ++k)
+    if (g.exec[k] == nullptr) slot = k;
+  if (slot < 0)
+    for (int k = 0; k < kGraphSlots; ++k)
+      if (g.used[k] + kIdleCalls < g.tick && g.retired[k] == nullptr && (slot < 0 || g.used[k] < g.used[slot])) slot = k;
+  if (!seen || slot < 0) {  // first sighting (or nowhere to keep a graph): launch directly, remember the block
+    if (!seen) {
+      g.seen[g.seen_at] = h;
+      g.seen_at = (g.seen_at + 1) % kSeen;
+    }
     return enqueue(st);
   }
-  // second sighting in a row: capture (nothing runs), instantiate, launch
+  // seen before: capture (nothing runs), instantiate, launch
   int rc = hip_ok(hipStreamBeginCapture(rt->cap, hipStreamCaptureModeRelaxed), "pwmlp pass: begin capture");
   if (rc != CL3D_OK) return rc;
   rc = enqueue(rt->cap);
@@ -116,15 +144,12 @@ static int run_pass(int dir, const cl3d_pwmlp_pass *p, hipStream_t st, PassRunti
   if (graph != nullptr) (void)hipGraphDestroy(graph);
   if (rc != CL3D_OK) {
     (void)hipGetLastError();
-    g.have_last = false;
     return rc;
   }
-  int slot = 0;  // an empty slot, else the least recently used
-  for (int k = 0; k < kGraphSlots; ++k) {
-    if (g.exec[k] == nullptr) { slot = k; break; }
-    if (g.used[k] < g.used[slot]) slot = k;
+  if (g.exec[slot] != nullptr) {  // (idle for kIdleCalls calls; destroyed another kIdleCalls calls from now)
+    g.retired[slot] = g.exec[slot];
+    g.retired_at[slot] = g.tick;
   }
-  if (g.exec[slot] != nullptr) (void)hipGraphExecDestroy(g.exec[slot]);
   g.key[slot] = *p;
   g.exec[slot] = exec;
   g.used[slot] = g.tick;
@@ -163,7 +188,8 @@ extern "C" int cl3d_pwmlp_train_forward(const cl3d_pwmlp_pass *p, cl3d_stream_t 
   if (p->B == 0) return CL3D_OK;
   PassRuntime *rt = pass_runtime();
   if (rt == nullptr) return fail(CL3D_E_LAUNCH, "pwmlp_train_forward: side streams could not be created");
-  return run_pass(0, p, (hipStream_t)stream, rt, [&](hipStream_t s) { return enqueue_forward(p, s, rt); });
+  std::lock_guard<std::mutex> use(rt->use);
+  return run_pass(0, p, (hipStream_t)stream, rt, rt->dev, [&](hipStream_t s) { return enqueue_forward(p, s, rt); });
 }
 
 static int enqueue_forward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::PassRuntime *rt) {
@@ -214,7 +240,8 @@ extern "C" int cl3d_pwmlp_train_backward(const cl3d_pwmlp_pass *p, cl3d_stream_t
   if (p->B == 0) return CL3D_OK;
   PassRuntime *rt = pass_runtime();
   if (rt == nullptr) return fail(CL3D_E_LAUNCH, "pwmlp_train_backward: side streams could not be created");
-  return run_pass(1, p, (hipStream_t)stream, rt, [&](hipStream_t s) { return enqueue_backward(p, s, rt); });
+  std::lock_guard<std::mutex> use(rt->use);
+  return run_pass(1, p, (hipStream_t)stream, rt, rt->dev, [&](hipStream_t s) { return enqueue_backward(p, s, rt); });
 }
 
 static int enqueue_backward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::PassRuntime *rt) {

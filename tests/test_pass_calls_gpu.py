@@ -102,3 +102,32 @@ def test_pass_calls_are_repeatable_and_leave_nothing_in_flight(graphs):
         assert after[0] - before[0] >= 2 and after[1] - before[1] >= 10, (before, after)
     else:
         assert after == before
+
+
+def test_more_distinct_passes_than_graph_slots_fall_back_to_direct_launches():
+    """Ten operators of ten shapes called round-robin: more distinct argument blocks than the library keeps launch graphs
+    for (eight per direction).  Every round gives the first round's bits, and the library does not re-capture a graph per
+    call (a graph is only replaced when it has been idle for 64 calls): at most 8 captures per direction."""
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    cfg = default_config("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df"}, cl3d_impl="fused")
+    ops = []
+    for k in range(10):
+        B, N, K, C = 2, 256 + 64 * k, 16, 32
+        q, s, qm, sm = _cloud(B, N, N, 0.0, seed=20 + k)
+        torch.manual_seed(k)
+        la = LocalAggregation(C, C, 0.2, K, cfg).cuda().train()
+        ops.append((la, q, s, qm, sm, torch.randn(B, C, N, device="cuda"), torch.randn(B, C, N, device="cuda")))
+    before = _graph_stats()
+    first = {}
+    for rnd in range(6):
+        for k, (la, q, s, qm, sm, feats, probe) in enumerate(ops):
+            la.zero_grad(set_to_none=True)
+            f = feats.clone().requires_grad_(True)
+            out = la(q, s, qm, sm, f)
+            (out * probe).sum().backward()
+            got = [int(t.view(torch.int32).long().sum()) for t in [out.detach(), f.grad] + [p.grad for p in la.parameters()]]
+            del out, f
+            assert first.setdefault(k, got) == got, f"operator {k}, round {rnd}"
+    torch.cuda.synchronize()
+    after = _graph_stats()
+    assert after[0] - before[0] <= 16, (before, after)
