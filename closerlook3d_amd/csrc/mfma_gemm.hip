@@ -746,6 +746,105 @@ static bool launch_rows_nolds(const float *F, const float *pro_scale, const floa
 #undef CL3D_NOLDS
 }
 
+// the same product with bf16 inputs (round 4; prototype and stand-alone check: scripts/micro/skinny_gemm_bf16.hip, 14 us
+// at the metric shape against 22.8 us for the staged bf16 kernel, which moreover cannot run beside the ball query): a
+// lane's A fragment for one v_mfma_f32_32x32x16_bf16 step is 8 channels of ONE point -- eight 4-byte loads, each a
+// 128-byte run across the 32 lanes of a half-wave -- rounded to bf16 (RNE, after the producing layer's BatchNorm + ReLU
+// when there is one) and packed; the weight fragments (C / 16 packs of 8 bf16) stay in registers.  Same number of
+// loads per block as the f32 kernel, an eighth of its MFMA cycles.
+template <int C, bool PRO>  // channels (compile time: the dead channels of a last step fold away), producer prologue
+__global__ __launch_bounds__(256, 5) void pwmlp_rows_nolds_bf16_kernel(const float *__restrict__ F, const float *__restrict__ pro_scale,
+                                                                       const float *__restrict__ pro_shift,
+                                                                       const float *__restrict__ wcat, float *__restrict__ out,
+                                                                       int N, int J, int nblocks) {
+  constexpr int CH16 = (C + 15) / 16;  // MFMA steps
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int j = 32 * (blockIdx.y * 4 + wave) + lr;  // this lane's output column
+  if (32 * (blockIdx.y * 4 + wave) >= J) return;    // (whole waves: no barrier in this kernel)
+  bf16x8 bw[CH16];
+#pragma unroll
+  for (int s = 0; s < CH16; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 16 * s + 8 * lh + e;
+      bw[s][e] = (__bf16)((j < J && k < C) ? wcat[(size_t)j * C + k] : 0.f);
+    }
+  const int per_cloud = N / 32;
+  const unsigned a_off = ((unsigned)(8 * lh) * (unsigned)N + (unsigned)lr) * 4u;  // lane part of every fragment address
+  const unsigned o_off = ((unsigned)(4 * lh) * (unsigned)J + (unsigned)(j < J ? j : 0)) * 4u;
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int b = __builtin_amdgcn_readfirstlane(blk / per_cloud);
+    const int n0 = __builtin_amdgcn_readfirstlane((blk - b * per_cloud) * 32);
+    const char *fb = reinterpret_cast<const char *>(F + (size_t)b * C * N + n0);
+    bf16x8 a[CH16];
+#pragma unroll
+    for (int s = 0; s < CH16; ++s) {
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool live = 16 * s + 8 * lh + e < C;  // (only the last step of C % 16 != 0 has dead channels)
+        x[e] = live ? *reinterpret_cast<const float *>(fb + (size_t)(16 * s + e) * N * 4u + a_off) : 0.f;
+      }
+      if constexpr (PRO) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = 16 * s + 8 * lh + e;
+          const bool live = k < C;
+          // (the index goes through an empty asm: left to itself the compiler keeps all 2 C / 16 x 8 per-lane constants
+          // of the prologue in registers across the block loop and spills; they are L1 hits)
+          int kk = live ? k : 0;
+          asm volatile("" : "+v"(kk));
+          const float z = __builtin_fmaf(x[e], pro_scale[kk], pro_shift[kk]);
+          x[e] = live ? (z > 0.f ? z : 0.f) : 0.f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[s][e] = (__bf16)x[e];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < CH16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s], bw[s], acc, 0, 0, 0);
+    if (j < J) {
+      char *ob = reinterpret_cast<char *>(out + ((size_t)b * N + n0) * J);
+#pragma unroll
+      for (int e = 0; e < 16; ++e)
+        *reinterpret_cast<float *>(ob + (size_t)((e & 3) + 8 * (e >> 2)) * J * 4u + o_off) = acc[e];
+    }
+  }
+}
+
+static bool launch_rows_nolds_bf16(const float *F, const float *pro_scale, const float *pro_shift, const float *wcat, float *ght,
+                                   int B, int C, int N, int Co, hipStream_t st) {
+  if ((N & 31) != 0 || B < 1) return false;
+  const int J = 2 * Co;
+  const long long nblocks = (long long)B * (N / 32);
+  if (nblocks > 0x7fffffffLL) return false;
+  const dim3 grid((unsigned)(nblocks < 256 ? nblocks : 256), (unsigned)ceil_div(ceil_div(J, 32), 4));
+#define CL3D_NOLDS16(C_)                                                                                                        \
+  do {                                                                                                                          \
+    if (pro_scale != nullptr)                                                                                                   \
+      hipLaunchKernelGGL((pwmlp_rows_nolds_bf16_kernel<C_, true>), grid, dim3(256), 0, st, F, pro_scale, pro_shift, wcat, ght, N, J, \
+                         (int)nblocks);                                                                                         \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((pwmlp_rows_nolds_bf16_kernel<C_, false>), grid, dim3(256), 0, st, F, pro_scale, pro_shift, wcat, ght, N, J, \
+                         (int)nblocks);                                                                                         \
+  } while (0)
+  switch (C) {
+    case 32: CL3D_NOLDS16(32); return true;
+    case 36: CL3D_NOLDS16(36); return true;
+    case 64: CL3D_NOLDS16(64); return true;
+    case 72:
+      if (pro_scale != nullptr) return false;  // (the prologue form spills at 72 channels: the staged kernel takes it)
+      CL3D_NOLDS16(72);
+      return true;
+    default: return false;
+  }
+#undef CL3D_NOLDS16
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -970,6 +1069,7 @@ static int point_gemm_fwd(const float *features, const float *pro_scale, const f
   const int rc = check_launch(who);
   if (rc != CL3D_OK || B == 0) return rc;
   if (precision == PREC_F32 && launch_rows_nolds(features, pro_scale, pro_shift, wcat, ght, B, C, N, Co, st)) return check_launch(who);
+  if (precision == PREC_BF16 && launch_rows_nolds_bf16(features, pro_scale, pro_shift, wcat, ght, B, C, N, Co, st)) return check_launch(who);
   GemmArgs a{};  // D[i = (cloud, point)][j = o] = sum_c F[c][point] wcat[o][c]  ->  ght [B*N, 2Co]
   a.A = channel_major(features, B, C, N, true);
   set_prologue(a.A, pro_scale, pro_shift, 0);
