@@ -941,7 +941,7 @@ class _PointwiseMLPPass(Function):
         p.out = out.data_ptr()
         with _lib.on_device(dev):
             _lib.check(lib.cl3d_pwmlp_train_forward(ctypes.byref(p), _stream(features)))
-        ctx.block, ctx.keep, ctx.need = p, [inputs, kept, out], need_grad
+        ctx.block, ctx.keep, ctx.need = p, [inputs, kept], need_grad  # (not `out`: the node must not own its own output)
         return out
 
     @staticmethod
@@ -974,7 +974,8 @@ class _PointwiseMLPPass(Function):
         with _lib.on_device(dev):
             _lib.check(lib.cl3d_pwmlp_train_backward(ctypes.byref(p), _stream(gout)))
         del scratch  # (everything that used it is queued on -- or joined into -- the stream whose allocations reuse it)
-        ctx.keep = None
+        # (ctx.keep stays: autograd drops the node -- and with it the forward's buffers -- unless the caller retains the
+        # graph, in which case a second backward pass reads them again)
         return (dfeat, dW, coef[3], coef[4]) + (None,) * 13
 
 

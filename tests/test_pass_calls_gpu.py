@@ -131,3 +131,26 @@ def test_more_distinct_passes_than_graph_slots_fall_back_to_direct_launches():
     torch.cuda.synchronize()
     after = _graph_stats()
     assert after[0] - before[0] <= 16, (before, after)
+
+
+def test_a_retained_graph_can_be_differentiated_twice():
+    """backward(retain_graph=True) followed by a second backward: the node keeps the forward pass's buffers alive, the second
+    pass gives the first one's gradients (accumulated: twice the value, exactly -- x + x is exact)."""
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    B, N, K, C = 2, 512, 16, 32
+    q, s, qm, sm = _cloud(B, N, N, 0.1, seed=9)
+    torch.manual_seed(5)
+    cfg = default_config("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df"}, cl3d_impl="fused")
+    la = LocalAggregation(C, C, 0.2, K, cfg).cuda().train()
+    f = torch.randn(B, C, N, device="cuda").requires_grad_(True)
+    probe = torch.randn(B, C, N, device="cuda")
+    out = la(q, s, qm, sm, f)
+    assert type(out.grad_fn).__name__.startswith("_PointwiseMLPPass")
+    loss = (out * probe).sum()
+    loss.backward(retain_graph=True)
+    once = [f.grad.clone()] + [p.grad.clone() for p in la.parameters()]
+    junk = [torch.randn(B, C, N, device="cuda") for _ in range(8)]  # (whatever the allocator hands out next)
+    loss.backward()
+    del junk
+    for a, b in zip([f.grad] + [p.grad for p in la.parameters()], once):
+        assert torch.equal(a, b + b)
