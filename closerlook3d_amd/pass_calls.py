@@ -1,0 +1,124 @@
+"""One C-ABI call per pass of a PointWiseMLP LocalAggregation in training mode: the autograd node over
+cl3d_pwmlp_train_forward / _backward (csrc/pass.hip).  fused.pointwise_mlp() takes this path for a stand-alone operator
+launched eagerly (outside HIP-graph capture); everything else goes kernel by kernel through fused._PointwiseMLP."""
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+
+
+def _stream(t):
+    return _lib.stream_ptr(t.device)
+
+
+class _PointwiseMLPPass(Function):
+    """The whole PointWiseMLP operator in training mode -- ball query, CSR inverse, per-point product, statistics pass,
+    BatchNorm, activation; and its whole backward -- as ONE C-ABI call per direction (csrc/pass.hip,
+    cl3d_pwmlp_train_forward / _backward): the library enqueues every kernel itself, the geometry work and the weight
+    gradient on its own side streams.  This is the eager caller's path (the reference's unchanged training loop makes one
+    `_ext` call per autograd node, pt_utils.py:16-61): launched kernel by kernel from Python the host sets the pace
+    (0.41 ms per step at the metric shape, 0.59 ms with the forks made from Python), a captured step keeps the
+    Python-side schedule (`pointwise_mlp` below).  Same kernels, same arithmetic, same bits as that path."""
+
+    @staticmethod
+    def forward(ctx, features, W, gamma, beta, running_mean, running_var, num_batches_tracked, query_xyz, support_xyz,
+                query_mask, support_mask, radius, nsample, momentum, eps, precision, need_grad):
+        B, C, N = features.shape
+        M, K, Co = query_xyz.shape[1], int(nsample), W.shape[0]
+        dev = features.device
+        lib = _lib.lib()
+        p = _lib.PwmlpPass()
+        p.B, p.N, p.M, p.K, p.C, p.Co, p.precision = B, N, M, K, C, Co, precision
+        p.radius, p.eps, p.momentum = float(radius), float(eps), float(momentum)
+        p.idx_ready = p.csr_ready = 0
+        inputs = (features, W, gamma, beta, running_mean, running_var, num_batches_tracked, query_xyz, support_xyz,
+                  query_mask, support_mask)  # kept alive on the node: the argument block points into them
+        for name, t in zip(("features", "W", "gamma", "beta", "running_mean", "running_var", "num_batches_tracked",
+                            "query_xyz", "support_xyz", "query_mask", "support_mask"), inputs):
+            setattr(p, name, t.data_ptr())
+        p.bq_ws_bytes = lib.cl3d_workspace_bytes(1, B, N, M, K, 0)  # CL3D_OP_BALL_QUERY
+        p.csr_ws_bytes = lib.cl3d_workspace_bytes(11, B, N, M * K, 1, 0) if need_grad else 0  # CL3D_OP_INVERSE_INDEX
+        p.gemm_ws_bytes = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)  # CL3D_OP_POINT_GEMM
+        p.n_partials = lib.cl3d_pwmlp_partials(B, M, Co)
+        # everything the pass leaves behind for its backward, and its scratch, is ONE allocation (the host sets the pace
+        # of an eager step: two dozen torch.empty calls cost ~40 us of it); `out` is a tensor of its own
+        arena = _Arena(p)
+        arena.add("idx", 4 * B * M * K)
+        arena.add("idx_mask", 4 * B * M * K)
+        arena.add("bq_ws", p.bq_ws_bytes)
+        if need_grad:
+            arena.add("inv_off", 4 * B * (N + 1))
+            arena.add("inv_slots", 4 * B * M * K)
+            arena.add("csr_ws", p.csr_ws_bytes)
+        arena.add("gemm_ws", p.gemm_ws_bytes)
+        arena.add("ght", 4 * B * N * 2 * Co)
+        arena.add("wr", 4 * Co * 3)
+        arena.add("wcat", 4 * 2 * Co * C)
+        arena.add("ystar", 4 * B * M * Co)
+        arena.add("sy", 4 * B * M * Co)
+        arena.add("kstar", B * M * Co)
+        arena.add("partial", 8 * p.n_partials * Co * 8)
+        arena.add("vec", 4 * 4 * Co)
+        arena.add("sums", 8 * Co * 6)
+        kept = arena.allocate(dev)
+        out = torch.empty((B, Co, M), dtype=torch.float32, device=dev)
+        p.out = out.data_ptr()
+        with _lib.on_device(dev):
+            _lib.check(lib.cl3d_pwmlp_train_forward(ctypes.byref(p), _stream(features)))
+        ctx.block, ctx.keep, ctx.need = p, [inputs, kept], need_grad  # (not `out`: the node must not own its own output)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        p = ctx.block
+        B, N, M, C, Co = p.B, p.N, p.M, p.C, p.Co
+        dev = gout.device
+        lib = _lib.lib()
+        gout = gout.contiguous()
+        p.gout = gout.data_ptr()
+        p.gemm_ws_bytes_b = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)
+        arena = _Arena(p)
+        arena.add("dz_cm", 4 * B * Co * M)
+        arena.add("ts_cm", 4 * B * Co * M)
+        arena.add("dz_t", 4 * B * M * Co)
+        arena.add("qtab", 16 * B * M)
+        arena.add("partial_b", 8 * p.n_partials * Co * 8)
+        arena.add("hit", 4 * B * Co * N)
+        arena.add("dwr", 4 * Co * 3)
+        arena.add("dght", 4 * B * N * 2 * Co)
+        arena.add("gemm_ws_d", p.gemm_ws_bytes_b)
+        arena.add("gemm_ws_w", p.gemm_ws_bytes_b)
+        scratch = arena.allocate(dev)
+        coef = torch.empty((5, Co), dtype=torch.float32, device=dev)
+        p.coef = coef.data_ptr()
+        dfeat = torch.empty((B, C, N), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dW = torch.empty((Co, 3 + 2 * C), dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        p.dfeat = dfeat.data_ptr() if dfeat is not None else None
+        p.dW = dW.data_ptr() if dW is not None else None
+        with _lib.on_device(dev):
+            _lib.check(lib.cl3d_pwmlp_train_backward(ctypes.byref(p), _stream(gout)))
+        del scratch  # (everything that used it is queued on -- or joined into -- the stream whose allocations reuse it)
+        # (ctx.keep stays: autograd drops the node -- and with it the forward's buffers -- unless the caller retains the
+        # graph, in which case a second backward pass reads them again)
+        return (dfeat, dW, coef[3], coef[4]) + (None,) * 13
+
+
+class _Arena:
+    """Named sub-buffers of ONE uint8 allocation, 256-byte aligned, their addresses written into the fields of an
+    argument block (a zero-size buffer keeps a valid, unused address)."""
+
+    def __init__(self, block):
+        self.block, self.items, self.size = block, [], 0
+
+    def add(self, name, nbytes):
+        self.items.append((name, self.size))
+        self.size += (max(int(nbytes), 1) + 255) & ~255
+
+    def allocate(self, device):
+        buf = torch.empty((self.size,), dtype=torch.uint8, device=device)
+        base = buf.data_ptr()
+        for name, off in self.items:
+            setattr(self.block, name, base + off)
+        return buf

@@ -1,4 +1,4 @@
-"""One C-ABI call per pass (csrc/pass.hip, fused._PointwiseMLPPass -- the eager caller's path; reference: one `_ext` call per
+"""One C-ABI call per pass (csrc/pass.hip, pass_calls._PointwiseMLPPass -- the eager caller's path; reference: one `_ext` call per
 autograd node, pt_utils.py:16-61) against the kernel-by-kernel path: the same kernels on the same inputs, so outputs, every
 gradient and the BatchNorm buffers must be BIT-equal -- over four training steps (the library captures a pass it sees twice
 in a row with an identical argument block into a launch graph and replays it from then on: direct, captured and replayed
