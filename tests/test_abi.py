@@ -158,3 +158,23 @@ def test_pass_calls_validate_their_argument_block_before_any_launch():
     assert b"null pointer" in lib.cl3d_last_error_string()
     assert lib.cl3d_pwmlp_train_backward(ctypes.byref(p), None) == -1
     assert b"null pointer" in lib.cl3d_last_error_string()
+
+
+def test_pass_arena_hands_out_aligned_disjoint_addresses():
+    """pass_calls._Arena: the sub-buffers of a pass's one allocation are 256-byte aligned, disjoint, in order, and a
+    zero-size request still gets an address of its own (CPU tensor: only the address arithmetic is exercised)."""
+    import torch
+    from closerlook3d_amd import _lib
+    from closerlook3d_amd.pass_calls import _Arena
+    p = _lib.PwmlpPass()
+    a = _Arena(p)
+    sizes = {"idx": 4 * 1000, "idx_mask": 1, "bq_ws": 0, "ght": 4 * 12345, "kstar": 777, "partial": 8 * 64 * 8}
+    for k, v in sizes.items():
+        a.add(k, v)
+    buf = a.allocate(torch.device("cpu"))
+    base, prev_end = buf.data_ptr(), buf.data_ptr()
+    for k, v in sizes.items():
+        addr = getattr(p, k)
+        assert addr is not None and (addr - base) % 256 == 0 and addr >= prev_end
+        prev_end = addr + max(v, 1)
+    assert prev_end <= base + buf.numel()
