@@ -159,6 +159,7 @@ ENTRY_KERNELS = {
     "cl3d_pwmlp_point_gemm_fwd": ["pwmlp_weights_kernel", "pwmlp_rows_nolds_kernel"],
     "cl3d_pwmlp_point_gemm_bwd_data": ["mfma_gemm_kernel"],
     "cl3d_pwmlp_point_gemm_bwd_weight": ["mfma_gemm_kernel", "gemm_reduce_kernel"],
+    "cl3d_pwmlp_point_gemm_bwd": ["pwmlp_point_grads_kernel", "gemm_reduce_kernel"],
     "cl3d_pwmlp_stats": ["pwmlp_query_kernel<0"],
     "cl3d_pwmlp_finalize_stats": ["pwmlp_finalize_kernel<0"],
     "cl3d_pwmlp_apply": ["pwmlp_rows_kernel<0"],
@@ -197,6 +198,8 @@ def step_model_bytes(B, N, M, K, C, kind="pointwisemlp"):
         "cl3d_pwmlp_point_gemm_fwd": (B * f * (C * N + N * 2 * Co), 0, "mfma+hbm"),
         "cl3d_pwmlp_point_gemm_bwd_data": (B * f * (C * N + N * 2 * Co), 0, "mfma+hbm"),
         "cl3d_pwmlp_point_gemm_bwd_weight": (B * f * (C * N + N * 2 * Co), 0, "mfma+hbm"),
+        # both gradients from one pass: d ght and the features read once, d features written once
+        "cl3d_pwmlp_point_gemm_bwd": (B * f * (2 * C * N + N * 2 * Co), 0, "mfma+hbm"),
         # TRAIN gather pass: one G row (Co floats) per slot + the centre's H row per query
         "cl3d_pwmlp_stats": (B * (f * N * 2 * Co + 4 * MK + xyzm + 2 * rows_q + M * Co), B * MK * f * Co, "l2-gather+latency"),
         "cl3d_pwmlp_apply": (B * 2 * rows_q, 0, "hbm"),
@@ -287,6 +290,7 @@ def contraction_block(B, C, N, Co, precision, reps=30):
            "flops": 3 * m["flops_per_gemm"], "us": round(us, 2),
            "fwd_us": round(mine["fwd_us"], 2), "bwd_data_us": round(mine["bwd_data_us"], 2),
            "bwd_weight_us": round(mine["bwd_weight_us"], 2),
+           "bwd_both_us": round(mine["bwd_both_us"], 2), "bwd_both_one_kernel": mine["bwd_both_one_kernel"],
            "achieved_TFLOPs": round(mine["tflops"], 2), "peak_TFLOPs": mine["peak_tflops"],
            "frac": round(mine["frac_of_mfma_peak"], 4),
            "hbm_bytes": 3 * m["hbm_bytes_per_gemm"], "hbm_frac": round(mine["frac_of_hbm_peak"], 4),

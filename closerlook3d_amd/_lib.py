@@ -53,6 +53,8 @@ SIGNATURES = {
     "cl3d_pwmlp_point_gemm_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _Z, _P],
     "cl3d_pwmlp_point_gemm_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_pwmlp_point_gemm_bwd_weight": [_P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
+    "cl3d_pwmlp_point_gemm_bwd_fused": [_I, _I, _I, _I, _I],
+    "cl3d_pwmlp_point_gemm_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _Z, _P],
     "cl3d_conv1x1_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_conv1x1_bn_act_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_conv1x1_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
@@ -84,6 +86,7 @@ class PwmlpPass(ctypes.Structure):
     _fields_ = (
         [(n, _I) for n in ("B", "N", "M", "K", "C", "Co", "precision", "idx_ready", "csr_ready", "n_partials")]
         + [(n, _F) for n in ("radius", "eps", "momentum")]
+        + [("reserved", _I)]
         + [(n, _P) for n in ("query_xyz", "support_xyz", "query_mask", "support_mask", "idx", "idx_mask", "inv_off",
                              "inv_slots", "bq_ws", "csr_ws", "gemm_ws", "gemm_ws_d", "gemm_ws_w")]
         + [(n, _Z) for n in ("bq_ws_bytes", "csr_ws_bytes", "gemm_ws_bytes", "gemm_ws_bytes_b")]
@@ -183,7 +186,7 @@ class trace:
 # CL3D_ABI_VERSION of include/cl3d.h: the library must have been built from the same header (a stale .so with another
 # argument layout would run with shifted pointers).  A constant, so that a copy of the package without the repository's
 # include/ directory still imports; tests/test_abi.py holds it to the header.
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def header_abi_version():

@@ -1499,6 +1499,9 @@ extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const f
   CL3D_REQUIRE(ght && wr && cA && cB && cD && hit_cm && dz_t && sy_t && qtab && support_xyz && inv_off && inv_slots && dght && radius > 0.f,
                "pwmlp_bwd_support: null pointer");
   if ((long long)M * Co * 4 > 0xffffffffLL) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support: M*Co too large");
+  // an entry's row offset carries the "centred" flag in bit 31 (kCentreFlag): offsets inside a cloud's table stay below 2 GiB
+  if ((long long)N * Co * 8 > 0x7fffffffLL)
+    return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support: N*Co too large for 31-bit row offsets");
   if (B == 0) return CL3D_OK;
   const int V = (Co % 4 == 0) ? 4 : 1;
   const LaneMap m = pick_lane_map(Co, V);

@@ -846,6 +846,164 @@ static bool launch_rows_nolds_bf16(const float *F, const float *pro_scale, const
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------
+// ---- BOTH gradients of the PointWiseMLP's per-point product from ONE pass over d ght (round 5) -------------------------
+//   d F[c][p]    = sum_o wcat[o][c] dght[p][o]      (data gradient, channel-major out)
+//   d wcat[o][c] = sum_p dght[p][o] F[c][p]         (weight gradient, over every point of the batch)
+// Round 4 ran them as two launches of mfma_gemm_kernel side by side on two queues (25 + 37 us alone, 41 + 48 together,
+// + 9 us for the 512-slice reduce): each read the 33.5 MB of d ght, the weight gradient as 512 K slices of a 128 x 64
+// tile whose partials were written and read again.  Here a workgroup owns a run of 64-point tiles: a tile's d ght
+// rows (32 KB) and feature rows (16 KB) are staged ONCE in LDS and feed both products; the weight-gradient
+// accumulators stay in registers across the workgroup's tiles (256 partial tiles instead of 512, written once);
+// wcat, the data gradient's constant operand, lives in registers for the whole launch.
+//   LDS     T [64 points][129]: d ght rows, row stride odd, so BOTH fragment orientations are conflict-free single reads:
+//             data gradient    B(k = o, j = p)   lane (p = lr, o = 2kk + lh)  -> address p*129 + o: 32 banks over lr
+//             weight gradient  A(i = o, k = p)   lane (o = 32w + lr, p = 2kk + lh) -> address p*129 + o: consecutive
+//           Fs[64 channels][65]: feature rows; weight gradient B(k = p, j = c) lane (c = lr, p = 2kk + lh) -> c*65 + p
+//           two copies of the pair: tile t+1 is written while tile t is multiplied, one barrier per tile.
+//   waves   data gradient 64 channels x 64 points = 2 x 2 blocks of 32 x 32, one per wave, 64 MFMA steps over o;
+//           weight gradient 128 x 64 = 4 x 2 blocks, wave w owns rows o = 32w .. 32w+31, 32 steps over the tile's points.
+//   order   sums run over points in ascending order inside a workgroup; the workgroups' partial tiles are added in
+//           workgroup order by gemm_reduce_kernel<1> (which also does the weight plumbing): bit-reproducible, and
+//           independent of the device (the grid is min(256, tiles), not the CU count).
+// C <= 64 channels and 2 Co <= 128 columns (zero padding below that), whole 64-point tiles per cloud.  The optional
+// prologue is the bottleneck's conv1 BatchNorm + ReLU applied to the feature rows as they are staged.
+struct PointGradArgs {
+  const float *dght, *F, *pro_scale, *pro_shift, *wcat;
+  float *dfeat, *partial;
+  int C, J, N, tiles, tiles_per_cloud;
+};
+
+constexpr int kPgTP = 64, kPgLdT = 129, kPgLdF = 65;
+constexpr int kPgBufFloats = kPgTP * kPgLdT + 64 * kPgLdF;
+constexpr int kPointGradsGrid = 256;
+
+// FULL: C == 64 and J == 128 (no padding, no masks: straight-line staging code, exact s_waitcnt counts -- with the masked
+// loads in the loop the compiler waited for EVERY outstanding load, the next tile's included, before the first MFMA);
+// PRO: the feature rows enter as max(scale[c] x + shift[c], 0)
+template <bool FULL, bool PRO>
+__global__ __launch_bounds__(256) void pwmlp_point_grads_kernel(PointGradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float pg_lds[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ci = wave >> 1, pi = wave & 1;  // this wave's block of the data gradient
+  const int C = FULL ? 64 : a.C, J = FULL ? 128 : a.J, N = a.N;
+
+  // the data gradient's A fragments: wcat[o = 2kk + lh][c = 32ci + lr], constant for the launch
+  float wreg[64];
+  {
+    const int c = 32 * ci + lr;
+#pragma unroll
+    for (int kk = 0; kk < 64; ++kk) {
+      const int o = 2 * kk + lh;
+      wreg[kk] = (FULL || (o < J && c < C)) ? a.wcat[(size_t)o * C + c] : 0.f;
+    }
+  }
+  f32x16 acc2[2];
+#pragma unroll
+  for (int y = 0; y < 2; ++y)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[y][e] = 0.f;
+
+  // staging: d ght rows as 32 lanes x 16 bytes per row (8 rows per pass of the workgroup), feature rows as 16 lanes x
+  // 16 bytes per channel (16 channels per pass)
+  const int tr = t >> 5, tc = 4 * (t & 31);
+  const int fc = t >> 4, fp = 4 * (t & 15);
+  float4 gT[8], gF[4];
+  auto issue = [&](int tile) {
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int b = tile / a.tiles_per_cloud, n0 = (tile - b * a.tiles_per_cloud) * kPgTP;
+    const float *src = a.dght + ((size_t)b * N + n0) * J + tc;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) gT[q] = (FULL || tc < J) ? ld4(src + (size_t)(tr + 8 * q) * J) : zero4;
+    const float *fs = a.F + (size_t)b * C * N + n0 + fp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = fc + 16 * q;
+      float4 v = (FULL || c < C) ? ld4(fs + (size_t)c * N) : zero4;
+      if (PRO && (FULL || c < C)) {
+        const float sc = a.pro_scale[c], sh = a.pro_shift[c];
+        v.x = __builtin_fmaf(v.x, sc, sh); v.y = __builtin_fmaf(v.y, sc, sh);
+        v.z = __builtin_fmaf(v.z, sc, sh); v.w = __builtin_fmaf(v.w, sc, sh);
+        v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f;
+        v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+      }
+      gF[q] = v;
+    }
+  };
+  auto to_lds = [&](int buf) {
+    float *T = pg_lds + buf * kPgBufFloats, *Fs = T + kPgTP * kPgLdT;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float *d = T + (tr + 8 * q) * kPgLdT + tc;
+      d[0] = gT[q].x; d[1] = gT[q].y; d[2] = gT[q].z; d[3] = gT[q].w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float *d = Fs + (fc + 16 * q) * kPgLdF + fp;
+      d[0] = gF[q].x; d[1] = gF[q].y; d[2] = gF[q].z; d[3] = gF[q].w;
+    }
+  };
+
+  int tile = blockIdx.x, buf = 0;
+  if (tile < a.tiles) {
+    issue(tile);
+    to_lds(0);
+  }
+  // the wcat fragments are pinned as ARRIVED here: left to itself the compiler sinks their loads below the barrier, and
+  // the tile loop's s_waitcnt logic then has to assume some are still outstanding on every iteration -- it waited for
+  // the NEXT tile's loads (issued at the top of the iteration) before the first MFMA, i.e. no prefetch at all
+#pragma unroll
+  for (int kk = 0; kk < 64; ++kk) asm volatile("" : "+v"(wreg[kk]));
+  __syncthreads();
+  for (; tile < a.tiles; tile += gridDim.x) {
+    const int next = tile + gridDim.x;
+    if (next < a.tiles) issue(next);  // in flight while this tile is multiplied
+    const float *T = pg_lds + buf * kPgBufFloats, *Fs = T + kPgTP * kPgLdT;
+    if (a.dfeat != nullptr) {
+      f32x16 acc1;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc1[e] = 0.f;
+      const float *tb = T + (32 * pi + lr) * kPgLdT + lh;
+#pragma unroll
+      for (int kk = 0; kk < 64; ++kk) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(wreg[kk], tb[2 * kk], acc1, 0, 0, 0);
+      // a lane holds point 32pi + lr and channels 32ci + (e & 3) + 8 (e >> 2) + 4 lh: 128-byte runs per store
+      const int b = tile / a.tiles_per_cloud, n0 = (tile - b * a.tiles_per_cloud) * kPgTP;
+      float *ob = a.dfeat + (size_t)b * C * N + n0 + 32 * pi + lr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int c = 32 * ci + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (FULL || c < C) ob[(size_t)c * N] = acc1[e];
+      }
+    }
+    if (a.partial != nullptr) {
+      const float *ta = T + lh * kPgLdT + 32 * wave + lr;
+      const float *f0 = Fs + lr * kPgLdF + lh, *f1 = f0 + 32 * kPgLdF;
+#pragma unroll
+      for (int kk = 0; kk < 32; ++kk) {
+        const float av = ta[2 * kk * kPgLdT];
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f0[2 * kk], acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, f1[2 * kk], acc2[1], 0, 0, 0);
+      }
+    }
+    if (next < a.tiles) to_lds(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  if (a.partial != nullptr) {
+    // this workgroup's partial d wcat [J][C]: a lane holds column c = 32y + lr and rows o = 32w + (e & 3) + 8 (e >> 2) + 4 lh
+    float *P = a.partial + (size_t)blockIdx.x * J * C;
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int c = 32 * y + lr;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int o = 32 * wave + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (FULL || (o < J && c < C)) P[(size_t)o * C + c] = acc2[y][e];
+      }
+    }
+  }
+}
+
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // operand whose r and k are plain strided axes
@@ -1049,7 +1207,58 @@ size_t gemm_family_workspace(int nb, int n, int rows_out, int rows_in, bool merg
   const size_t d = plan_workspace(rows_in, (int)P, rows_out, kMaxSplitFwd, false);           // input gradient
   w = f > w ? f : w;
   w = f2 > w ? f2 : w;
-  return d > w ? d : w;
+  w = d > w ? d : w;
+  if (merge) {  // pwmlp_point_grads_kernel: one partial d wcat tile per workgroup
+    const size_t g = (size_t)kPointGradsGrid * rows_out * rows_in * sizeof(float);
+    w = g > w ? g : w;
+  }
+  return w;
+}
+
+// ---- host side of pwmlp_point_grads_kernel
+static bool point_grads_covers(int B, int C, int N, int Co, int precision) {
+  return precision == PREC_F32 && B >= 1 && C >= 4 && C <= 64 && C % 4 == 0 && Co >= 2 && 2 * Co <= 128 && Co % 2 == 0 &&
+         N % kPgTP == 0 && N % 4 == 0;
+}
+
+static int launch_point_grads(const float *features, const float *pro_scale, const float *pro_shift, const float *dght,
+                              const float *wcat, const float *dwr, int B, int C, int N, int Co, float *dfeat, float *dW,
+                              void *ws, size_t ws_bytes, hipStream_t st, const char *who) {
+  const int J = 2 * Co;
+  const long long tiles = (long long)B * (N / kPgTP);
+  const int grid = (int)(tiles < kPointGradsGrid ? tiles : kPointGradsGrid);
+  const size_t need = dW != nullptr ? (size_t)grid * J * C * sizeof(float) : 0;
+  if (dW != nullptr && (ws == nullptr || ws_bytes < need))
+    return fail(CL3D_E_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, need);
+  if (!aligned16(dght) || !aligned16(features) || (pro_scale != nullptr && !aligned16(pro_scale)))
+    return fail(CL3D_E_INVALID, "%s: operands must be 16-byte aligned", who);
+  const size_t lds = (size_t)2 * kPgBufFloats * sizeof(float);
+  PointGradArgs a{};
+  a.dght = dght; a.F = features; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.wcat = wcat;
+  a.dfeat = dfeat; a.partial = dW != nullptr ? static_cast<float *>(ws) : nullptr;
+  a.C = C; a.J = J; a.N = N; a.tiles = (int)tiles; a.tiles_per_cloud = N / kPgTP;
+  const bool full = C == 64 && J == 128, pro = pro_scale != nullptr;
+  int rc = CL3D_OK;
+#define CL3D_PG(FULL_, PRO_)                                                                                          \
+  do {                                                                                                                \
+    static std::atomic<unsigned long long> granted{0};                                                                \
+    rc = lds_opt_in(granted, reinterpret_cast<const void *>(pwmlp_point_grads_kernel<FULL_, PRO_>), lds, who);         \
+    if (rc == CL3D_OK) hipLaunchKernelGGL((pwmlp_point_grads_kernel<FULL_, PRO_>), dim3(grid), dim3(256), lds, st, a); \
+  } while (0)
+  if (full && pro) CL3D_PG(true, true);
+  else if (full) CL3D_PG(true, false);
+  else if (pro) CL3D_PG(false, true);
+  else CL3D_PG(false, false);
+#undef CL3D_PG
+  if (rc != CL3D_OK) return rc;
+  rc = check_launch(who);
+  if (rc != CL3D_OK || dW == nullptr) return rc;
+  OutMap o{};
+  o.D = dW;
+  long long rgrid = ((long long)Co * C + 63) / 64;
+  if (rgrid > 16384) rgrid = 16384;
+  hipLaunchKernelGGL((gemm_reduce_kernel<1, 4>), dim3((unsigned)rgrid), dim3(256), 0, st, a.partial, grid, J, C, o, dwr, Co, C);
+  return check_launch(who);
 }
 
 }  // namespace cl3d
@@ -1143,6 +1352,34 @@ extern "C" int cl3d_pwmlp_point_gemm_bwd_weight_pro(const float *x, const float 
   CL3D_REQUIRE(B >= 1 && x && scale && shift && dght && dW, "pwmlp_point_gemm_bwd_weight_pro: null pointer");
   return point_gemm_bwd_weight(x, scale, shift, dght, dwr, B, C, N, Co, precision, dW, ws, ws_bytes, (hipStream_t)stream,
                                "cl3d_pwmlp_point_gemm_bwd_weight_pro");
+}
+
+extern "C" int cl3d_pwmlp_point_gemm_bwd_fused(int B, int C, int N, int Co, int precision) {
+  return point_grads_covers(B, C, N, Co, precision) && (long long)B * (N / kPgTP) <= 0x7fffffffLL ? 1 : 0;
+}
+
+// both gradients of the per-point product: ONE kernel over d ght where pwmlp_point_grads_kernel covers the shape
+// (cl3d_pwmlp_point_gemm_bwd_fused), the two products one after the other on `stream` otherwise
+extern "C" int cl3d_pwmlp_point_gemm_bwd(const float *features, const float *scale, const float *shift,
+                                         const float *dght, const float *wcat, const float *dwr, int B, int C, int N,
+                                         int Co, int precision, float *dfeatures, float *dW, void *ws, size_t ws_bytes,
+                                         cl3d_stream_t stream) {
+  GEMM_COMMON_CHECKS("pwmlp_point_gemm_bwd");
+  CL3D_REQUIRE((scale == nullptr) == (shift == nullptr), "pwmlp_point_gemm_bwd: scale and shift go together");
+  CL3D_REQUIRE(dfeatures != nullptr || dW != nullptr, "pwmlp_point_gemm_bwd: no output asked for");
+  CL3D_REQUIRE(B == 0 || (dght && wcat && (dW == nullptr || features)), "pwmlp_point_gemm_bwd: null pointer");
+  if (B == 0) return dW == nullptr ? CL3D_OK : fail(CL3D_E_INVALID, "pwmlp_point_gemm_bwd: a weight gradient needs B >= 1");
+  if (cl3d_pwmlp_point_gemm_bwd_fused(B, C, N, Co, precision) && features != nullptr)
+    return launch_point_grads(features, scale, shift, dght, wcat, dwr, B, C, N, Co, dfeatures, dW, ws, ws_bytes,
+                              (hipStream_t)stream, "cl3d_pwmlp_point_gemm_bwd");
+  if (dfeatures != nullptr) {
+    const int rc = cl3d_pwmlp_point_gemm_bwd_data(dght, wcat, B, C, N, Co, precision, dfeatures, ws, ws_bytes, stream);
+    if (rc != CL3D_OK) return rc;
+  }
+  if (dW != nullptr)
+    return point_gemm_bwd_weight(features, scale, shift, dght, dwr, B, C, N, Co, precision, dW, ws, ws_bytes,
+                                 (hipStream_t)stream, "cl3d_pwmlp_point_gemm_bwd");
+  return CL3D_OK;
 }
 
 // ---- the 1x1 Conv1d layers around the operator (backbones/resnet.py:32-39,58-66), channel-major in and out ---------

@@ -87,6 +87,17 @@ static PassGraphs g_graphs[2][64];
 static std::atomic<int> g_graphs_on{1};
 static std::atomic<long long> g_captures{0}, g_replays{0};
 
+static_assert(sizeof(cl3d_pwmlp_pass) == 14 * 4 + 13 * 8 + 4 * sizeof(size_t) + 29 * 8, "cl3d_pwmlp_pass has padding: compare field-wise");
+
+// the block as the launch-graph tables key it: a byte copy with the reserved word (the only bytes no field of the ABI
+// defines) cleared, so two calls with the same arguments compare equal whatever the caller left there
+static cl3d_pwmlp_pass block_key(const cl3d_pwmlp_pass *p) {
+  cl3d_pwmlp_pass k;
+  memcpy(&k, p, sizeof(k));
+  k.reserved = 0;
+  return k;
+}
+
 static unsigned long long block_hash(const cl3d_pwmlp_pass *p) {  // FNV-1a over the block's bytes (never 0)
   const unsigned char *b = reinterpret_cast<const unsigned char *>(p);
   unsigned long long h = 1469598103934665603ull;
@@ -104,6 +115,7 @@ static int run_pass(int dir, const cl3d_pwmlp_pass *p, hipStream_t st, PassRunti
     return enqueue(st);  // inside the caller's own capture: the launches become nodes of ITS graph
   }
   PassGraphs &g = g_graphs[dir][dev];
+  const cl3d_pwmlp_pass key = block_key(p);
   ++g.tick;
   for (int k = 0; k < kGraphSlots; ++k)
     if (g.retired[k] != nullptr && g.retired_at[k] + kIdleCalls < g.tick) {
@@ -111,12 +123,12 @@ static int run_pass(int dir, const cl3d_pwmlp_pass *p, hipStream_t st, PassRunti
       g.retired[k] = nullptr;
     }
   for (int k = 0; k < kGraphSlots; ++k)
-    if (g.exec[k] != nullptr && memcmp(&g.key[k], p, sizeof(*p)) == 0) {
+    if (g.exec[k] != nullptr && memcmp(&g.key[k], &key, sizeof(key)) == 0) {
       g.used[k] = g.tick;
       g_replays.fetch_add(1);
       return hip_ok(hipGraphLaunch(g.exec[k], st), "pwmlp pass: graph launch");
     }
-  const unsigned long long h = block_hash(p);
+  const unsigned long long h = block_hash(&key);
   bool seen = false;
   for (int k = 0; k < kSeen; ++k) seen = seen || g.seen[k] == h;
   int slot = -1;  // an empty slot, else one idle for kIdleCalls calls whose predecessor in the retired list is gone
@@ -150,7 +162,7 @@ static int run_pass(int dir, const cl3d_pwmlp_pass *p, hipStream_t st, PassRunti
     g.retired[slot] = g.exec[slot];
     g.retired_at[slot] = g.tick;
   }
-  g.key[slot] = *p;
+  memcpy(&g.key[slot], &key, sizeof(key));
   g.exec[slot] = exec;
   g.used[slot] = g.tick;
   g_captures.fetch_add(1);
@@ -199,25 +211,32 @@ static int enqueue_forward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::PassR
   // handed to a side stream starts one cross-queue hand-over (~10 us) late and its join is free once it has finished: so
   // the per-point product (26 us, needs nothing of the geometry) is what forks, and it is done long before the query
   // (55-62 us) is; the CSR build forks behind the query and is joined at the very end
+  // (the query is ENQUEUED first, the product forked from the point before it: in a captured pass the first-recorded root
+  // and its first-recorded dependents get the launch queue)
   CL3D_TRY(hip_ok(hipEventRecord(rt->ev_in, st), "pwmlp_train_forward: event"));
+  if (!p->idx_ready)
+    CL3D_TRY(cl3d_masked_ordered_ball_query(p->query_xyz, p->support_xyz, p->query_mask, p->support_mask, p->B, p->M, p->N,
+                                            p->radius, p->K, p->idx, p->idx_mask, p->bq_ws, p->bq_ws_bytes, st));
   CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[0], rt->ev_in, 0), "pwmlp_train_forward: fork"));
   CL3D_TRY(cl3d_pwmlp_point_gemm_fwd(p->features, p->W, p->B, p->C, p->N, p->Co, p->precision, p->ght, p->wr, p->wcat,
                                      p->gemm_ws, p->gemm_ws_bytes, rt->side[0]));
   CL3D_TRY(hip_ok(hipEventRecord(rt->ev_fork, rt->side[0]), "pwmlp_train_forward: event"));
-  if (!p->idx_ready)
-    CL3D_TRY(cl3d_masked_ordered_ball_query(p->query_xyz, p->support_xyz, p->query_mask, p->support_mask, p->B, p->M, p->N,
-                                            p->radius, p->K, p->idx, p->idx_mask, p->bq_ws, p->bq_ws_bytes, st));
   if (want_csr) {
     CL3D_REQUIRE(p->inv_slots != nullptr, "pwmlp_train_forward: null inv_slots");
     CL3D_TRY(hip_ok(hipEventRecord(rt->ev_bq, st), "pwmlp_train_forward: event"));
+  }
+  CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_fork, 0), "pwmlp_train_forward: join"));
+  CL3D_TRY(cl3d_pwmlp_stats(p->query_xyz, p->support_xyz, p->idx, p->ght, p->wr, p->gamma, p->B, p->N, p->M, p->K, p->Co,
+                            p->radius, p->ystar, p->kstar, p->sy, p->partial, p->n_partials, st));
+  // the CSR build is enqueued BEHIND the statistics pass (it still only waits for the query): a captured pass is laid out
+  // depth-first along each node's first-recorded dependent (that one stays on the node's queue, later ones move to
+  // another), so the statistics pass -- the critical chain -- must be the query's first dependent, not the CSR build
+  if (want_csr) {
     CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[1], rt->ev_bq, 0), "pwmlp_train_forward: fork"));
     CL3D_TRY(cl3d_build_inverse_index(p->idx, p->B, p->N, p->M * p->K, p->inv_off, p->inv_slots, p->csr_ws, p->csr_ws_bytes,
                                       rt->side[1]));
     CL3D_TRY(hip_ok(hipEventRecord(rt->ev_csr, rt->side[1]), "pwmlp_train_forward: event"));
   }
-  CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_fork, 0), "pwmlp_train_forward: join"));
-  CL3D_TRY(cl3d_pwmlp_stats(p->query_xyz, p->support_xyz, p->idx, p->ght, p->wr, p->gamma, p->B, p->N, p->M, p->K, p->Co,
-                            p->radius, p->ystar, p->kstar, p->sy, p->partial, p->n_partials, st));
   float *scale = p->vec, *shift = p->vec + p->Co, *mean = p->vec + 2 * p->Co, *invstd = p->vec + 3 * p->Co;
   CL3D_TRY(cl3d_pwmlp_finalize_stats(p->partial, p->n_partials, p->Co, (double)p->B * p->M * p->K, p->eps, p->momentum,
                                      p->gamma, p->beta, p->running_mean, p->running_var, p->num_batches_tracked, scale, shift,
@@ -257,8 +276,11 @@ static int enqueue_backward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::Pass
   CL3D_TRY(cl3d_pwmlp_bwd_hits(p->dz_cm, p->ts_cm, p->B, p->N, p->M, Co, p->hit, st));
   CL3D_TRY(cl3d_pwmlp_bwd_support(p->ght, p->wr, cA, cB, cD, p->hit, p->dz_t, p->sy, p->qtab, p->support_xyz, p->radius,
                                   p->inv_off, p->inv_slots, p->B, p->N, p->M, p->K, Co, p->dght, st));
-  // ---- the two gradient products side by side: the longer one (weights: product + slice reduce, ~45 us) on the caller's
+  // ---- the two gradient products: ONE kernel over d ght where it covers the shape; otherwise side by side, the longer one (weights: product + slice reduce, ~45 us) on the caller's
   // stream, the data gradient (~25 us) on the side stream -- hand-over included it ends first, the join is free
+  if (p->dW != nullptr && p->dfeat != nullptr && cl3d_pwmlp_point_gemm_bwd_fused(p->B, p->C, p->N, Co, p->precision))
+    return cl3d_pwmlp_point_gemm_bwd(p->features, nullptr, nullptr, p->dght, p->wcat, p->dwr, p->B, p->C, p->N, Co,
+                                     p->precision, p->dfeat, p->dW, p->gemm_ws_w, p->gemm_ws_bytes_b, st);  // one kernel forms both
   const bool fork = p->dW != nullptr && p->dfeat != nullptr;
   hipStream_t dst = st;
   if (fork) {

@@ -11,6 +11,7 @@ cover (non-shipped variants such as PosPool with max reduction or a two-layer Ad
 """
 import contextlib
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -71,28 +72,34 @@ def _stream(t):
     return _lib.stream_ptr(t.device)
 
 
-FORK_GRADS = True  # False: the two gradient products of a contraction one after the other (scripts' A/B)
-
-
 def _fork_join(device, side_fn, main_fn):
-    """Two independent pieces of a backward pass (the data gradient and the weight gradient of one contraction; the
-    arg-max scatter and the per-channel BatchNorm algebra) side by side: `side_fn` on a side HIP stream, `main_fn` on the
-    caller's, joined before returning.  Each is a short latency-bound launch that leaves most of the chip idle on its
-    own.  Active whenever the index streams are (pt_utils.async_index(): always while a HIP graph is captured, where the
-    fork becomes two parallel branches of the graph); otherwise one after the other on the caller's stream.  Outputs
-    are allocated by the caller BEFORE the fork (on the caller's stream); whatever side_fn allocates is scratch that
-    lives and dies on the side stream."""
-    if not (FORK_GRADS and device.type == 'cuda' and pt_utils.async_index()):
-        side_fn()
+    """Two independent pieces of a backward pass (the data gradient and the weight gradient of one contraction) side by
+    side: `main_fn` on the caller's stream, `side_fn` on a side HIP stream, joined before returning.  Active only while
+    a DECLARED whole-step HIP graph is captured (whole_step_capture(): forward and backward in one capture), where the
+    fork becomes two parallel branches of the graph; everywhere else -- eager launches, a capture that holds a backward
+    pass alone (torch.cuda.make_graphed_callables) -- the two run one after the other on the caller's stream.  A forked
+    pair inside a graph that holds ONLY a backward pass, reading tensors another capture allocated, gave replay-varying
+    gradients in round 4 (DESIGN 6 "Round 4 (b)", not root-caused): that configuration is refused here, not left to a
+    script's flag.
+    `main_fn` is enqueued FIRST: the HIP runtime lays a graph out depth-first along each node's first-captured dependent
+    (hip_graph_internal: the first edge inherits the parent's queue, every further edge gets another), so the piece
+    captured first behind the predecessor stays on the predecessor's queue and what follows it needs no cross-queue
+    hand-over (~10 us each in the replayed step, profiles/r04/step_timeline.txt).
+    Outputs are allocated by the caller BEFORE the fork (on the caller's stream); whatever side_fn allocates is scratch
+    that lives and dies on the side stream."""
+    if not (device.type == 'cuda' and pt_utils.async_index() and _forks_allowed()):
         main_fn()
+        side_fn()
         return
     main, side = torch.cuda.current_stream(device), pt_utils.index_stream(device, 2)
-    side.wait_stream(main)
+    ev0 = torch.cuda.Event()
+    ev0.record(main)       # the predecessor of both pieces
+    main_fn()
+    side.wait_event(ev0)
     with torch.cuda.stream(side):
         side_fn()
         ev = torch.cuda.Event()
         ev.record(side)
-    main_fn()
     main.wait_event(ev)
 
 
@@ -165,8 +172,58 @@ def _join_inverse(idx):
         _PENDING[:] = [t for t in _PENDING if t is not idx]
 
 
-_WHOLE_STEP = [False]
-_PENDING = []  # idx tensors whose CSR build a captured forward left on the index stream for its backward to join
+class _PerThread:
+    """A list whose contents belong to the calling thread: a stream capture is a per-thread affair (another thread may
+    capture, or run eagerly, on another device at the same time), so is the bookkeeping around one."""
+
+    def __init__(self, initial=()):
+        self._initial, self._tls = tuple(initial), threading.local()
+
+    def _l(self):
+        lst = getattr(self._tls, 'lst', None)
+        if lst is None:
+            lst = self._tls.lst = list(self._initial)
+        return lst
+
+    def __getitem__(self, k): return self._l()[k]
+    def __setitem__(self, k, v): self._l()[k] = v
+    def __delitem__(self, k): del self._l()[k]
+    def __len__(self): return len(self._l())
+    def __iter__(self): return iter(self._l())
+    def __contains__(self, x): return any(t is x for t in self._l())
+    def __eq__(self, other): return self._l() == other
+    def append(self, x): self._l().append(x)
+
+
+_WHOLE_STEP = _PerThread([False])
+_PENDING = _PerThread()  # idx tensors whose CSR build a captured forward left on the index stream for its backward to join
+_FORKS = _PerThread([None])  # None: gradient products fork in a declared whole-step capture only; else forked_gradients()
+
+
+def _forks_allowed():
+    return _WHOLE_STEP[0] if _FORKS[0] is None else _FORKS[0]
+
+
+@contextlib.contextmanager
+def forked_gradients(on):
+    """Explicit override of where the two gradient products of a contraction may run side by side on two HIP streams
+    (_fork_join).  Default (no override): only inside a capture declared with whole_step_capture() -- a graph that holds
+    forward AND backward.  forked_gradients(True) extends it to the capture it wraps: exact, as measured, for a graph
+    that holds the forward pass and PART of its backward (scripts/bench_backbone.py --overlap, graph A);
+    a graph that holds a backward pass ALONE and reads tensors another capture allocated gave wrong, replay-varying
+    gradients with such forks in it (not root-caused) -- do not use it there.  forked_gradients(False) takes
+    the forks out of a declared whole-step capture."""
+    old = _FORKS[0]
+    _FORKS[0] = None if on is None else bool(on)
+    try:
+        yield
+    finally:
+        _FORKS[0] = old
+
+
+def _is_unjoined_capture_error(e):
+    text = f"{type(e).__name__}: {e}".lower()
+    return "unjoined" in text or "capture" in text and "join" in text
 
 
 @contextlib.contextmanager
@@ -176,18 +233,22 @@ def whole_step_capture(on=True):
     then leave the CSR build it forked for its backward (on the index stream) to be joined by that backward's
     support-major pass, inside the same capture: joined at the end of the forward, the FIRST backward kernel inherits
     a cross-queue wait for a table only a later kernel reads (replayed step, round 3: ~12 us between the forward's
-    last kernel and the backward's first, against ~5 us between kernels of one queue).  Without the declaration a
-    captured forward pass ends fully joined, as hipStreamEndCapture demands of a capture that stops there
-    (torch.cuda.make_graphed_callables captures forward and backward separately); the backward is the same kernels
-    either way.  Eager launches never need it.  A declared capture whose backward did NOT run inside it is reported
-    here by name instead of as a bare hipErrorStreamCaptureUnjoined."""
+    last kernel and the backward's first, against ~5 us between kernels of one queue); and the two gradient products of
+    a contraction may run side by side (_fork_join).  Without the declaration a captured forward pass ends fully joined,
+    as hipStreamEndCapture demands of a capture that stops there (torch.cuda.make_graphed_callables captures forward and
+    backward separately), and a captured backward pass is single-stream; the kernels are the same either way.  Eager
+    launches never need it.  A declared capture whose backward did NOT run inside it is reported here by name instead of
+    as a bare hipErrorStreamCaptureUnjoined; any OTHER error raised inside the context (out of memory, a kernel's error
+    code) reaches the caller unchanged."""
     old = _WHOLE_STEP[0]
     _WHOLE_STEP[0] = bool(on)
     del _PENDING[:]
+    failed = False
     try:
         yield
     except Exception as e:
-        if _PENDING:
+        failed = True
+        if _PENDING and _is_unjoined_capture_error(e):
             raise RuntimeError(
                 f"whole_step_capture(): {len(_PENDING)} PointWiseMLP forward pass(es) left their CSR build on the index "
                 "stream, but no backward pass joined it inside the capture -- capture forward AND backward together, "
@@ -197,9 +258,9 @@ def whole_step_capture(on=True):
         _WHOLE_STEP[0] = old
         left = len(_PENDING)
         del _PENDING[:]
-    if left:
-        raise RuntimeError(f"whole_step_capture(): {left} PointWiseMLP forward pass(es) were captured without their "
-                           "backward pass; the captured graph ends with unjoined work")
+        if left and not failed:
+            raise RuntimeError(f"whole_step_capture(): {left} PointWiseMLP forward pass(es) were captured without their "
+                               "backward pass; the captured graph ends with unjoined work")
 
 
 def _join_geometry(idx):
@@ -245,6 +306,8 @@ class _FusedReduce(Function):
                 op, _p(query_xyz), _p(support_xyz), _p(query_mask), _p(idx), _p(idx_mask), _p(ft), B, N, M, K, C,
                 float(radius), int(normalize), reduction, _p(p0), _p(p1), pint, float(pfloat), int(constant),
                 _p(out), 1, _p(slotrec), _p(pairs), _stream(features)))
+        if need_grad:
+            _start_inverse(idx, N)
         ctx.save_for_backward(ft, slotrec, p0, p1, pairs)
         ctx.idx = idx
         ctx.meta = (op, B, N, M, K, C, pint, pfloat, constant)
@@ -303,14 +366,26 @@ def _wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
+_CSR_FIRST = os.environ.get('CL3D_CSR_FIRST') == '1'  # (round-5 A/B only: the round-4 order, CSR build captured behind the query)
+
+
 def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad=False):
-    """Ball query (and, when a backward will follow, the CSR inverse) on the index stream; the fused
-    Functions wait_ready() the result right before their first kernel that reads it."""
+    """Ball query on the index stream; the fused Functions wait_ready() the result right before their first kernel that
+    reads it and start the CSR inverse (when a backward will follow) right BEHIND that kernel (_start_inverse)."""
     idx, idx_mask = _ball_query(query_xyz.contiguous(), support_xyz.contiguous(), query_mask.contiguous(),
                                 support_mask.contiguous(), radius, nsample, defer=True)
-    if need_grad:
+    if need_grad and _CSR_FIRST:
         inverse_index(idx, support_xyz.shape[1], prefetch=True)
     return idx, idx_mask
+
+
+def _start_inverse(idx, n_support):
+    """Fork the CSR build of idx onto the index stream (no-op when it exists or is under way).  Called right AFTER the
+    forward kernel that reads idx has been enqueued: in a captured step the HIP runtime keeps a node's FIRST-captured
+    dependent on the node's own queue and hands every later one to another queue (_fork_join), so the order of these two
+    launches decides whether the step's critical chain -- ball query -> gather pass -> ... -- or the CSR build, which has
+    ~100 us of slack, pays the cross-queue hand-over behind the ball query (12.7 us in profiles/r04/step_timeline.txt)."""
+    inverse_index(idx, n_support, prefetch=True)
 
 
 def _deferred(out, idx, defer_join):
@@ -389,6 +464,8 @@ class _MaxPool(Function):
         with _lib.on_device(features.device):
             _lib.check(_lib.lib().cl3d_maxpool_fwd(_p(idx), _p(ft), B, N, M, K, C, _p(out), _p(kstar),
                                                    _stream(features)))
+        if need_grad:
+            _start_inverse(idx, N)
         ctx.save_for_backward(kstar)
         ctx.idx = idx
         ctx.meta = (B, N, M, K, C)
@@ -523,6 +600,8 @@ class _PointwiseMLP(Function):
                 _lib.check(lib.cl3d_pwmlp_stats(_p(query_xyz), _p(support_xyz), _p(idx), _p(ght), _p(wr), _p(gamma),
                                                 B, N, M, K, Co, float(radius), _p(ystar), _p(kstar), _p(sy),
                                                 _p(partial), nparts, st))
+                if need_grad:
+                    _start_inverse(idx, N)
                 # batch statistics, scale/shift and the running-statistics update in one small launch
                 _lib.check(lib.cl3d_pwmlp_finalize_stats(_p(partial), nparts, Co, float(n), float(eps), float(momentum),
                                                          _p(gamma), _p(beta), _p(running_mean), _p(running_var),
@@ -668,7 +747,13 @@ class _PointRows(Function):
                                                                 _p(ws), ws_bytes, _stream(features)))
 
         with _lib.on_device(dev):
-            _fork_join(dev, weight_grad, data_grad)
+            if need_x and need_w and lib.cl3d_pwmlp_point_gemm_bwd_fused(B, C, N, Co, prec):
+                # one kernel over d ght forms both (csrc/mfma_gemm.hip pwmlp_point_grads_kernel): nothing to fork
+                ws, ws_bytes = _gemm_scratch(14, B, N, Co, C, dev)
+                _lib.check(lib.cl3d_pwmlp_point_gemm_bwd(_p(features), None, None, _p(dght), _p(wcat), _p(dwr), B, C, N, Co,
+                                                         prec, _p(dfeat), _p(dW), _p(ws), ws_bytes, _stream(features)))
+            else:
+                _fork_join(dev, weight_grad, data_grad)
         return dfeat, dW, None
 
 
@@ -770,7 +855,12 @@ class _BnReluPointRows(Function):
         coef = torch.empty((5, C), dtype=torch.float32, device=dev)
         partial = torch.empty((ctx.nparts, C, 2), dtype=torch.float64, device=dev)
         with _lib.on_device(dev):
-            _fork_join(dev, weight_grad, data_grad)
+            if lib.cl3d_pwmlp_point_gemm_bwd_fused(B, C, N, Co, prec):
+                ws, ws_bytes = _gemm_scratch(14, B, N, Co, C, dev)
+                _lib.check(lib.cl3d_pwmlp_point_gemm_bwd(_p(y1), _p(vec[0]), _p(vec[1]), _p(dght), _p(wcat), _p(dwr), B, C, N,
+                                                         Co, prec, _p(dact), _p(dW), _p(ws), ws_bytes, _stream(y1)))
+            else:
+                _fork_join(dev, weight_grad, data_grad)
             _lib.check(lib.cl3d_bn_relu_bwd(_p(dact), _p(y1), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _p(gamma), B, C, N,
                                             float(B * N), _p(partial), ctx.nparts, _p(coef), _p(dy1), _stream(y1)))
         return dy1, coef[3], coef[4], None, dW, None

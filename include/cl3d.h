@@ -37,7 +37,7 @@ extern "C" {
  * 3: round 4 -- cl3d_pwmlp_support_summary / cl3d_pwmlp_bwd_support_sum are gone (cl3d_pwmlp_bwd_support is the one
  * support-major pass again, same argument list as in version 2); cl3d_pwmlp_train_forward / _backward added (one call
  * per pass, csrc/pass.hip); cl3d_sphere_crop_assemble takes the capacity of the index list it is handed */
-#define CL3D_ABI_VERSION 3
+#define CL3D_ABI_VERSION 4
 
 #define CL3D_OK 0
 #define CL3D_E_INVALID (-1)     /* bad argument (null pointer, negative size, ...) */
@@ -284,6 +284,18 @@ int cl3d_pwmlp_point_gemm_bwd_data(const float *dght, const float *wcat, int B, 
 int cl3d_pwmlp_point_gemm_bwd_weight(const float *features, const float *dght, const float *dwr, int B, int C,
                                      int N, int Co, int precision, float *dW, void *ws, size_t ws_bytes,
                                      cl3d_stream_t stream);
+/* Both gradients of the per-point product from ONE pass over d ght (round 5, csrc/mfma_gemm.hip
+ * pwmlp_point_grads_kernel): a workgroup stages a 64-point tile of d ght and of the features once in LDS and forms
+ * d features (wcat^T d ght) and its share of d wcat (d ght^T features) from it; the workgroups' partial tiles are added
+ * in workgroup order (bit-reproducible) by the reduce that also writes d W [Co,3+2C].  scale / shift (nullable
+ * together): the features enter the weight gradient as max(scale[c] x + shift[c], 0) -- the _pro form below.
+ * dfeatures or dW may be NULL (that gradient is not formed).  cl3d_pwmlp_point_gemm_bwd_fused() = 1 where the one-kernel
+ * form covers the shape (f32, C <= 64, 2 Co <= 128, whole 64-point tiles per cloud); elsewhere the call runs bwd_data and
+ * bwd_weight one after the other on `stream`.  ws: cl3d_workspace_bytes(CL3D_OP_POINT_GEMM, ...), required for dW. */
+int cl3d_pwmlp_point_gemm_bwd_fused(int B, int C, int N, int Co, int precision);
+int cl3d_pwmlp_point_gemm_bwd(const float *features, const float *scale, const float *shift, const float *dght,
+                              const float *wcat, const float *dwr, int B, int C, int N, int Co, int precision,
+                              float *dfeatures, float *dW, void *ws, size_t ws_bytes, cl3d_stream_t stream);
 /* The 1x1 Conv1d layers either side of the operator (backbones/resnet.py:32-39,58-66; bias-free), same kernel:
  * y [B,Co,N] = W [Co,C] x [B,C,N], its input gradient and its weight gradient
  * (ws: cl3d_workspace_bytes(CL3D_OP_CONV1X1, B, N, Co, 0, C); optional for fwd / bwd_data as above). */
@@ -393,6 +405,8 @@ int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const float *cA, c
 typedef struct cl3d_pwmlp_pass {
   int B, N, M, K, C, Co, precision, idx_ready, csr_ready, n_partials;
   float radius, eps, momentum;
+  int reserved;  /* (what would be padding: the block has none.  Ignored by the library -- a caller need not zero the
+                    block for its passes to be recognised as repeats and replayed from a launch graph) */
   const float *query_xyz, *support_xyz;
   const int32_t *query_mask, *support_mask;
   int32_t *idx, *idx_mask, *inv_off, *inv_slots;

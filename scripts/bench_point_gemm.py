@@ -58,8 +58,12 @@ def measure(B=16, C=64, N=4096, Co=64, reps=50, library=True):
         t_d = _time(lambda: lib.cl3d_pwmlp_point_gemm_bwd_data(p(dght), p(wcat), B, C, N, Co, prec, p(dfeat), p(ws), ws_bytes, st), reps)
         t_w = _time(lambda: lib.cl3d_pwmlp_point_gemm_bwd_weight(p(f), p(dght), p(dwr), B, C, N, Co, prec, p(dW), p(ws),
                                                                   ws_bytes, st), reps)
+        # both gradients in one call: one kernel over d ght where it covers the shape (round 5), else the two in a row
+        t_b = _time(lambda: lib.cl3d_pwmlp_point_gemm_bwd(p(f), None, None, p(dght), p(wcat), p(dwr), B, C, N, Co, prec,
+                                                          p(dfeat), p(dW), p(ws), ws_bytes, st), reps)
         tot = t_f + t_d + t_w
         out["mfma_" + name] = {
+            "bwd_both_us": t_b * 1e6, "bwd_both_one_kernel": bool(lib.cl3d_pwmlp_point_gemm_bwd_fused(B, C, N, Co, prec)),
             "fwd_us": t_f * 1e6, "bwd_data_us": t_d * 1e6, "bwd_weight_us": t_w * 1e6,  # each incl. its small side launch
             "tflops": 3 * flops / tot / 1e12, "frac_of_mfma_peak": 3 * flops / tot / 1e12 / PEAK_TFLOPS[name],
             "hbm_GBps": 3 * io_bytes / tot / 1e9, "frac_of_hbm_peak": 3 * io_bytes / tot / 1e9 / HBM_GBPS,
@@ -133,21 +137,10 @@ if __name__ == "__main__":
     ap.add_argument("--reps", type=int, default=50)
     ap.add_argument("--sweep", action="store_true", help="also the ModelNet backbone's operator shapes (width 144)")
     ap.add_argument("--convs", action="store_true", help="the 1x1 convolutions of the ModelNet backbone (config 2) vs torch Conv1d")
-    ap.add_argument("--tiles", action="store_true", help="tuning: every workgroup tile (CL3D_GEMM_TILE) per shape, f32 and bf16")
     a = ap.parse_args()
     if a.convs:
         for C, Co, N in CONFIG2_CONVS:
             print(json.dumps(measure_conv(a.B, C, N, Co, a.reps)))
-        sys.exit(0)
-    if a.tiles:
-        shapes = [(a.C, a.N)] + ([(72, 4096), (144, 1024), (288, 256), (576, 64)] if a.sweep else [])
-        for C, N in shapes:
-            for tile in ("2,2", "2,1", "1,2", "1,1"):
-                os.environ["CL3D_GEMM_TILE"] = tile
-                r = measure(a.B, C, N, C, a.reps, library=False)
-                print(json.dumps({"C": C, "N": N, "tile": tile,
-                                  "f32": [round(r["mfma_f32"][k], 1) for k in ("fwd_us", "bwd_data_us", "bwd_weight_us")],
-                                  "bf16": [round(r["mfma_bf16"][k], 1) for k in ("fwd_us", "bwd_data_us", "bwd_weight_us")]}))
         sys.exit(0)
     res = [measure(a.B, a.C, a.N, a.Co, a.reps)]
     if a.sweep:

@@ -108,6 +108,70 @@ def test_point_gemm_forward_and_gradients(B, C, N, Co, prec):
     assert torch.equal(dW, dW2)
 
 
+# round 5: both gradients from one pass over d ght (pwmlp_point_grads_kernel).  (B, C, N, Co, fused?)
+GRAD_SHAPES = [
+    (16, 64, 4096, 64, 1),   # the metric shape: the unmasked (FULL) variant, 256 workgroups x 4 tiles
+    (2, 64, 128, 64, 1),     # fewer tiles than workgroups
+    (3, 36, 192, 20, 1),     # padded channels and columns (C = 36 of 64, 2 Co = 40 of 128)
+    (1, 32, 64, 64, 1),      # a single tile
+    (5, 64, 320, 32, 1),     # tiles_per_cloud = 5: the (cloud, tile) decode
+    (2, 72, 256, 36, 0),     # C > 64: the call runs the two products one after the other
+    (2, 64, 100, 64, 0),     # N not a multiple of the 64-point tile: likewise
+]
+
+
+@pytest.mark.parametrize("B,C,N,Co,fused", GRAD_SHAPES)
+@pytest.mark.parametrize("pro", [False, True])
+def test_point_gemm_both_gradients_in_one_call(B, C, N, Co, fused, pro):
+    lib = _lib.lib()
+    assert lib.cl3d_pwmlp_point_gemm_bwd_fused(B, C, N, Co, 0) == fused
+    assert lib.cl3d_pwmlp_point_gemm_bwd_fused(B, C, N, Co, 1) == 0  # bf16: the two-product path
+    f, W, dght, dwr = _inputs(B, C, N, Co, seed=B * 77 + C + N)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    scale = (torch.rand(C, generator=g) + 0.5).to(_dev()) if pro else None
+    shift = (torch.randn(C, generator=g) * 0.3).to(_dev()) if pro else None
+    wr = torch.empty(Co, 3, device=_dev())
+    wcat = torch.empty(2 * Co, C, device=_dev())
+    ws_bytes = lib.cl3d_workspace_bytes(14, B, N, Co, 0, C)
+    ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=_dev())
+    _lib.check(lib.cl3d_pwmlp_split_weight(_p(W), Co, C, _p(wr), _p(wcat), _st()))
+    dfeat = torch.full((B, C, N), float("nan"), device=_dev())
+    dW = torch.full((Co, 3 + 2 * C), float("nan"), device=_dev())
+    _lib.check(lib.cl3d_pwmlp_point_gemm_bwd(_p(f), _p(scale), _p(shift), _p(dght), _p(wcat), _p(dwr), B, C, N, Co, 0,
+                                             _p(dfeat), _p(dW), _p(ws), ws_bytes, _st()))
+    wc64 = wcat.double()
+    act = f.double() if not pro else torch.relu(torch.addcmul(shift[None, :, None], f, scale[None, :, None])).double()
+    want_df = torch.einsum("bno,oc->bcn", dght.double(), wc64)
+    dwcat = torch.einsum("bno,bcn->oc", dght.double(), act)
+    want_dW = torch.cat([dwr.double(), dwcat[Co:], dwcat[:Co] - dwcat[Co:]], 1)
+    assert _rel(dfeat, want_df) <= TOL
+    assert _rel(dW, want_dW) <= 2e-5  # B*N-term sums
+    assert torch.equal(dW[:, :3], dwr)
+    # workgroup-ordered partial sums: bit-identical run to run, and each gradient alone equals the pair's
+    dfeat2, dW2 = torch.full_like(dfeat, float("nan")), torch.full_like(dW, float("nan"))
+    _lib.check(lib.cl3d_pwmlp_point_gemm_bwd(_p(f), _p(scale), _p(shift), _p(dght), _p(wcat), _p(dwr), B, C, N, Co, 0,
+                                             _p(dfeat2), None, _p(ws), ws_bytes, _st()))
+    _lib.check(lib.cl3d_pwmlp_point_gemm_bwd(_p(f), _p(scale), _p(shift), _p(dght), _p(wcat), _p(dwr), B, C, N, Co, 0,
+                                             None, _p(dW2), _p(ws), ws_bytes, _st()))
+    assert torch.equal(dfeat, dfeat2) and torch.equal(dW, dW2)
+    # the separate entry points agree to rounding (another summation order)
+    if not pro:
+        dW3 = torch.empty_like(dW)
+        _lib.check(lib.cl3d_pwmlp_point_gemm_bwd_weight(_p(f), _p(dght), _p(dwr), B, C, N, Co, 0, _p(dW3), _p(ws), ws_bytes, _st()))
+        assert _rel(dW3, dW.double()) <= 2e-5
+
+
+def test_point_gemm_both_gradients_argument_checks():
+    lib = _lib.lib()
+    x = torch.zeros(1, 64, 64, device=_dev())
+    g = torch.zeros(1, 64, 128, device=_dev())
+    w = torch.zeros(128, 64, device=_dev())
+    out = torch.zeros(64, 131, device=_dev())
+    assert lib.cl3d_pwmlp_point_gemm_bwd(_p(x), None, None, _p(g), _p(w), None, 1, 64, 64, 64, 0, None, None, None, 0, None) == -1
+    assert lib.cl3d_pwmlp_point_gemm_bwd(_p(x), _p(x), None, _p(g), _p(w), None, 1, 64, 64, 64, 0, _p(x), None, None, 0, None) == -1
+    assert lib.cl3d_pwmlp_point_gemm_bwd(_p(x), None, None, _p(g), _p(w), None, 1, 64, 64, 64, 0, None, _p(out), None, 0, None) == -3  # no scratch
+
+
 @pytest.mark.parametrize("B,C,N,Co", [(2, 72, 4096, 144), (4, 144, 1000, 36), (1, 3, 130, 72), (2, 1152, 64, 576),
                                       (1, 288, 10000, 288), (16, 2304, 16, 1152), (16, 1152, 16, 2304)])  # deep: K slices
 @pytest.mark.parametrize("prec", [0, 1])
