@@ -228,11 +228,14 @@ static int enqueue_forward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::PassR
   CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_fork, 0), "pwmlp_train_forward: join"));
   CL3D_TRY(cl3d_pwmlp_stats(p->query_xyz, p->support_xyz, p->idx, p->ght, p->wr, p->gamma, p->B, p->N, p->M, p->K, p->Co,
                             p->radius, p->ystar, p->kstar, p->sy, p->partial, p->n_partials, st));
-  // the CSR build is enqueued BEHIND the statistics pass (it still only waits for the query): a captured pass is laid out
-  // depth-first along each node's first-recorded dependent (that one stays on the node's queue, later ones move to
-  // another), so the statistics pass -- the critical chain -- must be the query's first dependent, not the CSR build
+  // the CSR build is enqueued BEHIND the statistics pass: a captured pass is laid out depth-first along each node's
+  // first-recorded dependent (that one stays on the node's queue, later ones move to the other), so the statistics
+  // pass -- the critical chain -- must be the query's first dependent, not the CSR build
   if (want_csr) {
     CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[1], rt->ev_bq, 0), "pwmlp_train_forward: fork"));
+    // ... and waits for the per-point product as well (long finished): the build and the product share the replayed
+    // pass's side queue, and this puts the product -- which the statistics pass needs -- in front (fused.py _start_inverse)
+    CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[1], rt->ev_fork, 0), "pwmlp_train_forward: order"));
     CL3D_TRY(cl3d_build_inverse_index(p->idx, p->B, p->N, p->M * p->K, p->inv_off, p->inv_slots, p->csr_ws, p->csr_ws_bytes,
                                       rt->side[1]));
     CL3D_TRY(hip_ok(hipEventRecord(rt->ev_csr, rt->side[1]), "pwmlp_train_forward: event"));

@@ -11,7 +11,6 @@ cover (non-shipped variants such as PosPool with max reduction or a two-layer Ad
 """
 import contextlib
 import os
-import threading
 
 import torch
 from torch.autograd import Function
@@ -124,11 +123,13 @@ def _build_inverse(idx, n_support):
     return off, slots
 
 
-def inverse_index(idx, n_support, prefetch=False):
+def inverse_index(idx, n_support, prefetch=False, after=None):
     """CSR inverse of idx [B,M,K] (or [B,M]) -> (off [B,N+1], slots [B,MK]); memoised on the tensor.
 
     prefetch=True (forward pass, when a backward will follow): start the build on the index stream right
-    behind the ball query and return nothing; the later call waits for it."""
+    behind the ball query and return nothing; the later call waits for it.  `after` (an event, prefetch only): the
+    build also waits for it -- a dependency it does not need, used to ORDER the side queue of a captured step
+    (_start_inverse)."""
     cached = getattr(idx, '_cl3d_inverse', None)
     if cached is not None and cached[0] == n_support:
         if not prefetch and cached[3] is not None:
@@ -143,6 +144,8 @@ def inverse_index(idx, n_support, prefetch=False):
             side.wait_stream(main)  # an idx produced in line on the caller's stream: the build follows it
         with torch.cuda.stream(side):
             wait_ready(idx)  # the ball query ran on the index stream; this covers a cached idx too
+            if after is not None:
+                side.wait_event(after)
             if not torch.cuda.is_current_stream_capturing():
                 idx.record_stream(side)  # read here: the allocator must not recycle it before this stream is done
             off, slots = _build_inverse(idx, n_support)
@@ -172,32 +175,12 @@ def _join_inverse(idx):
         _PENDING[:] = [t for t in _PENDING if t is not idx]
 
 
-class _PerThread:
-    """A list whose contents belong to the calling thread: a stream capture is a per-thread affair (another thread may
-    capture, or run eagerly, on another device at the same time), so is the bookkeeping around one."""
-
-    def __init__(self, initial=()):
-        self._initial, self._tls = tuple(initial), threading.local()
-
-    def _l(self):
-        lst = getattr(self._tls, 'lst', None)
-        if lst is None:
-            lst = self._tls.lst = list(self._initial)
-        return lst
-
-    def __getitem__(self, k): return self._l()[k]
-    def __setitem__(self, k, v): self._l()[k] = v
-    def __delitem__(self, k): del self._l()[k]
-    def __len__(self): return len(self._l())
-    def __iter__(self): return iter(self._l())
-    def __contains__(self, x): return any(t is x for t in self._l())
-    def __eq__(self, other): return self._l() == other
-    def append(self, x): self._l().append(x)
-
-
-_WHOLE_STEP = _PerThread([False])
-_PENDING = _PerThread()  # idx tensors whose CSR build a captured forward left on the index stream for its backward to join
-_FORKS = _PerThread([None])  # None: gradient products fork in a declared whole-step capture only; else forked_gradients()
+# Bookkeeping of ONE stream capture at a time per process (the engine runs one process per GPU).  Plain module state on
+# purpose: a step's backward pass runs on the autograd engine's device thread, not on the thread that captures, and has to
+# find -- and clear -- what the forward pass left here.
+_WHOLE_STEP = [False]
+_PENDING = []  # idx tensors whose CSR build a captured forward left on the index stream for its backward to join
+_FORKS = [None]  # None: gradient products fork in a declared whole-step capture only; else forked_gradients()
 
 
 def _forks_allowed():
@@ -295,6 +278,7 @@ class _FusedReduce(Function):
         B, C, N = features.shape
         _, M, K = idx.shape
         ft = _transposed(features)
+        pre = _mark(features.device) if need_grad else None
         wait_ready(idx)  # ball query ran on the index stream
         out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)  # channel-major, written by the kernel
         slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=features.device) if need_grad else None
@@ -307,7 +291,7 @@ class _FusedReduce(Function):
                 float(radius), int(normalize), reduction, _p(p0), _p(p1), pint, float(pfloat), int(constant),
                 _p(out), 1, _p(slotrec), _p(pairs), _stream(features)))
         if need_grad:
-            _start_inverse(idx, N)
+            _start_inverse(idx, N, pre)
         ctx.save_for_backward(ft, slotrec, p0, p1, pairs)
         ctx.idx = idx
         ctx.meta = (op, B, N, M, K, C, pint, pfloat, constant)
@@ -379,13 +363,32 @@ def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, ne
     return idx, idx_mask
 
 
-def _start_inverse(idx, n_support):
+def _mark(device):
+    """An event on the caller's stream at this point of a capture (None outside one / without the index streams)."""
+    if not (device.type == 'cuda' and pt_utils.async_index()):
+        return None
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    return ev
+
+
+def _start_inverse(idx, n_support, after=None):
     """Fork the CSR build of idx onto the index stream (no-op when it exists or is under way).  Called right AFTER the
-    forward kernel that reads idx has been enqueued: in a captured step the HIP runtime keeps a node's FIRST-captured
-    dependent on the node's own queue and hands every later one to another queue (_fork_join), so the order of these two
-    launches decides whether the step's critical chain -- ball query -> gather pass -> ... -- or the CSR build, which has
-    ~100 us of slack, pays the cross-queue hand-over behind the ball query (12.7 us in profiles/r04/step_timeline.txt)."""
-    inverse_index(idx, n_support, prefetch=True)
+    forward kernel that reads idx has been enqueued, with `after` = _mark() taken right BEFORE that kernel.
+
+    Why the order matters (scripts/micro/graph_queues.hip replays graphs of the step's shape built from timed spin
+    kernels in every capture order; gpurun_out/r05b, DESIGN 3.2 "Round 5"): the HIP runtime lays a graph out on TWO
+    queues, depth-first from the roots in capture order; a node's FIRST-captured dependent stays on the node's queue,
+    the next one goes to the other queue, and so does the next root.  A queue runs its nodes in that visiting order.
+    The step has two roots -- the ball query and the feature-side preparation (weight split + per-point product, or the
+    layout change) -- and the query has two dependents: the gather pass (critical: everything follows it) and the CSR
+    build (~100 us of slack).  So: (1) the gather pass must be captured BEFORE the CSR build, or it -- and the whole
+    chain behind it -- pays a cross-queue hand-over behind the query (r4: 12.7 us, again 10 us in front of the
+    support-major pass); (2) the CSR build then shares the side queue with the feature-side preparation and is VISITED
+    FIRST: the preparation, which the gather pass needs, would sit behind a build that waits for the query
+    (measured: step 0.314 -> 0.374 ms).  Making the build wait for `after` -- the preparation, finished long before the
+    query -- forces the side queue's order: preparation, then build."""
+    inverse_index(idx, n_support, prefetch=True, after=after)
 
 
 def _deferred(out, idx, defer_join):
@@ -458,6 +461,7 @@ class _MaxPool(Function):
         B, C, N = features.shape
         _, M, K = idx.shape
         ft = _transposed(features)
+        pre = _mark(features.device) if need_grad else None
         wait_ready(idx)
         out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)
         kstar = torch.empty((B, M, C), dtype=torch.uint8, device=features.device) if need_grad else None
@@ -465,7 +469,7 @@ class _MaxPool(Function):
             _lib.check(_lib.lib().cl3d_maxpool_fwd(_p(idx), _p(ft), B, N, M, K, C, _p(out), _p(kstar),
                                                    _stream(features)))
         if need_grad:
-            _start_inverse(idx, N)
+            _start_inverse(idx, N, pre)
         ctx.save_for_backward(kstar)
         ctx.idx = idx
         ctx.meta = (B, N, M, K, C)
@@ -583,6 +587,7 @@ class _PointwiseMLP(Function):
         lib = _lib.lib()
         n = B * M * K
         nparts = lib.cl3d_pwmlp_partials(B, M, Co)
+        pre = _mark(dev) if (need_grad and training) else None
         wait_ready(idx)  # ball query ran on the index stream while the per-point GEMM ran here
         out = torch.empty((B, Co, M), dtype=torch.float32, device=dev)  # channel-major, written by the kernels
         with _lib.on_device(dev):
@@ -601,7 +606,7 @@ class _PointwiseMLP(Function):
                                                 B, N, M, K, Co, float(radius), _p(ystar), _p(kstar), _p(sy),
                                                 _p(partial), nparts, st))
                 if need_grad:
-                    _start_inverse(idx, N)
+                    _start_inverse(idx, N, pre)
                 # batch statistics, scale/shift and the running-statistics update in one small launch
                 _lib.check(lib.cl3d_pwmlp_finalize_stats(_p(partial), nparts, Co, float(n), float(eps), float(momentum),
                                                          _p(gamma), _p(beta), _p(running_mean), _p(running_var),
