@@ -159,7 +159,7 @@ ENTRY_KERNELS = {
     "cl3d_pwmlp_point_gemm_fwd": ["pwmlp_weights_kernel", "pwmlp_rows_nolds_kernel"],
     "cl3d_pwmlp_point_gemm_bwd_data": ["mfma_gemm_kernel"],
     "cl3d_pwmlp_point_gemm_bwd_weight": ["mfma_gemm_kernel", "gemm_reduce_kernel"],
-    "cl3d_pwmlp_point_gemm_bwd": ["pwmlp_point_grads_kernel", "gemm_reduce_kernel"],
+    "cl3d_pwmlp_point_gemm_bwd": ["pwmlp_point_grads_kernel", "pwmlp_dw_reduce_kernel"],
     "cl3d_pwmlp_stats": ["pwmlp_query_kernel<0"],
     "cl3d_pwmlp_finalize_stats": ["pwmlp_finalize_kernel<0"],
     "cl3d_pwmlp_apply": ["pwmlp_rows_kernel<0"],

@@ -1215,6 +1215,54 @@ size_t gemm_family_workspace(int nb, int n, int rows_out, int rows_in, bool merg
   return w;
 }
 
+// the workgroups' partial d wcat tiles [nparts][2Co][C] -> d W [Co, 3+2C] (d W_c = bot, d W_d = top - bot, d W_r copied).
+// A workgroup owns four 16-byte pieces of the top half and the same four of the bottom half; its 64 thread groups take
+// the partials g, g+64, g+128, ... -- for the 256 partials of the metric shape that is 8 independent 16-byte loads per
+// thread, all in flight at once (gemm_reduce_kernel<1> walks its slices 16 apart in a loop of dependent round trips:
+// 8.6-12 us for these 8 MB) -- and the 64 sub-sums are added in group order through LDS: the order depends on nparts only.
+__global__ __launch_bounds__(256) void pwmlp_dw_reduce_kernel(const float *__restrict__ part, int nparts, int Co, int C,
+                                                              const float *__restrict__ dwr, float *__restrict__ dW) {
+  __shared__ float4 s_sum[2][64][4];
+  const int q = threadIdx.x & 3, g = threadIdx.x >> 2;
+  const long long half = (long long)Co * C, IJ = 2 * half;
+  const long long e = ((long long)blockIdx.x * 4 + q) * 4;  // first of this thread's four elements (o, c .. c+3)
+  float4 top = make_float4(0.f, 0.f, 0.f, 0.f), bot = top;
+  if (e < half) {
+#pragma unroll 4
+    for (int p = g; p < nparts; p += 64) {
+      const float4 t = *reinterpret_cast<const float4 *>(part + (size_t)p * IJ + e);
+      const float4 u = *reinterpret_cast<const float4 *>(part + (size_t)p * IJ + half + e);
+      top.x += t.x; top.y += t.y; top.z += t.z; top.w += t.w;
+      bot.x += u.x; bot.y += u.y; bot.z += u.z; bot.w += u.w;
+    }
+  }
+  s_sum[0][g][q] = top;
+  s_sum[1][g][q] = bot;
+  __syncthreads();
+  if (threadIdx.x < 32) {  // 2 halves x 4 pieces x 4 components: one lane per float, 64 adds in group order
+    const int h = threadIdx.x >> 4, qq = (threadIdx.x >> 2) & 3, comp = threadIdx.x & 3;
+    const float *src = reinterpret_cast<const float *>(&s_sum[h][0][qq]) + comp;
+    float acc = src[0];
+#pragma unroll 8
+    for (int k = 1; k < 64; ++k) acc += src[k * 16];
+    reinterpret_cast<float *>(&s_sum[h][0][qq])[comp] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int qq = threadIdx.x >> 2, comp = threadIdx.x & 3;
+    const long long ev = ((long long)blockIdx.x * 4 + qq) * 4 + comp;
+    if (ev < half) {
+      const float t = reinterpret_cast<const float *>(&s_sum[0][0][qq])[comp];
+      const float bt = reinterpret_cast<const float *>(&s_sum[1][0][qq])[comp];
+      const int oo = (int)(ev / C), c = (int)(ev - (long long)oo * C);
+      const int ld = 3 + 2 * C;
+      dW[(size_t)oo * ld + 3 + c] = bt;          // d W_c
+      dW[(size_t)oo * ld + 3 + C + c] = t - bt;  // d W_d
+      if (c < 3) dW[(size_t)oo * ld + c] = dwr ? dwr[oo * 3 + c] : 0.f;
+    }
+  }
+}
+
 // ---- host side of pwmlp_point_grads_kernel
 static bool point_grads_covers(int B, int C, int N, int Co, int precision) {
   return precision == PREC_F32 && B >= 1 && C >= 4 && C <= 64 && C % 4 == 0 && Co >= 2 && 2 * Co <= 128 && Co % 2 == 0 &&
@@ -1230,7 +1278,7 @@ static int launch_point_grads(const float *features, const float *pro_scale, con
   const size_t need = dW != nullptr ? (size_t)grid * J * C * sizeof(float) : 0;
   if (dW != nullptr && (ws == nullptr || ws_bytes < need))
     return fail(CL3D_E_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, need);
-  if (!aligned16(dght) || !aligned16(features) || (pro_scale != nullptr && !aligned16(pro_scale)))
+  if (!aligned16(dght) || !aligned16(features) || !aligned16(ws) || (pro_scale != nullptr && !aligned16(pro_scale)))
     return fail(CL3D_E_INVALID, "%s: operands must be 16-byte aligned", who);
   const size_t lds = (size_t)2 * kPgBufFloats * sizeof(float);
   PointGradArgs a{};
@@ -1253,11 +1301,8 @@ static int launch_point_grads(const float *features, const float *pro_scale, con
   if (rc != CL3D_OK) return rc;
   rc = check_launch(who);
   if (rc != CL3D_OK || dW == nullptr) return rc;
-  OutMap o{};
-  o.D = dW;
-  long long rgrid = ((long long)Co * C + 63) / 64;
-  if (rgrid > 16384) rgrid = 16384;
-  hipLaunchKernelGGL((gemm_reduce_kernel<1, 4>), dim3((unsigned)rgrid), dim3(256), 0, st, a.partial, grid, J, C, o, dwr, Co, C);
+  const int rgrid = ceil_div(Co * C, 16);  // (C % 4 == 0: a 16-byte piece never straddles a row of d wcat)
+  hipLaunchKernelGGL(pwmlp_dw_reduce_kernel, dim3(rgrid), dim3(256), 0, st, a.partial, grid, Co, C, dwr, dW);
   return check_launch(who);
 }
 

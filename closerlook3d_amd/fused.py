@@ -351,6 +351,7 @@ def _wants_grad(*tensors):
 
 
 _CSR_FIRST = os.environ.get('CL3D_CSR_FIRST') == '1'  # (round-5 A/B only: the round-4 order, CSR build captured behind the query)
+_CSR_AFTER = os.environ.get('CL3D_CSR_AFTER', 'product')  # (round-5 A/B only) what the PointWiseMLP's CSR build waits for
 
 
 def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad=False):
@@ -606,7 +607,10 @@ class _PointwiseMLP(Function):
                                                 B, N, M, K, Co, float(radius), _p(ystar), _p(kstar), _p(sy),
                                                 _p(partial), nparts, st))
                 if need_grad:
-                    _start_inverse(idx, N, pre)
+                    if _CSR_AFTER == 'stats':   # (round-5 A/B: the build starts when the statistics pass has ENDED)
+                        pre = _mark(dev)
+                    if _CSR_AFTER != 'apply':
+                        _start_inverse(idx, N, pre)
                 # batch statistics, scale/shift and the running-statistics update in one small launch
                 _lib.check(lib.cl3d_pwmlp_finalize_stats(_p(partial), nparts, Co, float(n), float(eps), float(momentum),
                                                          _p(gamma), _p(beta), _p(running_mean), _p(running_var),
@@ -614,6 +618,8 @@ class _PointwiseMLP(Function):
                                                          _p(invstd), _p(sums), st))
                 if not rows_out:
                     _lib.check(lib.cl3d_pwmlp_apply(_p(ystar), _p(scale), _p(shift), B, M, Co, _p(out), st))
+                if need_grad and _CSR_AFTER == 'apply':
+                    _start_inverse(idx, N, _mark(dev))
                 if need_grad:
                     ctx.save_for_backward(ght, wr, gamma, vec, ystar, sy, kstar, sums, query_xyz, support_xyz)
                     ctx.radius = float(radius)
