@@ -33,6 +33,10 @@ import os
 import sys
 import time
 
+# before the HIP runtime starts, whoever launched this rank (the driver's own `torch.distributed.run ... bench.py --gpus N`
+# included): dmabuf IPC, which RCCL needs on this driver (closerlook3d_amd/dp.py prepare_environment does the same)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -449,6 +453,115 @@ def cpu_baseline_voting(batches, num_classes, cloud_sizes):
     return (time.perf_counter() - t0) / len(batches)
 
 
+BACKBONE_OF = {"pointwisemlp": ("modelnet_pointwisemlp", "bf16"), "pseudo_grid": ("s3dis_pseudogrid", "f32"),
+               "adaptive_weight": ("partnet_adaptive", "f32"), "pospool": ("s3dis_pospool_deep", "f32")}
+
+
+def backbone_step(kind, world, rank, dev, steps=10, warmup=3):
+    """SURVEY 8(e)'s second figure, beside the operator-only headline: one training step of the BASELINE.json BACKBONE
+    this operator belongs to (pointwisemlp -> config 2: 16 x 4096 points, width 144, bf16 contractions) -- forward,
+    backward, the gradient mean of EVERY parameter over all ranks (one flat RCCL all-reduce of 74-106 MB, the exchange
+    the reference's DistributedDataParallel makes, function/train_modelnet_dist.py:206,280), SGD update.  The compute is
+    one HIP graph, the all-reduce sits between it and the update graph.  Measured after the headline's timed region;
+    weak scaling (every rank its own clouds).  Returns the dict that goes into the JSON line."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from bench_backbone import CONFIGS
+    import closerlook3d_amd
+    from closerlook3d_amd.backbones import ResNet
+    from closerlook3d_amd.dp import FlatGradients
+    from closerlook3d_amd.pt_utils import ball_query_cache
+    name, precision = BACKBONE_OF[kind]
+    bkind, B, N, radius, dl, nsamples, npoints, width = CONFIGS[name]
+    torch.manual_seed(0)
+    cfg = make_config(bkind, "auto")
+    cfg["cl3d_precision"] = precision
+    if bkind == "pospool" and "deep" in name:
+        cfg.pospool.position_embedding = "sin_cos"
+    net = ResNet(cfg, 3, radius, dl, nsamples, npoints, width=width, depth=2, bottleneck_ratio=2).to(dev).train(True)
+    params = [p for p in net.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-3)
+    xyz, mask, _ = synth_batch(B, N, 3, 7 + rank)
+    scale = 1.0 if N <= 16384 else 4.0
+    x = torch.from_numpy((xyz * scale).astype(np.float32)).to(dev)
+    m = torch.from_numpy(mask).to(dev)
+    feats = x.transpose(1, 2).contiguous()
+    flat = FlatGradients(params) if world > 1 else None
+
+    def compute():
+        if flat is not None:
+            flat.zero_()
+        else:
+            opt.zero_grad(set_to_none=True)
+        with ball_query_cache():
+            out = net(x, m, feats)["res5_features"]
+        out.square().mean().backward()
+        if world == 1:
+            opt.step()
+
+    def capture(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with closerlook3d_amd.whole_step_capture(), \
+                torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
+            fn()
+        return g
+
+    graph = update_graph = None
+    try:
+        graph = capture(compute)
+        if world > 1:
+            update_graph = capture(opt.step)
+    except Exception as e:
+        print(f"bench: backbone step: HIP graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+        graph = update_graph = None
+        torch.cuda.synchronize()
+    ar = []
+
+    def step():
+        graph.replay() if graph is not None else compute()
+        if world > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            flat.allreduce_mean(world)
+            e1.record()
+            ar.append((e0, e1))
+            update_graph.replay() if update_graph is not None else opt.step()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    del ar[:]
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = (time.perf_counter() - t0) / steps
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    out = {"config": name, "what": "5-stage residual backbone step: forward + backward + gradient mean over all ranks + SGD",
+           "precision": precision, "clouds_per_gpu": B, "points": N, "width": width, "steps": steps,
+           "launch": "hip_graph" if graph is not None else "eager", "ms_per_step": round(dt * 1e3, 3),
+           "input_points_per_s": round(world * B * N / dt, 1), "scaling": "weak",
+           "params_M": round(sum(p.numel() for p in params) / 1e6, 2)}
+    if world > 1:
+        out["allreduce_bytes"] = int(flat.buffer.numel() * 4)
+        out["allreduce_ms"] = round(float(np.mean([a.elapsed_time(b) for a, b in ar])), 3)
+        out["exchange"] = "one flat all-reduce (mean) of every parameter gradient between the step graph and the update graph"
+    return out
+
+
 def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--cpu-baseline-child":
         return cpu_baseline_child(*json.loads(sys.argv[2]))
@@ -471,6 +584,10 @@ def main():
                     help="untimed steps before the warm-up (clock ramp of an idle device; not part of --warmup / --steps)")
     ap.add_argument("--bursts", type=int, default=12, help="bursts of 8 launches per boundary kernel (median / min / max reported)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
+    ap.add_argument("--backbone", default="auto", choices=["auto", "on", "off"],
+                    help="also time the BASELINE backbone step incl. the gradient all-reduce (SURVEY 8(e)): 'backbone_step' in "
+                         "the JSON line; auto = on unless --no-kernel-roofline asks for a bare run")
+    ap.add_argument("--backbone-steps", type=int, default=10)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -498,8 +615,11 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     import closerlook3d_amd
-    from closerlook3d_amd.dp import FlatGradients
+    from closerlook3d_amd.dp import FlatGradients, device_identity, rank_census
     from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+
+    # who sits where: raises under RCCL when two ranks share a device (that is not a scaling run)
+    census = rank_census(device_identity(dev)) if world > 1 else [{"rank": 0, "device": device_identity(dev)}]
 
     kind = args.operator
     B, N, K = args.batch, args.points, args.nsample
@@ -600,6 +720,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    want_backbone = args.backbone == "on" or (args.backbone == "auto" and not args.no_kernel_roofline)
+    bb = None
+    if want_backbone:  # (a collective when N > 1: every rank runs it, after the headline's timed region)
+        try:
+            bb = backbone_step(kind, world, rank, dev, steps=args.backbone_steps)
+        except Exception as e:  # the headline stands on its own; say what happened
+            if world > 1:
+                raise
+            bb = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * N / (elapsed / args.steps)
@@ -616,10 +745,13 @@ def main():
                        "parallelism": f"dp{world} (clouds sharded, RCCL grad all-reduce)",
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": dist.get_backend() if world > 1 else None,
-                       "device": f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"},
+                       "device": f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}",
+                       "ranks": census, "distinct_devices": len({r["device"] for r in census})},
         }
         if one_dev and world > 1:  # every rank shared device 0 over gloo: the N > 1 code path, not a scaling number
             line["config"]["one_device_standin"] = True
+        if bb is not None:
+            line["backbone_step"] = bb
         if not args.no_kernel_roofline:
             # top level: the TIMED STEP's dominant kernel (longest C-ABI entry point of the step table): algorithmic
             # HBM bytes per launch / median launch duration, HIP events on the launch stream; `traffic` = its PMC HBM

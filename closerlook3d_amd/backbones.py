@@ -21,17 +21,12 @@ def _conv_bn(cin, cout, momentum, relu):
     return nn.Sequential(*layers)
 
 
-import os
-
-_BLOCK_ENGINE = 'engine'  # 'modules' (set by scripts/bench_backbone.py --block modules): nn.Conv1d / BatchNorm1d as in round 1
-_DECODE = 'split'  # 'cat' (scripts/bench_backbone.py --decode cat): the decoders concatenate as the reference does
-# False (scripts/bench_backbone.py --layerwise): a PointWiseMLP bottleneck layer by layer, with the activated tensors
-# between its layers materialised as in round 2; default: fused.pointwise_bottleneck
-_FUSE_BOTTLENECK = True
-# ... for layers with at least this many values per channel (B * N): below it the BatchNorm tails are single-launch
-# kernels that keep a channel in L2 (csrc/bn_relu.hip, bn2_*_small), and there is no round trip to HBM to save
+# A PointWiseMLP bottleneck runs without the [B,C,N] tensors between its layers (fused.pointwise_bottleneck) for layers
+# with at least this many values per channel (B * N): below it the BatchNorm tails are single-launch kernels that keep a
+# channel in L2 (csrc/bn_relu.hip, bn2_*_small), and there is no round trip to HBM to save.  (The A/B arms of earlier
+# rounds -- nn.Conv1d / BatchNorm1d blocks, the concatenating decoder, the layer-by-layer bottleneck -- are installed
+# from OUTSIDE the package by scripts/ab/library_arms.py.)
 _FUSE_MIN_VALUES = 16384
-
 
 
 def run_conv_bn(seq, x, impl='auto', precision='f32', residual=None, shortcut=None):
@@ -40,7 +35,7 @@ def run_conv_bn(seq, x, impl='auto', precision='f32', residual=None, shortcut=No
     BatchNorm / add / ReLU passes, BatchNorm folded into the convolution in inference), or module by module as the
     reference runs it when impl == 'grouped' or the configuration is outside what the kernels cover."""
     relu = len(seq) == 3 or residual is not None
-    if impl != 'grouped' and x.is_cuda and _BLOCK_ENGINE != 'modules':
+    if impl != 'grouped' and x.is_cuda:
         from . import fused
         y = fused.conv_bn_act(x, seq[0], seq[1], relu=relu, residual=residual,
                               res_conv=shortcut[0] if shortcut is not None else None,
@@ -86,7 +81,7 @@ class Bottleneck(nn.Module):
         # shortcut (+ its conv and BN) + add + ReLU as MFMA convolutions and fused BatchNorm passes
         shortcut = self.shortcut if self.in_channels != self.out_channels else None
         la = getattr(self.local_aggregation, 'local_aggregation_operator', None)
-        if (_FUSE_BOTTLENECK and self.impl != 'grouped' and _BLOCK_ENGINE != 'modules' and features.is_cuda and self.training
+        if (self.impl != 'grouped' and features.is_cuda and self.training
                 and type(la).__name__ == 'PointWiseMLP' and la.impl != 'grouped'
                 and features.shape[0] * features.shape[2] >= _FUSE_MIN_VALUES):
             # ... and, for a PointWiseMLP bottleneck in training, without the [B,C,N] tensors between its layers:
@@ -174,7 +169,7 @@ class _UpsampleDecoder(nn.Module):
                     end_points[f'res{fine}_mask'], end_points[f'res{coarse}_mask'])
             skip = end_points[f'res{fine}_features']
             out = None
-            if feats.is_cuda and _BLOCK_ENGINE != 'modules' and _DECODE != 'cat' and self.impl != 'grouped':
+            if feats.is_cuda and self.impl != 'grouped':
                 from . import fused  # the level without the concatenated tensor, see fused.decode_level
                 out = fused.decode_level(up, *geom, feats, skip, seq[0], seq[1], self.precision)
             if out is None:

@@ -55,6 +55,46 @@ def self_launch(script, argv, nproc, visible_devices=None):
     os.execvpe(cmd[0], cmd, env)
 
 
+def prepare_environment(environ=None):
+    """What every rank's environment needs BEFORE the HIP runtime starts (before the first torch.cuda call), whoever
+    launched it: HSA_ENABLE_IPC_MODE_LEGACY=0 -- this driver only supports dmabuf IPC, and without it RCCL's
+    cross-process buffer registration fails with `hipIpcGetMemHandle: invalid argument`.  self_launch() sets it for the
+    ranks it starts; a `torchrun ... bench.py --gpus 8` typed by someone else reaches the benches through this call.
+    An explicit setting in the environment is left alone."""
+    env = os.environ if environ is None else environ
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def device_identity(device):
+    """A string that two ranks share exactly when they sit on the SAME physical GPU: the device's UUID where the
+    runtime reports one, else its PCI bus id, else (nothing better) its ordinal and name."""
+    props = torch.cuda.get_device_properties(device)
+    uuid = getattr(props, "uuid", None)
+    if uuid is not None and str(uuid).strip("0-") != "":
+        return f"uuid:{uuid}"
+    bus = [getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    if all(b is not None for b in bus):
+        return "pci:%04x:%02x:%02x" % tuple(int(b) for b in bus)
+    return f"ordinal:{torch.cuda.current_device() if device is None else torch.device(device).index}:{props.name}"
+
+
+def rank_census(identity, group=None):
+    """[{rank, device}] of every rank of the job (all_gather_object), and the proof the JSON line carries that N ranks
+    sat on N DISTINCT devices: under the RCCL backend two ranks on one device raise here -- such a run is not a
+    scaling measurement and RCCL may deadlock on it; under gloo (the one-device stand-in) the list says so."""
+    world = dist.get_world_size(group)
+    got = [None] * world
+    dist.all_gather_object(got, {"rank": dist.get_rank(group), "device": identity}, group=group)
+    got.sort(key=lambda r: r["rank"])
+    devices = [r["device"] for r in got]
+    if dist.get_backend(group) == "nccl" and len(set(devices)) != world:
+        shared = sorted({d for d in devices if devices.count(d) > 1})
+        raise RuntimeError(f"data-parallel run over RCCL with ranks sharing a device: {shared} -- one process per GPU "
+                           f"(LOCAL_RANK must select distinct devices); census: {got}")
+    return got
+
+
 def shard_range(n, rank, world):
     """[lo, hi) of rank's contiguous shard of n items; sizes differ by at most one."""
     base, rem = divmod(n, world)

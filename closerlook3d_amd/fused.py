@@ -692,9 +692,7 @@ class _PointwiseMLP(Function):
 
 import os
 
-CONV_ENGINE = 'mfma'  # 'mfma': csrc/mfma_gemm.hip; 'library' (scripts' A/B): torch's Conv1d
 PRECISIONS = {'f32': 0, 'bf16': 1}  # CL3D_PRECISION_*: arithmetic of the dense contraction only
-POINT_GEMM = 'mfma'  # 'mfma': csrc/mfma_gemm.hip; 'bmm': the library GEMM (kept for scripts/bench_point_gemm.py's A/B)
 
 
 class _PointRows(Function):
@@ -766,41 +764,6 @@ class _PointRows(Function):
             else:
                 _fork_join(dev, weight_grad, data_grad)
         return dfeat, dW, None
-
-
-class _PointRowsLibrary(Function):
-    """The same contraction through the vendor library (torch.bmm -> rocBLAS / hipBLASLt) with the engine's two
-    weight-plumbing kernels around it: the baseline of scripts/bench_point_gemm.py, not used by the operators."""
-
-    @staticmethod
-    def forward(ctx, features, W):
-        B, C, N = features.shape
-        Co = W.shape[0]
-        W = W.contiguous()
-        wr = torch.empty((Co, 3), dtype=torch.float32, device=W.device)
-        wcat = torch.empty((2 * Co, C), dtype=torch.float32, device=W.device)
-        with _lib.on_device(W.device):
-            _lib.check(_lib.lib().cl3d_pwmlp_split_weight(_p(W), Co, C, _p(wr), _p(wcat), _stream(W)))
-        ctx.save_for_backward(features, wcat)
-        ght = torch.bmm(features.transpose(1, 2), wcat.t().unsqueeze(0).expand(B, -1, -1))
-        return ght, wr
-
-    @staticmethod
-    def backward(ctx, dght, dwr):
-        features, wcat = ctx.saved_tensors
-        B, C, N = features.shape
-        Co = wcat.shape[0] // 2
-        dfeat = dW = None
-        if dght is not None and ctx.needs_input_grad[0]:
-            dfeat = torch.bmm(wcat.t().unsqueeze(0).expand(B, -1, -1), dght.transpose(1, 2))  # [B,C,N]
-        if ctx.needs_input_grad[1]:
-            dwb = (torch.bmm(features, dght) if dght is not None
-                   else torch.zeros((B, C, 2 * Co), dtype=torch.float32, device=features.device))
-            dW = torch.empty((Co, 3 + 2 * C), dtype=torch.float32, device=features.device)
-            dwr = dwr.contiguous() if dwr is not None else None
-            with _lib.on_device(features.device):
-                _lib.check(_lib.lib().cl3d_pwmlp_merge_weight_grad(_p(dwr), _p(dwb), B, Co, C, _p(dW), _stream(dwb)))
-        return dfeat, dW
 
 
 class _BnReluPointRows(Function):
@@ -941,7 +904,7 @@ def pointwise_bottleneck(conv1, la, conv2, shortcut, query_xyz, support_xyz, que
     c1, bn1 = conv1[0], conv1[1]
     c2, bn2 = conv2[0], conv2[1]
     mconv, mbn = la.mlps.conv0[0], la.mlps.conv0[1]
-    if (CONV_ENGINE != 'mfma' or POINT_GEMM != 'mfma' or la.reduction != 'max' or la.num_mlps != 1
+    if (la.reduction != 'max' or la.num_mlps != 1
             or la.feature_type != 'dp_fi_df' or not (bn1.training and bn2.training and mbn.training)):
         return None
     if c1.bias is not None or c1.kernel_size != (1,) or c2.bias is not None or c2.kernel_size != (1,):
@@ -982,8 +945,6 @@ def pointwise_bottleneck(conv1, la, conv2, shortcut, query_xyz, support_xyz, que
 def point_rows(features, W, precision='f32'):
     """[G | H] rows and W_r of the factored PointWiseMLP contraction; precision 'f32' or 'bf16' (inputs of the
     contraction rounded to bf16, f32 accumulation; coordinates, indices and BatchNorm statistics stay f32)."""
-    if POINT_GEMM == 'bmm':
-        return _PointRowsLibrary.apply(features, W)
     return _PointRows.apply(features, W, PRECISIONS[precision])
 
 
@@ -994,8 +955,7 @@ PASS_CALLS = True
 
 def _use_pass_calls(training, need_grad, bn):
     return (PASS_CALLS and training and need_grad and pt_utils._BQ_CACHE is None and pt_utils.ASYNC_INDEX == 'auto'
-            and not torch.cuda.is_current_stream_capturing() and bn.running_mean is not None and bn.track_running_stats
-            and POINT_GEMM == 'mfma')
+            and not torch.cuda.is_current_stream_capturing() and bn.running_mean is not None and bn.track_running_stats)
 
 
 def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps, reduction,
@@ -1238,9 +1198,6 @@ def conv_bn_act(x, conv, bn, relu=True, residual=None, res_conv=None, res_bn=Non
         x2 = residual
         if res_conv is not None:
             x2 = _Conv1x1.apply(residual, res_conv.weight.view(Co, res_conv.weight.shape[1]), prec)
-    elif CONV_ENGINE == 'library':
-        y1 = torch.nn.functional.conv1d(x, conv.weight)
-        x2 = torch.nn.functional.conv1d(residual, res_conv.weight) if res_conv is not None else residual
     else:
         y1 = _Conv1x1.apply(x, W, prec)
         x2 = residual

@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--overlap-forks", default="", choices=["", "a", "b", "both", "none"],
                     help="--overlap: which of the two graphs keeps the side-stream forks (default a; b / both = the "
                          "configuration that gives wrong early-stage gradients, kept to reproduce it)")
+    ap.add_argument("--unsafe", action="store_true",
+                    help="required by --overlap-forks b|both: forked gradient products inside the graph that holds the early "
+                         "stages' backward ALONE give wrong, replay-varying gradients (DESIGN 6; kept to reproduce it)")
     ap.add_argument("--debug-two-graphs", default="", help="two-graph reproducer, comma list of: sync_between (device sync between the replays "
                     "of graph A and graph B), own_pool (graph B in a memory pool of its own), fresh_streams (graph B forks "
                     "onto streams graph A never saw)")
@@ -85,6 +88,12 @@ def main():
     ap.add_argument("--layerwise", action="store_true",
                     help="A/B: PointWiseMLP bottlenecks layer by layer (the activated tensors between their layers materialised)")
     args = ap.parse_args()
+    if args.overlap_forks in ("b", "both") and not args.unsafe:
+        raise SystemExit("--overlap-forks %s is the KNOWN-BAD configuration: a forked pair of gradient products inside graph B "
+                         "(the early stages' backward alone, reading tensors graph A's capture allocated) gives wrong, "
+                         "replay-varying early-stage gradients -- 43 + singletons of 200 replays in profiles/r04/"
+                         "two_graph_repeat_check.txt; mechanism not root-caused (DESIGN 6).  Add --unsafe to run it anyway, "
+                         "e.g. with --repeat-check 200." % args.overlap_forks)
     kind, B, N, radius, dl, nsamples, npoints, width = CONFIGS[args.config]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -98,14 +107,20 @@ def main():
     one_dev = os.environ.get("CL3D_BENCH_ONE_DEVICE") == "1"
     if one_dev:
         local_rank = 0
+    from closerlook3d_amd.dp import prepare_environment
+    prepare_environment()  # (before the first torch.cuda call: what RCCL needs from the HIP runtime on this driver)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if one_dev else "nccl", **({} if one_dev else {"device_id": dev}))
+        from closerlook3d_amd.dp import device_identity, rank_census
+        rank_census(device_identity(dev))  # raises under RCCL when two ranks share a device
     import closerlook3d_amd
-    from closerlook3d_amd import backbones as _bb
-    _bb._BLOCK_ENGINE, _bb._DECODE, _bb._FUSE_BOTTLENECK = args.block, args.decode, not args.layerwise
+    if args.block != "engine" or args.decode != "split" or args.layerwise:  # A/B arms, installed from outside the package
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from ab import library_arms
+        library_arms.install(block=args.block, decode=args.decode, layerwise=args.layerwise)
     from closerlook3d_amd import fused as _fu
     from closerlook3d_amd import pt_utils as _put
     _fork_shipped, _fork_count = _fu._fork_join, [0]
@@ -113,7 +128,7 @@ def main():
     def _fork_debug(device, side_fn, main_fn):
         """The engine's fork / join of two gradient products with the reproducer's switches: only some
         episodes of a capture fork; the two pieces one behind the other on the same two streams instead of side by side."""
-        if not (_fu.FORK_GRADS and device.type == 'cuda' and _put.async_index()):
+        if not (device.type == 'cuda' and _put.async_index() and _fu._forks_allowed()):
             return _fork_shipped(device, side_fn, main_fn)
         _fork_count[0] += 1
         if fork_only is not None and _fork_count[0] not in fork_only:
@@ -263,7 +278,11 @@ def main():
         if forks is not None:
             from closerlook3d_amd import pt_utils as _pu2
             _pu2.ASYNC_INDEX = 'auto' if forks else False
+        # one graph for the whole step: declared, the engine forks what it likes.  Two graphs (--overlap): not a whole step;
+        # the gradient-product forks are then an explicit choice per graph (fused.forked_gradients): on in graph A (forward +
+        # late-stage backward: exact), off in graph B unless --overlap-forks b|both --unsafe asks for the known-bad layout
         with closerlook3d_amd.whole_step_capture(not args.overlap), \
+                _fu.forked_gradients(bool(forks) if (args.overlap and forks is not None) else None), \
                 torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local" if world > 1 else "global"):
             fn()
         return g

@@ -161,8 +161,7 @@ def test_pointwisemlp_bottleneck_without_the_tensors_between_its_layers(strided,
     f_np = rng.standard_normal((B, cin, N)).astype(np.float32)
     res = {}
     for fuse in (True, False):
-        monkeypatch.setattr(backbones, "_FUSE_BOTTLENECK", fuse)
-        monkeypatch.setattr(backbones, "_FUSE_MIN_VALUES", 0)
+        monkeypatch.setattr(backbones, "_FUSE_MIN_VALUES", 0 if fuse else 1 << 62)  # fused / layer by layer
         torch.manual_seed(3)
         cfg = default_config("pointwisemlp", {"pointwisemlp__feature_type": "dp_fi_df"}, cl3d_precision=precision)
         btn = Bottleneck(cin, cout, 2, 0.12, K, cfg, downsample=strided, sampleDl=0.08, npoint=256).cuda().train(True)

@@ -146,11 +146,16 @@ def test_bench_py_runs_data_parallel_on_one_device():
     env = dict(os.environ, CL3D_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
-           "--batch", "4", "--no-cpu-baseline", "--no-kernel-roofline"]
+           "--batch", "4", "--no-cpu-baseline", "--no-kernel-roofline", "--backbone", "on", "--backbone-steps", "2"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    # who sat where, and the BASELINE backbone step incl. the flat gradient all-reduce beside the headline
+    assert [r_["rank"] for r_ in line["config"]["ranks"]] == [0, 1] and line["config"]["distinct_devices"] == 1  # (stand-in)
+    bb = line["backbone_step"]
+    assert bb["config"] == "modelnet_pointwisemlp" and bb["ms_per_step"] > 0 and bb["allreduce_bytes"] > 70e6, bb
+    assert bb["launch"] == "hip_graph", bb
 
 
 def test_overlapped_step_with_its_forks_equals_the_single_stream_two_graph_step(tmp_path):

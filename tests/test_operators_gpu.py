@@ -2,9 +2,14 @@
 loaded with the fixture's state dict (same parameter names as the reference) against the golden
 vectors produced by the reference's own Python modules.  Tolerance: 1e-5 (north_star) on outputs,
 slightly looser on gradients that accumulate over B*M*K terms."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from tests.helpers import assert_close, default_config, load_fixture, operator_fixtures, state_of
 
@@ -297,7 +302,9 @@ def test_point_rows_weight_plumbing_matches_autograd(B, C, N, Co, engine):
     and the vendor-library variant kept for the A/B script with its split / merge kernels (both the element-per-thread
     merge and the tiled one used once the per-cloud products outgrow the L2s) -- against the same algebra in plain
     autograd."""
-    from closerlook3d_amd.fused import _PointRows, _PointRowsLibrary
+    from closerlook3d_amd.fused import _PointRows
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from ab.library_arms import PointRowsLibrary as _PointRowsLibrary  # (the library arm lives outside the package)
     torch.manual_seed(C + Co)
     f = torch.randn(B, C, N, device="cuda")
     W = torch.randn(Co, 3 + 2 * C, device="cuda") / np.sqrt(C)
