@@ -40,6 +40,10 @@ SIGNATURES = {
     "cl3d_sphere_crop_query": [_P, _I, _P, ctypes.c_double, _I, _P, _P, _P, _Z, _P],
     "cl3d_sphere_crop_assemble": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P],
     "cl3d_transpose": [_P, _I, _I, _I, _P, _P],
+    "cl3d_transpose_bn_relu": [_P, _P, _P, _I, _I, _I, _P, _P],
+    "cl3d_bn_rows_partials": [ctypes.c_longlong, _I],
+    "cl3d_bn_rows_stats": [_P, ctypes.c_longlong, _I, _P, _I, ctypes.c_double, _F, _F] + [_P] * 10,
+    "cl3d_bn_rows_bwd": [_P] * 7 + [ctypes.c_longlong, _I, ctypes.c_double, _P, _I, _P, _P, _P],
     "cl3d_bn_partials": [_I, _I, _I],
     "cl3d_bn_relu_stats": [_P, _I, _I, _I, _P, _I, ctypes.c_double, _F, _F] + [_P] * 10,
     "cl3d_bn_relu_apply": [_P, _P, _P, _I, _I, _I, _P, _P],

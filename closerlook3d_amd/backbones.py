@@ -81,14 +81,15 @@ class Bottleneck(nn.Module):
         # shortcut (+ its conv and BN) + add + ReLU as MFMA convolutions and fused BatchNorm passes
         shortcut = self.shortcut if self.in_channels != self.out_channels else None
         la = getattr(self.local_aggregation, 'local_aggregation_operator', None)
-        if (self.impl != 'grouped' and features.is_cuda and self.training
-                and type(la).__name__ == 'PointWiseMLP' and la.impl != 'grouped'
+        if (self.impl != 'grouped' and features.is_cuda and self.training and getattr(la, 'impl', 'auto') != 'grouped'
                 and features.shape[0] * features.shape[2] >= _FUSE_MIN_VALUES):
-            # ... and, for a PointWiseMLP bottleneck in training, without the [B,C,N] tensors between its layers:
-            # conv1's BatchNorm + ReLU ride in the operator's contraction, the operator's in conv2's (fused.pointwise_bottleneck)
+            # ... and, in training, without the [B,C,N] tensors between the bottleneck's layers: conv1's BatchNorm + ReLU
+            # ride in the operator's input staging, the operator's own in conv2's (fused.pointwise_bottleneck for the
+            # PointWiseMLP, fused.reduce_bottleneck for PosPool / AdaptiveWeight / PseudoGrid)
             from . import fused
-            out = fused.pointwise_bottleneck(self.conv1, la, self.conv2, shortcut, query_xyz, xyz, query_mask, mask,
-                                             features, identity, self.precision)
+            whole = fused.pointwise_bottleneck if type(la).__name__ == 'PointWiseMLP' else fused.reduce_bottleneck
+            out = whole(self.conv1, la, self.conv2, shortcut, query_xyz, xyz, query_mask, mask, features, identity,
+                        self.precision)
             if out is not None:
                 return query_xyz, query_mask, out
         out = run_conv_bn(self.conv1, features, self.impl, self.precision)

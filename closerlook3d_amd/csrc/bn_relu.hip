@@ -522,6 +522,131 @@ __global__ __launch_bounds__(256) void bn2_bwd_small_kernel(BnSmallArgs a) {
   });
 }
 
+// ---- BatchNorm + ReLU on POINT-MAJOR rows [P, C] (round 5: the PosPool / AdaptiveWeight / PseudoGrid bottlenecks) -------
+// The fused reduction operators write their result as point-major rows, conv2 of the bottleneck reads rows and applies
+// max(scale x + shift, 0) while it stages them (cl3d_conv1x1_rows_*): the operator's BatchNorm then needs only its
+// STATISTICS forward (this kernel: column sums of a row-major matrix) and, backward, dx = A dz + Bc + D x on rows.  The
+// channel-major pair above would need the rows transposed first -- the [B,C,N] round trip f1 removes.
+// A workgroup owns `rows_per_block` consecutive rows: thread t -> 16-byte channel group t % CG of row offset t / CG
+// (a wave covers whole 128-byte pieces of consecutive rows: coalesced); per-thread float sums folded to double every
+// 16 rows; the row offsets are added in order through LDS.  Partials [G, C, 2] as the channel-major kernels write them,
+// so the same finalize kernels serve.
+struct BnRowsArgs {
+  const float *x, *g;      // [P, C]
+  const float *scale, *shift, *mean, *invstd, *cA, *cB, *cD;
+  float *out;              // [P, C]
+  double *partial;         // [G, C, 2]
+  long long P;
+  int C, rows_per_block;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_rows_stats_kernel(BnRowsArgs a) {
+  extern __shared__ double rs_lds[];  // [RO][CG][8]
+  const int CG = a.C >> 2;            // 16-byte channel groups per row
+  const int cgs = CG < 256 ? CG : 256;
+  const int RO = 256 / cgs;           // row offsets handled side by side
+  const int cgl = (int)threadIdx.x % cgs, ro = (int)threadIdx.x / cgs;
+  const long long p0 = (long long)blockIdx.x * a.rows_per_block;
+  const long long p1 = p0 + a.rows_per_block < a.P ? p0 + a.rows_per_block : a.P;
+  for (int cg0 = 0; cg0 < CG; cg0 += cgs) {  // (one pass for C <= 1024; the trip count is the same for every thread)
+    const int cg = cg0 + cgl;
+    const bool live = cg < CG;
+    const int c = 4 * (live ? cg : 0);
+    float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc, mu = sc, is = sc;
+    if (MODE == 1) {
+      sc = *reinterpret_cast<const float4 *>(a.scale + c); sh = *reinterpret_cast<const float4 *>(a.shift + c);
+      mu = *reinterpret_cast<const float4 *>(a.mean + c); is = *reinterpret_cast<const float4 *>(a.invstd + c);
+    }
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    double d0[4] = {0.0, 0.0, 0.0, 0.0}, d1[4] = {0.0, 0.0, 0.0, 0.0};
+    int it = 0;
+    if (ro < RO && live) {
+      for (long long p = p0 + ro; p < p1; p += RO) {
+        const float4 xv = *reinterpret_cast<const float4 *>(a.x + (size_t)p * a.C + c);
+        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            s0[e] += xs[e];
+            s1[e] = __builtin_fmaf(xs[e], xs[e], s1[e]);
+          }
+        } else {
+          const float4 gv = *reinterpret_cast<const float4 *>(a.g + (size_t)p * a.C + c);
+          const float gs[4] = {gv.x, gv.y, gv.z, gv.w};
+          const float scs[4] = {sc.x, sc.y, sc.z, sc.w}, shs[4] = {sh.x, sh.y, sh.z, sh.w};
+          const float mus[4] = {mu.x, mu.y, mu.z, mu.w}, iss[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float dz = __builtin_fmaf(xs[e], scs[e], shs[e]) > 0.f ? gs[e] : 0.f;
+            s0[e] += dz;
+            s1[e] = __builtin_fmaf(dz, (xs[e] - mus[e]) * iss[e], s1[e]);
+          }
+        }
+        if (++it == 16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            d0[e] += (double)s0[e]; d1[e] += (double)s1[e]; s0[e] = s1[e] = 0.f;
+          }
+          it = 0;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d0[e] += (double)s0[e];
+      d1[e] += (double)s1[e];
+    }
+    __syncthreads();  // (the previous channel pass has been read out)
+    if (ro < RO) {
+      double *l = rs_lds + ((size_t)ro * cgs + cgl) * 8;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        l[2 * e] = d0[e];
+        l[2 * e + 1] = d1[e];
+      }
+    }
+    __syncthreads();
+    if (ro == 0 && live) {
+      double t[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = rs_lds[(size_t)cgl * 8 + e];
+      for (int r = 1; r < RO; ++r)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] += rs_lds[((size_t)r * cgs + cgl) * 8 + e];
+      double *pp = a.partial + ((size_t)blockIdx.x * a.C + c) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) pp[e] = t[e];  // [c .. c+3][2]
+    }
+  }
+}
+
+// dx = A dz + Bc + D x on rows, dz = g gated by the ReLU recomputed from x
+__global__ __launch_bounds__(256) void bn_rows_bwd_apply_kernel(BnRowsArgs a) {
+  const int CG = a.C >> 2;
+  const long long total = a.P * CG;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int c = 4 * (int)(t % CG);
+    const float4 xv = *reinterpret_cast<const float4 *>(a.x + t * 4), gv = *reinterpret_cast<const float4 *>(a.g + t * 4);
+    const float4 sc = *reinterpret_cast<const float4 *>(a.scale + c), sh = *reinterpret_cast<const float4 *>(a.shift + c);
+    const float4 cA = *reinterpret_cast<const float4 *>(a.cA + c), cB = *reinterpret_cast<const float4 *>(a.cB + c);
+    const float4 cD = *reinterpret_cast<const float4 *>(a.cD + c);
+    auto f = [](float x, float g, float s, float h, float A, float B, float D) {
+      const float dz = __builtin_fmaf(x, s, h) > 0.f ? g : 0.f;
+      return __builtin_fmaf(A, dz, __builtin_fmaf(D, x, B));
+    };
+    *reinterpret_cast<float4 *>(a.out + t * 4) =
+        make_float4(f(xv.x, gv.x, sc.x, sh.x, cA.x, cB.x, cD.x), f(xv.y, gv.y, sc.y, sh.y, cA.y, cB.y, cD.y),
+                    f(xv.z, gv.z, sc.z, sh.z, cA.z, cB.z, cD.z), f(xv.w, gv.w, sc.w, sh.w, cA.w, cB.w, cD.w));
+  }
+}
+
+static int bn_rows_block(long long P) {  // rows per workgroup: ~1024 workgroups, at least 32 rows each
+  long long r = (P + 1023) / 1024;
+  r = r < 32 ? 32 : r;
+  return (int)((r + 7) & ~7LL);
+}
+
 static void bn_shape(BnArgs &a) {
   a.span = kBnSpan;
   a.chunks = ceil_div(a.N, a.span);
@@ -693,4 +818,70 @@ extern "C" int cl3d_bn_add_relu_train_fwd(const float *x1, const float *gamma1, 
   }
   return cl3d_bn_add_relu_apply(x1, vec1, vec1 + C, x2, mode2 == 2 ? vec2 : nullptr, mode2 == 2 ? vec2 + C : nullptr, relu, B,
                                 C, N, out, stream);
+}
+
+// ---- point-major rows [P, C] (C % 4 == 0): statistics forward, dx = A dz + Bc + D x backward -------------------------
+extern "C" int cl3d_bn_rows_partials(long long P, int C) {
+  (void)C;
+  if (P <= 0) return 1;
+  const int rpb = cl3d::bn_rows_block(P);
+  return (int)((P + rpb - 1) / rpb);
+}
+
+static int bn_rows_checks(const float *x, long long P, int C, int n_partials, const char *who) {
+  using namespace cl3d;
+  if (P < 1 || C < 4 || (C & 3) != 0) return fail(CL3D_E_INVALID, "%s: needs P >= 1 and C a positive multiple of 4", who);
+  if ((reinterpret_cast<uintptr_t>(x) & 15u) != 0) return fail(CL3D_E_INVALID, "%s: rows must be 16-byte aligned", who);
+  if (n_partials != cl3d_bn_rows_partials(P, C)) return fail(CL3D_E_INVALID, "%s: wrong partial count", who);
+  return CL3D_OK;
+}
+
+static size_t bn_rows_lds(int C) {
+  const int CG = C >> 2, cgs = CG < 256 ? CG : 256;
+  return (size_t)(256 / cgs) * cgs * 8 * sizeof(double);
+}
+
+extern "C" int cl3d_bn_rows_stats(const float *rows, long long P, int C, double *partial, int n_partials, double count,
+                                  float eps, float momentum, const float *gamma, const float *beta, float *running_mean,
+                                  float *running_var, int64_t *num_batches_tracked, float *scale, float *shift,
+                                  float *mean, float *invstd, cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(rows && partial && gamma && beta && scale && shift && mean && invstd && count > 0, "bn_rows_stats: null pointer");
+  int rc = bn_rows_checks(rows, P, C, n_partials, "bn_rows_stats");
+  if (rc != CL3D_OK) return rc;
+  BnRowsArgs a{};
+  a.x = rows; a.partial = partial; a.P = P; a.C = C; a.rows_per_block = bn_rows_block(P);
+  hipLaunchKernelGGL((bn_rows_stats_kernel<0>), dim3(n_partials), dim3(256), bn_rows_lds(C), (hipStream_t)stream, a);
+  BnFinArgs f{};
+  f.partial = partial; f.G = n_partials; f.C = C; f.count = count; f.eps = eps; f.momentum = momentum;
+  f.gamma = gamma; f.beta = beta; f.running_mean = running_mean; f.running_var = running_var;
+  f.num_batches_tracked = reinterpret_cast<long long *>(num_batches_tracked);
+  f.o0 = scale; f.o1 = shift; f.o2 = mean; f.o3 = invstd;
+  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(C), dim3(64), 0, (hipStream_t)stream, f);
+  return check_launch("cl3d_bn_rows_stats");
+}
+
+// g = gradient with respect to the ACTIVATED rows max(scale x + shift, 0); coef [5, C] = A, Bc, D, d gamma, d beta
+extern "C" int cl3d_bn_rows_bwd(const float *g, const float *rows, const float *scale, const float *shift,
+                                const float *mean, const float *invstd, const float *gamma, long long P, int C,
+                                double count, double *partial, int n_partials, float *coef, float *drows,
+                                cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(g && rows && scale && shift && mean && invstd && gamma && partial && coef && drows && count > 0,
+               "bn_rows_bwd: null pointer");
+  int rc = bn_rows_checks(rows, P, C, n_partials, "bn_rows_bwd");
+  if (rc != CL3D_OK) return rc;
+  CL3D_REQUIRE(((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(drows)) & 15u) == 0, "bn_rows_bwd: unaligned");
+  BnRowsArgs a{};
+  a.x = rows; a.g = g; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.partial = partial;
+  a.P = P; a.C = C; a.rows_per_block = bn_rows_block(P);
+  hipLaunchKernelGGL((bn_rows_stats_kernel<1>), dim3(n_partials), dim3(256), bn_rows_lds(C), (hipStream_t)stream, a);
+  BnFinArgs f{};
+  f.partial = partial; f.G = n_partials; f.C = C; f.count = count; f.gamma = gamma; f.mean_in = mean; f.invstd_in = invstd;
+  f.o0 = coef; f.o1 = coef + C; f.o2 = coef + 2 * C; f.o3 = coef + 3 * C; f.o4 = coef + 4 * C;
+  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(C), dim3(64), 0, (hipStream_t)stream, f);
+  a.cA = coef; a.cB = coef + C; a.cD = coef + 2 * C; a.out = drows;
+  const long long work = (P * (C >> 2) + 255) / 256;
+  hipLaunchKernelGGL(bn_rows_bwd_apply_kernel, dim3((unsigned)(work < 16384 ? work : 16384)), dim3(256), 0, (hipStream_t)stream, a);
+  return check_launch("cl3d_bn_rows_bwd");
 }

@@ -13,8 +13,12 @@ namespace cl3d {
 constexpr int kTrMax = 96;         // largest tile extent
 constexpr int kTrFloats = 3200;    // largest padded tile (12.5 KB of LDS: see tile_shape)
 
+// PRO: element (r, c) enters as max(row_scale[r] * x + row_shift[r], 0) -- the BatchNorm + ReLU of the layer that produced a
+// channel-major tensor (r = channel), applied in the layout change instead of in a pass of its own (round 5)
+template <bool PRO>
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                        int R, int C) {
+                                                        int R, int C, const float *__restrict__ row_scale,
+                                                        const float *__restrict__ row_shift) {
   __shared__ float tile[64 * 65];
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
@@ -26,6 +30,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
   for (int u = 0; u < 16; ++u) {  // all 16 loads of the thread in flight
     const int r = r0 + ty + 4 * u, c = c0 + tx;
     v[u] = s[(size_t)(r < R ? r : R - 1) * C + (c < C ? c : C - 1)];
+    if (PRO) {
+      const float z = __builtin_fmaf(v[u], row_scale[r < R ? r : R - 1], row_shift[r < R ? r : R - 1]);
+      v[u] = z > 0.f ? z : 0.f;
+    }
   }
 #pragma unroll
   for (int u = 0; u < 16; ++u) tile[(ty + 4 * u) * 65 + tx] = v[u];
@@ -38,8 +46,10 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 }
 
 // R % 4 == 0, C % 4 == 0, TR % 4 == 0, TC % 4 == 0, TR, TC <= kTrMax
+template <bool PRO>
 __global__ __launch_bounds__(256) void transpose4_kernel(const float *__restrict__ src, float *__restrict__ dst, int R,
-                                                         int C, int TR, int TC) {
+                                                         int C, int TR, int TC, const float *__restrict__ row_scale,
+                                                         const float *__restrict__ row_shift) {
   __shared__ float tile[kTrFloats];
   const int b = blockIdx.z;
   const int r0 = blockIdx.y * TR, c0 = blockIdx.x * TC;
@@ -54,8 +64,16 @@ __global__ __launch_bounds__(256) void transpose4_kernel(const float *__restrict
     const int e = u * 256 + (int)threadIdx.x;
     const int r = e / cq, c4 = e - r * cq;
     v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (e < TR * cq && r0 + r < R && c0 + 4 * c4 < C)
+    if (e < TR * cq && r0 + r < R && c0 + 4 * c4 < C) {
       v[u] = *reinterpret_cast<const float4 *>(s + (size_t)(r0 + r) * C + c0 + 4 * c4);
+      if (PRO) {
+        const float sc = row_scale[r0 + r], sh = row_shift[r0 + r];
+        v[u].x = __builtin_fmaf(v[u].x, sc, sh); v[u].y = __builtin_fmaf(v[u].y, sc, sh);
+        v[u].z = __builtin_fmaf(v[u].z, sc, sh); v[u].w = __builtin_fmaf(v[u].w, sc, sh);
+        v[u].x = v[u].x > 0.f ? v[u].x : 0.f; v[u].y = v[u].y > 0.f ? v[u].y : 0.f;
+        v[u].z = v[u].z > 0.f ? v[u].z : 0.f; v[u].w = v[u].w > 0.f ? v[u].w : 0.f;
+      }
+    }
   }
 #pragma unroll
   for (int u = 0; u < kMaxV; ++u) {
@@ -108,22 +126,39 @@ static void tile_shape(int R, int C, int *tr, int *tc) {
 
 }  // namespace cl3d
 
-extern "C" int cl3d_transpose(const float *src, int B, int R, int C, float *dst, cl3d_stream_t stream) {
+static int transpose_launch(const float *src, int B, int R, int C, float *dst, const float *row_scale,
+                            const float *row_shift, hipStream_t st, const char *who) {
+  using namespace cl3d;
   CL3D_REQUIRE(B >= 0 && R >= 0 && C >= 0, "transpose: bad sizes");
   if (B == 0 || R == 0 || C == 0) return CL3D_OK;
   CL3D_REQUIRE(src && dst, "transpose: null pointer");
   CL3D_REQUIRE(B <= 65535, "transpose: grid limit");
+  const bool pro = row_scale != nullptr;
   const bool vec = (R & 3) == 0 && (C & 3) == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
   if (vec) {
     int TR, TC;
-    cl3d::tile_shape(R, C, &TR, &TC);
-    CL3D_REQUIRE(cl3d::ceil_div(R, TR) <= 65535, "transpose: grid limit");
-    hipLaunchKernelGGL(cl3d::transpose4_kernel, dim3(cl3d::ceil_div(C, TC), cl3d::ceil_div(R, TR), B), dim3(256), 0,
-                       (hipStream_t)stream, src, dst, R, C, TR, TC);
-    return cl3d::check_launch("cl3d_transpose");
+    tile_shape(R, C, &TR, &TC);
+    CL3D_REQUIRE(ceil_div(R, TR) <= 65535, "transpose: grid limit");
+    const dim3 grid(ceil_div(C, TC), ceil_div(R, TR), B);
+    if (pro) hipLaunchKernelGGL((transpose4_kernel<true>), grid, dim3(256), 0, st, src, dst, R, C, TR, TC, row_scale, row_shift);
+    else hipLaunchKernelGGL((transpose4_kernel<false>), grid, dim3(256), 0, st, src, dst, R, C, TR, TC, row_scale, row_shift);
+    return check_launch(who);
   }
-  CL3D_REQUIRE(cl3d::ceil_div(R, 64) <= 65535, "transpose: grid limit");
-  hipLaunchKernelGGL(cl3d::transpose_kernel, dim3(cl3d::ceil_div(C, 64), cl3d::ceil_div(R, 64), B), dim3(256), 0,
-                     (hipStream_t)stream, src, dst, R, C);
-  return cl3d::check_launch("cl3d_transpose");
+  CL3D_REQUIRE(ceil_div(R, 64) <= 65535, "transpose: grid limit");
+  const dim3 grid(ceil_div(C, 64), ceil_div(R, 64), B);
+  if (pro) hipLaunchKernelGGL((transpose_kernel<true>), grid, dim3(256), 0, st, src, dst, R, C, row_scale, row_shift);
+  else hipLaunchKernelGGL((transpose_kernel<false>), grid, dim3(256), 0, st, src, dst, R, C, row_scale, row_shift);
+  return check_launch(who);
+}
+
+extern "C" int cl3d_transpose(const float *src, int B, int R, int C, float *dst, cl3d_stream_t stream) {
+  return transpose_launch(src, B, R, C, dst, nullptr, nullptr, (hipStream_t)stream, "cl3d_transpose");
+}
+
+// [B,R,C] -> [B,C,R] with max(row_scale[r] * x + row_shift[r], 0) applied on the way: a channel-major tensor's folded
+// BatchNorm + ReLU (r = channel) in the layout change that turns it into point-major rows
+extern "C" int cl3d_transpose_bn_relu(const float *src, const float *row_scale, const float *row_shift, int B, int R, int C,
+                                      float *dst, cl3d_stream_t stream) {
+  CL3D_REQUIRE(row_scale && row_shift, "transpose_bn_relu: null scale / shift");
+  return transpose_launch(src, B, R, C, dst, row_scale, row_shift, (hipStream_t)stream, "cl3d_transpose_bn_relu");
 }

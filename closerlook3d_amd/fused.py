@@ -942,6 +942,176 @@ def pointwise_bottleneck(conv1, la, conv2, shortcut, query_xyz, support_xyz, que
                        res_bn=shortcut[1] if shortcut is not None else None, precision=precision, conv_out=y2)
 
 
+class _ReduceBottleneckLA(Function):
+    """The PosPool / AdaptiveWeight / PseudoGrid operator INSIDE a bottleneck, without the [B,C,N] tensors either side of
+    it (backbones/resnet.py:32-39,47-66):
+        y1 [B,C,N]  conv1's RAW output  ->  batch statistics of BatchNorm 1  ->  the layout change to point-major rows
+                    applies max(scale1 y1 + shift1, 0) on the way (cl3d_transpose_bn_relu: conv1's activated tensor is
+                    never written)  ->  the fused reduction, writing POINT-MAJOR rows [B,M,C]  ->  batch statistics of
+                    the operator's own BatchNorm on the rows (cl3d_bn_rows_stats)
+    returns (rows, scale2, shift2): the consumer (conv2, _Conv1x1Rows) applies max(scale2 rows + shift2, 0) while it stages
+    its operand and hands back the gradient with respect to the ACTIVATED rows; backward: BatchNorm 2 + ReLU backward on
+    rows (cl3d_bn_rows_bwd), the support-major pass reading those rows directly (no transposition of the upstream
+    gradient), BatchNorm 1 + ReLU backward on (d act, y1) with the mask recomputed from y1 (cl3d_bn_relu_bwd)."""
+
+    @staticmethod
+    def forward(ctx, y1, gamma1, beta1, bn1, p0, p1, op, query_xyz, support_xyz, query_mask, idx, idx_mask, radius,
+                normalize, reduction, pint, pfloat, constant, gamma2, beta2, bn2):
+        y1 = y1.contiguous()
+        B, C, N = y1.shape
+        _, M, K = idx.shape
+        dev = y1.device
+        lib = _lib.lib()
+        vec1 = torch.empty((4, C), dtype=torch.float32, device=dev)
+        vec2 = torch.empty((4, C), dtype=torch.float32, device=dev)
+        nparts1 = lib.cl3d_bn_partials(B, C, N)
+        nparts2 = lib.cl3d_bn_rows_partials(B * M, C)
+        partial1 = torch.empty((nparts1, C, 2), dtype=torch.float64, device=dev)
+        partial2 = torch.empty((nparts2, C, 2), dtype=torch.float64, device=dev)
+        ft = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        rows = torch.empty((B, M, C), dtype=torch.float32, device=dev)
+        slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev)
+        pairs = None
+        if op == OP_PSEUDOGRID and C % 4 == 0 and not constant:
+            pairs = torch.empty((B, M, K, 8), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            st = _stream(y1)
+            _lib.check(lib.cl3d_bn_relu_stats(_p(y1), B, C, N, _p(partial1), nparts1, float(B * N), float(bn1.eps),
+                                              float(bn1.momentum), _p(gamma1), _p(beta1), _p(bn1.running_mean),
+                                              _p(bn1.running_var), _p(_step_counter(bn1)), _p(vec1[0]), _p(vec1[1]),
+                                              _p(vec1[2]), _p(vec1[3]), st))
+            _lib.check(lib.cl3d_transpose_bn_relu(_p(y1), _p(vec1[0]), _p(vec1[1]), B, C, N, _p(ft), st))
+            pre = _mark(dev)
+            wait_ready(idx)
+            _lib.check(lib.cl3d_fused_reduce_fwd(
+                op, _p(query_xyz), _p(support_xyz), _p(query_mask), _p(idx), _p(idx_mask), _p(ft), B, N, M, K, C,
+                float(radius), int(normalize), reduction, _p(p0), _p(p1), pint, float(pfloat), int(constant),
+                _p(rows), 0, _p(slotrec), _p(pairs), st))
+            _start_inverse(idx, N, pre)
+            _lib.check(lib.cl3d_bn_rows_stats(_p(rows), B * M, C, _p(partial2), nparts2, float(B * M), float(bn2.eps),
+                                              float(bn2.momentum), _p(gamma2), _p(beta2), _p(bn2.running_mean),
+                                              _p(bn2.running_var), _p(_step_counter(bn2)), _p(vec2[0]), _p(vec2[1]),
+                                              _p(vec2[2]), _p(vec2[3]), st))
+        ctx.save_for_backward(y1, vec1, gamma1, ft, slotrec, p0, p1, pairs, rows, vec2, gamma2)
+        ctx.idx = idx
+        ctx.meta = (op, B, N, M, K, C, pint, pfloat, constant, nparts1, nparts2)
+        _join_inverse(idx)  # (behind the statistics pass: the build is longer than the gather pass it runs beside)
+        scale2, shift2 = vec2[0], vec2[1]
+        ctx.mark_non_differentiable(scale2, shift2)
+        return rows, scale2, shift2
+
+    @staticmethod
+    def backward(ctx, g_act, *unused):
+        y1, vec1, gamma1, ft, slotrec, p0, p1, pairs, rows, vec2, gamma2 = ctx.saved_tensors
+        op, B, N, M, K, C, pint, pfloat, constant, nparts1, nparts2 = ctx.meta
+        dev = y1.device
+        lib = _lib.lib()
+        g_act = g_act.contiguous()
+        drows = torch.empty_like(rows)
+        coef2 = torch.empty((5, C), dtype=torch.float32, device=dev)
+        coef1 = torch.empty((5, C), dtype=torch.float32, device=dev)
+        partial2 = torch.empty((nparts2, C, 2), dtype=torch.float64, device=dev)
+        partial1 = torch.empty((nparts1, C, 2), dtype=torch.float64, device=dev)
+        dact = torch.empty((B, C, N), dtype=torch.float32, device=dev)
+        dy1 = torch.empty_like(y1)
+        nparts = lib.cl3d_fused_param_partials(op, B, N, C)
+        npar = {OP_ADAPTIVE: 4, OP_PSEUDOGRID: 16}.get(op, 0)
+        dparam = torch.empty((nparts, C, npar), dtype=torch.float32, device=dev) if nparts else None
+        g0 = g1 = None
+        if op == OP_ADAPTIVE:
+            g0 = torch.empty((C // pint, 3), dtype=torch.float32, device=dev)
+            g1 = torch.empty((C // pint,), dtype=torch.float32, device=dev)
+        elif op == OP_PSEUDOGRID:
+            g1 = torch.empty((pint, C), dtype=torch.float32, device=dev)
+        with _lib.on_device(dev):
+            st = _stream(y1)
+            _lib.check(lib.cl3d_bn_rows_bwd(_p(g_act), _p(rows), _p(vec2[0]), _p(vec2[1]), _p(vec2[2]), _p(vec2[3]), _p(gamma2),
+                                            B * M, C, float(B * M), _p(partial2), nparts2, _p(coef2), _p(drows), st))
+            off, slots = inverse_index(ctx.idx, N)
+            _lib.check(lib.cl3d_fused_reduce_bwd(op, _p(drows), _p(ft), _p(slotrec), _p(pairs), _p(ctx.idx), _p(off), _p(slots),
+                                                 B, N, M, K, C, _p(p0), _p(p1), pint, float(pfloat), int(constant), _p(dact), 1,
+                                                 _p(dparam), nparts, st))
+            if g1 is not None:
+                _lib.check(lib.cl3d_fused_param_reduce(op, _p(dparam), nparts, C, pint, _p(g0), _p(g1), st))
+            _lib.check(lib.cl3d_bn_relu_bwd(_p(dact), _p(y1), _p(vec1[0]), _p(vec1[1]), _p(vec1[2]), _p(vec1[3]), _p(gamma1),
+                                            B, C, N, float(B * N), _p(partial1), nparts1, _p(coef1), _p(dy1), st))
+        return (dy1, coef1[3], coef1[4], None, g0, g1) + (None,) * 12 + (coef2[3], coef2[4], None)
+
+
+def _reduce_operator_args(la):
+    """(op, p0, p1, normalize, reduction, pint, pfloat, constant) of a PosPool / AdaptiveWeight / PseudoGrid module, as
+    pospool() / adaptive_weight() / pseudo_grid() hand them to the kernels; None when the fused kernels do not cover it."""
+    kind = type(la).__name__
+    if kind == 'PosPool' and _supported('pospool', la):
+        C = la.in_channels
+        if la.position_embedding == 'xyz':
+            return None if C % 3 else (OP_POSPOOL_XYZ, None, None, True, _RED[la.reduction], 0, 0.0, False)
+        if C % 6:
+            return None
+        fd = C // 6
+        dev = next(la.parameters()).device
+        p0 = torch.pow(1.0 * 1000, (1.0 / fd) * torch.arange(fd, dtype=torch.float32, device=dev))
+        return (OP_POSPOOL_SINCOS, p0, None, True, _RED[la.reduction], 0, 0.0, False)
+    if kind == 'AdaptiveWeight' and _supported('adaptive_weight', la):
+        conv = la.mlps.conv0
+        return (OP_ADAPTIVE, conv.weight.view(conv.weight.shape[0], 3), conv.bias, True, _RED[la.reduction],
+                int(la.shared_channels), 0.0, False)
+    if kind == 'PseudoGrid' and _supported('pseudo_grid', la):
+        return (OP_PSEUDOGRID, la.K_points.contiguous(), la.kernel_weights, False, _RED['sum'], int(la.K_points.shape[0]),
+                1.0 / float(la.extent), la.KP_influence == 'constant')
+    return None
+
+
+def reduce_bottleneck(conv1, la, conv2, shortcut, query_xyz, support_xyz, query_mask, support_mask, features, identity,
+                      precision='f32'):
+    """A whole PosPool / AdaptiveWeight / PseudoGrid bottleneck in training mode without the [B,C,N] tensors between its
+    layers (the counterpart of pointwise_bottleneck for the three gather-and-reduce operators):
+        y1 = conv1(x)                                    MFMA convolution, raw output
+        rows, scale, shift = operator(act1(y1))          _ReduceBottleneckLA: BatchNorm + ReLU of conv1 in the layout change,
+                                                         the operator's result as point-major rows, its BatchNorm as statistics
+        y2 = conv2(act(rows))                            conv2 reads the rows, the operator's BatchNorm + ReLU in ITS staging
+        out = ReLU(BN2(y2) + shortcut)                   the fused tail of conv_bn_act
+    Returns None when the configuration is outside what the kernels cover (the caller then runs layer by layer)."""
+    c1, bn1 = conv1[0], conv1[1]
+    c2, bn2 = conv2[0], conv2[1]
+    if getattr(la, 'output_conv', True) or not hasattr(la, 'out_transform'):
+        return None  # (an operator whose output transform carries a convolution: layer by layer)
+    obn = la.out_transform[0]
+    if not (bn1.training and bn2.training and obn.training and la.training):
+        return None
+    if c1.bias is not None or c1.kernel_size != (1,) or c2.bias is not None or c2.kernel_size != (1,):
+        return None
+    if not (_bn_unit_ok(features, bn1) and _bn_ok(bn1) and obn.affine and obn.track_running_stats and obn.momentum is not None
+            and bn2.affine and bn2.track_running_stats and bn2.momentum is not None):
+        return None
+    C1 = c1.weight.shape[0]
+    if (features.shape[1] != c1.weight.shape[1] or la.in_channels != C1 or la.out_channels != C1 or c2.weight.shape[1] != C1
+            or C1 % 4 or C1 > 1024 or obn.num_features != C1):
+        return None
+    if not (features.is_cuda and query_xyz.is_cuda and query_xyz.dim() == 3 and features.shape[2] == support_xyz.shape[1]):
+        return None
+    oargs = _reduce_operator_args(la)
+    if oargs is None:
+        return None
+    sc, sbn = (shortcut[0], shortcut[1]) if shortcut is not None else (None, None)
+    if sbn is not None and not sbn.training:
+        return None
+    if not _residual_ok(c2, identity, sc, sbn, features.device, features.shape[0], query_xyz.shape[1]):
+        return None
+    features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
+    prec = PRECISIONS[precision]
+    op, p0, p1, normalize, reduction, pint, pfloat, constant = oargs
+    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, la.radius, la.nsample, True)
+    y1 = _Conv1x1.apply(features, c1.weight.view(C1, -1), prec)
+    rows, scale, shift = _ReduceBottleneckLA.apply(y1, bn1.weight, bn1.bias, bn1, p0, p1, op, query_xyz, support_xyz,
+                                                   query_mask, idx, idx_mask, la.radius, normalize, reduction, pint, pfloat,
+                                                   constant, obn.weight, obn.bias, obn)
+    y2 = _Conv1x1Rows.apply(rows, scale, shift, c2.weight.view(c2.weight.shape[0], C1), prec)
+    return conv_bn_act(None, c2, bn2, relu=True, residual=identity,
+                       res_conv=shortcut[0] if shortcut is not None else None,
+                       res_bn=shortcut[1] if shortcut is not None else None, precision=precision, conv_out=y2)
+
+
 def point_rows(features, W, precision='f32'):
     """[G | H] rows and W_r of the factored PointWiseMLP contraction; precision 'f32' or 'bf16' (inputs of the
     contraction rounded to bf16, f32 accumulation; coordinates, indices and BatchNorm statistics stay f32)."""

@@ -296,6 +296,23 @@ int cl3d_pwmlp_point_gemm_bwd_fused(int B, int C, int N, int Co, int precision);
 int cl3d_pwmlp_point_gemm_bwd(const float *features, const float *scale, const float *shift, const float *dght,
                               const float *wcat, const float *dwr, int B, int C, int N, int Co, int precision,
                               float *dfeatures, float *dW, void *ws, size_t ws_bytes, cl3d_stream_t stream);
+/* f1 for the PosPool / AdaptiveWeight / PseudoGrid bottlenecks (round 5; backbones/resnet.py:32-39,47-66): the
+ * BatchNorm + ReLU of conv1 rides in the layout change that feeds the operator (transpose_bn_relu: [B,R,C] -> [B,C,R]
+ * with max(row_scale[r] x + row_shift[r], 0), r = channel), and the operator's own BatchNorm works on the point-major
+ * rows [P = B*M, C] the operator writes and conv2 (cl3d_conv1x1_rows_*) reads: bn_rows_stats = batch statistics,
+ * scale / shift and the running-statistics update (nn.BatchNorm1d's rule); bn_rows_bwd takes the gradient with respect
+ * to the ACTIVATED rows, gates it by the ReLU (recomputed from rows) and returns d rows and coef [5,C] = A, Bc, D,
+ * d gamma, d beta.  C % 4 == 0, 16-byte aligned rows; partial [cl3d_bn_rows_partials(P, C), C, 2] doubles. */
+int cl3d_transpose_bn_relu(const float *src, const float *row_scale, const float *row_shift, int B, int R, int C,
+                           float *dst, cl3d_stream_t stream);
+int cl3d_bn_rows_partials(long long P, int C);
+int cl3d_bn_rows_stats(const float *rows, long long P, int C, double *partial, int n_partials, double count, float eps,
+                       float momentum, const float *gamma, const float *beta, float *running_mean, float *running_var,
+                       int64_t *num_batches_tracked, float *scale, float *shift, float *mean, float *invstd,
+                       cl3d_stream_t stream);
+int cl3d_bn_rows_bwd(const float *g, const float *rows, const float *scale, const float *shift, const float *mean,
+                     const float *invstd, const float *gamma, long long P, int C, double count, double *partial,
+                     int n_partials, float *coef, float *drows, cl3d_stream_t stream);
 /* The 1x1 Conv1d layers either side of the operator (backbones/resnet.py:32-39,58-66; bias-free), same kernel:
  * y [B,Co,N] = W [Co,C] x [B,C,N], its input gradient and its weight gradient
  * (ws: cl3d_workspace_bytes(CL3D_OP_CONV1X1, B, N, Co, 0, C); optional for fwd / bwd_data as above). */

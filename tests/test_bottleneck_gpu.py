@@ -194,3 +194,126 @@ def test_pointwisemlp_bottleneck_without_the_tensors_between_its_layers(strided,
         else:
             assert np.array_equal(a[3][k], b[3][k]), k
     assert set(a[2]) == set(b[2])
+
+
+REDUCE_KINDS = {
+    "pospool_xyz": ("pospool", {"pospool__position_embedding": "xyz", "pospool__reduction": "avg"}, 72),
+    "pospool_sincos": ("pospool", {"pospool__position_embedding": "sin_cos", "pospool__reduction": "avg"}, 72),
+    "adaptive_weight": ("adaptive_weight", {}, 64),
+    "pseudo_grid": ("pseudo_grid", {}, 64),
+}
+
+
+@pytest.mark.parametrize("strided", [False, True])
+@pytest.mark.parametrize("name", sorted(REDUCE_KINDS))
+def test_reduce_operator_bottleneck_without_the_tensors_between_its_layers(name, strided, monkeypatch):
+    """VERDICT r4 item 3 (SURVEY 8(f) rank 1 for the other three operators): a PosPool / AdaptiveWeight / PseudoGrid
+    bottleneck in training mode with conv1's BatchNorm + ReLU applied in the layout change that feeds the operator, the
+    operator's result kept as point-major rows and ITS BatchNorm + ReLU applied in conv2's staging
+    (fused.reduce_bottleneck; backbones/resnet.py:32-39,47-66) against the same module run layer by layer with the
+    activated tensors materialised: same output, same gradients (input, every parameter), same running statistics, 1e-5."""
+    from closerlook3d_amd import backbones, fused
+    from closerlook3d_amd.backbones import Bottleneck
+    from oracle import operators as oo
+    kind, over, mid = REDUCE_KINDS[name]
+    rng = np.random.default_rng(11)
+    B, N, K = 4, 1024, 16
+    cout = 2 * mid
+    cin = mid if strided else cout
+    xyz_np, mask_np = oo.make_cloud(rng, B, N, pad_frac=0.1)
+    xyz, mask = torch.from_numpy(xyz_np).cuda(), torch.from_numpy(mask_np).cuda()
+    f_np = rng.standard_normal((B, cin, N)).astype(np.float32)
+    res, took = {}, {}
+    real = fused.reduce_bottleneck
+    for fuse in (True, False):
+        monkeypatch.setattr(backbones, "_FUSE_MIN_VALUES", 0 if fuse else 1 << 62)  # fused / layer by layer
+        calls = []
+        monkeypatch.setattr(fused, "reduce_bottleneck", lambda *a, _c=calls, **k: (_c.append(1), real(*a, **k))[1])
+        torch.manual_seed(3)
+        cfg = default_config(kind, over)
+        btn = Bottleneck(cin, cout, 2, 0.12, K, cfg, downsample=strided, sampleDl=0.08, npoint=256).cuda().train(True)
+        with torch.no_grad():
+            for m in btn.modules():
+                if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.normal_(0, 0.2)
+        feats = torch.from_numpy(f_np).cuda().requires_grad_(True)
+        sub_xyz, sub_mask, out = btn(xyz, mask, feats)
+        took[fuse] = len(calls)
+        probe = torch.from_numpy(np.random.default_rng(6).standard_normal(tuple(out.shape)).astype(np.float32)).cuda()
+        (out * probe).sum().backward()
+        res[fuse] = (out.detach().cpu().numpy(), feats.grad.cpu().numpy(),
+                     {k: p.grad.cpu().numpy() for k, p in btn.named_parameters() if p.grad is not None},
+                     {k: v.detach().cpu().numpy() for k, v in btn.named_buffers()})
+    assert took == {True: 1, False: 0}, took  # the fused form really ran (and only where asked)
+    a, b = res[True], res[False]
+    assert_close(a[0], b[0], 1e-5, "out")
+    assert_close(a[1], b[1], 1e-4, "grad input")  # sums over B*N*K terms in another order
+    assert set(a[2]) == set(b[2])
+    for k in b[2]:
+        assert_close(a[2][k], b[2][k], 3e-4, f"grad {k}")
+    for k in b[3]:
+        if a[3][k].dtype.kind == "f":
+            assert_close(a[3][k], b[3][k], 1e-5, f"buffer {k}")
+        else:
+            assert np.array_equal(a[3][k], b[3][k]), k
+
+
+@pytest.mark.parametrize("P,C", [(65536, 64), (4096, 72), (1000, 288), (77, 12), (300, 1152)])
+def test_bn_on_point_major_rows_matches_torch(P, C):
+    """cl3d_bn_rows_stats / cl3d_bn_rows_bwd (BatchNorm + ReLU on rows [P, C], gradient taken with respect to the
+    activated rows) against nn.BatchNorm1d + ReLU in double precision."""
+    from closerlook3d_amd import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(P + C)
+    rows = (torch.randn(P, C, generator=g) * 1.5 + 0.3).to(dev)
+    gact = torch.randn(P, C, generator=g).to(dev)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(dev)
+    beta = (torch.randn(C, generator=g) * 0.2).to(dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    nbt = torch.zeros((), dtype=torch.int64, device=dev)
+    vec = torch.empty(4, C, device=dev)
+    G = lib.cl3d_bn_rows_partials(P, C)
+    partial = torch.empty(G, C, 2, dtype=torch.float64, device=dev)
+    st = _lib.stream_ptr(dev)
+    p = lambda t: t.data_ptr()  # noqa: E731
+    _lib.check(lib.cl3d_bn_rows_stats(p(rows), P, C, p(partial), G, float(P), 1e-5, 0.1, p(gamma), p(beta), p(rm), p(rv), p(nbt),
+                                      p(vec[0]), p(vec[1]), p(vec[2]), p(vec[3]), st))
+    x64 = rows.double().requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(C, momentum=0.1).to(dev).double()
+    with torch.no_grad():
+        bn.weight.copy_(gamma.double())
+        bn.bias.copy_(beta.double())
+    y = torch.relu(bn(x64))
+    y.backward(gact.double())
+    mean, var = rows.double().mean(0), rows.double().var(0, unbiased=False)
+    scale = gamma.double() / torch.sqrt(var + 1e-5)
+    assert torch.allclose(vec[2].double(), mean, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(vec[0].double(), scale, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(vec[1].double(), beta.double() - mean * scale, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(rm.double(), bn.running_mean, rtol=1e-5, atol=1e-6) and torch.allclose(rv.double(), bn.running_var, rtol=1e-5, atol=1e-6)
+    assert int(nbt) == 1
+    drows = torch.empty_like(rows)
+    coef = torch.empty(5, C, device=dev)
+    _lib.check(lib.cl3d_bn_rows_bwd(p(gact), p(rows), p(vec[0]), p(vec[1]), p(vec[2]), p(vec[3]), p(gamma), P, C, float(P),
+                                    p(partial), G, p(coef), p(drows), st))
+    big = float(x64.grad.abs().max())
+    assert float((drows.double() - x64.grad).abs().max()) <= 2e-5 * big
+    assert torch.allclose(coef[3].double(), bn.weight.grad, rtol=1e-4, atol=1e-4 * float(bn.weight.grad.abs().max()))
+    assert torch.allclose(coef[4].double(), bn.bias.grad, rtol=1e-4, atol=1e-4 * float(bn.bias.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,C,N", [(2, 64, 4096), (3, 72, 1000), (1, 10, 77), (2, 1152, 16)])
+def test_transpose_with_the_batchnorm_relu_prologue(B, C, N):
+    """cl3d_transpose_bn_relu == transpose(max(scale[c] x + shift[c], 0)), bit for bit (one fma + one max per element)."""
+    from closerlook3d_amd import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + C + N)
+    x = torch.randn(B, C, N, generator=g).to(dev)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    out = torch.full((B, N, C), float("nan"), device=dev)
+    _lib.check(lib.cl3d_transpose_bn_relu(x.data_ptr(), sc.data_ptr(), sh.data_ptr(), B, C, N, out.data_ptr(), _lib.stream_ptr(dev)))
+    want = torch.relu(torch.addcmul(sh[None, :, None], x, sc[None, :, None])).transpose(1, 2).contiguous()
+    assert torch.equal(out, want) or float((out - want).abs().max()) <= 1e-6 * float(want.abs().max())
