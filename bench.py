@@ -287,19 +287,27 @@ def contraction_block(B, C, N, Co, precision, reps=30):
     import bench_point_gemm
     m = bench_point_gemm.measure(B, C, N, Co, reps=reps)
     mine = m["mfma_" + precision]
-    us = mine["fwd_us"] + mine["bwd_data_us"] + mine["bwd_weight_us"]
-    out = {"kernel": "cl3d::mfma_gemm_kernel + cl3d::pwmlp_rows_nolds_kernel (f32 forward) (csrc/mfma_gemm.hip)",
+    # what the timed step runs: the forward product and ONE call that forms both gradients (one kernel over d ght where
+    # pwmlp_point_grads_kernel covers the shape -- f32 at the metric shape -- else the two products in a row)
+    us = mine["fwd_us"] + mine["bwd_both_us"]
+    peak = mine["peak_tflops"]
+    out = {"kernel": "cl3d::pwmlp_rows_nolds_kernel (forward) + cl3d::pwmlp_point_grads_kernel (both gradients) + "
+                     "cl3d::pwmlp_dw_reduce_kernel; cl3d::mfma_gemm_kernel where they do not cover the shape (csrc/mfma_gemm.hip)",
            "precision": precision,
            "instruction": "v_mfma_f32_32x32x2_f32" if precision == "f32" else "v_mfma_f32_32x32x16_bf16",
            "flops": 3 * m["flops_per_gemm"], "us": round(us, 2),
+           "separate_products_us": round(mine["fwd_us"] + mine["bwd_data_us"] + mine["bwd_weight_us"], 2),
            "fwd_us": round(mine["fwd_us"], 2), "bwd_data_us": round(mine["bwd_data_us"], 2),
            "bwd_weight_us": round(mine["bwd_weight_us"], 2),
            "bwd_both_us": round(mine["bwd_both_us"], 2), "bwd_both_one_kernel": mine["bwd_both_one_kernel"],
-           "achieved_TFLOPs": round(mine["tflops"], 2), "peak_TFLOPs": mine["peak_tflops"],
-           "frac": round(mine["frac_of_mfma_peak"], 4),
-           "hbm_bytes": 3 * m["hbm_bytes_per_gemm"], "hbm_frac": round(mine["frac_of_hbm_peak"], 4),
+           "achieved_TFLOPs": round(3 * m["flops_per_gemm"] / (us * 1e-6) / 1e12, 2), "peak_TFLOPs": peak,
+           "frac": round(3 * m["flops_per_gemm"] / (us * 1e-6) / 1e12 / peak, 4),
+           # bytes the step's two calls must move: features + ght (forward), d ght + features + d features (gradients)
+           "hbm_bytes": int(4 * B * N * (2 * C + 2 * 2 * Co + C)),
+           "hbm_frac": round(4 * B * N * (2 * C + 2 * 2 * Co + C) / (us * 1e-6) / HBM_PEAK, 4),
            "note": "2*B*N*C*2Co flops per product, three products (ght, d features, d weight); each time includes the "
-                   "product's small side launch (weight split / partial reduce)"}
+                   "call's small side launch (weight split / partial reduce); `separate_products_us` = the three products as "
+                   "three calls (round 4's form)"}
     other = "bf16" if precision == "f32" else "f32"
     o = m["mfma_" + other]
     out["other_precision"] = {"precision": other, "us": round(o["fwd_us"] + o["bwd_data_us"] + o["bwd_weight_us"], 2),
