@@ -72,33 +72,32 @@ def _stream(t):
 
 
 def _fork_join(device, side_fn, main_fn):
-    """Two independent pieces of a backward pass (the data gradient and the weight gradient of one contraction) side by
-    side: `main_fn` on the caller's stream, `side_fn` on a side HIP stream, joined before returning.  Active only while
-    a DECLARED whole-step HIP graph is captured (whole_step_capture(): forward and backward in one capture), where the
+    """Two independent pieces of a backward pass (the weight gradient and the data gradient of one contraction) side by
+    side: `side_fn` on a side HIP stream, `main_fn` on the caller's, joined before returning.  Active only while a
+    DECLARED whole-step HIP graph is captured (whole_step_capture(): forward and backward in one capture), where the
     fork becomes two parallel branches of the graph; everywhere else -- eager launches, a capture that holds a backward
     pass alone (torch.cuda.make_graphed_callables) -- the two run one after the other on the caller's stream.  A forked
     pair inside a graph that holds ONLY a backward pass, reading tensors another capture allocated, gave replay-varying
     gradients in round 4 (DESIGN 6 "Round 4 (b)", not root-caused): that configuration is refused here, not left to a
     script's flag.
-    `main_fn` is enqueued FIRST: the HIP runtime lays a graph out depth-first along each node's first-captured dependent
-    (hip_graph_internal: the first edge inherits the parent's queue, every further edge gets another), so the piece
-    captured first behind the predecessor stays on the predecessor's queue and what follows it needs no cross-queue
-    hand-over (~10 us each in the replayed step, profiles/r04/step_timeline.txt).
+    `side_fn` is the LONGER piece (callers pass the weight gradient: product + slice reduce) and is enqueued FIRST: the
+    HIP runtime lays a graph out depth-first along each node's first-captured dependent (that one inherits the node's
+    queue, the next one goes to the other queue; scripts/micro/graph_queues.hip), so the piece captured first -- and the
+    join node behind it -- stay on the predecessor's queue, and it is the SHORT piece that pays the two cross-queue
+    hand-overs, which it can afford (measured the other way round in round 5: the config-2 backbone 8.19 -> 8.39 ms).
     Outputs are allocated by the caller BEFORE the fork (on the caller's stream); whatever side_fn allocates is scratch
     that lives and dies on the side stream."""
     if not (device.type == 'cuda' and pt_utils.async_index() and _forks_allowed()):
-        main_fn()
         side_fn()
+        main_fn()
         return
     main, side = torch.cuda.current_stream(device), pt_utils.index_stream(device, 2)
-    ev0 = torch.cuda.Event()
-    ev0.record(main)       # the predecessor of both pieces
-    main_fn()
-    side.wait_event(ev0)
+    side.wait_stream(main)
     with torch.cuda.stream(side):
         side_fn()
         ev = torch.cuda.Event()
         ev.record(side)
+    main_fn()
     main.wait_event(ev)
 
 
@@ -350,17 +349,15 @@ def _wants_grad(*tensors):
     return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
-_CSR_FIRST = os.environ.get('CL3D_CSR_FIRST') == '1'  # (round-5 A/B only: the round-4 order, CSR build captured behind the query)
-_CSR_AFTER = os.environ.get('CL3D_CSR_AFTER', 'product')  # (round-5 A/B only) what the PointWiseMLP's CSR build waits for
-
-
 def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad=False):
     """Ball query on the index stream; the fused Functions wait_ready() the result right before their first kernel that
-    reads it and start the CSR inverse (when a backward will follow) right BEHIND that kernel (_start_inverse)."""
+    reads it and start the CSR inverse (when a backward will follow) right BEHIND that kernel (_start_inverse; `need_grad`
+    is kept for the callers' signature: the build is no longer started here).  Inside a backbone's forward, where the
+    query ran ahead of the feature pass, starting the build right behind the QUERY instead was measured again in round 5
+    (same box, alternating runs): config 2 8.09 against 8.12 ms (noise), config 3 6.19 against 5.68 ms, config 4 6.49
+    against 6.03 ms -- the build behind the consumer wins or ties everywhere."""
     idx, idx_mask = _ball_query(query_xyz.contiguous(), support_xyz.contiguous(), query_mask.contiguous(),
                                 support_mask.contiguous(), radius, nsample, defer=True)
-    if need_grad and _CSR_FIRST:
-        inverse_index(idx, support_xyz.shape[1], prefetch=True)
     return idx, idx_mask
 
 
@@ -607,10 +604,9 @@ class _PointwiseMLP(Function):
                                                 B, N, M, K, Co, float(radius), _p(ystar), _p(kstar), _p(sy),
                                                 _p(partial), nparts, st))
                 if need_grad:
-                    if _CSR_AFTER == 'stats':   # (round-5 A/B: the build starts when the statistics pass has ENDED)
-                        pre = _mark(dev)
-                    if _CSR_AFTER != 'apply':
-                        _start_inverse(idx, N, pre)
+                    # (the build made to wait for the END of the statistics pass, or captured behind the activation pass,
+                    # was measured too: 0.302-0.304 / 0.311 ms against 0.301 ms -- the contention moves, it does not go)
+                    _start_inverse(idx, N, pre)
                 # batch statistics, scale/shift and the running-statistics update in one small launch
                 _lib.check(lib.cl3d_pwmlp_finalize_stats(_p(partial), nparts, Co, float(n), float(eps), float(momentum),
                                                          _p(gamma), _p(beta), _p(running_mean), _p(running_var),
@@ -618,8 +614,6 @@ class _PointwiseMLP(Function):
                                                          _p(invstd), _p(sums), st))
                 if not rows_out:
                     _lib.check(lib.cl3d_pwmlp_apply(_p(ystar), _p(scale), _p(shift), B, M, Co, _p(out), st))
-                if need_grad and _CSR_AFTER == 'apply':
-                    _start_inverse(idx, N, _mark(dev))
                 if need_grad:
                     ctx.save_for_backward(ght, wr, gamma, vec, ystar, sy, kstar, sums, query_xyz, support_xyz)
                     ctx.radius = float(radius)
