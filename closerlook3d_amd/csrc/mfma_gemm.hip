@@ -1111,6 +1111,10 @@ static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, s
       double fill = (double)(tiles * real_split) / (double)(kCUs * resident);
       if (fill > 1.0) fill = 1.0;
       const double partial_us = real_split > 1 ? 3.0 + 2.0 * (double)real_split * I * J * 4.0 / 2.5e6 : 0.0;
+      // (round 5: a term for the operand bytes a tiling pulls through L2 -- tiles x K x (TI + TJ) x 4 B against 3-6 TB/s,
+      //  170 MB for the 1152 x 1152 x 1024 layer in 64 x 64 tiles -- pushed the plan towards 128 x 128 and made every shape
+      //  but two slower, the weight gradients by 2-3 x: config 2 6.67 -> 7.58 / 8.88 ms in bf16; gpurun_out/r05k.  The
+      //  tiling is not what holds this kernel back; its chunk pipeline is.  Dropped.)
       const double cost = flops / peak_flops_per_us / fill + partial_us + 2.0;
       if (cost < best_cost * 0.97) {
         best_cost = cost;
