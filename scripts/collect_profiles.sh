@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the summaries of one `bash scripts/gpu_check.sh <tag>` session from gpurun_out/<tag>/ into profiles/<round>/
-# under the names profiles/README.md lists.   bash scripts/collect_profiles.sh r03z r03
-TAG=$1; ROUND=${2:-r04}
+# under the names profiles/README.md lists.   bash scripts/collect_profiles.sh r05z r05
+TAG=$1; ROUND=${2:-r05}
 S=gpurun_out/$TAG; D=profiles/$ROUND
 mkdir -p $D
 cp $S/summary.txt $D/gpu_check_summary.txt
@@ -9,12 +9,11 @@ cp $S/bench.json $D/bench_pointwisemlp.json
 cp $S/bench_driver_flags.json $D/bench_pointwisemlp_driver_flags.json
 cp $S/bench_bf16.json $D/bench_pointwisemlp_bf16.json
 cp $S/bench_eager.json $D/bench_pointwisemlp_eager.json
-cp $S/prof/bench_kernel_stats.csv $D/bench_pointwisemlp_kernel_stats.csv 2>/dev/null || cp $(find $S/prof -name "bench_kernel_stats.csv" | head -1) $D/bench_pointwisemlp_kernel_stats.csv
-for f in step_counters.json step_timeline.txt pmc_traffic.json point_gemm.jsonl convs.jsonl bench_bq.jsonl step_variants.txt \
-         sorted_points_experiment.txt micro_gathers.txt bench_pospool.json bench_adaptive_weight.json bench_pseudo_grid.json \
-         bench_pseudo_grid_kernel_stats.csv bench_dataset_grid.json bench_voting.json bench_sphere_crop.json \
-         micro_pk_rate.txt eager_host.txt two_graph_repeat_check.txt; do
-  cp $S/$f $D/$f
+cp $(find $S/prof -name "bench_kernel_stats.csv" | head -1) $D/bench_pointwisemlp_kernel_stats.csv
+for f in step_counters.json step_timeline.txt pmc_traffic.json point_gemm.jsonl convs.jsonl bench_bq.jsonl \
+         bench_pospool.json bench_adaptive_weight.json bench_pseudo_grid.json bench_dataset_grid.json bench_voting.json \
+         bench_sphere_crop.json eager_host.txt two_graph_repeat_check.txt graph_queues.txt bench_two_ranks_one_device.json; do
+  cp $S/$f $D/$f 2>/dev/null || echo "missing $f"
 done
 cp $S/backbone_steady_state.txt $D/backbone_modelnet_pointwisemlp_bf16_steady_state.txt
 cp $(find $S/prof_bb -name "bb_kernel_stats.csv" | head -1) $D/backbone_modelnet_pointwisemlp_bf16_kernel_stats.csv
