@@ -60,6 +60,12 @@ __global__ __launch_bounds__(256) void csr_offsets_kernel(const unsigned *__rest
   }
 }
 
+// (Round 5, both measured on the replayed step and dropped: raising the wave priority of these kernels (s_setprio 1 / 2 /
+// 3) and shrinking their workgroups to two / one wave (32 / 16 KB of LDS).  Beside the PointWiseMLP's TRAIN pass -- four
+// workgroups per CU x 128 VGPRs: the whole register file -- the count pass spans 55-62 us against 11 us alone and the
+// TRAIN pass 69-77 us against 59; neither changed with either knob (step 0.301-0.306 ms against 0.295-0.305): a build
+// workgroup can only start where a TRAIN workgroup has retired, whatever its priority or size.)
+
 // ---- counting sort with wave-private LDS counters -------------------------------------------------
 constexpr int kCsrBatch = 8;  // slot loads in flight per lane
 
