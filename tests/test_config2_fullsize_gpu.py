@@ -19,8 +19,12 @@ from tests.helpers import default_config
 
 pytestmark = pytest.mark.gpu
 
-BF16_STAGE_REL_L2 = 5e-2   # one stage (two bottlenecks: six convolutions, two operators, max-pool) on identical inputs
-BF16_END_TO_END_REL_L2 = 0.6  # res5 features, bf16 vs f32 network (measured on MI355X: see the printed line)
+# The guard against a regression of the bf16 kernels is the PER-STAGE bound on identical inputs: measured 8.5e-3 (three runs,
+# same value: the path is deterministic), held to 1.3 x that.  The end-to-end figure is a property of the freshly initialised
+# network's conditioning (see the docstring), measured 0.427 three times out of three; it is held to 1.3 x its measured value
+# as VERDICT r4 asked, which is as tight as a quantity that moves with every flipped near-tie can honestly be held.
+BF16_STAGE_REL_L2 = 1.1e-2     # one stage (two bottlenecks: six convolutions, two operators, max-pool) on identical inputs
+BF16_END_TO_END_REL_L2 = 0.56  # res5 features, bf16 vs f32 network
 
 
 def _rel_l2(a, b):
