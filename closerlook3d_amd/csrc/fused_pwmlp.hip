@@ -1079,6 +1079,211 @@ __global__ __launch_bounds__(256) void pwmlp_rows_kernel(RowArgs a) {
   }
 }
 
+// ---- the same two passes for whole 64-channel chunks and whole 64-query tiles (every layer whose width is a
+// multiple of 64 on clouds of a multiple of 64 points: the metric shape), with ALL of a tile's loads in flight at once.
+// pwmlp_rows_kernel walks a tile in four batches, each a chain of dependent round trips (gout tile -> barrier -> per
+// batch: y*, k*, idx row -> the slot's coordinates): with one tile per workgroup and every workgroup resident the
+// whole launch is ONE such chain, ~10 round trips = 32 us for 82 MB at the metric shape.  Here a wave owns 16
+// consecutive queries: the upstream-gradient tile (16-byte loads), y*, k*, the 16 idx rows and the queries' own
+// coordinates (wave-uniform: scalar loads) are requested before anything is waited for, the arg-max slots' support
+// coordinates follow in two halves (the second half's gathers fly during the first half's arithmetic), and the
+// channel-major results leave as 16-byte stores.  Same expressions per element as pwmlp_rows_kernel; the double
+// partials are summed in (wave, query) order -- a fixed order, but not pwmlp_rows_kernel's.
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+template <typename T>
+__device__ __forceinline__ T ld_at(const char *base, unsigned byte_off) {  // uniform base + 32-bit lane offset: one access
+  return *reinterpret_cast<const T *>(base + byte_off);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 4) void pwmlp_rows64_kernel(RowArgs a) {
+  __shared__ __attribute__((aligned(16))) float tile[64 * 65];
+  __shared__ int tile2[MODE == ROWS_BWD ? 64 * 65 : 1];
+  double *red = reinterpret_cast<double *>(tile);
+  const int M = a.M, Co = a.Co, K = a.K;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tiles_per_cloud = M >> 6;
+  const int ntiles = a.B * tiles_per_cloud;
+  const int cbase = blockIdx.y * 64;  // one 64-channel chunk per blockIdx.y (the launch sets gridDim.y = Co / 64)
+  const unsigned K4 = 4u * (unsigned)K, Co4 = 4u * (unsigned)Co, M4 = 4u * (unsigned)M;
+  double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+  for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    // Every lane-dependent offset below is rebuilt per tile from an opaque copy of the thread index: as loop invariants
+    // they were hoisted out of the tile loop (zero-extended to 64-bit pairs, one per access) and spilled -- and a kernel
+    // with a scratch frame is not allowed next to another one on the captured step's queues.
+    unsigned tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const unsigned cl = tid & 63u;
+    const unsigned cc4 = tid >> 4, j4 = (tid & 15u) * 4u;  // channel-major side: channel rows cc4 + 16 u, four queries
+    const unsigned g4 = cc4 * M4 + 4u * j4;
+    const unsigned c4 = 4u * ((unsigned)cbase + cl);
+    const float scale = ld_at<float>(reinterpret_cast<const char *>(a.scale), c4);
+    const float shift = ld_at<float>(reinterpret_cast<const char *>(a.shift), c4);
+    const int b = t / tiles_per_cloud;
+    const int j0 = (t - b * tiles_per_cloud) * 64;
+    const size_t row0 = (size_t)b * M + j0 + 16 * w;  // first of this wave's 16 queries
+    float *const trow = tile + cc4 * 65 + j4;         // + 16 u rows
+    float *const town = tile + cl * 65 + 16 * w;      // + i: this lane's (channel, query) elements
+    if constexpr (MODE == ROWS_BWD) {
+      const float mean = ld_at<float>(reinterpret_cast<const char *>(a.mean), c4);
+      const float invstd = ld_at<float>(reinterpret_cast<const char *>(a.invstd), c4);
+      const char *gbase = reinterpret_cast<const char *>(a.gout + ((size_t)b * Co + cbase) * M + j0);
+      const char *ibase = reinterpret_cast<const char *>(a.idx + row0 * K);
+      const char *ybase = reinterpret_cast<const char *>(a.ystar_t + row0 * Co + cbase);
+      const char *kbase = reinterpret_cast<const char *>(a.kstar_t + row0 * Co + cbase);
+      const char *sbase = reinterpret_cast<const char *>(a.support_xyz + (size_t)b * a.N * 3);
+      char *dbase = reinterpret_cast<char *>(a.dz_t + row0 * Co + cbase);
+      char *zbase = reinterpret_cast<char *>(a.dz_cm + ((size_t)b * Co + cbase) * M + j0);
+      char *tbase = reinterpret_cast<char *>(a.ts_cm + ((size_t)b * Co + cbase) * M + j0);
+      // (1) everything that waits for nothing: the upstream-gradient tile, the wave's 16 idx rows, y*, the queries'
+      // coordinates.  One running offset register per stream, bumped between the loads (sixteen precomputed offsets per
+      // stream overflow the register file while the loads are in flight).
+      float4 gv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) gv[u] = ld_at<float4>(gbase, g4 + 16u * (unsigned)u * M4);
+      int iv[16], ks[16];
+      float y[16];
+      unsigned off = 4u * (cl < (unsigned)K ? cl : (unsigned)K - 1u);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        iv[i] = ld_at<int>(ibase, off);
+        off += K4;
+        asm volatile("" : "+v"(off));
+      }
+      off = 4u * cl;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        y[i] = ld_at<float>(ybase, off);
+        off += Co4;
+        asm volatile("" : "+v"(off));
+      }
+      // the wave's 16 queries' coordinates: 48 consecutive floats, one per lane, handed out by v_readlane below
+      const float qv = ld_at<float>(reinterpret_cast<const char *>(a.query_xyz + row0 * 3), 4u * (cl < 48u ? cl : 47u));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {  // the gradient tile arrives first (requested first)
+        float *row = trow + 16 * u * 65;
+        row[0] = gv[u].x; row[1] = gv[u].y; row[2] = gv[u].z; row[3] = gv[u].w;
+      }
+      // (2) the arg-max slots, requested once the gradient tile's registers are free: first needed after the coordinate
+      // gathers below, whose round trip they share
+      off = cl;
+      asm volatile("" : "+v"(off) : : "memory");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        ks[i] = ld_at<unsigned char>(kbase, off);
+        off += (unsigned)Co;
+        asm volatile("" : "+v"(off));
+      }
+      // (3) lane l holds slot l's support index: its coordinates, for the first eight queries
+      float sx[8], sy[8], sz[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float *sp = reinterpret_cast<const float *>(sbase + 12u * (unsigned)iv[i]);
+        sx[i] = sp[0]; sy[i] = sp[1]; sz[i] = sp[2];
+      }
+      // the lane's arg-max slot rides in the top byte of its index word from here on (N < 2^24, K <= 64: host check)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) iv[i] |= ks[i] << 24;
+      __syncthreads();
+      // the query table of the support-major pass, {coordinates, centre idx[j, 0]}: lane 0 holds both (its index word
+      // is slot 0 of the query's row)
+      const bool writes_qtab = a.qtab != nullptr && cbase == 0 && cl == 0;
+      off = 4u * cl;
+      asm volatile("" : "+v"(off));
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        if (h == 1) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float *sp = reinterpret_cast<const float *>(sbase + 12u * ((unsigned)iv[8 + i] & 0xffffffu));
+            sx[i] = sp[0]; sy[i] = sp[1]; sz[i] = sp[2];
+          }
+        }
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+          const int i = 8 * h + ii;
+          float qvi = qv;
+          asm volatile("" : "+v"(qvi));  // keeps the 48 v_readlane results from being formed (and held in SGPRs) up front
+          const float qx = lane_value(qvi, 3 * i), qy = lane_value(qvi, 3 * i + 1), qz = lane_value(qvi, 3 * i + 2);
+          if (writes_qtab) a.qtab[row0 + i] = make_float4(qx, qy, qz, __int_as_float(iv[i] & 0xffffff));
+          const int kq = (int)((unsigned)iv[i] >> 24);
+          const int ts = __shfl(iv[i], kq, CL3D_WAVE) & 0xffffff;
+          const float rx = (__shfl(sx[ii], kq, CL3D_WAVE) - qx) * a.inv_radius;
+          const float ry = (__shfl(sy[ii], kq, CL3D_WAVE) - qy) * a.inv_radius;
+          const float rz = (__shfl(sz[ii], kq, CL3D_WAVE) - qz) * a.inv_radius;
+          const float z = __builtin_fmaf(y[i], scale, shift);
+          const float dz = z > 0.f ? town[i] : 0.f;
+          town[i] = dz;  // own element of the tile: overwritten in place, transposed out below
+          (tile2 + (town - tile))[i] = ts;
+          *reinterpret_cast<float *>(dbase + off) = dz;
+          off += Co4;
+          asm volatile("" : "+v"(off));
+          acc[0] += (double)dz;
+          acc[1] += (double)(dz * ((y[i] - mean) * invstd));
+          acc[2] += (double)(dz * rx);
+          acc[3] += (double)(dz * ry);
+          acc[4] += (double)(dz * rz);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float *row = trow + 16 * u * 65;
+        const int *row2 = tile2 + (row - tile);
+        const unsigned o = g4 + 16u * (unsigned)u * M4;  // the byte offsets the upstream-gradient tile was read at
+        *reinterpret_cast<float4 *>(zbase + o) = make_float4(row[0], row[1], row[2], row[3]);
+        *reinterpret_cast<int4 *>(tbase + o) = make_int4(row2[0], row2[1], row2[2], row2[3]);
+      }
+      __syncthreads();  // the tile is overwritten by the next iteration (and by the closing reduction)
+    } else {
+      const char *ybase = reinterpret_cast<const char *>(a.ystar_t + row0 * Co + cbase);
+      char *obase = reinterpret_cast<char *>(a.out + ((size_t)b * Co + cbase) * M + j0);
+      float y[16];
+      unsigned off = 4u * cl;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        y[i] = ld_at<float>(ybase, off);
+        off += Co4;
+        asm volatile("" : "+v"(off));
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float z = __builtin_fmaf(y[i], scale, shift);
+        town[i] = z > 0.f ? z : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float *row = trow + 16 * u * 65;
+        *reinterpret_cast<float4 *>(obase + (g4 + 16u * (unsigned)u * M4)) = make_float4(row[0], row[1], row[2], row[3]);
+      }
+      __syncthreads();
+    }
+  }
+  if constexpr (MODE == ROWS_BWD) {  // fixed-order reduction over the four waves that share a channel
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int p = 0; p < 5; ++p) red[tid * 5 + p] = acc[p];
+    __syncthreads();
+    for (int e = tid; e < 64 * 5; e += 256) {
+      const int cc = e / 5, p = e - cc * 5;
+      double sum = 0.0;
+      for (int r = 0; r < 4; ++r) sum += red[(r * 64 + cc) * 5 + p];
+      a.partial[((size_t)blockIdx.x * Co + cbase + cc) * kPartialW + p] = sum;
+    }
+  }
+}
+
+// whether the whole-tile form covers a rows pass: 64-channel chunks, 64-query tiles, 16-byte channel-major rows
+static bool rows64_covers(const RowArgs &a, bool bwd) {
+  auto al16 = [](const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+  if (a.Co % 64 != 0 || a.M % 64 != 0) return false;
+  if (!bwd) return al16(a.out);
+  return a.K <= 64 && a.N < (1 << 24) && a.gout_channel_major && al16(a.gout) && al16(a.dz_cm) && al16(a.ts_cm);
+}
+
 // ---- fixed-order reduction of the per-block double partials + the per-channel BatchNorm algebra.
 // One block per channel; replaces ~30 tiny element-wise launches the same math costs in PyTorch.
 enum { FIN_STATS = 0, FIN_COEFFS = 1 };
@@ -1099,9 +1304,10 @@ template <int MODE>
 __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
   // thread t sums column k = t & 7 of the partial records g = t >> 3 (mod 32): a wave reads 8 whole 64-byte records
   // per load, kFinBatch loads are in flight per thread (the sums are a chain of memory round trips otherwise:
-  // measured 16.5 us for 1024 records x 64 channels before), and the 32 partial sums of a column are folded in a
+  // measured 16.5 us for 1024 records x 64 channels one at a time, 5.8-7 us eight at a time = four round trips; 32 at a
+  // time the 1024 records of the metric shape are ONE round trip), and the 32 partial sums of a column are folded in a
   // fixed order -- lanes by shuffle, then the four waves.
-  constexpr int kFinBatch = 8;
+  constexpr int kFinBatch = 32;
   __shared__ double s_red[4][8];
   __shared__ double s_tot[8];
   const int c = blockIdx.x;
@@ -1395,7 +1601,10 @@ extern "C" int cl3d_pwmlp_apply(const float *ystar_t, const float *scale, const 
   RowArgs a{};
   a.ystar_t = ystar_t; a.scale = scale; a.shift = shift; a.out = out; a.B = B; a.M = M; a.Co = Co; a.K = 1;
   const int gx = round_grid((long long)B * ceil_div(M, 64), 8192);
-  hipLaunchKernelGGL((pwmlp_rows_kernel<ROWS_APPLY>), dim3(gx, rows_chunks(Co)), dim3(256), 0, (hipStream_t)stream, a);
+  if (rows64_covers(a, false))
+    hipLaunchKernelGGL((pwmlp_rows64_kernel<ROWS_APPLY>), dim3(gx, Co / 64), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((pwmlp_rows_kernel<ROWS_APPLY>), dim3(gx, rows_chunks(Co)), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_apply");
 }
 
@@ -1457,8 +1666,11 @@ extern "C" int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, co
   a.query_xyz = query_xyz; a.support_xyz = support_xyz; a.inv_radius = 1.0f / radius; a.N = N;
   a.scale = scale; a.shift = shift; a.mean = mean;
   a.invstd = invstd; a.partial = partial; a.B = B; a.M = M; a.K = K; a.Co = Co;
-  hipLaunchKernelGGL((pwmlp_rows_kernel<ROWS_BWD>), dim3(n_partials, rows_chunks(Co)), dim3(256), 0, (hipStream_t)stream,
-                     a);
+  if (rows64_covers(a, true))
+    hipLaunchKernelGGL((pwmlp_rows64_kernel<ROWS_BWD>), dim3(n_partials, Co / 64), dim3(256), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL((pwmlp_rows_kernel<ROWS_BWD>), dim3(n_partials, rows_chunks(Co)), dim3(256), 0, (hipStream_t)stream,
+                       a);
   return check_launch("cl3d_pwmlp_bwd_rows");
 }
 
