@@ -1304,10 +1304,11 @@ template <int MODE>
 __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
   // thread t sums column k = t & 7 of the partial records g = t >> 3 (mod 32): a wave reads 8 whole 64-byte records
   // per load, kFinBatch loads are in flight per thread (the sums are a chain of memory round trips otherwise:
-  // measured 16.5 us for 1024 records x 64 channels one at a time, 5.8-7 us eight at a time = four round trips; 32 at a
-  // time the 1024 records of the metric shape are ONE round trip), and the 32 partial sums of a column are folded in a
-  // fixed order -- lanes by shuffle, then the four waves.
-  constexpr int kFinBatch = 32;
+  // measured 16.5 us for 1024 records x 64 channels one at a time, 5.8-6 us eight at a time; 32 at a time -- the metric
+  // shape's 1024 records in ONE round trip -- measured the same 6.1-6.5 us: what is left is the launch and 64 blocks
+  // pulling 64 KB each in 64-byte pieces), and the 32 partial sums of a column are folded in a fixed order -- lanes by
+  // shuffle, then the four waves.
+  constexpr int kFinBatch = 8;
   __shared__ double s_red[4][8];
   __shared__ double s_tot[8];
   const int c = blockIdx.x;
