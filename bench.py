@@ -166,10 +166,11 @@ ENTRY_KERNELS = {
     "cl3d_pwmlp_point_gemm_bwd": ["pwmlp_point_grads_kernel", "pwmlp_dw_reduce_kernel"],
     "cl3d_pwmlp_stats": ["pwmlp_query_kernel<0"],
     "cl3d_pwmlp_finalize_stats": ["pwmlp_finalize_kernel<0"],
-    "cl3d_pwmlp_apply": ["pwmlp_rows_kernel<0"],
-    "cl3d_pwmlp_bwd_rows": ["pwmlp_rows_kernel<1"],
+    "cl3d_pwmlp_apply": ["pwmlp_rows64_kernel<0", "pwmlp_rows_kernel<0"],   # whole-tile form first (the metric shape)
+    "cl3d_pwmlp_bwd_rows": ["pwmlp_rows64_kernel<1", "pwmlp_rows_kernel<1"],
     "cl3d_pwmlp_bwd_hits": ["pwmlp_hit_kernel"],
     "cl3d_pwmlp_bn_backward_coeffs": ["pwmlp_finalize_kernel<1"],
+    "cl3d_pwmlp_bwd_hits_coeffs": ["pwmlp_hit_coeffs_kernel"],  # both of the above in one launch (the training step)
     "cl3d_pwmlp_bwd_support": ["pwmlp_support_kernel"],
     "cl3d_fused_reduce_fwd": ["fused_reduce_fwd_kernel"],
     "cl3d_fused_reduce_bwd": ["fused_reduce_bwd_kernel", "pg_dkw_kernel"],
@@ -209,6 +210,7 @@ def step_model_bytes(B, N, M, K, C, kind="pointwisemlp"):
         "cl3d_pwmlp_apply": (B * 2 * rows_q, 0, "hbm"),
         "cl3d_pwmlp_bwd_rows": (B * (4 * rows_q + M * Co + 4 * MK + xyzm), 0, "hbm"),
         "cl3d_pwmlp_bwd_hits": (B * (2 * rows_q + f * Co * N), 0, "lds-atomics"),
+        "cl3d_pwmlp_bwd_hits_coeffs": (B * (2 * rows_q + f * Co * N), 0, "lds-atomics"),
         # support-major pass: one H row per slot through the CSR (slot ids, row bounds, the per-query table of bwd_rows)
         "cl3d_pwmlp_bwd_support": (B * (f * N * 2 * Co * 2 + f * Co * N + 2 * rows_q + 4 * MK + 4 * N + 16 * M + 12 * N), B * MK * f * Co, "l2-gather+latency"),
         # PosPool / AdaptiveWeight / PseudoGrid: one feature row per slot each way

@@ -77,6 +77,7 @@ SIGNATURES = {
     "cl3d_pwmlp_bwd_rows": [_P, _I] + [_P] * 5 + [_F] + [_P] * 4 + [_I] * 5 + [_P, _P, _P, _P, _P, _I, _P],
     "cl3d_pwmlp_bwd_hits": [_P, _P, _I, _I, _I, _I, _P, _P],
     "cl3d_pwmlp_bn_backward_coeffs": [_P, _I, _I, ctypes.c_double] + [_P] * 11,
+    "cl3d_pwmlp_bwd_hits_coeffs": [_P, _I, ctypes.c_double] + [_P] * 12 + [_I] * 4 + [_P, _P],
     "cl3d_pwmlp_bwd_support": [_P] * 10 + [_F, _P, _P] + [_I] * 5 + [_P, _P],
 }
 

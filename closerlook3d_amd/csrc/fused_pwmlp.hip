@@ -523,11 +523,9 @@ struct HitArgs {
   int B, N, M, Co, T;
 };
 
-__global__ __launch_bounds__(1024) void pwmlp_hit_kernel(HitArgs a) {
-  extern __shared__ double hacc[];  // [4][T]
+__device__ __forceinline__ void hit_block(const HitArgs &a, int b, double *hacc /* [4][T] */) {
   const int c0 = blockIdx.x * 4;
   const int n0 = blockIdx.y * a.T;
-  const int b = blockIdx.z;
   const int M = a.M, T = a.T;
   const int nch = a.Co - c0 < 4 ? a.Co - c0 : 4;
   const unsigned span = (unsigned)(a.N - n0 < T ? a.N - n0 : T);
@@ -567,6 +565,11 @@ __global__ __launch_bounds__(1024) void pwmlp_hit_kernel(HitArgs a) {
   for (int v = 0; v < nch; ++v)
     for (int i = threadIdx.x; i < (int)span; i += 1024)
       a.hit_cm[((size_t)b * a.Co + c0 + v) * a.N + n0 + i] = (float)hacc[(size_t)v * T + i];
+}
+
+__global__ __launch_bounds__(1024) void pwmlp_hit_kernel(HitArgs a) {
+  extern __shared__ double hacc[];  // [4][T]
+  hit_block(a, blockIdx.z, hacc);
 }
 
 // support-major backward pass through the CSR inverse of idx.  For support point i with slot list S_i:
@@ -1300,8 +1303,10 @@ struct FinArgs {
   float *o0, *o1, *o2, *o3, *o4, *o5;
 };
 
+// channel c by the 256 threads t = 0 .. 255 of one thread group; s_red [4][8] and s_tot [8] are the group's scratch.
+// `live` false: the group only keeps the barriers company (a channel index past the end in a multi-channel block).
 template <int MODE>
-__global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
+__device__ __forceinline__ void finalize_channel(const FinArgs &a, int c, int t, bool live, double (*s_red)[8], double *s_tot) {
   // thread t sums column k = t & 7 of the partial records g = t >> 3 (mod 32): a wave reads 8 whole 64-byte records
   // per load, kFinBatch loads are in flight per thread (the sums are a chain of memory round trips otherwise:
   // measured 16.5 us for 1024 records x 64 channels one at a time, 5.8-6 us eight at a time; 32 at a time -- the metric
@@ -1309,10 +1314,7 @@ __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
   // pulling 64 KB each in 64-byte pieces), and the 32 partial sums of a column are folded in a fixed order -- lanes by
   // shuffle, then the four waves.
   constexpr int kFinBatch = 8;
-  __shared__ double s_red[4][8];
-  __shared__ double s_tot[8];
-  const int c = blockIdx.x;
-  const int k = threadIdx.x & 7, gl = threadIdx.x >> 3;
+  const int k = t & 7, gl = t >> 3;
   double acc = 0.0;
   for (int g0 = 0; g0 < a.G; g0 += 32 * kFinBatch) {
     double v[kFinBatch];
@@ -1328,11 +1330,11 @@ __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
   acc += __shfl_xor(acc, 8, CL3D_WAVE);
   acc += __shfl_xor(acc, 16, CL3D_WAVE);
   acc += __shfl_xor(acc, 32, CL3D_WAVE);
-  if ((threadIdx.x & 63) < 8) s_red[threadIdx.x >> 6][k] = acc;
+  if ((t & 63) < 8) s_red[t >> 6][k] = acc;
   __syncthreads();
-  if (threadIdx.x < 8) s_tot[k] = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
+  if (t < 8) s_tot[k] = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  if (t != 0 || !live) return;
   if constexpr (MODE == FIN_STATS) {
     const double s0 = s_tot[0], s1 = s_tot[1];
     const double mean = s0 / a.count;
@@ -1369,6 +1371,33 @@ __global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
     for (int k = 0; k < 3; ++k)
       a.o5[c * 3 + k] = (float)(A * s_tot[2 + k] + Bc * a.sums[c * 6 + 3 + k] + D * a.sums[c * 6 + k]);
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void pwmlp_finalize_kernel(FinArgs a) {
+  __shared__ double s_red[4][8];
+  __shared__ double s_tot[8];
+  finalize_channel<MODE>(a, blockIdx.x, threadIdx.x, true, s_red, s_tot);
+}
+
+// The arg-max scatter and the BatchNorm-backward algebra in ONE launch: both only need what bwd_rows left, and as two
+// launches of the captured step they are 10.6 + 6.5 us one after the other (a fork costs more than either, DESIGN 3.2
+// "Round 5").  Slab z = 0 of the grid holds the algebra -- a 1024-thread block = four 256-thread groups = four channels,
+// dispatched first -- slabs z = 1 .. B the scatter blocks of cloud z - 1.  The scatter fills every CU with one block
+// (128 KB of LDS), so the Co / 4 algebra blocks delay as many scatter blocks by their ~4 us instead of the whole step by
+// a launch.
+__global__ __launch_bounds__(1024) void pwmlp_hit_coeffs_kernel(HitArgs h, FinArgs f) {
+  extern __shared__ double hacc[];  // [4][T]
+  if (blockIdx.z == 0) {
+    if (blockIdx.y != 0) return;
+    __shared__ double s_red[4][4][8];
+    __shared__ double s_tot[4][8];
+    const int g = threadIdx.x >> 8;
+    const int c = blockIdx.x * 4 + g;
+    finalize_channel<FIN_COEFFS>(f, c < f.Co ? c : f.Co - 1, threadIdx.x & 255, c < f.Co, s_red[g], s_tot[g]);
+    return;
+  }
+  hit_block(h, blockIdx.z - 1, hacc);
 }
 
 // {rel, centre index} per slot for callers of cl3d_pwmlp_fwd that ask for the records (element-wise; the engine's own
@@ -1693,6 +1722,33 @@ extern "C" int cl3d_pwmlp_bwd_hits(const float *dz_cm, const int32_t *ts_cm, int
   hipLaunchKernelGGL(pwmlp_hit_kernel, dim3(ceil_div(Co, 4), ntiles, B), dim3(1024), (size_t)4 * a.T * sizeof(double),
                      (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_bwd_hits");
+}
+
+extern "C" int cl3d_pwmlp_bwd_hits_coeffs(const double *partial, int n_partials, double count, const float *gamma,
+                                          const float *mean, const float *invstd, const double *sums, float *cA,
+                                          float *cB, float *cD, float *dgamma, float *dbeta, float *dwr,
+                                          const float *dz_cm, const int32_t *ts_cm, int B, int N, int M, int Co,
+                                          float *hit_cm, cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(B >= 1 && N >= 1 && M >= 1 && Co >= 1 && n_partials > 0 && count > 0, "pwmlp_bwd_hits_coeffs: bad sizes");
+  CL3D_REQUIRE(partial && gamma && mean && invstd && sums && cA && cB && cD && dgamma && dbeta && dwr && dz_cm && ts_cm && hit_cm,
+               "pwmlp_bwd_hits_coeffs: null pointer");
+  CL3D_REQUIRE(B <= 65534, "pwmlp_bwd_hits_coeffs: B exceeds grid.z limit");
+  static std::atomic<unsigned long long> granted{0};
+  int rc_lds = lds_opt_in(granted, reinterpret_cast<const void *>(pwmlp_hit_coeffs_kernel), 128 * 1024, "pwmlp_bwd_hits_coeffs");
+  if (rc_lds != CL3D_OK) return rc_lds;
+  HitArgs h{};
+  h.dz_cm = dz_cm; h.ts_cm = ts_cm; h.hit_cm = hit_cm; h.B = B; h.N = N; h.M = M; h.Co = Co;
+  h.T = N < 4096 ? N : 4096;  // 4 channels x T doubles = 128 KiB
+  const int ntiles = ceil_div(N, h.T);
+  CL3D_REQUIRE(ntiles <= 65535, "pwmlp_bwd_hits_coeffs: N too large");
+  FinArgs f{};
+  f.partial = partial; f.G = n_partials; f.Co = Co; f.count = count; f.gamma = gamma; f.mean_in = mean;
+  f.invstd_in = invstd; f.sums = const_cast<double *>(sums);
+  f.o0 = cA; f.o1 = cB; f.o2 = cD; f.o3 = dgamma; f.o4 = dbeta; f.o5 = dwr;
+  hipLaunchKernelGGL(pwmlp_hit_coeffs_kernel, dim3(ceil_div(Co, 4), ntiles, B + 1), dim3(1024),
+                     (size_t)4 * h.T * sizeof(double), (hipStream_t)stream, h, f);
+  return check_launch("cl3d_pwmlp_bwd_hits_coeffs");
 }
 
 extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const float *cA, const float *cB,

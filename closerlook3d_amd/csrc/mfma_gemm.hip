@@ -33,6 +33,7 @@
 // The PointWiseMLP weight [Co, 3+2C] = [W_r | W_c | W_d] is turned into wcat = [W_d ; W_c - W_d] and W_r by one small
 // launch ahead of the forward GEMM (pwmlp_weights_kernel); the weight-gradient reduce writes d W directly.
 #include "cl3d_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -52,6 +53,8 @@ struct GemmOperand {
   int vec;               // 16-byte loads along the contiguous axis are legal (alignment and extents)
   int fold;              // 0: none; 1: r = cloud * fold_n + point; 2: k = cloud * fold_n + point  (channel-major tensors)
   int fold_n;            // points per cloud
+  int fold_shift;        // log2(fold_n) when it is a power of two (every level of a grid-subsampled pyramid that halves
+                         // twice per stage), else -1: index -> (cloud, point) by shift instead of a division per access
   long long sb;          // cloud stride of a folded axis
   // prologue (nullable): element (r, k) enters the product as max(scale[c] * x + shift[c], 0) with c = k (pro_axis 0)
   // or c = r (pro_axis 1) -- the BatchNorm + ReLU that precedes this contraction in a bottleneck, applied while the
@@ -66,6 +69,7 @@ struct OutMap {
   float *D;
   long long si, sj;
   int fold_n;          // != 0: j = cloud * fold_n + point, cloud stride sb (channel-major output)
+  int fold_shift;      // log2(fold_n) or -1, as for the operands
   long long sb;
   // D = act(scale[i] * acc + shift[i] + res): BatchNorm folded to a per-row affine map, residual, ReLU
   const float *ep_scale, *ep_shift, *ep_res;
@@ -83,7 +87,7 @@ struct GemmArgs {
 
 __device__ __forceinline__ long long out_col(const OutMap &o, int j) {
   if (o.fold_n) {
-    const int b = j / o.fold_n;
+    const int b = o.fold_shift >= 0 ? j >> o.fold_shift : j / o.fold_n;
     return b * o.sb + (long long)(j - b * o.fold_n) * o.sj;
   }
   return (long long)j * o.sj;
@@ -99,11 +103,11 @@ __device__ __forceinline__ void out_store(const OutMap &o, int i, long long joff
 // element offset of (r, k) of an operand; the pointer base is wave-uniform, the offset a 32-bit lane value
 __device__ __forceinline__ unsigned gemm_off(const GemmOperand &s, int r, int k) {
   if (s.fold == 1) {
-    const int b = r / s.fold_n;
+    const int b = s.fold_shift >= 0 ? r >> s.fold_shift : r / s.fold_n;
     return (unsigned)(b * (int)s.sb + (r - b * s.fold_n) * s.sr + k * s.sk);
   }
   if (s.fold == 2) {
-    const int b = k / s.fold_n;
+    const int b = s.fold_shift >= 0 ? k >> s.fold_shift : k / s.fold_n;
     return (unsigned)(b * (int)s.sb + r * s.sr + (k - b * s.fold_n) * s.sk);
   }
   return (unsigned)(r * s.sr + k * s.sk);
@@ -1006,6 +1010,8 @@ __global__ __launch_bounds__(256) void pwmlp_point_grads_kernel(PointGradArgs a)
 
 static bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+static int log2_exact(int n) { return n > 0 && (n & (n - 1)) == 0 ? __builtin_ctz((unsigned)n) : -1; }
+
 // operand whose r and k are plain strided axes
 static GemmOperand plain(const float *p, long long sr, long long sk, int R, int K) {
   GemmOperand s{};
@@ -1021,6 +1027,7 @@ static GemmOperand plain(const float *p, long long sr, long long sk, int R, int 
 static GemmOperand channel_major(const float *p, int nb, int rows, int n, bool point_on_r) {
   GemmOperand s{};
   s.p = p; s.fold_n = n; s.sb = (long long)rows * n;
+  s.fold_shift = log2_exact(n);
   if (point_on_r) {
     s.sr = 1; s.sk = n; s.R = nb * n; s.rc = 1; s.fold = nb > 1 ? 1 : 0;
   } else {
@@ -1088,9 +1095,40 @@ struct Plan {
   int wi, wj, nsplit, cps;
 };
 
+// bf16: what a launch costs was measured over every tile and K split on the convolutions of the config-2 backbone
+// (scripts/micro/gemm_plan_sweep.py, 14 layers x 3 products x 4 tiles x 8-9 splits, launches replayed from a HIP graph;
+// profiles/r05/gemm_plan_sweep_bf16.jsonl) and does not follow the flop count at all -- these products are 1-3 GFLOP and
+// 7-75 MB, and a launch is a chain of memory round trips:
+//     T = T0 + RT + generations x ((chunks per workgroup - 1) x t_chunk + t_tail)  [+ the slice-sum launch]
+// T0 + RT ~ 7.5 us before the first chunk is in LDS; t_chunk = what one more 64-deep chunk costs a workgroup: its two
+// register sets cover one round trip between them (1.2 us for the 64 x 64 tile, 1.7 for 128 x 64, 0.65-2 for 128 x 128)
+// unless the workgroups resident on a CU together ask for more than the ~36 GB/s a CU draws (then chunk bytes x resident /
+// that rate); t_tail = the epilogue and the hand-over to the next workgroup on the CU; generations = workgroups / (256 CUs
+// x resident).  Least-squares fit of the logarithm: 9.7 % rms over the 1400 timings.  Plans chosen by the fit total 955 us
+// over the 42 products against 906 us for the best plan of each and 1204 us for the flop-count model this replaces (which
+// stays for f32, where it is within 5 % of the best: 1739 against 1649 us).
+static double bf16_launch_us(int I, int J, long long K, int wi, int wj, long long cps, long long real_split) {
+  const int t = (wi == 2 ? 1 : 0) + (wj == 2 ? 2 : 0);  // 64x64, 128x64, 64x128, 128x128
+  const double kChunk[4] = {1.171, 1.682, 1.644, 0.65}, kTail[4] = {5.662, 4.682, 3.924, 5.453};
+  const double kResident[4] = {4, 3, 3, 2};
+  const double T0 = 4.3, RT = 3.178, cu_kb_per_us = 35.636, red0 = 1.546, red_mb_per_us = 6.851;
+  const long long ti = ceil_div(I, 64 * wi), tj = ceil_div(J, 64 * wj);
+  const double wgs = (double)(ti * tj * real_split);
+  double conc = wgs / kCUs;
+  conc = conc < 1.0 ? 1.0 : (conc > kResident[t] ? kResident[t] : conc);
+  const double chunk_kb = (64.0 * wi + 64.0 * wj) * 64.0 * 4.0 / 1e3;
+  double t_chunk = conc * chunk_kb / cu_kb_per_us;
+  if (t_chunk < kChunk[t]) t_chunk = kChunk[t];
+  double gens = wgs / (kCUs * kResident[t]);
+  if (gens < 1.0) gens = 1.0;
+  double us = T0 + RT + gens * ((double)(cps - 1) * t_chunk + kTail[t]);
+  if (real_split > 1) us += red0 + (double)real_split * I * J * 4.0 * 2.0 / 1e6 / red_mb_per_us;
+  return us;
+}
+
 static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes, bool no_big_tile = false) {
   const int cand[4][3] = {{2, 2, 2}, {2, 1, 3}, {1, 2, 3}, {1, 1, 4}};  // wi, wj, resident workgroups per CU
-  const double peak_flops_per_us = precision == PREC_BF16 ? 1.2e9 : 157.3e6;  // bf16: what staging sustains, not 2.5 PF
+  const double peak_flops_per_us = 157.3e6;  // f32-input MFMA
   Plan best{2, 1, 1, (int)((K + gemm_kc(precision, 2, 1) - 1) / gemm_kc(precision, 2, 1))};
   double best_cost = 1e300;
   for (int c = 0; c < 4; ++c) {
@@ -1104,18 +1142,24 @@ static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, s
     const long long chunks = (K + kc - 1) / kc;
     const long long ti = ceil_div(I, 64 * wi), tj = ceil_div(J, 64 * wj), tiles = ti * tj;
     const double flops = 2.0 * (double)(ti * 64 * wi) * (double)(tj * 64 * wj) * (double)K;
-    for (long long split = 1; split <= max_split && split <= (chunks >= 4 ? chunks / 4 : 1); split += (split < 4 ? 1 : split / 2)) {
+    // f32 keeps >= 4 chunks per slice; bf16 slices go down to 2 (the fit above prices what that costs)
+    const long long min_cps = precision == PREC_BF16 ? 2 : 4;
+    for (long long split = 1; split <= max_split && split <= (chunks >= min_cps ? chunks / min_cps : 1); split += (split < 4 ? 1 : split / 2)) {
       if (split > 1 && (size_t)split * I * J * sizeof(float) > ws_bytes) break;
       const long long cps = (chunks + split - 1) / split;
       const long long real_split = (chunks + cps - 1) / cps;
-      double fill = (double)(tiles * real_split) / (double)(kCUs * resident);
-      if (fill > 1.0) fill = 1.0;
-      const double partial_us = real_split > 1 ? 3.0 + 2.0 * (double)real_split * I * J * 4.0 / 2.5e6 : 0.0;
-      // (round 5: a term for the operand bytes a tiling pulls through L2 -- tiles x K x (TI + TJ) x 4 B against 3-6 TB/s,
-      //  170 MB for the 1152 x 1152 x 1024 layer in 64 x 64 tiles -- pushed the plan towards 128 x 128 and made every shape
-      //  but two slower, the weight gradients by 2-3 x: config 2 6.67 -> 7.58 / 8.88 ms in bf16; gpurun_out/r05k.  The
-      //  tiling is not what holds this kernel back; its chunk pipeline is.  Dropped.)
-      const double cost = flops / peak_flops_per_us / fill + partial_us + 2.0;
+      double cost;
+      if (precision == PREC_BF16) {
+        cost = bf16_launch_us(I, J, K, wi, wj, cps, real_split);
+      } else {
+        double fill = (double)(tiles * real_split) / (double)(kCUs * resident);
+        if (fill > 1.0) fill = 1.0;
+        const double partial_us = real_split > 1 ? 3.0 + 2.0 * (double)real_split * I * J * 4.0 / 2.5e6 : 0.0;
+        // (round 5: a term for the operand bytes a tiling pulls through L2 -- tiles x K x (TI + TJ) x 4 B against 3-6 TB/s,
+        //  170 MB for the 1152 x 1152 x 1024 layer in 64 x 64 tiles -- pushed the plan towards 128 x 128 and made every shape
+        //  but two slower, the weight gradients by 2-3 x: config 2 6.67 -> 7.58 / 8.88 ms in bf16; gpurun_out/r05k.  Dropped.)
+        cost = flops / peak_flops_per_us / fill + partial_us + 2.0;
+      }
       if (cost < best_cost * 0.97) {
         best_cost = cost;
         best = Plan{wi, wj, (int)real_split, (int)cps};
@@ -1152,7 +1196,20 @@ static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t 
   const bool vec_pair = (am == STAGE_VEC_RC && bm == STAGE_VEC_KC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_RC) ||
                         (am == STAGE_VEC_RC && bm == STAGE_VEC_RC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_KC);
   const bool kc_pair_f32 = precision != PREC_BF16 && am == STAGE_VEC_KC && bm == STAGE_VEC_KC;
-  const Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, !vec_pair || kc_pair_f32);
+  Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, !vec_pair || kc_pair_f32);
+#ifdef CL3D_GEMM_PLAN_ENV  // variant builds of scripts/micro/gemm_plan_sweep.py only: CL3D_GEMM_FORCE="wi,wj,split"
+  if (const char *force = getenv("CL3D_GEMM_FORCE")) {
+    int fwi = 0, fwj = 0, fsplit = 0;
+    if (sscanf(force, "%d,%d,%d", &fwi, &fwj, &fsplit) == 3 && (fwi == 1 || fwi == 2) && (fwj == 1 || fwj == 2) && fsplit >= 1) {
+      const int kc = gemm_kc(precision, fwi, fwj);
+      const long long chunks = (a.K + kc - 1) / kc;
+      if (fsplit > chunks) fsplit = (int)chunks;
+      while (fsplit > 1 && (!ws || (size_t)fsplit * I * J * sizeof(float) > ws_bytes)) --fsplit;
+      const long long cps = (chunks + fsplit - 1) / fsplit;
+      p = Plan{fwi, fwj, (int)((chunks + cps - 1) / cps), (int)cps};
+    }
+  }
+#endif
   a.tiles_i = ceil_div(I, 64 * p.wi);
   a.tiles_j = ceil_div(J, 64 * p.wj);
   a.nsplit = p.nsplit;
@@ -1366,7 +1423,7 @@ extern "C" int cl3d_pwmlp_point_gemm_bwd_data(const float *dght, const float *wc
   GemmArgs a{};  // D[i = c][j = (cloud, point)] = sum_o wcat[o][c] dght[point][o]  ->  d features [B, C, N]
   a.A = plain(wcat, 1, C, C, 2 * Co);
   a.B = plain(dght, 2 * Co, 1, B * N, 2 * Co);
-  a.out.D = dfeatures; a.out.si = N; a.out.sj = 1; a.out.fold_n = B > 1 ? N : 0; a.out.sb = (long long)C * N;
+  a.out.D = dfeatures; a.out.si = N; a.out.sj = 1; a.out.fold_n = B > 1 ? N : 0; a.out.fold_shift = log2_exact(N); a.out.sb = (long long)C * N;
   a.K = 2 * Co;
   return run_gemm<0>(a, precision, kMaxSplitFwd, ws, ws_bytes, nullptr, 0, 0, (hipStream_t)stream,
                      "cl3d_pwmlp_point_gemm_bwd_data");
@@ -1438,7 +1495,7 @@ static int conv_forward(const float *x, const float *W, const float *scale, cons
   GemmArgs a{};  // D[i = o][j = (cloud, point)] = sum_c W[o][c] x[c][point]
   a.A = plain(W, C, 1, Co, C);
   a.B = channel_major(x, B, C, N, true);
-  a.out.D = y; a.out.si = N; a.out.sj = 1; a.out.fold_n = B > 1 ? N : 0; a.out.sb = (long long)Co * N;
+  a.out.D = y; a.out.si = N; a.out.sj = 1; a.out.fold_n = B > 1 ? N : 0; a.out.fold_shift = log2_exact(N); a.out.sb = (long long)Co * N;
   a.out.ep_scale = scale; a.out.ep_shift = shift; a.out.ep_res = residual; a.out.ep_relu = relu;
   a.K = C;
   return run_gemm<0>(a, precision, kMaxSplitFwd, ws, ws_bytes, nullptr, 0, 0, st, who);
@@ -1474,7 +1531,7 @@ extern "C" int cl3d_conv1x1_bwd_data(const float *dy, const float *W, int B, int
   GemmArgs a{};  // D[i = c][j = (cloud, point)] = sum_o W[o][c] dy[o][point]
   a.A = plain(W, 1, C, C, Co);
   a.B = channel_major(dy, B, Co, N, true);
-  a.out.D = dx; a.out.si = N; a.out.sj = 1; a.out.fold_n = B > 1 ? N : 0; a.out.sb = (long long)C * N;
+  a.out.D = dx; a.out.si = N; a.out.sj = 1; a.out.fold_n = B > 1 ? N : 0; a.out.fold_shift = log2_exact(N); a.out.sb = (long long)C * N;
   a.K = Co;
   return run_gemm<0>(a, precision, kMaxSplitFwd, ws, ws_bytes, nullptr, 0, 0, (hipStream_t)stream, "cl3d_conv1x1_bwd_data");
 }
@@ -1506,7 +1563,7 @@ extern "C" int cl3d_conv1x1_rows_fwd(const float *x_rows, const float *scale, co
   a.A = plain(W, C, 1, Co, C);
   a.B = plain(x_rows, C, 1, B * N, C);
   set_prologue(a.B, scale, shift, 0);
-  a.out.D = y; a.out.si = N; a.out.sj = 1; a.out.fold_n = B > 1 ? N : 0; a.out.sb = (long long)Co * N;
+  a.out.D = y; a.out.si = N; a.out.sj = 1; a.out.fold_n = B > 1 ? N : 0; a.out.fold_shift = log2_exact(N); a.out.sb = (long long)Co * N;
   a.K = C;
   return run_gemm<0>(a, precision, kMaxSplitFwd, ws, ws_bytes, nullptr, 0, 0, (hipStream_t)stream, "cl3d_conv1x1_rows_fwd");
 }

@@ -274,9 +274,8 @@ static int enqueue_backward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::Pass
   CL3D_TRY(cl3d_pwmlp_bwd_rows(p->gout, 1, p->ystar, p->kstar, p->idx, p->query_xyz, p->support_xyz, p->radius, scale, shift,
                                mean, invstd, p->B, p->N, p->M, p->K, Co, p->dz_cm, p->ts_cm, p->dz_t, p->qtab, p->partial_b,
                                p->n_partials, st));
-  CL3D_TRY(cl3d_pwmlp_bn_backward_coeffs(p->partial_b, p->n_partials, Co, (double)p->B * p->M * p->K, p->gamma, mean, invstd,
-                                         p->sums, cA, cB, cD, dgamma, dbeta, p->dwr, st));
-  CL3D_TRY(cl3d_pwmlp_bwd_hits(p->dz_cm, p->ts_cm, p->B, p->N, p->M, Co, p->hit, st));
+  CL3D_TRY(cl3d_pwmlp_bwd_hits_coeffs(p->partial_b, p->n_partials, (double)p->B * p->M * p->K, p->gamma, mean, invstd, p->sums,
+                                      cA, cB, cD, dgamma, dbeta, p->dwr, p->dz_cm, p->ts_cm, p->B, p->N, p->M, Co, p->hit, st));
   CL3D_TRY(cl3d_pwmlp_bwd_support(p->ght, p->wr, cA, cB, cD, p->hit, p->dz_t, p->sy, p->qtab, p->support_xyz, p->radius,
                                   p->inv_off, p->inv_slots, p->B, p->N, p->M, p->K, Co, p->dght, st));
   // ---- the two gradient products: ONE kernel over d ght where it covers the shape; otherwise side by side, the longer one (weights: product + slice reduce, ~45 us) on the caller's

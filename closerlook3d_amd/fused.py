@@ -664,18 +664,12 @@ class _PointwiseMLP(Function):
             cA, cB, cD, dgamma, dbeta = coef[0], coef[1], coef[2], coef[3], coef[4]
             dwr = torch.empty((Co, 3), dtype=torch.float32, device=dev)
 
-            def hits():  # the arg-max scatter ...
-                _lib.check(lib.cl3d_pwmlp_bwd_hits(_p(dz_cm), _p(ts_cm), B, N, M, Co, _p(hit), _stream(gout)))
-
-            def coeffs():  # ... beside the per-channel algebra: both only need what bwd_rows left
-                _lib.check(lib.cl3d_pwmlp_bn_backward_coeffs(_p(partial), nparts, Co, float(n), _p(gamma), _p(vec[2]),
-                                                             _p(vec[3]), _p(sums), _p(cA), _p(cB), _p(cD), _p(dgamma),
-                                                             _p(dbeta), _p(dwr), _stream(gout)))
-
-            # one after the other: a fork/join across HIP streams costs more idle time in a captured graph (measured
-            # ~29 us before the next kernel starts) than these two short launches take together (~15 us)
-            coeffs()
-            hits()
+            # the arg-max scatter and the per-channel algebra -- both only need what bwd_rows left -- in one launch (as
+            # two launches they are 10.6 + 6.5 us one after the other; a fork/join across HIP streams costs more idle time
+            # in a captured graph than either takes)
+            _lib.check(lib.cl3d_pwmlp_bwd_hits_coeffs(_p(partial), nparts, float(n), _p(gamma), _p(vec[2]), _p(vec[3]), _p(sums),
+                                                      _p(cA), _p(cB), _p(cD), _p(dgamma), _p(dbeta), _p(dwr), _p(dz_cm),
+                                                      _p(ts_cm), B, N, M, Co, _p(hit), st))
             dght = torch.empty((B, N, 2 * Co), dtype=torch.float32, device=dev)
             off, slots = inverse_index(idx, N)  # (waits for the build the forward pass forked, if it is still pending)
             _lib.check(lib.cl3d_pwmlp_bwd_support(_p(ght), _p(wr), _p(cA), _p(cB), _p(cD), _p(hit), _p(dz_t), _p(sy),

@@ -398,6 +398,13 @@ int cl3d_pwmlp_bn_backward_coeffs(const double *partial, int n_partials, int Co,
                                   const float *gamma, const float *mean, const float *invstd,
                                   const double *sums, float *cA, float *cB, float *cD, float *dgamma,
                                   float *dbeta, float *dwr, cl3d_stream_t stream);
+/* cl3d_pwmlp_bn_backward_coeffs and cl3d_pwmlp_bwd_hits in ONE launch (both only need what cl3d_pwmlp_bwd_rows left;
+ * same arguments, same results bit for bit): what the training backward pass calls.  B >= 1. */
+int cl3d_pwmlp_bwd_hits_coeffs(const double *partial, int n_partials, double count, const float *gamma,
+                               const float *mean, const float *invstd, const double *sums, float *cA, float *cB,
+                               float *cD, float *dgamma, float *dbeta, float *dwr, const float *dz_cm,
+                               const int32_t *ts_cm, int B, int N, int M, int Co, float *hit_cm,
+                               cl3d_stream_t stream);
 /* d ght [B,N,2Co] through the CSR inverse of idx (cl3d_build_inverse_index); dz_t, qtab: left by cl3d_pwmlp_bwd_rows of
  * the same step.  Per entry of a support point's slot list one lane looks up the slot's query record in qtab (its
  * coordinates -> the relative position; its centre idx[j, 0], reference local_aggregation_operators.py:290 -> whose H row

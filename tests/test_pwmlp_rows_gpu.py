@@ -101,3 +101,45 @@ def test_backward_rows_pass(B, N, M, K, Co):
     got = partial.sum(0)[:, :5]
     tol = 1e-12 * float(B * M) + 1e-9
     assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("B,N,M,K,Co", [(2, 256, 256, 32, 64), (3, 512, 128, 16, 128), (2, 300, 200, 20, 70), (16, 4096, 4096, 32, 64)])
+def test_hits_and_coefficients_in_one_launch_equal_the_two_launches(B, N, M, K, Co):
+    """cl3d_pwmlp_bwd_hits_coeffs == cl3d_pwmlp_bn_backward_coeffs + cl3d_pwmlp_bwd_hits, bit for bit (the same device code
+    per block, only the launch differs), incl. a channel count that is not a multiple of the four channels of a block."""
+    from closerlook3d_amd import _lib
+    lib = _lib.lib()
+    g = torch.Generator(device="cuda").manual_seed(B + N + Co)
+    rnd = lambda *s: torch.randn(*s, device="cuda", generator=g)
+    n_partials = lib.cl3d_pwmlp_partials(B, M, Co)
+    partial = rnd(n_partials, Co, 8).double()
+    gamma, mean, invstd = rnd(Co), rnd(Co) * 0.2, torch.rand(Co, device="cuda", generator=g) + 0.5
+    sums = rnd(Co, 6).double()
+    dz_cm = rnd(B, Co, M) * (torch.rand(B, Co, M, device="cuda", generator=g) > 0.3)
+    ts_cm = torch.randint(0, N, (B, Co, M), device="cuda", generator=g, dtype=torch.int32)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    count = float(B * M * K)
+    out = []
+    for merged in (False, True):
+        coef = torch.full((5, Co), float("nan"), device="cuda")
+        dwr = torch.full((Co, 3), float("nan"), device="cuda")
+        hit = torch.full((B, Co, N), float("nan"), device="cuda")
+        with _lib.on_device(hit.device):
+            if merged:
+                _lib.check(lib.cl3d_pwmlp_bwd_hits_coeffs(_p(partial), n_partials, count, _p(gamma), _p(mean), _p(invstd), _p(sums),
+                                                          _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]), _p(coef[4]), _p(dwr),
+                                                          _p(dz_cm), _p(ts_cm), B, N, M, Co, _p(hit), st))
+            else:
+                _lib.check(lib.cl3d_pwmlp_bn_backward_coeffs(_p(partial), n_partials, Co, count, _p(gamma), _p(mean), _p(invstd),
+                                                             _p(sums), _p(coef[0]), _p(coef[1]), _p(coef[2]), _p(coef[3]),
+                                                             _p(coef[4]), _p(dwr), st))
+                _lib.check(lib.cl3d_pwmlp_bwd_hits(_p(dz_cm), _p(ts_cm), B, N, M, Co, _p(hit), st))
+        torch.cuda.synchronize()
+        out.append((coef, dwr, hit))
+    for a, b in zip(*out):
+        assert not torch.isnan(b).any()
+        assert torch.equal(a, b)
+    # and the scatter itself against index_add in double
+    want = torch.zeros(B, Co, N, dtype=torch.float64, device="cuda")
+    want.scatter_add_(2, ts_cm.long(), dz_cm.double())
+    assert torch.allclose(out[1][2].double(), want, rtol=1e-6, atol=1e-6)
