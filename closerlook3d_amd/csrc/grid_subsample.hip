@@ -59,6 +59,7 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
   extern __shared__ unsigned long long lds_keys[];  // [P] (in-LDS path only)
   __shared__ float s_red[6][kSubThreads / 64];
   __shared__ int s_scan[kSubThreads / 64];
+  __shared__ int s_scan2[8];
   __shared__ int s_tmp;
   __shared__ int s_T[512];
   __shared__ int s_E[256];
@@ -203,43 +204,56 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
   // nv == 0: the reference reads its zero-filled scratch and ends up with one cell {point 0}
   const int end = nv > 0 ? total : 1;
 
-  // ---- 4. shuffle position tables
-  if (tid == 0) {
-    int k0 = nv > 0 ? key_cell(key_at(0)) % 256 : 0;
-    s_T[0] = k0;
-    for (int i = 1; i < 512; ++i) {
-      k0 = (17 * k0 + 139) % 256;
-      s_T[i] = k0;
-    }
+  // ---- 4. shuffle position tables.  (Round 5: every table in parallel.  Thread 0 alone used to iterate the generator
+  // 512 times and then run the 511-step prefix sum as a chain of dependent LDS round trips -- ~50 us of the kernel's
+  // 52-72 us whatever N; the values are the same integers.)
+  if (tid < 512) {  // T[i]: the generator applied i times to k0, by the thread that owns entry i
+    int k = nv > 0 ? key_cell(key_at(0)) % 256 : 0;
+    for (int i = 0; i < tid; ++i) k = (17 * k + 139) % 256;
+    s_T[tid] = k;
   }
   __syncthreads();
   const int nA = end < 256 ? end : 256;
   if (tid < 256) {
     int e = 0;
     const int v = s_T[tid];
-    for (int i = 0; i < tid; ++i) e += (s_T[i] == v) ? 1 : 0;
+#pragma unroll 8
+    for (int i = 0; i < 256; ++i) e += (i < tid && s_T[i] == v) ? 1 : 0;  // same address across the wave: LDS broadcasts
     s_E[tid] = e;
     s_invB[s_T[256 + tid]] = tid;  // T[256..511] is a permutation of 0..255
   }
   if (tid < 511) {
     const int v = tid - 255;
     int c = 0;
-    for (int i = 0; i < nA; ++i) c += (s_T[i] == v) ? 1 : 0;
+#pragma unroll 8
+    for (int i = 0; i < 256; ++i) c += (i < nA && s_T[i] == v) ? 1 : 0;
     s_cntA[tid] = c;
   }
   __syncthreads();
-  if (tid == 0) {
-    int acc = 0;
-    const int nB = end - 256;  // number of cells with i >= 256 (may be <= 0)
-    for (int vi = 0; vi < 511; ++vi) {
-      s_base[vi] = acc;
-      const int v = vi - 255;
+  {  // base[vi] = exclusive prefix sum of (cells with key v among the first 256) + (among the rest), v = vi - 255
+    int term = 0;
+    if (tid < 511) {
+      const int nB = end - 256;  // number of cells with i >= 256 (may be <= 0)
+      const int v = tid - 255;
       int cB = 0;
       if (v >= 0 && nB > 0) {
         const int r = s_invB[v];
         if (nB > r) cB = ((nB - 1 - r) >> 8) + 1;
       }
-      acc += s_cntA[vi] + cB;
+      term = s_cntA[tid] + cB;
+    }
+    int inc = term;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += v;
+    }
+    if (lane == 63 && wave < 8) s_scan2[wave] = inc;
+    __syncthreads();
+    if (tid < 512) {
+      int before = 0;
+      for (int w = 0; w < wave; ++w) before += s_scan2[w];
+      s_base[tid] = before + inc - term;
     }
   }
   __syncthreads();
