@@ -1773,6 +1773,9 @@ extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const f
     return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support: N*Co too large for 31-bit row offsets");
   if (B == 0) return CL3D_OK;
   const int V = (Co % 4 == 0) ? 4 : 1;
+  // (round 5: a map chosen for the per-ENTRY chain instead of for busy channel lanes -- e.g. 32 lanes per point for Co = 72,
+  //  one round per 32-entry list and one channel chunk instead of 9 lanes, four rounds, two chunks -- measured slower on the
+  //  config-2 backbone: 59.5 against 56.6 us per launch on average)
   const LaneMap m = pick_lane_map(Co, V);
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);

@@ -19,10 +19,15 @@
 //      instead of sorting; each barycentre is written straight to its final slot;
 //   5. wrap-around padding with mask 0 (:146-151).
 #include <cstring>
+#include <type_traits>
 
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include "ball_query.h"
+
+#ifndef CL3D_SUB_PHASE
+#define CL3D_SUB_PHASE 0   // timing builds only: the kernel returns after phase n (scripts/micro/kernel_variants.py)
+#endif
 
 namespace cl3d {
 
@@ -51,12 +56,77 @@ struct SubParams {
   int pad[3];
 };
 
+// Bitonic network over P = R x 1024 keys (R = 1: P <= 1024 keys on the first P threads), thread t holding elements
+// t R .. t R + R - 1 in REGISTERS.  A compare-exchange at distance j stays inside the thread for j < R, goes through a wave
+// shuffle for j < 64 R, and only the 10 (P = 4096) cross-wave stages of the 78 go through LDS and barriers.  Against the
+// all-in-LDS network (two 64-bit reads, two conditional writes and a barrier per stage: 38.5 us at N = 4096) this one takes
+// 30 us -- by early-exit builds (scripts/micro/grid_subsample_phases.py) ~11 us in the 45 shuffle stages, ~4 in the 23
+// in-register ones and the rest in the 20 barriers of 16 waves; not the 8 us the instruction count suggests.  Element e keeps the smaller key of the pair (e, e ^ j) iff ((e & j) == 0) == ((e & k) == 0).  Keys are unique,
+// so every correct network yields the same array.  Sorted keys are left in lds[0 .. P).
+template <int R>
+__device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[R], int P, unsigned long long *lds, int tid) {
+  const int e0 = tid * R;
+  for (int k = 2; k <= P; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j < R) {
+#pragma unroll
+        for (int J = R >> 1; J >= 1; J >>= 1) {
+          if (j != J) continue;
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            if (r & J) continue;
+            const bool up = ((e0 + r) & k) == 0;
+            const unsigned long long a = key[r], c = key[r | J];
+            if ((a > c) == up) {
+              key[r] = c;
+              key[r | J] = a;
+            }
+          }
+        }
+      } else if (j < 64 * R) {
+        const int d = j / R;  // partner lane = lane ^ d, same r
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const unsigned long long other = __shfl_xor(key[r], d, 64);
+          const int e = e0 + r;
+          const bool keep_min = ((e & j) == 0) == ((e & k) == 0);
+          const bool other_smaller = other < key[r];
+          if (keep_min == other_smaller) key[r] = other;
+        }
+      } else {
+        __syncthreads();  // the previous cross-wave stage's readers are done
+        if (e0 < P) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) lds[e0 + r] = key[r];
+        }
+        __syncthreads();
+        if (e0 < P) {
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const int e = e0 + r;
+            const unsigned long long other = lds[e ^ j];
+            const bool keep_min = ((e & j) == 0) == ((e & k) == 0);
+            const bool other_smaller = other < key[r];
+            if (keep_min == other_smaller) key[r] = other;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (e0 < P) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) lds[e0 + r] = key[r];
+  }
+  __syncthreads();
+}
+
 template <bool PRESORTED, bool KEYS_ONLY>
 __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
     const float *__restrict__ xyz, const int *__restrict__ mask, int N, int m, float dl, int P,
     float *__restrict__ sub_xyz, int *__restrict__ sub_mask, unsigned long long *__restrict__ gkeys,
-    SubParams *__restrict__ params) {
-  extern __shared__ unsigned long long lds_keys[];  // [P] (in-LDS path only)
+    SubParams *__restrict__ params, int stage_xyz) {
+  extern __shared__ unsigned long long lds_keys[];  // [P] (in-LDS path only), then the cloud's coordinates [3N] when staged
   __shared__ float s_red[6][kSubThreads / 64];
   __shared__ int s_scan[kSubThreads / 64];
   __shared__ int s_scan2[8];
@@ -76,6 +146,11 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
   float *o = sub_xyz + (size_t)b * m * 3;
   int *om = sub_mask + (size_t)b * m;
 
+  // stage_xyz (in-LDS path, the keys and 12 N bytes fit): the cloud's coordinates are copied to LDS by the bounding-box
+  // sweep; the cell ids and, above all, the per-cell folds -- a chain of dependent loads per cell -- read them there
+  float *s_xyz = reinterpret_cast<float *>(lds_keys + P);
+  const bool staged = !PRESORTED && !KEYS_ONLY && stage_xyz != 0;
+  auto coord = [&](int i, int a) -> float { return staged ? s_xyz[i * 3 + a] : p[i * 3 + a]; };
   const unsigned long long *skeys = PRESORTED ? gkeys + (size_t)b * N : lds_keys;
   auto key_at = [&](int pos) -> unsigned long long {
     if constexpr (PRESORTED) {  // strip the cloud byte, bring {cell, index} back to the 32|32 layout
@@ -102,6 +177,7 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
       const float v = p[i * 3 + a];
+      if (staged) s_xyz[i * 3 + a] = v;
       if (v > mx[a]) mx[a] = v;
       if (v < mn[a]) mn[a] = v;
     }
@@ -131,6 +207,7 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
       if (vmx > mx[a]) mx[a] = vmx;
     }
   }
+  if (CL3D_SUB_PHASE == 1) return;
   const float inv = 1.0f / dl;
   const float ox = floorf(mn[0] * inv) * dl;
   const float oy = floorf(mn[1] * inv) * dl;
@@ -139,43 +216,50 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
   const int NY = (int)floorf((mx[1] - oy) / dl) + 1;
 
   // ---- 2. keys + bitonic sort
-  for (int i = tid; i < P; i += kSubThreads) {
+  auto make_key = [&](int i) -> unsigned long long {
     unsigned long long key = ~0ull;
     if (i < nv) {
-      const int iX = (int)floorf((p[i * 3 + 0] - ox) / dl);
-      const int iY = (int)floorf((p[i * 3 + 1] - oy) / dl);
-      const int iZ = (int)floorf((p[i * 3 + 2] - oz) / dl);
+      const int iX = (int)floorf((coord(i, 0) - ox) / dl);
+      const int iY = (int)floorf((coord(i, 1) - oy) / dl);
+      const int iZ = (int)floorf((coord(i, 2) - oz) / dl);
       const int cell = iX + NX * iY + NX * NY * iZ;
       key = ((unsigned long long)(((unsigned)cell) ^ 0x80000000u) << 32) | (unsigned)i;
     }
-    if constexpr (KEYS_ONLY) {
-      if (i < N) gkeys[(size_t)b * N + i] = big_key(b, (int)(((unsigned)(key >> 32)) ^ 0x80000000u), i, i < nv);
-    } else {
-      lds_keys[i] = key;
-    }
-  }
+    return key;
+  };
   if constexpr (KEYS_ONLY) {
+    for (int i = tid; i < P; i += kSubThreads) {
+      const unsigned long long key = make_key(i);
+      if (i < N) gkeys[(size_t)b * N + i] = big_key(b, (int)(((unsigned)(key >> 32)) ^ 0x80000000u), i, i < nv);
+    }
     if (tid == 0) params[b].nv = nv;
     return;
-  }
-  __syncthreads();
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (P >> 1); t += kSubThreads) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int l = i | j;
-        const unsigned long long a = lds_keys[i], c = lds_keys[l];
-        const bool up = (i & k) == 0;
-        if ((a > c) == up) {
-          lds_keys[i] = c;
-          lds_keys[l] = a;
-        }
+  } else {
+    auto sort_with = [&](auto rtag) {
+      constexpr int R = decltype(rtag)::value;
+      unsigned long long key[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) key[r] = tid * R + r < P ? make_key(tid * R + r) : ~0ull;
+      if (CL3D_SUB_PHASE != 6) {
+        bitonic_sort_regs<R>(key, P, lds_keys, tid);
+      } else {  // (timing build 6: keys made, not sorted)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (tid * R + r < P) lds_keys[tid * R + r] = key[r];
+        __syncthreads();
       }
-      __syncthreads();
+    };
+    switch (P / kSubThreads) {  // keys per thread (P is a power of two, <= kSubMaxN = 16 x 1024)
+      case 0: case 1: sort_with(std::integral_constant<int, 1>{}); break;
+      case 2: sort_with(std::integral_constant<int, 2>{}); break;
+      case 4: sort_with(std::integral_constant<int, 4>{}); break;
+      case 8: sort_with(std::integral_constant<int, 8>{}); break;
+      default: sort_with(std::integral_constant<int, 16>{}); break;
     }
   }
 
   }  // !PRESORTED
+  if (CL3D_SUB_PHASE == 2 || CL3D_SUB_PHASE >= 6) return;
 
   // ---- 3. heads: contiguous run per thread, block scan of head counts
   const int run = (P + kSubThreads - 1) / kSubThreads;
@@ -204,30 +288,62 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
   // nv == 0: the reference reads its zero-filled scratch and ends up with one cell {point 0}
   const int end = nv > 0 ? total : 1;
 
+  if (CL3D_SUB_PHASE == 3) return;
   // ---- 4. shuffle position tables.  (Round 5: every table in parallel.  Thread 0 alone used to iterate the generator
   // 512 times and then run the 511-step prefix sum as a chain of dependent LDS round trips -- ~50 us of the kernel's
   // 52-72 us whatever N; the values are the same integers.)
-  if (tid < 512) {  // T[i]: the generator applied i times to k0, by the thread that owns entry i
-    int k = nv > 0 ? key_cell(key_at(0)) % 256 : 0;
-    for (int i = 0; i < tid; ++i) k = (17 * k + 139) % 256;
-    s_T[tid] = k;
-  }
-  __syncthreads();
+  // T[i]: the generator k -> (17 k + 139) % 256 applied i times to k0.  From a non-negative k0 -- every cell id below
+  // 2^31 -- values stay non-negative, `%` is `& 255`, and the generator has FULL period (c odd, a - 1 a multiple of 4):
+  // T[0..255] is a permutation of 0..255 and T[256 + r] = T[r].  So no key repeats among the first 256 (E = 0), value v
+  // is counted there iff its position is below nA, and the inverse of the second block is the position table itself.
+  const int k0 = nv > 0 ? key_cell(key_at(0)) % 256 : 0;
   const int nA = end < 256 ? end : 256;
-  if (tid < 256) {
-    int e = 0;
-    const int v = s_T[tid];
-#pragma unroll 8
-    for (int i = 0; i < 256; ++i) e += (i < tid && s_T[i] == v) ? 1 : 0;  // same address across the wave: LDS broadcasts
-    s_E[tid] = e;
-    s_invB[s_T[256 + tid]] = tid;  // T[256..511] is a permutation of 0..255
-  }
-  if (tid < 511) {
-    const int v = tid - 255;
-    int c = 0;
-#pragma unroll 8
-    for (int i = 0; i < 256; ++i) c += (i < nA && s_T[i] == v) ? 1 : 0;
-    s_cntA[tid] = c;
+  if (k0 >= 0) {
+    if (tid < 512) {
+      // i applications of an affine map are ONE affine map (a_i, c_i), composed from the powers of two in i
+      unsigned A = 1u, C = 0u, a = 17u, c = 139u;
+      for (int bit = tid; bit != 0; bit >>= 1) {
+        if (bit & 1) {
+          A = (a * A) & 255u;
+          C = (a * C + c) & 255u;
+        }
+        c = (a * c + c) & 255u;
+        a = (a * a) & 255u;
+      }
+      const int k = (int)((A * (unsigned)k0 + C) & 255u);
+      s_T[tid] = k;
+      if (tid < 256) {
+        s_E[tid] = 0;
+        s_invB[k] = tid;  // position of value k in either block
+      }
+    }
+    __syncthreads();
+    if (tid < 511) {
+      const int v = tid - 255;
+      s_cntA[tid] = (v >= 0 && s_invB[v] < nA) ? 1 : 0;
+    }
+  } else {
+    // a negative first key (a cell id past 2^31 wrapped): C++'s signed remainder step by step, as the reference does it,
+    // and the general counting loops
+    if (tid < 512) {
+      int k = k0;
+      for (int i = 0; i < tid; ++i) k = (17 * k + 139) % 256;
+      s_T[tid] = k;
+    }
+    __syncthreads();
+    if (tid < 256) {
+      int e = 0;
+      const int v = s_T[tid];
+      for (int i = 0; i < tid; ++i) e += (s_T[i] == v) ? 1 : 0;
+      s_E[tid] = e;
+      s_invB[s_T[256 + tid]] = tid;  // T[256..511] is a permutation of 0..255
+    }
+    if (tid < 511) {
+      const int v = tid - 255;
+      int c = 0;
+      for (int i = 0; i < nA; ++i) c += (s_T[i] == v) ? 1 : 0;
+      s_cntA[tid] = c;
+    }
   }
   __syncthreads();
   {  // base[vi] = exclusive prefix sum of (cells with key v among the first 256) + (among the rest), v = vi - 255
@@ -258,6 +374,7 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
   }
   __syncthreads();
 
+  if (CL3D_SUB_PHASE == 4) return;
   auto position = [&](int i) -> int {
     if (i < 256) return s_base[s_T[i] + 255] + s_E[i];
     const int r = (i - 256) & 255;
@@ -278,15 +395,15 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
       const int cell = key_cell(key_at(pos));
       if (!(pos == 0 || cell != key_cell(key_at(pos - 1)))) continue;
       int j = key_orig(key_at(pos));
-      float xs = p[j * 3 + 0], ys = p[j * 3 + 1], zs = p[j * 3 + 2];
+      float xs = coord(j, 0), ys = coord(j, 1), zs = coord(j, 2);
       float pnum = 1.0f;
       for (int pp = pos + 1; pp < nv; ++pp) {
         const unsigned long long kk = key_at(pp);
         if (key_cell(kk) != cell) break;
         j = key_orig(kk);
-        xs += p[j * 3 + 0];
-        ys += p[j * 3 + 1];
-        zs += p[j * 3 + 2];
+        xs += coord(j, 0);
+        ys += coord(j, 1);
+        zs += coord(j, 2);
         pnum += 1.0f;
       }
       const int dst = position(top);
@@ -301,6 +418,7 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
   }
   __syncthreads();
 
+  if (CL3D_SUB_PHASE == 5) return;
   // ---- 5. wrap-around padding
   for (int i = end + tid; i < m; i += kSubThreads) {
     const int src = i % end;
@@ -347,22 +465,24 @@ extern "C" int cl3d_masked_grid_subsampling(const float *xyz, const int32_t *mas
     p += (n * 8 + 255) & ~(size_t)255;
     size_t temp_bytes = ws_bytes - (size_t)(p - static_cast<char *>(ws));
     hipLaunchKernelGGL((cl3d::grid_subsample_kernel<false, true>), dim3(B), dim3(cl3d::kSubThreads), 0, st, xyz, mask, N,
-                       m, sampleDl, N, sub_xyz, sub_mask, keys_in, params);
+                       m, sampleDl, N, sub_xyz, sub_mask, keys_in, params, 0);
     hipError_t e = rocprim::radix_sort_keys(p, temp_bytes, (const unsigned long long *)keys_in, keys_out, (unsigned)n,
                                             0, 64, st);
     if (e != hipSuccess) return cl3d::fail(CL3D_E_LAUNCH, "grid_subsampling: radix sort: %s", hipGetErrorString(e));
     hipLaunchKernelGGL((cl3d::grid_subsample_kernel<true, false>), dim3(B), dim3(cl3d::kSubThreads), 0, st, xyz, mask, N,
-                       m, sampleDl, N, sub_xyz, sub_mask, keys_out, params);
+                       m, sampleDl, N, sub_xyz, sub_mask, keys_out, params, 0);
     return cl3d::check_launch("cl3d_masked_grid_subsampling(large)");
   }
   int P = 2;
   while (P < N) P <<= 1;
-  const size_t lds = (size_t)P * sizeof(unsigned long long);
+  size_t lds = (size_t)P * sizeof(unsigned long long);
+  const int stage_xyz = lds + (size_t)N * 12 <= 120 * 1024 ? 1 : 0;  // + ~8 KB of static tables: within the CU's 160 KB
+  if (stage_xyz) lds += (size_t)N * 12;
   static std::atomic<unsigned long long> sort_granted{0};
   int rc_lds = cl3d::lds_opt_in(sort_granted, reinterpret_cast<const void *>(cl3d::grid_subsample_kernel<false, false>),
                                 128 * 1024, "grid_subsampling");
   if (rc_lds != CL3D_OK) return rc_lds;
   hipLaunchKernelGGL((cl3d::grid_subsample_kernel<false, false>), dim3(B), dim3(cl3d::kSubThreads), lds, st, xyz, mask, N,
-                     m, sampleDl, P, sub_xyz, sub_mask, (unsigned long long *)nullptr, (cl3d::SubParams *)nullptr);
+                     m, sampleDl, P, sub_xyz, sub_mask, (unsigned long long *)nullptr, (cl3d::SubParams *)nullptr, stage_xyz);
   return cl3d::check_launch("cl3d_masked_grid_subsampling");
 }
