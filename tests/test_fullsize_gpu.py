@@ -87,7 +87,8 @@ def test_group_round_trip_full_shape(clouds):
     # <gather(f), a> == <f, scatter(a)>  (adjointness), in double
     lhs2 = (g.double() * a.double()).sum()
     rhs2 = (f.double() * _ext.group_points_grad(a, idx, N).double()).sum()
-    assert abs(lhs2 - rhs2) / abs(lhs2) < 1e-6
+    # (relative to the size of the terms: the sum itself can land near zero for an unlucky draw)
+    assert abs(lhs2 - rhs2) / (g.double() * a.double()).abs().sum() < 1e-7
 
 
 @pytest.mark.parametrize("kind,over,C", [

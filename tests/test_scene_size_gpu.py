@@ -94,7 +94,10 @@ def test_gather_scatter_and_inverse_index_at_scene_size(name):
     a = torch.randn(B, C, N, K, device="cuda")
     back = _ext.group_points_grad(a, idx, N)
     lhs, rhs = (g.double() * a.double()).sum(), (f.double() * back.double()).sum()
-    assert abs(lhs - rhs) / abs(lhs) < 1e-6, "gather and scatter-add are not adjoint"
+    # relative to the size of the terms, not of their sum: the two sides are sums of products of normal deviates, and the
+    # sum itself can come out near zero for an unlucky draw (seen once: the inputs follow torch's global generator)
+    scale = (g.double() * a.double()).abs().sum()
+    assert abs(lhs - rhs) / scale < 1e-7, "gather and scatter-add are not adjoint"
     ones = _ext.group_points_grad(torch.ones(B, 1, N, K, device="cuda"), idx, N)[:, 0]
     want = torch.stack([torch.bincount(idx[b].flatten().long(), minlength=N) for b in range(B)]).float()
     assert torch.equal(ones, want)
