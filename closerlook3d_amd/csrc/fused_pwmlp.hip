@@ -572,6 +572,44 @@ __global__ __launch_bounds__(1024) void pwmlp_hit_kernel(HitArgs a) {
   hit_block(a, blockIdx.z, hacc);
 }
 
+// Few queries per cloud (the deep stages: M = 16 .. 1024 queries, hundreds of channels).  hit_block gives a block four
+// channel rows and walks them 4096 queries at a time: at M = 16 four of its 1024 threads have work, and the 4608 blocks of a
+// 1152-channel layer take 20 us for 1.2 MB.  Here a block owns CHB = 4096 / M channel rows -- thread t the four queries
+// 4 (t % (M/4)) .. of row t / (M/4): one 16-byte load per thread and array -- of ONE cloud whose N <= 16384 / CHB support
+// points all fit the block's LDS accumulators.  Same sums (doubles of a few dozen floats: exact, order-free).
+__global__ __launch_bounds__(1024) void pwmlp_hit_wide_kernel(HitArgs a, int CHB) {
+  extern __shared__ double hacc[];  // [CHB][N]
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.x * CHB;
+  const int M = a.M, N = a.N, q = M >> 2;
+  const int nch = a.Co - c0 < CHB ? a.Co - c0 : CHB;
+  for (int t = threadIdx.x; t < nch * N; t += 1024) hacc[t] = 0.0;
+  __syncthreads();
+  const int v = threadIdx.x / q, j = 4 * (threadIdx.x - v * q);
+  if (v < nch) {
+    const size_t o = ((size_t)b * a.Co + c0 + v) * M + j;
+    const float4 d = *reinterpret_cast<const float4 *>(a.dz_cm + o);
+    const int4 t = *reinterpret_cast<const int4 *>(a.ts_cm + o);
+    double *hv = hacc + (size_t)v * N;
+    if (d.x != 0.f && (unsigned)t.x < (unsigned)N) atomicAdd(&hv[t.x], (double)d.x);
+    if (d.y != 0.f && (unsigned)t.y < (unsigned)N) atomicAdd(&hv[t.y], (double)d.y);
+    if (d.z != 0.f && (unsigned)t.z < (unsigned)N) atomicAdd(&hv[t.z], (double)d.z);
+    if (d.w != 0.f && (unsigned)t.w < (unsigned)N) atomicAdd(&hv[t.w], (double)d.w);
+  }
+  __syncthreads();
+  float *out = a.hit_cm + ((size_t)b * a.Co + c0) * N;  // the block's rows are consecutive: one contiguous run
+  for (int e = threadIdx.x; e < nch * N; e += 1024) out[e] = (float)hacc[e];
+}
+
+// channel rows per block of the wide form, 0 where it does not apply (M a power of two in 4 .. 1024 so that the threads
+// tile CHB rows exactly; at least 8 rows -- below that hit_block's four rows per block do as well)
+static int hit_wide_rows(int N, int M) {
+  if (M < 4 || M > 1024 || (M & (M - 1)) != 0) return 0;
+  int chb = 4096 / M;
+  while (chb > 0 && (long long)chb * N > 16384) chb >>= 1;  // 128 KB of double accumulators
+  return chb >= 8 ? chb : 0;
+}
+
 // support-major backward pass through the CSR inverse of idx.  For support point i with slot list S_i:
 //   dG_i = sum_{s in S_i} dy_s,  dy_s = D y_s + Bc + A dz [slot s is the arg-max],  y_s = W_r rel_s + H[centre_s] + G_i
 //        = D (W_r . sum rel_s + sum H[centre_s] + |S_i| G_i) + |S_i| Bc + A hit_i
@@ -1704,6 +1742,16 @@ extern "C" int cl3d_pwmlp_bwd_rows(const float *gout, int gout_channel_major, co
   return check_launch("cl3d_pwmlp_bwd_rows");
 }
 
+static int launch_hit_wide(const cl3d::HitArgs &a, int chb, hipStream_t st, const char *who) {
+  using namespace cl3d;
+  static std::atomic<unsigned long long> granted{0};
+  int rc_lds = lds_opt_in(granted, reinterpret_cast<const void *>(pwmlp_hit_wide_kernel), 128 * 1024, who);
+  if (rc_lds != CL3D_OK) return rc_lds;
+  hipLaunchKernelGGL(pwmlp_hit_wide_kernel, dim3(ceil_div(a.Co, chb), 1, a.B), dim3(1024), (size_t)chb * a.N * sizeof(double), st,
+                     a, chb);
+  return check_launch(who);
+}
+
 extern "C" int cl3d_pwmlp_bwd_hits(const float *dz_cm, const int32_t *ts_cm, int B, int N, int M, int Co,
                                    float *hit_cm, cl3d_stream_t stream) {
   using namespace cl3d;
@@ -1716,6 +1764,7 @@ extern "C" int cl3d_pwmlp_bwd_hits(const float *dz_cm, const int32_t *ts_cm, int
   if (rc_lds != CL3D_OK) return rc_lds;
   HitArgs a{};
   a.dz_cm = dz_cm; a.ts_cm = ts_cm; a.hit_cm = hit_cm; a.B = B; a.N = N; a.M = M; a.Co = Co;
+  if (const int chb = hit_wide_rows(N, M)) return launch_hit_wide(a, chb, (hipStream_t)stream, "cl3d_pwmlp_bwd_hits");
   a.T = N < 4096 ? N : 4096;  // 4 channels x T doubles = 128 KiB
   const int ntiles = ceil_div(N, a.T);
   CL3D_REQUIRE(ntiles <= 65535, "pwmlp_bwd_hits: N too large");
@@ -1737,6 +1786,13 @@ extern "C" int cl3d_pwmlp_bwd_hits_coeffs(const double *partial, int n_partials,
   static std::atomic<unsigned long long> granted{0};
   int rc_lds = lds_opt_in(granted, reinterpret_cast<const void *>(pwmlp_hit_coeffs_kernel), 128 * 1024, "pwmlp_bwd_hits_coeffs");
   if (rc_lds != CL3D_OK) return rc_lds;
+  if (hit_wide_rows(N, M)) {
+    // few queries per cloud: the scatter is a handful of wide blocks, and the one-launch form would carry Co / 4 x B
+    // blocks for it -- two small launches instead
+    const int rc = cl3d_pwmlp_bn_backward_coeffs(partial, n_partials, Co, count, gamma, mean, invstd, sums, cA, cB, cD, dgamma,
+                                                 dbeta, dwr, stream);
+    return rc != CL3D_OK ? rc : cl3d_pwmlp_bwd_hits(dz_cm, ts_cm, B, N, M, Co, hit_cm, stream);
+  }
   HitArgs h{};
   h.dz_cm = dz_cm; h.ts_cm = ts_cm; h.hit_cm = hit_cm; h.B = B; h.N = N; h.M = M; h.Co = Co;
   h.T = N < 4096 ? N : 4096;  // 4 channels x T doubles = 128 KiB

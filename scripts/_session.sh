@@ -1,2 +1,3 @@
-python scripts/micro/grid_subsample_phases.py 2>&1
-for i in 1 2 3; do timeout 900 python -m pytest tests/test_native_gpu.py tests/test_ref_pin_gpu.py tests/test_scene_size_gpu.py -x -q -p no:cacheprovider --tb=short 2>&1 | tail -12; done
+timeout 900 python -m pytest tests/test_pwmlp_rows_gpu.py tests/test_operators_gpu.py tests/test_config2_fullsize_gpu.py tests/test_bottleneck_gpu.py tests/test_pass_calls_gpu.py -x -q -p no:cacheprovider 2>&1 | tail -3
+for i in 1 2; do timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp --precision bf16 2>/dev/null | tail -1 | cut -c150-260; done
+timeout 600 python bench.py --no-cpu-baseline --no-kernel-roofline --backbone off 2>/dev/null | cut -c1-260
