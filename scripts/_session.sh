@@ -1,3 +1,4 @@
-timeout 900 python -m pytest tests/test_pwmlp_rows_gpu.py tests/test_operators_gpu.py tests/test_config2_fullsize_gpu.py tests/test_bottleneck_gpu.py tests/test_pass_calls_gpu.py -x -q -p no:cacheprovider 2>&1 | tail -3
-for i in 1 2; do timeout 600 python scripts/bench_backbone.py --config modelnet_pointwisemlp --precision bf16 2>/dev/null | tail -1 | cut -c150-260; done
-timeout 600 python bench.py --no-cpu-baseline --no-kernel-roofline --backbone off 2>/dev/null | cut -c1-260
+OUT=gpurun_out/r05zz; mkdir -p $OUT; export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof2 -o bench -- python $R/bench.py --no-cpu-baseline --backbone off --precondition 0 > $R/$OUT/rocprof2.log 2>&1); echo "rocprof rc=$?"
+python scripts/step_timeline.py "$OUT/prof2/**/bench_kernel_trace.csv" | tee $OUT/step_timeline.txt
+rm -rf $OUT/prof2

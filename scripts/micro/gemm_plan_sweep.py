@@ -39,7 +39,7 @@ def build():
     print("built", LIB)
 
 
-def run(reps, precisions):
+def run(reps, precisions, point_products=False):
     os.environ["CL3D_LIB"] = LIB
     import torch
     sys.path.insert(0, ROOT)
@@ -72,7 +72,12 @@ def run(reps, precisions):
             best = min(best, a.elapsed_time(b) * 1e3 / reps)
         return best
 
-    for C, n, Co in LAYERS:
+    if point_products:
+        layers = [(72, 4096, 72), (36, 4096, 36), (72, 1024, 72), (144, 1024, 144), (144, 256, 144), (288, 256, 288),
+                  (288, 64, 288), (576, 64, 576), (576, 16, 576), (1152, 16, 1152)]
+    else:
+        layers = LAYERS
+    for C, n, Co in layers:
         x = torch.randn(B, C, n, device=dev)
         dy = torch.randn(B, Co, n, device=dev)
         W = torch.randn(Co, C, device=dev) / C ** 0.5
@@ -86,11 +91,23 @@ def run(reps, precisions):
                 "bwd_data": lambda st: lib.cl3d_conv1x1_bwd_data(p(dy), p(W), B, C, n, Co, prec, p(dx), p(ws), ws.numel(), st),
                 "bwd_weight": lambda st: lib.cl3d_conv1x1_bwd_weight(p(x), p(dy), B, C, n, Co, prec, p(dW), p(ws), ws.numel(), st),
             }
+            if point_products:  # the PointWiseMLP's per-point contraction [B n, C] x [C, 2 Co] and its two gradients
+                Wp = torch.randn(Co, 3 + 2 * C, device=dev) / C ** 0.5
+                ght = torch.empty(B, n, 2 * Co, device=dev)
+                dght = torch.randn(B, n, 2 * Co, device=dev)
+                wr, wcat = torch.empty(Co, 3, device=dev), torch.empty(2 * Co, C, device=dev)
+                dwr, dWp = torch.randn(Co, 3, device=dev), torch.empty(Co, 3 + 2 * C, device=dev)
+                lib.cl3d_pwmlp_point_gemm_fwd(p(x), p(Wp), B, C, n, Co, prec, p(ght), p(wr), p(wcat), p(ws), ws.numel(), _lib.stream_ptr(dev))
+                products = {
+                    "pt_fwd": lambda st: lib.cl3d_pwmlp_point_gemm_fwd(p(x), p(Wp), B, C, n, Co, prec, p(ght), p(wr), p(wcat), p(ws), ws.numel(), st),
+                    "pt_bwd_data": lambda st: lib.cl3d_pwmlp_point_gemm_bwd_data(p(dght), p(wcat), B, C, n, Co, prec, p(dx), p(ws), ws.numel(), st),
+                    "pt_bwd_weight": lambda st: lib.cl3d_pwmlp_point_gemm_bwd_weight(p(x), p(dght), p(dwr), B, C, n, Co, prec, p(dWp), p(ws), ws.numel(), st),
+                }
             for name, fn in products.items():
                 os.environ.pop("CL3D_GEMM_FORCE", None)
                 auto = timed(fn)
                 print(json.dumps({"layer": [C, n, Co], "prec": prec_name, "product": name, "plan": "auto", "us": round(auto, 2)}), flush=True)
-                splits = [1, 2, 3, 4, 6, 8, 12, 16] if name != "bwd_weight" else [1, 2, 4, 8, 16, 32, 64, 128, 256]
+                splits = [1, 2, 3, 4, 6, 8, 12, 16] if not name.endswith("bwd_weight") else [1, 2, 4, 8, 16, 32, 64, 128, 256]
                 for wi, wj in ((1, 1), (2, 1), (1, 2), (2, 2)):
                     row = {}
                     for sp in splits:
@@ -106,8 +123,9 @@ if __name__ == "__main__":
     ap.add_argument("--run", action="store_true")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--precisions", default="bf16")
+    ap.add_argument("--point", action="store_true", help="the PointWiseMLP per-point products instead of the convolutions")
     a = ap.parse_args()
     if a.build:
         build()
     if a.run:
-        run(a.reps, a.precisions.split(","))
+        run(a.reps, a.precisions.split(","), a.point)
