@@ -594,6 +594,9 @@ def main():
                     help="untimed steps before the warm-up (clock ramp of an idle device; not part of --warmup / --steps)")
     ap.add_argument("--bursts", type=int, default=12, help="bursts of 8 launches per boundary kernel (median / min / max reported)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a HIP graph")
+    ap.add_argument("--optimizer", default="torch", choices=["torch", "flat"],
+                    help="torch: torch.optim.SGD, the reference's optimizer (default); flat: the engine's one-launch update over flat "
+                         "buffers (closerlook3d_amd.optim.FlatSGD) -- same arithmetic, no Python per parameter: for eager launches")
     ap.add_argument("--backbone", default="auto", choices=["auto", "on", "off"],
                     help="also time the BASELINE backbone step incl. the gradient all-reduce (SURVEY 8(e)): 'backbone_step' in "
                          "the JSON line; auto = on unless --no-kernel-roofline asks for a bare run")
@@ -642,14 +645,21 @@ def main():
     cfg["cl3d_precision"] = args.precision
     module = LocalAggregation(C, C, radius, K, cfg).to(dev).train(True)
     params = [p for p in module.parameters() if p.requires_grad]
-    opt = torch.optim.SGD(params, lr=1e-3) if params else None
+    if args.optimizer == "flat" and params:
+        # the engine's one-launch update over flat buffers (closerlook3d_amd/optim.py): same arithmetic, one C-ABI call
+        # instead of torch.optim.SGD's Python -- what an EAGERLY launched step gains (the replayed step has no host side)
+        from closerlook3d_amd.optim import FlatSGD
+        opt = FlatSGD(params, lr=1e-3)
+    else:
+        opt = torch.optim.SGD(params, lr=1e-3) if params else None
     xyz, mask, feats = (torch.from_numpy(a).to(dev) for a in synth_batch(B, N, C, 1000 + rank))
     feats.requires_grad_(True)
     probe = torch.randn(B, C, N, device=dev)
 
     # N > 1: the parameter gradients live in one flat buffer (zeroed inside the captured step, exchanged with a
     # single in-place RCCL all-reduce) and the update is a second, tiny graph -- three host calls per step
-    flat = FlatGradients(params) if (world > 1 and params) else None
+    flat = FlatGradients(params) if (world > 1 and params and args.optimizer != "flat") else None
+    flat_opt_grads = opt.flat_grads[0] if (world > 1 and params and args.optimizer == "flat") else None
 
     def compute():  # forward + backward (+ the parameter update when there is no gradient exchange)
         feats.grad = None
@@ -702,6 +712,9 @@ def main():
         if world > 1:
             if flat is not None:
                 flat.allreduce_mean(world)
+            elif flat_opt_grads is not None:
+                dist.all_reduce(flat_opt_grads)
+                flat_opt_grads.div_(world)
             if update_graph is not None:
                 update_graph.replay()
             elif opt is not None:
@@ -751,7 +764,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"ModelNet40-shape {kind} LocalAggregation fwd+bwd", "operator": kind,
                        "impl": args.impl, "clouds_per_gpu": B, "points": N, "nsample": K, "channels": C,
-                       "radius": round(radius, 5), "contraction_precision": args.precision, "launch": "hip_graph" if graph is not None else "eager",
+                       "radius": round(radius, 5), "contraction_precision": args.precision, "launch": "hip_graph" if graph is not None else "eager", "optimizer": "torch.optim.SGD" if args.optimizer == "torch" else "closerlook3d_amd.optim.FlatSGD",
                        "parallelism": f"dp{world} (clouds sharded, RCCL grad all-reduce)",
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": dist.get_backend() if world > 1 else None,

@@ -1,0 +1,90 @@
+"""FlatSGD: torch.optim.SGD's update as ONE launch of the engine (csrc/optim.hip, cl3d_sgd_step) over flat buffers.
+
+The reference trains with torch.optim.SGD (function/train_modelnet_dist.py:137-141; momentum and weight decay from the
+YAML).  On the device that optimizer is already a single multi-tensor kernel; what an eagerly launched step pays for it is
+the HOST: `optimizer.step()` + `optimizer.zero_grad()` are ~0.11 ms of Python next to a 0.29 ms local-aggregation step
+(profiles/r05/eager_host.txt).  FlatSGD moves every parameter of a group into one flat fp32 buffer (the parameter
+tensors become views of it, as `dp.FlatGradients` does for the gradients, which it also owns), so a step is one C-ABI
+call per parameter group, and the same call zeroes the gradients for the next accumulation:
+
+    opt = FlatSGD(model.parameters(), lr=0.01, momentum=0.9, weight_decay=1e-3)
+    loss.backward(); opt.step()            # no zero_grad() needed (it is a no-op kept for loop compatibility)
+    opt.flat_grads                         # one buffer per group: what a data-parallel step all-reduces
+
+Same arithmetic per element as torch.optim.SGD (tests/test_optim_gpu.py holds it to the library optimizer over several
+steps, with momentum, dampening, Nesterov and weight decay).  Only fp32 parameters on one device; a parameter that received
+no gradient in a step still holds a zero gradient here (torch.optim.SGD would skip it: with weight decay or momentum the two
+differ for such parameters -- the networks of this repository give every parameter a gradient in every step).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+class FlatSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False):
+        if nesterov and (momentum <= 0 or dampening != 0):
+            raise ValueError("Nesterov momentum requires a momentum and zero dampening")
+        super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
+                                      nesterov=nesterov))
+        self.flat_params, self.flat_grads, self._bufs, self._steps = [], [], [], []
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.requires_grad]
+            if not ps:
+                self.flat_params.append(None); self.flat_grads.append(None); self._bufs.append(None); self._steps.append(0)
+                continue
+            dev = ps[0].device
+            for p in ps:
+                if p.dtype != torch.float32 or p.device != dev:
+                    raise TypeError("FlatSGD: fp32 parameters on one device per group")
+            total = sum(p.numel() for p in ps)
+            flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+            flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+            off = 0
+            with torch.no_grad():
+                for p in ps:
+                    n = p.numel()
+                    flat_p[off:off + n].copy_(p.detach().reshape(-1))
+                    if p.grad is not None:
+                        flat_g[off:off + n].copy_(p.grad.detach().reshape(-1))
+                    p.data = flat_p[off:off + n].view(p.shape)   # the parameter IS a slice of the flat buffer from now on
+                    p.grad = flat_g[off:off + n].view(p.shape)   # ... and autograd accumulates into a slice of the other
+                    off += n
+            self.flat_params.append(flat_p)
+            self.flat_grads.append(flat_g)
+            self._bufs.append(torch.zeros(total, dtype=torch.float32, device=dev) if group["momentum"] != 0 else None)
+            self._steps.append(0)
+
+    def zero_grad(self, set_to_none=False):
+        """The step itself leaves the gradients zeroed; kept so that the reference's loop runs unchanged.  (Never sets
+        the gradients to None: they are views of the flat buffer.)"""
+        return None
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.lib()
+        for gi, group in enumerate(self.param_groups):
+            flat_p = self.flat_params[gi]
+            if flat_p is None:
+                continue
+            flat_g, buf = self.flat_grads[gi], self._bufs[gi]
+            # torch's first step sets buf = g; from a zeroed buffer that is what momentum * buf + (1 - dampening) * g gives
+            # unless dampening != 0 -- only then does the kernel need to be told, and only then may the first step not be
+            # frozen into a captured graph (the flag would be replayed)
+            first = 1 if (self._steps[gi] == 0 and group["dampening"] != 0 and buf is not None) else 0
+            if first and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FlatSGD with dampening: run one step eagerly before capturing it in a graph")
+            with _lib.on_device(flat_p.device):
+                _lib.check(lib.cl3d_sgd_step(
+                    ctypes.c_void_p(flat_p.data_ptr()), ctypes.c_void_p(flat_g.data_ptr()),
+                    ctypes.c_void_p(buf.data_ptr()) if buf is not None else None, flat_p.numel(), float(group["lr"]),
+                    float(group["momentum"]), float(group["dampening"]), float(group["weight_decay"]),
+                    1 if group["nesterov"] else 0, first, 1, _lib.stream_ptr(flat_p.device)))
+            self._steps[gi] += 1
+        return loss

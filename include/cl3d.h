@@ -296,6 +296,13 @@ int cl3d_pwmlp_point_gemm_bwd_fused(int B, int C, int N, int Co, int precision);
 int cl3d_pwmlp_point_gemm_bwd(const float *features, const float *scale, const float *shift, const float *dght,
                               const float *wcat, const float *dwr, int B, int C, int N, int Co, int precision,
                               float *dfeatures, float *dW, void *ws, size_t ws_bytes, cl3d_stream_t stream);
+/* torch.optim.SGD's update (reference function/train_modelnet_dist.py:137-141: the optimizer of every training loop) over
+ * flat buffers of n floats in one launch: g = grad + weight_decay p; buf = first_step ? g : momentum buf + (1 - dampening) g;
+ * g = nesterov ? g + momentum buf : buf (momentum_buf non-null iff momentum != 0); p -= lr g; zero_grad != 0: grad = 0
+ * afterwards (the flat gradient buffer autograd accumulates into).  closerlook3d_amd/optim.py: FlatSGD. */
+int cl3d_sgd_step(float *param, float *grad, float *momentum_buf, long long n, float lr, float momentum,
+                  float dampening, float weight_decay, int nesterov, int first_step, int zero_grad,
+                  cl3d_stream_t stream);
 /* f1 for the PosPool / AdaptiveWeight / PseudoGrid bottlenecks (round 5; backbones/resnet.py:32-39,47-66): the
  * BatchNorm + ReLU of conv1 rides in the layout change that feeds the operator (transpose_bn_relu: [B,R,C] -> [B,C,R]
  * with max(row_scale[r] x + row_shift[r], 0), r = channel), and the operator's own BatchNorm works on the point-major
