@@ -5,7 +5,8 @@
 // device that optimizer is already one multi-tensor kernel; what this entry point removes is the HOST side of an eagerly
 // launched step -- torch.optim.SGD.step + zero_grad are ~0.11 ms of Python per step next to a 0.29 ms step
 // (profiles/r05/eager_host.txt) -- for callers that keep their parameters in one flat buffer (closerlook3d_amd/optim.py:
-// FlatSGD re-points every parameter at a view of it).  torch.optim.SGD's arithmetic, per element:
+// FlatSGD re-points every parameter at a view of it; measured on the repository's benches: no gain, see there).
+// torch.optim.SGD's arithmetic, per element:
 //     g = grad + weight_decay * p;   buf = first step ? g : momentum * buf + (1 - dampening) * g;
 //     g = nesterov ? g + momentum * buf : buf   (momentum != 0);      p -= lr * g
 // and, optionally, grad = 0 for the next step's accumulation (the flat gradient buffer is what autograd adds into).

@@ -3,7 +3,10 @@
 The reference trains with torch.optim.SGD (function/train_modelnet_dist.py:137-141; momentum and weight decay from the
 YAML).  On the device that optimizer is already a single multi-tensor kernel; what an eagerly launched step pays for it is
 the HOST: `optimizer.step()` + `optimizer.zero_grad()` are ~0.11 ms of Python next to a 0.29 ms local-aggregation step
-(profiles/r05/eager_host.txt).  FlatSGD moves every parameter of a group into one flat fp32 buffer (the parameter
+(profiles/r05/eager_host.txt).  (Measured, profiles/r05/eager_optimizer_ab.txt: no gain on this repository's benches -- the
+in-place accumulation into the flat gradient buffer costs a small kernel per parameter, which outweighs the saved Python
+where the step is already device-bound, and the host-bound eager steps vary too much from process to process to show a
+difference.  Offered for loops with many parameters; `bench.py` keeps torch.optim.SGD.)  FlatSGD moves every parameter of a group into one flat fp32 buffer (the parameter
 tensors become views of it, as `dp.FlatGradients` does for the gradients, which it also owns), so a step is one C-ABI
 call per parameter group, and the same call zeroes the gradients for the next accumulation:
 

@@ -29,10 +29,6 @@ echo "== bench --precision bf16 (config 2's arithmetic)" | tee -a $OUT/summary.t
 timeout 900 python bench.py --precision bf16 --no-cpu-baseline --backbone off 2>/dev/null | tee $OUT/bench_bf16.json | cut -c1-300 | tee -a $OUT/summary.txt
 echo "== bench, eager launches" | tee -a $OUT/summary.txt
 timeout 900 python bench.py --no-graph --no-cpu-baseline --no-kernel-roofline 2>/dev/null | tee $OUT/bench_eager.json | cut -c1-260 | tee -a $OUT/summary.txt
-echo "== eager launches, torch.optim.SGD against the engine's one-launch update (bench.py --optimizer flat)" | tee -a $OUT/summary.txt
-for op in pointwisemlp adaptive_weight pospool pseudo_grid; do for o in torch flat; do
-  timeout 600 python bench.py --operator $op --no-graph --optimizer $o --no-cpu-baseline --no-kernel-roofline --backbone off 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('eager', '$op', '$o', d['ms_per_step'], 'ms')" | tee -a $OUT/eager_optimizer.txt | tee -a $OUT/summary.txt
-done; done
 echo "== ball query: LDS-resident kernel vs cell grid through HBM (same op, pinned path)" | tee -a $OUT/summary.txt
 for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
 for p in tile cells; do CL3D_BQ_PATH=$p timeout 120 python scripts/bench_bq.py --mult 4.0 | tee -a $OUT/bench_bq.jsonl | tee -a $OUT/summary.txt; done
