@@ -1111,6 +1111,9 @@ def point_rows(features, W, precision='f32'):
 PASS_CALLS = True
 
 
+PW_CSR_FIRST = True  # (module attribute: scripts set it to False for the A/B; see pointwise_mlp)
+
+
 def _use_pass_calls(training, need_grad, bn):
     return (PASS_CALLS and training and need_grad and pt_utils._BQ_CACHE is None and pt_utils.ASYNC_INDEX == 'auto'
             and not torch.cuda.is_current_stream_capturing() and bn.running_mean is not None and bn.track_running_stats)
@@ -1130,8 +1133,22 @@ def pointwise_mlp(query_xyz, support_xyz, query_mask, support_mask, features, ra
         return _PointwiseMLPPass.apply(features, W.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                        _step_counter(bn), query_xyz, support_xyz, query_mask, support_mask, radius,
                                        nsample, bn.momentum, bn.eps, PRECISIONS[precision], True)
-    idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad)
-    ght, wr = point_rows(features, W, precision)
+    # Capture order (round 5, second session; profiles/r05/pw_capture_order.txt): query, per-point product, CSR build, and
+    # only then the gather pass (inside _PointwiseMLP.forward).  The runtime lays a captured step out depth-first along each
+    # node's FIRST-captured dependent (_start_inverse): with the build captured before the gather pass, the build inherits
+    # the query's queue and its count pass runs the moment the query ends -- 11 us, alone, instead of 60 us squeezed in
+    # behind the gather pass's workgroups -- while the gather pass joins the product's queue (it pays one cross-queue
+    # hand-over either way: behind the product before, behind the query now).  The rest of the build then finishes under the
+    # gather pass instead of beside bwd_rows: TRAIN 71 -> 62 us, bwd_rows 34 -> 23, step 0.2905 -> 0.2841 ms (three
+    # alternating pairs).  PW_CSR_FIRST = False restores the order of the round's first session (build behind the consumer),
+    # which stays the better one for the gather-and-reduce operators inside backbones (_query's note).
+    if PW_CSR_FIRST and need_grad:
+        idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad)
+        ght, wr = point_rows(features, W, precision)
+        _start_inverse(idx, support_xyz.shape[1], None)
+    else:
+        idx, _ = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, need_grad)
+        ght, wr = point_rows(features, W, precision)
     use_batch_stats = training or bn.running_mean is None
     momentum = bn.momentum  # never None here: use_fused() sends that configuration to the grouped path
     return _PointwiseMLP.apply(ght.contiguous(), wr, bn.weight, bn.bias, bn.running_mean, bn.running_var,
