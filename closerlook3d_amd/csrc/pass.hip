@@ -221,25 +221,22 @@ static int enqueue_forward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::PassR
   CL3D_TRY(cl3d_pwmlp_point_gemm_fwd(p->features, p->W, p->B, p->C, p->N, p->Co, p->precision, p->ght, p->wr, p->wcat,
                                      p->gemm_ws, p->gemm_ws_bytes, rt->side[0]));
   CL3D_TRY(hip_ok(hipEventRecord(rt->ev_fork, rt->side[0]), "pwmlp_train_forward: event"));
+  // The CSR build is enqueued BEFORE the statistics pass (round 5, second session; fused.pointwise_mlp has the same order
+  // and the measurements): a captured pass is laid out depth-first along each node's first-recorded dependent, so the
+  // build inherits the query's queue and its count pass runs the moment the query ends -- 11 us alone instead of 60 us
+  // squeezed in behind the statistics pass's workgroups -- while the statistics pass joins the product's queue (one
+  // cross-queue hand-over either way: behind the product before, behind the query now).
   if (want_csr) {
     CL3D_REQUIRE(p->inv_slots != nullptr, "pwmlp_train_forward: null inv_slots");
     CL3D_TRY(hip_ok(hipEventRecord(rt->ev_bq, st), "pwmlp_train_forward: event"));
-  }
-  CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_fork, 0), "pwmlp_train_forward: join"));
-  CL3D_TRY(cl3d_pwmlp_stats(p->query_xyz, p->support_xyz, p->idx, p->ght, p->wr, p->gamma, p->B, p->N, p->M, p->K, p->Co,
-                            p->radius, p->ystar, p->kstar, p->sy, p->partial, p->n_partials, st));
-  // the CSR build is enqueued BEHIND the statistics pass: a captured pass is laid out depth-first along each node's
-  // first-recorded dependent (that one stays on the node's queue, later ones move to the other), so the statistics
-  // pass -- the critical chain -- must be the query's first dependent, not the CSR build
-  if (want_csr) {
     CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[1], rt->ev_bq, 0), "pwmlp_train_forward: fork"));
-    // ... and waits for the per-point product as well (long finished): the build and the product share the replayed
-    // pass's side queue, and this puts the product -- which the statistics pass needs -- in front (fused.py _start_inverse)
-    CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[1], rt->ev_fork, 0), "pwmlp_train_forward: order"));
     CL3D_TRY(cl3d_build_inverse_index(p->idx, p->B, p->N, p->M * p->K, p->inv_off, p->inv_slots, p->csr_ws, p->csr_ws_bytes,
                                       rt->side[1]));
     CL3D_TRY(hip_ok(hipEventRecord(rt->ev_csr, rt->side[1]), "pwmlp_train_forward: event"));
   }
+  CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_fork, 0), "pwmlp_train_forward: join"));
+  CL3D_TRY(cl3d_pwmlp_stats(p->query_xyz, p->support_xyz, p->idx, p->ght, p->wr, p->gamma, p->B, p->N, p->M, p->K, p->Co,
+                            p->radius, p->ystar, p->kstar, p->sy, p->partial, p->n_partials, st));
   float *scale = p->vec, *shift = p->vec + p->Co, *mean = p->vec + 2 * p->Co, *invstd = p->vec + 3 * p->Co;
   CL3D_TRY(cl3d_pwmlp_finalize_stats(p->partial, p->n_partials, p->Co, (double)p->B * p->M * p->K, p->eps, p->momentum,
                                      p->gamma, p->beta, p->running_mean, p->running_var, p->num_batches_tracked, scale, shift,
