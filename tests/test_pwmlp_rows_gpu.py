@@ -19,7 +19,8 @@ SHAPES = [  # B, N, M, K, Co
     (2, 256, 256, 32, 64),     # rows64: one chunk
     (3, 512, 128, 16, 128),    # rows64: two chunks, M != N, K = 16
     (1, 640, 640, 64, 64),     # rows64: K = 64, every lane a slot
-    (16, 1024, 1024, 32, 64),  # rows64: more tiles than partial records at B * M / 8 = 2048 -> capped grid, tile loop
+    (16, 1024, 1024, 32, 64),  # rows64: fewer tiles (256) than workgroups (1024 partial records)
+    (20, 2048, 4096, 16, 64),  # rows64: 1280 tiles on 1024 workgroups -- the tile loop runs twice for a quarter of them
     (2, 256, 256, 32, 48),     # general kernel: width not a multiple of 64
     (2, 200, 200, 20, 64),     # general kernel: ragged tiles
     (2, 256, 192, 7, 72),      # general kernel
