@@ -210,7 +210,8 @@ static int enqueue_forward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::PassR
   // ---- the LONGEST chain stays on the caller's stream: ball query -> statistics pass -> BatchNorm -> activation.  A piece
   // handed to a side stream starts one cross-queue hand-over (~10 us) late and its join is free once it has finished: so
   // the per-point product (26 us, needs nothing of the geometry) is what forks, and it is done long before the query
-  // (55-62 us) is; the CSR build forks behind the query and is joined at the very end
+  // (55-62 us) is; the CSR build forks behind the query -- BEFORE the statistics pass is enqueued, see below -- and is joined
+  // at the very end
   // (the query is ENQUEUED first, the product forked from the point before it: in a captured pass the first-recorded root
   // and its first-recorded dependents get the launch queue)
   CL3D_TRY(hip_ok(hipEventRecord(rt->ev_in, st), "pwmlp_train_forward: event"));

@@ -387,7 +387,14 @@ def _start_inverse(idx, n_support, after=None):
     support-major pass); (2) the CSR build then shares the side queue with the feature-side preparation and is VISITED
     FIRST: the preparation, which the gather pass needs, would sit behind a build that waits for the query
     (measured: step 0.314 -> 0.374 ms).  Making the build wait for `after` -- the preparation, finished long before the
-    query -- forces the side queue's order: preparation, then build."""
+    query -- forces the side queue's order: preparation, then build.
+
+    That is the order inside a backbone (shared, mostly prefetched geometry).  A STAND-ALONE operator step takes the other
+    one since the round's second session -- build captured BEFORE the gather pass, `after` = None (pointwise_mlp,
+    REDUCE_CSR_FIRST): point (1) above prices the gather pass's hand-over behind the query, but the gather pass pays one
+    hand-over anyway (behind the feature-side preparation), and with the build as the query's first dependent its count pass
+    runs alone the moment the query ends instead of squeezed in behind the gather pass's workgroups (60 -> 11 us; step
+    0.2885 -> 0.281 ms, profiles/r05/pw_capture_order.txt)."""
     inverse_index(idx, n_support, prefetch=True, after=after)
 
 
