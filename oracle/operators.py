@@ -173,6 +173,43 @@ def masked_upsample_nearest(up_xyz, xyz, up_mask, mask, features):
     return _Group.apply(features, idx)[..., 0].contiguous()
 
 
+def _conv_bn(x, state, prefix, relu, eps=1e-5):
+    """Conv1d(1x1, no bias) + BatchNorm1d in training mode [+ ReLU] from a state dict (backbones/resnet.py:30-32)."""
+    x = F.conv1d(x, state[prefix + "0.weight"])
+    x = F.batch_norm(x, None, None, state[prefix + "1.weight"], state[prefix + "1.bias"], training=True, eps=eps)
+    return torch.relu(x) if relu else x
+
+
+def bottleneck(xyz, mask, features, state, kind, operator_kwargs, radius, nsample, in_channels, out_channels,
+               downsample=False, sampleDl=None, npoint=None, eps=1e-5):
+    """A whole residual `Bottleneck` in training mode (backbones/resnet.py:22-68) around one of the three gather-and-
+    reduce operators: [MaskedMaxPool ->] conv1+BN+ReLU -> operator -> BN+ReLU (the operator's out_transform,
+    local_aggregation_operators.py:43-45) -> conv2+BN (+ shortcut conv+BN) -> add -> ReLU.  `state`: the module's
+    state dict as tensors (requires_grad where a gradient is wanted).  -> (query_xyz, query_mask, out)."""
+    if downsample:
+        q_xyz, q_mask, identity = masked_max_pool(xyz, mask, features, npoint, radius, nsample, sampleDl)
+    else:
+        q_xyz, q_mask, identity = xyz, mask, features
+    x = _conv_bn(features, state, "conv1.", True, eps)
+    a = (q_xyz, xyz, q_mask, mask, x, radius, nsample)
+    pre = "local_aggregation.local_aggregation_operator."
+    if kind == "pospool":
+        y = pospool(*a, **operator_kwargs)
+    elif kind == "adaptive_weight":
+        y = adaptive_weight(*a, [state[pre + "mlps.conv0.weight"].flatten(1)], [state[pre + "mlps.conv0.bias"]],
+                            **operator_kwargs)
+    elif kind == "pseudo_grid":
+        y = pseudo_grid(*a, state[pre + "K_points"], state[pre + "kernel_weights"], **operator_kwargs)
+    else:
+        raise NotImplementedError(kind)
+    y = torch.relu(F.batch_norm(y, None, None, state[pre + "out_transform.0.weight"], state[pre + "out_transform.0.bias"],
+                                training=True, eps=eps))
+    y = _conv_bn(y, state, "conv2.", False, eps)
+    if in_channels != out_channels:
+        identity = _conv_bn(identity, state, "shortcut.", False, eps)
+    return q_xyz, q_mask, torch.relu(y + identity)
+
+
 # ------------------------------------------------------------------ synthetic clouds (SURVEY 8(d))
 def make_cloud(rng, B, N, kind='uniform', pad_frac=0.0):
     """xyz [B,N,3] f32, mask [B,N] i32 with the dataset contract: valid points first, padding last,

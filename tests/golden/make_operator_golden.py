@@ -10,7 +10,8 @@ reference's code, executed as is.
 Each fixture stores inputs, every parameter/buffer of the module (state_dict), the forward output
 and the gradients of `sum(output * probe)` w.r.t. the input features and all parameters.
 
-    python tests/golden/make_operator_golden.py
+    python tests/golden/make_operator_golden.py                       # everything
+    python tests/golden/make_operator_golden.py --only bottlenecks    # tests/golden/bottleneck_*.npz alone
 """
 import os
 import sys
@@ -120,7 +121,44 @@ def _randomize_bn(mod, seed):
                 m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
 
 
-def main():
+BOTTLENECK_CASES = [  # name, kind, overrides, (cin, cout), strided
+    ("pospool_xyz_plain", "pospool", dict(pospool__position_embedding="xyz", pospool__reduction="avg"), (48, 48), False),
+    ("pospool_sincos_strided", "pospool", dict(pospool__position_embedding="sin_cos", pospool__reduction="avg"), (24, 48), True),
+    ("adaptive_weight_plain", "adaptive_weight", dict(adaptive_weight__num_mlps=1, adaptive_weight__reduction="avg"), (48, 48), False),
+    ("adaptive_weight_strided", "adaptive_weight", dict(adaptive_weight__num_mlps=1, adaptive_weight__reduction="avg"), (24, 48), True),
+    ("pseudo_grid_plain", "pseudo_grid", dict(pseudo_grid__KP_influence="linear"), (48, 48), False),
+    ("pseudo_grid_strided", "pseudo_grid", dict(pseudo_grid__KP_influence="linear"), (24, 48), True),
+]
+
+
+def bottlenecks(Bottleneck):
+    """Whole `Bottleneck`s of the three gather-and-reduce operators (backbones/resnet.py:22-68), plain and strided, every
+    parameter gradient kept: the reference pins of fused.reduce_bottleneck.  The strided PosPool-xyz
+    one is operators_strided_bottleneck.npz above."""
+    B, N, K = 2, 256, 16
+    for ci, (name, kind, over, (cin, cout), strided) in enumerate(BOTTLENECK_CASES):
+        cfg = _config(kind, **over)
+        xyz, mask, feats = _inputs(1000 + ci, B, N, cin, 0.25)
+        torch.manual_seed(1100 + ci)
+        np.random.seed(1100 + ci)
+        btn = Bottleneck(cin, cout, 2, 0.15, K, cfg, downsample=strided, sampleDl=0.12 if strided else None,
+                         npoint=64 if strided else None)
+        _randomize_bn(btn, 1200 + ci)
+        btn.train(True)
+        state = _state(btn)
+        rec = _run_module(btn, [torch.from_numpy(a) for a in (xyz, mask, feats)], 2, 1300 + ci)
+        for k, v in btn.state_dict().items():  # BatchNorm running statistics AFTER the step
+            if "running_" in k:
+                rec["after__" + k] = v.detach().clone().numpy()
+        rec.update(state)
+        rec.update(xyz=xyz, mask=mask, features=feats, kind=np.array(kind), over=np.array(repr(over)),
+                   cin=np.int32(cin), cout=np.int32(cout), strided=np.int32(strided), radius=np.float32(0.15),
+                   nsample=np.int32(K), sampleDl=np.float32(0.12), npoint=np.int32(64))
+        np.savez_compressed(os.path.join(OUT, f"bottleneck_{name}.npz"), **rec)
+        print("bottleneck", name, rec["out"].shape, float(np.abs(rec["out"]).mean()))
+
+
+def main(only=None):
     os.environ["JOB_LOG_DIR"] = tempfile.mkdtemp(prefix="cl3d_golden_")
     _install_stubs()
     sys.path.insert(0, REF)
@@ -135,6 +173,9 @@ def main():
     import pt_utils as ref_pt_utils  # the reference's own file (ops/pt_custom_ops is on sys.path now)
     assert ref_pt_utils.__file__.startswith(REF), ref_pt_utils.__file__
 
+    if only == "bottlenecks":
+        bottlenecks(Bottleneck)
+        return
     B, N, K, C = 2, 256, 16, 12
     cases = [
         ("pospool_xyz_avg", "pospool", dict(pospool__position_embedding="xyz", pospool__reduction="avg"), 1.5, 0.25, True),
@@ -215,6 +256,8 @@ def main():
         print("resnet", kind, rec["out"].shape, float(np.abs(rec["out"]).mean()))
 
 
+    bottlenecks(Bottleneck)
+
     # parameter/buffer names and shapes of the remaining caller (no forward needed): checkpoint compatibility
     from models.heads.segmentation_head import MultiPartSegHeadResNet
     import json
@@ -224,4 +267,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(only=sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None)

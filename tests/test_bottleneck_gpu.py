@@ -259,6 +259,112 @@ def test_reduce_operator_bottleneck_without_the_tensors_between_its_layers(name,
             assert np.array_equal(a[3][k], b[3][k]), k
 
 
+def _bottleneck_fixtures():
+    import glob
+    import os
+    from tests.helpers import GOLDEN
+    return sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "bottleneck_*.npz"))) + \
+        ["operators_strided_bottleneck.npz"]
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+@pytest.mark.parametrize("name", _bottleneck_fixtures())
+def test_reduce_bottleneck_matches_the_reference(name, fuse, monkeypatch):
+    """fused.reduce_bottleneck held to the REFERENCE -- whole `Bottleneck`s (backbones/resnet.py:22-68)
+    of PosPool xyz / sin_cos, AdaptiveWeight and PseudoGrid, plain and strided, run by the reference's own Python
+    (tests/golden/make_operator_golden.py: `bottlenecks`) -- with the size threshold at 0 so the fused form is the one
+    that runs (counted), at the operator fixtures' tolerances: output 1e-5, input gradient 5e-5, every parameter gradient
+    2e-4, sub-sampled coordinates / masks bit for bit, running statistics after the step 1e-5.  fuse=False runs the same
+    fixture layer by layer (the path the small fixtures used to take)."""
+    from closerlook3d_amd import backbones, fused
+    from closerlook3d_amd.backbones import Bottleneck
+    from tests.helpers import load_fixture, state_of
+    fx = load_fixture(name)
+    if name.startswith("operators_strided"):
+        kind, over = "pospool", {"pospool__position_embedding": "xyz", "pospool__reduction": "avg"}
+        cin, cout, strided = 24, 48, True
+    else:
+        kind, over, cin, cout, strided = fx["kind"], fx["over"], int(fx["cin"]), int(fx["cout"]), bool(fx["strided"])
+    monkeypatch.setattr(backbones, "_FUSE_MIN_VALUES", 0 if fuse else 1 << 62)
+    calls = []
+    real = fused.reduce_bottleneck
+
+    def counted(*a, **k):
+        out = real(*a, **k)
+        calls.append(out is not None)
+        return out
+    monkeypatch.setattr(fused, "reduce_bottleneck", counted)
+    btn = Bottleneck(cin, cout, 2, 0.15, 16, default_config(kind, over), downsample=strided,
+                     sampleDl=0.12 if strided else None, npoint=64 if strided else None)
+    btn.load_state_dict(state_of(fx), strict=True)
+    btn = btn.cuda().train(True)
+    feats = torch.from_numpy(fx["features"]).cuda().requires_grad_(True)
+    sub_xyz, sub_mask, out = btn(torch.from_numpy(fx["xyz"]).cuda(), torch.from_numpy(fx["mask"]).cuda(), feats)
+    assert calls == ([True] if fuse else []), calls  # the fused form really ran, to the end (and only where asked)
+    if strided:
+        assert np.array_equal(sub_xyz.cpu().numpy().view(np.uint32), fx["out0"].view(np.uint32))
+        assert np.array_equal(sub_mask.cpu().numpy(), fx["out1"])
+    (out * torch.from_numpy(fx["probe"]).cuda()).sum().backward()
+    assert_close(out.detach().cpu().numpy(), fx["out"], 1e-5, f"{name} out")
+    assert_close(feats.grad.cpu().numpy(), fx["grad_features"], 5e-5, f"{name} grad_features")
+    checked = 0
+    for k, p in btn.named_parameters():
+        if "grad__" + k in fx:
+            assert p.grad is not None, k
+            assert_close(p.grad.cpu().numpy(), fx["grad__" + k], 2e-4, f"{name} grad {k}")
+            checked += 1
+    assert checked == len([k for k in fx if k.startswith("grad__")]) and checked >= 6
+    for k, v in btn.state_dict().items():
+        if "after__" + k in fx:
+            assert_close(v.cpu().numpy(), fx["after__" + k], 1e-5, f"{name} {k} after the step")
+
+
+def test_pospool_resnet_with_every_bottleneck_fused_matches_the_reference(monkeypatch):
+    """the reference-generated PosPool ResNet + segmentation-head fixture used to run below
+    backbones._FUSE_MIN_VALUES and never entered fused.reduce_bottleneck.  Threshold 0: every bottleneck whose width the
+    kernels cover (C % 4 == 0 and C % 3 == 0 here: 12, 24, 48, 96 of the fixture's 6 ... 96) runs fused, under
+    ball_query_cache() (the blocks of a stage share one idx and one CSR table), against the reference's outputs."""
+    from closerlook3d_amd import backbones, fused
+    from closerlook3d_amd.backbones import ResNet, SceneSegHeadResNet
+    from closerlook3d_amd.pt_utils import ball_query_cache
+    from tests.helpers import load_fixture, state_of
+    fx = load_fixture("operators_resnet_seg_pospool.npz")
+    monkeypatch.setattr(backbones, "_FUSE_MIN_VALUES", 0)
+    calls = []
+    real = fused.reduce_bottleneck
+
+    def counted(*a, **k):
+        out = real(*a, **k)
+        calls.append(out is not None)
+        return out
+    monkeypatch.setattr(fused, "reduce_bottleneck", counted)
+    K = 16
+    net = ResNet(default_config("pospool", fx["over"]), 3, 0.1, 0.05, [K] * 5, [128, 48, 16, 8], width=12, depth=2,
+                 bottleneck_ratio=2)
+    head = SceneSegHeadResNet(5, 12, 0.1, [K] * 5)
+    net.load_state_dict(state_of(fx, "backbone."), strict=True)
+    head.load_state_dict(state_of(fx, "head."), strict=True)
+    net, head = net.cuda().train(True), head.cuda().train(True)
+    feats = torch.from_numpy(fx["features"]).cuda().requires_grad_(True)
+    with ball_query_cache():
+        ep = net(torch.from_numpy(fx["xyz"]).cuda(), torch.from_numpy(fx["mask"]).cuda(), feats)
+        logits = head(ep)
+    assert len(calls) == 9 and sum(calls) >= 7, calls  # nine bottlenecks; mid widths 6 (x2, not covered), 12 ... 96
+    assert np.array_equal(ep["res5_xyz"].cpu().numpy().view(np.uint32), fx["out0"].view(np.uint32))
+    assert np.array_equal(ep["res5_mask"].cpu().numpy(), fx["out1"])
+    assert_close(ep["res5_features"].detach().cpu().numpy(), fx["out2"], 2e-4, "res5_features")
+    assert_close(logits.detach().cpu().numpy(), fx["out"], 2e-4, "logits")
+    (logits * torch.from_numpy(fx["probe"]).cuda()).sum().backward()
+    assert torch.isfinite(feats.grad).all()
+    # avg reductions have no arg-max routing between the input and res1, so the early parameters' gradients are smooth:
+    # hold every stored parameter gradient of the backbone loosely in norm (ten BatchNorm layers deep)
+    for k, p in net.named_parameters():
+        if "grad__backbone." + k in fx and p.grad is not None:
+            want = fx["grad__backbone." + k]
+            got = p.grad.cpu().numpy()
+            assert np.linalg.norm(got - want) <= 5e-2 * np.linalg.norm(want) + 1e-6, k
+
+
 @pytest.mark.parametrize("P,C", [(65536, 64), (4096, 72), (1000, 288), (77, 12), (300, 1152)])
 def test_bn_on_point_major_rows_matches_torch(P, C):
     """cl3d_bn_rows_stats / cl3d_bn_rows_bwd (BatchNorm + ReLU on rows [P, C], gradient taken with respect to the

@@ -43,6 +43,45 @@ def test_strided_bottleneck_pieces():
     assert np.array_equal(sub_mask.numpy(), fx["out1"])
 
 
+BOTTLENECKS = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "bottleneck_*.npz")))
+
+
+@pytest.mark.parametrize("name", BOTTLENECKS + ["operators_strided_bottleneck.npz"])
+def test_oracle_bottleneck_matches_reference_python(name):
+    """oracle.operators.bottleneck (the checker of fused.reduce_bottleneck on the GPU box) against whole `Bottleneck`s run
+    by the reference's own Python (tests/golden/make_operator_golden.py: bottlenecks): output, input gradient, every
+    parameter gradient."""
+    from tests.helpers import state_of
+    fx = load_fixture(name)
+    if name.startswith("operators_strided"):
+        kind, over, cin, cout, strided = "pospool", {"pospool__position_embedding": "xyz", "pospool__reduction": "avg"}, 24, 48, True
+    else:
+        kind, over, cin, cout, strided = fx["kind"], fx["over"], int(fx["cin"]), int(fx["cout"]), bool(fx["strided"])
+    st = {k: v.clone().requires_grad_(v.dtype == torch.float32 and "running" not in k and "K_points" not in k)
+          for k, v in state_of(fx).items()}
+    if kind == "pospool":
+        kw = dict(position_embedding=over["pospool__position_embedding"], reduction=over["pospool__reduction"])
+    elif kind == "adaptive_weight":
+        kw = dict(shared_channels=1, reduction=over["adaptive_weight__reduction"])
+    else:
+        kw = dict(extent=2 * 1.0 * 0.15 / 5.0, influence=over["pseudo_grid__KP_influence"])
+    feats = torch.from_numpy(fx["features"]).clone().requires_grad_(True)
+    q_xyz, q_mask, out = oo.bottleneck(torch.from_numpy(fx["xyz"]), torch.from_numpy(fx["mask"]), feats, st, kind, kw,
+                                       0.15, 16, cin, cout, downsample=strided, sampleDl=0.12, npoint=64)
+    if strided:
+        assert np.array_equal(q_xyz.numpy(), fx["out0"]) and np.array_equal(q_mask.numpy(), fx["out1"])
+    (out * torch.from_numpy(fx["probe"])).sum().backward()
+    assert_close(out.detach().numpy(), fx["out"], TOL, f"{name}: out")
+    assert_close(feats.grad.numpy(), fx["grad_features"], 2e-5, f"{name}: grad_features")
+    checked = 0
+    for k, v in st.items():
+        if "grad__" + k in fx:
+            assert v.grad is not None, k
+            assert_close(v.grad.numpy(), fx["grad__" + k], 5e-5, f"{name}: grad {k}")
+            checked += 1
+    assert checked == sum(1 for k in fx if k.startswith("grad__"))
+
+
 NATIVE = sorted(glob.glob(os.path.join(GOLDEN, "native_*.npz")))
 
 
