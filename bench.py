@@ -523,14 +523,32 @@ def backbone_step(kind, world, rank, dev, steps=10, warmup=3):
         return g
 
     graph = update_graph = None
+    failure = None
     try:
-        graph = capture(compute)
-        if world > 1:
-            update_graph = capture(opt.step)
-    except Exception as e:
-        print(f"bench: backbone step: HIP graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
-        graph = update_graph = None
-        torch.cuda.synchronize()
+        try:
+            graph = capture(compute)
+            if world > 1:
+                update_graph = capture(opt.step)
+        except torch.OutOfMemoryError:
+            raise
+        except Exception as e:
+            print(f"bench: backbone step: HIP graph capture failed ({type(e).__name__}: {e}); eager launches", file=sys.stderr)
+            graph = update_graph = None
+            torch.cuda.synchronize()
+            compute()  # (eager launches must at least run once on this rank before the ranks meet in a collective)
+            torch.cuda.synchronize()
+    except Exception as e:  # out of memory, a kernel's error code: this rank cannot run the step
+        failure = f"{type(e).__name__}: {e}"
+    if world > 1:
+        # one rank failing before the first collective must not leave the others in the all-reduce below.  The
+        # ranks agree on a flag here (the only collective a failed rank still joins); on failure every rank returns the
+        # error record and the headline, already measured, is printed with it.
+        ok = torch.tensor([0 if failure else 1], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            return {"config": name, "error": failure or "another rank could not set the step up (its stderr has the reason)"}
+    elif failure:
+        return {"config": name, "error": failure}
     ar = []
 
     def step():
@@ -749,9 +767,11 @@ def main():
         try:
             bb = backbone_step(kind, world, rank, dev, steps=args.backbone_steps)
         except Exception as e:  # the headline stands on its own; say what happened
-            if world > 1:
-                raise
+            # (set-up failures of any rank come back as an agreed {"error": ...}; what still raises here for N > 1 happened
+            # between collectives, where the ranks cannot be re-joined -- rank 0 prints its headline before giving up)
             bb = {"error": f"{type(e).__name__}: {e}"}
+            if world > 1:
+                bb["fatal"] = True
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * N / (elapsed / args.steps)
@@ -826,6 +846,9 @@ def main():
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
     if world > 1:
+        if bb is not None and bb.get("fatal"):  # a rank lost the others mid-step: the line is out, end the job
+            sys.stdout.flush()
+            os._exit(1 if rank else 0)
         dist.barrier()  # rank 0 measured the per-kernel rooflines after the timed region: leave together
         dist.destroy_process_group()
 

@@ -364,7 +364,8 @@ def _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, ne
 
 
 def _mark(device):
-    """An event on the caller's stream at this point of a capture (None outside one / without the index streams)."""
+    """An event recorded on the caller's stream at this point -- inside a capture an ordering edge for the index stream's
+    work (_start_inverse), in eager launches a plain (cheap) event with the same meaning; None without the index streams."""
     if not (device.type == 'cuda' and pt_utils.async_index()):
         return None
     ev = torch.cuda.Event()
@@ -953,7 +954,7 @@ class _ReduceBottleneckLA(Function):
 
     @staticmethod
     def forward(ctx, y1, gamma1, beta1, bn1, p0, p1, op, query_xyz, support_xyz, query_mask, idx, idx_mask, radius,
-                normalize, reduction, pint, pfloat, constant, gamma2, beta2, bn2):
+                normalize, reduction, pint, pfloat, constant, gamma2, beta2, bn2, need_grad=True):
         y1 = y1.contiguous()
         B, C, N = y1.shape
         _, M, K = idx.shape
@@ -967,9 +968,11 @@ class _ReduceBottleneckLA(Function):
         partial2 = torch.empty((nparts2, C, 2), dtype=torch.float64, device=dev)
         ft = torch.empty((B, N, C), dtype=torch.float32, device=dev)
         rows = torch.empty((B, M, C), dtype=torch.float32, device=dev)
-        slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev)
+        # (a training-mode forward under torch.no_grad() -- BatchNorm recalibration, evaluation with batch statistics --
+        # keeps nothing for a backward and builds no CSR table: ADVICE r5)
+        slotrec = torch.empty((B, M, K, 4), dtype=torch.float32, device=dev) if need_grad else None
         pairs = None
-        if op == OP_PSEUDOGRID and C % 4 == 0 and not constant:
+        if need_grad and op == OP_PSEUDOGRID and C % 4 == 0 and not constant:
             pairs = torch.empty((B, M, K, 8), dtype=torch.float32, device=dev)
         with _lib.on_device(dev):
             st = _stream(y1)
@@ -978,13 +981,14 @@ class _ReduceBottleneckLA(Function):
                                               _p(bn1.running_var), _p(_step_counter(bn1)), _p(vec1[0]), _p(vec1[1]),
                                               _p(vec1[2]), _p(vec1[3]), st))
             _lib.check(lib.cl3d_transpose_bn_relu(_p(y1), _p(vec1[0]), _p(vec1[1]), B, C, N, _p(ft), st))
-            pre = _mark(dev)
+            pre = _mark(dev) if need_grad else None
             wait_ready(idx)
             _lib.check(lib.cl3d_fused_reduce_fwd(
                 op, _p(query_xyz), _p(support_xyz), _p(query_mask), _p(idx), _p(idx_mask), _p(ft), B, N, M, K, C,
                 float(radius), int(normalize), reduction, _p(p0), _p(p1), pint, float(pfloat), int(constant),
                 _p(rows), 0, _p(slotrec), _p(pairs), st))
-            _start_inverse(idx, N, pre)
+            if need_grad:
+                _start_inverse(idx, N, pre)
             _lib.check(lib.cl3d_bn_rows_stats(_p(rows), B * M, C, _p(partial2), nparts2, float(B * M), float(bn2.eps),
                                               float(bn2.momentum), _p(gamma2), _p(beta2), _p(bn2.running_mean),
                                               _p(bn2.running_var), _p(_step_counter(bn2)), _p(vec2[0]), _p(vec2[1]),
@@ -1032,7 +1036,7 @@ class _ReduceBottleneckLA(Function):
                 _lib.check(lib.cl3d_fused_param_reduce(op, _p(dparam), nparts, C, pint, _p(g0), _p(g1), st))
             _lib.check(lib.cl3d_bn_relu_bwd(_p(dact), _p(y1), _p(vec1[0]), _p(vec1[1]), _p(vec1[2]), _p(vec1[3]), _p(gamma1),
                                             B, C, N, float(B * N), _p(partial1), nparts1, _p(coef1), _p(dy1), st))
-        return (dy1, coef1[3], coef1[4], None, g0, g1) + (None,) * 12 + (coef2[3], coef2[4], None)
+        return (dy1, coef1[3], coef1[4], None, g0, g1) + (None,) * 12 + (coef2[3], coef2[4], None, None)
 
 
 def _reduce_operator_args(la):
@@ -1098,11 +1102,13 @@ def reduce_bottleneck(conv1, la, conv2, shortcut, query_xyz, support_xyz, query_
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     prec = PRECISIONS[precision]
     op, p0, p1, normalize, reduction, pint, pfloat, constant = oargs
-    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, la.radius, la.nsample, True)
+    need_grad = _wants_grad(features, identity, c1.weight, bn1.weight, bn1.bias, p0, p1, obn.weight, obn.bias, c2.weight,
+                            bn2.weight, bn2.bias)
+    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, la.radius, la.nsample, need_grad)
     y1 = _Conv1x1.apply(features, c1.weight.view(C1, -1), prec)
     rows, scale, shift = _ReduceBottleneckLA.apply(y1, bn1.weight, bn1.bias, bn1, p0, p1, op, query_xyz, support_xyz,
                                                    query_mask, idx, idx_mask, la.radius, normalize, reduction, pint, pfloat,
-                                                   constant, obn.weight, obn.bias, obn)
+                                                   constant, obn.weight, obn.bias, obn, need_grad)
     y2 = _Conv1x1Rows.apply(rows, scale, shift, c2.weight.view(c2.weight.shape[0], C1), prec)
     return conv_bn_act(None, c2, bn2, relu=True, residual=identity,
                        res_conv=shortcut[0] if shortcut is not None else None,

@@ -33,6 +33,7 @@ class FlatSGD(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, momentum=momentum, dampening=dampening, weight_decay=weight_decay,
                                       nesterov=nesterov))
         self.flat_params, self.flat_grads, self._bufs, self._steps = [], [], [], []
+        self._recheck = False
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.requires_grad]
             if not ps:
@@ -59,6 +60,64 @@ class FlatSGD(torch.optim.Optimizer):
             self.flat_grads.append(flat_g)
             self._bufs.append(torch.zeros(total, dtype=torch.float32, device=dev) if group["momentum"] != 0 else None)
             self._steps.append(0)
+            self._expose_state(len(self._bufs) - 1)
+
+    def _expose_state(self, gi):
+        """torch.optim.SGD's per-parameter state, `state[p]['momentum_buffer']`, as VIEWS of the flat momentum buffer: what
+        `state_dict()` saves and the reference's checkpoints hold (function/train_modelnet_dist.py:145,160 saves and
+        restores `optimizer.state_dict()`), so a resumed run continues with its momentum."""
+        buf = self._bufs[gi]
+        if buf is None:
+            return
+        off = 0
+        for p in self.param_groups[gi]["params"]:
+            if not p.requires_grad:
+                continue
+            n = p.numel()
+            self.state[p]["momentum_buffer"] = buf[off:off + n].view(p.shape)
+            off += n
+
+    def load_state_dict(self, state_dict):
+        """Accepts its own state dict and torch.optim.SGD's (same layout: one `momentum_buffer` per parameter).  The base
+        class replaces the state tensors by copies; they are copied INTO the flat buffer and the state re-pointed at its
+        views.  A group that comes back with momentum has taken its first step (torch sets buf = g there)."""
+        super().load_state_dict(state_dict)
+        self._recheck = True
+        for gi, group in enumerate(self.param_groups):
+            buf = self._bufs[gi]
+            if group["momentum"] != 0 and buf is None and self.flat_params[gi] is not None:
+                buf = self._bufs[gi] = torch.zeros_like(self.flat_params[gi])
+            if buf is None:
+                continue
+            off, loaded = 0, False
+            with torch.no_grad():
+                for p in group["params"]:
+                    if not p.requires_grad:
+                        continue
+                    n = p.numel()
+                    mb = self.state.get(p, {}).get("momentum_buffer")
+                    if mb is not None and mb.data_ptr() != buf[off:off + n].data_ptr():
+                        buf[off:off + n].copy_(mb.detach().reshape(-1).to(buf.dtype))
+                        loaded = True
+                    off += n
+            if loaded:
+                self._steps[gi] = max(self._steps[gi], 1)
+            self._expose_state(gi)
+
+    def _check_views(self, gi):
+        """A `module.zero_grad(set_to_none=True)`, a `.to()` or a `p.grad = ...` after construction detaches a parameter
+        from the flat buffers; the flat update would then silently apply zeros.  Fail instead."""
+        flat_p, flat_g = self.flat_params[gi], self.flat_grads[gi]
+        p0, g0 = flat_p.data_ptr(), flat_g.data_ptr()
+        off = 0
+        for p in self.param_groups[gi]["params"]:
+            if not p.requires_grad:
+                continue
+            if p.data_ptr() != p0 + 4 * off or p.grad is None or p.grad.data_ptr() != g0 + 4 * off:
+                raise RuntimeError("FlatSGD: a parameter or its .grad no longer lives in the flat buffers (zero_grad("
+                                   "set_to_none=True) on the module, .to() or a re-assigned .grad after the optimizer was "
+                                   "built); use optimizer.zero_grad() and build the optimizer after moving the model")
+            off += p.numel()
 
     def zero_grad(self, set_to_none=False):
         """The step itself leaves the gradients zeroed; kept so that the reference's loop runs unchanged.  (Never sets
@@ -77,6 +136,8 @@ class FlatSGD(torch.optim.Optimizer):
             if flat_p is None:
                 continue
             flat_g, buf = self.flat_grads[gi], self._bufs[gi]
+            if self._steps[gi] % 64 == 0 or self._recheck:  # (a loop that detaches them does so in its first iteration)
+                self._check_views(gi)
             # torch's first step sets buf = g; from a zeroed buffer that is what momentum * buf + (1 - dampening) * g gives
             # unless dampening != 0 -- only then does the kernel need to be told, and only then may the first step not be
             # frozen into a captured graph (the flag would be replayed)
@@ -90,4 +151,5 @@ class FlatSGD(torch.optim.Optimizer):
                     float(group["momentum"]), float(group["dampening"]), float(group["weight_decay"]),
                     1 if group["nesterov"] else 0, first, 1, _lib.stream_ptr(flat_p.device)))
             self._steps[gi] += 1
+        self._recheck = False
         return loss

@@ -66,7 +66,9 @@ def main():
                          "stages' backward ALONE give wrong, replay-varying gradients (DESIGN 6; kept to reproduce it)")
     ap.add_argument("--debug-two-graphs", default="", help="two-graph reproducer, comma list of: sync_between (device sync between the replays "
                     "of graph A and graph B), own_pool (graph B in a memory pool of its own), fresh_streams (graph B forks "
-                    "onto streams graph A never saw)")
+                    "onto streams graph A never saw), same_stream (warm-up and every capture on ONE explicit stream: autograd's "
+                    "AccumulateGrad nodes run on the stream that was current when a parameter was first used -- the warm-up's -- "
+                    "which is otherwise a third branch of every captured backward pass)")
     ap.add_argument("--fork-mode", default="reuse", choices=["reuse", "serial_side", "after", "probe"],
                     help="two-graph reproducer: how a forked pair of gradient products is laid out (reuse = shipped)")
     ap.add_argument("--fork-only", default="", help="debug: comma list of fork episodes (1-based, counted from graph B's capture) that fork")
@@ -261,13 +263,18 @@ def main():
         if world == 1:
             opt.step()
 
+    _one_stream = {}
+
     def capture(fn, pool=None, warm=None, forks=None):
         """warm: what to run eagerly first (default: fn itself).  Graph B is captured right behind graph A with no eager
         step in between: it must walk the autograd graph -- and read the cut gradients -- that graph A's capture built."""
         if warm is None:
             warm = fn
+        same = "same_stream" in set(args.debug_two_graphs.split(","))
+        if same and "s" not in _one_stream:
+            _one_stream["s"] = torch.cuda.Stream()
         if warm:
-            side = torch.cuda.Stream()
+            side = _one_stream["s"] if same else torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(3):
@@ -283,7 +290,8 @@ def main():
         # late-stage backward: exact), off in graph B unless --overlap-forks b|both --unsafe asks for the known-bad layout
         with closerlook3d_amd.whole_step_capture(not args.overlap), \
                 _fu.forked_gradients(bool(forks) if (args.overlap and forks is not None) else None), \
-                torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local" if world > 1 else "global"):
+                torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local" if world > 1 else "global",
+                                 **({"stream": _one_stream["s"]} if same else {})):
             fn()
         return g
 

@@ -94,3 +94,8 @@ echo "== dataset-side grid subsampling, voting, sphere crops" | tee -a $OUT/summ
 timeout 600 python scripts/bench_dataset_grid.py 2>/dev/null | tee $OUT/bench_dataset_grid.json | tee -a $OUT/summary.txt
 timeout 300 python scripts/bench_voting.py 2>/dev/null | tee $OUT/bench_voting.json | tee -a $OUT/summary.txt
 timeout 300 python scripts/bench_sphere_crop.py 2>/dev/null | tee $OUT/bench_sphere_crop.json | tee -a $OUT/summary.txt
+# closing cleanup: the rocprof traces of the PMC / kernel-trace passes stay out of what is merged back (the
+# summaries above are what is kept), and the marker tells a finished session from a truncated one
+find $OUT -name "*kernel_trace*" -delete 2>/dev/null
+find $OUT -type f -size +3M -delete 2>/dev/null
+echo "== done $(date -u +%H:%M:%S)" | tee -a $OUT/summary.txt

@@ -365,6 +365,33 @@ def test_pospool_resnet_with_every_bottleneck_fused_matches_the_reference(monkey
             assert np.linalg.norm(got - want) <= 5e-2 * np.linalg.norm(want) + 1e-6, k
 
 
+@pytest.mark.parametrize("name", ["bottleneck_adaptive_weight_plain.npz", "bottleneck_pseudo_grid_strided.npz"])
+def test_reduce_bottleneck_forward_without_a_backward_keeps_nothing(name, monkeypatch):
+    """a training-mode forward under torch.no_grad() (BatchNorm recalibration) through fused.reduce_bottleneck:
+    same output and running statistics as the reference's fixture, no slot records, no CSR build."""
+    from closerlook3d_amd import backbones, fused
+    from closerlook3d_amd.backbones import Bottleneck
+    from tests.helpers import load_fixture, state_of
+    fx = load_fixture(name)
+    cin, cout, strided = int(fx["cin"]), int(fx["cout"]), bool(fx["strided"])
+    monkeypatch.setattr(backbones, "_FUSE_MIN_VALUES", 0)
+    started = []
+    real_start = fused._start_inverse
+    monkeypatch.setattr(fused, "_start_inverse", lambda *a, **k: (started.append(1), real_start(*a, **k))[1])
+    btn = Bottleneck(cin, cout, 2, 0.15, 16, default_config(fx["kind"], fx["over"]), downsample=strided,
+                     sampleDl=0.12 if strided else None, npoint=64 if strided else None)
+    btn.load_state_dict(state_of(fx), strict=True)
+    btn = btn.cuda().train(True)
+    with torch.no_grad():
+        _, _, out = btn(torch.from_numpy(fx["xyz"]).cuda(), torch.from_numpy(fx["mask"]).cuda(),
+                        torch.from_numpy(fx["features"]).cuda())
+    assert not started, "a forward without a backward started a CSR build"
+    assert_close(out.cpu().numpy(), fx["out"], 1e-5, "out")
+    for k, v in btn.state_dict().items():
+        if "after__" + k in fx:
+            assert_close(v.cpu().numpy(), fx["after__" + k], 1e-5, f"{k} after the step")
+
+
 @pytest.mark.parametrize("P,C", [(65536, 64), (4096, 72), (1000, 288), (77, 12), (300, 1152)])
 def test_bn_on_point_major_rows_matches_torch(P, C):
     """cl3d_bn_rows_stats / cl3d_bn_rows_bwd (BatchNorm + ReLU on rows [P, C], gradient taken with respect to the
