@@ -463,6 +463,10 @@ def cpu_baseline_voting(batches, num_classes, cloud_sizes):
     return (time.perf_counter() - t0) / len(batches)
 
 
+# "same": warm-up and capture on closerlook3d_amd.step_stream() (round 6); "separate": torch's usual two streams (the A/B arm,
+# --capture-stream separate)
+CAPTURE_STREAM = "same"
+
 BACKBONE_OF = {"pointwisemlp": ("modelnet_pointwisemlp", "bf16"), "pseudo_grid": ("s3dis_pseudogrid", "f32"),
                "adaptive_weight": ("partnet_adaptive", "f32"), "pospool": ("s3dis_pospool_deep", "f32")}
 
@@ -509,7 +513,9 @@ def backbone_step(kind, world, rank, dev, steps=10, warmup=3):
             opt.step()
 
     def capture(fn):
-        side = torch.cuda.Stream()
+        # warm-up and capture on ONE stream (closerlook3d_amd.step_stream: autograd's AccumulateGrad nodes then run on the
+        # capture stream instead of forming a third branch of the captured backward pass)
+        side = closerlook3d_amd.step_stream(dev) if CAPTURE_STREAM == "same" else torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
@@ -518,7 +524,8 @@ def backbone_step(kind, world, rank, dev, steps=10, warmup=3):
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with closerlook3d_amd.whole_step_capture(), \
-                torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
+                torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global",
+                                 **({"stream": side} if CAPTURE_STREAM == "same" else {})):
             fn()
         return g
 
@@ -615,11 +622,15 @@ def main():
     ap.add_argument("--optimizer", default="torch", choices=["torch", "flat"],
                     help="torch: torch.optim.SGD, the reference's optimizer (default); flat: the engine's one-launch update over flat "
                          "buffers (closerlook3d_amd.optim.FlatSGD) -- same arithmetic, no Python per parameter: for eager launches")
+    ap.add_argument("--capture-stream", default="same", choices=["same", "separate"],
+                    help="same (default): warm-up and capture on one stream; separate: a warm-up stream of its own (A/B)")
     ap.add_argument("--backbone", default="auto", choices=["auto", "on", "off"],
                     help="also time the BASELINE backbone step incl. the gradient all-reduce (SURVEY 8(e)): 'backbone_step' in "
                          "the JSON line; auto = on unless --no-kernel-roofline asks for a bare run")
     ap.add_argument("--backbone-steps", type=int, default=10)
     args = ap.parse_args()
+    global CAPTURE_STREAM
+    CAPTURE_STREAM = args.capture_stream
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -691,7 +702,7 @@ def main():
             opt.step()
 
     def capture(fn):
-        side = torch.cuda.Stream()
+        side = closerlook3d_amd.step_stream(dev) if CAPTURE_STREAM == "same" else torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
@@ -704,7 +715,8 @@ def main():
         # (forward and backward of the step in ONE capture: the operator may leave its forked geometry work to be
         # joined by its backward, closerlook3d_amd.whole_step_capture)
         with closerlook3d_amd.whole_step_capture(), \
-                torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global"):
+                torch.cuda.graph(g, capture_error_mode="thread_local" if world > 1 else "global",
+                                 **({"stream": side} if CAPTURE_STREAM == "same" else {})):
             fn()
         return g
 
@@ -784,7 +796,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"ModelNet40-shape {kind} LocalAggregation fwd+bwd", "operator": kind,
                        "impl": args.impl, "clouds_per_gpu": B, "points": N, "nsample": K, "channels": C,
-                       "radius": round(radius, 5), "contraction_precision": args.precision, "launch": "hip_graph" if graph is not None else "eager", "optimizer": "torch.optim.SGD" if args.optimizer == "torch" else "closerlook3d_amd.optim.FlatSGD",
+                       "radius": round(radius, 5), "contraction_precision": args.precision, "launch": "hip_graph" if graph is not None else "eager", "capture_stream": CAPTURE_STREAM, "optimizer": "torch.optim.SGD" if args.optimizer == "torch" else "closerlook3d_amd.optim.FlatSGD",
                        "parallelism": f"dp{world} (clouds sharded, RCCL grad all-reduce)",
                        "world_size": dist.get_world_size() if world > 1 else 1,
                        "backend": dist.get_backend() if world > 1 else None,

@@ -57,7 +57,12 @@ def group_points_grad(grad_out, idx, n):
     return out
 
 
-def masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample):
+BQ_PATHS = {"auto": 0, "tile": 1, "cells": 2, "exhaustive": 3}
+
+
+def masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, path=0):
+    """The reference's signature; `path` (engine extension, default 0 = the library's choice) names one implementation
+    (BQ_PATHS): every path returns the same bits (tests/test_bq_paths_gpu.py), pt_utils picks by measurement."""
     _check("query_xyz", query_xyz, torch.float32)
     _check("support_xyz", support_xyz, torch.float32)
     _check("query_mask", query_mask, torch.int32)
@@ -71,8 +76,8 @@ def masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, 
     ws_bytes = lib.cl3d_workspace_bytes(1, B, N, M, int(nsample), 0)  # CL3D_OP_BALL_QUERY
     ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=query_xyz.device) if ws_bytes else None
     with _lib.on_device(query_xyz.device):
-        _lib.check(lib.cl3d_masked_ordered_ball_query(
-            _p(query_xyz), _p(support_xyz), _p(query_mask), _p(support_mask), B, M, N, float(radius),
+        _lib.check(lib.cl3d_masked_ordered_ball_query_path(
+            int(path), _p(query_xyz), _p(support_xyz), _p(query_mask), _p(support_mask), B, M, N, float(radius),
             int(nsample), _p(idx), _p(idx_mask), _p(ws) if ws is not None else None, ws_bytes,
             _lib.stream_ptr(query_xyz.device)))
     return [idx, idx_mask]

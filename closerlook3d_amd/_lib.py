@@ -23,6 +23,8 @@ _Z = ctypes.c_size_t
 # that every symbol declared in the header is exported by the library and listed here).
 SIGNATURES = {
     "cl3d_masked_ordered_ball_query": [_P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _Z, _P],
+    "cl3d_masked_ordered_ball_query_path": [_I, _P, _P, _P, _P, _I, _I, _I, _F, _I, _P, _P, _P, _Z, _P],
+    "cl3d_ball_query_paths": [_I, _I, _I],
     "cl3d_fused_supported": [_I, _I, _I],
     "cl3d_group_points": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
     "cl3d_group_points_grad": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
@@ -192,7 +194,7 @@ class trace:
 # CL3D_ABI_VERSION of include/cl3d.h: the library must have been built from the same header (a stale .so with another
 # argument layout would run with shifted pointers).  A constant, so that a copy of the package without the repository's
 # include/ directory still imports; tests/test_abi.py holds it to the header.
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def header_abi_version():

@@ -251,17 +251,32 @@ int ball_query_exhaustive(const float *query_xyz, const float *support_xyz, cons
 
 }  // namespace cl3d
 
-extern "C" int cl3d_masked_ordered_ball_query(const float *query_xyz, const float *support_xyz,
-                                              const int32_t *query_mask,
-                                              const int32_t *support_mask, int B, int M, int N,
-                                              float radius, int nsample, int32_t *idx,
-                                              int32_t *idx_mask, void *ws, size_t ws_bytes,
-                                              cl3d_stream_t stream) {
+// path: 0 = the library's own choice (by size; CL3D_BQ_PATH pins it), 1 = tile (the cloud resident in one CU's LDS),
+// 2 = cells (cell grid through HBM scratch), 3 = exhaustive.  Every path returns the same bits; a path that does not apply
+// to the sizes (or needs scratch that was not given) is refused, never silently replaced.
+static int ball_query_on_path(int path, const float *query_xyz, const float *support_xyz, const int32_t *query_mask,
+                              const int32_t *support_mask, int B, int M, int N, float radius, int nsample, int32_t *idx,
+                              int32_t *idx_mask, void *ws, size_t ws_bytes, hipStream_t st) {
   CL3D_REQUIRE(B >= 0 && M >= 0 && N >= 1 && nsample >= 1, "ball_query: bad sizes B=%d M=%d N=%d K=%d", B, M, N, nsample);
+  CL3D_REQUIRE(path >= 0 && path <= 3, "ball_query: path must be 0 (auto), 1 (tile), 2 (cells) or 3 (exhaustive)");
   if (B == 0 || M == 0) return CL3D_OK;
   CL3D_REQUIRE(query_xyz && support_xyz && query_mask && support_mask && idx && idx_mask, "ball_query: null pointer");
   CL3D_REQUIRE(B <= 65535, "ball_query: B exceeds grid.y limit");
-  hipStream_t st = (hipStream_t)stream;
+  if (path == 1) {
+    if (!cl3d::ball_query_tile_applicable(M, N, nsample))
+      return cl3d::fail(CL3D_E_UNSUPPORTED, "ball_query: the tile path does not take M=%d N=%d K=%d", M, N, nsample);
+    return cl3d::ball_query_tile(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx, idx_mask, st);
+  }
+  if (path == 2) {
+    if (ws == nullptr || !cl3d::ball_query_cells_applicable(M, N, nsample))
+      return cl3d::fail(CL3D_E_UNSUPPORTED, "ball_query: the cells path needs scratch and does not take M=%d N=%d K=%d without it",
+                        M, N, nsample);
+    return cl3d::ball_query_cells(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx, idx_mask, ws,
+                                  ws_bytes, st);
+  }
+  if (path == 3)
+    return cl3d::ball_query_exhaustive(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx, idx_mask,
+                                       nullptr, st);
   // CL3D_BQ_PATH=tile|cells|exhaustive pins one implementation where it applies (A/B timing, tests of the
   // less-travelled paths); every path returns the same bits
   static const int pinned = [] {
@@ -280,6 +295,37 @@ extern "C" int cl3d_masked_ordered_ball_query(const float *query_xyz, const floa
                                   idx_mask, ws, ws_bytes, st);
   return cl3d::ball_query_exhaustive(query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx,
                                      idx_mask, nullptr, st);
+}
+
+extern "C" int cl3d_masked_ordered_ball_query(const float *query_xyz, const float *support_xyz,
+                                              const int32_t *query_mask,
+                                              const int32_t *support_mask, int B, int M, int N,
+                                              float radius, int nsample, int32_t *idx,
+                                              int32_t *idx_mask, void *ws, size_t ws_bytes,
+                                              cl3d_stream_t stream) {
+  return ball_query_on_path(0, query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx, idx_mask, ws,
+                            ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int cl3d_masked_ordered_ball_query_path(int path, const float *query_xyz, const float *support_xyz,
+                                                   const int32_t *query_mask, const int32_t *support_mask, int B, int M,
+                                                   int N, float radius, int nsample, int32_t *idx, int32_t *idx_mask,
+                                                   void *ws, size_t ws_bytes, cl3d_stream_t stream) {
+  return ball_query_on_path(path, query_xyz, support_xyz, query_mask, support_mask, B, M, N, radius, nsample, idx, idx_mask, ws,
+                            ws_bytes, (hipStream_t)stream);
+}
+
+// bit p set: path p (1 tile, 2 cells -- given scratch of cl3d_workspace_bytes(CL3D_OP_BALL_QUERY, ...) --, 3 exhaustive) takes
+// these sizes.  More than one bit: the caller may time them against each other for ITS point density (pt_utils does,
+// once per (sizes, radius) key) -- which of tile / cells is faster depends on how many points fall inside the radius,
+// a property of the data, not of the sizes.
+extern "C" int cl3d_ball_query_paths(int M, int N, int nsample) {
+  if (M < 1 || N < 1 || nsample < 1) return 0;
+  int mask = 0;
+  if (cl3d::ball_query_tile_applicable(M, N, nsample)) mask |= 1 << 1;
+  if (cl3d::ball_query_cells_applicable(M, N, nsample)) mask |= 1 << 2;
+  if ((size_t)4 * 1 * 7 * nsample * sizeof(int) <= (size_t)64 * 1024) mask |= 1 << 3;
+  return mask;
 }
 
 extern "C" int cl3d_masked_nearest_query(const float *query_xyz, const float *support_xyz,

@@ -36,6 +36,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
+#include <mutex>
 
 namespace cl3d {
 
@@ -83,6 +84,12 @@ struct GemmArgs {
   int K;               // contraction extent (clouds folded in for weight gradients)
   int nsplit, chunks_per_split;
   int tiles_i, tiles_j;
+  // nsplit > 1 and tickets != nullptr: the slices of a tile are summed INSIDE this launch -- every workgroup draws a
+  // ticket for its tile after its partial is written; the one that draws the last adds the partials in slice order
+  // 0, 1, 2, ... (whatever the order in which they arrived: bit-reproducible), sends the sums through `out` and puts
+  // the ticket counter back to zero for the next launch.  No second launch, no 5 us hand-over between two kernels.
+  unsigned *tickets;   // one counter per output tile, zero on entry and on exit
+  int vec_out;         // the output map takes four consecutive j at once (16-byte stores; host-checked alignment)
 };
 
 __device__ __forceinline__ long long out_col(const OutMap &o, int j) {
@@ -358,6 +365,83 @@ struct StagePick<PREC_BF16, TR, KC> {
   static constexpr int kLdsBytes = StageBF16<TR>::kLdsPacks * 16;
 };
 
+// ---- K slices summed inside the launch.  Called by every workgroup of a sliced product after its
+// partial tile is in memory.  Release / acquire at device scope around the ticket: the partial stores are made visible
+// (the L2 of this XCD written back) before the ticket is drawn, and the workgroup that draws the last ticket drops what
+// its XCD's L2 may still hold of the scratch from an earlier launch before it reads the other slices.
+template <int TI, int TJ>
+__device__ __forceinline__ void sum_slices_by_last_arrival(const GemmArgs &a, int i0, int j0, int tile) {
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned drawn = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = drawn == (unsigned)(a.nsplit - 1);
+    if (last) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int I = a.A.R, J = a.B.R;
+  const long long IJ = (long long)I * J;
+  const OutMap &o = a.out;
+  if (a.vec_out) {  // J % 4 == 0: a float4 never straddles the matrix edge, a row or a cloud
+    // a thread's NE float4 pieces of the tile are loaded together for every slice: NE independent 16-byte loads in
+    // flight per thread (4 / 8 / 16 KB ... 64 KB per workgroup), the slices added one after the other
+    constexpr int NE = TI * TJ / 4 / 256;
+    const float *src[NE];
+    float4 acc[NE];
+    bool live[NE];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      const int q = e * 256 + threadIdx.x, i = i0 + q / (TJ / 4), j = j0 + 4 * (q % (TJ / 4));
+      live[e] = i < I && j < J;
+      src[e] = a.partial + (live[e] ? (long long)i * J + j : 0);
+      acc[e] = *reinterpret_cast<const float4 *>(src[e]);
+    }
+    for (int p = 1; p < a.nsplit; ++p) {
+      float4 v[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) v[e] = *reinterpret_cast<const float4 *>(src[e] + (size_t)p * IJ);
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        acc[e].x += v[e].x; acc[e].y += v[e].y; acc[e].z += v[e].z; acc[e].w += v[e].w;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      if (!live[e]) continue;
+      const int q = e * 256 + threadIdx.x, i = i0 + q / (TJ / 4), j = j0 + 4 * (q % (TJ / 4));
+      const long long at = i * o.si + out_col(o, j);
+      float4 r = acc[e];
+      if (o.ep_scale) {
+        const float sc = o.ep_scale[i], sh = o.ep_shift[i];
+        r.x = __builtin_fmaf(r.x, sc, sh); r.y = __builtin_fmaf(r.y, sc, sh);
+        r.z = __builtin_fmaf(r.z, sc, sh); r.w = __builtin_fmaf(r.w, sc, sh);
+      }
+      if (o.ep_res) {
+        const float4 t = *reinterpret_cast<const float4 *>(o.ep_res + at);
+        r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+      }
+      if (o.ep_relu) {
+        r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f;
+        r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f;
+      }
+      *reinterpret_cast<float4 *>(o.D + at) = r;
+    }
+  } else {
+    for (int q = threadIdx.x; q < TI * TJ; q += 256) {
+      const int i = i0 + q / TJ, j = j0 + q % TJ;
+      if (i >= I || j >= J) continue;
+      const float *src = a.partial + (long long)i * J + j;
+      float acc = src[0];
+      for (int p = 1; p < a.nsplit; ++p) acc += src[(size_t)p * IJ];
+      out_store(o, i, out_col(o, j), acc);
+    }
+  }
+}
+
 template <int PREC, int WI, int WJ, int AM, int BM>
 __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
   constexpr int TI = 64 * WI, TJ = 64 * WJ;
@@ -548,6 +632,7 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
         }
       }
     }
+  if (part && a.tickets != nullptr) sum_slices_by_last_arrival<TI, TJ>(a, i0, j0, ti * a.tiles_j + tj);
 }
 
 // ---- slice-ordered sum of the split-K partials.  A workgroup owns 16 consecutive elements of the I x J tile; its 16
@@ -1080,6 +1165,8 @@ static void launch_modes(GemmArgs &a, int wi, int wj, int blocks, hipStream_t st
 
 
 constexpr int kCUs = 256;
+constexpr int kTicketMaxSplit = 16;  // more slices than this: the partials are summed by a launch of their own, over the whole chip
+constexpr double kInLaunchSumKBperUs = 40.0;  // what ONE workgroup streams while it sums its tile's slices (measured: profiles/r06)
 
 
 // Workgroup tile and K slicing for an I x J output over K.  Two regimes decide the time of a product here:
@@ -1095,6 +1182,16 @@ struct Plan {
   int wi, wj, nsplit, cps;
 };
 
+// (variant builds of scripts/micro/gemm_plan_sweep.py only: CL3D_GEMM_FUSED_SUM=0 restores the two-launch slice sum for the A/B)
+static bool fused_slice_sum() {
+#ifdef CL3D_GEMM_PLAN_ENV
+  const char *e = getenv("CL3D_GEMM_FUSED_SUM");  // (read per call: the sweep switches it between timings)
+  return !(e && e[0] == '0');
+#else
+  return true;
+#endif
+}
+
 // bf16: what a launch costs was measured over every tile and K split on the convolutions of the config-2 backbone
 // (scripts/micro/gemm_plan_sweep.py, 14 layers x 3 products x 4 tiles x 8-9 splits, launches replayed from a HIP graph;
 // profiles/r05/gemm_plan_sweep_bf16.jsonl) and does not follow the flop count at all -- these products are 1-3 GFLOP and
@@ -1107,11 +1204,20 @@ struct Plan {
 // x resident).  Least-squares fit of the logarithm: 9.7 % rms over the 1400 timings.  Plans chosen by the fit total 955 us
 // over the 42 products against 906 us for the best plan of each and 1204 us for the flop-count model this replaces (which
 // stays for f32, where it is within 5 % of the best: 1739 against 1649 us).
-static double bf16_launch_us(int I, int J, long long K, int wi, int wj, long long cps, long long real_split) {
+// what summing `split` slices costs on top of the product: a launch of its own over the whole chip (two-launch form), or
+// the last arrival of every tile reading its tile of every slice (in-launch form: no launch, no hand-over, but ONE
+// workgroup per tile streams split x tile bytes at what a single workgroup draws)
+static double slice_sum_us(int I, int J, int wi, int wj, long long split, bool in_launch) {
+  if (split <= 1) return 0.0;
+  if (in_launch && split <= kTicketMaxSplit) return 0.6 + (double)split * (64.0 * wi) * (64.0 * wj) * 4.0 / 1e3 / kInLaunchSumKBperUs;
+  return 1.546 + 5.0 + (double)split * I * J * 4.0 * 2.0 / 1e6 / 6.851;  // (+ the ~5 us between two launches of one queue)
+}
+
+static double bf16_launch_us(int I, int J, long long K, int wi, int wj, long long cps, long long real_split, bool in_launch) {
   const int t = (wi == 2 ? 1 : 0) + (wj == 2 ? 2 : 0);  // 64x64, 128x64, 64x128, 128x128
   const double kChunk[4] = {1.171, 1.682, 1.644, 0.65}, kTail[4] = {5.662, 4.682, 3.924, 5.453};
   const double kResident[4] = {4, 3, 3, 2};
-  const double T0 = 4.3, RT = 3.178, cu_kb_per_us = 35.636, red0 = 1.546, red_mb_per_us = 6.851;
+  const double T0 = 4.3, RT = 3.178, cu_kb_per_us = 35.636;
   const long long ti = ceil_div(I, 64 * wi), tj = ceil_div(J, 64 * wj);
   const double wgs = (double)(ti * tj * real_split);
   double conc = wgs / kCUs;
@@ -1122,11 +1228,11 @@ static double bf16_launch_us(int I, int J, long long K, int wi, int wj, long lon
   double gens = wgs / (kCUs * kResident[t]);
   if (gens < 1.0) gens = 1.0;
   double us = T0 + RT + gens * ((double)(cps - 1) * t_chunk + kTail[t]);
-  if (real_split > 1) us += red0 + (double)real_split * I * J * 4.0 * 2.0 / 1e6 / red_mb_per_us;
-  return us;
+  return us + slice_sum_us(I, J, wi, wj, real_split, in_launch);
 }
 
-static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes, bool no_big_tile = false) {
+static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, size_t ws_bytes, bool no_big_tile = false,
+                      bool in_launch_sum = false) {
   const int cand[4][3] = {{2, 2, 2}, {2, 1, 3}, {1, 2, 3}, {1, 1, 4}};  // wi, wj, resident workgroups per CU
   const double peak_flops_per_us = 157.3e6;  // f32-input MFMA
   Plan best{2, 1, 1, (int)((K + gemm_kc(precision, 2, 1) - 1) / gemm_kc(precision, 2, 1))};
@@ -1150,11 +1256,14 @@ static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, s
       const long long real_split = (chunks + cps - 1) / cps;
       double cost;
       if (precision == PREC_BF16) {
-        cost = bf16_launch_us(I, J, K, wi, wj, cps, real_split);
+        cost = bf16_launch_us(I, J, K, wi, wj, cps, real_split, in_launch_sum);
       } else {
         double fill = (double)(tiles * real_split) / (double)(kCUs * resident);
         if (fill > 1.0) fill = 1.0;
-        const double partial_us = real_split > 1 ? 3.0 + 2.0 * (double)real_split * I * J * 4.0 / 2.5e6 : 0.0;
+        const double partial_us = real_split <= 1 ? 0.0
+                                  : (in_launch_sum && real_split <= kTicketMaxSplit)
+                                        ? slice_sum_us(I, J, wi, wj, real_split, true) + (double)real_split * I * J * 4.0 / 2.5e6
+                                        : 3.0 + 2.0 * (double)real_split * I * J * 4.0 / 2.5e6;
         // (round 5: a term for the operand bytes a tiling pulls through L2 -- tiles x K x (TI + TJ) x 4 B against 3-6 TB/s,
         //  170 MB for the 1152 x 1152 x 1024 layer in 64 x 64 tiles -- pushed the plan towards 128 x 128 and made every shape
         //  but two slower, the weight gradients by 2-3 x: config 2 6.67 -> 7.58 / 8.88 ms in bf16; gpurun_out/r05k.  Dropped.)
@@ -1172,12 +1281,49 @@ static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, s
 // scratch a GEMM of this shape may use for K slices (0 when it never splits)
 static size_t plan_workspace(int I, int J, long long K, int max_split, bool always_reduce) {
   size_t worst = 0;
-  for (int prec = 0; prec < 2; ++prec) {
-    const Plan p = plan_gemm(I, J, K, prec, max_split, ~(size_t)0);
-    const size_t bytes = (p.nsplit > 1 || always_reduce) ? (size_t)p.nsplit * I * J * sizeof(float) : 0;
-    worst = bytes > worst ? bytes : worst;
-  }
+  for (int prec = 0; prec < 2; ++prec)
+    for (int in_launch = 0; in_launch < (always_reduce ? 1 : 2); ++in_launch) {  // (either form of the slice sum may be the one that runs)
+      const Plan p = plan_gemm(I, J, K, prec, max_split, ~(size_t)0, false, in_launch != 0);
+      const size_t bytes = (p.nsplit > 1 || always_reduce) ? (size_t)p.nsplit * I * J * sizeof(float) : 0;
+      worst = bytes > worst ? bytes : worst;
+    }
   return worst;
+}
+
+// ---- ticket counters of the in-launch slice sums: one zero-initialised ring per device, handed out in pieces of one
+// counter per output tile.  A piece is zero again when its launch has finished (the last arrival resets it), so it may
+// be handed out again later -- and a launch captured into a HIP graph re-uses its piece on every replay.  The ring
+// (2^20 counters) is far longer than the tiles of all launches that can be in flight or captured in one step's graph
+// before the bump pointer comes round (a sliced product has few tiles: that is why it was sliced).  The first piece of
+// a device is allocated outside stream capture (hipMalloc + hipMemset are not stream operations); a first call that
+// arrives during a capture gets none and takes the two-launch form.
+constexpr size_t kTicketRing = (size_t)1 << 20;
+static unsigned *ticket_piece(size_t n, hipStream_t st) {
+  static std::mutex mu;
+  static unsigned *ring[64] = {};
+  static size_t next[64] = {};
+  int dev = 0;
+  if (n == 0 || n > kTicketRing / 4 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (ring[dev] == nullptr) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    unsigned *p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p), kTicketRing * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(p, 0, kTicketRing * sizeof(unsigned)) != hipSuccess) {
+      (void)hipGetLastError();
+      if (p) (void)hipFree(p);
+      return nullptr;
+    }
+    ring[dev] = p;
+  }
+  if (next[dev] + n > kTicketRing) next[dev] = 0;
+  unsigned *piece = ring[dev] + next[dev];
+  next[dev] += n;
+  return piece;
 }
 
 constexpr int kMaxSplitFwd = 16;    // forward / input-gradient products: K = channels
@@ -1196,7 +1342,8 @@ static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t 
   const bool vec_pair = (am == STAGE_VEC_RC && bm == STAGE_VEC_KC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_RC) ||
                         (am == STAGE_VEC_RC && bm == STAGE_VEC_RC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_KC);
   const bool kc_pair_f32 = precision != PREC_BF16 && am == STAGE_VEC_KC && bm == STAGE_VEC_KC;
-  Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, !vec_pair || kc_pair_f32);
+  const bool in_launch = REDUCE_MODE == 0 && fused_slice_sum();
+  Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, !vec_pair || kc_pair_f32, in_launch);
 #ifdef CL3D_GEMM_PLAN_ENV  // variant builds of scripts/micro/gemm_plan_sweep.py only: CL3D_GEMM_FORCE="wi,wj,split"
   if (const char *force = getenv("CL3D_GEMM_FORCE")) {
     int fwi = 0, fwj = 0, fsplit = 0;
@@ -1223,13 +1370,22 @@ static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t 
   }
   const long long blocks = (long long)a.tiles_i * a.tiles_j * p.nsplit;
   if (blocks > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "%s: grid too large", who);
+  a.tickets = nullptr;
+  a.vec_out = 0;
+  if (REDUCE_MODE == 0 && p.nsplit > 1 && p.nsplit <= kTicketMaxSplit && fused_slice_sum()) {
+    a.tickets = ticket_piece((size_t)a.tiles_i * a.tiles_j, st);
+    a.vec_out = J % 4 == 0 && final_out.sj == 1 && final_out.si % 4 == 0 &&
+                (final_out.fold_n == 0 || (final_out.fold_n % 4 == 0 && final_out.sb % 4 == 0)) &&
+                (reinterpret_cast<uintptr_t>(final_out.D) & 15u) == 0 && (reinterpret_cast<uintptr_t>(a.partial) & 15u) == 0 &&
+                (!final_out.ep_res || (reinterpret_cast<uintptr_t>(final_out.ep_res) & 15u) == 0);
+  }
   if (precision == PREC_BF16) {
     launch_modes<PREC_BF16>(a, p.wi, p.wj, (int)blocks, st);
   } else {
     launch_modes<PREC_F32>(a, p.wi, p.wj, (int)blocks, st);
   }
   int rc = check_launch(who);
-  if (rc != CL3D_OK || !reduce) return rc;
+  if (rc != CL3D_OK || !reduce || a.tickets != nullptr) return rc;
   if (REDUCE_MODE == 0 && p.nsplit <= 16 && J % 4 == 0 && final_out.sj == 1 && final_out.si % 4 == 0 &&
       (final_out.fold_n == 0 || (final_out.fold_n % 4 == 0 && final_out.sb % 4 == 0)) &&
       (reinterpret_cast<uintptr_t>(final_out.D) & 15u) == 0 &&

@@ -203,6 +203,20 @@ def forked_gradients(on):
         _FORKS[0] = old
 
 
+_STEP_STREAMS = {}
+
+
+def step_stream(device=None):
+    """One stream per device for warm-up AND capture of a training step (closerlook3d_amd.step_stream has the why)."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())
+    st = _STEP_STREAMS.get(dev)
+    if st is None:
+        st = _STEP_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _is_unjoined_capture_error(e):
     text = f"{type(e).__name__}: {e}".lower()
     return "unjoined" in text or "capture" in text and "join" in text

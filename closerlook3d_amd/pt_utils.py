@@ -151,9 +151,63 @@ def wait_ready(t):
 _CONSUMER_STREAM = None  # set by prefetch_geometry: the compute stream that will read what is produced ahead of it
 
 
+# ---- which ball-query implementation, by measurement.  For clouds of up to 4096 points two paths
+# apply -- `tile` (the cloud resident in one CU's LDS) and `cells` (cell grid through HBM scratch) -- and which is faster
+# depends on how many points fall inside the radius (the reference's ">3K candidates" regime,
+# masked_ordered_ball_query_gpu.cu:58-75): at the metric shape tile wins at a mean in-radius count of 1.5 K (53 against
+# 66 us) and loses at 4 K (260 against 203 us).  The density is a property of the data, the geometry of a stage is static
+# per (batch shape, radius): the first time a key is seen OUTSIDE a stream capture both paths are timed (two extra
+# launches each, once, with a host wait -- off the steady state) and the winner is kept; inside a capture, or with the
+# tuner off, an unseen key takes the library's choice.
+BQ_TUNE = True              # False: always the library's own choice by size (tests pin paths through CL3D_BQ_PATH instead)
+_BQ_PATH_TABLE = {}         # key -> (path, {path: microseconds})
+
+
+def bq_tune_key(device_index, B, M, N, nsample, radius):
+    """Sizes, and the radius in quarter-octave buckets: a stage's radius is a constant of the configuration, so equal
+    keys mean the same stage on same-shaped batches; different densities (another dataset, another radius) get their own."""
+    import math
+    bucket = int(round(4.0 * math.log2(radius))) if radius > 0 and math.isfinite(radius) else None
+    return (int(device_index), int(B), int(M), int(N), int(nsample), bucket)
+
+
+def _bq_path(query_xyz, support_xyz, query_mask, support_mask, radius, nsample):
+    """0 (library's choice) or the measured winner among the applicable paths for this key."""
+    if not (BQ_TUNE and query_xyz.is_cuda) or os.environ.get("CL3D_BQ_PATH"):
+        return 0
+    B, M, _ = query_xyz.shape
+    N = support_xyz.shape[1]
+    if B * M < 4096:
+        return 0  # (a few microseconds either way)
+    key = bq_tune_key(query_xyz.device.index or 0, B, M, N, nsample, radius)
+    hit = _BQ_PATH_TABLE.get(key)
+    if hit is not None:
+        return hit[0]
+    from . import _lib
+    mask = _lib.lib().cl3d_ball_query_paths(M, N, int(nsample))
+    cands = [p for p in (1, 2) if mask >> p & 1]
+    if len(cands) < 2 or torch.cuda.is_current_stream_capturing():
+        if len(cands) < 2:
+            _BQ_PATH_TABLE[key] = (0, {})
+        return 0
+    times = {}
+    for p in cands:
+        _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, path=p)  # warm
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, path=p)
+        e1.record()
+        e1.synchronize()
+        times[p] = e0.elapsed_time(e1) * 1e3
+    best = min(times, key=times.get)
+    _BQ_PATH_TABLE[key] = (best, times)
+    return best
+
+
 def _run_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample):
+    path = _bq_path(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
     if not (query_xyz.is_cuda and async_index()):
-        return _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+        return _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, path)
     dev = query_xyz.device
     main, side = torch.cuda.current_stream(dev), index_stream(dev)
     # inside prefetch_geometry the caller already IS on the index stream; the stream that will consume the result is
@@ -162,7 +216,7 @@ def _run_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, ns
     if main != side:
         side.wait_stream(main)  # the coordinates were produced on the caller's stream
     with torch.cuda.stream(side):
-        out = _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample)
+        out = _ext.masked_ordered_ball_query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, path)
         ev = torch.cuda.Event()
         ev.record(side)
     capturing = torch.cuda.is_current_stream_capturing()

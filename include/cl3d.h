@@ -37,7 +37,7 @@ extern "C" {
  * 3: round 4 -- cl3d_pwmlp_support_summary / cl3d_pwmlp_bwd_support_sum are gone (cl3d_pwmlp_bwd_support is the one
  * support-major pass again, same argument list as in version 2); cl3d_pwmlp_train_forward / _backward added (one call
  * per pass, csrc/pass.hip); cl3d_sphere_crop_assemble takes the capacity of the index list it is handed */
-#define CL3D_ABI_VERSION 4
+#define CL3D_ABI_VERSION 5
 
 #define CL3D_OK 0
 #define CL3D_E_INVALID (-1)     /* bad argument (null pointer, negative size, ...) */
@@ -88,6 +88,18 @@ int cl3d_masked_ordered_ball_query(const float *query_xyz, const float *support_
                                    int M, int N, float radius, int nsample, int32_t *idx,
                                    int32_t *idx_mask, void *ws, size_t ws_bytes,
                                    cl3d_stream_t stream);
+
+/* the same op on a named implementation: path 0 = the library's choice (identical to the call above), 1 = tile (the cloud
+ * resident in one CU's LDS; N, M <= 4096), 2 = cells (cell grid through HBM scratch), 3 = exhaustive scan.  Same bits
+ * from every path; CL3D_E_UNSUPPORTED when the path does not take the sizes.  cl3d_ball_query_paths: bit p set = path p
+ * applies.  Which of tile / cells is faster depends on the point density inside the radius (the reference's ">3K
+ * candidates" regime, masked_ordered_ball_query_gpu.cu:58-75) -- a property of the data: a caller with a static geometry
+ * times the applicable paths once and keeps the winner (closerlook3d_amd/pt_utils.py does). */
+int cl3d_masked_ordered_ball_query_path(int path, const float *query_xyz, const float *support_xyz,
+                                        const int32_t *query_mask, const int32_t *support_mask, int B, int M,
+                                        int N, float radius, int nsample, int32_t *idx, int32_t *idx_mask,
+                                        void *ws, size_t ws_bytes, cl3d_stream_t stream);
+int cl3d_ball_query_paths(int M, int N, int nsample);
 
 /* replaces group_points (group_points.cpp:17-40 + group_points_gpu.cu:13-33).
  * points [B,C,N], idx [B,M,K] -> out [B,C,M,K]. */

@@ -66,9 +66,10 @@ def main():
                          "stages' backward ALONE give wrong, replay-varying gradients (DESIGN 6; kept to reproduce it)")
     ap.add_argument("--debug-two-graphs", default="", help="two-graph reproducer, comma list of: sync_between (device sync between the replays "
                     "of graph A and graph B), own_pool (graph B in a memory pool of its own), fresh_streams (graph B forks "
-                    "onto streams graph A never saw), same_stream (warm-up and every capture on ONE explicit stream: autograd's "
+                    "onto streams graph A never saw), other_stream (the warm-up on a stream of its own, as before round 6: autograd's "
                     "AccumulateGrad nodes run on the stream that was current when a parameter was first used -- the warm-up's -- "
-                    "which is otherwise a third branch of every captured backward pass)")
+                    "which is then a third branch of every captured backward pass; with --overlap-forks b this is the layout "
+                    "that gives replay-varying gradients)")
     ap.add_argument("--fork-mode", default="reuse", choices=["reuse", "serial_side", "after", "probe"],
                     help="two-graph reproducer: how a forked pair of gradient products is laid out (reuse = shipped)")
     ap.add_argument("--fork-only", default="", help="debug: comma list of fork episodes (1-based, counted from graph B's capture) that fork")
@@ -270,9 +271,9 @@ def main():
         step in between: it must walk the autograd graph -- and read the cut gradients -- that graph A's capture built."""
         if warm is None:
             warm = fn
-        same = "same_stream" in set(args.debug_two_graphs.split(","))
+        same = "other_stream" not in set(args.debug_two_graphs.split(","))  # (round 6: one stream is the default)
         if same and "s" not in _one_stream:
-            _one_stream["s"] = torch.cuda.Stream()
+            _one_stream["s"] = closerlook3d_amd.step_stream(dev)
         if warm:
             side = _one_stream["s"] if same else torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

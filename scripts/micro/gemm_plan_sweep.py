@@ -39,8 +39,9 @@ def build():
     print("built", LIB)
 
 
-def run(reps, precisions, point_products=False):
+def run(reps, precisions, point_products=False, fused_sum="1"):
     os.environ["CL3D_LIB"] = LIB
+    os.environ["CL3D_GEMM_FUSED_SUM"] = fused_sum  # 1: K slices summed inside the launch (round 6), 0: by a launch of their own
     import torch
     sys.path.insert(0, ROOT)
     from closerlook3d_amd import _lib
@@ -106,14 +107,14 @@ def run(reps, precisions, point_products=False):
             for name, fn in products.items():
                 os.environ.pop("CL3D_GEMM_FORCE", None)
                 auto = timed(fn)
-                print(json.dumps({"layer": [C, n, Co], "prec": prec_name, "product": name, "plan": "auto", "us": round(auto, 2)}), flush=True)
+                print(json.dumps({"layer": [C, n, Co], "prec": prec_name, "product": name, "plan": "auto", "fused_sum": fused_sum, "us": round(auto, 2)}), flush=True)
                 splits = [1, 2, 3, 4, 6, 8, 12, 16] if not name.endswith("bwd_weight") else [1, 2, 4, 8, 16, 32, 64, 128, 256]
                 for wi, wj in ((1, 1), (2, 1), (1, 2), (2, 2)):
                     row = {}
                     for sp in splits:
                         os.environ["CL3D_GEMM_FORCE"] = f"{wi},{wj},{sp}"
                         row[sp] = round(timed(fn), 2)
-                    print(json.dumps({"layer": [C, n, Co], "prec": prec_name, "product": name, "tile": [wi, wj], "us_by_split": row}), flush=True)
+                    print(json.dumps({"layer": [C, n, Co], "prec": prec_name, "product": name, "tile": [wi, wj], "fused_sum": fused_sum, "us_by_split": row}), flush=True)
     os.environ.pop("CL3D_GEMM_FORCE", None)
 
 
@@ -124,8 +125,9 @@ if __name__ == "__main__":
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--precisions", default="bf16")
     ap.add_argument("--point", action="store_true", help="the PointWiseMLP per-point products instead of the convolutions")
+    ap.add_argument("--fused-sum", default="1", choices=["0", "1"], help="how K slices are summed (1 = inside the launch)")
     a = ap.parse_args()
     if a.build:
         build()
     if a.run:
-        run(a.reps, a.precisions.split(","), a.point)
+        run(a.reps, a.precisions.split(","), a.point, a.fused_sum)

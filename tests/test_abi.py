@@ -39,7 +39,7 @@ def test_library_loads_and_reports_version(libpath):
     import torch  # noqa: F401  (binds the HIP runtime first, as the product does)
     h = ctypes.CDLL(libpath)
     from closerlook3d_amd import _lib
-    assert h.cl3d_abi_version() == _lib.ABI_VERSION == 4  # bumped with round 5's new entry points (include/cl3d.h)
+    assert h.cl3d_abi_version() == _lib.ABI_VERSION == 5  # bumped with round 6's new entry points (include/cl3d.h)
     assert _lib.header_abi_version() == _lib.ABI_VERSION  # the package's constant is the header's
     h.cl3d_last_error_string.restype = ctypes.c_char_p
     assert isinstance(h.cl3d_last_error_string(), bytes)

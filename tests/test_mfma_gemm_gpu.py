@@ -206,6 +206,51 @@ def test_conv1x1_matches_conv1d(B, C, N, Co, prec):
         assert _rel(y, ref.double()) <= 2e-5
 
 
+@pytest.mark.parametrize("B,C,N,Co", [(16, 1152, 16, 2304), (16, 2304, 16, 1152), (2, 1152, 64, 576), (16, 576, 62, 288),
+                                      (3, 1000, 37, 130)])
+@pytest.mark.parametrize("prec", [0, 1])
+def test_k_slices_summed_inside_the_launch(B, C, N, Co, prec):
+    """Round 6: the K slices of a deep-stage product are summed by the workgroup that arrives last
+    at each output tile, in slice order -- no second launch.  Held here: (a) the inference epilogue (per-row affine map,
+    residual, ReLU: cl3d_conv1x1_bn_act_fwd) goes through that sum unchanged, against float64; (b) one bit pattern over
+    40 launches, half of them racing a second product on another stream (arrival order differs, the sum's order does
+    not), which also shows that every ticket counter is back at zero when a launch ends; (c) N = 62 / 37 (N % 4 != 0)
+    takes the element-wise output path of the same sum."""
+    lib = _lib.lib()
+    g = torch.Generator(device="cpu").manual_seed(7 * C + Co)
+    x = torch.randn(B, C, N, generator=g).to(_dev())
+    W = (torch.randn(Co, C, generator=g) / (C ** 0.5)).to(_dev())
+    scale = (0.5 + torch.rand(Co, generator=g)).to(_dev())
+    shift = torch.randn(Co, generator=g).to(_dev())
+    res = torch.randn(B, Co, N, generator=g).to(_dev())
+    ws_bytes = lib.cl3d_workspace_bytes(15, B, N, Co, 0, C)
+    assert ws_bytes > 0, "this shape was meant to be cut along K"
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=_dev())
+    ws2 = torch.empty(ws_bytes, dtype=torch.uint8, device=_dev())
+    rnd = (lambda t: t.double()) if prec == 0 else _bf16_round
+    want = torch.relu(torch.einsum("oc,bcn->bon", rnd(W), rnd(x)) * scale.double()[None, :, None] + shift.double()[None, :, None]
+                      + res.double())
+    side = torch.cuda.Stream()
+    y2 = torch.empty(B, Co, N, device=_dev())
+    first = None
+    for it in range(40):
+        y = torch.full((B, Co, N), float("nan"), device=_dev())
+        if it % 2:  # a second sliced product beside it on another stream: the two share the chip, tiles finish in another order
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                _lib.check(lib.cl3d_conv1x1_fwd(_p(x), _p(W), B, C, N, Co, prec, _p(y2), _p(ws2), ws_bytes, side.cuda_stream))
+        _lib.check(lib.cl3d_conv1x1_bn_act_fwd(_p(x), _p(W), _p(scale), _p(shift), _p(res), 1, B, C, N, Co, prec, _p(y),
+                                               _p(ws), ws_bytes, _st()))
+        torch.cuda.current_stream().wait_stream(side)
+        if first is None:
+            first = y.clone()
+            assert _rel(y, want) <= 2 * TOL
+        else:
+            assert torch.equal(y, first), f"launch {it}: the sliced product is not bit-reproducible"
+    plain = torch.einsum("oc,bcn->bon", rnd(W), rnd(x))
+    assert _rel(y2, plain) <= TOL
+
+
 def test_bad_arguments_are_refused():
     lib = _lib.lib()
     assert lib.cl3d_pwmlp_point_gemm_fwd(None, None, 1, 8, 16, 4, 0, None, None, None, None, 0, None) == -1
