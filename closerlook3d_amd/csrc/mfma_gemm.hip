@@ -366,29 +366,32 @@ struct StagePick<PREC_BF16, TR, KC> {
 };
 
 // ---- K slices summed inside the launch.  Called by every workgroup of a sliced product after its
-// partial tile is in memory.  Release / acquire at device scope around the ticket: the partial stores are made visible
-// (the L2 of this XCD written back) before the ticket is drawn, and the workgroup that draws the last ticket drops what
-// its XCD's L2 may still hold of the scratch from an earlier launch before it reads the other slices.
+// partial tile has been STORED AT DEVICE SCOPE (write_tiles kind 2).  No fence anywhere: the barrier below waits for every
+// thread's stores to be acknowledged (vmcnt(0)), a device-scope store is acknowledged when it is visible to the other
+// XCDs, the ticket is a device-scope atomic issued after that barrier, and the workgroup that draws the last ticket reads
+// the other slices with device-scope loads (which do not hit whatever its own XCD's L2 still holds of the scratch).
+__device__ __forceinline__ float ld_device_scope(const float *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int TI, int TJ>
 __device__ __forceinline__ void sum_slices_by_last_arrival(const GemmArgs &a, int i0, int j0, int tile) {
   __shared__ int s_last;
-  __threadfence();
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned drawn = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned drawn = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = drawn == (unsigned)(a.nsplit - 1);
     if (last) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = last;
   }
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   const int I = a.A.R, J = a.B.R;
   const long long IJ = (long long)I * J;
   const OutMap &o = a.out;
-  if (a.vec_out) {  // J % 4 == 0: a float4 never straddles the matrix edge, a row or a cloud
-    // a thread's NE float4 pieces of the tile are loaded together for every slice: NE independent 16-byte loads in
-    // flight per thread (4 / 8 / 16 KB ... 64 KB per workgroup), the slices added one after the other
+  if (a.vec_out) {  // J % 4 == 0: four consecutive j never straddle the matrix edge, a row or a cloud
+    // a thread's NE four-element pieces of the tile are requested together for every slice (4 NE independent loads in
+    // flight per thread), the slices added one after the other: 0, 1, 2, ...
     constexpr int NE = TI * TJ / 4 / 256;
     const float *src[NE];
     float4 acc[NE];
@@ -398,12 +401,16 @@ __device__ __forceinline__ void sum_slices_by_last_arrival(const GemmArgs &a, in
       const int q = e * 256 + threadIdx.x, i = i0 + q / (TJ / 4), j = j0 + 4 * (q % (TJ / 4));
       live[e] = i < I && j < J;
       src[e] = a.partial + (live[e] ? (long long)i * J + j : 0);
-      acc[e] = *reinterpret_cast<const float4 *>(src[e]);
+      acc[e] = make_float4(ld_device_scope(src[e]), ld_device_scope(src[e] + 1), ld_device_scope(src[e] + 2),
+                           ld_device_scope(src[e] + 3));
     }
     for (int p = 1; p < a.nsplit; ++p) {
       float4 v[NE];
 #pragma unroll
-      for (int e = 0; e < NE; ++e) v[e] = *reinterpret_cast<const float4 *>(src[e] + (size_t)p * IJ);
+      for (int e = 0; e < NE; ++e) {
+        const float *sp = src[e] + (size_t)p * IJ;
+        v[e] = make_float4(ld_device_scope(sp), ld_device_scope(sp + 1), ld_device_scope(sp + 2), ld_device_scope(sp + 3));
+      }
 #pragma unroll
       for (int e = 0; e < NE; ++e) {
         acc[e].x += v[e].x; acc[e].y += v[e].y; acc[e].z += v[e].z; acc[e].w += v[e].w;
@@ -435,8 +442,8 @@ __device__ __forceinline__ void sum_slices_by_last_arrival(const GemmArgs &a, in
       const int i = i0 + q / TJ, j = j0 + q % TJ;
       if (i >= I || j >= J) continue;
       const float *src = a.partial + (long long)i * J + j;
-      float acc = src[0];
-      for (int p = 1; p < a.nsplit; ++p) acc += src[(size_t)p * IJ];
+      float acc = ld_device_scope(src);
+      for (int p = 1; p < a.nsplit; ++p) acc += ld_device_scope(src + (size_t)p * IJ);
       out_store(o, i, out_col(o, j), acc);
     }
   }
@@ -617,22 +624,35 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
   const int I = a.A.R, J = a.B.R;
   const bool part = a.nsplit > 1;
   float *P = part ? a.partial + (long long)z * I * J : nullptr;
+  // kind 0: the result through the output map; 1: this slice's partial tile (summed by a later launch: plain stores, the
+  // kernel boundary makes them visible); 2: the same for the in-launch sum -- device-scope stores (written through this
+  // XCD's L2: another XCD's workgroup will read them inside this launch, and a fence per workgroup -- an L2 write-back and
+  // invalidate each -- serialises on the L2: 63 -> 180 us for 288 .. 2304 workgroups, profiles/r06/gemm_plan_sweep_*fence*)
+  auto write_tiles = [&](auto kind) {
 #pragma unroll
-  for (int x = 0; x < WI; ++x)
+    for (int x = 0; x < WI; ++x)
 #pragma unroll
-    for (int y = 0; y < WJ; ++y) {
-      const int j = j0 + wj0 + 32 * y + lr;
-      const long long joff = part ? j : out_col(a.out, j);
+      for (int y = 0; y < WJ; ++y) {
+        const int j = j0 + wj0 + 32 * y + lr;
+        const long long joff = decltype(kind)::value ? j : out_col(a.out, j);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int i = i0 + wi0 + 32 * x + (e & 3) + 8 * (e >> 2) + 4 * lh;
-        if (i < I && j < J) {
-          if (part) P[(long long)i * J + j] = acc[x][y][e];
-          else out_store(a.out, i, joff, acc[x][y][e]);
+        for (int e = 0; e < 16; ++e) {
+          const int i = i0 + wi0 + 32 * x + (e & 3) + 8 * (e >> 2) + 4 * lh;
+          if (i < I && j < J) {
+            if constexpr (decltype(kind)::value == 2)
+              __hip_atomic_store(P + (long long)i * J + j, acc[x][y][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else if constexpr (decltype(kind)::value == 1) P[(long long)i * J + j] = acc[x][y][e];
+            else out_store(a.out, i, joff, acc[x][y][e]);
+          }
         }
       }
-    }
-  if (part && a.tickets != nullptr) sum_slices_by_last_arrival<TI, TJ>(a, i0, j0, ti * a.tiles_j + tj);
+  };
+  if (!part) write_tiles(std::integral_constant<int, 0>{});
+  else if (a.tickets == nullptr) write_tiles(std::integral_constant<int, 1>{});
+  else {
+    write_tiles(std::integral_constant<int, 2>{});
+    sum_slices_by_last_arrival<TI, TJ>(a, i0, j0, ti * a.tiles_j + tj);
+  }
 }
 
 // ---- slice-ordered sum of the split-K partials.  A workgroup owns 16 consecutive elements of the I x J tile; its 16

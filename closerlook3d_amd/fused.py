@@ -77,9 +77,12 @@ def _fork_join(device, side_fn, main_fn):
     DECLARED whole-step HIP graph is captured (whole_step_capture(): forward and backward in one capture), where the
     fork becomes two parallel branches of the graph; everywhere else -- eager launches, a capture that holds a backward
     pass alone (torch.cuda.make_graphed_callables) -- the two run one after the other on the caller's stream.  A forked
-    pair inside a graph that holds ONLY a backward pass, reading tensors another capture allocated, gave replay-varying
-    gradients in round 4 (DESIGN 6 "Round 4 (b)", not root-caused): that configuration is refused here, not left to a
-    script's flag.
+    pair inside a graph that holds ONLY a backward pass gave replay-varying gradients in rounds 3-5; round 6 traced it to
+    a THIRD concurrent branch in that graph: autograd runs every AccumulateGrad node on the stream that was current when
+    the parameter was first used -- the warm-up's, when the warm-up has a stream of its own, which is how
+    torch.cuda.make_graphed_callables and the usual torch.cuda.graph recipe work.  With warm-up and capture on ONE stream
+    (closerlook3d_amd.step_stream) the same forks are exact (profiles/r06/two_graph_repeat_check.txt).  A capture
+    this module knows nothing about may still have that third branch, so an undeclared capture stays single-stream here.
     `side_fn` is the LONGER piece (callers pass the weight gradient: product + slice reduce) and is enqueued FIRST: the
     HIP runtime lays a graph out depth-first along each node's first-captured dependent (that one inherits the node's
     queue, the next one goes to the other queue; scripts/micro/graph_queues.hip), so the piece captured first -- and the
@@ -192,9 +195,10 @@ def forked_gradients(on):
     (_fork_join).  Default (no override): only inside a capture declared with whole_step_capture() -- a graph that holds
     forward AND backward.  forked_gradients(True) extends it to the capture it wraps: exact, as measured, for a graph
     that holds the forward pass and PART of its backward (scripts/bench_backbone.py --overlap, graph A);
-    a graph that holds a backward pass ALONE and reads tensors another capture allocated gave wrong, replay-varying
-    gradients with such forks in it (not root-caused) -- do not use it there.  forked_gradients(False) takes
-    the forks out of a declared whole-step capture."""
+    a graph that holds a backward pass ALONE gave wrong, replay-varying gradients with such forks in it whenever the
+    warm-up had run on a stream of its own (autograd's AccumulateGrad stream then is a third branch of that graph)
+    -- use it there only with warm-up and capture on closerlook3d_amd.step_stream().  forked_gradients(False) takes the
+    forks out of a declared whole-step capture."""
     old = _FORKS[0]
     _FORKS[0] = None if on is None else bool(on)
     try:

@@ -62,7 +62,7 @@ def main():
                     help="--overlap: which of the two graphs keeps the side-stream forks (default a; b / both = the "
                          "configuration that gives wrong early-stage gradients, kept to reproduce it)")
     ap.add_argument("--unsafe", action="store_true",
-                    help="required by --overlap-forks b|both: forked gradient products inside the graph that holds the early "
+                    help="required by --overlap-forks b|both WITH --debug-two-graphs other_stream: forked gradient products inside the graph that holds the early "
                          "stages' backward ALONE give wrong, replay-varying gradients (DESIGN 6; kept to reproduce it)")
     ap.add_argument("--debug-two-graphs", default="", help="two-graph reproducer, comma list of: sync_between (device sync between the replays "
                     "of graph A and graph B), own_pool (graph B in a memory pool of its own), fresh_streams (graph B forks "
@@ -91,12 +91,14 @@ def main():
     ap.add_argument("--layerwise", action="store_true",
                     help="A/B: PointWiseMLP bottlenecks layer by layer (the activated tensors between their layers materialised)")
     args = ap.parse_args()
-    if args.overlap_forks in ("b", "both") and not args.unsafe:
-        raise SystemExit("--overlap-forks %s is the KNOWN-BAD configuration: a forked pair of gradient products inside graph B "
-                         "(the early stages' backward alone, reading tensors graph A's capture allocated) gives wrong, "
-                         "replay-varying early-stage gradients -- 43 + singletons of 200 replays in profiles/r04/"
-                         "two_graph_repeat_check.txt; mechanism not root-caused (DESIGN 6).  Add --unsafe to run it anyway, "
-                         "e.g. with --repeat-check 200." % args.overlap_forks)
+    if args.overlap_forks in ("b", "both") and "other_stream" in args.debug_two_graphs.split(",") and not args.unsafe:
+        raise SystemExit("--overlap-forks %s together with --debug-two-graphs other_stream is the KNOWN-BAD layout: a forked pair of "
+                         "gradient products inside graph B (the early stages' backward alone) WHILE autograd's AccumulateGrad nodes "
+                         "run on the warm-up's stream -- a third concurrent branch of that graph -- gives wrong, replay-varying "
+                         "early-stage gradients (38-114 + singletons of 200 replays, profiles/r06/two_graph_repeat_check.txt; "
+                         "with warm-up and capture on ONE stream, the default since round 6, the same forks are exact over "
+                         "5 x 1000 replays: DESIGN 6).  Add --unsafe to run it anyway, e.g. with --repeat-check 200."
+                         % args.overlap_forks)
     kind, B, N, radius, dl, nsamples, npoints, width = CONFIGS[args.config]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -83,13 +83,13 @@ timeout 600 python scripts/bench_backbone.py --gpus 2 --config partnet_adaptive 
 timeout 600 python scripts/bench_backbone.py --gpus 2 --config partnet_adaptive --overlap 2>/dev/null | grep '^{' | tail -1 | cut -c1-500 | tee -a $OUT/summary.txt
 timeout 600 python bench.py --gpus 2 --no-cpu-baseline --no-kernel-roofline --backbone on 2>/dev/null | grep '^{' | tail -1 | tee $OUT/bench_two_ranks_one_device.json | cut -c1-1500 | tee -a $OUT/summary.txt
 echo "== two-graph step, 200 replays without the update: distinct bit patterns of the exchanged gradients (DESIGN 6)" | tee -a $OUT/summary.txt
-for cfg in "" "--overlap --overlap-forks none" "--overlap --overlap-forks a" "--overlap --overlap-forks b --unsafe"; do
+for cfg in "" "--overlap --overlap-forks none" "--overlap --overlap-forks a" "--overlap --overlap-forks b" "--overlap --overlap-forks both" "--overlap --overlap-forks b --debug-two-graphs other_stream --unsafe"; do
   timeout 300 python scripts/bench_backbone.py --gpus 2 --config modelnet_small --warmup 1 --head $cfg --repeat-check 200 2>/dev/null | grep repeat_check | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); v=d['varying_parameters']
 print('[$cfg]', 'late', d['distinct_late'][:4], 'early', d['distinct_early'][:4], 'varying parameters', len(v))" | tee -a $OUT/two_graph_repeat_check.txt | tee -a $OUT/summary.txt
 done
-timeout 60 python scripts/bench_backbone.py --gpus 2 --config modelnet_small --head --overlap --overlap-forks b 2>&1 | tail -2 | cut -c1-400 | sed 's/^/without --unsafe: /' | tee -a $OUT/two_graph_repeat_check.txt | tee -a $OUT/summary.txt
+timeout 60 python scripts/bench_backbone.py --gpus 2 --config modelnet_small --head --overlap --overlap-forks b --debug-two-graphs other_stream 2>&1 | tail -2 | cut -c1-400 | sed 's/^/without --unsafe: /' | tee -a $OUT/two_graph_repeat_check.txt | tee -a $OUT/summary.txt
 echo "== dataset-side grid subsampling, voting, sphere crops" | tee -a $OUT/summary.txt
 timeout 600 python scripts/bench_dataset_grid.py 2>/dev/null | tee $OUT/bench_dataset_grid.json | tee -a $OUT/summary.txt
 timeout 300 python scripts/bench_voting.py 2>/dev/null | tee $OUT/bench_voting.json | tee -a $OUT/summary.txt
