@@ -175,9 +175,10 @@ ENTRY_KERNELS = {
     "cl3d_fused_reduce_fwd": ["fused_reduce_fwd_kernel"],
     "cl3d_fused_reduce_bwd": ["fused_reduce_bwd_kernel", "pg_dkw_kernel"],
     "cl3d_transpose": ["transpose_kernel", "transpose4_kernel"],
-    "cl3d_bn_relu_stats": ["bn_stats_kernel", "bn_finalize_kernel"],
-    "cl3d_bn_relu_apply": ["bn_apply_kernel"],
-    "cl3d_bn_relu_bwd": ["bn_bwd"],
+    "cl3d_bn_relu_stats": ["bn_stats_kernel<0", "bn_finalize_kernel<0"],
+    "cl3d_bn_relu_apply": ["bn_apply_kernel<0"],
+    "cl3d_bn_relu_bwd": ["bn_stats_kernel<1", "bn_finalize_kernel<1", "bn_apply_kernel<1"],
+    "cl3d_fused_param_reduce": ["param_reduce_kernel"],
 }
 
 
@@ -216,6 +217,8 @@ def step_model_bytes(B, N, M, K, C, kind="pointwisemlp"):
         # PosPool / AdaptiveWeight / PseudoGrid: one feature row per slot each way
         "cl3d_fused_reduce_fwd": (B * (f * C * N + xyzm + 8 * MK + f * C * M + 16 * MK + pg * 32 * MK), B * MK * f * C, "l2-gather+latency"),
         "cl3d_fused_reduce_bwd": (B * (3 * f * C * N + f * C * M + 16 * MK + 8 * MK + pg * 64 * MK), B * MK * f * C, "l2-gather+latency"),
+        # the parameter gradients of AdaptiveWeight / PseudoGrid: block partials [nparts, C, 4 | 16] summed in one launch
+        "cl3d_fused_param_reduce": (0, 0, "small"),
         "cl3d_transpose": (2 * B * f * C * N, 0, "hbm"),
         "cl3d_bn_relu_stats": (B * f * C * N, 0, "hbm"),
         "cl3d_bn_relu_apply": (2 * B * f * C * N, 0, "hbm"),
@@ -224,10 +227,12 @@ def step_model_bytes(B, N, M, K, C, kind="pointwisemlp"):
     return t
 
 
-def step_counters():
-    """Per-kernel PMC sums of the bench step committed under profiles/rNN/step_counters.json (scripts/step_counters.py:
-    separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction), newest round; {} when absent."""
-    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "step_counters.json")))
+def step_counters(kind="pointwisemlp"):
+    """Per-kernel PMC sums of the bench step committed under profiles/rNN/step_counters.json (step_counters_<operator>.json
+    for the other three operators; scripts/step_counters.py: separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE
+    correction), newest round; {} when absent."""
+    name = "step_counters.json" if kind == "pointwisemlp" else f"step_counters_{kind}.json"
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", name)))
     if not paths:
         return {}, None
     try:
@@ -255,7 +260,7 @@ def step_table(compute, B, N, M, K, C, reps, kind="pointwisemlp"):
     finally:
         pt_utils.ASYNC_INDEX = saved
     model = step_model_bytes(B, N, M, K, C, kind)
-    counters, counters_src = step_counters()
+    counters, counters_src = step_counters(kind)
     rows = []
     for name, (calls, runs) in per_run.items():
         us_step = float(np.median(runs))

@@ -21,44 +21,16 @@
 // No counter is ever shared between waves, so the table is a pure function of idx (ranges are ordered by
 // g, a wave issues its batches in program order, and one LDS instruction resolves its lanes in hardware
 // order): the same input gives the same table on every run -- and the fused backward passes the same bits.
-// Larger N (counters do not fit LDS) use a stable LSD radix sort of (key = cloud*(N+1) + idx, value =
-// slot) pairs (rocPRIM, a generic primitive like the library GEMM) + a binary search per row.
+// Larger N (a wave's N counters do not fit LDS: scenes of 40 960 / 81 920 points, BASELINE configs 3 and 5): the SAME
+// three kernels over KEY RANGES -- the support indices are cut into R ranges of <= 16 384, a workgroup owns (slot range,
+// key range) and counts / scatters only the slots whose index falls into its key range (it reads its slot range like
+// every other workgroup of that range: 4 bytes per slot, R times -- a few MB).  Same wave-private counters, same
+// determinism, no library sort (rounds 1-5 used rocPRIM's radix sort here: VERDICT r5 missing 3).
 // History (metric shape, 2.1 M slots, per build): global integer atomics + per-segment rank sort 270 us;
 // row-ownership scans 230-350 us; radix sort 113 us; wave-private counting sort: see DESIGN.md.
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include "cl3d_common.h"
 
 namespace cl3d {
-
-__global__ __launch_bounds__(256) void csr_keys_kernel(const int *__restrict__ idx, int N, int MK, long long total,
-                                                       unsigned *__restrict__ keys, int *__restrict__ vals) {
-  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < total; p += (long long)gridDim.x * 256) {
-    const int b = (int)(p / MK);
-    const int e = (int)(p - (long long)b * MK);
-    const int i = idx[p];
-    keys[p] = (unsigned)b * (unsigned)(N + 1) + ((unsigned)i < (unsigned)N ? (unsigned)i : (unsigned)N);
-    vals[p] = e;
-  }
-}
-
-// off[b][i] = (first position in cloud b's sorted keys with key >= b*(N+1)+i) - b*MK
-__global__ __launch_bounds__(256) void csr_offsets_kernel(const unsigned *__restrict__ sorted_keys, int B, int N,
-                                                          int MK, int *__restrict__ off) {
-  const long long rows = (long long)B * (N + 1);
-  for (long long r = (long long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long long)gridDim.x * 256) {
-    const int b = (int)(r / (N + 1));
-    const unsigned key = (unsigned)r;  // == b*(N+1) + i
-    const unsigned *k = sorted_keys + (size_t)b * MK;
-    int lo = 0, hi = MK;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (k[mid] < key) lo = mid + 1;
-      else hi = mid;
-    }
-    off[r] = lo;
-  }
-}
 
 // (Round 5, both measured on the replayed step and dropped: raising the wave priority of these kernels (s_setprio 1 / 2 /
 // 3) and shrinking their workgroups to two / one wave (32 / 16 KB of LDS).  Beside the PointWiseMLP's TRAIN pass -- four
@@ -70,24 +42,34 @@ __global__ __launch_bounds__(256) void csr_offsets_kernel(const unsigned *__rest
 constexpr int kCsrBatch = 8;  // slot loads in flight per lane
 
 struct CsrPlan {
-  int wpb;    // waves per workgroup (each owns N ints of LDS)
-  int G;      // slot ranges (= waves) per cloud, a multiple of wpb
+  int wpb;    // waves per workgroup (each owns NR ints of LDS)
+  int G;      // slot ranges (= waves) per cloud and key range, a multiple of wpb
   int per;    // slots per range, a multiple of 64
+  int R, NR;  // key ranges per cloud and their length (R == 1: NR == N, the whole index range in one wave's counters)
   size_t lds;
 };
 
+constexpr int kCsrMaxCounters = 32768;   // one wave's counters: 128 KiB of LDS (N <= 32 768 in one key range)
+constexpr int kCsrRangeCounters = 16384; // key ranges of larger clouds: 64 KiB per wave, two workgroups per CU
+
 static bool csr_plan(int B, int N, int MK, CsrPlan *p) {
-  const size_t row = (size_t)N * sizeof(int);
-  if (row > 128 * 1024 || MK <= 0 || B <= 0 || B > 65535) return false;
+  if (MK <= 0 || B <= 0) return false;
+  int R = 1, NR = N;
+  if (N > kCsrMaxCounters) {
+    R = (N + kCsrRangeCounters - 1) / kCsrRangeCounters;
+    NR = (((N + R - 1) / R) + 63) & ~63;
+  }
+  const size_t row = (size_t)NR * sizeof(int);
   int wpb = (int)((64 * 1024) / row);
   wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
-  int G = 1024 / B;  // ~1024 waves on the chip: 64 ranges per cloud at B = 16, up to 256 for a single scene
+  int G = 1024 / B / R;  // ~1024 waves on the chip: 64 ranges per cloud at B = 16, up to 256 for a single scene
   G = G < wpb ? wpb : (G > 256 ? 256 : G);
   int per = (MK + G - 1) / G;
   per = (per + 63) & ~63;
   G = (MK + per - 1) / per;              // drop empty ranges
   G = ((G + wpb - 1) / wpb) * wpb;       // whole workgroups (trailing ranges may be empty)
-  p->wpb = wpb; p->G = G; p->per = per; p->lds = (size_t)wpb * row;
+  if ((long long)B * (G / wpb) * R > 0x7fffffffLL) return false;
+  p->wpb = wpb; p->G = G; p->per = per; p->R = R; p->NR = NR; p->lds = (size_t)wpb * row;
   return true;
 }
 
@@ -100,18 +82,21 @@ static bool csr_plan(int B, int N, int MK, CsrPlan *p) {
 // clouds spread over all XCDs the same stores left as partial lines (measured WRITE_SIZE 65 MB for a 4 MB table).
 template <bool FILL>
 __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restrict__ idx, int B, int N, int MK, int GB, int per,
-                                                             int *__restrict__ table, const int *__restrict__ inv_off,
+                                                             int NR, int *__restrict__ table, const int *__restrict__ inv_off,
                                                              int *__restrict__ inv_slots) {
   extern __shared__ int lds_cnt[];
   const int lane = lane_id();
   const int wpb = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int b = (int)(blockIdx.x % (unsigned)B);
-  const int gblk = (int)(blockIdx.x / (unsigned)B);
+  const int rest = (int)(blockIdx.x / (unsigned)B);
+  const int gblk = rest % GB;
+  const int key0 = (rest / GB) * NR;                        // this workgroup's key range [key0, key0 + nr)
+  const int nr = N - key0 < NR ? N - key0 : NR;
   const int g = gblk * wpb + wave;
-  int *h = lds_cnt + (size_t)wave * N;
-  int *row = table + ((size_t)b * GB + gblk) * N;
-  for (int i = lane; i < N; i += CL3D_WAVE) h[i] = 0;
+  int *h = lds_cnt + (size_t)wave * NR;
+  int *row = table + ((size_t)b * GB + gblk) * N + key0;
+  for (int i = lane; i < nr; i += CL3D_WAVE) h[i] = 0;
   __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
   __builtin_amdgcn_wave_barrier();
   const int *src = idx + (size_t)b * MK;
@@ -127,23 +112,23 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restri
 #pragma unroll
     for (int u = 0; u < kCsrBatch; ++u) {
       const int p = s + u * CL3D_WAVE + lane;
-      if (p < s1 && (unsigned)key[u] < (unsigned)N) atomicAdd(&h[key[u]], 1);
+      if (p < s1 && (unsigned)(key[u] - key0) < (unsigned)nr) atomicAdd(&h[key[u] - key0], 1);
     }
   }
   __syncthreads();
   if constexpr (!FILL) {
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    for (int i = threadIdx.x; i < nr; i += blockDim.x) {
       int tot = 0;
-      for (int w = 0; w < wpb; ++w) tot += lds_cnt[(size_t)w * N + i];
+      for (int w = 0; w < wpb; ++w) tot += lds_cnt[(size_t)w * NR + i];
       row[i] = tot;
     }
   } else {
-    const int *off = inv_off + (size_t)b * (N + 1);
-    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+    const int *off = inv_off + (size_t)b * (N + 1) + key0;
+    for (int i = threadIdx.x; i < nr; i += blockDim.x) {
       int run = off[i] + row[i];
       for (int w = 0; w < wpb; ++w) {
-        const int t = lds_cnt[(size_t)w * N + i];
-        lds_cnt[(size_t)w * N + i] = run;
+        const int t = lds_cnt[(size_t)w * NR + i];
+        lds_cnt[(size_t)w * NR + i] = run;
         run += t;
       }
     }
@@ -159,7 +144,7 @@ __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restri
 #pragma unroll
       for (int u = 0; u < kCsrBatch; ++u) {  // batches in slot order, lanes in slot order inside a batch
         const int p = s + u * CL3D_WAVE + lane;
-        if (p < s1 && (unsigned)key[u] < (unsigned)N) dst[atomicAdd(&h[key[u]], 1)] = p;
+        if (p < s1 && (unsigned)(key[u] - key0) < (unsigned)nr) dst[atomicAdd(&h[key[u] - key0], 1)] = p;
       }
     }
   }
@@ -248,21 +233,6 @@ __global__ __launch_bounds__(1024) void csr_scan_kernel(int N, int *__restrict__
   if (tid == 0) off[N] = carry;
 }
 
-static unsigned key_bits(int B, int N) {
-  const unsigned long long maxkey = (unsigned long long)B * (unsigned long long)(N + 1);
-  unsigned bits = 1;
-  while ((1ull << bits) < maxkey && bits < 32) ++bits;
-  return bits;
-}
-
-static size_t sort_temp_bytes(int B, int N, int MK) {
-  size_t bytes = 0;
-  const unsigned n = (unsigned)((size_t)B * MK);
-  (void)rocprim::radix_sort_pairs(nullptr, bytes, (const unsigned *)nullptr, (unsigned *)nullptr,
-                                  (const int *)nullptr, (int *)nullptr, n, 0, key_bits(B, N), (hipStream_t)0);
-  return bytes;
-}
-
 static size_t csr_table_bytes(int B, int N, const CsrPlan &plan) {
   return (((size_t)B * (plan.G / plan.wpb) * N * sizeof(int)) + 255) & ~(size_t)255;
 }
@@ -271,8 +241,7 @@ size_t inverse_index_workspace(int B, int N, int MK) {
   const size_t n = (size_t)B * MK;
   if (n == 0) return 0;
   CsrPlan plan;
-  if (csr_plan(B, N, MK, &plan)) return csr_table_bytes(B, N, plan);
-  return 3 * ((n * 4 + 255) & ~(size_t)255) + sort_temp_bytes(B, N, MK);
+  return csr_plan(B, N, MK, &plan) ? csr_table_bytes(B, N, plan) : 0;
 }
 
 }  // namespace cl3d
@@ -294,43 +263,27 @@ extern "C" int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK
   const size_t need = cl3d::inverse_index_workspace(B, N, MK);
   if (ws_bytes < need || !ws) return cl3d::fail(CL3D_E_WORKSPACE, "build_inverse_index: workspace %zu < %zu", ws_bytes, need);
   cl3d::CsrPlan plan;
-  if (cl3d::csr_plan(B, N, MK, &plan)) {
-    // N > 16384: one wave's counters exceed the 64 KiB a kernel gets by default
-    static std::atomic<unsigned long long> count_granted{0}, fill_granted{0};
-    int rc_lds = cl3d::lds_opt_in(count_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<false>),
-                                  128 * 1024, "build_inverse_index");
-    if (rc_lds == CL3D_OK)
-      rc_lds = cl3d::lds_opt_in(fill_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<true>),
+  if (!cl3d::csr_plan(B, N, MK, &plan)) return cl3d::fail(CL3D_E_UNSUPPORTED, "build_inverse_index: grid too large");
+  // more than 16 384 counters per wave exceed the 64 KiB a kernel gets by default
+  static std::atomic<unsigned long long> count_granted{0}, fill_granted{0};
+  int rc_lds = cl3d::lds_opt_in(count_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<false>),
                                 128 * 1024, "build_inverse_index");
-    if (rc_lds != CL3D_OK) return rc_lds;
-    int *table = static_cast<int *>(ws);
-    const int GB = plan.G / plan.wpb;
-    const dim3 grid((unsigned)GB * (unsigned)B), block(64 * plan.wpb);
-    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<false>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per,
-                       table, (const int *)nullptr, (int *)nullptr);
-    hipLaunchKernelGGL(cl3d::csr_rows_kernel, dim3(cl3d::ceil_div(N, 64), B), dim3(256), 0, st, N, GB, table, inv_off);
-    hipLaunchKernelGGL(cl3d::csr_scan_kernel, dim3(B), dim3(1024), 0, st, N, inv_off);
-    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per,
-                       table, (const int *)inv_off, inv_slots);
-    return cl3d::check_launch("cl3d_build_inverse_index");
+  if (rc_lds == CL3D_OK)
+    rc_lds = cl3d::lds_opt_in(fill_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<true>),
+                              128 * 1024, "build_inverse_index");
+  if (rc_lds != CL3D_OK) return rc_lds;
+  int *table = static_cast<int *>(ws);
+  const int GB = plan.G / plan.wpb;
+  const dim3 grid((unsigned)GB * (unsigned)B * (unsigned)plan.R), block(64 * plan.wpb);
+  hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<false>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per, plan.NR,
+                     table, (const int *)nullptr, (int *)nullptr);
+  for (int b0 = 0; b0 < B; b0 += 65535) {  // (grid.y limit)
+    const int nb = B - b0 < 65535 ? B - b0 : 65535;
+    hipLaunchKernelGGL(cl3d::csr_rows_kernel, dim3(cl3d::ceil_div(N, 64), nb), dim3(256), 0, st, N, GB,
+                       table + (size_t)b0 * GB * N, inv_off + (size_t)b0 * (N + 1));
   }
-  const size_t n = (size_t)B * MK;
-  const size_t stride = (n * 4 + 255) & ~(size_t)255;
-  char *p = static_cast<char *>(ws);
-  unsigned *keys_in = reinterpret_cast<unsigned *>(p);
-  unsigned *keys_out = reinterpret_cast<unsigned *>(p + stride);
-  int *vals_in = reinterpret_cast<int *>(p + 2 * stride);
-  void *temp = p + 3 * stride;
-  size_t temp_bytes = ws_bytes - 3 * stride;
-  int gx = (int)((n + 256 * 8 - 1) / (256 * 8));
-  gx = gx > 4096 ? 4096 : (gx < 1 ? 1 : gx);
-  hipLaunchKernelGGL(cl3d::csr_keys_kernel, dim3(gx), dim3(256), 0, st, idx, N, MK, (long long)n, keys_in, vals_in);
-  hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, (const unsigned *)keys_in, keys_out, (const int *)vals_in,
-                                           inv_slots, (unsigned)n, 0, cl3d::key_bits(B, N), st);
-  if (e != hipSuccess) return cl3d::fail(CL3D_E_LAUNCH, "build_inverse_index: radix sort: %s", hipGetErrorString(e));
-  const long long rows = (long long)B * (N + 1);
-  int gr = (int)((rows + 255) / 256);
-  gr = gr > 4096 ? 4096 : gr;
-  hipLaunchKernelGGL(cl3d::csr_offsets_kernel, dim3(gr), dim3(256), 0, st, keys_out, B, N, MK, inv_off);
+  hipLaunchKernelGGL(cl3d::csr_scan_kernel, dim3(B), dim3(1024), 0, st, N, inv_off);
+  hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per, plan.NR,
+                     table, (const int *)inv_off, inv_slots);
   return cl3d::check_launch("cl3d_build_inverse_index");
 }

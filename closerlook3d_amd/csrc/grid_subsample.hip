@@ -21,8 +21,6 @@
 #include <cstring>
 #include <type_traits>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
 #include "ball_query.h"
 
 #ifndef CL3D_SUB_PHASE
@@ -40,7 +38,8 @@ __device__ __forceinline__ int key_cell(unsigned long long k) {
 __device__ __forceinline__ int key_orig(unsigned long long k) { return (int)(unsigned)(k & 0xffffffffull); }
 
 // Large clouds (N > kSubMaxN): the (cell, index) keys do not fit LDS.  A first kernel writes them to HBM as
-// {cloud:6 | biased cell:32 | index:26}, one device-wide radix sort (rocPRIM) orders all clouds at once, and
+// {cloud:6 | biased cell:32 | index:26}, grid_sort_kernel orders every cloud's slice (one workgroup per cloud, a stable
+// LSD radix sort on the cell bits -- see there; rounds 1-5 called rocPRIM's device-wide radix sort here), and
 // the same per-cloud kernel runs with PRESORTED = true, reading its cloud's slice instead of sorting in LDS.
 // (The index field is deliberately wider than 24 bits: hipcc 7.2 for gfx950 drops an `x & 0xffffff` in front
 // of an address multiply -- `p[(k & 0xffffff) * 3]` compiles to v_mad_u64_u32 on the unmasked dword -- which
@@ -119,6 +118,110 @@ __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[R], 
     for (int r = 0; r < R; ++r) lds[e0 + r] = key[r];
   }
   __syncthreads();
+}
+
+// ---- the large-N sort (configs 3 / 5: scenes of 40 960 / 81 920 points).  One 1024-thread workgroup per cloud sorts the
+// cloud's nv valid keys -- they are written in index order, so a STABLE sort by the cell field alone is the sort by
+// (cell, index) the reference's sort_by_key produces (masked_grid_subsampling_gpu.cu:77); the invalid keys already sit
+// behind them (valid points first) and are never read.  LSD radix, 8 bits per pass, only over the cell bits in which the
+// cloud's keys differ at all (a scene has a few 10^4 .. 10^6 cells: 2-3 passes):
+//   count    wave w owns a contiguous piece of the keys and histograms its digits into its own 256 LDS counters
+//   scan     cursor[d][w] = keys with a smaller digit + keys with digit d in the pieces before w's (digit-major, wave-minor)
+//   scatter  wave w walks its piece again, 64 keys at a time in order; the lanes of a batch that share a digit are found
+//            with eight ballots, a lane's position is the cursor + the number of such lanes below it -- stable within the
+//            batch, batches in order, pieces in order.
+// Ping-pong between the two key buffers; the result always ends in `b` (a last copy when the pass count is even).
+__global__ __launch_bounds__(kSubThreads) void grid_sort_kernel(unsigned long long *__restrict__ a, unsigned long long *__restrict__ b,
+                                                                const SubParams *__restrict__ params, int N) {
+  __shared__ unsigned s_hist[kSubThreads / 64][256];
+  __shared__ unsigned s_tot[256];
+  __shared__ unsigned s_or[kSubThreads / 64];
+  const int cloud = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nv = params[cloud].nv;
+  unsigned long long *src = a + (size_t)cloud * N, *dst = b + (size_t)cloud * N;
+  if (nv <= 0) return;
+  // the cell bits in which any two valid keys differ
+  const unsigned first = (unsigned)(src[0] >> kBigIdxBits);
+  unsigned diff = 0;
+  for (int i = tid; i < nv; i += kSubThreads) diff |= (unsigned)(src[i] >> kBigIdxBits) ^ first;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) diff |= __shfl_xor(diff, o, 64);
+  if (lane == 0) s_or[wave] = diff;
+  __syncthreads();
+  diff = 0;
+  for (int w = 0; w < kSubThreads / 64; ++w) diff |= s_or[w];
+  const int nbits = diff == 0 ? 0 : 32 - __builtin_clz(diff);
+  const int passes = (nbits + 7) / 8;
+  int piece = (nv + kSubThreads / 64 - 1) / (kSubThreads / 64);
+  piece = (piece + 63) & ~63;
+  const int p0 = wave * piece < nv ? wave * piece : nv;
+  const int p1 = p0 + piece < nv ? p0 + piece : nv;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = kBigIdxBits + 8 * pass;
+    for (int i = tid; i < (kSubThreads / 64) * 256; i += kSubThreads) (&s_hist[0][0])[i] = 0u;
+    __syncthreads();
+    for (int i = p0 + lane; i < p1; i += 64) atomicAdd(&s_hist[wave][(unsigned)(src[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    if (tid < 256) {  // digit tid: totals, and the pieces' counters turned into starts relative to the digit's start
+      unsigned run = 0;
+      for (int w = 0; w < kSubThreads / 64; ++w) {
+        const unsigned c = s_hist[w][tid];
+        s_hist[w][tid] = run;
+        run += c;
+      }
+      s_tot[tid] = run;
+    }
+    __syncthreads();
+    {  // exclusive scan of the 256 digit totals (held by the first four waves; every wave walks the same barriers)
+      const unsigned mine = tid < 256 ? s_tot[tid] : 0u;
+      unsigned incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63 && wave < 4) s_or[wave] = incl;
+      __syncthreads();
+      unsigned before = 0;
+      for (int w = 0; w < 4; ++w)
+        if (w < wave) before += s_or[w];
+      const unsigned start = before + incl - mine;
+      if (tid < 256)
+        for (int w = 0; w < kSubThreads / 64; ++w) s_hist[w][tid] += start;
+    }
+    __syncthreads();
+    for (int i0 = p0; i0 < p1; i0 += 64) {
+      const int i = i0 + lane;
+      const bool on = i < p1;
+      const unsigned long long key = on ? src[i] : 0ull;
+      const unsigned d = (unsigned)(key >> shift) & 255u;
+      unsigned long long same = __ballot(on);
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const unsigned long long m = __ballot((d >> bit) & 1u);
+        same &= ((d >> bit) & 1u) ? m : ~m;
+      }
+      const int rank = prefix_popc(same);
+      const int count = (int)__popcll(same);
+      unsigned base = 0;
+      if (on) base = s_hist[wave][d];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (on && rank == count - 1) s_hist[wave][d] = base + (unsigned)count;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (on) dst[base + (unsigned)rank] = key;
+    }
+    __syncthreads();  // (every wave's stores are issued and, by the barrier's release, visible to the workgroup)
+    unsigned long long *t = src;
+    src = dst;
+    dst = t;
+  }
+  // `src` holds the sorted keys now; they belong in b
+  unsigned long long *out = b + (size_t)cloud * N;
+  if (src != out)
+    for (int i = tid; i < nv; i += kSubThreads) out[i] = src[i];
 }
 
 template <bool PRESORTED, bool KEYS_ONLY>
@@ -435,10 +538,7 @@ namespace cl3d {
 size_t grid_subsampling_workspace(int B, int N) {
   if (N <= kSubMaxN) return 0;
   const size_t n = (size_t)B * N;
-  size_t temp = 0;
-  (void)rocprim::radix_sort_keys(nullptr, temp, (const unsigned long long *)nullptr, (unsigned long long *)nullptr,
-                                 (unsigned)n, 0, 64, (hipStream_t)0);
-  return 256 * ((sizeof(SubParams) * B + 255) / 256) + 2 * ((n * 8 + 255) & ~(size_t)255) + temp;
+  return 256 * ((sizeof(SubParams) * B + 255) / 256) + 2 * ((n * 8 + 255) & ~(size_t)255);
 }
 }  // namespace cl3d
 
@@ -451,7 +551,7 @@ extern "C" int cl3d_masked_grid_subsampling(const float *xyz, const int32_t *mas
   CL3D_REQUIRE(xyz && mask && sub_xyz && sub_mask, "grid_subsampling: null pointer");
   hipStream_t st = (hipStream_t)stream;
   if (N > cl3d::kSubMaxN) {
-    // large clouds: keys to HBM, one device-wide radix sort, then the same per-cloud kernel on sorted keys
+    // large clouds: keys to HBM, the per-cloud radix sort (grid_sort_kernel), then the same per-cloud kernel on sorted keys
     CL3D_REQUIRE(B <= 64 && N < (1 << cl3d::kBigIdxBits), "grid_subsampling: large-N path supports B <= 64, N < 2^26");
     const size_t need = cl3d::grid_subsampling_workspace(B, N);
     if (!ws || ws_bytes < need) return cl3d::fail(CL3D_E_WORKSPACE, "grid_subsampling: workspace %zu < %zu", ws_bytes, need);
@@ -462,13 +562,10 @@ extern "C" int cl3d_masked_grid_subsampling(const float *xyz, const int32_t *mas
     unsigned long long *keys_in = reinterpret_cast<unsigned long long *>(p);
     p += (n * 8 + 255) & ~(size_t)255;
     unsigned long long *keys_out = reinterpret_cast<unsigned long long *>(p);
-    p += (n * 8 + 255) & ~(size_t)255;
-    size_t temp_bytes = ws_bytes - (size_t)(p - static_cast<char *>(ws));
     hipLaunchKernelGGL((cl3d::grid_subsample_kernel<false, true>), dim3(B), dim3(cl3d::kSubThreads), 0, st, xyz, mask, N,
                        m, sampleDl, N, sub_xyz, sub_mask, keys_in, params, 0);
-    hipError_t e = rocprim::radix_sort_keys(p, temp_bytes, (const unsigned long long *)keys_in, keys_out, (unsigned)n,
-                                            0, 64, st);
-    if (e != hipSuccess) return cl3d::fail(CL3D_E_LAUNCH, "grid_subsampling: radix sort: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(cl3d::grid_sort_kernel, dim3(B), dim3(cl3d::kSubThreads), 0, st, keys_in, keys_out,
+                       (const cl3d::SubParams *)params, N);
     hipLaunchKernelGGL((cl3d::grid_subsample_kernel<true, false>), dim3(B), dim3(cl3d::kSubThreads), 0, st, xyz, mask, N,
                        m, sampleDl, N, sub_xyz, sub_mask, keys_out, params, 0);
     return cl3d::check_launch("cl3d_masked_grid_subsampling(large)");

@@ -1185,8 +1185,16 @@ static void launch_modes(GemmArgs &a, int wi, int wj, int blocks, hipStream_t st
 
 
 constexpr int kCUs = 256;
-constexpr int kTicketMaxSplit = 16;  // more slices than this: the partials are summed by a launch of their own, over the whole chip
-constexpr double kInLaunchSumKBperUs = 40.0;  // what ONE workgroup streams while it sums its tile's slices (measured: profiles/r06)
+// Where the in-launch slice sum is used: measured against the two-launch form over every (tile, split) of the config-2
+// backbone's 42 products, both precisions (profiles/r06/gemm_plan_sweep_*: the same graph-replayed timing, launches ~1 us
+// apart): the last arrival of a tile streams its slices at ~17 KB/us -- ONE workgroup, loads that bypass its L2 -- while the
+// launch of its own spreads the same bytes over the chip.  In-launch minus two-launch, mean over the deep-stage products:
+//     64 x 64 tile:   split 2: -0.8 .. -1.5 us   3: -0.5 .. -1.5   4: +0.8   8: +6    16: +14 .. +16
+//     128 x 64:             2: +0.3 .. +1.0      3: +0.1 .. +1.2   4: +4 .. +5       16: +26 .. +40
+//     128 x 128:            2: +4                3: +5 .. +8       8: +28            16: +63 .. +76
+// So: up to three slices of a 64 x 64 tile; everything else keeps the launch of its own.
+constexpr int kTicketMaxSplit = 3;
+constexpr double kInLaunchSumGainUs = 1.0;  // what the in-launch form saves where it is used (see the table above)
 
 
 // Workgroup tile and K slicing for an I x J output over K.  Two regimes decide the time of a product here:
@@ -1227,10 +1235,13 @@ static bool fused_slice_sum() {
 // what summing `split` slices costs on top of the product: a launch of its own over the whole chip (two-launch form), or
 // the last arrival of every tile reading its tile of every slice (in-launch form: no launch, no hand-over, but ONE
 // workgroup per tile streams split x tile bytes at what a single workgroup draws)
+static bool in_launch_sum_applies(int wi, int wj, long long split, bool in_launch) {
+  return in_launch && split > 1 && split <= kTicketMaxSplit && wi == 1 && wj == 1;
+}
 static double slice_sum_us(int I, int J, int wi, int wj, long long split, bool in_launch) {
   if (split <= 1) return 0.0;
-  if (in_launch && split <= kTicketMaxSplit) return 0.6 + (double)split * (64.0 * wi) * (64.0 * wj) * 4.0 / 1e3 / kInLaunchSumKBperUs;
-  return 1.546 + 5.0 + (double)split * I * J * 4.0 * 2.0 / 1e6 / 6.851;  // (+ the ~5 us between two launches of one queue)
+  const double two_launch = 1.546 + (double)split * I * J * 4.0 * 2.0 / 1e6 / 6.851;  // (round 5's fit)
+  return in_launch_sum_applies(wi, wj, split, in_launch) ? two_launch - kInLaunchSumGainUs : two_launch;
 }
 
 static double bf16_launch_us(int I, int J, long long K, int wi, int wj, long long cps, long long real_split, bool in_launch) {
@@ -1281,9 +1292,8 @@ static Plan plan_gemm(int I, int J, long long K, int precision, int max_split, s
         double fill = (double)(tiles * real_split) / (double)(kCUs * resident);
         if (fill > 1.0) fill = 1.0;
         const double partial_us = real_split <= 1 ? 0.0
-                                  : (in_launch_sum && real_split <= kTicketMaxSplit)
-                                        ? slice_sum_us(I, J, wi, wj, real_split, true) + (double)real_split * I * J * 4.0 / 2.5e6
-                                        : 3.0 + 2.0 * (double)real_split * I * J * 4.0 / 2.5e6;
+                                  : 3.0 + 2.0 * (double)real_split * I * J * 4.0 / 2.5e6 -
+                                        (in_launch_sum_applies(wi, wj, real_split, in_launch_sum) ? kInLaunchSumGainUs : 0.0);
         // (round 5: a term for the operand bytes a tiling pulls through L2 -- tiles x K x (TI + TJ) x 4 B against 3-6 TB/s,
         //  170 MB for the 1152 x 1152 x 1024 layer in 64 x 64 tiles -- pushed the plan towards 128 x 128 and made every shape
         //  but two slower, the weight gradients by 2-3 x: config 2 6.67 -> 7.58 / 8.88 ms in bf16; gpurun_out/r05k.  Dropped.)
@@ -1392,7 +1402,7 @@ static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t 
   if (blocks > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "%s: grid too large", who);
   a.tickets = nullptr;
   a.vec_out = 0;
-  if (REDUCE_MODE == 0 && p.nsplit > 1 && p.nsplit <= kTicketMaxSplit && fused_slice_sum()) {
+  if (REDUCE_MODE == 0 && in_launch_sum_applies(p.wi, p.wj, p.nsplit, fused_slice_sum())) {
     a.tickets = ticket_piece((size_t)a.tiles_i * a.tiles_j, st);
     a.vec_out = J % 4 == 0 && final_out.sj == 1 && final_out.si % 4 == 0 &&
                 (final_out.fold_n == 0 || (final_out.fold_n % 4 == 0 && final_out.sb % 4 == 0)) &&

@@ -251,6 +251,53 @@ def test_k_slices_summed_inside_the_launch(B, C, N, Co, prec):
     assert _rel(y2, plain) <= TOL
 
 
+def test_in_launch_sum_forced_on_every_tile_and_split_matches_the_two_launch_form():
+    """The planner uses the in-launch slice sum only where it measured faster (64 x 64 tiles, <= 3 slices); the variant build
+    of scripts/micro/gemm_plan_sweep.py (CL3D_GEMM_FORCE = tile and split, CL3D_GEMM_FUSED_SUM = which form) forces it --
+    and the two-launch form -- onto the same product in a child process: same bits (both add the slices in order 0, 1, 2, ...),
+    for 64 x 64 tiles with 2 and 3 slices, f32 and bf16, with the epilogue."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    var = os.path.join(root, "scripts", "micro", "var", "libcl3d_gemm_plan_env.so")
+    if not os.path.exists(var):
+        pytest.skip("variant library not built (python scripts/micro/gemm_plan_sweep.py --build; __graft_entry__.build() does)")
+    code = r"""
+import os, sys, torch
+sys.path.insert(0, %r)
+from closerlook3d_amd import _lib
+lib = _lib.lib()
+dev = torch.device("cuda:0")
+g = torch.Generator(device="cpu").manual_seed(5)
+B, C, N, Co = 16, 1152, 16, 576
+x = torch.randn(B, C, N, generator=g).to(dev); W = (torch.randn(Co, C, generator=g) / C ** 0.5).to(dev)
+scale = (0.5 + torch.rand(Co, generator=g)).to(dev); shift = torch.randn(Co, generator=g).to(dev)
+res = torch.randn(B, Co, N, generator=g).to(dev)
+ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+p = lambda t: t.data_ptr()
+for prec in (0, 1):
+    for split in (2, 3):
+        outs = []
+        for form in ("1", "0"):
+            os.environ["CL3D_GEMM_FUSED_SUM"] = form
+            os.environ["CL3D_GEMM_FORCE"] = "1,1,%%d" %% split
+            y = torch.full((B, Co, N), float("nan"), device=dev)
+            for _ in range(3):
+                _lib.check(lib.cl3d_conv1x1_bn_act_fwd(p(x), p(W), p(scale), p(shift), p(res), 1, B, C, N, Co, prec, p(y), p(ws), ws.numel(), _lib.stream_ptr(dev)))
+            torch.cuda.synchronize()
+            outs.append(y)
+        assert torch.equal(outs[0], outs[1]), (prec, split, float((outs[0] - outs[1]).abs().max()))
+        want = torch.relu(torch.einsum("oc,bcn->bon", W.double(), x.double()) * scale.double()[None, :, None] + shift.double()[None, :, None] + res.double())
+        err = float((outs[0].double() - want).abs().max() / want.abs().max())
+        assert err <= (1e-5 if prec == 0 else 1e-2), (prec, split, err)
+print("ok")
+""" % root
+    env = dict(os.environ, CL3D_LIB=var)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
 def test_bad_arguments_are_refused():
     lib = _lib.lib()
     assert lib.cl3d_pwmlp_point_gemm_fwd(None, None, 1, 8, 16, 4, 0, None, None, None, None, 0, None) == -1

@@ -221,10 +221,13 @@ def _fused_vs_oracle(kind, over, C, K, N, mult, tweak=None):
     assert torch.equal(out, out2) and torch.equal(f.grad, f2.grad)
 
 
-@pytest.mark.parametrize("B,N,M,K", [(3, 500, 321, 17), (2, 4096, 4096, 32), (1, 20000, 5000, 16), (1, 40000, 3000, 8)])
+@pytest.mark.parametrize("B,N,M,K", [(3, 500, 321, 17), (2, 4096, 4096, 32), (1, 20000, 5000, 16), (1, 40000, 3000, 8),
+                                     (1, 40960, 10240, 31), (2, 81920, 20480, 26), (1, 32768, 1000, 5), (1, 32769, 1000, 5),
+                                     (3, 100000, 777, 3)])
 def test_inverse_index_matches_numpy(B, N, M, K):
-    """CSR inverse (wave-private counting sort for N <= 32768, radix sort beyond) == numpy's stable argsort;
-    indices outside [0,N) are dropped; the table is identical build after build."""
+    """CSR inverse (wave-private counting sort; N > 32 768: the same kernels over key ranges of <= 16 384 support indices --
+    configs 3 / 5's scenes, round 6: no library sort) == numpy's stable argsort; indices outside [0,N) are dropped; the
+    table is identical build after build."""
     from closerlook3d_amd.fused import inverse_index
     rng = np.random.default_rng(4)
     idx = rng.integers(0, N, (B, M, K)).astype(np.int32)
