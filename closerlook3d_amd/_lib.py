@@ -103,6 +103,19 @@ class PwmlpPass(ctypes.Structure):
                              "gout", "dz_cm", "dz_t", "qtab", "hit", "coef", "dwr", "dght", "dfeat", "dW", "ts_cm")])
 
 
+class ReducePass(ctypes.Structure):
+    """cl3d_reduce_pass of include/cl3d.h (PosPool / AdaptiveWeight / PseudoGrid, one C-ABI call per pass): field for field."""
+    _fields_ = (
+        [(n, _I) for n in ("B", "N", "M", "K", "C", "op", "normalize", "reduction", "pint", "constant", "idx_ready",
+                           "csr_ready", "nparts")]
+        + [(n, _F) for n in ("radius", "pfloat")]
+        + [("reserved", _I)]
+        + [(n, _P) for n in ("query_xyz", "support_xyz", "query_mask", "support_mask", "features", "p0", "p1", "idx",
+                             "idx_mask", "inv_off", "inv_slots", "bq_ws", "csr_ws")]
+        + [(n, _Z) for n in ("bq_ws_bytes", "csr_ws_bytes")]
+        + [(n, _P) for n in ("ft", "out", "slotrec", "pairs", "gout", "gout_t", "dfeat", "dparam", "g0", "g1")])
+
+
 def _declare(handle):
     handle.cl3d_abi_version.restype = _I
     handle.cl3d_abi_version.argtypes = []
@@ -119,6 +132,10 @@ def _declare(handle):
     for name in ("cl3d_pwmlp_train_forward", "cl3d_pwmlp_train_backward"):
         fn = getattr(handle, name)
         fn.argtypes = [ctypes.POINTER(PwmlpPass), _P]
+        fn.restype = _I
+    for name in ("cl3d_reduce_train_forward", "cl3d_reduce_train_backward"):
+        fn = getattr(handle, name)
+        fn.argtypes = [ctypes.POINTER(ReducePass), _P]
         fn.restype = _I
 
 

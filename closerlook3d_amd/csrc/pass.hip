@@ -73,8 +73,9 @@ static int hip_ok(hipError_t e, const char *what) {
 // kIdleCalls calls (a loop over more distinct blocks than slots falls back to direct launches instead of re-capturing
 // every call), and an evicted graph is destroyed kIdleCalls calls later still (its last launch has long drained).
 constexpr int kGraphSlots = 8, kSeen = 32, kIdleCalls = 64;
+template <class Block>
 struct PassGraphs {
-  cl3d_pwmlp_pass key[kGraphSlots];
+  Block key[kGraphSlots];
   hipGraphExec_t exec[kGraphSlots] = {};
   unsigned long long used[kGraphSlots] = {};
   unsigned long long seen[kSeen] = {};  // hashes of the last blocks that were launched directly
@@ -83,7 +84,11 @@ struct PassGraphs {
   unsigned long long retired_at[kGraphSlots] = {};
   unsigned long long tick = 0;
 };
-static PassGraphs g_graphs[2][64];
+template <class Block>
+static PassGraphs<Block> &graphs_of(int dir, int dev) {
+  static PassGraphs<Block> g[2][64];
+  return g[dir][dev];
+}
 static std::atomic<int> g_graphs_on{1};
 static std::atomic<long long> g_captures{0}, g_replays{0};
 
@@ -91,14 +96,18 @@ static_assert(sizeof(cl3d_pwmlp_pass) == 14 * 4 + 13 * 8 + 4 * sizeof(size_t) + 
 
 // the block as the launch-graph tables key it: a byte copy with the reserved word (the only bytes no field of the ABI
 // defines) cleared, so two calls with the same arguments compare equal whatever the caller left there
-static cl3d_pwmlp_pass block_key(const cl3d_pwmlp_pass *p) {
-  cl3d_pwmlp_pass k;
+static_assert(sizeof(cl3d_reduce_pass) == 16 * 4 + 13 * 8 + 2 * sizeof(size_t) + 10 * 8, "cl3d_reduce_pass has padding: compare field-wise");
+
+template <class Block>
+static Block block_key(const Block *p) {
+  Block k;
   memcpy(&k, p, sizeof(k));
   k.reserved = 0;
   return k;
 }
 
-static unsigned long long block_hash(const cl3d_pwmlp_pass *p) {  // FNV-1a over the block's bytes (never 0)
+template <class Block>
+static unsigned long long block_hash(const Block *p) {  // FNV-1a over the block's bytes (never 0)
   const unsigned char *b = reinterpret_cast<const unsigned char *>(p);
   unsigned long long h = 1469598103934665603ull;
   for (size_t k = 0; k < sizeof(*p); ++k) h = (h ^ b[k]) * 1099511628211ull;
@@ -106,16 +115,16 @@ static unsigned long long block_hash(const cl3d_pwmlp_pass *p) {  // FNV-1a over
 }
 
 // (called with the device's PassRuntime::use lock held: one pass at a time per device uses the side streams and events)
-template <class Enqueue>
-static int run_pass(int dir, const cl3d_pwmlp_pass *p, hipStream_t st, PassRuntime *rt, int dev, Enqueue &&enqueue) {
+template <class Block, class Enqueue>
+static int run_pass(int dir, const Block *p, hipStream_t st, PassRuntime *rt, int dev, Enqueue &&enqueue) {
   if (!g_graphs_on.load()) return enqueue(st);
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
     (void)hipGetLastError();
     return enqueue(st);  // inside the caller's own capture: the launches become nodes of ITS graph
   }
-  PassGraphs &g = g_graphs[dir][dev];
-  const cl3d_pwmlp_pass key = block_key(p);
+  PassGraphs<Block> &g = graphs_of<Block>(dir, dev);
+  const Block key = block_key(p);
   ++g.tick;
   for (int k = 0; k < kGraphSlots; ++k)
     if (g.retired[k] != nullptr && g.retired_at[k] + kIdleCalls < g.tick) {
@@ -297,4 +306,73 @@ static int enqueue_backward(const cl3d_pwmlp_pass *p, hipStream_t st, cl3d::Pass
                                               p->gemm_ws_w, p->gemm_ws_bytes_b, st));
   if (fork) CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_w, 0), "pwmlp_train_backward: join"));
   return CL3D_OK;
+}
+
+// ---- the three gather-and-reduce operators (PosPool / AdaptiveWeight / PseudoGrid), one call per pass (round 6) -------
+//   forward    caller's stream: ball query ... joins the layout change: the fused reduction; joins the CSR
+//                                                     |   side 0: features [B,C,N] -> rows [B,N,C]
+//                                                     |   side 1: (behind the query) CSR inverse
+//   backward   caller's stream: upstream gradient -> rows, support-major pass, parameter gradients
+static int enqueue_reduce_forward(const cl3d_reduce_pass *p, hipStream_t st, cl3d::PassRuntime *rt) {
+  using namespace cl3d;
+  const bool want_csr = p->inv_off != nullptr && !p->csr_ready;
+  CL3D_TRY(hip_ok(hipEventRecord(rt->ev_in, st), "reduce_train_forward: event"));
+  if (!p->idx_ready)
+    CL3D_TRY(cl3d_masked_ordered_ball_query(p->query_xyz, p->support_xyz, p->query_mask, p->support_mask, p->B, p->M, p->N,
+                                            p->radius, p->K, p->idx, p->idx_mask, p->bq_ws, p->bq_ws_bytes, st));
+  CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[0], rt->ev_in, 0), "reduce_train_forward: fork"));
+  CL3D_TRY(cl3d_transpose(p->features, p->B, p->C, p->N, p->ft, rt->side[0]));
+  CL3D_TRY(hip_ok(hipEventRecord(rt->ev_fork, rt->side[0]), "reduce_train_forward: event"));
+  if (want_csr) {  // (enqueued before the gather pass: the build inherits the query's queue, cl3d_pwmlp_train_forward's note)
+    CL3D_REQUIRE(p->inv_slots != nullptr, "reduce_train_forward: null inv_slots");
+    CL3D_TRY(hip_ok(hipEventRecord(rt->ev_bq, st), "reduce_train_forward: event"));
+    CL3D_TRY(hip_ok(hipStreamWaitEvent(rt->side[1], rt->ev_bq, 0), "reduce_train_forward: fork"));
+    CL3D_TRY(cl3d_build_inverse_index(p->idx, p->B, p->N, p->M * p->K, p->inv_off, p->inv_slots, p->csr_ws, p->csr_ws_bytes,
+                                      rt->side[1]));
+    CL3D_TRY(hip_ok(hipEventRecord(rt->ev_csr, rt->side[1]), "reduce_train_forward: event"));
+  }
+  CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_fork, 0), "reduce_train_forward: join"));
+  CL3D_TRY(cl3d_fused_reduce_fwd(p->op, p->query_xyz, p->support_xyz, p->query_mask, p->idx, p->idx_mask, p->ft, p->B, p->N,
+                                 p->M, p->K, p->C, p->radius, p->normalize, p->reduction, p->p0, p->p1, p->pint, p->pfloat,
+                                 p->constant, p->out, 1, p->slotrec, p->pairs, st));
+  if (want_csr) CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_csr, 0), "reduce_train_forward: join"));
+  return CL3D_OK;
+}
+
+static int enqueue_reduce_backward(const cl3d_reduce_pass *p, hipStream_t st) {
+  CL3D_TRY(cl3d_transpose(p->gout, p->B, p->C, p->M, p->gout_t, st));
+  CL3D_TRY(cl3d_fused_reduce_bwd(p->op, p->gout_t, p->ft, p->slotrec, p->pairs, p->idx, p->inv_off, p->inv_slots, p->B, p->N,
+                                 p->M, p->K, p->C, p->p0, p->p1, p->pint, p->pfloat, p->constant, p->dfeat, 1, p->dparam,
+                                 p->nparts, st));
+  if (p->g1 != nullptr)
+    CL3D_TRY(cl3d_fused_param_reduce(p->op, p->dparam, p->nparts, p->C, p->pint, p->g0, p->g1, st));
+  return CL3D_OK;
+}
+
+extern "C" int cl3d_reduce_train_forward(const cl3d_reduce_pass *p, cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(p != nullptr, "reduce_train_forward: null argument block");
+  CL3D_REQUIRE(p->B >= 0 && p->N >= 1 && p->M >= 1 && p->K >= 1 && p->C >= 1 && p->radius > 0.f && p->op >= 0 && p->op <= 3,
+               "reduce_train_forward: bad sizes");
+  CL3D_REQUIRE(p->query_xyz && p->support_xyz && p->query_mask && p->support_mask && p->idx && p->idx_mask && p->features &&
+                   p->ft && p->out,
+               "reduce_train_forward: null pointer");
+  if (p->B == 0) return CL3D_OK;
+  PassRuntime *rt = pass_runtime();
+  if (rt == nullptr) return fail(CL3D_E_LAUNCH, "reduce_train_forward: side streams could not be created");
+  std::lock_guard<std::mutex> use(rt->use);
+  return run_pass(0, p, (hipStream_t)stream, rt, rt->dev, [&](hipStream_t s) { return enqueue_reduce_forward(p, s, rt); });
+}
+
+extern "C" int cl3d_reduce_train_backward(const cl3d_reduce_pass *p, cl3d_stream_t stream) {
+  using namespace cl3d;
+  CL3D_REQUIRE(p != nullptr, "reduce_train_backward: null argument block");
+  CL3D_REQUIRE(p->gout && p->gout_t && p->ft && p->slotrec && p->idx && p->inv_off && p->inv_slots && p->dfeat,
+               "reduce_train_backward: null pointer");
+  CL3D_REQUIRE(p->nparts == 0 || p->dparam != nullptr, "reduce_train_backward: null dparam");
+  if (p->B == 0) return CL3D_OK;
+  PassRuntime *rt = pass_runtime();
+  if (rt == nullptr) return fail(CL3D_E_LAUNCH, "reduce_train_backward: side streams could not be created");
+  std::lock_guard<std::mutex> use(rt->use);
+  return run_pass(1, p, (hipStream_t)stream, rt, rt->dev, [&](hipStream_t s) { return enqueue_reduce_backward(p, s); });
 }

@@ -437,7 +437,6 @@ def join_pending(out):
 def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, embedding, reduction,
             defer_join=False):
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
-    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, _wants_grad(features))
     C = features.shape[1]
     if embedding == 'xyz':
         if C % 3:
@@ -449,9 +448,27 @@ def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, 
         fd = C // 6
         op = OP_POSPOOL_SINCOS
         p0 = torch.pow(1.0 * 1000, (1.0 / fd) * torch.arange(fd, dtype=torch.float32, device=features.device))
+    if _use_reduce_pass(_wants_grad(features)):
+        return _reduce_pass(features, p0, None, op, query_xyz, support_xyz, query_mask, support_mask, radius, nsample, True,
+                            _RED[reduction], 0, 0.0, False)
+    idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, _wants_grad(features))
     out = _FusedReduce.apply(features, p0, None, op, query_xyz, support_xyz, query_mask, idx, idx_mask, radius,
                              True, _RED[reduction], 0, 0.0, False, _wants_grad(features), defer_join)
     return _deferred(out, idx, defer_join)
+
+
+def _use_reduce_pass(need_grad):
+    """The one-call-per-pass path of the three gather-and-reduce operators (pass_calls._ReducePass): a stand-alone operator
+    whose backward will follow, launched eagerly, no per-forward geometry memo -- the conditions of _use_pass_calls."""
+    return (PASS_CALLS and need_grad and pt_utils._BQ_CACHE is None and pt_utils.ASYNC_INDEX == 'auto'
+            and not torch.cuda.is_current_stream_capturing())
+
+
+def _reduce_pass(features, p0, p1, op, query_xyz, support_xyz, query_mask, support_mask, radius, nsample, normalize,
+                 reduction, pint, pfloat, constant):
+    from .pass_calls import _ReducePass
+    return _ReducePass.apply(features, p0, p1, op, query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
+                             normalize, reduction, pint, pfloat, constant)
 
 
 def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps,
@@ -459,6 +476,9 @@ def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, 
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     conv = mlps.conv0
     w = conv.weight.view(conv.weight.shape[0], 3)
+    if _use_reduce_pass(_wants_grad(features, w, conv.bias)):
+        return _reduce_pass(features, w, conv.bias, OP_ADAPTIVE, query_xyz, support_xyz, query_mask, support_mask, radius,
+                            nsample, True, _RED[reduction], int(shared_channels), 0.0, False)
     idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
                            _wants_grad(features, w, conv.bias))
     out = _FusedReduce.apply(features, w, conv.bias, OP_ADAPTIVE, query_xyz, support_xyz, query_mask, idx,
@@ -470,6 +490,10 @@ def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, 
 def pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, k_points,
                 kernel_weights, extent, influence, defer_join=False):
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
+    if _use_reduce_pass(_wants_grad(features, kernel_weights)):
+        return _reduce_pass(features, k_points.contiguous(), kernel_weights, OP_PSEUDOGRID, query_xyz, support_xyz, query_mask,
+                            support_mask, radius, nsample, False, _RED['sum'], int(k_points.shape[0]), 1.0 / float(extent),
+                            influence == 'constant')
     idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
                            _wants_grad(features, kernel_weights))
     out = _FusedReduce.apply(features, k_points.contiguous(), kernel_weights, OP_PSEUDOGRID, query_xyz,

@@ -1,6 +1,8 @@
-"""One C-ABI call per pass of a PointWiseMLP LocalAggregation in training mode: the autograd node over
-cl3d_pwmlp_train_forward / _backward (csrc/pass.hip).  fused.pointwise_mlp() takes this path for a stand-alone operator
-launched eagerly (outside HIP-graph capture); everything else goes kernel by kernel through fused._PointwiseMLP."""
+"""One C-ABI call per pass of a LocalAggregation operator in training mode: the autograd nodes over
+cl3d_pwmlp_train_forward / _backward (PointWiseMLP) and cl3d_reduce_train_forward / _backward (PosPool / AdaptiveWeight /
+PseudoGrid, round 6) of csrc/pass.hip.  fused.pointwise_mlp() / pospool() / adaptive_weight() / pseudo_grid() take this path
+for a stand-alone operator launched eagerly (outside HIP-graph capture); everything else goes kernel by kernel through
+fused._PointwiseMLP / fused._FusedReduce."""
 import ctypes
 
 import torch
@@ -103,6 +105,81 @@ class _PointwiseMLPPass(Function):
         # (ctx.keep stays: autograd drops the node -- and with it the forward's buffers -- unless the caller retains the
         # graph, in which case a second backward pass reads them again)
         return (dfeat, dW, coef[3], coef[4]) + (None,) * 13
+
+
+class _ReducePass(Function):
+    """A PosPool / AdaptiveWeight / PseudoGrid operator up to its output transform -- ball query, CSR inverse, layout
+    change, the fused reduction; and its whole backward -- as ONE C-ABI call per direction (csrc/pass.hip,
+    cl3d_reduce_train_forward / _backward; round 6): the eager caller's path for these three operators,
+    as _PointwiseMLPPass is for the fourth.  Same kernels, same arithmetic, same bits as fused._FusedReduce."""
+
+    @staticmethod
+    def forward(ctx, features, p0, p1, op, query_xyz, support_xyz, query_mask, support_mask, radius, nsample, normalize,
+                reduction, pint, pfloat, constant):
+        B, C, N = features.shape
+        M, K = query_xyz.shape[1], int(nsample)
+        dev = features.device
+        lib = _lib.lib()
+        p = _lib.ReducePass()
+        p.B, p.N, p.M, p.K, p.C, p.op = B, N, M, K, C, int(op)
+        p.normalize, p.reduction, p.pint, p.constant = int(normalize), int(reduction), int(pint), int(constant)
+        p.radius, p.pfloat = float(radius), float(pfloat)
+        p.idx_ready = p.csr_ready = 0
+        inputs = (features, p0, p1, query_xyz, support_xyz, query_mask, support_mask)  # kept alive: the block points into them
+        for name, t in zip(("features", "p0", "p1", "query_xyz", "support_xyz", "query_mask", "support_mask"), inputs):
+            setattr(p, name, t.data_ptr() if t is not None else None)
+        p.bq_ws_bytes = lib.cl3d_workspace_bytes(1, B, N, M, K, 0)            # CL3D_OP_BALL_QUERY
+        p.csr_ws_bytes = lib.cl3d_workspace_bytes(11, B, N, M * K, 1, 0)      # CL3D_OP_INVERSE_INDEX
+        p.nparts = lib.cl3d_fused_param_partials(int(op), B, N, C)
+        arena = _Arena(p)
+        arena.add("idx", 4 * B * M * K)
+        arena.add("idx_mask", 4 * B * M * K)
+        arena.add("bq_ws", p.bq_ws_bytes)
+        arena.add("inv_off", 4 * B * (N + 1))
+        arena.add("inv_slots", 4 * B * M * K)
+        arena.add("csr_ws", p.csr_ws_bytes)
+        arena.add("ft", 4 * B * N * C)
+        arena.add("slotrec", 16 * B * M * K)
+        sparse = int(op) == 3 and C % 4 == 0 and not constant  # PseudoGrid's (kernel point, influence) pairs
+        if sparse:
+            arena.add("pairs", 32 * B * M * K)
+        kept = arena.allocate(dev)
+        if not sparse:
+            p.pairs = None
+        out = torch.empty((B, C, M), dtype=torch.float32, device=dev)
+        p.out = out.data_ptr()
+        with _lib.on_device(dev):
+            _lib.check(lib.cl3d_reduce_train_forward(ctypes.byref(p), _stream(features)))
+        ctx.block, ctx.keep = p, [inputs, kept]
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        p = ctx.block
+        B, N, M, C, op = p.B, p.N, p.M, p.C, p.op
+        dev = gout.device
+        lib = _lib.lib()
+        gout = gout.contiguous()
+        p.gout = gout.data_ptr()
+        npar = {2: 4, 3: 16}.get(op, 0)
+        arena = _Arena(p)
+        arena.add("gout_t", 4 * B * M * C)
+        arena.add("dparam", 4 * p.nparts * C * npar)
+        scratch = arena.allocate(dev)
+        dfeat = torch.empty((B, C, N), dtype=torch.float32, device=dev)
+        p.dfeat = dfeat.data_ptr()
+        g0 = g1 = None
+        if op == 2:
+            g0 = torch.empty((C // p.pint, 3), dtype=torch.float32, device=dev)
+            g1 = torch.empty((C // p.pint,), dtype=torch.float32, device=dev)
+        elif op == 3:
+            g1 = torch.empty((p.pint, C), dtype=torch.float32, device=dev)
+        p.g0 = g0.data_ptr() if g0 is not None else None
+        p.g1 = g1.data_ptr() if g1 is not None else None
+        with _lib.on_device(dev):
+            _lib.check(lib.cl3d_reduce_train_backward(ctypes.byref(p), _stream(gout)))
+        del scratch
+        return (dfeat, g0, g1) + (None,) * 12
 
 
 class _Arena:

@@ -475,6 +475,35 @@ int cl3d_pwmlp_train_backward(const cl3d_pwmlp_pass *p, cl3d_stream_t stream);
 int cl3d_pwmlp_pass_graphs(int enable);
 int cl3d_pwmlp_pass_graph_stats(long long *captures, long long *replays);
 
+/* ---- the same for the three gather-and-reduce operators (round 6; csrc/pass.hip): a PosPool / AdaptiveWeight / PseudoGrid
+ * LocalAggregation UP TO its output transform (the BatchNorm + ReLU behind it stay calls of their own, cl3d_bn_relu_*) --
+ * forward: ball query, layout change of the features (forked), the fused reduction, the CSR inverse (forked behind the
+ * query, joined at the end); backward: layout change of the upstream gradient, the support-major pass, the parameters'
+ * gradients -- enqueued by ONE call per direction, with the same launch-graph cache as the PointWiseMLP passes
+ * (cl3d_pwmlp_pass_graphs / _graph_stats govern and count both).  What it replaces in the reference: MaskedQueryAndGroup
+ * + the operator's tensor algebra, local_aggregation_operators.py:65-103,188-214,383-419, one `_ext` call per autograd
+ * node in its eager loop (pt_utils.py:16-61).  op / p0 / p1 / pint / pfloat / constant / normalize / reduction as in
+ * cl3d_fused_reduce_fwd; features [B,C,N] and out [B,C,M] channel-major (the reference's layout); ft [B,N,C], gout_t
+ * [B,M,C] point-major scratch; slotrec [B,M,K,4] / pairs [B,M,K,8] (NULL without a backward / for the other operators);
+ * dparam [nparts, C, 4 | 16] with nparts = cl3d_fused_param_partials; g0 / g1: the parameters' gradients
+ * (cl3d_fused_param_reduce), NULL for PosPool.  Every buffer is the caller's; every fork is joined before return. */
+typedef struct cl3d_reduce_pass {
+  int B, N, M, K, C, op, normalize, reduction, pint, constant, idx_ready, csr_ready, nparts;
+  float radius, pfloat;
+  int reserved;  /* (what would be padding; ignored, as in cl3d_pwmlp_pass) */
+  const float *query_xyz, *support_xyz;
+  const int32_t *query_mask, *support_mask;
+  const float *features, *p0, *p1;
+  int32_t *idx, *idx_mask, *inv_off, *inv_slots;
+  void *bq_ws, *csr_ws;
+  size_t bq_ws_bytes, csr_ws_bytes;
+  float *ft, *out, *slotrec, *pairs;
+  const float *gout;
+  float *gout_t, *dfeat, *dparam, *g0, *g1;
+} cl3d_reduce_pass;
+int cl3d_reduce_train_forward(const cl3d_reduce_pass *p, cl3d_stream_t stream);
+int cl3d_reduce_train_backward(const cl3d_reduce_pass *p, cl3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,8 +78,9 @@ def test_invalid_arguments_return_codes_not_exit(libpath):
 def test_python_binding_table_covers_header():
     from closerlook3d_amd import _lib
     names = set(_declared()) - {"cl3d_abi_version", "cl3d_last_error_string", "cl3d_workspace_bytes", "cl3d_d2_form",
-                                "cl3d_pwmlp_pass"}
-    by_pointer = {"cl3d_pwmlp_train_forward", "cl3d_pwmlp_train_backward"}  # (argument block by pointer: _lib._declare)
+                                "cl3d_pwmlp_pass", "cl3d_reduce_pass"}
+    by_pointer = {"cl3d_pwmlp_train_forward", "cl3d_pwmlp_train_backward", "cl3d_reduce_train_forward",
+                  "cl3d_reduce_train_backward"}  # (argument block by pointer: _lib._declare)
     assert names == set(_lib.SIGNATURES) | by_pointer, (names ^ (set(_lib.SIGNATURES) | by_pointer))
 
 
@@ -126,20 +127,22 @@ def test_cpu_tensors_rejected_like_the_reference():
         _ext.group_points(torch.rand(1, 2, 8), torch.zeros(1, 2, 2, dtype=torch.int32))
 
 
-def test_pass_argument_block_matches_the_header(tmp_path):
-    """cl3d_pwmlp_pass (include/cl3d.h) against its ctypes mirror (_lib.PwmlpPass): size and the offset of every field, as the
-    C compiler lays the header's struct out."""
+@pytest.mark.parametrize("cname,mirror", [("cl3d_pwmlp_pass", "PwmlpPass"), ("cl3d_reduce_pass", "ReducePass")])
+def test_pass_argument_block_matches_the_header(tmp_path, cname, mirror):
+    """cl3d_pwmlp_pass / cl3d_reduce_pass (include/cl3d.h) against their ctypes mirrors (_lib.PwmlpPass / ReducePass): size
+    and the offset of every field, as the C compiler lays the header's struct out."""
     from closerlook3d_amd import _lib
-    fields = [n for n, _ in _lib.PwmlpPass._fields_]
+    cls = getattr(_lib, mirror)
+    fields = [n for n, _ in cls._fields_]
     src = tmp_path / "offsets.c"
     src.write_text('#include <stddef.h>\n#include <stdio.h>\n#include "cl3d.h"\nint main(void) {\n'
-                   + '  printf("%zu\\n", sizeof(cl3d_pwmlp_pass));\n'
-                   + "".join(f'  printf("%zu\\n", offsetof(cl3d_pwmlp_pass, {n}));\n' for n in fields) + "  return 0;\n}\n")
+                   + f'  printf("%zu\\n", sizeof({cname}));\n'
+                   + "".join(f'  printf("%zu\\n", offsetof({cname}, {n}));\n' for n in fields) + "  return 0;\n}\n")
     exe = tmp_path / "offsets"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
-    assert got[0] == ctypes.sizeof(_lib.PwmlpPass)
-    assert got[1:] == [getattr(_lib.PwmlpPass, n).offset for n in fields]
+    assert got[0] == ctypes.sizeof(cls)
+    assert got[1:] == [getattr(cls, n).offset for n in fields]
 
 
 def test_pass_calls_validate_their_argument_block_before_any_launch():
@@ -158,6 +161,16 @@ def test_pass_calls_validate_their_argument_block_before_any_launch():
     assert b"null pointer" in lib.cl3d_last_error_string()
     assert lib.cl3d_pwmlp_train_backward(ctypes.byref(p), None) == -1
     assert b"null pointer" in lib.cl3d_last_error_string()
+    # the same for the three gather-and-reduce operators' passes (round 6)
+    assert lib.cl3d_reduce_train_forward(None, None) == -1 and b"null argument block" in lib.cl3d_last_error_string()
+    assert lib.cl3d_reduce_train_backward(None, None) == -1
+    r = _lib.ReducePass()
+    assert lib.cl3d_reduce_train_forward(ctypes.byref(r), None) == -1 and b"bad sizes" in lib.cl3d_last_error_string()
+    r.B, r.N, r.M, r.K, r.C, r.op, r.radius = 2, 64, 64, 8, 12, 0, 0.1
+    assert lib.cl3d_reduce_train_forward(ctypes.byref(r), None) == -1 and b"null pointer" in lib.cl3d_last_error_string()
+    assert lib.cl3d_reduce_train_backward(ctypes.byref(r), None) == -1 and b"null pointer" in lib.cl3d_last_error_string()
+    r.op = 4
+    assert lib.cl3d_reduce_train_forward(ctypes.byref(r), None) == -1 and b"bad sizes" in lib.cl3d_last_error_string()
 
 
 def test_pass_arena_hands_out_aligned_disjoint_addresses():

@@ -154,3 +154,72 @@ def test_a_retained_graph_can_be_differentiated_twice():
     del junk
     for a, b in zip([f.grad] + [p.grad for p in la.parameters()], once):
         assert torch.equal(a, b + b)
+
+
+REDUCE_OPS = [  # name, kind, overrides, C
+    ("pospool_xyz", "pospool", {"pospool__position_embedding": "xyz", "pospool__reduction": "avg"}, 72),
+    ("pospool_sincos", "pospool", {"pospool__position_embedding": "sin_cos", "pospool__reduction": "avg"}, 36),
+    ("adaptive_weight", "adaptive_weight", {}, 64),
+    ("adaptive_weight_shared", "adaptive_weight", {"adaptive_weight__shared_channels": 2, "adaptive_weight__reduction": "sum"}, 32),
+    ("pseudo_grid", "pseudo_grid", {}, 64),
+    ("pseudo_grid_constant", "pseudo_grid", {"pseudo_grid__KP_influence": "constant"}, 24),
+]
+
+
+@pytest.mark.parametrize("strided", [False, True])
+@pytest.mark.parametrize("name,kind,over,C", REDUCE_OPS)
+def test_reduce_pass_calls_equal_the_kernel_by_kernel_path(name, kind, over, C, strided, monkeypatch):
+    """Round 6: cl3d_reduce_train_forward / _backward -- the one-call-per-pass path of PosPool /
+    AdaptiveWeight / PseudoGrid (pass_calls._ReducePass) -- against fused._FusedReduce kernel by kernel: bit-equal outputs,
+    feature and parameter gradients and BatchNorm buffers over four training steps (direct, captured and replayed calls),
+    M == N and a strided layer, padded clouds; and the launch-graph cache is the one the PointWiseMLP passes use."""
+    from closerlook3d_amd import fused
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    B, N, K, radius = 3, 1024, 16, 0.15
+    M = 256 if strided else N
+    q, s, qm, sm = _cloud(B, N, M, 0.1, seed=len(name) + C)
+    torch.manual_seed(1)
+    feats = torch.randn(B, C, N, device="cuda")
+    probe = torch.randn(B, C, M, device="cuda")
+    res = {}
+    before = _graph_stats()
+    for on in (True, False):
+        monkeypatch.setattr(fused, "PASS_CALLS", on)
+        torch.manual_seed(2)
+        la = LocalAggregation(C, C, radius, K, default_config(kind, over, cl3d_impl="fused")).cuda().train()
+        steps = []
+        for step in range(4):
+            la.zero_grad(set_to_none=True)
+            f = feats.clone().requires_grad_(True)
+            out = la(q, s, qm, sm, f)
+            (out * probe).sum().backward()
+            steps.append([out.detach().clone(), f.grad.clone()] + [p.grad.clone() for p in la.parameters() if p.grad is not None]
+                         + [b.clone() for b in la.buffers()])
+        torch.cuda.synchronize()
+        res[on] = steps
+        if on:
+            mid = _graph_stats()
+            assert mid[0] - before[0] >= 1 and mid[1] - before[1] >= 1, (before, mid)  # captured once, then replayed
+        else:
+            assert _graph_stats() == mid  # the kernel-by-kernel path never touches the pass graphs
+    for a_step, b_step in zip(res[True], res[False]):
+        assert len(a_step) == len(b_step) and len(a_step) >= 4
+        for a, b in zip(a_step, b_step):
+            assert torch.equal(a, b), "the pass calls run the kernel-by-kernel path's kernels: the bits must agree"
+
+
+def test_reduce_pass_is_what_an_eager_step_takes_and_a_capture_does_not(monkeypatch):
+    from closerlook3d_amd import fused
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    q, s, qm, sm = _cloud(2, 512, 512, 0.0, seed=9)
+    la = LocalAggregation(24, 24, 0.2, 16, default_config("pospool", {"pospool__position_embedding": "xyz", "pospool__reduction": "avg"},
+                                                          cl3d_impl="fused")).cuda().train()
+    taken = []
+    real = fused._reduce_pass
+    monkeypatch.setattr(fused, "_reduce_pass", lambda *a, **k: (taken.append(1), real(*a, **k))[1])
+    f = torch.randn(2, 24, 512, device="cuda", requires_grad=True)
+    la(q, s, qm, sm, f).sum().backward()
+    assert taken == [1]
+    with torch.no_grad():  # no backward will follow: the kernel-by-kernel forward (nothing kept)
+        la(q, s, qm, sm, f)
+    assert taken == [1]
