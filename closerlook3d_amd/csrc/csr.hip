@@ -39,7 +39,6 @@ namespace cl3d {
 // workgroup can only start where a TRAIN workgroup has retired, whatever its priority or size.)
 
 // ---- counting sort with wave-private LDS counters -------------------------------------------------
-constexpr int kCsrBatch = 8;  // slot loads in flight per lane
 
 struct CsrPlan {
   int wpb;    // waves per workgroup (each owns NR ints of LDS)
@@ -62,7 +61,10 @@ static bool csr_plan(int B, int N, int MK, CsrPlan *p) {
   const size_t row = (size_t)NR * sizeof(int);
   int wpb = (int)((64 * 1024) / row);
   wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
-  int G = 1024 / B / R;  // ~1024 waves on the chip: 64 ranges per cloud at B = 16, up to 256 for a single scene
+  // ~1024 waves on the chip: 64 ranges per cloud at B = 16, up to 256 for a single scene.  Key ranges: 512 -- their
+  // single-wave workgroups hold 64 KiB of LDS each, two per CU, so 512 are resident at once (1020 ran in two rounds:
+  // 170 us per count pass on an 81 920-point scene), and the [G][N] counter table halves
+  int G = (R > 1 ? 512 : 1024) / B / R;
   G = G < wpb ? wpb : (G > 256 ? 256 : G);
   int per = (MK + G - 1) / G;
   per = (per + 63) & ~63;
@@ -80,7 +82,7 @@ static bool csr_plan(int B, int N, int MK, CsrPlan *p) {
 // so with B a multiple of 8 every workgroup of a cloud runs on ONE XCD and the 4-byte scatter stores of the fill pass
 // (64 random rows per wave instruction) merge into whole lines in that XCD's L2 before they leave it -- with the
 // clouds spread over all XCDs the same stores left as partial lines (measured WRITE_SIZE 65 MB for a 4 MB table).
-template <bool FILL>
+template <bool FILL, int kCsrBatch = 8>  // kCsrBatch: slot loads in flight per lane (16 for the single-wave workgroups of key ranges)
 __global__ __launch_bounds__(256) void csr_count_fill_kernel(const int *__restrict__ idx, int B, int N, int MK, int GB, int per,
                                                              int NR, int *__restrict__ table, const int *__restrict__ inv_off,
                                                              int *__restrict__ inv_slots) {
@@ -266,24 +268,40 @@ extern "C" int cl3d_build_inverse_index(const int32_t *idx, int B, int N, int MK
   if (!cl3d::csr_plan(B, N, MK, &plan)) return cl3d::fail(CL3D_E_UNSUPPORTED, "build_inverse_index: grid too large");
   // more than 16 384 counters per wave exceed the 64 KiB a kernel gets by default
   static std::atomic<unsigned long long> count_granted{0}, fill_granted{0};
+  static std::atomic<unsigned long long> count16_granted{0}, fill16_granted{0};
   int rc_lds = cl3d::lds_opt_in(count_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<false>),
                                 128 * 1024, "build_inverse_index");
   if (rc_lds == CL3D_OK)
     rc_lds = cl3d::lds_opt_in(fill_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<true>),
                               128 * 1024, "build_inverse_index");
+  if (rc_lds == CL3D_OK && plan.R > 1)
+    rc_lds = cl3d::lds_opt_in(count16_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<false, 16>),
+                              128 * 1024, "build_inverse_index");
+  if (rc_lds == CL3D_OK && plan.R > 1)
+    rc_lds = cl3d::lds_opt_in(fill16_granted, reinterpret_cast<const void *>(cl3d::csr_count_fill_kernel<true, 16>),
+                              128 * 1024, "build_inverse_index");
   if (rc_lds != CL3D_OK) return rc_lds;
   int *table = static_cast<int *>(ws);
   const int GB = plan.G / plan.wpb;
   const dim3 grid((unsigned)GB * (unsigned)B * (unsigned)plan.R), block(64 * plan.wpb);
-  hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<false>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per, plan.NR,
-                     table, (const int *)nullptr, (int *)nullptr);
+  // (key ranges: single-wave workgroups whose only parallelism is loads in flight -- 16 per lane instead of 8)
+  if (plan.R > 1)
+    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<false, 16>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per, plan.NR,
+                       table, (const int *)nullptr, (int *)nullptr);
+  else
+    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<false>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per, plan.NR,
+                       table, (const int *)nullptr, (int *)nullptr);
   for (int b0 = 0; b0 < B; b0 += 65535) {  // (grid.y limit)
     const int nb = B - b0 < 65535 ? B - b0 : 65535;
     hipLaunchKernelGGL(cl3d::csr_rows_kernel, dim3(cl3d::ceil_div(N, 64), nb), dim3(256), 0, st, N, GB,
                        table + (size_t)b0 * GB * N, inv_off + (size_t)b0 * (N + 1));
   }
   hipLaunchKernelGGL(cl3d::csr_scan_kernel, dim3(B), dim3(1024), 0, st, N, inv_off);
-  hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per, plan.NR,
-                     table, (const int *)inv_off, inv_slots);
+  if (plan.R > 1)
+    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true, 16>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per, plan.NR,
+                       table, (const int *)inv_off, inv_slots);
+  else
+    hipLaunchKernelGGL((cl3d::csr_count_fill_kernel<true>), grid, block, plan.lds, st, idx, B, N, MK, GB, plan.per, plan.NR,
+                       table, (const int *)inv_off, inv_slots);
   return cl3d::check_launch("cl3d_build_inverse_index");
 }

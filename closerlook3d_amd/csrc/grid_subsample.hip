@@ -131,6 +131,7 @@ __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[R], 
 //            with eight ballots, a lane's position is the cursor + the number of such lanes below it -- stable within the
 //            batch, batches in order, pieces in order.
 // Ping-pong between the two key buffers; the result always ends in `b` (a last copy when the pass count is even).
+constexpr int kSortAhead = 4;  // key batches (of 64) a wave requests before it consumes the first
 __global__ __launch_bounds__(kSubThreads) void grid_sort_kernel(unsigned long long *__restrict__ a, unsigned long long *__restrict__ b,
                                                                 const SubParams *__restrict__ params, int N) {
   __shared__ unsigned s_hist[kSubThreads / 64][256];
@@ -161,7 +162,17 @@ __global__ __launch_bounds__(kSubThreads) void grid_sort_kernel(unsigned long lo
     const int shift = kBigIdxBits + 8 * pass;
     for (int i = tid; i < (kSubThreads / 64) * 256; i += kSubThreads) (&s_hist[0][0])[i] = 0u;
     __syncthreads();
-    for (int i = p0 + lane; i < p1; i += 64) atomicAdd(&s_hist[wave][(unsigned)(src[i] >> shift) & 255u], 1u);
+    for (int i0 = p0; i0 < p1; i0 += 64 * kSortAhead) {  // kSortAhead batches requested together: one round trip, not four
+      unsigned long long k[kSortAhead];
+#pragma unroll
+      for (int u = 0; u < kSortAhead; ++u) {
+        const int i = i0 + 64 * u + lane;
+        k[u] = src[i < p1 ? i : p1 - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < kSortAhead; ++u)
+        if (i0 + 64 * u + lane < p1) atomicAdd(&s_hist[wave][(unsigned)(k[u] >> shift) & 255u], 1u);
+    }
     __syncthreads();
     if (tid < 256) {  // digit tid: totals, and the pieces' counters turned into starts relative to the digit's start
       unsigned run = 0;
@@ -191,10 +202,20 @@ __global__ __launch_bounds__(kSubThreads) void grid_sort_kernel(unsigned long lo
         for (int w = 0; w < kSubThreads / 64; ++w) s_hist[w][tid] += start;
     }
     __syncthreads();
-    for (int i0 = p0; i0 < p1; i0 += 64) {
+    for (int j0 = p0; j0 < p1; j0 += 64 * kSortAhead) {
+      unsigned long long kk[kSortAhead];
+#pragma unroll
+      for (int u = 0; u < kSortAhead; ++u) {
+        const int i = j0 + 64 * u + lane;
+        kk[u] = src[i < p1 ? i : p1 - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < kSortAhead; ++u) {
+      const int i0 = j0 + 64 * u;
+      if (i0 >= p1) break;  // (uniform)
       const int i = i0 + lane;
       const bool on = i < p1;
-      const unsigned long long key = on ? src[i] : 0ull;
+      const unsigned long long key = on ? kk[u] : 0ull;
       const unsigned d = (unsigned)(key >> shift) & 255u;
       unsigned long long same = __ballot(on);
 #pragma unroll
@@ -212,6 +233,7 @@ __global__ __launch_bounds__(kSubThreads) void grid_sort_kernel(unsigned long lo
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
       if (on) dst[base + (unsigned)rank] = key;
+      }
     }
     __syncthreads();  // (every wave's stores are issued and, by the barrier's release, visible to the workgroup)
     unsigned long long *t = src;
