@@ -14,7 +14,6 @@
 //   OP_ADAPTIVE        w_c = bias[c/S] + W[c/S,:] . rel          (weight_type 'dp', one conv layer)
 //   OP_PSEUDOGRID      out_c = sum_p kw[p,c] * sum_k h_p(rel_k) mask_k f_c,k,  h_p = max(1 - |rel-KP_p| / extent, 0)
 #include "fused_common.h"
-#include <mutex>
 
 namespace cl3d {
 
@@ -994,41 +993,6 @@ extern "C" int cl3d_fused_reduce_fwd(int op, const float *query_xyz, const float
   return check_launch("cl3d_fused_reduce_fwd");
 }
 
-namespace cl3d {
-// one side stream + two events per device for the forked kernel-weight pass of PseudoGrid's backward (created on first
-// use, non-blocking; `use` serialises the calls of one device: the events are shared)
-struct PgFork {
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  std::mutex use;
-  bool ok = false;
-};
-static PgFork *pg_fork() {
-  static PgFork f[64];
-  static std::mutex mu;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  PgFork &r = f[dev];
-  if (!r.ok) {
-    if (hipStreamCreateWithFlags(&r.side, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming) != hipSuccess) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    r.ok = true;
-  }
-  return &r;
-}
-#ifndef CL3D_PG_FORK
-#define CL3D_PG_FORK 1   // 0: variant build for the A/B (scripts/ab/build_variant.py): both passes on the caller's stream
-#endif
-static bool pg_fork_pays(int B, int M, int K, int C) {
-  return CL3D_PG_FORK != 0 && (long long)B * M * K * C >= (1ll << 25);  // >= ~34 M (slot, channel) pairs per pass
-}
-}  // namespace cl3d
-
 extern "C" int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *ft,
                                      const float *slotrec, const float *pairs, const int32_t *idx, const int32_t *inv_off,
                                      const int32_t *inv_slots, int B, int N, int M, int K, int C,
@@ -1065,62 +1029,26 @@ extern "C" int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *f
   const long long tiles = (long long)B * ceil_div(N, waves * m.QW);
   const int gx = has_params ? n_partials : round_grid(tiles, 4096);
   const int gy = chunk_grid(tiles < gx ? tiles : gx, m.chunks);
-  // PseudoGrid's backward is TWO gather passes that share nothing but their inputs: the support-major pass (d features)
-  // and the query-major pass below (d kernel_weights).  One behind the other they were 95.7 + 83.0 us of a 0.386 ms step
-  // at the metric shape, each latency-bound at 0.17 of HBM (profiles/r06/bench_pseudo_grid.json): for large layers the
-  // second one is forked onto a stream of the library's from the point BEFORE the first is enqueued and joined behind it
-  // (two cross-queue hand-overs of ~10 us against ~80 us of overlap; small layers keep one stream).
-  PgFork *fork = nullptr;
-  hipStream_t dkw_stream = (hipStream_t)stream;
-  if (op == OP_PSEUDOGRID && pg_fork_pays(B, M, K, C)) {
-    fork = pg_fork();
-    if (fork != nullptr) {
-      fork->use.lock();
-      if (hipEventRecord(fork->ev_fork, (hipStream_t)stream) != hipSuccess ||
-          hipStreamWaitEvent(fork->side, fork->ev_fork, 0) != hipSuccess) {
-        (void)hipGetLastError();
-        fork->use.unlock();
-        fork = nullptr;
-      } else {
-        dkw_stream = fork->side;
-      }
-    }
-  }
   if (V == 4) launch_bwd<4>(op, a, dim3(gx, gy), dim3(64 * waves), lds, (hipStream_t)stream);
   else launch_bwd<1>(op, a, dim3(gx, gy), dim3(64 * waves), lds, (hipStream_t)stream);
   rc = check_launch("cl3d_fused_reduce_bwd");
-  if (rc != CL3D_OK || op != OP_PSEUDOGRID) {
-    if (fork != nullptr) {  // (the side stream waits for an event and has nothing enqueued: nothing to join)
-      fork->use.unlock();
-    }
-    return rc;
-  }
+  if (rc != CL3D_OK || op != OP_PSEUDOGRID) return rc;
   // d kernel_weights: query-major pass (the forward loop with the output gradient folded in)
+  CL3D_REQUIRE(idx, "fused_reduce_bwd: PseudoGrid needs idx");
   size_t lds_dkw = 0;
   const LaneMap mf = dkw_lane_map(C, K, V, &lds_dkw);
   a.L = mf.L; a.QW = mf.QW; a.chunks = mf.chunks;
-  if (idx == nullptr || lds_dkw > 64 * 1024) {
-    if (fork != nullptr) {  // join what was forked (an event wait, nothing else), then refuse
-      (void)hipEventRecord(fork->ev_join, fork->side);
-      (void)hipStreamWaitEvent((hipStream_t)stream, fork->ev_join, 0);
-      fork->use.unlock();
-    }
-    if (idx == nullptr) return fail(CL3D_E_INVALID, "fused_reduce_bwd: PseudoGrid needs idx");
-    return fail(CL3D_E_UNSUPPORTED, "fused_reduce_bwd: nsample=%d needs %zu B of LDS", K, lds_dkw);
-  }
+  if (lds_dkw > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "fused_reduce_bwd: nsample=%d needs %zu B of LDS", K, lds_dkw);
   const long long tiles_q = (long long)B * ceil_div(M, 4 * mf.QW);
   const dim3 grid_dkw(n_partials, chunk_grid(tiles_q < n_partials ? tiles_q : n_partials, mf.chunks));
+  // (round 6: this pass forked onto a stream of the library's, beside the support-major pass instead of behind it, was
+  // built and measured again -- scripts/micro/kernel_variants.py "pg_nofork", profiles/r06/session7_summary.txt: side by
+  // side the two take 167 + 105 us instead of 83 + 96 one behind the other -- both are bound by issue and L2 requests, not
+  // by exposed latency -- and the step 0.389-0.390 against 0.384-0.386 ms; as in round 3, dropped)
   // (a sparse form of this pass -- per-lane-group accumulators in LDS, updated per pair -- was built and measured: 188 us
   // against 95 us for the dense loop, whose 32 packed FMAs per slot cost no more than the ballots, address arithmetic
   // and dependent LDS read-modify-writes of ~1.2 updates; the gradient of the kernel weights stays dense)
-  if (V == 4) hipLaunchKernelGGL((pg_dkw_kernel<4>), grid_dkw, dim3(256), lds_dkw, dkw_stream, a);
-  else hipLaunchKernelGGL((pg_dkw_kernel<1>), grid_dkw, dim3(256), lds_dkw, dkw_stream, a);
-  rc = check_launch("cl3d_fused_reduce_bwd(dkw)");
-  if (fork != nullptr) {  // join: the caller's stream waits for the side pass (never the host)
-    if (rc == CL3D_OK && (hipEventRecord(fork->ev_join, fork->side) != hipSuccess ||
-                          hipStreamWaitEvent((hipStream_t)stream, fork->ev_join, 0) != hipSuccess))
-      rc = fail(CL3D_E_LAUNCH, "fused_reduce_bwd: join: %s", hipGetErrorString(hipGetLastError()));
-    fork->use.unlock();
-  }
-  return rc;
+  if (V == 4) hipLaunchKernelGGL((pg_dkw_kernel<4>), grid_dkw, dim3(256), lds_dkw, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((pg_dkw_kernel<1>), grid_dkw, dim3(256), lds_dkw, (hipStream_t)stream, a);
+  return check_launch("cl3d_fused_reduce_bwd(dkw)");
 }
