@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the summaries of one `bash scripts/gpu_check.sh <tag>` session from gpurun_out/<tag>/ into profiles/<round>/
 # under the names profiles/README.md lists.   bash scripts/collect_profiles.sh r05z r05
-TAG=$1; ROUND=${2:-r05}
+TAG=$1; ROUND=${2:-r06}
 S=gpurun_out/$TAG; D=profiles/$ROUND
 mkdir -p $D
 cp $S/summary.txt $D/gpu_check_summary.txt

@@ -3,7 +3,7 @@
 # timed step and of the ball_query+group boundary, the contraction, the other operators, the backbone configs, the
 # data-parallel stand-ins and the round's micro-benchmarks.
 # Usage (from the repo root on the GPU box): bash scripts/gpu_check.sh [tag]      (then scripts/collect_profiles.sh)
-TAG=${1:-r05}
+TAG=${1:-r06}
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -61,7 +61,8 @@ timeout 600 python scripts/bench_point_gemm.py --sweep 2>/dev/null | tee $OUT/po
 timeout 600 python scripts/bench_point_gemm.py --convs --reps 20 2>/dev/null > $OUT/convs.jsonl
 echo "== other operators (bench.py --operator)" | tee -a $OUT/summary.txt
 for op in pospool adaptive_weight pseudo_grid; do
-  timeout 600 python bench.py --operator $op --no-cpu-baseline --no-kernel-roofline 2>/dev/null | tee $OUT/bench_$op.json | cut -c1-330 | tee -a $OUT/summary.txt
+  # (with the step table: the PMC columns come from profiles/rNN/step_counters_$op.json, scripts/sessions/r06_s4.sh collects them)
+  timeout 600 python bench.py --operator $op --no-cpu-baseline --backbone off 2>/dev/null | tee $OUT/bench_$op.json | cut -c1-330 | tee -a $OUT/summary.txt
 done
 echo "== backbone steps (scripts/bench_backbone.py); configs 3 / 4 / 5 also layer by layer (f1 off)" | tee -a $OUT/summary.txt
 for c in modelnet_small modelnet_pointwisemlp s3dis_pseudogrid partnet_adaptive s3dis_pospool_deep; do
