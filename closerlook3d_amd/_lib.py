@@ -113,7 +113,11 @@ class ReducePass(ctypes.Structure):
         + [(n, _P) for n in ("query_xyz", "support_xyz", "query_mask", "support_mask", "features", "p0", "p1", "idx",
                              "idx_mask", "inv_off", "inv_slots", "bq_ws", "csr_ws")]
         + [(n, _Z) for n in ("bq_ws_bytes", "csr_ws_bytes")]
-        + [(n, _P) for n in ("ft", "out", "slotrec", "pairs", "gout", "gout_t", "dfeat", "dparam", "g0", "g1")])
+        + [(n, _P) for n in ("ft", "out", "slotrec", "pairs", "gout", "gout_t", "dfeat", "dparam", "g0", "g1")]
+        + [(n, _P) for n in ("gamma", "beta", "running_mean", "running_var", "num_batches_tracked", "act", "vec", "graw",
+                             "coef", "bn_partial")]
+        + [(n, _F) for n in ("eps", "momentum")]
+        + [("bn_parts", _I), ("reserved2", _I)])
 
 
 def _declare(handle):

@@ -96,13 +96,17 @@ static_assert(sizeof(cl3d_pwmlp_pass) == 14 * 4 + 13 * 8 + 4 * sizeof(size_t) + 
 
 // the block as the launch-graph tables key it: a byte copy with the reserved word (the only bytes no field of the ABI
 // defines) cleared, so two calls with the same arguments compare equal whatever the caller left there
-static_assert(sizeof(cl3d_reduce_pass) == 16 * 4 + 13 * 8 + 2 * sizeof(size_t) + 10 * 8, "cl3d_reduce_pass has padding: compare field-wise");
+static_assert(sizeof(cl3d_reduce_pass) == 16 * 4 + 13 * 8 + 2 * sizeof(size_t) + 10 * 8 + 10 * 8 + 4 * 4,
+              "cl3d_reduce_pass has padding: compare field-wise");
+
+static void clear_reserved(cl3d_pwmlp_pass &k) { k.reserved = 0; }
+static void clear_reserved(cl3d_reduce_pass &k) { k.reserved = 0; k.reserved2 = 0; }
 
 template <class Block>
 static Block block_key(const Block *p) {
   Block k;
   memcpy(&k, p, sizeof(k));
-  k.reserved = 0;
+  clear_reserved(k);
   return k;
 }
 
@@ -335,12 +339,23 @@ static int enqueue_reduce_forward(const cl3d_reduce_pass *p, hipStream_t st, cl3
   CL3D_TRY(cl3d_fused_reduce_fwd(p->op, p->query_xyz, p->support_xyz, p->query_mask, p->idx, p->idx_mask, p->ft, p->B, p->N,
                                  p->M, p->K, p->C, p->radius, p->normalize, p->reduction, p->p0, p->p1, p->pint, p->pfloat,
                                  p->constant, p->out, 1, p->slotrec, p->pairs, st));
+  if (p->gamma != nullptr)  // the output transform: BatchNorm1d (batch statistics) + ReLU on the raw result
+    CL3D_TRY(cl3d_bn_add_relu_train_fwd(p->out, p->gamma, p->beta, p->running_mean, p->running_var, p->num_batches_tracked,
+                                        p->eps, p->momentum, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 1,
+                                        p->B, p->C, p->M, p->bn_partial, p->bn_parts, p->vec, nullptr, p->act, st));
   if (want_csr) CL3D_TRY(hip_ok(hipStreamWaitEvent(st, rt->ev_csr, 0), "reduce_train_forward: join"));
   return CL3D_OK;
 }
 
 static int enqueue_reduce_backward(const cl3d_reduce_pass *p, hipStream_t st) {
-  CL3D_TRY(cl3d_transpose(p->gout, p->B, p->C, p->M, p->gout_t, st));
+  const float *g = p->gout;
+  if (p->gamma != nullptr) {  // BatchNorm + ReLU backward: gradient w.r.t. the activated output -> w.r.t. the raw result
+    CL3D_TRY(cl3d_bn_add_relu_bwd(p->gout, p->act, p->out, p->vec + 2 * p->C, p->vec + 3 * p->C, p->gamma, nullptr, nullptr,
+                                  nullptr, nullptr, 1, p->B, p->C, p->M, (double)p->B * p->M, p->bn_partial, p->bn_parts,
+                                  p->coef, nullptr, p->graw, nullptr, st));
+    g = p->graw;
+  }
+  CL3D_TRY(cl3d_transpose(g, p->B, p->C, p->M, p->gout_t, st));
   CL3D_TRY(cl3d_fused_reduce_bwd(p->op, p->gout_t, p->ft, p->slotrec, p->pairs, p->idx, p->inv_off, p->inv_slots, p->B, p->N,
                                  p->M, p->K, p->C, p->p0, p->p1, p->pint, p->pfloat, p->constant, p->dfeat, 1, p->dparam,
                                  p->nparts, st));
@@ -357,6 +372,9 @@ extern "C" int cl3d_reduce_train_forward(const cl3d_reduce_pass *p, cl3d_stream_
   CL3D_REQUIRE(p->query_xyz && p->support_xyz && p->query_mask && p->support_mask && p->idx && p->idx_mask && p->features &&
                    p->ft && p->out,
                "reduce_train_forward: null pointer");
+  CL3D_REQUIRE(p->gamma == nullptr || (p->beta && p->running_mean && p->running_var && p->act && p->vec && p->bn_partial &&
+                                       p->bn_parts == cl3d_bn_partials(p->B, p->C, p->M) && p->momentum >= 0.f),
+               "reduce_train_forward: the output transform needs beta, running statistics, act, vec and bn_partial");
   if (p->B == 0) return CL3D_OK;
   PassRuntime *rt = pass_runtime();
   if (rt == nullptr) return fail(CL3D_E_LAUNCH, "reduce_train_forward: side streams could not be created");
@@ -370,6 +388,8 @@ extern "C" int cl3d_reduce_train_backward(const cl3d_reduce_pass *p, cl3d_stream
   CL3D_REQUIRE(p->gout && p->gout_t && p->ft && p->slotrec && p->idx && p->inv_off && p->inv_slots && p->dfeat,
                "reduce_train_backward: null pointer");
   CL3D_REQUIRE(p->nparts == 0 || p->dparam != nullptr, "reduce_train_backward: null dparam");
+  CL3D_REQUIRE(p->gamma == nullptr || (p->act && p->out && p->vec && p->graw && p->coef && p->bn_partial),
+               "reduce_train_backward: the output transform needs act, out, vec, graw, coef and bn_partial");
   if (p->B == 0) return CL3D_OK;
   PassRuntime *rt = pass_runtime();
   if (rt == nullptr) return fail(CL3D_E_LAUNCH, "reduce_train_backward: side streams could not be created");

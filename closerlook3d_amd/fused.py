@@ -435,7 +435,7 @@ def join_pending(out):
 
 
 def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, embedding, reduction,
-            defer_join=False):
+            defer_join=False, out_bn=None):
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     C = features.shape[1]
     if embedding == 'xyz':
@@ -450,7 +450,7 @@ def pospool(query_xyz, support_xyz, query_mask, support_mask, features, radius, 
         p0 = torch.pow(1.0 * 1000, (1.0 / fd) * torch.arange(fd, dtype=torch.float32, device=features.device))
     if _use_reduce_pass(_wants_grad(features)):
         return _reduce_pass(features, p0, None, op, query_xyz, support_xyz, query_mask, support_mask, radius, nsample, True,
-                            _RED[reduction], 0, 0.0, False)
+                            _RED[reduction], 0, 0.0, False, out_bn)
     idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample, _wants_grad(features))
     out = _FusedReduce.apply(features, p0, None, op, query_xyz, support_xyz, query_mask, idx, idx_mask, radius,
                              True, _RED[reduction], 0, 0.0, False, _wants_grad(features), defer_join)
@@ -465,20 +465,28 @@ def _use_reduce_pass(need_grad):
 
 
 def _reduce_pass(features, p0, p1, op, query_xyz, support_xyz, query_mask, support_mask, radius, nsample, normalize,
-                 reduction, pint, pfloat, constant):
+                 reduction, pint, pfloat, constant, out_bn=None):
+    """out_bn (an nn.BatchNorm1d in training mode that the kernels cover, or None): the operator's BatchNorm + ReLU output
+    transform inside the same two C-ABI calls; the result then is marked so that the module does not apply it again."""
     from .pass_calls import _ReducePass
+    if out_bn is not None and _bn_unit_ok(features, out_bn) and out_bn.training and out_bn.running_mean is not None:
+        out = _ReducePass.apply(features, p0, p1, op, query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
+                                normalize, reduction, pint, pfloat, constant, out_bn.weight, out_bn.bias,
+                                out_bn.running_mean, out_bn.running_var, _step_counter(out_bn), out_bn.momentum, out_bn.eps)
+        out._cl3d_activated = True
+        return out
     return _ReducePass.apply(features, p0, p1, op, query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
                              normalize, reduction, pint, pfloat, constant)
 
 
 def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, mlps,
-                    shared_channels, reduction, defer_join=False):
+                    shared_channels, reduction, defer_join=False, out_bn=None):
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     conv = mlps.conv0
     w = conv.weight.view(conv.weight.shape[0], 3)
     if _use_reduce_pass(_wants_grad(features, w, conv.bias)):
         return _reduce_pass(features, w, conv.bias, OP_ADAPTIVE, query_xyz, support_xyz, query_mask, support_mask, radius,
-                            nsample, True, _RED[reduction], int(shared_channels), 0.0, False)
+                            nsample, True, _RED[reduction], int(shared_channels), 0.0, False, out_bn)
     idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
                            _wants_grad(features, w, conv.bias))
     out = _FusedReduce.apply(features, w, conv.bias, OP_ADAPTIVE, query_xyz, support_xyz, query_mask, idx,
@@ -488,12 +496,12 @@ def adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, features, 
 
 
 def pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, features, radius, nsample, k_points,
-                kernel_weights, extent, influence, defer_join=False):
+                kernel_weights, extent, influence, defer_join=False, out_bn=None):
     features, query_xyz, support_xyz, query_mask, support_mask = _checked(features, query_xyz, support_xyz, query_mask, support_mask)
     if _use_reduce_pass(_wants_grad(features, kernel_weights)):
         return _reduce_pass(features, k_points.contiguous(), kernel_weights, OP_PSEUDOGRID, query_xyz, support_xyz, query_mask,
                             support_mask, radius, nsample, False, _RED['sum'], int(k_points.shape[0]), 1.0 / float(extent),
-                            influence == 'constant')
+                            influence == 'constant', out_bn)
     idx, idx_mask = _query(query_xyz, support_xyz, query_mask, support_mask, radius, nsample,
                            _wants_grad(features, kernel_weights))
     out = _FusedReduce.apply(features, k_points.contiguous(), kernel_weights, OP_PSEUDOGRID, query_xyz,

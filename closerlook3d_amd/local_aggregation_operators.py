@@ -61,7 +61,14 @@ class _OutputTransform(nn.Module):
                 nn.BatchNorm1d(out_channels, momentum=bn_momentum),
                 nn.ReLU(inplace=True))
 
+    def _out_bn(self):
+        """The BatchNorm1d of a plain `out_transform` (no output convolution), which the one-call-per-pass path of the
+        fused operators applies itself (pass_calls._ReducePass); None otherwise."""
+        return None if self.output_conv else self.out_transform[0]
+
     def _output(self, x):
+        if getattr(x, '_cl3d_activated', False):  # the pass call already applied BatchNorm + ReLU (and joined everything)
+            return x
         # fused path: BatchNorm1d + ReLU through the engine's streaming kernels (same parameters / buffers /
         # running-statistics rule); 'grouped' keeps the reference's module-by-module dataflow
         if getattr(self, 'impl', 'auto') != 'grouped' and x.is_cuda:
@@ -107,7 +114,8 @@ class PosPool(_OutputTransform):
         from . import fused
         if fused.use_fused(self.impl, 'pospool', self):
             out = fused.pospool(query_xyz, support_xyz, query_mask, support_mask, support_features,
-                                self.radius, self.nsample, self.position_embedding, self.reduction, defer_join=True)
+                                self.radius, self.nsample, self.position_embedding, self.reduction, defer_join=True,
+                                out_bn=self._out_bn())
             return self._output(out)
         feats, rel, nmask = self.grouper(query_xyz, support_xyz, query_mask, support_mask, support_features)
         agg = feats * self._embedding(rel, support_features.shape[1])
@@ -146,7 +154,7 @@ class AdaptiveWeight(_OutputTransform):
         if fused.use_fused(self.impl, 'adaptive_weight', self):
             out = fused.adaptive_weight(query_xyz, support_xyz, query_mask, support_mask, support_features,
                                         self.radius, self.nsample, self.mlps, self.shared_channels,
-                                        self.reduction, defer_join=True)
+                                        self.reduction, defer_join=True, out_bn=self._out_bn())
             return self._output(out)
         B, C, M = support_features.shape[0], support_features.shape[1], query_xyz.shape[1]
         feats, rel, nmask = self.grouper(query_xyz, support_xyz, query_mask, support_mask, support_features)
@@ -267,7 +275,7 @@ class PseudoGrid(_OutputTransform):
         if fused.use_fused(self.impl, 'pseudo_grid', self):
             out = fused.pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, support_features,
                                     self.radius, self.nsample, self.K_points, self.kernel_weights,
-                                    self.extent, self.KP_influence, defer_join=True)
+                                    self.extent, self.KP_influence, defer_join=True, out_bn=self._out_bn())
             return self._output(out)
         B, C, M = support_features.shape[0], support_features.shape[1], query_xyz.shape[1]
         feats, rel, nmask = self.grouper(query_xyz, support_xyz, query_mask, support_mask, support_features)

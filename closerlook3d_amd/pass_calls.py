@@ -115,7 +115,10 @@ class _ReducePass(Function):
 
     @staticmethod
     def forward(ctx, features, p0, p1, op, query_xyz, support_xyz, query_mask, support_mask, radius, nsample, normalize,
-                reduction, pint, pfloat, constant):
+                reduction, pint, pfloat, constant, gamma=None, beta=None, running_mean=None, running_var=None,
+                num_batches_tracked=None, momentum=0.1, eps=1e-5):
+        """gamma ... eps (optional): the operator's BatchNorm1d + ReLU output transform rides in the same two calls; the
+        node then returns the ACTIVATED output and its backward also yields d gamma, d beta."""
         B, C, N = features.shape
         M, K = query_xyz.shape[1], int(nsample)
         dev = features.device
@@ -143,14 +146,30 @@ class _ReducePass(Function):
         sparse = int(op) == 3 and C % 4 == 0 and not constant  # PseudoGrid's (kernel point, influence) pairs
         if sparse:
             arena.add("pairs", 32 * B * M * K)
+        with_bn = gamma is not None
+        if with_bn:
+            p.bn_parts = lib.cl3d_bn_partials(B, C, M)
+            p.eps, p.momentum = float(eps), float(momentum)
+            arena.add("out", 4 * B * C * M)                       # the raw result: kept for the BatchNorm backward
+            arena.add("vec", 4 * 4 * C)
+            arena.add("bn_partial", 8 * 2 * p.bn_parts * C * 2)
+            bn_inputs = (gamma, beta, running_mean, running_var, num_batches_tracked)
+            for name, t in zip(("gamma", "beta", "running_mean", "running_var", "num_batches_tracked"), bn_inputs):
+                setattr(p, name, t.data_ptr() if t is not None else None)
+            inputs = inputs + bn_inputs
         kept = arena.allocate(dev)
         if not sparse:
             p.pairs = None
         out = torch.empty((B, C, M), dtype=torch.float32, device=dev)
-        p.out = out.data_ptr()
+        if with_bn:
+            p.act = out.data_ptr()
+        else:
+            p.out = out.data_ptr()
         with _lib.on_device(dev):
             _lib.check(lib.cl3d_reduce_train_forward(ctypes.byref(p), _stream(features)))
-        ctx.block, ctx.keep = p, [inputs, kept]
+        ctx.block, ctx.keep, ctx.with_bn = p, [inputs, kept], with_bn
+        if with_bn:
+            ctx.save_for_backward(out)  # (the activated output gates the ReLU in the backward pass)
         return out
 
     @staticmethod
@@ -165,6 +184,13 @@ class _ReducePass(Function):
         arena = _Arena(p)
         arena.add("gout_t", 4 * B * M * C)
         arena.add("dparam", 4 * p.nparts * C * npar)
+        coef = None
+        if ctx.with_bn:
+            (act,) = ctx.saved_tensors
+            p.act = act.data_ptr()
+            arena.add("graw", 4 * B * C * M)
+            coef = torch.empty((5, C), dtype=torch.float32, device=dev)
+            p.coef = coef.data_ptr()
         scratch = arena.allocate(dev)
         dfeat = torch.empty((B, C, N), dtype=torch.float32, device=dev)
         p.dfeat = dfeat.data_ptr()
@@ -179,7 +205,9 @@ class _ReducePass(Function):
         with _lib.on_device(dev):
             _lib.check(lib.cl3d_reduce_train_backward(ctypes.byref(p), _stream(gout)))
         del scratch
-        return (dfeat, g0, g1) + (None,) * 12
+        if ctx.with_bn:
+            return (dfeat, g0, g1) + (None,) * 12 + (coef[3], coef[4]) + (None,) * 5
+        return (dfeat, g0, g1) + (None,) * 12 + (None,) * 7
 
 
 class _Arena:

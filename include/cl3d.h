@@ -476,7 +476,7 @@ int cl3d_pwmlp_pass_graphs(int enable);
 int cl3d_pwmlp_pass_graph_stats(long long *captures, long long *replays);
 
 /* ---- the same for the three gather-and-reduce operators (round 6; csrc/pass.hip): a PosPool / AdaptiveWeight / PseudoGrid
- * LocalAggregation UP TO its output transform (the BatchNorm + ReLU behind it stay calls of their own, cl3d_bn_relu_*) --
+ * LocalAggregation up to -- or, optionally, including -- its BatchNorm + ReLU output transform --
  * forward: ball query, layout change of the features (forked), the fused reduction, the CSR inverse (forked behind the
  * query, joined at the end); backward: layout change of the upstream gradient, the support-major pass, the parameters'
  * gradients -- enqueued by ONE call per direction, with the same launch-graph cache as the PointWiseMLP passes
@@ -486,7 +486,8 @@ int cl3d_pwmlp_pass_graph_stats(long long *captures, long long *replays);
  * cl3d_fused_reduce_fwd; features [B,C,N] and out [B,C,M] channel-major (the reference's layout); ft [B,N,C], gout_t
  * [B,M,C] point-major scratch; slotrec [B,M,K,4] / pairs [B,M,K,8] (NULL without a backward / for the other operators);
  * dparam [nparts, C, 4 | 16] with nparts = cl3d_fused_param_partials; g0 / g1: the parameters' gradients
- * (cl3d_fused_param_reduce), NULL for PosPool.  Every buffer is the caller's; every fork is joined before return. */
+ * (cl3d_fused_param_reduce), NULL for PosPool.  Every buffer is the caller's; every fork is joined before return.
+ * Optionally (gamma != NULL) the BatchNorm1d + ReLU output transform rides in the same two calls: see the block's tail. */
 typedef struct cl3d_reduce_pass {
   int B, N, M, K, C, op, normalize, reduction, pint, constant, idx_ready, csr_ready, nparts;
   float radius, pfloat;
@@ -500,6 +501,19 @@ typedef struct cl3d_reduce_pass {
   float *ft, *out, *slotrec, *pairs;
   const float *gout;
   float *gout_t, *dfeat, *dparam, *g0, *g1;
+  /* the operator's output transform when it is the plain BatchNorm1d + ReLU (`out_transform`,
+   * local_aggregation_operators.py:43-45,107-110), in the same two calls: gamma != NULL turns it on.  Forward: `out`
+   * [B,C,M] is the operator's raw result, `act` [B,C,M] what the caller sees = ReLU(BatchNorm(out)) with batch statistics,
+   * running statistics and num_batches_tracked (nullable) updated as nn.BatchNorm1d does; vec [4,C] = scale, shift, mean,
+   * invstd; bn_partial [2, bn_parts, C, 2] doubles with bn_parts = cl3d_bn_partials(B, C, M).  Backward: `gout` is the
+   * gradient with respect to `act`, graw [B,C,M] scratch, coef [5,C] receives (.., .., .., d gamma, d beta). */
+  const float *gamma, *beta;
+  float *running_mean, *running_var;
+  int64_t *num_batches_tracked;
+  float *act, *vec, *graw, *coef;
+  double *bn_partial;
+  float eps, momentum;
+  int bn_parts, reserved2;
 } cl3d_reduce_pass;
 int cl3d_reduce_train_forward(const cl3d_reduce_pass *p, cl3d_stream_t stream);
 int cl3d_reduce_train_backward(const cl3d_reduce_pass *p, cl3d_stream_t stream);
