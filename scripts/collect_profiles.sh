@@ -12,7 +12,7 @@ cp $S/bench_eager.json $D/bench_pointwisemlp_eager.json
 cp $(find $S/prof -name "bench_kernel_stats.csv" | head -1) $D/bench_pointwisemlp_kernel_stats.csv
 for f in step_counters.json step_timeline.txt pmc_traffic.json point_gemm.jsonl convs.jsonl bench_bq.jsonl \
          bench_pospool.json bench_adaptive_weight.json bench_pseudo_grid.json bench_dataset_grid.json bench_voting.json \
-         bench_sphere_crop.json eager_host.txt two_graph_repeat_check.txt graph_queues.txt bench_two_ranks_one_device.json; do
+         bench_sphere_crop.json eager_host.txt graph_queues.txt bench_two_ranks_one_device.json; do
   cp $S/$f $D/$f 2>/dev/null || echo "missing $f"
 done
 cp $S/backbone_steady_state.txt $D/backbone_modelnet_pointwisemlp_bf16_steady_state.txt
