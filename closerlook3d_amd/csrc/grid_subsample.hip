@@ -26,6 +26,9 @@
 #ifndef CL3D_SUB_PHASE
 #define CL3D_SUB_PHASE 0   // timing builds only: the kernel returns after phase n (scripts/micro/kernel_variants.py)
 #endif
+#ifndef CL3D_SUB_SORT
+#define CL3D_SUB_SORT 1    // in-LDS sort: 1 = stable radix sort on the cell bits (round 6), 0 = the bitonic network (A/B builds)
+#endif
 
 namespace cl3d {
 
@@ -116,6 +119,115 @@ __device__ __forceinline__ void bitonic_sort_regs(unsigned long long (&key)[R], 
   if (e0 < P) {
 #pragma unroll
     for (int r = 0; r < R; ++r) lds[e0 + r] = key[r];
+  }
+  __syncthreads();
+}
+
+// ---- round 6: the in-LDS sort as a stable LSD radix sort on the CELL bits.  Keys are made in index order, so a stable
+// sort by cell alone is the sort by (cell, index) -- and a cloud of N points has at most N occupied cells of a grid with a
+// few thousand: 10-13 significant bits = TWO 8-bit passes, against the 78 compare-exchange stages (20 of them through
+// barriers) of the bitonic network on the full 64-bit keys: 30 us of the kernel's 48 at N = 4096.  Layout: wave w owns the
+// elements [w 64 R, (w+1) 64 R), lane l holds the elements w 64 R + 64 b + l (b = 0 .. R-1) in registers for the whole
+// pass, so a batch b is 64 consecutive elements and the passes need ONE key buffer in LDS (everything is read into
+// registers before anything is scattered).  Per pass: wave-private digit histograms (LDS atomics), cursors
+// (digit-major, wave-minor), and a scatter in which the lanes of a batch that share a digit are found with eight ballots
+// -- stable within the batch, batches in order, waves in order.  Only the nv valid keys are sorted (the rest of the
+// array is never read).  Same result as any correct sort: the keys are unique.
+template <int R>
+__device__ __forceinline__ void radix_sort_lds(unsigned long long (&key)[R], int nv, unsigned long long *lds,
+                                               unsigned (*hist)[256], unsigned *tot, unsigned *wsum, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wbase = wave * 64 * R;
+  // the cell bits in which any two valid keys differ
+  if (tid == 0) wsum[16] = (unsigned)(key[0] >> 32);
+  __syncthreads();
+  const unsigned first = wsum[16];
+  unsigned diff = 0;
+#pragma unroll
+  for (int b = 0; b < R; ++b)
+    if (wbase + 64 * b + lane < nv) diff |= (unsigned)(key[b] >> 32) ^ first;
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) diff |= __shfl_xor(diff, o, 64);
+  if (lane == 0) wsum[wave] = diff;
+  __syncthreads();
+  diff = 0;
+  for (int w = 0; w < kSubThreads / 64; ++w) diff |= wsum[w];
+  const int nbits = diff == 0 ? 0 : 32 - __builtin_clz(diff);
+  const int passes = (nbits + 7) / 8;
+  for (int pass = 0; pass < passes; ++pass) {
+    const int shift = 32 + 8 * pass;
+    __syncthreads();  // (wsum and the histograms of the previous pass have been read)
+    for (int i = tid; i < (kSubThreads / 64) * 256; i += kSubThreads) (&hist[0][0])[i] = 0u;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < R; ++b)
+      if (wbase + 64 * b + lane < nv) atomicAdd(&hist[wave][(unsigned)(key[b] >> shift) & 255u], 1u);
+    __syncthreads();
+    if (tid < 256) {
+      unsigned run = 0;
+      for (int w = 0; w < kSubThreads / 64; ++w) {
+        const unsigned c = hist[w][tid];
+        hist[w][tid] = run;
+        run += c;
+      }
+      tot[tid] = run;
+    }
+    __syncthreads();
+    {
+      const unsigned mine = tid < 256 ? tot[tid] : 0u;
+      unsigned incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63 && wave < 4) wsum[wave] = incl;
+      __syncthreads();
+      unsigned before = 0;
+      for (int w = 0; w < 4; ++w)
+        if (w < wave) before += wsum[w];
+      const unsigned start = before + incl - mine;
+      if (tid < 256)
+        for (int w = 0; w < kSubThreads / 64; ++w) hist[w][tid] += start;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < R; ++b) {
+      const bool on = wbase + 64 * b + lane < nv;
+      const unsigned d = (unsigned)(key[b] >> shift) & 255u;
+      unsigned long long same = __ballot(on);
+      if (same == 0ull) break;  // (uniform: this wave's remaining batches lie beyond the valid keys)
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const unsigned long long m = __ballot((d >> bit) & 1u);
+        same &= ((d >> bit) & 1u) ? m : ~m;
+      }
+      const int rank = prefix_popc(same);
+      const int count = (int)__popcll(same);
+      unsigned base = 0;
+      if (on) base = hist[wave][d];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (on && rank == count - 1) hist[wave][d] = base + (unsigned)count;
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (on) lds[base + (unsigned)rank] = key[b];
+    }
+    __syncthreads();
+    if (pass + 1 < passes) {
+#pragma unroll
+      for (int b = 0; b < R; ++b) {
+        const int e = wbase + 64 * b + lane;
+        key[b] = e < nv ? lds[e] : ~0ull;
+      }
+    }
+  }
+  if (passes == 0) {  // one occupied cell (or no valid key): index order is the sorted order
+#pragma unroll
+    for (int b = 0; b < R; ++b) {
+      const int e = wbase + 64 * b + lane;
+      if (e < nv) lds[e] = key[b];
+    }
   }
   __syncthreads();
 }
@@ -261,6 +373,9 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
   __shared__ int s_invB[256];
   __shared__ int s_cntA[511];
   __shared__ int s_base[512];
+  __shared__ unsigned s_hist[kSubThreads / 64][256];  // radix sort: wave-private digit counters / cursors
+  __shared__ unsigned s_tot[256];
+  __shared__ unsigned s_wsum[kSubThreads / 64 + 1];
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
@@ -363,6 +478,13 @@ __global__ __launch_bounds__(kSubThreads) void grid_subsample_kernel(
     auto sort_with = [&](auto rtag) {
       constexpr int R = decltype(rtag)::value;
       unsigned long long key[R];
+      if (CL3D_SUB_SORT == 1) {  // (round 6) stable radix sort on the cell bits; keys in the wave-batch layout it works on
+        const int wbase = wave * 64 * R;
+#pragma unroll
+        for (int r = 0; r < R; ++r) key[r] = make_key(wbase + 64 * r + lane);  // (~0 beyond the valid points)
+        radix_sort_lds<R>(key, nv, lds_keys, s_hist, s_tot, s_wsum, tid);
+        return;
+      }
 #pragma unroll
       for (int r = 0; r < R; ++r) key[r] = tid * R + r < P ? make_key(tid * R + r) : ~0ull;
       if (CL3D_SUB_PHASE != 6) {
@@ -595,7 +717,7 @@ extern "C" int cl3d_masked_grid_subsampling(const float *xyz, const int32_t *mas
   int P = 2;
   while (P < N) P <<= 1;
   size_t lds = (size_t)P * sizeof(unsigned long long);
-  const int stage_xyz = lds + (size_t)N * 12 <= 120 * 1024 ? 1 : 0;  // + ~8 KB of static tables: within the CU's 160 KB
+  const int stage_xyz = lds + (size_t)N * 12 <= 120 * 1024 ? 1 : 0;  // + ~26 KB of static tables (8 KB of shuffle tables, 17 KB of radix-sort counters): within the CU's 160 KB
   if (stage_xyz) lds += (size_t)N * 12;
   static std::atomic<unsigned long long> sort_granted{0};
   int rc_lds = cl3d::lds_opt_in(sort_granted, reinterpret_cast<const void *>(cl3d::grid_subsample_kernel<false, false>),

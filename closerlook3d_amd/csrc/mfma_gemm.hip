@@ -1321,26 +1321,29 @@ static size_t plan_workspace(int I, int J, long long K, int max_split, bool alwa
 }
 
 // ---- ticket counters of the in-launch slice sums: one zero-initialised ring per device, handed out in pieces of one
-// counter per output tile.  A piece is zero again when its launch has finished (the last arrival resets it), so it may
-// be handed out again later -- and a launch captured into a HIP graph re-uses its piece on every replay.  The ring
-// (2^20 counters) is far longer than the tiles of all launches that can be in flight or captured in one step's graph
-// before the bump pointer comes round (a sliced product has few tiles: that is why it was sliced).  The first piece of
-// a device is allocated outside stream capture (hipMalloc + hipMemset are not stream operations); a first call that
-// arrives during a capture gets none and takes the two-launch form.
+// counter per output tile.  A piece is zero again when its launch has finished (the last arrival resets it).  Launches
+// that are being CAPTURED into a HIP graph keep their piece for as long as the graph lives (every replay uses it), so
+// they draw from the upper half of the ring, which is never handed out twice -- when it is used up a captured launch gets
+// no piece and takes the two-launch form; eager launches draw from the lower half, round and round (2^19 counters: far
+// more than the tiles of all launches that can be in flight at once -- a sliced product has few tiles, that is why it was
+// sliced).  The ring is allocated outside stream capture (hipMalloc + hipMemset are not stream operations); a first
+// call that arrives during a capture gets no piece.
 constexpr size_t kTicketRing = (size_t)1 << 20;
 static unsigned *ticket_piece(size_t n, hipStream_t st) {
   static std::mutex mu;
   static unsigned *ring[64] = {};
-  static size_t next[64] = {};
+  static size_t next_eager[64] = {}, next_captured[64] = {};
   int dev = 0;
-  if (n == 0 || n > kTicketRing / 4 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (n == 0 || n > kTicketRing / 8 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  const bool capturing = cs != hipStreamCaptureStatusNone;
   std::lock_guard<std::mutex> lock(mu);
   if (ring[dev] == nullptr) {
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
+    if (capturing) return nullptr;
     unsigned *p = nullptr;
     if (hipMalloc(reinterpret_cast<void **>(&p), kTicketRing * sizeof(unsigned)) != hipSuccess ||
         hipMemset(p, 0, kTicketRing * sizeof(unsigned)) != hipSuccess) {
@@ -1350,9 +1353,16 @@ static unsigned *ticket_piece(size_t n, hipStream_t st) {
     }
     ring[dev] = p;
   }
-  if (next[dev] + n > kTicketRing) next[dev] = 0;
-  unsigned *piece = ring[dev] + next[dev];
-  next[dev] += n;
+  const size_t half = kTicketRing / 2;
+  if (capturing) {
+    if (next_captured[dev] + n > half) return nullptr;
+    unsigned *piece = ring[dev] + half + next_captured[dev];
+    next_captured[dev] += n;
+    return piece;
+  }
+  if (next_eager[dev] + n > half) next_eager[dev] = 0;
+  unsigned *piece = ring[dev] + next_eager[dev];
+  next_eager[dev] += n;
   return piece;
 }
 
