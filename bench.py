@@ -627,9 +627,6 @@ def main():
     ap.add_argument("--optimizer", default="torch", choices=["torch", "flat"],
                     help="torch: torch.optim.SGD, the reference's optimizer (default); flat: the engine's one-launch update over flat "
                          "buffers (closerlook3d_amd.optim.FlatSGD) -- same arithmetic, no Python per parameter: for eager launches")
-    ap.add_argument("--pipelined", action="store_true",
-                    help="also time two consecutive steps captured as one graph with the second batch's geometry prefetched "
-                         "behind the first step's forward (an extra field, not the headline)")
     ap.add_argument("--capture-stream", default="same", choices=["same", "separate"],
                     help="same (default): warm-up and capture on one stream; separate: a warm-up stream of its own (A/B)")
     ap.add_argument("--backbone", default="auto", choices=["auto", "on", "off"],
@@ -781,47 +778,6 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # --pipelined (opt-in, world 1, PointWiseMLP-style eager modules): TWO consecutive steps captured as one graph, the
-    # geometry of the second step's batch (ball query + CSR inverse: functions of its coordinates only, which a data loader
-    # has ahead of time) issued on the index streams right behind the first step's forward pass, so that it runs beside the
-    # first step's backward.  Every kernel of both steps runs (the second batch is its own tensors: a memo miss); what is
-    # measured is what cross-step prefetching of the geometry buys, reported BESIDE the headline, never as it.
-    pipelined = None
-    if args.pipelined and world == 1 and graph is not None and opt is not None:
-        from closerlook3d_amd import fused as _fused, pt_utils as _pt
-        xyz_b, mask_b = xyz.clone(), mask.clone()
-
-        def compute_pair():
-            with _pt.ball_query_cache():
-                feats.grad = None
-                opt.zero_grad(set_to_none=True)
-                out_a = module(xyz, xyz, mask, mask, feats)
-                idx_b, _ = _fused._query(xyz_b, xyz_b, mask_b, mask_b, radius, K, True)   # next batch: query ...
-                _fused._start_inverse(idx_b, N, None)                                    # ... and CSR inverse go ahead
-                out_a.backward(probe)
-                opt.step()
-                feats.grad = None
-                opt.zero_grad(set_to_none=True)
-                out_b = module(xyz_b, xyz_b, mask_b, mask_b, feats)
-                out_b.backward(probe)
-                opt.step()
-        try:
-            pair = capture(compute_pair)
-            for _ in range(20):
-                pair.replay()
-            torch.cuda.synchronize()
-            reps = max(args.steps // 2, 10)
-            t1 = time.perf_counter()
-            for _ in range(reps):
-                pair.replay()
-            torch.cuda.synchronize()
-            dt = (time.perf_counter() - t1) / (2 * reps)
-            pipelined = {"what": "two consecutive steps as one graph, the second batch's ball query + CSR inverse issued behind "
-                                 "the first step's forward (cross-step geometry prefetch); every kernel of both steps runs",
-                         "ms_per_step": round(dt * 1e3, 4), "points_per_s": round(B * N / dt, 1), "steps_timed": 2 * reps}
-        except Exception as e:
-            pipelined = {"error": f"{type(e).__name__}: {e}"}
-
     want_backbone = args.backbone == "on" or (args.backbone == "auto" and not args.no_kernel_roofline)
     bb = None
     if want_backbone:  # (a collective when N > 1: every rank runs it, after the headline's timed region)
@@ -856,8 +812,6 @@ def main():
             line["config"]["one_device_standin"] = True
         if bb is not None:
             line["backbone_step"] = bb
-        if pipelined is not None:
-            line["pipelined_pair"] = pipelined
         if not args.no_kernel_roofline:
             # top level: the TIMED STEP's dominant kernel (longest C-ABI entry point of the step table): algorithmic
             # HBM bytes per launch / median launch duration, HIP events on the launch stream; `traffic` = its PMC HBM

@@ -41,6 +41,9 @@ CONFIGS = {
 
 
 def main():
+    import faulthandler
+    import signal
+    faulthandler.register(signal.SIGUSR1, all_threads=True)  # `kill -USR1 <rank pid>` prints every thread's Python stack
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="modelnet_pointwisemlp", choices=sorted(CONFIGS))
     ap.add_argument("--gpus", type=int, default=1)
