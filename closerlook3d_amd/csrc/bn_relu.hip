@@ -13,13 +13,91 @@
 
 namespace cl3d {
 
+struct BnFinArgs {
+  const double *partial;  // [G, C, 2]
+  int G, C;
+  double count;
+  float eps, momentum;
+  const float *gamma, *beta, *mean_in, *invstd_in;
+  float *running_mean, *running_var;
+  long long *num_batches_tracked;  // nn.BatchNorm's step counter, bumped by the block of channel 0 (may be null)
+  float *o0, *o1, *o2, *o3, *o4;
+};
+
 struct BnArgs {
   const float *x, *g;          // [B,C,N]
   const float *scale, *shift, *mean, *invstd, *cA, *cB, *cD;
   float *out;                  // [B,C,N]
   double *partial;             // [B*chunks, C, 2]
   int B, C, N, chunks, span;   // a block reduces `span` points of one (cloud, channel) row
+  unsigned *tickets;           // [C] or null.  Set: the workgroup that arrives last at a channel's ticket runs `fin`
+  BnFinArgs fin;               //   for that channel (statistics kernels only) and no finalize launch follows
 };
+
+// The per-channel algebra behind a statistics pass, on the first 64 threads of a workgroup.
+// MODE 0: batch statistics -> scale, shift, mean, invstd (+ running update);  MODE 1: backward coefficients.
+// DEVICE_SCOPE: the partials were written by other workgroups of the SAME launch (round 6: the statistics kernels run
+// this themselves, in the workgroup that arrives last at the channel's ticket -- no finalize launch); they are read with
+// device-scope loads.  Same summation order either way (thread t adds blocks t, t + 64, ...; a butterfly over the wave).
+template <int MODE, bool DEVICE_SCOPE>
+__device__ __forceinline__ void bn_finalize_channel(const BnFinArgs &a, int c, int tid) {
+  double s0 = 0.0, s1 = 0.0;
+  for (int g = tid; g < a.G; g += 64) {
+    const double *p = a.partial + ((size_t)g * a.C + c) * 2;
+    if constexpr (DEVICE_SCOPE) {
+      s0 += __hip_atomic_load(const_cast<double *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s1 += __hip_atomic_load(const_cast<double *>(p) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      s0 += p[0];
+      s1 += p[1];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    s0 += __shfl_xor(s0, o, 64);
+    s1 += __shfl_xor(s1, o, 64);
+  }
+  if (tid != 0) return;
+  if (MODE == 0) {
+    const double mean = s0 / a.count;
+    double var = s1 / a.count - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)a.eps);
+    const double scale = (double)a.gamma[c] * invstd;
+    a.o0[c] = (float)scale;
+    a.o1[c] = (float)((double)a.beta[c] - mean * scale);
+    a.o2[c] = (float)mean;
+    a.o3[c] = (float)invstd;
+    if (a.running_mean != nullptr) {  // nn.BatchNorm1d: running = (1-m) running + m batch, unbiased variance
+      const double unbiased = var * (a.count / (a.count > 1.0 ? a.count - 1.0 : 1.0));
+      a.running_mean[c] = a.running_mean[c] * (1.0f - a.momentum) + a.momentum * (float)mean;
+      a.running_var[c] = a.running_var[c] * (1.0f - a.momentum) + a.momentum * (float)unbiased;
+    }
+    if (c == 0 && a.num_batches_tracked != nullptr) *a.num_batches_tracked += 1;
+  } else {  // dx = A dz + Bc + D x   (s0 = sum dz = d beta, s1 = sum dz * xhat = d gamma)
+    const double invstd = (double)a.invstd_in[c], mean = (double)a.mean_in[c];
+    const double A = (double)a.gamma[c] * invstd;
+    const double D = -A * invstd * s1 / a.count;
+    const double Bc = -A * s0 / a.count - D * mean;
+    a.o0[c] = (float)A;
+    a.o1[c] = (float)Bc;
+    a.o2[c] = (float)D;
+    a.o3[c] = (float)s1;
+    a.o4[c] = (float)s0;
+  }
+}
+
+// a workgroup's partial pair: plain stores (a finalize launch follows) or device-scope stores (another workgroup of this
+// launch reads them)
+__device__ __forceinline__ void bn_store_partial(double *p, double t0, double t1, bool device_scope) {
+  if (device_scope) {
+    __hip_atomic_store(p, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p + 1, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    p[0] = t0;
+    p[1] = t1;
+  }
+}
 
 // points of one (cloud, channel) row per workgroup of the statistics passes (2048 -- twice the workgroups, two 16-byte
 // items per thread instead of four -- measured in round 3: no faster, 6.7 / 12.4 against 7.4 / 12.0 us)
@@ -84,11 +162,11 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(BnArgs a) {
   d1 += (double)s1;
   const double t0 = block_sum(d0, scratch);
   const double t1 = block_sum(d1, scratch);
-  if (threadIdx.x == 0) {
-    double *p = a.partial + ((size_t)part * a.C + c) * 2;
-    p[0] = t0;
-    p[1] = t1;
-  }
+  if (threadIdx.x == 0) bn_store_partial(a.partial + ((size_t)part * a.C + c) * 2, t0, t1, a.tickets != nullptr);
+  if (a.tickets == nullptr) return;
+  __shared__ int s_last;
+  if (!last_arrival(a.tickets + c, gridDim.y, &s_last)) return;
+  if (threadIdx.x < 64) bn_finalize_channel<MODE, true>(a.fin, c, threadIdx.x);
 }
 
 // MODE 0: out = ReLU(scale x + shift);  MODE 1: dx = A dz + Bc + D x with dz = g gated by the ReLU
@@ -127,60 +205,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(BnArgs a) {
   }
 }
 
-struct BnFinArgs {
-  const double *partial;  // [G, C, 2]
-  int G, C;
-  double count;
-  float eps, momentum;
-  const float *gamma, *beta, *mean_in, *invstd_in;
-  float *running_mean, *running_var;
-  long long *num_batches_tracked;  // nn.BatchNorm's step counter, bumped by the block of channel 0 (may be null)
-  float *o0, *o1, *o2, *o3, *o4;
-};
-
-// MODE 0: batch statistics -> scale, shift, mean, invstd (+ running update);  MODE 1: backward coefficients
+// the same algebra as a launch of its own (one 64-thread workgroup per channel): when no ticket piece is available
 template <int MODE>
 __global__ __launch_bounds__(64) void bn_finalize_kernel(BnFinArgs a) {
-  const int c = blockIdx.x;
-  double s0 = 0.0, s1 = 0.0;
-  for (int g = threadIdx.x; g < a.G; g += 64) {
-    const double *p = a.partial + ((size_t)g * a.C + c) * 2;
-    s0 += p[0];
-    s1 += p[1];
-  }
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) {
-    s0 += __shfl_xor(s0, o, 64);
-    s1 += __shfl_xor(s1, o, 64);
-  }
-  if (threadIdx.x != 0) return;
-  if (MODE == 0) {
-    const double mean = s0 / a.count;
-    double var = s1 / a.count - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    const double invstd = 1.0 / sqrt(var + (double)a.eps);
-    const double scale = (double)a.gamma[c] * invstd;
-    a.o0[c] = (float)scale;
-    a.o1[c] = (float)((double)a.beta[c] - mean * scale);
-    a.o2[c] = (float)mean;
-    a.o3[c] = (float)invstd;
-    if (a.running_mean != nullptr) {  // nn.BatchNorm1d: running = (1-m) running + m batch, unbiased variance
-      const double unbiased = var * (a.count / (a.count > 1.0 ? a.count - 1.0 : 1.0));
-      a.running_mean[c] = a.running_mean[c] * (1.0f - a.momentum) + a.momentum * (float)mean;
-      a.running_var[c] = a.running_var[c] * (1.0f - a.momentum) + a.momentum * (float)unbiased;
-    }
-    if (c == 0 && a.num_batches_tracked != nullptr) *a.num_batches_tracked += 1;
-  } else {  // dx = A dz + Bc + D x   (s0 = sum dz = d beta, s1 = sum dz * xhat = d gamma)
-    const double invstd = (double)a.invstd_in[c], mean = (double)a.mean_in[c];
-    const double A = (double)a.gamma[c] * invstd;
-    const double D = -A * invstd * s1 / a.count;
-    const double Bc = -A * s0 / a.count - D * mean;
-    a.o0[c] = (float)A;
-    a.o1[c] = (float)Bc;
-    a.o2[c] = (float)D;
-    a.o3[c] = (float)s1;
-    a.o4[c] = (float)s0;
-  }
+  bn_finalize_channel<MODE, false>(a, blockIdx.x, threadIdx.x);
 }
 
 // ---- the tail of a bottleneck: out = ReLU(BN1(x1) + R),  R = 0 | x2 (identity shortcut) | BN2(x2) (conv shortcut)
@@ -198,6 +226,8 @@ struct Bn2Args {
   int mode2;             // 0: no second branch, 1: identity, 2: affine (its own BatchNorm)
   int relu;
   int vec;               // N % 4 == 0 and every tensor 16-byte aligned: the backward kernels move 16 bytes per lane
+  unsigned *tickets;     // [C] or null; set: the last arrival at a channel's ticket runs fin1 (and fin2 when mode2 == 2)
+  BnFinArgs fin1, fin2;  //   inside bn2_bwd_stats_kernel, no finalize launches follow
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -285,15 +315,14 @@ __global__ __launch_bounds__(256) void bn2_bwd_stats_kernel(Bn2Args a) {
   const double t1 = block_sum(d1, scratch);
   const double t2 = block_sum(d2, scratch);
   if (threadIdx.x == 0) {
-    double *p = a.p1 + ((size_t)part * a.C + c) * 2;
-    p[0] = t0;
-    p[1] = t1;
-    if (a.mode2 == 2) {
-      double *q = a.p2 + ((size_t)part * a.C + c) * 2;
-      q[0] = t0;
-      q[1] = t2;
-    }
+    bn_store_partial(a.p1 + ((size_t)part * a.C + c) * 2, t0, t1, a.tickets != nullptr);
+    if (a.mode2 == 2) bn_store_partial(a.p2 + ((size_t)part * a.C + c) * 2, t0, t2, a.tickets != nullptr);
   }
+  if (a.tickets == nullptr) return;
+  __shared__ int s_last;
+  if (!last_arrival(a.tickets + c, gridDim.y, &s_last)) return;
+  if (threadIdx.x < 64) bn_finalize_channel<1, true>(a.fin1, c, threadIdx.x);
+  else if (threadIdx.x < 128 && a.mode2 == 2) bn_finalize_channel<1, true>(a.fin2, c, threadIdx.x - 64);
 }
 
 __global__ __launch_bounds__(256) void bn2_bwd_apply_kernel(Bn2Args a) {
@@ -652,6 +681,18 @@ static void bn_shape(BnArgs &a) {
   a.chunks = ceil_div(a.N, a.span);
 }
 
+// One ticket per channel for a statistics launch whose last-arriving workgroup finishes the channel itself (round 6; one
+// launch and one graph node fewer per BatchNorm pass).  CL3D_BN_FOLD=0 builds the form with a finalize launch of its own
+// (the A/B arm of scripts/micro/kernel_variants.py); a null piece (ring used up by captured launches, first call inside
+// a capture) takes that form too.
+#ifndef CL3D_BN_FOLD
+#define CL3D_BN_FOLD 1
+#endif
+static unsigned *bn_tickets(int C, hipStream_t st) {
+  if (!CL3D_BN_FOLD) return nullptr;
+  return ticket_piece((size_t)C, st);
+}
+
 }  // namespace cl3d
 
 extern "C" int cl3d_bn_partials(int B, int C, int N) {
@@ -670,13 +711,15 @@ extern "C" int cl3d_bn_relu_stats(const float *x, int B, int C, int N, double *p
   BnArgs a{};
   a.x = x; a.partial = partial; a.B = B; a.C = C; a.N = N;
   bn_shape(a);
-  hipLaunchKernelGGL((bn_stats_kernel<0>), dim3(C, n_partials), dim3(256), 0, (hipStream_t)stream, a);
   BnFinArgs f{};
   f.partial = partial; f.G = n_partials; f.C = C; f.count = count; f.eps = eps; f.momentum = momentum;
   f.gamma = gamma; f.beta = beta; f.running_mean = running_mean; f.running_var = running_var;
   f.num_batches_tracked = reinterpret_cast<long long *>(num_batches_tracked);
   f.o0 = scale; f.o1 = shift; f.o2 = mean; f.o3 = invstd;
-  hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(C), dim3(64), 0, (hipStream_t)stream, f);
+  a.tickets = bn_tickets(C, (hipStream_t)stream);
+  a.fin = f;
+  hipLaunchKernelGGL((bn_stats_kernel<0>), dim3(C, n_partials), dim3(256), 0, (hipStream_t)stream, a);
+  if (!a.tickets) hipLaunchKernelGGL((bn_finalize_kernel<0>), dim3(C), dim3(64), 0, (hipStream_t)stream, f);
   return check_launch("cl3d_bn_relu_stats");
 }
 
@@ -706,11 +749,14 @@ extern "C" int cl3d_bn_relu_bwd(const float *g, const float *x, const float *sca
   a.x = x; a.g = g; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd; a.partial = partial;
   a.B = B; a.C = C; a.N = N;
   bn_shape(a);
-  hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(C, n_partials), dim3(256), 0, (hipStream_t)stream, a);
   BnFinArgs f{};
   f.partial = partial; f.G = n_partials; f.C = C; f.count = count; f.gamma = gamma; f.mean_in = mean; f.invstd_in = invstd;
   f.o0 = coef; f.o1 = coef + C; f.o2 = coef + 2 * C; f.o3 = coef + 3 * C; f.o4 = coef + 4 * C;  // A, Bc, D, d gamma, d beta
-  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(C), dim3(64), 0, (hipStream_t)stream, f);
+  a.tickets = bn_tickets(C, (hipStream_t)stream);
+  a.fin = f;
+  hipLaunchKernelGGL((bn_stats_kernel<1>), dim3(C, n_partials), dim3(256), 0, (hipStream_t)stream, a);
+  if (!a.tickets) hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(C), dim3(64), 0, (hipStream_t)stream, f);
+  a.tickets = nullptr;
   a.cA = coef; a.cB = coef + C; a.cD = coef + 2 * C; a.out = dx;
   const long long work = (long long)B * C * ceil_div(N, 1024);
   hipLaunchKernelGGL((bn_apply_kernel<1>), dim3((unsigned)(work < 65536 ? work : 65536)), dim3(256), 0,
@@ -764,15 +810,20 @@ extern "C" int cl3d_bn_add_relu_bwd(const float *g, const float *out, const floa
   a.chunks = ceil_div(N, a.span);
   a.vec = (N & 3) == 0 && ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(x1) |
                             reinterpret_cast<uintptr_t>(x2) | reinterpret_cast<uintptr_t>(dx1) | reinterpret_cast<uintptr_t>(dx2)) & 15u) == 0;
-  hipLaunchKernelGGL(bn2_bwd_stats_kernel, dim3(C, n_partials), dim3(256), 0, st, a);
   BnFinArgs f{};
   f.partial = a.p1; f.G = n_partials; f.C = C; f.count = count; f.gamma = gamma1; f.mean_in = mean1; f.invstd_in = invstd1;
   f.o0 = coef1; f.o1 = coef1 + C; f.o2 = coef1 + 2 * C; f.o3 = coef1 + 3 * C; f.o4 = coef1 + 4 * C;
-  hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(C), dim3(64), 0, st, f);
+  a.fin1 = f;
   if (a.mode2 == 2) {
     f.partial = a.p2; f.gamma = gamma2; f.mean_in = mean2; f.invstd_in = invstd2;
     f.o0 = coef2; f.o1 = coef2 + C; f.o2 = coef2 + 2 * C; f.o3 = coef2 + 3 * C; f.o4 = coef2 + 4 * C;
-    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(C), dim3(64), 0, st, f);
+    a.fin2 = f;
+  }
+  a.tickets = bn_tickets(C, st);
+  hipLaunchKernelGGL(bn2_bwd_stats_kernel, dim3(C, n_partials), dim3(256), 0, st, a);
+  if (!a.tickets) {
+    hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(C), dim3(64), 0, st, a.fin1);
+    if (a.mode2 == 2) hipLaunchKernelGGL((bn_finalize_kernel<1>), dim3(C), dim3(64), 0, st, a.fin2);
   }
   a.c1 = coef1; a.c2 = coef2; a.o1 = dx1; a.o2 = dx2;
   const long long work = (long long)B * C * ceil_div(N, 1024);

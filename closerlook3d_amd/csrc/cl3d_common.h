@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <mutex>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -50,6 +51,70 @@ inline int lds_opt_in(std::atomic<unsigned long long> &granted, const void *kern
   if (e != hipSuccess) return fail(CL3D_E_LAUNCH, "%s: LDS opt-in (%zu B): %s", who, bytes, hipGetErrorString(e));
   if (tracked) granted.fetch_or(1ull << dev, std::memory_order_relaxed);
   return CL3D_OK;
+}
+
+// ---- ticket counters of the in-launch sums (the K slices of a product: csrc/mfma_gemm.hip; the partial blocks of a
+// BatchNorm statistics pass: csrc/bn_relu.hip): one zero-initialised ring per device, handed out in pieces of one
+// counter per output tile / channel.  A piece is zero again when its launch has finished (the last arrival resets it).  Launches
+// that are being CAPTURED into a HIP graph keep their piece for as long as the graph lives (every replay uses it), so
+// they draw from the upper half of the ring, which is never handed out twice -- when it is used up a captured launch gets
+// no piece and takes the two-launch form; eager launches draw from the lower half, round and round (2^19 counters: far
+// more than the tiles of all launches that can be in flight at once -- a sliced product has few tiles, that is why it was
+// sliced).  The ring is allocated outside stream capture (hipMalloc + hipMemset are not stream operations); a first
+// call that arrives during a capture gets no piece.
+constexpr size_t kTicketRing = (size_t)1 << 20;
+inline unsigned *ticket_piece(size_t n, hipStream_t st) {
+  static std::mutex mu;
+  static unsigned *ring[64] = {};
+  static size_t next_eager[64] = {}, next_captured[64] = {};
+  int dev = 0;
+  if (n == 0 || n > kTicketRing / 8 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  const bool capturing = cs != hipStreamCaptureStatusNone;
+  std::lock_guard<std::mutex> lock(mu);
+  if (ring[dev] == nullptr) {
+    if (capturing) return nullptr;
+    unsigned *p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p), kTicketRing * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(p, 0, kTicketRing * sizeof(unsigned)) != hipSuccess) {
+      (void)hipGetLastError();
+      if (p) (void)hipFree(p);
+      return nullptr;
+    }
+    ring[dev] = p;
+  }
+  const size_t half = kTicketRing / 2;
+  if (capturing) {
+    if (next_captured[dev] + n > half) return nullptr;
+    unsigned *piece = ring[dev] + half + next_captured[dev];
+    next_captured[dev] += n;
+    return piece;
+  }
+  if (next_eager[dev] + n > half) next_eager[dev] = 0;
+  unsigned *piece = ring[dev] + next_eager[dev];
+  next_eager[dev] += n;
+  return piece;
+}
+
+// last arrival at a ticket: called by EVERY thread of a workgroup after its device-scope stores (each wave waits for its
+// stores to be acknowledged -- the explicit s_waitcnt: a workgroup-scope barrier alone need not wait for vmcnt -- and the
+// ticket is a device-scope atomic issued behind the barrier); block-uniform result.  The last arrival
+// puts the counter back to zero (`total` workgroups draw from `ticket`).  s_flag: one int of LDS.
+__device__ __forceinline__ bool last_arrival(unsigned *ticket, unsigned total, int *s_flag) {
+  __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned drawn = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = drawn == total - 1u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_flag = last;
+  }
+  __syncthreads();
+  return *s_flag != 0;
 }
 
 // ---- device helpers -------------------------------------------------------------------

@@ -366,9 +366,9 @@ struct StagePick<PREC_BF16, TR, KC> {
 };
 
 // ---- K slices summed inside the launch.  Called by every workgroup of a sliced product after its
-// partial tile has been STORED AT DEVICE SCOPE (write_tiles kind 2).  No fence anywhere: the barrier below waits for every
-// thread's stores to be acknowledged (vmcnt(0)), a device-scope store is acknowledged when it is visible to the other
-// XCDs, the ticket is a device-scope atomic issued after that barrier, and the workgroup that draws the last ticket reads
+// partial tile has been STORED AT DEVICE SCOPE (write_tiles kind 2).  No fence anywhere: every wave waits for its own stores
+// to be acknowledged (an explicit s_waitcnt vmcnt(0) in last_arrival), a device-scope store is acknowledged when it is
+// visible to the other XCDs, the ticket is a device-scope atomic issued after the barrier, and the last arrival reads
 // the other slices with device-scope loads (which do not hit whatever its own XCD's L2 still holds of the scratch).
 __device__ __forceinline__ float ld_device_scope(const float *p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -376,16 +376,10 @@ __device__ __forceinline__ float ld_device_scope(const float *p) {
 
 template <int TI, int TJ>
 __device__ __forceinline__ void sum_slices_by_last_arrival(const GemmArgs &a, int i0, int j0, int tile) {
+  // (cl3d_common.h: every wave waits for its slice stores to be acknowledged before the barrier in front of the ticket --
+  //  round 6 found the barrier alone compiled to s_waitcnt vmcnt(63): no wait)
   __shared__ int s_last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned drawn = __hip_atomic_fetch_add(a.tickets + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = drawn == (unsigned)(a.nsplit - 1);
-    if (last) __hip_atomic_store(a.tickets + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = last;
-  }
-  __syncthreads();
-  if (!s_last) return;
+  if (!last_arrival(a.tickets + tile, (unsigned)a.nsplit, &s_last)) return;
   const int I = a.A.R, J = a.B.R;
   const long long IJ = (long long)I * J;
   const OutMap &o = a.out;
@@ -1320,51 +1314,7 @@ static size_t plan_workspace(int I, int J, long long K, int max_split, bool alwa
   return worst;
 }
 
-// ---- ticket counters of the in-launch slice sums: one zero-initialised ring per device, handed out in pieces of one
-// counter per output tile.  A piece is zero again when its launch has finished (the last arrival resets it).  Launches
-// that are being CAPTURED into a HIP graph keep their piece for as long as the graph lives (every replay uses it), so
-// they draw from the upper half of the ring, which is never handed out twice -- when it is used up a captured launch gets
-// no piece and takes the two-launch form; eager launches draw from the lower half, round and round (2^19 counters: far
-// more than the tiles of all launches that can be in flight at once -- a sliced product has few tiles, that is why it was
-// sliced).  The ring is allocated outside stream capture (hipMalloc + hipMemset are not stream operations); a first
-// call that arrives during a capture gets no piece.
-constexpr size_t kTicketRing = (size_t)1 << 20;
-static unsigned *ticket_piece(size_t n, hipStream_t st) {
-  static std::mutex mu;
-  static unsigned *ring[64] = {};
-  static size_t next_eager[64] = {}, next_captured[64] = {};
-  int dev = 0;
-  if (n == 0 || n > kTicketRing / 8 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
-    (void)hipGetLastError();
-    return nullptr;
-  }
-  const bool capturing = cs != hipStreamCaptureStatusNone;
-  std::lock_guard<std::mutex> lock(mu);
-  if (ring[dev] == nullptr) {
-    if (capturing) return nullptr;
-    unsigned *p = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&p), kTicketRing * sizeof(unsigned)) != hipSuccess ||
-        hipMemset(p, 0, kTicketRing * sizeof(unsigned)) != hipSuccess) {
-      (void)hipGetLastError();
-      if (p) (void)hipFree(p);
-      return nullptr;
-    }
-    ring[dev] = p;
-  }
-  const size_t half = kTicketRing / 2;
-  if (capturing) {
-    if (next_captured[dev] + n > half) return nullptr;
-    unsigned *piece = ring[dev] + half + next_captured[dev];
-    next_captured[dev] += n;
-    return piece;
-  }
-  if (next_eager[dev] + n > half) next_eager[dev] = 0;
-  unsigned *piece = ring[dev] + next_eager[dev];
-  next_eager[dev] += n;
-  return piece;
-}
+// (ticket counters of the in-launch slice sums: cl3d::ticket_piece, cl3d_common.h)
 
 constexpr int kMaxSplitFwd = 16;    // forward / input-gradient products: K = channels
 constexpr int kMaxSplitWgrad = 512; // weight gradients: K = every point of the batch

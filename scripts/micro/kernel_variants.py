@@ -28,6 +28,9 @@ VARIANTS = {  # tag: (source file, extra defines)
     "sup_sb2_late_w5": ("fused_pwmlp.hip", ["-DCL3D_SUP_LATE=1", "-DCL3D_SUP_SB=2", "-DCL3D_SUP_WAVES=5"]),
     # round 6: grid subsampling's in-LDS sort as the bitonic network of round 5 (the shipped build: radix sort on the cell bits)
     "sub_bitonic": ("grid_subsample.hip", ["-DCL3D_SUB_SORT=0"]),
+    # round 6: BatchNorm statistics followed by a finalize launch of their own (shipped: the last-arriving workgroup of the
+    # statistics launch finishes the channel)
+    "bn_finalize_launch": ("bn_relu.hip", ["-DCL3D_BN_FOLD=0"]),
     # (round 6: "pg_nofork" = fused_reduce.hip with -DCL3D_PG_FORK=0 was the A/B arm of PseudoGrid's forked kernel-weight
     #  pass; the fork measured slower and was removed with its macro -- profiles/r06/session7_summary.txt, commit dbb7bed)
 }

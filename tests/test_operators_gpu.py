@@ -368,6 +368,53 @@ def test_bn_relu_matches_torch_modules(B, C, N, training):
         assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("B,C,N", [(16, 72, 4096), (70, 8, 40000), (5, 144, 1000)])
+def test_bn_statistics_finished_inside_the_launch_repeat_bit_for_bit(B, C, N):
+    """Round 6: the workgroup that arrives last at a channel's ticket finishes the channel's statistics (no finalize
+    launch).  Whichever workgroup that is, the partial blocks are added in block order: 100 eager passes and 100
+    replays of a captured pass over the same input give the same bits, forward (scale/shift seen through the output,
+    running statistics) and backward (dx, d gamma, d beta).  (70, 8, 40000): 210 partial blocks per channel, more
+    than the 64 lanes that add them.)"""
+    from closerlook3d_amd import fused
+    import closerlook3d_amd
+    torch.manual_seed(B + C)
+    bn = torch.nn.BatchNorm1d(C, momentum=0.1).cuda().train(True)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.normal_(0, 0.3)
+    x = (torch.randn(B, C, N, device="cuda") * 1.7 + 0.4).requires_grad_(True)
+    g = torch.randn(B, C, N, device="cuda")
+
+    def one_pass():
+        with torch.no_grad():
+            bn.running_mean.zero_()
+            bn.running_var.fill_(1.0)
+        x.grad = bn.weight.grad = bn.bias.grad = None
+        out = fused.bn_relu(x, bn)
+        out.backward(g)
+        return [t.detach().clone() for t in (out, x.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var)]
+
+    st = closerlook3d_amd.step_stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        first = one_pass()
+        for _ in range(100):
+            for a, b in zip(one_pass(), first):
+                assert torch.equal(a, b)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            held = one_pass()
+        for _ in range(100):
+            with torch.no_grad():
+                bn.running_mean.zero_()
+                bn.running_var.fill_(1.0)
+            graph.replay()
+            for a, b in zip(held[:4] + [bn.running_mean, bn.running_var], first):
+                assert torch.equal(a, b)
+    torch.cuda.current_stream().wait_stream(st)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("rel,B,N", [("modelnet/pointwisemlp_dp_fi_df_fc1.yaml", 2, 2048),
                                      ("partnet/adaptiveweight_dp_fc1_avg.yaml", 2, 2500),
                                      ("s3dis/pseudo_grid.yaml", 1, 8000)])
