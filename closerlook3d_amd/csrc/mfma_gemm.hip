@@ -443,6 +443,9 @@ __device__ __forceinline__ void sum_slices_by_last_arrival(const GemmArgs &a, in
   }
 }
 
+#ifndef CL3D_GEMM_XCD
+#define CL3D_GEMM_XCD 1  // (0: the plain tile order, the A/B arm of scripts/micro/kernel_variants.py)
+#endif
 template <int PREC, int WI, int WJ, int AM, int BM>
 __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
   constexpr int TI = 64 * WI, TJ = 64 * WJ;
@@ -455,12 +458,34 @@ __global__ __launch_bounds__(256, 2) void mfma_gemm_kernel(GemmArgs a) {
   constexpr int kPair = SA::kLdsBytes + SB::kLdsBytes;
   __shared__ __attribute__((aligned(16))) unsigned char lds[NBUF * kPair];
 
-  // tile / K slice of this workgroup
+  // tile / K slice of this workgroup.  Workgroups go to the eight XCDs round robin (blockIdx % 8) and each XCD has its
+  // own L2, so the workgroups that read the same operand strips are given to ONE XCD back to back: XCD x takes the x-th
+  // eighth of the (slice, tile) list -- slices outermost, the short side of the output fastest (the tail that does not
+  // fill a round of eight keeps the plain order).  Neighbours in that list share their strips: the 2-3 channel tiles
+  // over one run of points (a layer's product over 65 536 points), the 4-9 tiles of one slice of an early layer's weight
+  // gradient; and an XCD's L2 is filled with an eighth of the operand bytes instead of a strip of every slice.
+  // Measured on the replayed backbones against the plain order (sessions 14a-c, alternating runs, profiles/r06/):
+  // config 2 bf16 6.05 -> 5.95 ms, config 5 20.02 -> 19.91, configs 3 / 4 unchanged, config 2 f32 7.81 -> 7.83; early-stage
+  // bf16 products alone 33 -> 28 us (forward, d x), 45 -> 41 (d W).  Two narrower forms were measured too: the list of a
+  // slice only (config 2 bf16 6.02), that for >= 16 tiles per slice and the whole list below (6.01).
   int bid = blockIdx.x;
-  const int tj = bid % a.tiles_j;
-  bid /= a.tiles_j;
-  const int ti = bid % a.tiles_i;
-  const int z = bid / a.tiles_i;  // K slice
+#if CL3D_GEMM_XCD
+  {
+    const int eighth = (int)gridDim.x >> 3;
+    if (bid < (eighth << 3)) bid = (bid & 7) * eighth + (bid >> 3);
+  }
+#endif
+  const int per_slice = a.tiles_i * a.tiles_j;
+  const int z = bid / per_slice;  // K slice
+  bid -= z * per_slice;
+  int ti, tj;
+  if (a.tiles_j <= a.tiles_i) {
+    tj = bid % a.tiles_j;
+    ti = bid / a.tiles_j;
+  } else {
+    ti = bid % a.tiles_i;
+    tj = bid / a.tiles_i;
+  }
   const int i0 = ti * TI, j0 = tj * TJ;
   const int chunks = (a.K + KC - 1) / KC;
   int g0 = 0, g1 = chunks;
@@ -782,7 +807,7 @@ __global__ __launch_bounds__(256, 5) void pwmlp_rows_nolds_kernel(const float *_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int j = 32 * (blockIdx.y * 4 + wave) + lr;  // this lane's output column
-  if (32 * (blockIdx.y * 4 + wave) >= J) return;    // (whole waves: no barrier in this kernel)
+  if (32 * ((int)blockIdx.y * 4 + wave) >= J) return;  // (whole waves: no barrier in this kernel)
   float bw[CH];
 #pragma unroll
   for (int s = 0; s < CH; ++s) {
@@ -864,7 +889,7 @@ __global__ __launch_bounds__(256, 5) void pwmlp_rows_nolds_bf16_kernel(const flo
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int j = 32 * (blockIdx.y * 4 + wave) + lr;  // this lane's output column
-  if (32 * (blockIdx.y * 4 + wave) >= J) return;    // (whole waves: no barrier in this kernel)
+  if (32 * ((int)blockIdx.y * 4 + wave) >= J) return;  // (whole waves: no barrier in this kernel)
   bf16x8 bw[CH16];
 #pragma unroll
   for (int s = 0; s < CH16; ++s)

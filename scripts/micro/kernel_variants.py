@@ -31,6 +31,8 @@ VARIANTS = {  # tag: (source file, extra defines)
     # round 6: BatchNorm statistics followed by a finalize launch of their own (shipped: the last-arriving workgroup of the
     # statistics launch finishes the channel)
     "bn_finalize_launch": ("bn_relu.hip", ["-DCL3D_BN_FOLD=0"]),
+    # round 6: the GEMM's tiles in plain order (shipped: the tiles that share the large operand strip on one XCD)
+    "gemm_plain_order": ("mfma_gemm.hip", ["-DCL3D_GEMM_XCD=0"]),
     # (round 6: "pg_nofork" = fused_reduce.hip with -DCL3D_PG_FORK=0 was the A/B arm of PseudoGrid's forked kernel-weight
     #  pass; the fork measured slower and was removed with its macro -- profiles/r06/session7_summary.txt, commit dbb7bed)
 }
