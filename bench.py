@@ -491,6 +491,8 @@ def backbone_step(kind, world, rank, dev, steps=10, warmup=3):
     from closerlook3d_amd.pt_utils import ball_query_cache
     name, precision = BACKBONE_OF[kind]
     bkind, B, N, radius, dl, nsamples, npoints, width = CONFIGS[name]
+    import closerlook3d_amd
+    closerlook3d_amd.gemm_autotune(True)  # tile / K-slice plans of the dense products timed during the warm-up steps
     torch.manual_seed(0)
     cfg = make_config(bkind, "auto")
     cfg["cl3d_precision"] = precision
@@ -594,7 +596,9 @@ def backbone_step(kind, world, rank, dev, steps=10, warmup=3):
            "precision": precision, "clouds_per_gpu": B, "points": N, "width": width, "steps": steps,
            "launch": "hip_graph" if graph is not None else "eager", "ms_per_step": round(dt * 1e3, 3),
            "input_points_per_s": round(world * B * N / dt, 1), "scaling": "weak",
-           "params_M": round(sum(p.numel() for p in params) / 1e6, 2)}
+           "params_M": round(sum(p.numel() for p in params) / 1e6, 2),
+           "gemm_plans": "measured during the warm-up steps (closerlook3d_amd.gemm_autotune): %d products, %d off the model's plan"
+                         % closerlook3d_amd.gemm_autotune_stats()}
     if world > 1:
         out["allreduce_bytes"] = int(flat.buffer.numel() * 4)
         out["allreduce_ms"] = round(float(np.mean([a.elapsed_time(b) for a, b in ar])), 3)

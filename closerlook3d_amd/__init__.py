@@ -41,3 +41,23 @@ def step_stream(device=None):
     """
     from .fused import step_stream as _s
     return _s(device)
+
+
+def gemm_autotune(enable=True):
+    """Tile / K-slice plans of the engine's dense products (csrc/mfma_gemm.hip: the 1x1 convolutions and the PointWiseMLP's
+    per-point products) by MEASUREMENT instead of the launch-time model: process-wide, off by default; returns the previous
+    setting.  On: the first eager call of a product (a warm-up step before a capture is enough) times the plausible plans
+    on the caller's stream and keeps the winner for the process (`include/cl3d.h: cl3d_gemm_autotune`).  A plan fixes the
+    order in which K slices are summed, so two processes may then differ in the last bits of a result; one process never
+    does.  Measured on the config-2 backbone in DESIGN 3.3."""
+    from . import _lib
+    return bool(_lib.lib().cl3d_gemm_autotune(1 if enable else 0))
+
+
+def gemm_autotune_stats():
+    """(products measured so far, how many of them kept a plan other than the model's)."""
+    import ctypes
+    from . import _lib
+    a, b = ctypes.c_longlong(0), ctypes.c_longlong(0)
+    _lib.check(_lib.lib().cl3d_gemm_autotune_stats(ctypes.byref(a), ctypes.byref(b)))
+    return int(a.value), int(b.value)

@@ -70,6 +70,8 @@ SIGNATURES = {
     "cl3d_conv1x1_rows_fwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_conv1x1_rows_bwd_data": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
     "cl3d_conv1x1_rows_bwd_weight": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _Z, _P],
+    "cl3d_gemm_autotune": [_I],
+    "cl3d_gemm_autotune_stats": [_P, _P],
     "cl3d_sgd_step": [_P, _P, _P, ctypes.c_longlong, _F, _F, _F, _F, _I, _I, _I, _P],
     "cl3d_pwmlp_split_weight": [_P, _I, _I, _P, _P, _P],
     "cl3d_pwmlp_merge_weight_grad": [_P, _P, _I, _I, _I, _P, _P],

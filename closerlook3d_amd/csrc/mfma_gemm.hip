@@ -35,8 +35,11 @@
 #include "cl3d_common.h"
 #include <stdio.h>
 #include <stdlib.h>
-#include <type_traits>
+#include <map>
 #include <mutex>
+#include <tuple>
+#include <type_traits>
+#include <vector>
 
 namespace cl3d {
 
@@ -1345,33 +1348,13 @@ constexpr int kMaxSplitFwd = 16;    // forward / input-gradient products: K = ch
 constexpr int kMaxSplitWgrad = 512; // weight gradients: K = every point of the batch
 
 // REDUCE_MODE 0: result through the output map; 1: PointWiseMLP weight-gradient merge (always via the reduce kernel)
+// launch_plan: the product under plan p (+ the launch that sums its K slices, where the plan has one).  `a` by value: the
+// measured-plan path below launches the same product under several plans.
 template <int REDUCE_MODE>
-static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t ws_bytes, const float *dwr, int Co, int C,
-                    hipStream_t st, const char *who) {
+static int launch_plan(GemmArgs a, const Plan &p, int precision, void *ws, const float *dwr, int Co, int C, hipStream_t st,
+                       const char *who) {
   const int I = a.A.R, J = a.B.R;
-  if (I == 0 || J == 0) return CL3D_OK;
   const bool always_reduce = REDUCE_MODE == 1;
-  if (always_reduce && (!ws || ws_bytes < (size_t)I * J * sizeof(float)))
-    return fail(CL3D_E_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, plan_workspace(I, J, a.K, max_split, true));
-  const int am = stage_mode(a.A), bm = stage_mode(a.B);
-  const bool vec_pair = (am == STAGE_VEC_RC && bm == STAGE_VEC_KC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_RC) ||
-                        (am == STAGE_VEC_RC && bm == STAGE_VEC_RC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_KC);
-  const bool kc_pair_f32 = precision != PREC_BF16 && am == STAGE_VEC_KC && bm == STAGE_VEC_KC;
-  const bool in_launch = REDUCE_MODE == 0 && fused_slice_sum();
-  Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, !vec_pair || kc_pair_f32, in_launch);
-#ifdef CL3D_GEMM_PLAN_ENV  // variant builds of scripts/micro/gemm_plan_sweep.py only: CL3D_GEMM_FORCE="wi,wj,split"
-  if (const char *force = getenv("CL3D_GEMM_FORCE")) {
-    int fwi = 0, fwj = 0, fsplit = 0;
-    if (sscanf(force, "%d,%d,%d", &fwi, &fwj, &fsplit) == 3 && (fwi == 1 || fwi == 2) && (fwj == 1 || fwj == 2) && fsplit >= 1) {
-      const int kc = gemm_kc(precision, fwi, fwj);
-      const long long chunks = (a.K + kc - 1) / kc;
-      if (fsplit > chunks) fsplit = (int)chunks;
-      while (fsplit > 1 && (!ws || (size_t)fsplit * I * J * sizeof(float) > ws_bytes)) --fsplit;
-      const long long cps = (chunks + fsplit - 1) / fsplit;
-      p = Plan{fwi, fwj, (int)((chunks + cps - 1) / cps), (int)cps};
-    }
-  }
-#endif
   a.tiles_i = ceil_div(I, 64 * p.wi);
   a.tiles_j = ceil_div(J, 64 * p.wj);
   a.nsplit = p.nsplit;
@@ -1422,6 +1405,144 @@ static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t 
     hipLaunchKernelGGL((gemm_reduce_kernel<REDUCE_MODE, 1>), dim3((unsigned)grid), dim3(256), 0, st, a.partial, p.nsplit, I,
                        J, final_out, dwr, Co, C);
   return check_launch(who);
+}
+
+// ---- plans by measurement (round 6, opt-in: cl3d_gemm_autotune(1)).  The launch-time model above is a fit with 15 % rms;
+// over the config-2 backbone's 72 products the plans it picks cost 8-9 % more than the best plan of each
+// (profiles/r06/gemm_plan_sweep_*_xcd.jsonl).  With the switch on, the FIRST call of a product outside stream capture --
+// key: extents, operand modes, precision, prologue / epilogue, slice budget, scratch size -- runs every plan the model
+// prices within 2.5x of its best a few times between two events on the caller's stream (the product is a pure function
+// of its operands: running it again changes nothing), and the winner is kept for the process.  Inside a capture a product
+// never seen before takes the model's plan.  Off by default: a different plan is a different summation order of the K
+// slices, so with the switch on two PROCESSES may differ in the last bits of a result (one process never does: a key
+// keeps its plan); bench.py / scripts/bench_backbone.py turn it on and say so in their lines.
+struct TuneKey {
+  long long K;
+  size_t ws_bytes;
+  int I, J, precision, am, bm, mode, max_split, flags;
+  bool operator<(const TuneKey &o) const {
+    return std::tie(K, ws_bytes, I, J, precision, am, bm, mode, max_split, flags) <
+           std::tie(o.K, o.ws_bytes, o.I, o.J, o.precision, o.am, o.bm, o.mode, o.max_split, o.flags);
+  }
+};
+static std::atomic<int> g_autotune{0};
+static std::mutex g_tune_mu;
+static std::map<TuneKey, Plan> g_tuned;
+static std::atomic<long long> g_tune_counts[2];  // products measured, products whose measured plan differs from the model's
+
+static std::vector<Plan> candidate_plans(int I, int J, long long K, int precision, int max_split, size_t ws_bytes,
+                                         bool no_big_tile, bool in_launch_sum, const Plan &model) {
+  const int cand[4][2] = {{2, 2}, {2, 1}, {1, 2}, {1, 1}};
+  const double budget = 2.5 * bf16_launch_us(I, J, K, model.wi, model.wj, model.cps, model.nsplit, in_launch_sum);
+  std::vector<Plan> out;
+  for (int c = 0; c < 4; ++c) {
+    const int wi = cand[c][0], wj = cand[c][1];
+    if (no_big_tile && wi * wj == 4) continue;
+    const int kc = gemm_kc(precision, wi, wj);
+    const long long chunks = (K + kc - 1) / kc;
+    const long long min_cps = precision == PREC_BF16 ? 2 : 4;
+    for (long long split = 1; split <= max_split && split <= (chunks >= min_cps ? chunks / min_cps : 1); split += (split < 4 ? 1 : split / 2)) {
+      if (split > 1 && (size_t)split * I * J * sizeof(float) > ws_bytes) break;
+      const long long cps = (chunks + split - 1) / split;
+      const long long real_split = (chunks + cps - 1) / cps;
+      // (the bf16 fit prices both precisions here: only a coarse screen -- a weight gradient in one slice is 50x off)
+      if (bf16_launch_us(I, J, K, wi, wj, cps, real_split, in_launch_sum) > budget) continue;
+      bool seen = false;
+      for (const Plan &q : out) seen = seen || (q.wi == wi && q.wj == wj && q.nsplit == (int)real_split);
+      if (!seen) out.push_back(Plan{wi, wj, (int)real_split, (int)cps});
+    }
+  }
+  return out;
+}
+
+template <int REDUCE_MODE>
+static Plan measured_plan(const GemmArgs &a, const Plan &model, int precision, int max_split, void *ws, size_t ws_bytes,
+                          bool no_big_tile, bool in_launch, const float *dwr, int Co, int C, hipStream_t st, const char *who) {
+  constexpr int kReps = 3;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+    (void)hipGetLastError();
+    if (e0) (void)hipEventDestroy(e0);
+    return model;
+  }
+  Plan best = model;
+  float best_ms = 1e30f, model_ms = 1e30f;
+  std::vector<Plan> cands = candidate_plans(a.A.R, a.B.R, a.K, precision, max_split, ws_bytes, no_big_tile, in_launch, model);
+  bool has_model = false;
+  for (const Plan &q : cands) has_model = has_model || (q.wi == model.wi && q.wj == model.wj && q.nsplit == model.nsplit);
+  if (!has_model) cands.push_back(model);
+  for (const Plan &q : cands) {
+    bool ok = launch_plan<REDUCE_MODE>(a, q, precision, ws, dwr, Co, C, st, who) == CL3D_OK;  // (code object, caches)
+    ok = ok && hipEventRecord(e0, st) == hipSuccess;
+    for (int r = 0; ok && r < kReps; ++r) ok = launch_plan<REDUCE_MODE>(a, q, precision, ws, dwr, Co, C, st, who) == CL3D_OK;
+    float ms = 0.f;
+    ok = ok && hipEventRecord(e1, st) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+         hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      best = model;
+      break;
+    }
+    if (q.wi == model.wi && q.wj == model.wj && q.nsplit == model.nsplit) model_ms = ms;
+    if (ms < best_ms) {
+      best_ms = ms;
+      best = q;
+    }
+  }
+  if (best_ms > 0.98f * model_ms) best = model;  // (within the timing's noise of the model's plan: keep that)
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return best;
+}
+
+template <int REDUCE_MODE>
+static int run_gemm(GemmArgs &a, int precision, int max_split, void *ws, size_t ws_bytes, const float *dwr, int Co, int C,
+                    hipStream_t st, const char *who) {
+  const int I = a.A.R, J = a.B.R;
+  if (I == 0 || J == 0) return CL3D_OK;
+  const bool always_reduce = REDUCE_MODE == 1;
+  if (always_reduce && (!ws || ws_bytes < (size_t)I * J * sizeof(float)))
+    return fail(CL3D_E_WORKSPACE, "%s: workspace %zu < %zu", who, ws_bytes, plan_workspace(I, J, a.K, max_split, true));
+  const int am = stage_mode(a.A), bm = stage_mode(a.B);
+  const bool vec_pair = (am == STAGE_VEC_RC && bm == STAGE_VEC_KC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_RC) ||
+                        (am == STAGE_VEC_RC && bm == STAGE_VEC_RC) || (am == STAGE_VEC_KC && bm == STAGE_VEC_KC);
+  const bool kc_pair_f32 = precision != PREC_BF16 && am == STAGE_VEC_KC && bm == STAGE_VEC_KC;
+  const bool in_launch = REDUCE_MODE == 0 && fused_slice_sum();
+  const bool no_big_tile = !vec_pair || kc_pair_f32;
+  Plan p = plan_gemm(I, J, a.K, precision, ws ? max_split : 1, ws ? ws_bytes : 0, no_big_tile, in_launch);
+  if (g_autotune.load(std::memory_order_relaxed) != 0) {
+    const int flags = (a.A.pro_scale ? 1 : 0) | (a.B.pro_scale ? 2 : 0) | (a.out.ep_scale ? 4 : 0) | (a.out.ep_res ? 8 : 0) |
+                      (a.out.ep_relu ? 16 : 0) | (a.out.fold_n ? 32 : 0) | (a.A.fold ? 64 : 0) | (a.B.fold ? 128 : 0);
+    const TuneKey key{a.K, ws ? ws_bytes : 0, I, J, precision, am, bm, REDUCE_MODE, ws ? max_split : 1, flags};
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+    std::lock_guard<std::mutex> lock(g_tune_mu);
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) {
+      p = it->second;
+    } else if (!capturing) {
+      const Plan m = measured_plan<REDUCE_MODE>(a, p, precision, ws ? max_split : 1, ws, ws ? ws_bytes : 0, no_big_tile,
+                                                in_launch, dwr, Co, C, st, who);
+      g_tune_counts[0] += 1;
+      if (m.wi != p.wi || m.wj != p.wj || m.nsplit != p.nsplit) g_tune_counts[1] += 1;
+      g_tuned[key] = m;
+      p = m;
+    }
+  }
+#ifdef CL3D_GEMM_PLAN_ENV  // variant builds of scripts/micro/gemm_plan_sweep.py only: CL3D_GEMM_FORCE="wi,wj,split"
+  if (const char *force = getenv("CL3D_GEMM_FORCE")) {
+    int fwi = 0, fwj = 0, fsplit = 0;
+    if (sscanf(force, "%d,%d,%d", &fwi, &fwj, &fsplit) == 3 && (fwi == 1 || fwi == 2) && (fwj == 1 || fwj == 2) && fsplit >= 1) {
+      const int kc = gemm_kc(precision, fwi, fwj);
+      const long long chunks = (a.K + kc - 1) / kc;
+      if (fsplit > chunks) fsplit = (int)chunks;
+      while (fsplit > 1 && (!ws || (size_t)fsplit * I * J * sizeof(float) > ws_bytes)) --fsplit;
+      const long long cps = (chunks + fsplit - 1) / fsplit;
+      p = Plan{fwi, fwj, (int)((chunks + cps - 1) / cps), (int)cps};
+    }
+  }
+#endif
+  return launch_plan<REDUCE_MODE>(a, p, precision, ws, dwr, Co, C, st, who);
 }
 
 static int round_up_grid(int n) {
@@ -1766,4 +1887,13 @@ extern "C" int cl3d_conv1x1_rows_bwd_weight(const float *x_rows, const float *sc
   a.out.D = dW; a.out.si = C; a.out.sj = 1;
   return run_gemm<0>(a, precision, kMaxSplitWgrad, ws, ws_bytes, nullptr, 0, 0, (hipStream_t)stream,
                      "cl3d_conv1x1_rows_bwd_weight");
+}
+
+// ---- plans by measurement: the switch (process-wide; see measured_plan above) and its counters
+extern "C" int cl3d_gemm_autotune(int enable) { return cl3d::g_autotune.exchange(enable != 0 ? 1 : 0); }
+
+extern "C" int cl3d_gemm_autotune_stats(long long *measured, long long *changed) {
+  if (measured) *measured = cl3d::g_tune_counts[0].load();
+  if (changed) *changed = cl3d::g_tune_counts[1].load();
+  return CL3D_OK;
 }

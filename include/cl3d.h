@@ -371,6 +371,15 @@ int cl3d_conv1x1_rows_bwd_data(const float *dy, const float *W, int B, int C, in
 int cl3d_conv1x1_rows_bwd_weight(const float *x_rows, const float *scale, const float *shift, const float *dy, int B,
                                  int C, int N, int Co, int precision, float *dW, void *ws, size_t ws_bytes,
                                  cl3d_stream_t stream);
+/* Tile and K-slice plans of the products above BY MEASUREMENT (process-wide switch, off by default; returns the previous
+ * setting).  On: the first call of a product outside stream capture -- key: extents, operand layouts, precision, prologue /
+ * epilogue, scratch size -- times the plans the launch-time model prices within 2.5x of its best on the caller's stream
+ * (a product is a pure function of its operands) and keeps the winner for the process; inside a capture an unseen product
+ * takes the model's plan.  A plan fixes the order in which K slices are summed: with the switch on two PROCESSES may
+ * differ in the last bits of a result, one process never does.  cl3d_gemm_autotune_stats: products measured so far,
+ * and how many of them kept a plan other than the model's (either pointer may be NULL). */
+int cl3d_gemm_autotune(int enable);
+int cl3d_gemm_autotune_stats(long long *measured, long long *changed);
 /* weight plumbing of the factored contraction: W [Co,3+2C] = [W_r | W_c | W_d] -> wr [Co,3], wcat [2Co,C] =
  * [W_d ; W_c - W_d];  d W from d wr (nullable) and the per-cloud products dwb [B,C,2Co] = F_b G_b. */
 int cl3d_pwmlp_split_weight(const float *W, int Co, int C, float *wr, float *wcat, cl3d_stream_t stream);

@@ -52,6 +52,9 @@ def main():
     ap.add_argument("--impl", default="auto")
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"],
                     help="arithmetic of the dense contractions (PointWiseMLP rows and 1x1 convolutions); BASELINE config 2 is bf16")
+    ap.add_argument("--gemm-plans", default="measured", choices=["model", "measured"],
+                    help="tile / K-slice plans of the dense products: the launch-time model, or timed at first sight during the "
+                         "warm-up steps (closerlook3d_amd.gemm_autotune)")
     ap.add_argument("--no-cache", action="store_true", help="disable the per-forward ball-query memo")
     ap.add_argument("--head", action="store_true",
                     help="backbone + the scene-segmentation head (nearest up-sampling decoder + classifier) in the step")
@@ -125,6 +128,7 @@ def main():
         from closerlook3d_amd.dp import device_identity, rank_census
         rank_census(device_identity(dev))  # raises under RCCL when two ranks share a device
     import closerlook3d_amd
+    closerlook3d_amd.gemm_autotune(args.gemm_plans == "measured")
     if args.block != "engine" or args.decode != "split" or args.layerwise:  # A/B arms, installed from outside the package
         sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
         from ab import library_arms
@@ -466,6 +470,7 @@ def main():
     if rank == 0:
         line = {"config": args.config, "operator": kind, "n_gpus": world, "clouds_per_gpu": B, "points": N, "width": width,
                 "precision": args.precision, "launch": "hip_graph" if graph is not None else "eager",
+                "gemm_plans": args.gemm_plans,
                 "ms_per_step": round(dt * 1e3, 3), "input_points_per_s": round(world * B * N / dt, 1), "scaling": "weak",
                 "head": "scene_seg" if head is not None else None,
                 "params_M": round(sum(p.numel() for p in params) / 1e6, 2),
@@ -479,6 +484,8 @@ def main():
             line["backend"] = dist.get_backend()
             line["world_size"] = dist.get_world_size()
         line["device"] = f"cuda:{local_rank} {torch.cuda.get_device_name(local_rank)}"
+        if args.gemm_plans == "measured":
+            line["gemm_plans_measured"], line["gemm_plans_changed"] = closerlook3d_amd.gemm_autotune_stats()
         if one_dev and world > 1:
             line["one_device_standin"] = True
         if args.checksums:  # same seeds, same steps: the exchange scheme must not change a bit of either

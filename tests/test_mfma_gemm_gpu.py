@@ -307,3 +307,59 @@ def test_bad_arguments_are_refused():
     g = torch.zeros(1, 16, 8, device=_dev())
     # the PointWiseMLP weight gradient always goes through the reduce kernel: scratch is mandatory
     assert lib.cl3d_pwmlp_point_gemm_bwd_weight(_p(x), _p(g), None, 1, 8, 16, 4, 0, _p(w), None, 0, None) == -3
+
+
+def test_measured_plans_give_the_model_plans_results_and_stay_put():
+    """cl3d_gemm_autotune (round 6): with the switch on, the first eager call of a product times the plausible (tile, K
+    split) plans and keeps one for the process.  Whatever it keeps, the result is the product (1e-5 relative in f32 against
+    float64; the plans differ only in the order the K slices are added), repeated calls give the same bits (a key keeps
+    its plan), a product first seen inside a stream capture takes the model's plan without synchronising, and the counters
+    move."""
+    import closerlook3d_amd
+    from closerlook3d_amd import _lib
+    lib = _lib.lib()
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    p = lambda t: t.data_ptr()  # noqa: E731
+    ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
+    was = closerlook3d_amd.gemm_autotune(True)
+    try:
+        before = closerlook3d_amd.gemm_autotune_stats()[0]
+        for (B, C, N, Co) in ((16, 288, 256, 576), (16, 1152, 16, 1152), (4, 72, 4096, 144)):
+            x = torch.randn(B, C, N, generator=g).to(dev)
+            dy = torch.randn(B, Co, N, generator=g).to(dev)
+            W = (torch.randn(Co, C, generator=g) / C ** 0.5).to(dev)
+            y, dx, dW = torch.empty(B, Co, N, device=dev), torch.empty(B, C, N, device=dev), torch.empty(Co, C, device=dev)
+            st = _lib.stream_ptr(dev)
+            runs = []
+            for _ in range(3):
+                _lib.check(lib.cl3d_conv1x1_fwd(p(x), p(W), B, C, N, Co, 0, p(y), p(ws), ws.numel(), st))
+                _lib.check(lib.cl3d_conv1x1_bwd_data(p(dy), p(W), B, C, N, Co, 0, p(dx), p(ws), ws.numel(), st))
+                _lib.check(lib.cl3d_conv1x1_bwd_weight(p(x), p(dy), B, C, N, Co, 0, p(dW), p(ws), ws.numel(), st))
+                torch.cuda.synchronize()
+                runs.append((y.clone(), dx.clone(), dW.clone()))
+            for a, b in zip(runs[0], runs[2]):
+                assert torch.equal(a, b)
+            want = (torch.einsum("oc,bcn->bon", W.double(), x.double()), torch.einsum("oc,bon->bcn", W.double(), dy.double()),
+                    torch.einsum("bon,bcn->oc", dy.double(), x.double()))
+            for got, ref in zip(runs[0], want):
+                assert float((got.double() - ref).abs().max() / ref.abs().max()) <= 1e-5
+        assert closerlook3d_amd.gemm_autotune_stats()[0] >= before + 9
+        # an unseen product inside a capture: no measurement (it would have to synchronise), the model's plan, same product
+        B, C, N, Co = 8, 144, 512, 200
+        x = torch.randn(B, C, N, generator=g).to(dev)
+        W = (torch.randn(Co, C, generator=g) / C ** 0.5).to(dev)
+        y = torch.empty(B, Co, N, device=dev)
+        seen = closerlook3d_amd.gemm_autotune_stats()[0]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            _lib.check(lib.cl3d_conv1x1_fwd(p(x), p(W), B, C, N, Co, 0, p(y), p(ws), ws.numel(), _lib.stream_ptr(dev)))
+        assert closerlook3d_amd.gemm_autotune_stats()[0] == seen
+        graph.replay()
+        torch.cuda.synchronize()
+        ref = torch.einsum("oc,bcn->bon", W.double(), x.double())
+        assert float((y.double() - ref).abs().max() / ref.abs().max()) <= 1e-5
+    finally:
+        closerlook3d_amd.gemm_autotune(was)
