@@ -14,6 +14,7 @@
 //     features are summed in a fixed order without atomics.
 #pragma once
 #include "cl3d_common.h"
+#include <stdlib.h>
 
 namespace cl3d {
 
@@ -23,19 +24,45 @@ struct LaneMap {
   int chunks;  // passes over the channel axis: chunk c covers channels [(c*L+cl)*V, +V)
 };
 
-// choose lanes-per-row to keep as many of the 64 lanes busy as possible, preferring wide rows
-inline LaneMap pick_lane_map(int C, int V) {
+// How a row of C channels is cut over the lanes of a wave: L lanes x V channels per piece, QW = 64 / L rows side by side,
+// `chunks` passes over the channel axis.  Rounds 1-5 minimised chunks / QW (wave-passes per row) -- for 72 channels 9 lanes x
+// 7 rows, two passes.  But the gather passes are bound by the cache lines a wave-load touches, not by issue slots: a piece of
+// L x 16 B that starts anywhere costs ~L/8 + 1 lines, so 7 rows x 144 B are 15 lines for 63 lanes where 3 rows x 288 B are
+// 10 for 54, and every pass repeats the per-slot index / coordinate work.  Measured on the PointWiseMLP step (round 6,
+// profiles/r06/session19*_summary.txt; TRAIN + support-major pass, us): 72 channels 18 lanes 156.7 / 9 lanes 180 / 12 lanes
+// 201; 144 channels 18 lanes 96.4 / 12 lanes 103.5 / 36 lanes 109; 288 channels 24 lanes 65.4 / 12 lanes 71.1; 36 and 64
+// channels: 9 and 16 lanes (one pass) as before.  The rule that reproduces those choices: wave-passes per row times
+// (1 + 6 / L), wider pieces preferred unless a narrower cut is 8 % better, and L then shrunk to what the pass count needs
+// (to a multiple of 8 lanes = 128 B where that keeps the rows per wave).  `wide` false keeps the old rule: PosPool's sin / cos
+// embedding is bound by its arithmetic per (slot, channel), not by the gathers, and wants the fewest wave-passes per row
+// (config 5, sin_cos at 144-1152 channels: 19.8 ms with the old maps, 20.4 with the wide ones; session20_summary.txt).
+#ifndef CL3D_LANE_RULE
+#define CL3D_LANE_RULE 1  // (0: rounds 1-5's rule, the A/B arm of scripts/micro/kernel_variants.py)
+#endif
+inline LaneMap pick_lane_map(int C, int V, int max_L = 64, bool wide = true) {
   const int rowv = (C + V - 1) / V;
+#ifdef CL3D_LANE_ENV  // variant builds of scripts/micro/kernel_variants.py only: CL3D_LANES = lanes per row
+  if (const char *e = getenv("CL3D_LANES")) {
+    const int L = atoi(e);
+    if (L >= 1 && L <= 64) return LaneMap{L, 64 / L, (rowv + L - 1) / L};
+  }
+#endif
   double best = 1e30;
   LaneMap m{1, 64, rowv};
-  for (int L = 64; L >= 1; --L) {
+  for (int L = max_L; L >= 1; --L) {
     const int qw = 64 / L;
     const int chunks = (rowv + L - 1) / L;
-    const double cost = (double)chunks / qw;
+    double cost = (double)chunks / qw;
+    if (CL3D_LANE_RULE && wide) cost *= 1.0 + 6.0 / (double)(L < rowv ? L : rowv);
     if (cost < best * 0.92) {  // only go narrower for a real gain
       best = cost;
       m = LaneMap{L, qw, chunks};
     }
+  }
+  if (CL3D_LANE_RULE && wide) {
+    const int need = (rowv + m.chunks - 1) / m.chunks, need8 = (need + 7) & ~7;
+    if (need8 <= max_L && 64 / need8 == m.QW) m.L = need8;
+    else if (64 / need == m.QW) m.L = need;
   }
   return m;
 }

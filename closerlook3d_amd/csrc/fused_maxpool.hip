@@ -10,6 +10,12 @@
 
 namespace cl3d {
 
+// The pooling kernels keep rounds 1-5's lane maps (most rows per wave): measured against the wide maps of fused_common.h on
+// the replayed backbones, config 4 5.66 against 5.75 ms, config 5 19.75 against 19.87, configs 2 / 3 the same
+// (profiles/r06/session20c_summary.txt).
+constexpr bool kMaxpoolWide = false;
+
+
 struct MaxArgs {
   const int *idx;             // [B,M,K]
   const float *ft;            // fwd: [B,N,C] point-major features
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(MaxArgs a) {
 
 bool maxpool_supported(int K, int C) {
   if (K < 1 || K > 255 || C < 1) return false;
-  LaneMap m = pick_lane_map(C, (C % 4 == 0) ? 4 : 1);
+  LaneMap m = pick_lane_map(C, (C % 4 == 0) ? 4 : 1, 64, kMaxpoolWide);
   while (4 * (size_t)m.QW * (K + 1) * sizeof(int) > 48 * 1024 && m.QW > 1) m.QW -= 1;
   return 4 * (size_t)m.QW * (K + 1) * sizeof(int) <= 64 * 1024;
 }
@@ -165,7 +171,7 @@ extern "C" int cl3d_maxpool_fwd(const int32_t *idx, const float *ft, int B, int 
   MaxArgs a{};
   a.idx = idx; a.ft = ft; a.out = out; a.kstar_t = kstar_t; a.B = B; a.N = N; a.M = M; a.K = K; a.C = C;
   const int V = (C % 4 == 0) ? 4 : 1;
-  LaneMap m = pick_lane_map(C, V);
+  LaneMap m = pick_lane_map(C, V, 64, kMaxpoolWide);
   while (4 * (size_t)m.QW * (K + 1) * sizeof(int) > 48 * 1024 && m.QW > 1) m.QW -= 1;
   if (4 * (size_t)m.QW * (K + 1) * sizeof(int) > 64 * 1024) return fail(CL3D_E_UNSUPPORTED, "maxpool_fwd: nsample too large for LDS");
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
@@ -189,7 +195,7 @@ extern "C" int cl3d_maxpool_bwd(const float *gout_t, const unsigned char *kstar_
   a.gout_t = gout_t; a.kstar_t = const_cast<unsigned char *>(kstar_t); a.inv_off = inv_off; a.inv_slots = inv_slots;
   a.dft = dft; a.dft_channel_major = dft_channel_major; a.B = B; a.N = N; a.M = M; a.K = K; a.C = C;
   const int V = (C % 4 == 0) ? 4 : 1;
-  const LaneMap m = pick_lane_map(C, V);
+  const LaneMap m = pick_lane_map(C, V, 64, kMaxpoolWide);
   a.L = m.L; a.QW = m.QW; a.chunks = m.chunks;
   const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
   const int gx = round_grid(tiles, 8192);

@@ -1472,7 +1472,8 @@ static int pw_check(const PwArgs &a, const char *who) {
 // inside the replayed step, next to the CSR build on the other queue, 1 is (0.3623-0.3635 vs 0.3791-0.3799 ms per
 // step on two boxes).  1 is the default; CL3D_PW_QPG=2 selects the other for A/B timing.
 static LaneMap pw_lane_map(int Co, int K, int V, int nacc, int qpg, size_t *lds_out) {
-  LaneMap m = pick_lane_map(Co, V);
+  // (<= 48 lanes per row: the waves' double accumulators -- 4 x L x V x nacc x 8 B -- have to fit beside the slot tile)
+  LaneMap m = pick_lane_map(Co, V, 48);
   if (m.QW > 16) {
     m.QW = 16;
     m.L = 4;

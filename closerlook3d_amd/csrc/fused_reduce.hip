@@ -836,7 +836,7 @@ static void launch_bwd(int op, const ReduceArgs &a, dim3 grid, dim3 block, size_
 }
 
 static LaneMap fwd_lane_map(int op, int C, int K, int V, size_t *lds_out, bool sparse = false) {
-  LaneMap m = pick_lane_map(C, V);
+  LaneMap m = pick_lane_map(C, V, 64, op != OP_POSPOOL_SINCOS);
   if (m.QW > 16) {  // keep the per-block slot tile modest
     m.QW = 16;
     m.L = 4;
@@ -1019,7 +1019,7 @@ extern "C" int cl3d_fused_reduce_bwd(int op, const float *gout_t, const float *f
   CL3D_REQUIRE(!has_params || (ft && dparam && n_partials == cl3d_fused_param_partials(op, B, N, C)),
                "fused_reduce_bwd: parameter-gradient buffer must have cl3d_fused_param_partials() blocks");
   const int V = (C % 4 == 0) ? 4 : 1;
-  LaneMap m = pick_lane_map(C, V);
+  LaneMap m = pick_lane_map(C, V, 64, op != OP_POSPOOL_SINCOS);
   // PseudoGrid carries 2*kMaxKP*V accumulators per lane: two waves per block keep the LDS slice at 32 KiB
   const int waves = 4;
   const int NP = op == OP_ADAPTIVE ? 4 : 0;  // PseudoGrid's parameter gradient has its own kernel below

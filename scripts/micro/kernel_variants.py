@@ -33,6 +33,10 @@ VARIANTS = {  # tag: (source file, extra defines)
     "bn_finalize_launch": ("bn_relu.hip", ["-DCL3D_BN_FOLD=0"]),
     # round 6: the GEMM's tiles in plain order (shipped: the tiles that share the large operand strip on one XCD)
     "gemm_plain_order": ("mfma_gemm.hip", ["-DCL3D_GEMM_XCD=0"]),
+    # round 6: the PointWiseMLP passes with the lanes per row taken from CL3D_LANES (how a 72- / 144-channel row is cut)
+    "pw_lanes_env": ("fused_pwmlp.hip", ["-DCL3D_LANE_ENV"]),
+    # round 6: the lane maps of round 1-5 (most queries per wave; shipped: fewer, wider row pieces per wave-load)
+    "lane_rule_r5": (("fused_pwmlp.hip", "fused_reduce.hip", "fused_maxpool.hip"), ["-DCL3D_LANE_RULE=0"]),
     # (round 6: "pg_nofork" = fused_reduce.hip with -DCL3D_PG_FORK=0 was the A/B arm of PseudoGrid's forked kernel-weight
     #  pass; the fork measured slower and was removed with its macro -- profiles/r06/session7_summary.txt, commit dbb7bed)
 }
@@ -45,16 +49,23 @@ def build(only=None):
     for tag, (src, defs) in VARIANTS.items():
         if only and tag not in only:
             continue
-        obj = os.path.join(VAR, f"var_{tag}.o")
-        procs.append((tag, src, obj, subprocess.Popen([HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, src), "-o", obj],
-                                                      stderr=subprocess.DEVNULL)))
-    for tag, src, obj, p in procs:
+        srcs = [src] if isinstance(src, str) else list(src)  # (a variant may rebuild several files with its defines)
+        for one in srcs:
+            obj = os.path.join(VAR, f"var_{tag}_{one[:-4]}.o")
+            procs.append((tag, one, obj, subprocess.Popen([HIPCC] + FLAGS + defs + ["-c", os.path.join(CSRC, one), "-o", obj],
+                                                          stderr=subprocess.DEVNULL)))
+    by_tag = {}
+    for tag, one, obj, p in procs:
         if p.wait() != 0:
-            raise SystemExit(f"hipcc failed on variant {tag}")
+            raise SystemExit(f"hipcc failed on variant {tag} ({one})")
+        by_tag.setdefault(tag, []).append((one, obj))
+    for tag, pairs in by_tag.items():
         lib = os.path.join(VAR, f"libcl3d_{tag}.so")
-        others = [o for o in objs if os.path.basename(o) != src[:-4] + ".o"]
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + others + [obj])
-        os.remove(obj)
+        replaced = {one[:-4] + ".o" for one, _ in pairs}
+        others = [o for o in objs if os.path.basename(o) not in replaced]
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + others + [obj for _, obj in pairs])
+        for _, obj in pairs:
+            os.remove(obj)
         print("built", lib)
 
 
