@@ -38,6 +38,8 @@ SIGNATURES = {
     "cl3d_fused_reduce_bwd": [_I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _F, _I, _P, _I, _P, _I, _P],
     "cl3d_maxpool_fwd": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
     "cl3d_maxpool_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _I, _P],
+    "cl3d_maxpool_fwd_targets": [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P],
+    "cl3d_maxpool_bwd_targets": [_P, _P, _I, _I, _I, _I, _P, _P],
     "cl3d_dataset_grid_subsampling": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P, _P, _P, ctypes.c_size_t, _P],
     "cl3d_sphere_crop_query": [_P, _I, _P, ctypes.c_double, _I, _P, _P, _P, _Z, _P],
     "cl3d_sphere_crop_assemble": [_P, _P, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _Z, _P],

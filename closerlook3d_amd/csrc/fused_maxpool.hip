@@ -6,6 +6,13 @@
 // (first maximum, as max_pool2d's backward routes it) is kept as one byte per (query, channel).  The
 // backward is an ordered gather through the CSR inverse of idx: a slot passes its query's gradient on
 // exactly for the channels whose arg-max it is.  No atomics, fixed summation order.
+//
+// Round 6: the TARGET form.  The forward pass can leave the arg-max's SUPPORT INDEX per (channel, query) instead of its slot
+// (cl3d_maxpool_fwd_targets: int32 [B,C,M], channel-major like the output), and the backward is then a scatter with exactly
+// one target per (query, channel) -- cl3d_maxpool_bwd_targets = the PointWiseMLP's arg-max scatter (pwmlp_hit_kernel:
+// ds_add_f64 into LDS rows of doubles, a few floats per row: exact, order-free), on the channel-major gradient as autograd
+// hands it over: no CSR inverse of idx (four launches per pooling layer), no transposed copy of the gradient, M C adds
+// instead of M K C tests.  85 -> ~20 us for the first pooling layer of the config-2 backbone.
 #include "fused_common.h"
 
 namespace cl3d {
@@ -21,6 +28,7 @@ struct MaxArgs {
   const float *ft;            // fwd: [B,N,C] point-major features
   float *out;                 // fwd: [B,C,M] channel-major (the API layout), written directly
   unsigned char *kstar_t;     // [B,M,C]
+  int *target_cm;             // fwd, nullable: [B,C,M] support index of the arg-max (the target form)
   const float *gout_t;        // bwd: [B,M,C]
   const int *inv_off, *inv_slots;
   float *dft;                 // bwd: [B,N,C], or [B,C,N] when dft_channel_major
@@ -85,6 +93,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(MaxArgs a) {
     for (int v = 0; v < V; ++v) {
       a.out[((size_t)b * C + c0 + v) * M + j] = best[v];
       if (a.kstar_t) a.kstar_t[orow + v] = (unsigned char)kb[v];
+      if (a.target_cm) a.target_cm[((size_t)b * C + c0 + v) * M + j] = my[kb[v]];
     }
   }
 }
@@ -161,15 +170,15 @@ bool maxpool_supported(int K, int C) {
 
 }  // namespace cl3d
 
-extern "C" int cl3d_maxpool_fwd(const int32_t *idx, const float *ft, int B, int N, int M, int K, int C, float *out,
-                                unsigned char *kstar_t, cl3d_stream_t stream) {
+static int maxpool_forward(const int32_t *idx, const float *ft, int B, int N, int M, int K, int C, float *out,
+                           unsigned char *kstar_t, int32_t *target_cm, cl3d_stream_t stream) {
   using namespace cl3d;
   CL3D_REQUIRE(B >= 0 && N >= 1 && M >= 0 && K >= 1 && C >= 1, "maxpool_fwd: bad sizes");
   if (K > 255) return fail(CL3D_E_UNSUPPORTED, "maxpool_fwd: nsample=%d > 255 (arg-max is stored in a byte)", K);
   if (B == 0 || M == 0) return CL3D_OK;
   CL3D_REQUIRE(idx && ft && out, "maxpool_fwd: null pointer");
   MaxArgs a{};
-  a.idx = idx; a.ft = ft; a.out = out; a.kstar_t = kstar_t; a.B = B; a.N = N; a.M = M; a.K = K; a.C = C;
+  a.idx = idx; a.ft = ft; a.out = out; a.kstar_t = kstar_t; a.target_cm = target_cm; a.B = B; a.N = N; a.M = M; a.K = K; a.C = C;
   const int V = (C % 4 == 0) ? 4 : 1;
   LaneMap m = pick_lane_map(C, V, 64, kMaxpoolWide);
   while (4 * (size_t)m.QW * (K + 1) * sizeof(int) > 48 * 1024 && m.QW > 1) m.QW -= 1;
@@ -181,6 +190,24 @@ extern "C" int cl3d_maxpool_fwd(const int32_t *idx, const float *ft, int B, int 
   if (V == 4) hipLaunchKernelGGL((maxpool_fwd_kernel<4>), grid, dim3(256), lds, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((maxpool_fwd_kernel<1>), grid, dim3(256), lds, (hipStream_t)stream, a);
   return check_launch("cl3d_maxpool_fwd");
+}
+
+extern "C" int cl3d_maxpool_fwd(const int32_t *idx, const float *ft, int B, int N, int M, int K, int C, float *out,
+                                unsigned char *kstar_t, cl3d_stream_t stream) {
+  return maxpool_forward(idx, ft, B, N, M, K, C, out, kstar_t, nullptr, stream);
+}
+
+extern "C" int cl3d_maxpool_fwd_targets(const int32_t *idx, const float *ft, int B, int N, int M, int K, int C, float *out,
+                                        int32_t *target_cm, cl3d_stream_t stream) {
+  if (B > 0 && M > 0 && !target_cm) return cl3d::fail(CL3D_E_INVALID, "maxpool_fwd_targets: null pointer");
+  return maxpool_forward(idx, ft, B, N, M, K, C, out, nullptr, target_cm, stream);
+}
+
+extern "C" int cl3d_maxpool_bwd_targets(const float *gout, const int32_t *target_cm, int B, int N, int M, int C,
+                                        float *dfeat, cl3d_stream_t stream) {
+  // d features[b, c, i] = sum over the queries j whose arg-max for channel c is support point i of gout[b, c, j]: the
+  // PointWiseMLP's arg-max scatter (csrc/fused_pwmlp.hip), every row of d features written (zero where nothing points)
+  return cl3d_pwmlp_bwd_hits(gout, target_cm, B, N, M, C, dfeat, stream);
 }
 
 extern "C" int cl3d_maxpool_bwd(const float *gout_t, const unsigned char *kstar_t, const int32_t *inv_off,

@@ -512,37 +512,57 @@ def pseudo_grid(query_xyz, support_xyz, query_mask, support_mask, features, radi
 
 
 class _MaxPool(Function):
-    """out[b,c,j] = max_k f[b,c,idx[b,j,k]] with max_pool2d's gradient routing (first maximum)."""
+    """out[b,c,j] = max_k f[b,c,idx[b,j,k]] with max_pool2d's gradient routing (first maximum).
+
+    Round 6: the forward pass keeps the arg-max's SUPPORT INDEX per (channel, query) (`cl3d_maxpool_fwd_targets`) and the
+    backward is a scatter with one target per (query, channel) on the channel-major gradient (`cl3d_maxpool_bwd_targets`:
+    doubles in LDS, exact and order-free) -- no CSR inverse of idx, no transposed copy of the gradient.  MAXPOOL_TARGETS =
+    False restores the slot-byte form with its ordered gather through the CSR inverse (the A/B arm; same values up to the
+    rounding of a sum of a few floats)."""
 
     @staticmethod
     def forward(ctx, features, idx, need_grad):
         B, C, N = features.shape
         _, M, K = idx.shape
         ft = _transposed(features)
-        pre = _mark(features.device) if need_grad else None
+        targets = need_grad and MAXPOOL_TARGETS
+        pre = _mark(features.device) if need_grad and not targets else None
         wait_ready(idx)
         out = torch.empty((B, C, M), dtype=torch.float32, device=features.device)
-        kstar = torch.empty((B, M, C), dtype=torch.uint8, device=features.device) if need_grad else None
+        kept = None
         with _lib.on_device(features.device):
-            _lib.check(_lib.lib().cl3d_maxpool_fwd(_p(idx), _p(ft), B, N, M, K, C, _p(out), _p(kstar),
-                                                   _stream(features)))
-        if need_grad:
+            if targets:
+                kept = torch.empty((B, C, M), dtype=torch.int32, device=features.device)
+                _lib.check(_lib.lib().cl3d_maxpool_fwd_targets(_p(idx), _p(ft), B, N, M, K, C, _p(out), _p(kept),
+                                                               _stream(features)))
+            else:
+                kept = torch.empty((B, M, C), dtype=torch.uint8, device=features.device) if need_grad else None
+                _lib.check(_lib.lib().cl3d_maxpool_fwd(_p(idx), _p(ft), B, N, M, K, C, _p(out), _p(kept),
+                                                       _stream(features)))
+        if need_grad and not targets:
             _start_inverse(idx, N, pre)
-        ctx.save_for_backward(kstar)
-        ctx.idx = idx
+        ctx.save_for_backward(kept)
+        ctx.idx = None if targets else idx
+        ctx.targets = targets
         ctx.meta = (B, N, M, K, C)
-        _join_inverse(idx)
+        if not targets:
+            _join_inverse(idx)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        (kstar,) = ctx.saved_tensors
+        (kept,) = ctx.saved_tensors
         B, N, M, K, C = ctx.meta
+        dfeat = torch.empty((B, C, N), dtype=torch.float32, device=gout.device)  # channel-major, written by the kernel
+        if ctx.targets:
+            gout = gout.contiguous()
+            with _lib.on_device(gout.device):
+                _lib.check(_lib.lib().cl3d_maxpool_bwd_targets(_p(gout), _p(kept), B, N, M, C, _p(dfeat), _stream(gout)))
+            return dfeat, None, None
         gout_t = _transposed(gout)
         off, slots = inverse_index(ctx.idx, N)
-        dfeat = torch.empty((B, C, N), dtype=torch.float32, device=gout.device)  # channel-major, written by the kernel
         with _lib.on_device(gout.device):
-            _lib.check(_lib.lib().cl3d_maxpool_bwd(_p(gout_t), _p(kstar), _p(off), _p(slots), B, N, M, K, C, _p(dfeat), 1,
+            _lib.check(_lib.lib().cl3d_maxpool_bwd(_p(gout_t), _p(kept), _p(off), _p(slots), B, N, M, K, C, _p(dfeat), 1,
                                                    _stream(gout)))
         return dfeat, None, None
 
@@ -1175,6 +1195,8 @@ def point_rows(features, W, precision='f32'):
 # memo: a backbone that shares geometry between its blocks keeps the kernel-by-kernel path, which shares it)
 PASS_CALLS = True
 
+
+MAXPOOL_TARGETS = True  # max pooling keeps support indices and scatters its gradient (see _MaxPool); False: slot bytes + CSR gather
 
 PW_CSR_FIRST = True  # (module attribute: scripts set it to False for the A/B; see pointwise_mlp)
 # the same order for a STAND-ALONE PosPool / AdaptiveWeight / PseudoGrid step (no per-forward geometry memo): 0.269 -> 0.264,

@@ -265,6 +265,13 @@ int cl3d_maxpool_fwd(const int32_t *idx, const float *ft, int B, int N, int M, i
 int cl3d_maxpool_bwd(const float *gout_t, const unsigned char *kstar_t, const int32_t *inv_off,
                      const int32_t *inv_slots, int B, int N, int M, int K, int C, float *dft,
                      int dft_channel_major, cl3d_stream_t stream);
+/* The same pooling with the arg-max kept as its SUPPORT INDEX, target_cm int32 [B,C,M] (channel-major like out), and the
+ * backward as a scatter with one target per (query, channel): gout [B,C,M] and dfeat [B,C,N] channel-major, no CSR inverse,
+ * no transposed gradient; sums in double in LDS (a few floats per row: exact, order-free), every element of dfeat written. */
+int cl3d_maxpool_fwd_targets(const int32_t *idx, const float *ft, int B, int N, int M, int K, int C, float *out,
+                             int32_t *target_cm, cl3d_stream_t stream);
+int cl3d_maxpool_bwd_targets(const float *gout, const int32_t *target_cm, int B, int N, int M, int C, float *dfeat,
+                             cl3d_stream_t stream);
 
 /* PointWiseMLP 'dp_fi_df', one Conv2d+BatchNorm2d+ReLU layer, max reduction
  * (local_aggregation_operators.py:288-301).  ght [B,N,2*Co]: row i = [W_d f_i | (W_c - W_d) f_i];

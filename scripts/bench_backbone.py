@@ -55,6 +55,9 @@ def main():
     ap.add_argument("--gemm-plans", default="measured", choices=["model", "measured"],
                     help="tile / K-slice plans of the dense products: the launch-time model, or timed at first sight during the "
                          "warm-up steps (closerlook3d_amd.gemm_autotune)")
+    ap.add_argument("--maxpool", default="targets", choices=["targets", "slots"],
+                    help="max pooling's backward: a scatter on kept support indices (default) or the ordered gather through the CSR "
+                         "inverse of rounds 1-5 (A/B arm)")
     ap.add_argument("--no-cache", action="store_true", help="disable the per-forward ball-query memo")
     ap.add_argument("--head", action="store_true",
                     help="backbone + the scene-segmentation head (nearest up-sampling decoder + classifier) in the step")
@@ -135,6 +138,7 @@ def main():
         library_arms.install(block=args.block, decode=args.decode, layerwise=args.layerwise)
     from closerlook3d_amd import fused as _fu
     from closerlook3d_amd import pt_utils as _put
+    _fu.MAXPOOL_TARGETS = args.maxpool == "targets"
     _fork_shipped, _fork_count = _fu._fork_join, [0]
 
     def _fork_debug(device, side_fn, main_fn):

@@ -126,7 +126,8 @@ def test_overlapped_exchange_gives_the_same_step_as_the_flat_one():
         env = dict(os.environ, CL3D_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "scripts", "bench_backbone.py"), "--gpus", "2",
-               "--config", "modelnet_small", "--steps", "3", "--warmup", "1", "--checksums", "--head", *flag]
+               "--config", "modelnet_small", "--steps", "3", "--warmup", "1", "--checksums", "--head", "--gemm-plans", "model",
+               *flag]
         r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
         lines[bool(flag)] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
@@ -174,8 +175,10 @@ def test_overlapped_step_with_its_forks_equals_the_single_stream_two_graph_step(
     dumps, lines = {}, {}
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    # (--gemm-plans model: the bench's default since round 6 is plans measured at first sight, and a plan fixes the order in
+    #  which the K slices of a product are summed -- bit patterns compared ACROSS processes, as here, need the same plans)
     base = [sys.executable, os.path.join(ROOT, "scripts", "bench_backbone.py"), "--gpus", "2", "--config", "modelnet_small",
-            "--warmup", "1", "--head", "--overlap"]
+            "--warmup", "1", "--head", "--overlap", "--gemm-plans", "model"]
     def repeat_check(mode):
         r = subprocess.run(base + ["--overlap-forks", mode, "--repeat-check", "60"], cwd=ROOT, env=env, capture_output=True,
                            text=True, timeout=900)

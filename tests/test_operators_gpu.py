@@ -270,11 +270,17 @@ def test_eval_mode_inference_paths_agree():
             assert_close(a(*t).cpu().numpy(), b(*t).cpu().numpy(), 1e-5, f"{kind} eval fused vs grouped")
 
 
-@pytest.mark.parametrize("C,K,N,npoint", [(24, 16, 512, 128), (144, 32, 2048, 512), (10, 9, 300, 77)])
-def test_fused_max_pool_matches_reference_dataflow(C, K, N, npoint):
-    """MaskedMaxPool: fused kernel == gather + F.max_pool2d (values and gradient routing, incl. ReLU-zero ties)."""
+@pytest.mark.parametrize("targets", [True, False])
+@pytest.mark.parametrize("C,K,N,npoint", [(24, 16, 512, 128), (144, 32, 2048, 512), (10, 9, 300, 77), (8, 24, 9000, 2252)])
+def test_fused_max_pool_matches_reference_dataflow(C, K, N, npoint, targets, monkeypatch):
+    """MaskedMaxPool: fused kernel == gather + F.max_pool2d (values and gradient routing, incl. ReLU-zero ties), in both
+    forms of the engine's pooling: the arg-max kept as a support index with the gradient scattered (round 6, the default;
+    9000 points: three support tiles of the scatter's LDS rows, 77 / 2252 queries: not a multiple of four) and the
+    arg-max kept as a slot byte with the ordered gather through the CSR inverse."""
+    from closerlook3d_amd import fused as _fused
     from closerlook3d_amd.pt_utils import MaskedMaxPool
     from oracle import operators as oo
+    monkeypatch.setattr(_fused, "MAXPOOL_TARGETS", targets)
     rng = np.random.default_rng(C + K)
     B = 2
     xyz, mask = oo.make_cloud(rng, B, N, pad_frac=0.15)
