@@ -263,6 +263,12 @@ def test_in_launch_sum_forced_on_every_tile_and_split_matches_the_two_launch_for
     var = os.path.join(root, "scripts", "micro", "var", "libcl3d_gemm_plan_env.so")
     if not os.path.exists(var):
         pytest.skip("variant library not built (python scripts/micro/gemm_plan_sweep.py --build; __graft_entry__.build() does)")
+    import ctypes
+    from closerlook3d_amd import _lib as _shipped
+    handle = ctypes.CDLL(var)
+    stale = [name for name in _shipped.SIGNATURES if not hasattr(handle, name)]
+    if stale:  # (built before the ABI grew: the loader of the child process would refuse it)
+        pytest.skip(f"variant library is older than the shipped one (lacks {stale[:3]}): rebuild it with __graft_entry__.build()")
     code = r"""
 import os, sys, torch
 sys.path.insert(0, %r)
