@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round 6 session 22: steady-state kernel table of config 2 (bf16, measured plans, new lane maps, scattered pooling) and the
+# GEMM launches by grid
+cd "$(dirname "$0")/../.." || exit 1
+OUT=gpurun_out/r06_s22
+mkdir -p $OUT
+export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
+R=$GRAFT_REPO_ROOT
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --output-format csv -d $R/$OUT/prof_bb -o bb -- python $R/scripts/bench_backbone.py --config modelnet_pointwisemlp --precision bf16 --steps 150 > $R/$OUT/rocprof_bb.log 2>&1)
+grep '^{' $OUT/rocprof_bb.log | tail -1 | cut -c1-400 | tee $OUT/summary.txt
+T=$(find $OUT/prof_bb -name "bb_kernel_trace.csv" | head -1)
+STEPS=$(python - "$T" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+t_end = max(int(r["End_Timestamp"]) for r in rows)
+print(sum(1 for r in rows if "pwmlp_hit_coeffs_kernel" in r["Kernel_Name"] and int(r["Start_Timestamp"]) >= t_end - 400e6) // 4)
+PY
+)
+echo "steps in the last 400 ms: $STEPS" | tee -a $OUT/summary.txt
+python scripts/ktrace_tail.py $T 400 $STEPS 45 | tee $OUT/backbone_steady_state.txt | tee -a $OUT/summary.txt
+echo "== mfma_gemm_kernel by (kernel, grid)" | tee -a $OUT/summary.txt
+python scripts/ktrace_calls.py $T mfma_gemm_kernel --by-grid 400 $STEPS | head -60 | tee -a $OUT/summary.txt
+rm -rf $OUT/prof_bb
+echo "== done" | tee -a $OUT/summary.txt
