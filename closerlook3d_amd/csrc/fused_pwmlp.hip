@@ -1621,9 +1621,23 @@ extern "C" int cl3d_pwmlp_merge_weight_grad(const float *dwr, const float *dwb, 
   return cl3d::check_launch("cl3d_pwmlp_merge_weight_grad");
 }
 
+// The gather passes run gx x chunks workgroups (chunks = passes over the channel axis, on gridDim.y), four resident per CU.
+// Where a workgroup would get one or two tiles, gx x chunks is kept at or below the 1024 that are resident at once: ONE
+// generation of persistent workgroups with more tiles each instead of two generations of one or two (round 6, config 2's
+// 144-channel layers at 16 384 points: backbone step bf16 5.61 / 5.70 / 5.62 against 5.70 / 5.69 / 5.67 ms, f32 neutral;
+// profiles/r06/session27_summary.txt).  With many tiles per workgroup the two generations cost nothing and the
+// chunk-by-chunk order keeps an XCD's L2 on one half of the rows (144 channels x 65 536 points: 0.829 against 0.849 ms).
+static int pw_resident_cap(int chunks, long long tiles) {
+  if (chunks <= 1 || tiles >= 2048) return 1024;
+  const int cap = 1024 / chunks;
+  return cap < 8 ? 8 : cap & ~7;
+}
+
 extern "C" int cl3d_pwmlp_partials(int B, int M, int Co) {
-  (void)Co;
-  return cl3d::round_grid(((long long)B * M + 7) / 8, 1024);
+  size_t lds = 0;
+  const int chunks = Co >= 1 ? cl3d::pw_lane_map(Co, 32, (Co % 4 == 0) ? 4 : 1, 8, 1, &lds).chunks : 1;  // (chunks depend on Co only)
+  const long long want = ((long long)B * M + 7) / 8;  // (at most two 16-query tiles per workgroup)
+  return cl3d::round_grid(want, pw_resident_cap(chunks, want / 2));
 }
 
 extern "C" int cl3d_pwmlp_stats(const float *query_xyz, const float *support_xyz, const int32_t *idx,
@@ -1838,7 +1852,9 @@ extern "C" int cl3d_pwmlp_bwd_support(const float *ght, const float *wr, const f
   const long long tiles = (long long)B * ceil_div(N, 4 * m.QW);
   if (tiles > 0x7fffffffLL) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support: too many tiles");
   if (m.L * V > 256) return fail(CL3D_E_UNSUPPORTED, "pwmlp_bwd_support: %d channels per chunk", m.L * V);
-  const int gx = round_grid(tiles, 256 * CL3D_SUP_WAVES);  // persistent: as many workgroups per CU as fit, each pipelines over its tiles
+  // persistent: as many workgroups per CU as fit -- counting the channel chunks on gridDim.y where tiles are few -- each
+  // pipelines over its tiles
+  const int gx = round_grid(tiles, pw_resident_cap(m.chunks, tiles) * CL3D_SUP_WAVES / 4);
   if (V == 4) hipLaunchKernelGGL((pwmlp_support_kernel<4, CL3D_SUP_SB>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((pwmlp_support_kernel<1, 8>), dim3(gx, m.chunks), dim3(256), 0, (hipStream_t)stream, a);
   return check_launch("cl3d_pwmlp_bwd_support");
