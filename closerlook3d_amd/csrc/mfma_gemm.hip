@@ -697,7 +697,8 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restric
 #pragma unroll
     for (int v = 0; v < VEC; ++v) top[v] = bot[v] = 0.f;
     if (e < n_el) {
-      for (int p = sg; p < nsplit; p += 16) {
+#pragma unroll 4
+      for (int p = sg; p < nsplit; p += 16) {  // (unrolled: four slices' loads in flight, added in the same order)
         if constexpr (VEC == 4) {
           const float4 t = *reinterpret_cast<const float4 *>(part + (size_t)p * IJ + e);
           top[0] += t.x; top[1] += t.y; top[2] += t.z; top[3] += t.w;
@@ -751,6 +752,7 @@ __global__ __launch_bounds__(256) void gemm_reduce4_kernel(const float *__restri
   for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
     const long long e = q * 4;
     float4 acc = *reinterpret_cast<const float4 *>(part + e);
+#pragma unroll 4
     for (int p = 1; p < nsplit; ++p) {
       const float4 v = *reinterpret_cast<const float4 *>(part + (size_t)p * IJ + e);
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
@@ -771,6 +773,39 @@ __global__ __launch_bounds__(256) void gemm_reduce4_kernel(const float *__restri
       acc.z = acc.z > 0.f ? acc.z : 0.f; acc.w = acc.w > 0.f ? acc.w : 0.f;
     }
     *reinterpret_cast<float4 *>(o.D + at) = acc;
+  }
+}
+
+// MODE 1 of gemm_reduce_kernel for few slices (nsplit <= 16: the deep layers' weight gradients, K = 256 .. 4096 points): one
+// thread per four consecutive input channels of an output row -- d wcat's two halves read with 16-byte loads, slices added in
+// order p = 0, 1, ... (the order gemm_reduce_kernel's sixteen slice groups give for nsplit <= 16), every thread storing.
+// gemm_reduce_kernel<1, 4> spends a 256-thread workgroup on 64 elements with nsplit x 16 threads loading and 16 storing:
+// 34 us for the 1152 x 1152 layer's 10.6 MB, 22 us for 576 x 576 (profiles/r06/session26_summary.txt).  Needs C % 4 == 0.
+__global__ __launch_bounds__(256) void gemm_reduce_w4_kernel(const float *__restrict__ part, int nsplit, long long IJ,
+                                                             float *__restrict__ dW, const float *__restrict__ dwr, int Co,
+                                                             int C) {
+  const long long half = (long long)Co * C, n4 = half / 4;
+  const int ld = 3 + 2 * C;
+  for (long long q = (long long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long long)gridDim.x * 256) {
+    const long long e = q * 4;
+    float4 t = *reinterpret_cast<const float4 *>(part + e);         // d wcat[o][c]      = d (W_d) part
+    float4 b = *reinterpret_cast<const float4 *>(part + half + e);  // d wcat[Co + o][c] = d (W_c - W_d) part
+#pragma unroll 4
+    for (int p = 1; p < nsplit; ++p) {
+      const float4 u = *reinterpret_cast<const float4 *>(part + (size_t)p * IJ + e);
+      const float4 v = *reinterpret_cast<const float4 *>(part + (size_t)p * IJ + half + e);
+      t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+      b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    const int oo = (int)(e / C), c = (int)(e - (long long)oo * C);
+    float *row = dW + (size_t)oo * ld;
+    row[3 + c] = b.x; row[3 + c + 1] = b.y; row[3 + c + 2] = b.z; row[3 + c + 3] = b.w;                  // d W_c
+    row[3 + C + c] = t.x - b.x; row[3 + C + c + 1] = t.y - b.y; row[3 + C + c + 2] = t.z - b.z;          // d W_d
+    row[3 + C + c + 3] = t.w - b.w;
+    if (c == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) row[k] = dwr ? dwr[oo * 3 + k] : 0.f;
+    }
   }
 }
 
@@ -1396,6 +1431,13 @@ static int launch_plan(GemmArgs a, const Plan &p, int precision, void *ws, const
   const long long n_el = REDUCE_MODE == 0 ? (long long)I * J : (long long)Co * C;
   const bool vec4 = (REDUCE_MODE == 0 ? J % 4 == 0 : C % 4 == 0) && ((long long)I * J) % 4 == 0 &&
                     (reinterpret_cast<uintptr_t>(a.partial) & 15u) == 0;
+  if (REDUCE_MODE == 1 && vec4 && p.nsplit <= 16) {
+    long long g4 = (n_el / 4 + 255) / 256;
+    if (g4 > 8192) g4 = 8192;
+    hipLaunchKernelGGL(gemm_reduce_w4_kernel, dim3((unsigned)g4), dim3(256), 0, st, a.partial, p.nsplit, (long long)I * J,
+                       final_out.D, dwr, Co, C);
+    return check_launch(who);
+  }
   long long grid = (n_el + (vec4 ? 63 : 15)) / (vec4 ? 64 : 16);
   if (grid > 16384) grid = 16384;
   if (vec4)

@@ -71,7 +71,10 @@ def _stream(t):
     return _lib.stream_ptr(t.device)
 
 
-def _fork_join(device, side_fn, main_fn):
+FORK_MIN_POINTS = 0  # A/B: contractions over fewer points (B * N) than this run their two gradient products in line
+
+
+def _fork_join(device, side_fn, main_fn, points=None):
     """Two independent pieces of a backward pass (the weight gradient and the data gradient of one contraction) side by
     side: `side_fn` on a side HIP stream, `main_fn` on the caller's, joined before returning.  Active only while a
     DECLARED whole-step HIP graph is captured (whole_step_capture(): forward and backward in one capture), where the
@@ -90,7 +93,8 @@ def _fork_join(device, side_fn, main_fn):
     hand-overs, which it can afford (measured the other way round in round 5: the config-2 backbone 8.19 -> 8.39 ms).
     Outputs are allocated by the caller BEFORE the fork (on the caller's stream); whatever side_fn allocates is scratch
     that lives and dies on the side stream."""
-    if not (device.type == 'cuda' and pt_utils.async_index() and _forks_allowed()):
+    if not (device.type == 'cuda' and pt_utils.async_index() and _forks_allowed()) or (
+            points is not None and points < FORK_MIN_POINTS):
         side_fn()
         main_fn()
         return
@@ -830,7 +834,7 @@ class _PointRows(Function):
                 _lib.check(lib.cl3d_pwmlp_point_gemm_bwd(_p(features), None, None, _p(dght), _p(wcat), _p(dwr), B, C, N, Co,
                                                          prec, _p(dfeat), _p(dW), _p(ws), ws_bytes, _stream(features)))
             else:
-                _fork_join(dev, weight_grad, data_grad)
+                _fork_join(dev, weight_grad, data_grad, B * N)
         return dfeat, dW, None
 
 
@@ -902,7 +906,7 @@ class _BnReluPointRows(Function):
                 _lib.check(lib.cl3d_pwmlp_point_gemm_bwd(_p(y1), _p(vec[0]), _p(vec[1]), _p(dght), _p(wcat), _p(dwr), B, C, N,
                                                          Co, prec, _p(dact), _p(dW), _p(ws), ws_bytes, _stream(y1)))
             else:
-                _fork_join(dev, weight_grad, data_grad)
+                _fork_join(dev, weight_grad, data_grad, B * N)
             _lib.check(lib.cl3d_bn_relu_bwd(_p(dact), _p(y1), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _p(gamma), B, C, N,
                                             float(B * N), _p(partial), ctx.nparts, _p(coef), _p(dy1), _stream(y1)))
         return dy1, coef[3], coef[4], None, dW, None
@@ -954,7 +958,7 @@ class _Conv1x1Rows(Function):
                                                             _p(ws), ws_bytes, _stream(rows)))
 
         with _lib.on_device(dev):
-            _fork_join(dev, weight_grad, data_grad)
+            _fork_join(dev, weight_grad, data_grad, B * N)
         return drows, None, None, dW, None
 
 
@@ -1295,7 +1299,7 @@ class _Conv1x1(Function):
                 _lib.check(lib.cl3d_conv1x1_bwd_weight(_p(x), _p(dy), B, C, N, Co, prec, _p(dW), _p(ws), ws_bytes, _stream(x)))
 
         with _lib.on_device(x.device):
-            _fork_join(x.device, weight_grad, data_grad)
+            _fork_join(x.device, weight_grad, data_grad, B * N)
         return dx, dW, None, (dy if ctx.has_residual and ctx.needs_input_grad[3] else None)
 
 

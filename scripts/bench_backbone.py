@@ -99,6 +99,9 @@ def main():
                     help="A/B: 'cat' lets the decoders concatenate as the reference does")
     ap.add_argument("--layerwise", action="store_true",
                     help="A/B: PointWiseMLP bottlenecks layer by layer (the activated tensors between their layers materialised)")
+    ap.add_argument("--fork-min-points", type=int, default=0,
+                    help="A/B: contractions over fewer points (B * N) than this run their two gradient products in line instead of "
+                         "as two branches of the graph (fused.FORK_MIN_POINTS)")
     args = ap.parse_args()
     if args.overlap_forks in ("b", "both") and "other_stream" in args.debug_two_graphs.split(",") and not args.unsafe:
         raise SystemExit("--overlap-forks %s together with --debug-two-graphs other_stream is the KNOWN-BAD layout: a forked pair of "
@@ -137,6 +140,7 @@ def main():
         from ab import library_arms
         library_arms.install(block=args.block, decode=args.decode, layerwise=args.layerwise)
     from closerlook3d_amd import fused as _fu
+    _fu.FORK_MIN_POINTS = args.fork_min_points
     from closerlook3d_amd import pt_utils as _put
     _fu.MAXPOOL_TARGETS = args.maxpool == "targets"
     _fork_shipped, _fork_count = _fu._fork_join, [0]
