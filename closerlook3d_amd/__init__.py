@@ -21,6 +21,21 @@ def whole_step_capture(on=True):
     return _w(on)
 
 
+def deferred_weight_gradients(on=True):
+    """Context manager, inside a declared whole-step capture: the weight gradients of the engine's contractions stay on
+    their side stream beside the rest of the backward pass instead of being joined layer by layer; the step calls
+    join_weight_gradients() between backward() and whatever reads the parameters' .grad
+    (closerlook3d_amd.fused.deferred_weight_gradients)."""
+    from .fused import deferred_weight_gradients as _d
+    return _d(on)
+
+
+def join_weight_gradients():
+    """Join the deferred weight gradients and hand each to its parameter's .grad (closerlook3d_amd.fused.join_weight_gradients)."""
+    from .fused import join_weight_gradients as _j
+    return _j()
+
+
 def step_stream(device=None):
     """The HIP stream on which a training step should be BOTH warmed up and captured (one per device).
 

@@ -72,9 +72,20 @@ def _stream(t):
 
 
 FORK_MIN_POINTS = 0  # A/B: contractions over fewer points (B * N) than this run their two gradient products in line
+_DEFER = [False]      # deferred_weight_gradients(): weight gradients stay on the side stream until join_weight_gradients()
+_DEFERRED = []        # (event, parameter, d W, side stream) of the weight gradients not joined yet
 
 
-def _fork_join(device, side_fn, main_fn, points=None):
+def _weight_leaf(W):
+    """The nn.Parameter a contraction's weight argument is a plain reshape of (conv.weight.view(Co, -1)), or None: the
+    tensor a deferred weight gradient is handed to."""
+    base = W if W._base is None else W._base
+    if base.is_leaf and base.requires_grad and base.numel() == W.numel() and W.is_contiguous() and base.is_contiguous():
+        return base
+    return None
+
+
+def _fork_join(device, side_fn, main_fn, points=None, defer=None):
     """Two independent pieces of a backward pass (the weight gradient and the data gradient of one contraction) side by
     side: `side_fn` on a side HIP stream, `main_fn` on the caller's, joined before returning.  Active only while a
     DECLARED whole-step HIP graph is captured (whole_step_capture(): forward and backward in one capture), where the
@@ -92,13 +103,37 @@ def _fork_join(device, side_fn, main_fn, points=None):
     join node behind it -- stay on the predecessor's queue, and it is the SHORT piece that pays the two cross-queue
     hand-overs, which it can afford (measured the other way round in round 5: the config-2 backbone 8.19 -> 8.39 ms).
     Outputs are allocated by the caller BEFORE the fork (on the caller's stream); whatever side_fn allocates is scratch
-    that lives and dies on the side stream."""
+    that lives and dies on the side stream.
+
+    `defer` = (parameter, d W, tensors side_fn reads), under deferred_weight_gradients() only: the join is NOT taken here.
+    Nothing of the backward pass reads a weight gradient, so the side stream keeps running it beside the layers that
+    follow and join_weight_gradients() -- called by the step between backward() and the optimizer -- joins the side stream
+    once and hands every d W to its parameter's .grad.  Returns True when the gradient was deferred: the caller then
+    returns None for the weight (autograd has nothing to accumulate).  What side_fn reads is marked as in use on the side
+    stream (record_stream): the caller's stream frees those tensors long before the side stream has read them."""
     if not (device.type == 'cuda' and pt_utils.async_index() and _forks_allowed()) or (
             points is not None and points < FORK_MIN_POINTS):
         side_fn()
         main_fn()
-        return
+        return False
     main, side = torch.cuda.current_stream(device), pt_utils.index_stream(device, 2)
+    if _DEFER[0] and defer is not None and defer[0] is not None and defer[1] is not None:
+        # deferred: the caller's piece is captured FIRST -- it is then the predecessor's first dependent and stays on its
+        # queue (the rule above), so the chain the backward pass waits for never changes queue at a fork; the weight
+        # gradient, which nothing waits for until the step's join, takes the hand-over
+        at_fork = torch.cuda.Event()
+        at_fork.record(main)
+        main_fn()
+        side.wait_event(at_fork)
+        with torch.cuda.stream(side):
+            side_fn()
+            ev = torch.cuda.Event()
+            ev.record(side)
+        for t in defer[2]:
+            if t is not None:
+                t.record_stream(side)
+        _DEFERRED.append((ev, defer[0], defer[1], side))
+        return True
     side.wait_stream(main)
     with torch.cuda.stream(side):
         side_fn()
@@ -106,6 +141,57 @@ def _fork_join(device, side_fn, main_fn, points=None):
         ev.record(side)
     main_fn()
     main.wait_event(ev)
+    return False
+
+
+@contextlib.contextmanager
+def deferred_weight_gradients(on=True):
+    """Inside a declared whole-step capture (whole_step_capture()): the weight gradients of the engine's contractions (the
+    1x1 convolutions, the PointWiseMLP's per-point product) are not joined where they are formed.  The step must call
+    join_weight_gradients() after backward() and before anything reads a parameter's .grad (the optimizer, a gradient
+    exchange); a capture that ends without it fails loudly (hipErrorStreamCaptureUnjoined, reported by name here).  The
+    deferred gradients reach .grad directly -- parameter hooks do not see them -- and only for weights that are plain
+    reshapes of a leaf parameter; every other weight gradient is joined in place as before."""
+    old = _DEFER[0]
+    _DEFER[0] = bool(on)
+    try:
+        yield
+        if _DEFERRED:
+            n = len(_DEFERRED)
+            join_weight_gradients()
+            raise RuntimeError(f"deferred_weight_gradients(): {n} weight gradient(s) were still on the side stream when the "
+                               "context ended -- call closerlook3d_amd.join_weight_gradients() after backward()")
+    finally:
+        _DEFER[0] = old
+        del _DEFERRED[:]
+
+
+def join_weight_gradients():
+    """The caller's stream picks up the side stream that ran the deferred weight gradients (one wait per device: the side
+    stream is in order) and every d W is handed to its parameter: .grad = d W where it was None, .grad += d W (on the
+    caller's stream, behind the wait) where a gradient is accumulated -- flat gradient buffers (dp.FlatGradients) included.
+    Returns how many gradients it delivered."""
+    if not _DEFERRED:
+        return 0
+    last = {}
+    for ev, _, dW, _ in _DEFERRED:
+        last[dW.device] = ev
+    for dev, ev in last.items():
+        torch.cuda.current_stream(dev).wait_event(ev)
+    with torch.no_grad():
+        into, what = [], []
+        for _, param, dW, _ in _DEFERRED:
+            g = dW.view_as(param)
+            if param.grad is None:
+                param.grad = g
+            else:
+                into.append(param.grad)
+                what.append(g)
+        if into:  # accumulated gradients (flat buffers): one multi-tensor add for all of them, behind the wait
+            torch._foreach_add_(into, what)
+    n = len(_DEFERRED)
+    del _DEFERRED[:]
+    return n
 
 
 def _gemm_scratch(op, B, N, Co, C, device):
@@ -794,6 +880,7 @@ class _PointRows(Function):
                                                             _p(wcat), _p(ws), ws_bytes, _stream(features)))
         ctx.save_for_backward(features, wcat)
         ctx.precision = precision
+        ctx.w_leaf = _weight_leaf(W)
         return ght, wr
 
     @staticmethod
@@ -833,8 +920,9 @@ class _PointRows(Function):
                 ws, ws_bytes = _gemm_scratch(14, B, N, Co, C, dev)
                 _lib.check(lib.cl3d_pwmlp_point_gemm_bwd(_p(features), None, None, _p(dght), _p(wcat), _p(dwr), B, C, N, Co,
                                                          prec, _p(dfeat), _p(dW), _p(ws), ws_bytes, _stream(features)))
-            else:
-                _fork_join(dev, weight_grad, data_grad, B * N)
+            elif _fork_join(dev, weight_grad, data_grad, B * N,
+                            (ctx.w_leaf, dW, (features, dght, dwr))):
+                dW = None  # handed to the parameter by join_weight_gradients()
         return dfeat, dW, None
 
 
@@ -870,6 +958,7 @@ class _BnReluPointRows(Function):
         ctx.save_for_backward(y1, vec, gamma, wcat)
         ctx.precision = precision
         ctx.nparts = nparts
+        ctx.w_leaf = _weight_leaf(W)
         return ght, wr
 
     @staticmethod
@@ -905,8 +994,8 @@ class _BnReluPointRows(Function):
                 ws, ws_bytes = _gemm_scratch(14, B, N, Co, C, dev)
                 _lib.check(lib.cl3d_pwmlp_point_gemm_bwd(_p(y1), _p(vec[0]), _p(vec[1]), _p(dght), _p(wcat), _p(dwr), B, C, N,
                                                          Co, prec, _p(dact), _p(dW), _p(ws), ws_bytes, _stream(y1)))
-            else:
-                _fork_join(dev, weight_grad, data_grad, B * N)
+            elif _fork_join(dev, weight_grad, data_grad, B * N, (ctx.w_leaf, dW, (y1, vec, dght, dwr))):
+                dW = None  # handed to the parameter by join_weight_gradients()
             _lib.check(lib.cl3d_bn_relu_bwd(_p(dact), _p(y1), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _p(gamma), B, C, N,
                                             float(B * N), _p(partial), ctx.nparts, _p(coef), _p(dy1), _stream(y1)))
         return dy1, coef[3], coef[4], None, dW, None
@@ -931,6 +1020,7 @@ class _Conv1x1Rows(Function):
                                                         _p(ws), ws_bytes, _stream(rows)))
         ctx.save_for_backward(rows, scale, shift, W)
         ctx.precision = precision
+        ctx.w_leaf = _weight_leaf(W)
         return y
 
     @staticmethod
@@ -958,7 +1048,9 @@ class _Conv1x1Rows(Function):
                                                             _p(ws), ws_bytes, _stream(rows)))
 
         with _lib.on_device(dev):
-            _fork_join(dev, weight_grad, data_grad, B * N)
+            if _fork_join(dev, weight_grad, data_grad, B * N,
+                          (ctx.w_leaf, dW, (rows, scale, shift, dy))):
+                dW = None  # handed to the parameter by join_weight_gradients()
         return drows, None, None, dW, None
 
 
@@ -1275,6 +1367,7 @@ class _Conv1x1(Function):
         ctx.save_for_backward(x, W)
         ctx.precision = precision
         ctx.has_residual = residual is not None
+        ctx.w_leaf = _weight_leaf(W)
         return y
 
     @staticmethod
@@ -1299,7 +1392,8 @@ class _Conv1x1(Function):
                 _lib.check(lib.cl3d_conv1x1_bwd_weight(_p(x), _p(dy), B, C, N, Co, prec, _p(dW), _p(ws), ws_bytes, _stream(x)))
 
         with _lib.on_device(x.device):
-            _fork_join(x.device, weight_grad, data_grad, B * N)
+            if _fork_join(x.device, weight_grad, data_grad, B * N, (ctx.w_leaf, dW, (x, dy))):
+                dW = None  # handed to the parameter by join_weight_gradients()
         return dx, dW, None, (dy if ctx.has_residual and ctx.needs_input_grad[3] else None)
 
 

@@ -99,6 +99,11 @@ def main():
                     help="A/B: 'cat' lets the decoders concatenate as the reference does")
     ap.add_argument("--layerwise", action="store_true",
                     help="A/B: PointWiseMLP bottlenecks layer by layer (the activated tensors between their layers materialised)")
+    ap.add_argument("--weight-grads", default="deferred", choices=["joined", "deferred"],
+                    help="deferred (default): the contractions' weight gradients stay on the side stream beside the rest of the "
+                         "backward pass and are joined once, in front of the optimizer / the gradient exchange "
+                         "(closerlook3d_amd.deferred_weight_gradients; config 2 bf16 5.60 -> 5.09 ms, profiles/r06/session35_summary.txt); "
+                         "joined: layer by layer, as rounds 3-6 had it.  The two-graph --overlap step always joins layer by layer")
     ap.add_argument("--fork-min-points", type=int, default=0,
                     help="A/B: contractions over fewer points (B * N) than this run their two gradient products in line instead of "
                          "as two branches of the graph (fused.FORK_MIN_POINTS)")
@@ -145,11 +150,11 @@ def main():
     _fu.MAXPOOL_TARGETS = args.maxpool == "targets"
     _fork_shipped, _fork_count = _fu._fork_join, [0]
 
-    def _fork_debug(device, side_fn, main_fn):
+    def _fork_debug(device, side_fn, main_fn, points=None, defer=None):
         """The engine's fork / join of two gradient products with the reproducer's switches: only some
         episodes of a capture fork; the two pieces one behind the other on the same two streams instead of side by side."""
         if not (device.type == 'cuda' and _put.async_index() and _fu._forks_allowed()):
-            return _fork_shipped(device, side_fn, main_fn)
+            return _fork_shipped(device, side_fn, main_fn, points, defer)
         _fork_count[0] += 1
         if fork_only is not None and _fork_count[0] not in fork_only:
             side_fn()
@@ -187,7 +192,7 @@ def main():
             main.wait_event(ev)
             pr["late"].add_((pr["c_side"] != pr["c_main"]).long())  # the caller went on before the side's piece ended?
         else:
-            _fork_shipped(device, side_fn, main_fn)
+            return _fork_shipped(device, side_fn, main_fn, points, defer)
 
     _probe = {}
     if args.fork_mode == "probe":
@@ -278,6 +283,7 @@ def main():
             ep = net(x, m, feats)
             out = head(ep) if head is not None else ep["res5_features"]
         out.square().mean().backward()
+        closerlook3d_amd.join_weight_gradients()  # (nothing to do unless --weight-grads deferred)
         if world == 1:
             opt.step()
 
@@ -307,6 +313,7 @@ def main():
         # the gradient-product forks are then an explicit choice per graph (fused.forked_gradients): on in graph A (forward +
         # late-stage backward: exact), off in graph B unless --overlap-forks b|both --unsafe asks for the known-bad layout
         with closerlook3d_amd.whole_step_capture(not args.overlap), \
+                closerlook3d_amd.deferred_weight_gradients(args.weight_grads == "deferred" and not args.overlap), \
                 _fu.forked_gradients(bool(forks) if (args.overlap and forks is not None) else None), \
                 torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local" if world > 1 else "global",
                                  **({"stream": _one_stream["s"]} if same else {})):
@@ -478,7 +485,8 @@ def main():
     if rank == 0:
         line = {"config": args.config, "operator": kind, "n_gpus": world, "clouds_per_gpu": B, "points": N, "width": width,
                 "precision": args.precision, "launch": "hip_graph" if graph is not None else "eager",
-                "gemm_plans": args.gemm_plans,
+                "gemm_plans": args.gemm_plans, "weight_grads": args.weight_grads,
+                "graph_queues": os.environ.get("DEBUG_HIP_FORCE_GRAPH_QUEUES", "runtime default"),
                 "ms_per_step": round(dt * 1e3, 3), "input_points_per_s": round(world * B * N / dt, 1), "scaling": "weak",
                 "head": "scene_seg" if head is not None else None,
                 "params_M": round(sum(p.numel() for p in params) / 1e6, 2),
