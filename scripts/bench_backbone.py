@@ -368,6 +368,9 @@ def main():
     comm_stream = torch.cuda.Stream() if overlap else None
     from closerlook3d_amd.dp import _mean_inplace
 
+    _dbg_sync = os.environ.get("CL3D_DP_SYNC") == "1"  # (debug: device-wide waits around the exchange)
+    _dbg_noex = os.environ.get("CL3D_DP_NOEXCHANGE") == "1"  # (debug, with --repeat-check: this rank's own gradients)
+
     def run():
         if overlap:
             if graph is not None:
@@ -402,11 +405,16 @@ def main():
             else:
                 compute()
             if world > 1:
+                if _dbg_sync:
+                    torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                flat.allreduce_mean(world)
+                if not _dbg_noex:
+                    flat.allreduce_mean(world)
                 e1.record()
                 ar_events.append((e0, e1))
+                if _dbg_sync:
+                    torch.cuda.synchronize()
         if world > 1 and not args.repeat_check:
             if update_graph is not None:
                 update_graph.replay()
@@ -416,9 +424,77 @@ def main():
     if args.repeat_check and world > 1:
         seen_late, seen_early, order, per_seen = {}, {}, [], {}
         per_param = [(n_, p_) for n_, p_ in list(net.named_parameters()) + ([("head." + k, v) for k, v in head.named_parameters()] if head is not None else []) if p_.requires_grad]
+        rc_trace, rc_traces = [], []
+        if args.dump_forward and rank == 0:  # (eager only: which module's output first varies over the replays)
+            def _rc_bits(o):
+                if torch.is_tensor(o):
+                    return [int(o.detach().contiguous().view(torch.int32).long().sum())] if o.dtype == torch.float32 else [int(o.long().sum())]
+                if isinstance(o, dict):
+                    return [b for k in sorted(o) for b in _rc_bits(o[k])]
+                if isinstance(o, (tuple, list)):
+                    return [b for t in o for b in _rc_bits(t)]
+                return []
+            for name_, mod_ in net.named_modules():
+                mod_.register_forward_hook(lambda m_, i_, o_, name_=name_: rc_trace.append((name_, _rc_bits(o_))))
+            if os.environ.get("CL3D_TRACE_PWMLP") == "1":  # the gather pass's operands and products, read back through HIP
+                import ctypes as _ct
+                from closerlook3d_amd import _lib as _cl
+                _hip = _ct.CDLL("libamdhip64.so")
+                _l = _cl.lib()
+
+                def _dev_bits(ptr, nbytes):
+                    torch.cuda.synchronize()
+                    ptr = getattr(ptr, "value", ptr)
+                    buf = np.empty(nbytes // 4, dtype=np.uint32)
+                    rc_ = _hip.hipMemcpy(_ct.c_void_p(buf.ctypes.data), _ct.c_void_p(ptr), _ct.c_size_t(nbytes // 4 * 4), 2)
+                    return [int(buf.astype(np.uint64).sum()), int(rc_)]
+                _orig_stats = _l.cl3d_pwmlp_stats
+                _first_layer = {}
+
+                def _traced_stats(*a_):
+                    q, s_, idx, ght, wr, gamma, B_, N_, M_, K_, Co_, rad, ystar, kstar, sy, partial, nparts, st_ = a_
+                    tag = "stats[N=%d,Co=%d]" % (N_, Co_)
+                    for nm, ptr, nb in (("q", q, B_ * M_ * 12), ("s", s_, B_ * N_ * 12), ("idx", idx, B_ * M_ * K_ * 4),
+                                        ("ght", ght, B_ * N_ * 2 * Co_ * 4), ("wr", wr, Co_ * 12), ("gamma", gamma, Co_ * 4)):
+                        rc_trace.append((tag + ".in." + nm, _dev_bits(ptr, nb)))
+                    r_ = _orig_stats(*a_)
+                    for nm, ptr, nb in (("ystar", ystar, B_ * M_ * Co_ * 4), ("kstar", kstar, B_ * M_ * Co_), ("sy", sy, B_ * M_ * Co_ * 4),
+                                        ("partial", partial, nparts * Co_ * 64)):
+                        rc_trace.append((tag + ".out." + nm, _dev_bits(ptr, nb)))
+                    if True:  # element by element against replay 0, call by call
+                        call_no = sum(1 for t_ in rc_trace if t_[0].endswith(".out.ystar"))
+                        torch.cuda.synchronize()
+                        cur = {}
+                        for nm, ptr, n_el in (("ystar", ystar, B_ * M_ * Co_), ("sy", sy, B_ * M_ * Co_)):
+                            buf = np.empty(n_el, dtype=np.float32)
+                            _hip.hipMemcpy(_ct.c_void_p(buf.ctypes.data), _ct.c_void_p(ptr), _ct.c_size_t(n_el * 4), 2)
+                            cur[nm] = buf.reshape(B_, M_, Co_)
+                        ref = _first_layer.setdefault(call_no, cur)
+                        for nm in cur:
+                            d_ = np.argwhere(cur[nm].view(np.uint32) != ref[nm].view(np.uint32))
+                            if len(d_):
+                                bs, js, cs = np.unique(d_[:, 0]), np.unique(d_[:, 1]), np.unique(d_[:, 2])
+                                print("first layer: call %d %s %s: %d elements differ from replay 0; clouds %s; %d queries %s...; channels %s; e.g. %s" % (
+                                    call_no, tag, nm, len(d_), bs.tolist()[:16], len(js), js.tolist()[:24], cs.tolist(),
+                                    [(tuple(int(v) for v in i_), float(ref[nm][tuple(i_)]), float(cur[nm][tuple(i_)])) for i_ in d_[:6]]),
+                                    file=sys.stderr, flush=True)
+                    return r_
+                _l.cl3d_pwmlp_stats = _traced_stats
+            import torch.autograd.function as _taf
+            for cname in dir(_fu):  # every autograd Function of the engine: its outputs in call order
+                cls = getattr(_fu, cname)
+                if isinstance(cls, type) and issubclass(cls, _taf.Function) and cls is not _taf.Function:
+                    def _wrapped(*a_, _cls=cls, _orig=cls.apply, **k_):
+                        o_ = _orig(*a_, **k_)
+                        shapes = [tuple(t.shape) for t in a_ if torch.is_tensor(t)][:2]
+                        rc_trace.append(("%s%s" % (_cls.__name__, shapes), _rc_bits(o_)))
+                        return o_
+                    cls.apply = _wrapped
         for it in range(args.repeat_check):
+            del rc_trace[:]
             run()
             torch.cuda.synchronize()
+            rc_traces.append(list(rc_trace))
             bits = flat.buffer.view(torch.int32).long()
             kl, ke = int(bits[:n_late].sum()), int(bits[n_late:].sum())
             seen_late[kl] = seen_late.get(kl, 0) + 1
@@ -427,6 +503,10 @@ def main():
             for n_, p_ in per_param:
                 per_seen.setdefault(n_, set()).add(int(p_.grad.view(torch.int32).long().sum()))
         if rank == 0:
+            if args.dump_forward and rc_traces and rc_traces[0]:
+                vary = [k for k in range(len(rc_traces[0])) if any(len(t) <= k or t[k] != rc_traces[0][k] for t in rc_traces[1:])]
+                print(json.dumps({"forward_outputs": len(rc_traces[0]), "varying_forward_outputs": len(vary),
+                                  "first_varying": [rc_traces[0][k][0] for k in vary[:12]]}), file=sys.stderr, flush=True)
             print(json.dumps({"repeat_check": args.repeat_check, "overlap": bool(overlap), "forks": args.overlap_forks,
                               "debug": args.debug_two_graphs, "comm_on_main": args.comm_on_main, "graph": graph is not None,
                               "pattern_late": max(seen_late, key=seen_late.get), "pattern_early": max(seen_early, key=seen_early.get),
@@ -508,6 +588,8 @@ def main():
             grads = torch.cat([p.grad.reshape(-1).double() for p in params if p.grad is not None])
             line["grad_l2"] = float(grads.norm())
             line["param_l2"] = float(torch.cat([p.detach().reshape(-1).double() for p in params]).norm())
+            named = list(net.named_parameters()) + ([("head." + k, v) for k, v in head.named_parameters()] if head is not None else [])
+            line["grad_l2_by_param"] = [[n_, float(p_.grad.double().norm())] for n_, p_ in named if p_.grad is not None]
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
