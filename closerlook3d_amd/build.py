@@ -29,6 +29,11 @@ FLAGS = [
     "-ffp-contract=off",
     # native global_atomic_add_f32 for the large-N scatter fallback
     "-munsafe-fp-atomics",
+    # no compiler-made packed FP32: the SLP vectoriser pairs scalar FMAs into v_pk_* instructions and, for an operand in
+    # the high half of a register pair, sets op_sel on it -- the form that read zeros beside bf16 MFMA kernels (round 6,
+    # DESIGN 6; csrc/fused_pwmlp.hip pk_low).  The packed code that is left is written out by hand and checked by
+    # tests/test_isa_packed_operands.py
+    "-fno-slp-vectorize",
     "-Wall", "-Wextra", "-Wno-unused-parameter",
 ]
 

@@ -77,6 +77,22 @@ __device__ __forceinline__ float pw_preact(const float w[3], float rx, float ry,
 // (div_k / div_magic: cl3d_common.h)
 typedef float pw_f2 __attribute__((ext_vector_type(2)));
 
+// A scalar that every lane pair of a packed instruction reads, in a register pair of its own with the value in the pair's
+// LOW dword (the other dword is never read: both result lanes take the low one, `op_sel_hi` = 0 on that operand).  Left
+// to itself the compiler feeds v_pk_fma_f32 the slot record's registers as ds_read_b128 delivered them, and for rel.z --
+// the record's last dword, the HIGH half of an aligned pair -- sets `op_sel` on the operand (the low result lane reads
+// the pair's high dword).  That form returned 0.0 to the low lane, in the wave's last sixteen lanes, a few hundred
+// times per launch whenever a dense bf16 MFMA contraction -- the engine's or the vendor library's, in this process or
+// in another one -- ran on the same CUs: sum y / y* / the batch statistics wrong by W_r[c][z] * rel.z of one slot in the
+// even channels (round 6, sessions 37-62; DESIGN 6 "What may run beside a bf16 contraction").  Without `op_sel`: 0 wrong
+// elements in 240 launches against 60-100 % of the launches with it.  tests/test_isa_packed_operands.py holds the
+// library to it.
+__device__ __forceinline__ pw_f2 pk_low(float x) {
+  pw_f2 p = __builtin_shufflevector((pw_f2)(x), (pw_f2)(x), 0, -1);  // (element 1 left undefined: one move, not two)
+  asm("" : "+v"(p));
+  return __builtin_shufflevector(p, p, 0, 0);
+}
+
 // query-major gather passes.  Persistent blocks: tile = 4*QW*QPG queries of one cloud (every lane group walks QPG
 // queries of a tile one after the other).
 // V == 4 is only used when Co % 4 == 0 and V == 1 rows are single elements, so a lane with c0 < Co always
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
             accr[0] += sr_.y;
             accr[1] += sr_.z;
             accr[2] += sr_.w;
-            const pw_f2 rx = (pw_f2)(sr_.y), ry = (pw_f2)(sr_.z), rz = (pw_f2)(sr_.w);
+            const pw_f2 rx = pk_low(sr_.y), ry = pk_low(sr_.z), rz = pk_low(sr_.w);
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
               pw_f2 t = __builtin_elementwise_fma(w0[h], rx, h2[h]);

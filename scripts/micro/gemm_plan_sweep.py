@@ -19,7 +19,7 @@ CSRC = os.path.join(ROOT, "closerlook3d_amd", "csrc")
 VAR = os.path.join(ROOT, "scripts", "micro", "var")
 LIB = os.path.join(VAR, "libcl3d_gemm_plan_env.so")
 HIPCC = "/opt/rocm/bin/hipcc"
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-munsafe-fp-atomics", "-fno-slp-vectorize",
          "-DCL3D_D2_FORM=0", "-DCL3D_GEMM_PLAN_ENV"]
 
 LAYERS = [  # C, points per cloud, Co  (B = 16 clouds)

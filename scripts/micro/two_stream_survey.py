@@ -38,7 +38,21 @@ def victims():
                 out = la(x, x, m, m, ff)
                 out.backward(gout)
                 return {"out": out, "d features": ff.grad, "d params": torch.cat([p.grad.reshape(-1) for p in la.parameters() if p.grad is not None])}
-            yield "%s C=%d" % (kind, C), step
+            if os.environ.get("BACKWARD_ONLY") != "1":
+                yield "%s C=%d" % (kind, C), step
+                continue
+            # the backward kernels alone: ONE forward pass before the load starts (held in `keep`), only backward() under the load
+            ff0 = f.clone().requires_grad_(True)
+            out0 = la(x, x, m, m, ff0)
+            torch.cuda.synchronize()
+
+            def bstep(la=la, ff0=ff0, out0=out0, gout=gout):
+                ff0.grad = None
+                for p in la.parameters():
+                    p.grad = None
+                out0.backward(gout, retain_graph=True)
+                return {"d features": ff0.grad, "d params": torch.cat([p.grad.reshape(-1) for p in la.parameters() if p.grad is not None])}
+            yield "%s C=%d backward only" % (kind, C), bstep
     xyz, mask, feats = bench.synth_batch(B, N, 64, 5)
     x = torch.from_numpy(xyz).to(dev); m = torch.from_numpy(mask).to(dev); f = torch.from_numpy(feats).to(dev)
 
@@ -48,7 +62,8 @@ def victims():
         grouped = pt_utils.grouping_operation(ff, idx)
         grouped.backward(grouped.detach())
         return {"idx": idx, "grouped": grouped, "d features": ff.grad}
-    yield "ball query + group_points + grad", native
+    if os.environ.get("BACKWARD_ONLY") != "1":
+        yield "ball query + group_points + grad", native
 
 
 def sweep(tag, prec):
@@ -84,6 +99,9 @@ def sweep(tag, prec):
 
 
 if __name__ == "__main__":
-    sweep("alone", None)
-    sweep("beside f32 contractions", 0)
+    if os.environ.get("BACKWARD_ONLY") != "1":
+        sweep("alone", None)
+        sweep("beside f32 contractions", 0)
     sweep("beside bf16 contractions", 1)
+    if os.environ.get("BACKWARD_ONLY") == "1":
+        sweep("beside bf16 contractions", 1)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 6 session 57: does idling a few cycles between the wait for a pair of gathered rows and their first use (variant libraries
+# Round 6 sessions 57 / 61: variant libraries of the TRAIN walk (VARIANTS=...) beside bf16 contractions on a second stream: 57 = idling a few cycles
 # walk_nop7 / walk_nop1, csrc/fused_pwmlp.hip CL3D_WALK_NOP) remove the wrong elements beside bf16 contractions?
 cd "$(dirname "$0")/../.." || exit 1
 OUT=gpurun_out/${1:-r06_s57}
