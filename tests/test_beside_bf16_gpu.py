@@ -1,0 +1,116 @@
+"""Every fused operator and the ball query stay bit-repeatable while a dense bf16 contraction runs beside them.
+
+Round 6 (DESIGN 6 "What may run beside a bf16 contraction"): before the fix in csrc/fused_pwmlp.hip (pk_low) and the build
+(-fno-slp-vectorize) the PointWiseMLP gather pass and AdaptiveWeight's forward pass returned a few hundred wrong elements in
+60-100 % of their launches whenever a bf16 MFMA contraction -- the engine's own or torch.matmul, as here -- was resident on
+the same CUs (a packed-FP32 operand read through op_sel came back as 0.0 in the wave's last sixteen lanes).  The probe of
+profiles/r06/session50-62 as a test: the operands are fixed, so every launch must give the same bits."""
+import threading
+import time
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B, N, K, RADIUS, LAUNCHES = 16, 4096, 32, 0.14, 40
+
+
+def _bits(t):
+    return int(t.detach().contiguous().view(torch.int32).long().sum())
+
+
+class _Bf16Load:
+    """torch.matmul in bf16, back to back on a stream of its own, from a host thread."""
+
+    def __init__(self, dev):
+        self.dev, self.stop = dev, False
+        self.a = torch.randn(4096, 2304, device=dev, dtype=torch.bfloat16)
+        self.b = torch.randn(2304, 1152, device=dev, dtype=torch.bfloat16)
+        self.stream = torch.cuda.Stream(dev)
+        self.thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        torch.cuda.set_device(self.dev)
+        with torch.cuda.stream(self.stream):
+            while not self.stop:
+                for _ in range(20):
+                    torch.matmul(self.a, self.b)
+                self.stream.synchronize()
+
+    def __enter__(self):
+        self.thread.start()
+        time.sleep(0.5)
+        return self
+
+    def __exit__(self, *exc):
+        self.stop = True
+        self.thread.join()
+
+
+def _config(kind):
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+    return Cfg(bn_momentum=0.1, density_parameter=5.0, local_aggregation_type=kind, cl3d_impl="fused",
+               pospool=Cfg(position_embedding='xyz', reduction='avg', output_conv=False),
+               adaptive_weight=Cfg(weight_type='dp', num_mlps=1, shared_channels=1, weight_softmax=False, reduction='avg',
+                                   output_conv=False),
+               pointwisemlp=Cfg(feature_type='dp_fi_df', num_mlps=1, reduction='max'),
+               pseudo_grid=Cfg(fixed_kernel_points='center', KP_influence='linear', KP_extent=1.0, num_kernel_points=15,
+                               convolution_mode='sum', output_conv=False))
+
+
+def _cloud(C, seed=5):
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    xyz = torch.from_numpy(rng.random((B, N, 3), dtype=np.float32)).to(dev)
+    mask = torch.ones(B, N, dtype=torch.int32, device=dev)
+    feats = torch.from_numpy(rng.standard_normal((B, C, N)).astype(np.float32)).to(dev)
+    return xyz, mask, feats
+
+
+@pytest.mark.parametrize("kind,C", [("pointwisemlp", 64), ("pointwisemlp", 144), ("adaptive_weight", 72), ("pospool", 72),
+                                    ("pseudo_grid", 72)])
+def test_operator_is_repeatable_beside_a_bf16_contraction(kind, C):
+    from closerlook3d_amd.local_aggregation_operators import LocalAggregation
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    la = LocalAggregation(C, C, RADIUS, K, _config(kind)).to(dev).train(True)
+    xyz, mask, feats = _cloud(C)
+    gout = torch.randn(B, C, N, generator=torch.Generator().manual_seed(2)).to(dev)
+    seen = {"out": set(), "d features": set(), "d parameters": set()}
+    side = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()  # (the operands were made on the default stream)
+    with _Bf16Load(dev), torch.cuda.stream(side):
+        for _ in range(LAUNCHES):
+            f = feats.clone().requires_grad_(True)
+            for p in la.parameters():
+                p.grad = None
+            out = la(xyz, xyz, mask, mask, f)
+            out.backward(gout)
+            side.synchronize()
+            seen["out"].add(_bits(out))
+            seen["d features"].add(_bits(f.grad))
+            seen["d parameters"].add(_bits(torch.cat([p.grad.reshape(-1) for p in la.parameters() if p.grad is not None])))
+    assert {k: len(v) for k, v in seen.items()} == {"out": 1, "d features": 1, "d parameters": 1}
+
+
+def test_ball_query_and_grouping_are_repeatable_beside_a_bf16_contraction():
+    from closerlook3d_amd import pt_utils
+    dev = torch.device("cuda:0")
+    xyz, mask, feats = _cloud(64)
+    seen = {"idx": set(), "grouped": set(), "d features": set()}
+    side = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()  # (the operands were made on the default stream)
+    with _Bf16Load(dev), torch.cuda.stream(side):
+        for _ in range(LAUNCHES):
+            idx, _ = pt_utils._ball_query(xyz, xyz, mask, mask, RADIUS, K)
+            f = feats.clone().requires_grad_(True)
+            grouped = pt_utils.grouping_operation(f, idx)
+            grouped.backward(grouped.detach())
+            side.synchronize()
+            seen["idx"].add(_bits(idx))
+            seen["grouped"].add(_bits(grouped))
+            seen["d features"].add(_bits(f.grad))
+    assert {k: len(v) for k, v in seen.items()} == {"idx": 1, "grouped": 1, "d features": 1}
