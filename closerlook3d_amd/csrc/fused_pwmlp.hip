@@ -37,6 +37,17 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// The TRAIN walk's arithmetic: 0 (shipped since round 6, session 65) = scalar FMAs, two channels' chains interleaved by the
+// compiler; 1 = packed pairs (v_pk_fma_f32, rounds 4-6: scripts/micro/kernel_variants.py "train_packed").  A packed FP32
+// instruction occupies the vector pipe for two slots on gfx950, so the packed walk never had fewer cycles, only fewer
+// instructions -- and its four-deep dependent chains stalled the issue (round 5's ISA account: 34 % of the pass).  Scalar,
+// same box, alternating runs: TRAIN 66.2-66.5 -> 62.6-63.4 us, the replayed step 0.2842-0.2856 -> 0.2809-0.2824 ms, 110
+// VGPRs against 115, the same bits (each packed half WAS the scalar operation); and no packed operand is left in the
+// pass for the fault of DESIGN 6 to find (profiles/r06/session65_summary.txt).
+#ifndef CL3D_TRAIN_PK
+#define CL3D_TRAIN_PK 0
+#endif
+
 namespace cl3d {
 
 enum { PW_TRAIN = 0, PW_FWD = 1 };
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
     constexpr int NF = NACC > 0 ? 5 : 1;
     // (V == 4: the running sums live as two packed pairs per quantity -- the TRAIN walk below is v_pk_fma_f32 / v_pk_add_f32
     // on channel pairs: per-element IEEE, the same bits as the scalar chain, two channels per VALU slot)
-    constexpr bool PK = V == 4 && MODE == PW_TRAIN;
+    constexpr bool PK = CL3D_TRAIN_PK && V == 4 && MODE == PW_TRAIN;
     constexpr int VA = PK ? 2 : V;
     using acc_t = typename std::conditional<PK, pw_f2, float>::type;
     acc_t accf[NF][VA];

@@ -37,6 +37,8 @@ VARIANTS = {  # tag: (source file, extra defines)
     "pw_lanes_env": ("fused_pwmlp.hip", ["-DCL3D_LANE_ENV"]),
     # round 6: the lane maps of round 1-5 (most queries per wave; shipped: fewer, wider row pieces per wave-load)
     "lane_rule_r5": (("fused_pwmlp.hip", "fused_reduce.hip", "fused_maxpool.hip"), ["-DCL3D_LANE_RULE=0"]),
+    # round 6, session 65: the TRAIN walk on packed pairs (rounds 4-6; shipped since: scalar FMAs)
+    "train_packed": ("fused_pwmlp.hip", ["-DCL3D_TRAIN_PK=1"]),
     # (round 6, session 61: "walk_rz_pair" = rel.z of the TRAIN walk in a register pair of its own was the A/B arm that removed
     #  the wrong elements beside bf16 contractions; shipped as pk_low() in csrc/fused_pwmlp.hip)
     # (round 6: "pg_nofork" = fused_reduce.hip with -DCL3D_PG_FORK=0 was the A/B arm of PseudoGrid's forked kernel-weight
