@@ -64,7 +64,20 @@ constexpr int kTlFlat = CL3D_TL_FLAT;             // window batches (of 64) whos
 constexpr int kTlIdxRounds = 4;                   // rank-by-index rounds held in registers: kTlCapMul*K <= 256
 constexpr int kTlRankRounds = 2;                  // rank-by-distance rounds held in registers: 3*K <= 128
 
+// both queries of a pass: CL3D_TL_PK = 1 a packed pair (v_pk_*_f32, rounds 4-6; scripts/micro/kernel_variants.py "bq_packed"),
+// 0 (shipped since round 6, session 66) two scalar chains -- the packed chain never had fewer cycles (a packed FP32
+// instruction takes two slots on gfx950; round 4 said so of its own gain), the scalar one measures the same or 1 % faster
+// (67.0-67.3 against 67.5-68.2 us alone, the replayed step 0.2807 against 0.2817 ms, alternating), returns the same bits (it
+// IS cl3d::dist2), and leaves no packed operand in the kernel for the fault of DESIGN 6 to find -- the candidate's y comes
+// out of ds_read_b128 in the high half of a register pair, exactly the operand that read zeros in the gather pass.
+#ifndef CL3D_TL_PK
+#define CL3D_TL_PK 0
+#endif
+#if CL3D_TL_PK
 typedef float tl_v2f __attribute__((ext_vector_type(2)));
+#else
+struct tl_v2f { float x, y; };
+#endif
 
 __host__ __device__ inline int tl_pad4(int x) { return (x + 3) & ~3; }
 
@@ -107,6 +120,12 @@ __device__ __forceinline__ float tl_uniform(float v) {
 // IEEE per element: each half is bit for bit the scalar chain of dist2; the library is built with -ffp-contract=off,
 // so nothing is fused or split behind this).  Same CL3D_D2_FORM switch as cl3d_common.h.
 __device__ __forceinline__ tl_v2f tl_dist2_pair(tl_v2f qx, tl_v2f qy, tl_v2f qz, float x, float y, float z) {
+#if !CL3D_TL_PK
+  tl_v2f r;  // (the scalar chain itself: cl3d::dist2)
+  r.x = dist2(qx.x, qy.x, qz.x, x, y, z);
+  r.y = dist2(qx.y, qy.y, qz.y, x, y, z);
+  return r;
+#else
   const tl_v2f dx = qx - x, dy = qy - y, dz = qz - z;
 #if CL3D_D2_FORM == 0
   const tl_v2f xx = dx * dx;
@@ -120,6 +139,7 @@ __device__ __forceinline__ tl_v2f tl_dist2_pair(tl_v2f qx, tl_v2f qy, tl_v2f qz,
 #else
   const tl_v2f xx = dx * dx;
   return __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, xx));
+#endif
 #endif
 }
 

@@ -44,9 +44,37 @@ struct ReduceArgs {
 // Packed fp32 (v_pk_fma_f32 / v_pk_mul_f32: two lanes' worth of fp32 per VALU slot).  PseudoGrid spends
 // P x V = 15 x 4 FMAs per (slot, lane); with the V = 4 channels of a lane held as two float pairs the same
 // arithmetic (each product and sum rounded exactly as before) issues half as many instructions.
+// CL3D_PG_PK = 0: the same pairs as two scalar FMAs each (scripts/micro/kernel_variants.py "pg_scalar").  Measured in round 6,
+// session 67, because the TRAIN walk and the ball query got FASTER as scalar code: here the packed form stays -- the operator
+// step 0.3896-0.3904 against 0.3927-0.3935 ms, config 3 4.63-4.66 against 4.69-4.70, every pair (15 influences x 4 channels per
+// slot: the instruction count matters).  Its packed operands carry `op_sel` but come out of VALU arithmetic, not
+// out of ds_read_b128, and the kernels stayed bit-exact beside bf16 contractions in every survey (up to 400 launches).
+#ifndef CL3D_PG_PK
+#define CL3D_PG_PK 1
+#endif
+#if CL3D_PG_PK
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 pk_splat(float x) { return (f2)(x); }
+#else
+struct f2 {
+  float e[2];
+  __device__ __forceinline__ float &operator[](int i) { return e[i]; }
+  __device__ __forceinline__ const float &operator[](int i) const { return e[i]; }
+};
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) {
+  f2 r;
+  r.e[0] = __builtin_fmaf(a.e[0], b.e[0], c.e[0]);
+  r.e[1] = __builtin_fmaf(a.e[1], b.e[1], c.e[1]);
+  return r;
+}
+__device__ __forceinline__ f2 pk_splat(float x) {
+  f2 r;
+  r.e[0] = x;
+  r.e[1] = x;
+  return r;
+}
+#endif
 
 __device__ __forceinline__ float kp_influence(float rx, float ry, float rz, const float *kp, float inv_extent,
                                               int constant) {

@@ -37,6 +37,10 @@ VARIANTS = {  # tag: (source file, extra defines)
     "pw_lanes_env": ("fused_pwmlp.hip", ["-DCL3D_LANE_ENV"]),
     # round 6: the lane maps of round 1-5 (most queries per wave; shipped: fewer, wider row pieces per wave-load)
     "lane_rule_r5": (("fused_pwmlp.hip", "fused_reduce.hip", "fused_maxpool.hip"), ["-DCL3D_LANE_RULE=0"]),
+    # round 6, session 67: PseudoGrid's channel pairs as scalar FMAs (shipped: packed -- scalar measured 0.8-1 % slower)
+    "pg_scalar": ("fused_reduce.hip", ["-DCL3D_PG_PK=0"]),
+    # round 6, session 66: the ball query's two distance chains as one packed chain (rounds 4-6; shipped since: scalar)
+    "bq_packed": ("ball_query_lds.hip", ["-DCL3D_TL_PK=1"]),
     # round 6, session 65: the TRAIN walk on packed pairs (rounds 4-6; shipped since: scalar FMAs)
     "train_packed": ("fused_pwmlp.hip", ["-DCL3D_TRAIN_PK=1"]),
     # (round 6, session 61: "walk_rz_pair" = rel.z of the TRAIN walk in a register pair of its own was the A/B arm that removed
