@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, WPE) void pwmlp_query_kernel(PwArgs a) {
     // atomics, and half the VGPRs of double register accumulators, which the gather loop's occupancy needs
     constexpr int kFlushTiles = 8 / QPG;  // <= 8 queries x K slots per running float sum
     constexpr int NF = NACC > 0 ? 5 : 1;
-    // (V == 4: the running sums live as two packed pairs per quantity -- the TRAIN walk below is v_pk_fma_f32 / v_pk_add_f32
+    // (CL3D_TRAIN_PK = 1 only -- V == 4: the running sums live as two packed pairs per quantity, the TRAIN walk below is v_pk_fma_f32 / v_pk_add_f32
     // on channel pairs: per-element IEEE, the same bits as the scalar chain, two channels per VALU slot)
     constexpr bool PK = CL3D_TRAIN_PK && V == 4 && MODE == PW_TRAIN;
     constexpr int VA = PK ? 2 : V;
