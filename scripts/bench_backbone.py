@@ -15,6 +15,14 @@ step (closerlook3d_amd/dp.py), BatchNorm statistics per rank as in the reference
 The compute (zero gradients, forward, backward) is one HIP graph, the all-reduce stays outside it, the optimiser step
 is a second graph; the line reports the step time (max over ranks), the all-reduce time (HIP events) and its bytes.
 CL3D_BENCH_ONE_DEVICE=1 puts every rank on GPU 0 over gloo (exercises the N>1 code path on a 1-GPU box).
+
+Probes (N > 1; how round 6 traced a checksum that would not repeat down to one instruction):
+    --checksums                    norms of the last step's gradients, of the parameters, and per parameter
+    --repeat-check N               replay the step N times WITHOUT the update: distinct bit patterns of the gradients, by parameter
+      ... --no-graph --dump-forward x   also: the first module / autograd Function whose OUTPUT varies over the replays
+      ... CL3D_TRACE_PWMLP=1            also: the gather pass's operands and products, read back through hipMemcpy, element by element
+    CL3D_DP_DEBUG=1 (norms per warm-up step), CL3D_DP_SYNC=1 (device-wide waits around the exchange),
+    CL3D_DP_NOEXCHANGE=1 (with --repeat-check: this rank's own gradients)
 """
 import argparse
 import json
