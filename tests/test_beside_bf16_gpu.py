@@ -114,3 +114,37 @@ def test_ball_query_and_grouping_are_repeatable_beside_a_bf16_contraction():
             seen["grouped"].add(_bits(grouped))
             seen["d features"].add(_bits(f.grad))
     assert {k: len(v) for k, v in seen.items()} == {"idx": 1, "grouped": 1, "d features": 1}
+
+
+@pytest.mark.parametrize("kind,precision", [("pointwisemlp", "bf16"), ("pointwisemlp", "f32"), ("adaptive_weight", "f32")])
+def test_backbone_step_is_repeatable_beside_a_bf16_contraction(kind, precision):
+    """A whole 5-stage residual backbone (grid subsampling, ball queries, CSR builds, pooling, BatchNorm tails, the engine's
+    contractions, every bottleneck fused) forward + backward in eager launches, 4 clouds x 2048 points: the gradient of every
+    parameter must repeat bit for bit beside the bf16 load -- what `bench_backbone.py --gpus 2 --repeat-check` showed NOT to hold
+    for the bf16 config-2 step before the fix (every parameter varied, profiles/r06/session40_summary.txt)."""
+    from closerlook3d_amd.backbones import ResNet
+    from closerlook3d_amd.pt_utils import ball_query_cache
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    cfg = _config(kind)
+    cfg["cl3d_impl"] = "auto"
+    cfg["cl3d_precision"] = precision
+    net = ResNet(cfg, 3, 0.1, 0.04, [16] * 5, [512, 128, 32, 8], width=72, depth=2, bottleneck_ratio=2).to(dev).train(True)
+    rng = np.random.default_rng(3)
+    xyz = torch.from_numpy(rng.random((4, 2048, 3), dtype=np.float32)).to(dev)
+    mask = torch.ones(4, 2048, dtype=torch.int32, device=dev)
+    feats = xyz.transpose(1, 2).contiguous()
+    params = [p for p in net.parameters() if p.requires_grad]
+    seen = set()
+    side = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    with _Bf16Load(dev), torch.cuda.stream(side):
+        for _ in range(12):
+            for p in params:
+                p.grad = None
+            with ball_query_cache():
+                out = net(xyz, mask, feats)["res5_features"]
+            out.square().mean().backward()
+            side.synchronize()
+            seen.add(tuple(_bits(p.grad) for p in params if p.grad is not None))
+    assert len(seen) == 1
